@@ -1,0 +1,991 @@
+// ORACLE -- TEST INFRASTRUCTURE ONLY (see scs_oracle.h for the contract).
+//
+// CPU restatement of the SCSsim `genreads` hot path.  Every function cites the
+// reference file:line it follows (paths relative to the reference root,
+// qasimyu/scssim).  Two random back-ends:
+//   ref     : the reference's own streams, consumed in the reference's order
+//             (lib/threadpool/ThreadPool.cpp:41-47,203-212; glibc rand();
+//             libstdc++ normal_distribution over minstd_rand0) -> byte-identical
+//             FASTQ to the compiled reference at -t 1 under oracle/seedshim.cpp.
+//   counter : Philox4x32-10 keyed by logical ids (DESIGN.md "RNG remapping").
+// Apart from where a draw comes from, the two modes differ only in the three
+// places marked [REMAP] below (primer-pool snapshot per pass, chunked weight
+// sum, GC-factor normal sampler) -- each is order-free so that any thread /
+// GPU schedule gives the same bytes.
+#include "scs_oracle.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <functional>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <stdexcept>
+#include <random>
+#include <sstream>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace {
+
+std::string g_err;
+double g_timings[6];
+
+[[noreturn]] void fail(const std::string& m) { throw std::runtime_error(m); }
+
+const double ZERO_FINAL = 2.2204e-16;   // lib/mydefine/MyDefine.cpp:20, lib/matrix/Matrix.h:86
+
+// ---------------------------------------------------------------------------
+// Philox4x32-10 (Salmon, Moraes, Dror, Shaw, SC'11).  Published algorithm.
+// ---------------------------------------------------------------------------
+inline void philox(const uint32_t c_in[4], const uint32_t k_in[2], uint32_t out[4]) {
+    uint32_t c0 = c_in[0], c1 = c_in[1], c2 = c_in[2], c3 = c_in[3];
+    uint32_t k0 = k_in[0], k1 = k_in[1];
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// ---------------------------------------------------------------------------
+// Deterministic log: classic argument reduction x = 2^k (1+f), s = f/(2+f),
+// degree-14 minimax in s (the fdlibm e_log scheme and coefficients).  Uses only
+// IEEE +,-,*,/ so that x86 and gfx950 give the same bits (no contraction).
+// ---------------------------------------------------------------------------
+double det_log(double x) {
+    const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
+    const double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01,
+                 Lg3 = 2.857142874366239149e-01, Lg4 = 2.222219843214978396e-01,
+                 Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+                 Lg7 = 1.479819860511658591e-01;
+    if (x != x) return x;
+    if (x < 0) return std::nan("");
+    if (x == 0) return -HUGE_VAL;
+    uint64_t b; memcpy(&b, &x, 8);
+    int k = 0;
+    if ((b >> 52) == 0) { x *= 18014398509481984.0; memcpy(&b, &x, 8); k = -54; }   // subnormal: * 2^54
+    if ((b >> 52) == 0x7ff) return x;
+    k += (int)(b >> 52) - 1023;
+    b = (b & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL;
+    double m; memcpy(&m, &b, 8);
+    if (m >= 1.4142135623730951) { m = m * 0.5; k += 1; }
+    double f = m - 1.0;
+    double s = f / (2.0 + f);
+    double z = s * s, w = z * z;
+    double t1 = w * (Lg2 + w * (Lg4 + w * Lg6));
+    double t2 = z * (Lg1 + w * (Lg3 + w * (Lg5 + w * Lg7)));
+    double R = t2 + t1;
+    double hfsq = 0.5 * f * f;
+    double dk = (double)k;
+    return dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
+}
+
+// ---------------------------------------------------------------------------
+// Random source.  Every draw site names its counter-mode key; in ref mode the
+// key is ignored and the reference's sequential streams are advanced instead.
+// ---------------------------------------------------------------------------
+enum Stage : uint32_t {
+    ST_FRAGSPLIT = 1, ST_POISSON = 2, ST_ATTACH = 3, ST_ERR = 4, ST_ERRALT = 5, ST_WEIGHT = 6,
+    ST_ALLOC_TOP = 7, ST_ALLOC_CHUNK = 8, ST_PAIR = 9, ST_INDEL = 10, ST_INDEL_INS = 11, ST_BASE = 12
+};
+
+struct Key { uint32_t idx; uint64_t uid; uint32_t stage_word; int word; };
+inline Key mk(uint32_t stage, uint32_t aux, uint64_t uid, uint32_t idx, int word) {
+    return Key{idx, uid, stage | (aux << 8), word};
+}
+
+struct RefStreams {           // one worker thread (-t 1) + the main thread
+    std::mt19937 w_real, w_int;     // ThreadPool.cpp:41-47: two copies of one seeded generator
+    std::mt19937 m_real, m_int;     // main thread: map::operator[] default-constructs (seed 5489)
+};
+
+struct Rng {
+    bool counter = false;
+    uint32_t key[2] = {0, 0};
+    RefStreams* ref = nullptr;
+
+    inline uint32_t word(const Key& k) const {
+        uint32_t c[4] = {k.idx, (uint32_t)k.uid, (uint32_t)(k.uid >> 32), k.stage_word}, o[4];
+        philox(c, key, o);
+        return o[k.word];
+    }
+    // ThreadPool::randomDouble / randomInteger both map x -> x / 2^32  (ThreadPool.cpp:203-212)
+    inline double real(const Key& k) { return (counter ? word(k) : (uint32_t)ref->w_real()) / 4294967296.0; }
+    inline double integer(const Key& k) { return (counter ? word(k) : (uint32_t)ref->w_int()) / 4294967296.0; }
+    inline double main_real(const Key& k) { return (counter ? word(k) : (uint32_t)ref->m_real()) / 4294967296.0; }
+    // glibc: rand()/(RAND_MAX+1.0)  (MyDefine.cpp:285-292)
+    inline double grand(const Key& k) { return counter ? word(k) / 4294967296.0 : rand() / (RAND_MAX + 1.0); }
+};
+
+// randIndx(double* cdf, ac): MyDefine.cpp:274-282
+inline unsigned rand_indx(const double* cdf, unsigned ac, double u) {
+    double r = ZERO_FINAL + (1 - ZERO_FINAL) * u;
+    for (unsigned k = 0; k < ac; ++k) if (r <= cdf[k]) return k;
+    return ac - 1;
+}
+
+// ---------------------------------------------------------------------------
+// Bases.  codes 0..3 = ACGT (config "bases", lib/config/Config.cpp:24), 4 = N / any other
+// ---------------------------------------------------------------------------
+const char BASES[] = "ACGTN";
+inline uint8_t code_of(char c) {
+    switch (c) { case 'A': case 'a': return 0; case 'C': case 'c': return 1;
+                 case 'G': case 'g': return 2; case 'T': case 't': return 3; default: return 4; }
+}
+inline uint8_t comp_code(uint8_t c) { return c < 4 ? (uint8_t)(3 - c) : (uint8_t)4; }   // MyDefine.cpp:352-367
+inline bool is_gc(uint8_t c) { return c == 1 || c == 2; }
+
+// ---------------------------------------------------------------------------
+// FASTA (lib/fastahack/Fasta.cpp:45-215,304-334; lib/genome/Genome.cpp:176-195,272-278)
+// Records in file order; index key = first token of the header with a leading
+// "chrom"/"chr" (first occurrence) stripped (Fasta.cpp:59-68).  Sequence upper-cased.
+// ---------------------------------------------------------------------------
+struct Record { std::string name; std::vector<uint8_t> code; };
+
+std::vector<Record> load_fasta(const std::string& path) {
+    std::ifstream ifs(path);
+    if (!ifs.is_open()) fail("could not open " + path);
+    std::vector<Record> recs;
+    std::string line;
+    while (std::getline(ifs, line)) {
+        if (!line.empty() && line.back() == '\r') line.pop_back();
+        if (line.empty() || line[0] == ';') continue;
+        if (line[0] == '>') {
+            std::string nm = line.substr(1);
+            size_t e = nm.find_first_of(" \t");
+            if (e != std::string::npos) nm = nm.substr(0, e);
+            size_t i = nm.find("chrom");
+            if (i == std::string::npos) { i = nm.find("chr"); if (i != std::string::npos) nm = nm.substr(i + 3); }
+            else nm = nm.substr(i + 5);
+            recs.push_back(Record{nm, {}});
+        } else {
+            if (recs.empty()) fail("FASTA sequence before header in " + path);
+            auto& v = recs.back().code;
+            for (char c : line) v.push_back(code_of(c));
+        }
+    }
+    if (recs.empty()) fail("ERROR: reference sequence cannot be empty!");
+    return recs;
+}
+
+// ---------------------------------------------------------------------------
+// Profile (lib/profile/Profile.cpp:69-123 kmers, 171-214 init, 930-1234 load,
+// 832-863/897-927 normParas(true), 1363-1430 initCDFs; Matrix.h:328-336,483-522)
+// ---------------------------------------------------------------------------
+struct Profile {
+    int L = 0, bins = 0, kmer = 3, N = 4, kmerCount = 84, nq = 94;
+    double insertRate = 0, delRate = 0, stdISize = 0, gcStd = 0;
+    std::vector<double> insCdf, delCdf;
+    std::vector<double> subs1, subs2;     // [84][bins][4]  (dist, then cdf in place)
+    bool haveCdf2 = false;
+    std::vector<double> qual;             // [16][bins][94]
+    std::vector<int> isizeAlphabet;
+    std::vector<double> isizeCdf;
+    double gcMeans[101];
+    std::map<std::string, int> kmerIndex;
+};
+
+std::string trim(const std::string& s) {
+    size_t a = s.find_first_not_of(" \t\r\n");
+    if (a == std::string::npos) return "";
+    size_t b = s.find_last_not_of(" \t\r\n");
+    return s.substr(a, b - a + 1);
+}
+std::vector<std::string> split(const std::string& s, char d) {       // lib/split/split.cpp:3-16
+    std::vector<std::string> out; std::stringstream ss(s); std::string it;
+    while (std::getline(ss, it, d)) out.push_back(it);
+    return out;
+}
+bool next_line(std::ifstream& ifs, std::string& line) {             // MyDefine.cpp:337-349
+    line.clear();
+    while (std::getline(ifs, line)) { if (!line.empty() && line[0] != '#') break; }
+    return !line.empty();
+}
+
+void row_normalize(double* m, int rows, int cols) {                   // Matrix::normalize(0)
+    for (int i = 0; i < rows; ++i) {
+        double s = 0; for (int j = 0; j < cols; ++j) s += m[i * cols + j];
+        for (int j = 0; j < cols; ++j) m[i * cols + j] /= (ZERO_FINAL + s);
+    }
+}
+void row_cumsum(double* m, int rows, int cols) {                      // Matrix::cumsum
+    for (int i = 0; i < rows; ++i)
+        for (int j = 1; j < cols; ++j) m[i * cols + j] = m[i * cols + j] + m[i * cols + j - 1];
+}
+double normpdf(double x, double mu, double sigma) {                   // MyDefine.cpp:54-57
+    double PI = 3.1415926;
+    return exp(-pow(x - mu, 2) / (2 * pow(sigma, 2))) / (sqrt(2 * PI) * sigma);
+}
+
+Profile* load_profile(const std::string& path, bool paired, int isize) {
+    std::ifstream ifs(path);
+    if (!ifs.is_open()) fail("can not open file " + path);
+    auto P = std::make_unique<Profile>();
+    std::string line, bases;
+    int binCount = -1, kmer = -1, readLength = -1;
+    while (next_line(ifs, line)) {                                    // Profile.cpp:946-990
+        auto f = split(line, ':');
+        if (f.size() != 2) fail("malformed model file header: " + line);
+        std::string k = trim(f[0]), v = trim(f[1]);
+        if (k == "bases") bases = v; else if (k == "binCount") binCount = atoi(v.c_str());
+        else if (k == "kmer") kmer = atoi(v.c_str()); else if (k == "readLength") readLength = atoi(v.c_str());
+        else fail("malformed model file header: " + line);
+        if (!bases.empty() && binCount > 0 && kmer > 0 && readLength > 0) break;
+    }
+    if (bases != "ACGT" || kmer != 3 || binCount <= 0 || readLength <= 0) fail("unsupported profile header in " + path);
+    if (binCount != readLength) fail("profile needs binCount == readLength (Profile.cpp:183 sets bins := readLength)");
+    P->L = readLength; P->bins = readLength;
+    const int B = P->bins;
+    // k-mer order (Profile.cpp:69-123): 4 x "XXb", 16 x "Xab", 64 x "abc", each ACGT-lexicographic
+    {
+        int k = 0; const char* b = "ACGT";
+        for (int c = 0; c < 4; ++c) P->kmerIndex[std::string("XX") + b[c]] = k++;
+        for (int a = 0; a < 4; ++a) for (int c = 0; c < 4; ++c) P->kmerIndex[std::string("X") + b[a] + b[c]] = k++;
+        for (int a = 0; a < 4; ++a) for (int c2 = 0; c2 < 4; ++c2) for (int c = 0; c < 4; ++c)
+            P->kmerIndex[std::string() + b[a] + b[c2] + b[c]] = k++;
+    }
+    P->subs1.assign((size_t)84 * B * 4, 0.0); P->subs2.assign((size_t)84 * B * 4, 0.0);
+    P->qual.assign((size_t)16 * B * 94, 0.0);
+    std::vector<double> insF(1, 0.0), delF(1, 0.0);
+    int loaded = 0;
+    while (next_line(ifs, line)) {
+        if (line == "[Insert Rate]") { if (!next_line(ifs, line)) fail("malformed profile"); P->insertRate = atof(trim(line).c_str()); loaded++; }
+        else if (line == "[Insert Frequency]") {
+            if (!next_line(ifs, line)) fail("malformed profile");
+            auto f = split(line, '\t'); insF.clear(); for (auto& s : f) insF.push_back(atof(trim(s).c_str())); loaded++;
+        }
+        else if (line == "[Deletion Rate]") { if (!next_line(ifs, line)) fail("malformed profile"); P->delRate = atof(trim(line).c_str()); loaded++; }
+        else if (line == "[Deletion Frequency]") {
+            if (!next_line(ifs, line)) fail("malformed profile");
+            auto f = split(line, '\t'); delF.clear(); for (auto& s : f) delF.push_back(atof(trim(s).c_str())); loaded++;
+        }
+        else if (line == "[Substitution Probs]") {
+            for (int i = 0; i < 84; ++i) {
+                if (!next_line(ifs, line)) fail("malformed profile");
+                auto f = split(line, ':');
+                if (f.size() != 2 || trim(f[0]) != "kmer") fail("malformed profile: " + line);
+                auto it = P->kmerIndex.find(trim(f[1]));
+                if (it == P->kmerIndex.end()) fail("unrecognized kmer " + line);
+                int ki = it->second;
+                for (int j = 0; j < 2 * B; ++j) {
+                    if (!next_line(ifs, line)) fail("malformed profile");
+                    auto g = split(line, '\t');
+                    if (g.size() != 4) fail("malformed profile: " + line);
+                    for (int k = 0; k < 4; ++k) {
+                        double p = atof(trim(g[k]).c_str());
+                        if (j < B) P->subs1[((size_t)ki * B + j) * 4 + k] = p;
+                        else P->subs2[((size_t)ki * B + (j - B)) * 4 + k] = p;
+                    }
+                }
+            }
+            loaded++;
+        }
+        else if (line == "[Base Quality Distribution]") {
+            for (int i = 0; i < 16; ++i) {
+                if (!next_line(ifs, line)) fail("malformed profile");
+                auto f = split(line, ':');
+                if (f.size() != 2 || trim(f[0]) != "basePairIndx") fail("malformed profile: " + line);
+                int bp = atoi(trim(f[1]).c_str());
+                if (bp < 0 || bp > 15) fail("unrecognized basePairIndx");
+                for (int j = 0; j < B; ++j) {
+                    if (!next_line(ifs, line)) fail("malformed profile");
+                    auto g = split(line, '\t');
+                    if (g.size() != 94) fail("malformed profile (quality row)");
+                    for (int k = 0; k < 94; ++k) P->qual[((size_t)bp * B + j) * 94 + k] = atof(trim(g[k]).c_str());
+                }
+            }
+            loaded++;
+        }
+        else if (line == "[Insert Size Standard Deviation]") { if (!next_line(ifs, line)) fail("malformed profile"); P->stdISize = atof(trim(line).c_str()); loaded++; }
+        else if (line == "[Log Ratio Mean Value]") {
+            for (int j = 0; j < 101; ++j) {
+                if (!next_line(ifs, line)) fail("malformed profile");
+                auto g = split(line, '\t'); if (g.size() != 2) fail("malformed profile: " + line);
+                int gc = atoi(g[0].c_str()); if (gc < 0 || gc > 100) fail("bad gc row");
+                P->gcMeans[gc] = atof(g[1].c_str());
+            }
+            loaded++;
+        }
+        else if (line == "[Log Ratio Standard Deviation]") { if (!next_line(ifs, line)) fail("malformed profile"); P->gcStd = atof(trim(line).c_str()); loaded++; }
+    }
+    if (loaded < 9) fail("Error: corrupted model file " + path + ", failed to load some parameters!");
+
+    // ---- normParas(true): Profile.cpp:832-863 -------------------------------------------------
+    for (int i = 0; i < 84; ++i) {
+        int last = i < 4 ? i : (i < 20 ? (i - 4) % 4 : (i - 20) % 4);          // index of kmers[i][kmer-1]
+        for (auto* M : {&P->subs1, &P->subs2}) {
+            double* m = M->data() + (size_t)i * B * 4;
+            row_normalize(m, B, 4);
+            for (int j = 0; j < B; ++j) {                                     // Profile.cpp:844-856 (tmp.get(0,j) reads row j's sum)
+                double s = 0; for (int k = 0; k < 4; ++k) s += m[j * 4 + k];
+                if (s < ZERO_FINAL) m[j * 4 + last] = 1;
+            }
+        }
+    }
+    for (int i = 0; i < 16; ++i) row_normalize(P->qual.data() + (size_t)i * B * 94, B, 94);   // Profile.cpp:860-862
+    if (paired && P->stdISize > 0) {                                           // Profile.cpp:908-926
+        int mean = isize + 1;
+        int interval = (int)(6 * P->stdISize);
+        int lo = std::max(mean - interval / 2, readLength);
+        int hi = 2 * mean - lo;
+        std::vector<double> d;
+        for (int x = lo; x <= hi; ++x) { P->isizeAlphabet.push_back(x); d.push_back(normpdf(x, mean, P->stdISize)); }
+        if (d.empty()) fail("empty insert size range");
+        row_normalize(d.data(), 1, (int)d.size());
+        row_cumsum(d.data(), 1, (int)d.size());                                // initCDFs Profile.cpp:1399-1402
+        P->isizeCdf = d;
+    }
+    // ---- initCDFs: Profile.cpp:1363-1430 -------------------------------------------------------
+    P->insCdf = insF; row_cumsum(P->insCdf.data(), 1, (int)P->insCdf.size());
+    P->delCdf = delF; row_cumsum(P->delCdf.data(), 1, (int)P->delCdf.size());
+    for (int i = 0; i < 16; ++i) {                                             // quality normalised a second time (1393)
+        double* m = P->qual.data() + (size_t)i * B * 94;
+        row_normalize(m, B, 94); row_cumsum(m, B, 94);
+    }
+    for (int i = 0; i < 84; ++i) row_cumsum(P->subs1.data() + (size_t)i * B * 4, B, 4);
+    P->haveCdf2 = paired && P->stdISize > 0;                                   // Profile.cpp:1416-1428
+    if (P->haveCdf2) for (int i = 0; i < 84; ++i) row_cumsum(P->subs2.data() + (size_t)i * B * 4, B, 4);
+    return P.release();
+}
+
+// k-mer index of the 3 context codes (5 = 'X'); -1 when not in the table (Profile.cpp:216-222)
+inline int kmer_index(uint8_t a, uint8_t b, uint8_t c) {
+    if (c > 3) return -1;
+    if (a == 5 && b == 5) return c;
+    if (a == 5 && b < 4) return 4 + b * 4 + c;
+    if (a < 4 && b < 4) return 20 + a * 16 + b * 4 + c;
+    return -1;
+}
+
+// ---------------------------------------------------------------------------
+// predict(): Profile.cpp:1582-1697 (+1515-1580).  window = n codes; outputs n' bases/quals.
+// ---------------------------------------------------------------------------
+int predict(const Profile& P, Rng& rng, const uint8_t* win, int n, bool isRead1,
+            uint64_t uid, uint32_t attempt, char* out_b, char* out_q) {
+    const uint32_t rd = isRead1 ? 0u : 1u;
+    const uint32_t aux = rd | (attempt << 1);
+    std::vector<int> indelLens; indelLens.reserve(n);
+    std::vector<std::vector<uint8_t>> ins(n);
+    int indelLength = 0;
+    for (int j = 0; j < n;) {                                                  // 1606-1622
+        int k = 0; bool isIns = false;
+        double p = rng.real(mk(ST_INDEL, aux, uid, j, 0));                      // getIndelSeq 1552-1570
+        if (p <= P.insertRate) {
+            k = rand_indx(P.insCdf.data(), P.insCdf.size(), rng.real(mk(ST_INDEL, aux, uid, j, 2)));
+            for (int t = 0; t < k; ++t) {
+                double u = rng.integer(mk(ST_INDEL_INS, aux, uid, (uint32_t)j | ((uint32_t)(t / 4) << 16), t % 4));
+                ins[j].push_back((uint8_t)(long)(0 + (P.N - 1 - 0) * u));       // randomInteger(0, N-1): never 'T'
+            }
+            isIns = !ins[j].empty();
+        } else {
+            p = rng.real(mk(ST_INDEL, aux, uid, j, 1));
+            if (p < P.delRate / (1 - P.insertRate))
+                k = rand_indx(P.delCdf.data(), P.delCdf.size(), rng.real(mk(ST_INDEL, aux, uid, j, 2)));
+        }
+        if (!isIns && k > 0) {                                                  // deletion
+            k = std::min(n - j, k);
+            indelLength -= k;
+            indelLens.push_back(k);
+            for (int i = 1; i < k; ++i) indelLens.push_back(0);
+            j += k;
+        } else {
+            indelLength += k; j++; indelLens.push_back(k);
+        }
+    }
+    if (n + indelLength < 50) {                                                 // 1623-1630
+        indelLength = 0;
+        for (auto& v : ins) v.clear();
+        indelLens.assign(n, 0);
+    }
+    std::vector<uint8_t> src; src.reserve(n + indelLength + 2);
+    for (int j = 0; j < n;) {                                                   // 1632-1654
+        if (ins[j].empty() && indelLens[j] > 0) { j += indelLens[j]; continue; }
+        src.push_back(win[j]);
+        for (uint8_t b : ins[j]) src.push_back(b);
+        j++;
+    }
+    const int m = n + indelLength;
+    if ((int)src.size() != m) fail("predict: length bookkeeping mismatch");
+    const int B = P.bins;
+    const std::vector<double>& subs = (isRead1 || !P.haveCdf2) ? P.subs1 : P.subs2;   // 1523-1550
+    for (int j = 0; j < m; ++j) {                                               // 1666-1694
+        uint8_t c0 = j >= 2 ? src[j - 2] : 5, c1 = j >= 1 ? src[j - 1] : 5, c2 = src[j];
+        int refIndx = c2 < 4 ? c2 : -1;
+        int bin = j * B / m;
+        int ki = kmer_index(c0, c1, c2);
+        int k;
+        if (ki < 0) k = refIndx;
+        else k = rand_indx(&subs[((size_t)ki * B + bin) * 4], 4, rng.real(mk(ST_BASE, aux, uid, j, 0)));
+        if (k < 0) {
+            out_b[j] = 'N';
+            out_q[j] = (char)(long)(33 + (53 - 33) * rng.integer(mk(ST_BASE, aux, uid, j, 2)));   // getRandBaseQuality 1578-1580
+        } else {
+            out_b[j] = BASES[k];
+            int bp = refIndx * 4 + k;
+            out_q[j] = (char)(33 + rand_indx(&P.qual[((size_t)bp * B + bin) * 94], 94, rng.real(mk(ST_BASE, aux, uid, j, 1))));
+        }
+    }
+    return m;
+}
+
+// ---------------------------------------------------------------------------
+// Pipeline state
+// ---------------------------------------------------------------------------
+struct Frag {                 // lib/fragment/Fragment.h:20-31
+    int rec; long start; int len; int strand; int primers;
+    std::vector<uint8_t> T;   // template strand c(F) used by amplify (Fragment.cpp:65-68)
+};
+struct Amp {                  // lib/amplicon/Amplicon.h:47-53 (packed fields unpacked)
+    uint32_t parent;          // semis: fragment index; fulls: index into semis
+    uint32_t spos, len, gc;
+    uint32_t primers;         // 12-bit (Amplicon.cpp:76-79)
+    uint64_t uid;             // lineage id (counter-mode key)
+    uint32_t err_off; uint32_t err_cnt;
+};
+struct AmpList { std::vector<Amp> a; std::vector<uint32_t> errs; };   // err = pos<<3 | alt  (AmpError, Amplicon.cpp:13-45)
+
+struct Params {
+    long primers = 100000; double gamma = 1e-9, coverage = 5, ber = 3.4e-4;
+    int isize = 260; bool paired = true; int threads = 1;
+    int ampMin = 1000, ampMax = 2000, fragSize = 1000, fragMin = 10000, fragMax = 100000;   // Config.cpp:35-48, Fragment.cpp:15-16
+    bool counter = false; uint64_t seed = 1; long long fixed_time = 1234567890LL; bool verbose = true;
+};
+
+inline uint64_t semi_uid(uint64_t frag, uint32_t pass, uint32_t i) { return (frag << 23) | ((uint64_t)pass << 20) | i; }
+inline uint64_t full_uid(uint64_t semi, uint32_t cyc, uint32_t i) { return (semi << 15) | ((uint64_t)cyc << 12) | i; }
+
+struct Sim {
+    Params prm; Rng rng; RefStreams streams;
+    std::vector<Record> recs; Profile* prof = nullptr;
+    std::vector<Frag> frags; AmpList semis, fulls;
+    std::vector<long> primerCount;          // 65536 counters (Malbac.cpp:36-81; flat instead of trie)
+    std::vector<long> primerPending;        // [REMAP] counter mode: decrements applied at pass end
+    unsigned long totalPrimers = 0;
+    std::vector<unsigned> readNumbers;
+    // GC-factor engines (ref mode): Profile.cpp:1405-1411
+    std::vector<std::default_random_engine> gcGen; std::vector<std::normal_distribution<double>> gcDist;
+    ~Sim() { delete prof; }
+};
+
+template <class F>
+void parallel_blocks(size_t n, int threads, size_t min_block, F f) {
+    if (n == 0) return;
+    size_t nb = std::max<size_t>(1, std::min<size_t>((size_t)threads * 4, (n + min_block - 1) / min_block));
+    if (threads <= 1) nb = 1;
+    std::vector<std::thread> th; size_t next = 0; std::mutex* mu = new std::mutex;
+    auto worker = [&]() {
+        for (;;) { size_t b; { std::lock_guard<std::mutex> g(*mu); b = next++; } if (b >= nb) break;
+                   f(b, n * b / nb, n * (b + 1) / nb); }
+    };
+    if (threads <= 1) worker(); else { for (int t = 0; t < threads; ++t) th.emplace_back(worker); for (auto& t : th) t.join(); }
+    delete mu;
+}
+
+// ---- a1: Genome::splitToFrags (Genome.cpp:753-782) + Fragment::createSequence (Fragment.cpp:40-50)
+void split_to_frags(Sim& S) {
+    const Params& p = S.prm;
+    for (size_t r = 0; r < S.recs.size(); ++r) {
+        long chrLen = (long)S.recs[r].code.size(), pos = 1; uint32_t k = 0;
+        while (pos <= chrLen) {
+            double u = S.rng.grand(mk(ST_FRAGSPLIT, 0, r, k++, 0));
+            int fl = (int)(long)(p.fragMin + (p.fragMax + 1 - p.fragMin) * u);   // randomInteger(minSize, maxSize+1)
+            if (pos + fl - 1 > chrLen) break;
+            S.frags.push_back(Frag{(int)r, pos, fl, 1, 0, {}});
+            S.frags.push_back(Frag{(int)r, pos, fl, -1, 0, {}});
+            pos += fl;
+        }
+        if (pos <= chrLen) {                                                    // tail emitted twice with strand +1 (quirk kept)
+            S.frags.push_back(Frag{(int)r, pos, (int)(chrLen - pos + 1), 1, 0, {}});
+            S.frags.push_back(Frag{(int)r, pos, (int)(chrLen - pos + 1), 1, 0, {}});
+        }
+    }
+    for (auto& f : S.frags) {
+        const uint8_t* g = S.recs[f.rec].code.data() + (f.start - 1);
+        f.T.resize(f.len);
+        // stored F: strand +1 -> reversed slice, -1 -> complemented slice; template strand T = c(F)
+        if (f.strand == 1) for (int i = 0; i < f.len; ++i) f.T[i] = comp_code(g[f.len - 1 - i]);
+        else for (int i = 0; i < f.len; ++i) f.T[i] = comp_code(comp_code(g[i]));
+    }
+}
+
+// ---- a2: primer pool (Malbac.cpp:36-103) ----------------------------------------------------
+inline int primer_index(const uint8_t* t) {
+    int idx = 0; for (int k = 0; k < 8; ++k) { if (t[k] > 3) return -1; idx = (idx << 2) | t[k]; } return idx;
+}
+struct PrimerPool {
+    Sim& S; std::vector<long>* pending;           // per-thread pending deltas in counter mode
+    bool take(const uint8_t* t) {                 // updatePrimerCount(s, -1)
+        int idx = primer_index(t);
+        if (idx < 0) return false;                // N-containing 8-mer: node with no stock (A.8 D-item)
+        if (S.prm.counter) {                      // [REMAP] availability = stock at pass start
+            if (S.primerCount[idx] <= 0) return false;
+            (*pending)[idx]++; return true;
+        }
+        if (S.primerCount[idx] - 1 < 0) return false;
+        S.primerCount[idx] -= 1; return true;
+    }
+};
+
+// ---- a3: Malbac::setPrimers (Malbac.cpp:236-283) + poissRand (MyDefine.cpp:69-80) ------------
+long poiss_rand(Sim& S, double lambda, uint32_t call, uint32_t kind, uint64_t tuid) {
+    long x = -1; double log1 = 0, log2 = -lambda; uint32_t t = 0;
+    do {
+        double u = S.rng.grand(mk(ST_POISSON, kind | (call << 1), tuid, t / 4, t % 4)); t++;
+        log1 += log(u); x++;
+    } while (log1 >= log2);
+    return x;
+}
+void set_primers(Sim& S, bool onlyFrags, uint32_t call) {
+    unsigned long templateNum = 0; double totalLen = 0;
+    for (auto& f : S.frags) totalLen += (unsigned)f.len;
+    templateNum += S.frags.size();
+    if (!onlyFrags) { templateNum += S.semis.a.size(); for (auto& a : S.semis.a) totalLen += a.len; }
+    unsigned long expected = (unsigned long)(S.totalPrimers * S.prm.gamma * templateNum);
+    unsigned long count = 0;
+    for (size_t i = 0; i < S.frags.size(); ++i) {
+        double lambda = expected * (1.0 * (unsigned)S.frags[i].len / totalLen);
+        unsigned long k = (unsigned long)poiss_rand(S, lambda, call, 0, i);
+        count += k; S.frags[i].primers = (int)k;
+    }
+    if (!onlyFrags) for (auto& a : S.semis.a) {
+        double lambda = expected * (1.0 * a.len / totalLen);
+        unsigned long k = (unsigned long)poiss_rand(S, lambda, call, 1, a.uid);
+        count += k; a.primers = (uint32_t)(k & 0xFFF);
+    }
+    S.totalPrimers -= count;
+}
+
+// ---- a4/a5: Fragment::amplify (Fragment.cpp:52-137) / Amplicon::amplify (Amplicon.cpp:156-240) --
+// T = template strand (c(F) or c(S)); appends created amplicons in creation order.
+void amplify_template(Sim& S, Rng& rng, PrimerPool& pool, bool fromFrag, uint64_t tuid, uint32_t parent,
+                      const uint8_t* T, unsigned length, unsigned primerNum, uint32_t pass,
+                      std::vector<uint8_t>& posAttached, AmpList& out) {
+    const Params& p = S.prm;
+    if ((int)length < p.ampMin + 27) return;
+    posAttached.assign(length, 0);
+    const uint32_t kind = fromFrag ? 0u : 1u, aux = kind | (pass << 1);
+    for (unsigned i = 0; i < primerNum; ++i) {
+        int tryTimes = 0; unsigned spos = 0, alen = 0;
+        do {
+            uint32_t blk = (i << 6) | (uint32_t)tryTimes;
+            spos = (unsigned)(long)(27 + ((long)length - 27) * rng.integer(mk(ST_ATTACH, aux, tuid, blk, 0)));
+            alen = (unsigned)(p.ampMin + (double)(p.ampMax + 1 - p.ampMin) * rng.real(mk(ST_ATTACH, aux, tuid, blk, 1)));
+            tryTimes++;
+            if (tryTimes > 50) break;
+            if (spos + alen > length || posAttached[spos] == 1) continue;
+            if (pool.take(T + spos)) break;
+        } while (1);
+        if (tryTimes > 50) break;
+        posAttached[spos] = 1;
+        int gc = 0; bool hasN = false;                                           // countGC MyDefine.cpp:434-452
+        for (unsigned j = 0; j < alen; ++j) { uint8_t c = T[spos + j]; if (is_gc(c)) gc++; else if (c > 3) hasN = true; }
+        if (hasN) gc = 0;
+        const uint64_t nuid = fromFrag ? semi_uid(tuid, pass, i) : full_uid(tuid, pass, i);
+        uint32_t off = (uint32_t)out.errs.size();
+        for (unsigned j = 8; j < alen; ++j) {
+            double pr = rng.real(mk(ST_ERR, kind, nuid, j / 4, j % 4));
+            if (pr < p.ber) {
+                uint8_t base = T[spos + j]; unsigned n; uint32_t a = 0;
+                do {
+                    Key k = mk(ST_ERRALT, kind, nuid, j | ((a / 4) << 16), a % 4); a++;
+                    // Fragment.cpp:110 draws from the int stream, Amplicon.cpp:213 from the real stream
+                    n = fromFrag ? (unsigned)(long)(0 + (4 - 0) * rng.integer(k)) : (unsigned)(0 + (4 - 0) * rng.real(k));
+                } while (n == base);
+                if (is_gc((uint8_t)n)) gc++;
+                if (is_gc(base)) gc--;
+                out.errs.push_back((j << 3) | n);
+            }
+        }
+        out.a.push_back(Amp{parent, spos, alen, (uint32_t)std::max(0, gc), 0, nuid, off, (uint32_t)out.errs.size() - off});
+    }
+}
+
+// ---- a7: Amplicon::getSequence (Amplicon.cpp:255-382), closed form ----------------
+// semi S[t] = (T_frag[s..s+l) with subs)[l-1-t]
+void semi_sequence(const Sim& S, const Amp& a, std::vector<uint8_t>& out) {
+    const Frag& f = S.frags[a.parent];
+    out.resize(a.len);
+    std::vector<uint8_t> tmp(f.T.begin() + a.spos, f.T.begin() + a.spos + a.len);
+    for (uint32_t e = 0; e < a.err_cnt; ++e) { uint32_t v = S.semis.errs[a.err_off + e]; tmp[v >> 3] = (uint8_t)(v & 7); }
+    for (uint32_t t = 0; t < a.len; ++t) out[t] = tmp[a.len - 1 - t];
+}
+// full U[t] = c(S)[s2+t] with subs
+void full_sequence(const Sim& S, const Amp& a, std::vector<uint8_t>& scratch, std::vector<uint8_t>& out) {
+    semi_sequence(S, S.semis.a[a.parent], scratch);
+    out.resize(a.len);
+    for (uint32_t t = 0; t < a.len; ++t) out[t] = comp_code(scratch[a.spos + t]);
+    for (uint32_t e = 0; e < a.err_cnt; ++e) { uint32_t v = S.fulls.errs[a.err_off + e]; out[v >> 3] = (uint8_t)(v & 7); }
+}
+
+// append `add` to `dst`; ref order = reversed creation order per pool task (insertLinkList prepends,
+// Amplicon.cpp:574-585; one task at -t 1, Malbac.cpp:324,351).  Counter mode keeps the same order.
+void append_reversed(AmpList& dst, AmpList& add) {
+    for (size_t i = add.a.size(); i-- > 0;) {
+        Amp a = add.a[i]; uint32_t off = (uint32_t)dst.errs.size();
+        for (uint32_t e = 0; e < a.err_cnt; ++e) dst.errs.push_back(add.errs[a.err_off + e]);
+        a.err_off = off; dst.a.push_back(a);
+    }
+}
+
+void apply_pending(Sim& S, std::vector<std::vector<long>>& pend) {
+    if (!S.prm.counter) return;
+    for (auto& v : pend) for (size_t i = 0; i < v.size(); ++i) if (v[i]) { S.primerCount[i] -= v[i]; }
+    for (auto& c : S.primerCount) if (c < 0) c = 0;                                // [REMAP] clamp at pass end
+}
+
+// Malbac::amplifyFrags (Malbac.cpp:318-343)
+void amplify_frags(Sim& S, uint32_t pass) {
+    int th = S.prm.counter ? S.prm.threads : 1;
+    size_t n = S.frags.size();
+    std::vector<AmpList> parts; std::vector<std::vector<long>> pend;
+    size_t nbMax = (size_t)std::max(1, th) * 4; parts.resize(nbMax); pend.resize(nbMax);
+    parallel_blocks(n, th, 1, [&](size_t b, size_t lo, size_t hi) {
+        pend[b].assign(65536, 0); PrimerPool pool{S, &pend[b]}; std::vector<uint8_t> pa; Rng rng = S.rng;
+        for (size_t i = lo; i < hi; ++i) {
+            Frag& f = S.frags[i];
+            amplify_template(S, rng, pool, true, i, (uint32_t)i, f.T.data(), f.len, f.primers, pass, pa, parts[b]);
+        }
+    });
+    AmpList all;
+    for (auto& pt : parts) { for (auto a : pt.a) { uint32_t off = (uint32_t)all.errs.size();
+        for (uint32_t e = 0; e < a.err_cnt; ++e) all.errs.push_back(pt.errs[a.err_off + e]); a.err_off = off; all.a.push_back(a); } }
+    apply_pending(S, pend);
+    append_reversed(S.semis, all);
+}
+// Malbac::amplifySemiAmplicons (Malbac.cpp:345-368)
+void amplify_semis(Sim& S, uint32_t cyc) {
+    int th = S.prm.counter ? S.prm.threads : 1;
+    size_t n = S.semis.a.size();
+    std::vector<AmpList> parts; std::vector<std::vector<long>> pend;
+    size_t nbMax = (size_t)std::max(1, th) * 4; parts.resize(nbMax); pend.resize(nbMax);
+    parallel_blocks(n, th, 64, [&](size_t b, size_t lo, size_t hi) {
+        pend[b].assign(65536, 0); PrimerPool pool{S, &pend[b]}; std::vector<uint8_t> pa, seq, tc; Rng rng = S.rng;
+        for (size_t i = lo; i < hi; ++i) {
+            const Amp& a = S.semis.a[i];
+            if ((int)a.len < S.prm.ampMin + 27) continue;
+            semi_sequence(S, a, seq); tc.resize(seq.size());
+            for (size_t t = 0; t < seq.size(); ++t) tc[t] = comp_code(seq[t]);       // Amplicon.cpp:171-172
+            amplify_template(S, rng, pool, false, a.uid, (uint32_t)i, tc.data(), a.len, a.primers, cyc, pa, parts[b]);
+        }
+    });
+    AmpList all;
+    for (auto& pt : parts) { for (auto a : pt.a) { uint32_t off = (uint32_t)all.errs.size();
+        for (uint32_t e = 0; e < a.err_cnt; ++e) all.errs.push_back(pt.errs[a.err_off + e]); a.err_off = off; all.a.push_back(a); } }
+    apply_pending(S, pend);
+    append_reversed(S.fulls, all);
+}
+
+// Malbac::amplify (Malbac.cpp:173-201)
+void amplify(Sim& S) {
+    if (S.prm.verbose) fprintf(stderr, "\nMALBAC amplification...\n");
+    S.primerCount.assign(65536, S.prm.primers);
+    S.totalPrimers = 65536UL * (unsigned long)S.prm.primers;
+    set_primers(S, true, 0);
+    amplify_frags(S, 0);
+    for (int i = 0; i < 5; ++i) {
+        if (S.totalPrimers == 0) break;
+        if (S.prm.verbose) fprintf(stderr, "cycle number: %d\n", i + 1);
+        set_primers(S, false, i + 1);
+        amplify_semis(S, i);
+        if (S.prm.verbose) fprintf(stderr, "semi amplicon amplification done!\n");
+        if (i < 4) { amplify_frags(S, i + 1); if (S.prm.verbose) fprintf(stderr, "fragment amplification done!\n"); }
+    }
+}
+
+// ---- a8: Amplicon::getWeightedLength (Amplicon.cpp:396-400) + Profile::getGCFactor (1503-1513) ---
+double gc_factor(Sim& S, int gc, uint64_t uid) {
+    if (gc < 0 || gc > 100) return 0;
+    if (!S.prm.counter) {
+        double v = S.gcDist[gc](S.gcGen[gc]);
+        while (v < 0) v = S.gcDist[gc](S.gcGen[gc]);
+        return v;
+    }
+    // [REMAP] Marsaglia polar normal from keyed uniforms; log via det_log so a GPU can reproduce the bits.
+    for (uint32_t a = 0;; ++a) {
+        uint32_t c[4] = {a, (uint32_t)uid, (uint32_t)(uid >> 32), ST_WEIGHT}, o[4];
+        philox(c, S.rng.key, o);
+        double x = 2.0 * ((o[0] + 0.5) / 4294967296.0) - 1.0, y = 2.0 * ((o[1] + 0.5) / 4294967296.0) - 1.0;
+        double r2 = x * x + y * y;
+        if (r2 > 1.0 || r2 == 0.0) continue;
+        double mult = sqrt(-2.0 * det_log(r2) / r2);
+        double v = S.prof->gcMeans[gc] + S.prof->gcStd * (y * mult);
+        if (v < 0) continue;
+        return v;
+    }
+}
+
+// ---- a9: Malbac::setReadCounts (Malbac.cpp:370-408) + randIndx_hp/batchSampling (MyDefine.cpp:191-272)
+void set_read_counts(Sim& S, long reads) {
+    const size_t ac = S.fulls.a.size();
+    std::vector<double> w(ac);
+    const unsigned fragSize = S.prm.fragSize;
+    if (S.prm.counter) {
+        parallel_blocks(ac, S.prm.threads, 4096, [&](size_t, size_t lo, size_t hi) {
+            for (size_t i = lo; i < hi; ++i) { const Amp& a = S.fulls.a[i]; int gc = 100 * a.gc / a.len;
+                w[i] = gc_factor(S, gc, a.uid) * a.len / (fragSize * fragSize); } });
+    } else {
+        for (size_t i = 0; i < ac; ++i) { const Amp& a = S.fulls.a[i]; int gc = 100 * a.gc / a.len;
+            w[i] = gc_factor(S, gc, a.uid) * a.len / (fragSize * fragSize); }
+    }
+    const unsigned chunk = (unsigned)std::max<size_t>(1, std::min<size_t>(1000, ac / 1));   // loadPerThread at -t 1
+    double total = 0;
+    if (S.prm.counter) {        // [REMAP] chunked sum: per-1000 partials, then partials in order
+        for (size_t s = 0; s < ac; s += chunk) { double part = 0; for (size_t i = s; i < std::min(ac, s + chunk); ++i) part += w[i]; total += part; }
+    } else for (size_t i = 0; i < ac; ++i) total += w[i];
+    for (size_t i = 0; i < ac; ++i) w[i] /= (ZERO_FINAL + total);                 // wls.normalize(0)
+    S.readNumbers.assign(ac, 0);
+    unsigned long sum = 0;
+    for (size_t i = 0; i < ac; ++i) { unsigned rc = (unsigned)(w[i] * reads); S.readNumbers[i] = rc; sum += rc; }
+    reads -= (long)sum;
+    // randIndx_hp(wls, reads, readNumbers, true)
+    unsigned long n = (unsigned long)reads;
+    struct Chunk { size_t s, e; unsigned quota; std::vector<double> cdf; };
+    std::vector<Chunk> chunks; std::vector<double> totalProbs; unsigned long count = 0;
+    for (size_t s = 0; s < ac; s += chunk) {
+        size_t e = std::min(ac, s + chunk) - 1;
+        Chunk c{s, e, 0, {}};
+        double tp = 0; for (size_t i = s; i <= e; ++i) tp += w[i];
+        c.cdf.resize(e - s + 1); double run = 0;
+        for (size_t i = s; i <= e; ++i) { run = run + w[i] / tp; c.cdf[i - s] = run; }
+        c.quota = (unsigned)(tp * n); count += c.quota;
+        totalProbs.push_back(tp); chunks.push_back(std::move(c));
+    }
+    n -= count;
+    if (n > 0 && !chunks.empty()) {
+        std::vector<double> probs(totalProbs.size()); probs[0] = totalProbs[0];
+        for (size_t i = 1; i < probs.size(); ++i) probs[i] = probs[i - 1] + totalProbs[i];
+        uint32_t t = 0;
+        while (n-- > 0) { unsigned j = rand_indx(probs.data(), probs.size(), S.rng.main_real(mk(ST_ALLOC_TOP, 0, 0, t++, 0))); chunks[j].quota += 1; }
+    }
+    for (size_t c = 0; c < chunks.size(); ++c) {                                  // batchSampling, one task per chunk, FIFO
+        Chunk& ch = chunks[c];
+        for (unsigned t = 0; t < ch.quota; ++t) {
+            unsigned j = rand_indx(ch.cdf.data(), ch.cdf.size(), S.rng.real(mk(ST_ALLOC_CHUNK, 0, c, t, 0)));
+            S.readNumbers[ch.s + j] += 1;
+        }
+    }
+    if (S.prm.paired) { int k = 1; for (size_t i = 0; i < ac; ++i) if (S.readNumbers[i] % 2 == 1) { S.readNumbers[i] += k; k *= -1; } }
+}
+
+// ---- a11: Amplicon::yieldReads (Amplicon.cpp:402-565) -----------------------------------------
+struct ReadOut { std::string f1, f2; unsigned long pairs = 0; std::string dump; };
+
+void yield_reads_range(Sim& S, Rng& rng, size_t lo, size_t hi, ReadOut& out, bool dump) {
+    const Profile& P = *S.prof; const int L = P.L; const bool paired = S.prm.paired;
+    std::vector<uint8_t> scratch, seq, win(L);
+    std::vector<char> ob(2 * L + 128), oq(2 * L + 128);
+    char name[64];
+    for (size_t i = lo; i < hi; ++i) {
+        int n = (int)S.readNumbers[i];
+        if (n == 0) continue;
+        const Amp& a = S.fulls.a[i];
+        full_sequence(S, a, scratch, seq);
+        const int ampLen = (int)a.len;
+        if (ampLen < L) continue;
+        int fragCount = 0, failCount = 0;
+        while (n > 0) {
+            fragCount++;
+            const uint32_t att = (uint32_t)(fragCount - 1);
+            if (!paired) {
+                long pos = (long)(0 + (double)(ampLen - L + 1 - 0) * rng.integer(mk(ST_PAIR, 0, a.uid, att, 1)));
+                int m = predict(P, rng, &seq[pos], L, true, a.uid, att, ob.data(), oq.data());
+                int k = snprintf(name, sizeof name, "@%d#%d\n", (int)i, fragCount);
+                out.f1.append(name, k); out.f1.append(ob.data(), m); out.f1.append("\n+\n"); out.f1.append(oq.data(), m); out.f1.push_back('\n');
+                out.pairs++; n--;
+                continue;
+            }
+            int isz = P.isizeAlphabet.empty() ? -1 :
+                      P.isizeAlphabet[rand_indx(P.isizeCdf.data(), P.isizeCdf.size(), rng.real(mk(ST_PAIR, 0, a.uid, att, 0)))];
+            if (isz < 0) fail("Error: unrecognized parameter name \"insertSize\"");      // Profile.cpp:1483-1485 (exit(1))
+            if (isz < L || isz > ampLen) { failCount++; if (failCount > 1000) break; continue; }
+            long pos = (long)(0 + (double)(ampLen - isz + 1 - 0) * rng.integer(mk(ST_PAIR, 0, a.uid, att, 1)));
+            int m1 = predict(P, rng, &seq[pos], L, true, a.uid, att, ob.data(), oq.data());
+            int k = snprintf(name, sizeof name, "@%d#%d/1\n", (int)i, fragCount);
+            out.f1.append(name, k); out.f1.append(ob.data(), m1); out.f1.append("\n+\n"); out.f1.append(oq.data(), m1); out.f1.push_back('\n');
+            for (int t = 0; t < L; ++t) win[t] = comp_code(seq[pos + isz - 1 - t]);    // revcomp of the far end
+            int m2 = predict(P, rng, win.data(), L, false, a.uid, att, ob.data(), oq.data());
+            k = snprintf(name, sizeof name, "@%d#%d/2\n", (int)i, fragCount);
+            out.f2.append(name, k); out.f2.append(ob.data(), m2); out.f2.append("\n+\n"); out.f2.append(oq.data(), m2); out.f2.push_back('\n');
+            if (dump) { char b[128]; int q = snprintf(b, sizeof b, "%zu\t%d\t%ld\t%d\t%d\t%d\n", i, fragCount, pos, isz, m1, m2); out.dump.append(b, q); }
+            out.pairs++; n -= 2;
+        }
+    }
+}
+
+void dump_amps(const std::string& path, const AmpList& L) {
+    FILE* f = fopen(path.c_str(), "w"); if (!f) fail("cannot write " + path);
+    for (size_t i = 0; i < L.a.size(); ++i) { const Amp& a = L.a[i];
+        fprintf(f, "%zu\t%u\t%u\t%u\t%u\t%u\t%llu\t", i, a.parent, a.spos, a.len, a.gc, a.primers, (unsigned long long)a.uid);
+        for (uint32_t e = 0; e < a.err_cnt; ++e) fprintf(f, "%s%u:%u", e ? "," : "", L.errs[a.err_off + e] >> 3, L.errs[a.err_off + e] & 7);
+        fputc('\n', f); }
+    fclose(f);
+}
+
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+int genreads(const scso_params& q) {
+    Sim S; Params& p = S.prm;
+    p.primers = q.primers; p.gamma = q.gamma; p.coverage = q.coverage; p.isize = q.isize; p.paired = q.paired != 0;
+    p.threads = std::max(1, q.threads); p.counter = q.rng_mode == 1; p.seed = q.seed; p.fixed_time = q.fixed_time; p.verbose = q.verbose != 0;
+    if (!p.counter) p.threads = 1;
+    S.rng.counter = p.counter; S.rng.key[0] = (uint32_t)p.seed; S.rng.key[1] = (uint32_t)(p.seed >> 32); S.rng.ref = &S.streams;
+    if (!p.counter) {
+        srand((unsigned)p.fixed_time);                                                    // scssim.cpp:47
+        unsigned seed = (unsigned)(p.fixed_time * 1000000000LL);                          // ThreadPool.cpp:41
+        S.streams.w_real = std::mt19937(seed); S.streams.w_int = std::mt19937(seed);
+    }
+    double t0 = now_s();
+    S.recs = load_fasta(q.input_fasta);
+    if (p.verbose) fprintf(stderr, "\nReference sequence was loaded from file %s\n", q.input_fasta);
+    S.prof = load_profile(q.profile, p.paired, p.isize);
+    if (p.verbose) fprintf(stderr, "profile was loaded from file %s\n", q.profile);
+    if (!p.counter) {                                                                     // Profile.cpp:1405-1411
+        unsigned seed = (unsigned)(p.fixed_time * 1000000000LL);
+        for (int l = 0; l < 101; ++l) { S.gcGen.emplace_back(seed); S.gcDist.emplace_back(S.prof->gcMeans[l], S.prof->gcStd); }
+    }
+    double t1 = now_s();
+    split_to_frags(S);
+    double t2 = now_s();
+    amplify(S);
+    double t3 = now_s();
+    // Malbac::yieldReads (Malbac.cpp:410-460)
+    unsigned long refLen = 0;
+    for (auto& r : S.recs) { auto f = split(r.name, '_'); refLen += atoi(f.back().c_str()); }
+    refLen /= 2;
+    unsigned long reads = (unsigned long)(refLen * p.coverage / (long)S.prof->L);
+    if (p.verbose) fprintf(stderr, "\nNumber of reads to generate: %lu\n", reads);
+    set_read_counts(S, (long)reads);
+    double t4 = now_s();
+    std::string pre = q.output_prefix ? q.output_prefix : "";
+    FILE *o1 = nullptr, *o2 = nullptr;
+    if (!pre.empty()) {
+        o1 = fopen((pre + (p.paired ? "_1.fq" : ".fq")).c_str(), "w");
+        if (!o1) fail("Error: can not open fastq file to save results:\n" + pre);
+        if (p.paired) { o2 = fopen((pre + "_2.fq").c_str(), "w"); if (!o2) fail("Error: can not open fastq file to save results:\n" + pre); }
+    }
+    if (p.verbose) fprintf(stderr, "\n*****Producing reads*****\n");
+    const bool dump = q.dump_prefix != nullptr;
+    FILE* dr = dump ? fopen((std::string(q.dump_prefix) + ".reads.tsv").c_str(), "w") : nullptr;
+    unsigned long pairs = 0;
+    const size_t ac = S.fulls.a.size(), step = (size_t)p.threads * 4 * 2048;
+    for (size_t base = 0; base < ac; base += step) {                                       // bounded memory: wave of blocks, written in order
+        size_t end = std::min(ac, base + step);
+        size_t nbMax = (size_t)p.threads * 4; std::vector<ReadOut> outs(nbMax);
+        parallel_blocks(end - base, p.threads, 256, [&](size_t b, size_t lo, size_t hi) { Rng rng = S.rng; yield_reads_range(S, rng, base + lo, base + hi, outs[b], dump); });
+        for (auto& o : outs) { if (o1) fwrite(o.f1.data(), 1, o.f1.size(), o1); if (o2) fwrite(o.f2.data(), 1, o.f2.size(), o2);
+                               if (dr) fwrite(o.dump.data(), 1, o.dump.size(), dr); pairs += o.pairs; }
+    }
+    if (o1) fclose(o1); if (o2) fclose(o2); if (dr) fclose(dr);
+    double t5 = now_s();
+    if (dump) {
+        std::string d = q.dump_prefix;
+        FILE* f = fopen((d + ".frags.tsv").c_str(), "w");
+        for (size_t i = 0; i < S.frags.size(); ++i) fprintf(f, "%zu\t%d\t%ld\t%d\t%d\n", i, S.frags[i].rec, S.frags[i].start, S.frags[i].len, S.frags[i].strand);
+        fclose(f);
+        dump_amps(d + ".semis.tsv", S.semis); dump_amps(d + ".fulls.tsv", S.fulls);
+        f = fopen((d + ".readnum.tsv").c_str(), "w");
+        for (size_t i = 0; i < S.readNumbers.size(); ++i) if (S.readNumbers[i]) fprintf(f, "%zu\t%u\n", i, S.readNumbers[i]);
+        fclose(f);
+    }
+    if (p.verbose) {
+        fprintf(stderr, "\nReads generation done!\n");
+        fprintf(stderr, "[oracle] frags=%zu semis=%zu fulls=%zu primers_left=%lu pairs=%lu | load %.2fs frag %.2fs amplify %.2fs alloc %.2fs readgen %.2fs\n",
+                S.frags.size(), S.semis.a.size(), S.fulls.a.size(), S.totalPrimers, pairs, t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4);
+    }
+    g_timings[0] = t1 - t0; g_timings[1] = t2 - t1; g_timings[2] = t3 - t2; g_timings[3] = t4 - t3; g_timings[4] = t5 - t4; g_timings[5] = (double)pairs;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+void scso_philox4x32_10(const uint32_t* ctr, const uint32_t* key, uint32_t* out) { philox(ctr, key, out); }
+double scso_det_log(double x) { return det_log(x); }
+const char* scso_last_error(void) { return g_err.c_str(); }
+void scso_last_timings(double out[6]) { for (int i = 0; i < 6; ++i) out[i] = g_timings[i]; }
+
+void scso_default_params(scso_params* p) {
+    memset(p, 0, sizeof *p);
+    p->primers = 100000; p->gamma = 1e-9; p->coverage = 5; p->isize = 260; p->paired = 1; p->threads = 1;
+    p->rng_mode = 1; p->seed = 1; p->fixed_time = 1234567890LL; p->verbose = 1;
+}
+
+int scso_genreads(const scso_params* p) {
+    try { return genreads(*p); }
+    catch (const std::exception& e) { g_err = e.what(); return 1; }
+}
+
+void* scso_profile_load(const char* path, int paired, int isize) {
+    try { return load_profile(path, paired != 0, isize); }
+    catch (const std::exception& e) { g_err = e.what(); return nullptr; }
+}
+void scso_profile_free(void* h) { delete (Profile*)h; }
+int scso_profile_read_length(void* h) { return ((Profile*)h)->L; }
+int scso_profile_kmer_count(void* h) { return ((Profile*)h)->kmerCount; }
+size_t scso_profile_table(void* h, int which, const double** data) {
+    Profile* P = (Profile*)h;
+    const std::vector<double>* v = nullptr;
+    switch (which) {
+        case 0: v = &P->subs1; break; case 1: v = &P->subs2; break; case 2: v = &P->qual; break;
+        case 3: v = &P->insCdf; break; case 4: v = &P->delCdf; break; case 5: v = &P->isizeCdf; break;
+        case 6: *data = P->gcMeans; return 101;
+        default: *data = nullptr; return 0;
+    }
+    *data = v->data(); return v->size();
+}
+void scso_profile_scalars(void* h, double out[8]) {
+    Profile* P = (Profile*)h;
+    out[0] = P->insertRate; out[1] = P->delRate; out[2] = P->stdISize; out[3] = P->gcStd;
+    out[4] = P->isizeAlphabet.empty() ? -1 : P->isizeAlphabet[0]; out[5] = (double)P->isizeAlphabet.size();
+    out[6] = P->haveCdf2 ? 1 : 0; out[7] = P->bins;
+}
+int scso_predict_counter(void* h, const uint8_t* window, int n, int is_read1, uint64_t seed, uint64_t uid,
+                         uint32_t attempt, char* out_bases, char* out_quals) {
+    try {
+        Rng rng; rng.counter = true; rng.key[0] = (uint32_t)seed; rng.key[1] = (uint32_t)(seed >> 32);
+        return predict(*(Profile*)h, rng, window, n, is_read1 != 0, uid, attempt, out_bases, out_quals);
+    } catch (const std::exception& e) { g_err = e.what(); return -1; }
+}
+
+}  // extern "C"
+
+#ifdef SCS_ORACLE_MAIN
+// scs_oracle genreads: the reference's genreads CLI (src/scssim.cpp:285-404) + oracle extras
+//   --rng ref|counter   --seed N   --fixed-time T   --dump PREFIX   -q (quiet)
+#include <getopt.h>
+int main(int argc, char** argv) {
+    if (argc < 2 || strcmp(argv[1], "genreads") != 0) { fprintf(stderr, "usage: scs_oracle genreads -i simu.fa -m model.profile -o prefix [options]\n"); return 1; }
+    scso_params p; scso_default_params(&p);
+    static option lo[] = {{"input", 1, 0, 'i'}, {"primers", 1, 0, 'p'}, {"gamma", 1, 0, 'r'}, {"model", 1, 0, 'm'}, {"layout", 1, 0, 'l'},
+                          {"coverage", 1, 0, 'c'}, {"isize", 1, 0, 's'}, {"threads", 1, 0, 't'}, {"output", 1, 0, 'o'},
+                          {"rng", 1, 0, 1000}, {"seed", 1, 0, 1001}, {"fixed-time", 1, 0, 1002}, {"dump", 1, 0, 1003}, {0, 0, 0, 0}};
+    int c; argc--; argv++;
+    while ((c = getopt_long(argc, argv, "i:p:r:m:l:c:s:t:o:q", lo, nullptr)) != -1) switch (c) {
+        case 'i': p.input_fasta = optarg; break; case 'p': p.primers = atol(optarg); break; case 'r': p.gamma = atof(optarg); break;
+        case 'm': p.profile = optarg; break; case 'l': p.paired = strcmp(optarg, "SE") != 0; break; case 'c': p.coverage = atof(optarg); break;
+        case 's': p.isize = atoi(optarg); break; case 't': p.threads = atoi(optarg); break; case 'o': p.output_prefix = optarg; break;
+        case 'q': p.verbose = 0; break;
+        case 1000: p.rng_mode = strcmp(optarg, "ref") == 0 ? 0 : 1; break; case 1001: p.seed = strtoull(optarg, 0, 10); break;
+        case 1002: p.fixed_time = atoll(optarg); break; case 1003: p.dump_prefix = optarg; break;
+        default: return 1;
+    }
+    if (!p.input_fasta || !p.profile || !p.output_prefix) { fprintf(stderr, "Error: -i, -m and -o are required\n"); return 1; }
+    int rc = scso_genreads(&p);
+    if (rc) fprintf(stderr, "%s\n", scso_last_error());
+    return rc;
+}
+#endif
