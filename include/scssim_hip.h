@@ -1,0 +1,154 @@
+/* scssim_hip.h -- C ABI of the MI355X-native `genreads` hot path.
+ *
+ * Drop-in boundary for qasimyu/scssim (reference paths below are relative to
+ * the reference root).  The reference has no plugin/FFI layer: its genreads
+ * driver (src/scssim.cpp:46-67) calls five methods on global objects.  Each
+ * entry point here replaces one of those calls (or the pool job behind it), so
+ * a maintainer swaps the bodies of those five calls for the functions below
+ * (INTEGRATION.md shows the patch).  Plain C types only; every function
+ * returns 0 on success or an SCS_E* code and never throws or exits.
+ * One scs_ctx per host thread; a ctx owns one HIP device and one stream.
+ */
+#ifndef SCSSIM_HIP_H
+#define SCSSIM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SCS_OK          0
+#define SCS_EINVAL      1   /* bad argument / call order                         */
+#define SCS_EIO         2   /* file could not be opened / malformed (the reference exit(1)/exit(-1)s) */
+#define SCS_EDEVICE     3   /* HIP error, no device, out of memory               */
+#define SCS_EOVERFLOW   4   /* a fixed-size device work buffer overflowed (never silent) */
+
+typedef struct scs_ctx scs_ctx;
+
+/* Mirrors the reference's Config defaults (lib/config/Config.cpp:13-49) and the
+ * genreads options (src/scssim.cpp:285-404). */
+typedef struct scs_config {
+    int      device;            /* HIP device ordinal                                  */
+    void*    stream;            /* hipStream_t to run on, or NULL = ctx-owned stream   */
+    uint64_t seed;              /* counter-RNG seed (the reference seeds from time(): scssim.cpp:47) */
+    long     primers;           /* -p  [100000]                                        */
+    double   gamma;             /* -r  [1e-9]                                          */
+    double   coverage;          /* -c  [5]                                             */
+    int      isize;             /* -s  [260]                                           */
+    int      paired;            /* -l  PE=1 / SE=0 [1]                                 */
+    double   ber;               /* Config "ber" 3.4e-4                                 */
+    int      amplicon_min_len;  /* 1000                                                */
+    int      amplicon_max_len;  /* 2000                                                */
+    int      frag_size;         /* Config "fragSize" 1000 (weight denominator)         */
+    int      frag_min;          /* Fragment::minSize 10000 (lib/fragment/Fragment.cpp:15-16) */
+    int      frag_max;          /* Fragment::maxSize 100000                            */
+    int      shard_rank;        /* this process' shard (fragment-lineage sharding)     */
+    int      shard_count;       /* number of shards; 1 = whole job                     */
+    int      verbose;           /* progress lines on stderr as the reference prints    */
+} scs_config;
+
+typedef struct scs_stats {
+    uint64_t records, genome_bases, fragments, semi_amplicons, full_amplicons;
+    uint64_t primers_left;       /* Malbac::totalPrimers after amplify                 */
+    uint64_t reads_requested, pairs_written, reads_written;
+    uint64_t fastq_bytes[2];
+    uint64_t algorithmic_bytes;  /* 1526 B per created amplicon + per pair (isize + FASTQ bytes) */
+    double   t_stage[8];         /* seconds: load, frags, amplify, weights, allocate, yield, -, total */
+} scs_stats;
+
+void        scs_default_config(scs_config* cfg);
+int         scs_create(const scs_config* cfg, scs_ctx** out);
+void        scs_destroy(scs_ctx* ctx);
+/* message of the last failure on ctx (or of the last failed scs_create when ctx == NULL) */
+const char* scs_last_error(const scs_ctx* ctx);
+int         scs_set_seed(scs_ctx* ctx, uint64_t seed);
+
+/* Profile::train(file) = load + normParas(true) + initCDFs  (lib/profile/Profile.cpp:1432-1436).
+ * Parses the .profile text, builds the CDF tables in double exactly as the reference, converts
+ * every CDF entry to the exact uint32 draw threshold, uploads them.  Sets the read length. */
+int         scs_load_profile(scs_ctx* ctx, const char* profile_path);
+int         scs_read_length(const scs_ctx* ctx);
+
+/* Genome::loadData for genreads = Genome::loadRefSeq (lib/genome/Genome.cpp:18-25,176-195):
+ * simuvars-style FASTA (records <chr>_<hap>_<reflen>); ".gz" is inflated with `gzip -cd` as there. */
+int         scs_load_genome_fasta(scs_ctx* ctx, const char* fasta_path);
+/* Same, from memory: names[i] as they appear after '>' ; seqs[i] = lens[i] ASCII bases. */
+int         scs_upload_genome(scs_ctx* ctx, int n_records, const char* const* names,
+                              const char* const* seqs, const uint64_t* lens);
+
+/* Malbac::createFrags -> Genome::splitToFrags + Fragment::createSequence
+ * (lib/malbac/Malbac.cpp:143-145, lib/genome/Genome.cpp:753-782, lib/fragment/Fragment.cpp:40-50) */
+int         scs_create_frags(scs_ctx* ctx);
+
+/* Malbac::amplify (lib/malbac/Malbac.cpp:173-201): createPrimers, setPrimers, and the 1+5 cycles of
+ * Fragment::batchAmplify / Amplicon::batchAmplify pool jobs (Fragment.cpp:52-152, Amplicon.cpp:156-253).
+ * Amplicons stay resident in HBM. */
+int         scs_amplify(scs_ctx* ctx);
+
+/* Malbac::setReadCounts (Malbac.cpp:370-408) incl. Amplicon::getWeightedLength (Amplicon.cpp:396-400),
+ * Profile::getGCFactor (Profile.cpp:1503-1513) and randIndx_hp/batchSampling (MyDefine.cpp:191-272).
+ * reads == 0: derive it from the record names and coverage as Malbac::yieldReads does (Malbac.cpp:413-420). */
+int         scs_allocate_reads(scs_ctx* ctx, uint64_t reads);
+
+/* Sink = SeqWriter::write(char*) / write(char*,char*) (lib/seqwriter/SeqWriter.cpp:41-54).
+ * Called in output order with host buffers valid only during the call; fq2/n2 are NULL/0 for SE.
+ * Return non-zero to abort. */
+typedef int (*scs_sink_fn)(void* user, const char* fq1, size_t n1, const char* fq2, size_t n2);
+
+/* Malbac::yieldReads fan-out + Amplicon::yieldReads jobs (Malbac.cpp:436-457, Amplicon.cpp:402-565)
+ * with Profile::predict (Profile.cpp:1582-1697) per read.  FASTQ text is produced on the device
+ * and handed to `sink` batch by batch (sink may be NULL: generate and count only). */
+int         scs_yield_reads(scs_ctx* ctx, scs_sink_fn sink, void* user);
+
+/* Same, but the FASTQ pool stays in HBM in caller-owned device buffers (for the RCCL gather of the
+ * read pool).  Fails with SCS_EOVERFLOW if a capacity is too small; n1 / n2 receive the byte counts. */
+int         scs_yield_reads_device(scs_ctx* ctx, void* d_fq1, size_t cap1, void* d_fq2, size_t cap2,
+                                   uint64_t* n1, uint64_t* n2, uint64_t* pairs);
+
+/* createFrags + amplify + allocate + yield in one call (the body of main()'s genreads branch,
+ * src/scssim.cpp:59-65). */
+int         scs_run_genreads(scs_ctx* ctx, scs_sink_fn sink, void* user);
+
+int         scs_get_stats(const scs_ctx* ctx, scs_stats* out);
+
+/* ---- kernel-level entry points (unit parity tests; same kernels as the pipeline) ------------ */
+
+/* char* Profile::predict(char* refSeq, int isRead1)  (lib/profile/Profile.cpp:1582-1697) for a batch:
+ * windows = n_reads x L base codes (0..3 = ACGT, 4 = N) on the HOST; per read the lineage uid,
+ * the attempt number and the read-1 flag select the counter-RNG substream.  out_bases/out_quals:
+ * n_reads x out_stride chars; out_len[i] = produced length n'. */
+int         scs_predict_batch(scs_ctx* ctx, const uint8_t* windows, size_t n_reads,
+                              const uint64_t* uids, const uint32_t* attempts, const uint8_t* is_read1,
+                              char* out_bases, char* out_quals, int32_t* out_len, int out_stride);
+
+/* Philox4x32-10 on the device for n counters (ctr: n x 4, key: 2, out: n x 4; host pointers). */
+int         scs_philox_batch(scs_ctx* ctx, const uint32_t* ctr, size_t n, const uint32_t* key, uint32_t* out);
+/* det_log on the device (host pointers). */
+int         scs_detlog_batch(scs_ctx* ctx, const double* x, size_t n, double* out);
+
+/* Download the amplicon tables (kind 0 = semi, 1 = full) for stage-level parity tests.  Any pointer
+ * may be NULL.  Arrays must hold scs_stats.{semi,full}_amplicons entries; errs: up to 4 packed
+ * (pos<<3|alt) entries per amplicon in errs[4*i..], count in nerr[i] (>4 = overflow list truncated). */
+int         scs_download_amplicons(scs_ctx* ctx, int kind, uint32_t* parent, uint32_t* spos, uint32_t* len,
+                                   uint32_t* gc, uint32_t* primers, uint64_t* uid, uint32_t* errs, uint32_t* nerr);
+int         scs_download_read_numbers(scs_ctx* ctx, uint32_t* read_numbers);
+
+/* ---- host-only table access (no GPU needed): the thresholds scs_load_profile uploads -------------
+ * which: 0 subs read1 [84][bins][4], 1 subs read2, 2 quality [16][bins][94], 3 insert length,
+ *        4 deletion length, 5 insert size.  thr/cdf point into memory owned by the handle. */
+int         scs_profile_open(const char* profile_path, int paired, int isize, void** handle, char* errbuf, size_t errlen);
+int         scs_profile_table(void* handle, int which, const uint32_t** thr, const double** cdf, size_t* n);
+/* out[0..7] = read length, bins, t_insert, t_delete, isize_min, have_cdf2, insert_rate, del_rate */
+int         scs_profile_scalars(void* handle, double* out);
+void        scs_profile_close(void* handle);
+
+/* Timing of the dominant kernel (HIP events on the ctx stream, accumulated over the last
+ * scs_yield_reads / scs_amplify call): name, launches, total milliseconds. */
+int         scs_kernel_time(const scs_ctx* ctx, int which, const char** name, uint64_t* launches, double* ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SCSSIM_HIP_H */

@@ -1,0 +1,9 @@
+"""scssim_amd -- host-side mirror of the SCSsim `genreads` interface over the MI355X C ABI.
+
+The product is `libscssim_hip.so` (hand-written gfx950 kernels + C ABI, include/scssim_hip.h) and the
+`scssim` CLI.  This package is ctypes plumbing for tests, bench.py and torch.distributed drivers:
+method names follow the reference's call sequence (src/scssim.cpp:46-67: loadData, train(profile),
+createFrags, amplify, yieldReads).  There is no CPU fallback: importing works anywhere, creating a
+`GenReads` needs the built library and a GPU, and fails loudly otherwise.
+"""
+from .api import GenReads, ScsError, Profile, lib_path, load_library, build  # noqa: F401

@@ -1,0 +1,299 @@
+import ctypes as C
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def lib_path():
+    return os.path.join(HERE, "libscssim_hip.so")
+
+
+def build(verbose=False):
+    """Compile the HIP library and the CLI for gfx950 (hipcc cross-compiles without a GPU)."""
+    subprocess.check_call(["make", "-C", os.path.join(HERE, "csrc"), "-j4"] + ([] if verbose else ["-s"]))
+
+
+class ScsError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("scssim_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+class _Config(C.Structure):
+    _fields_ = [("device", C.c_int), ("stream", C.c_void_p), ("seed", C.c_uint64), ("primers", C.c_long),
+                ("gamma", C.c_double), ("coverage", C.c_double), ("isize", C.c_int), ("paired", C.c_int),
+                ("ber", C.c_double), ("amplicon_min_len", C.c_int), ("amplicon_max_len", C.c_int),
+                ("frag_size", C.c_int), ("frag_min", C.c_int), ("frag_max", C.c_int),
+                ("shard_rank", C.c_int), ("shard_count", C.c_int), ("verbose", C.c_int)]
+
+
+class _Stats(C.Structure):
+    _fields_ = [("records", C.c_uint64), ("genome_bases", C.c_uint64), ("fragments", C.c_uint64),
+                ("semi_amplicons", C.c_uint64), ("full_amplicons", C.c_uint64), ("primers_left", C.c_uint64),
+                ("reads_requested", C.c_uint64), ("pairs_written", C.c_uint64), ("reads_written", C.c_uint64),
+                ("fastq_bytes", C.c_uint64 * 2), ("algorithmic_bytes", C.c_uint64), ("t_stage", C.c_double * 8)]
+
+
+_SINK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t)
+_lib = None
+
+
+def load_library():
+    """dlopen the in-tree library; raises if it has not been built (no fallback path exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    p = lib_path()
+    if not os.path.exists(p):
+        raise ImportError("%s is missing: run scssim_amd.build() / make -C scssim_amd/csrc (no CPU fallback exists)" % p)
+    L = C.CDLL(p)
+    L.scs_last_error.restype = C.c_char_p
+    L.scs_last_error.argtypes = [C.c_void_p]
+    L.scs_create.argtypes = [C.POINTER(_Config), C.POINTER(C.c_void_p)]
+    L.scs_destroy.argtypes = [C.c_void_p]
+    L.scs_set_seed.argtypes = [C.c_void_p, C.c_uint64]
+    L.scs_load_profile.argtypes = [C.c_void_p, C.c_char_p]
+    L.scs_read_length.argtypes = [C.c_void_p]
+    L.scs_load_genome_fasta.argtypes = [C.c_void_p, C.c_char_p]
+    L.scs_upload_genome.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(C.c_uint64)]
+    for f in ("scs_create_frags", "scs_amplify"):
+        getattr(L, f).argtypes = [C.c_void_p]
+    L.scs_allocate_reads.argtypes = [C.c_void_p, C.c_uint64]
+    L.scs_yield_reads.argtypes = [C.c_void_p, _SINK, C.c_void_p]
+    L.scs_run_genreads.argtypes = [C.c_void_p, _SINK, C.c_void_p]
+    L.scs_yield_reads_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                         C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.scs_get_stats.argtypes = [C.c_void_p, C.POINTER(_Stats)]
+    L.scs_kernel_time.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
+    L.scs_predict_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    L.scs_philox_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    L.scs_detlog_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    L.scs_download_amplicons.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 8
+    L.scs_download_read_numbers.argtypes = [C.c_void_p, C.c_void_p]
+    L.scs_profile_open.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.c_char_p, C.c_size_t]
+    L.scs_profile_table.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.POINTER(C.c_double)), C.POINTER(C.c_size_t)]
+    L.scs_profile_scalars.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+    L.scs_profile_close.argtypes = [C.c_void_p]
+    _lib = L
+    return L
+
+
+class Profile:
+    """Host-only view of a .profile model: the exact uint32 thresholds and the double CDFs they come from
+    (mirrors Profile::train(file), reference lib/profile/Profile.cpp:1432-1436).  Needs no GPU."""
+
+    TABLES = {"subs1": 0, "subs2": 1, "qual": 2, "ins": 3, "del": 4, "isize": 5}
+
+    def __init__(self, path, paired=True, isize=260):
+        import numpy as np
+        self._np = np
+        L = load_library()
+        self._h = C.c_void_p()
+        err = C.create_string_buffer(512)
+        rc = L.scs_profile_open(os.fsencode(path), int(paired), int(isize), C.byref(self._h), err, 512)
+        if rc:
+            raise ScsError(rc, err.value.decode())
+        sc = (C.c_double * 8)()
+        L.scs_profile_scalars(self._h, sc)
+        (self.read_length, self.bins, self.t_insert, self.t_delete, self.isize_min, self.have_cdf2) = [int(v) for v in sc[:6]]
+        self.insert_rate, self.del_rate = sc[6], sc[7]
+
+    def table(self, name):
+        np = self._np
+        thr = C.POINTER(C.c_uint32)()
+        cdf = C.POINTER(C.c_double)()
+        n = C.c_size_t()
+        rc = load_library().scs_profile_table(self._h, self.TABLES[name], C.byref(thr), C.byref(cdf), C.byref(n))
+        if rc:
+            raise ScsError(rc, "bad table")
+        if n.value == 0:
+            return np.zeros(0, np.uint32), np.zeros(0, np.float64)
+        return (np.ctypeslib.as_array(thr, (n.value,)).copy(), np.ctypeslib.as_array(cdf, (n.value,)).copy())
+
+    def close(self):
+        if self._h:
+            load_library().scs_profile_close(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class GenReads:
+    """One `scssim genreads` job on one MI355X.  Mirrors the reference's driver (src/scssim.cpp:46-67)."""
+
+    def __init__(self, profile=None, input_fasta=None, primers=100000, gamma=1e-9, coverage=5.0, isize=260,
+                 layout="PE", seed=1, device=0, stream=None, shard_rank=0, shard_count=1, verbose=False):
+        import numpy as np
+        self._np = np
+        self._L = load_library()
+        cfg = _Config()
+        self._L.scs_default_config.argtypes = [C.POINTER(_Config)]
+        self._L.scs_default_config(C.byref(cfg))
+        cfg.device, cfg.stream, cfg.seed = device, stream, seed
+        cfg.primers, cfg.gamma, cfg.coverage, cfg.isize = primers, gamma, coverage, isize
+        if layout not in ("PE", "SE"):
+            raise ValueError("Error: sequence layout incorrectly specified!")
+        cfg.paired = 1 if layout == "PE" else 0
+        cfg.shard_rank, cfg.shard_count, cfg.verbose = shard_rank, shard_count, int(verbose)
+        self.paired = bool(cfg.paired)
+        self._ctx = C.c_void_p()
+        rc = self._L.scs_create(C.byref(cfg), C.byref(self._ctx))
+        if rc:
+            raise ScsError(rc, self._L.scs_last_error(None).decode())
+        if input_fasta is not None:
+            self.load_genome(input_fasta)
+        if profile is not None:
+            self.load_profile(profile)
+
+    # ---- plumbing
+    def _ck(self, rc):
+        if rc:
+            raise ScsError(rc, self._L.scs_last_error(self._ctx).decode())
+
+    def close(self):
+        if self._ctx:
+            self._L.scs_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- reference call sequence
+    def load_genome(self, path):            # Genome::loadData
+        self._ck(self._L.scs_load_genome_fasta(self._ctx, os.fsencode(path)))
+
+    def upload_genome(self, names, seqs):
+        n = len(names)
+        bn = [s.encode() if isinstance(s, str) else s for s in names]
+        bs = [s.encode() if isinstance(s, str) else bytes(s) for s in seqs]
+        self._ck(self._L.scs_upload_genome(self._ctx, n, (C.c_char_p * n)(*bn), (C.c_char_p * n)(*bs),
+                                           (C.c_uint64 * n)(*[len(s) for s in bs])))
+
+    def load_profile(self, path):           # Profile::train(file)
+        self._ck(self._L.scs_load_profile(self._ctx, os.fsencode(path)))
+
+    @property
+    def read_length(self):
+        return self._L.scs_read_length(self._ctx)
+
+    def set_seed(self, seed):
+        self._ck(self._L.scs_set_seed(self._ctx, seed))
+
+    def create_frags(self):                 # Malbac::createFrags
+        self._ck(self._L.scs_create_frags(self._ctx))
+
+    def amplify(self):                      # Malbac::amplify
+        self._ck(self._L.scs_amplify(self._ctx))
+
+    def allocate_reads(self, reads=0):      # Malbac::setReadCounts
+        self._ck(self._L.scs_allocate_reads(self._ctx, reads))
+
+    def yield_reads(self, collect=True):    # Malbac::yieldReads -> (fastq1, fastq2) bytes
+        parts1, parts2 = [], []
+
+        def sink(_u, p1, n1, p2, n2):
+            if collect:
+                parts1.append(C.string_at(p1, n1) if n1 else b"")
+                parts2.append(C.string_at(p2, n2) if n2 else b"")
+            return 0
+        cb = _SINK(sink)
+        self._ck(self._L.scs_yield_reads(self._ctx, cb, None))
+        return b"".join(parts1), b"".join(parts2)
+
+    def yield_reads_device(self, d_fq1, cap1, d_fq2, cap2):
+        """FASTQ pool stays in HBM: d_fq1/d_fq2 are device pointers (e.g. torch uint8 tensors' data_ptr())."""
+        n1, n2, pairs = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        self._ck(self._L.scs_yield_reads_device(self._ctx, d_fq1, cap1, d_fq2, cap2, C.byref(n1), C.byref(n2), C.byref(pairs)))
+        return n1.value, n2.value, pairs.value
+
+    def run(self, collect=True):
+        self.create_frags()
+        self.amplify()
+        self.allocate_reads(0)
+        return self.yield_reads(collect)
+
+    def run_to_files(self, prefix):
+        fq1, fq2 = self.run()
+        if self.paired:
+            open(prefix + "_1.fq", "wb").write(fq1)
+            open(prefix + "_2.fq", "wb").write(fq2)
+        else:
+            open(prefix + ".fq", "wb").write(fq1)
+
+    # ---- introspection
+    def stats(self):
+        st = _Stats()
+        self._ck(self._L.scs_get_stats(self._ctx, C.byref(st)))
+        d = {k: getattr(st, k) for k, _ in _Stats._fields_ if k not in ("fastq_bytes", "t_stage")}
+        d["fastq_bytes"] = list(st.fastq_bytes)
+        d["t_stage"] = list(st.t_stage)
+        return d
+
+    def kernel_times(self):
+        out = {}
+        for i in range(5):
+            name, n, ms = C.c_char_p(), C.c_uint64(), C.c_double()
+            self._ck(self._L.scs_kernel_time(self._ctx, i, C.byref(name), C.byref(n), C.byref(ms)))
+            out[name.value.decode()] = dict(launches=n.value, ms=ms.value)
+        return out
+
+    def download_amplicons(self, kind):
+        np = self._np
+        st = self.stats()
+        n = st["semi_amplicons"] if kind == 0 else st["full_amplicons"]
+        a = {k: np.zeros(n, np.uint32) for k in ("parent", "spos", "len", "gc", "primers")}
+        a["uid"] = np.zeros(n, np.uint64)
+        a["errs"] = np.zeros((n, 4), np.uint32)
+        a["nerr"] = np.zeros(n, np.uint32)
+        ptr = lambda x: x.ctypes.data_as(C.c_void_p)
+        self._ck(self._L.scs_download_amplicons(self._ctx, kind, ptr(a["parent"]), ptr(a["spos"]), ptr(a["len"]), ptr(a["gc"]),
+                                                ptr(a["primers"]), ptr(a["uid"]), ptr(a["errs"]), ptr(a["nerr"])))
+        return a
+
+    def download_read_numbers(self):
+        np = self._np
+        rn = np.zeros(self.stats()["full_amplicons"], np.uint32)
+        self._ck(self._L.scs_download_read_numbers(self._ctx, rn.ctypes.data_as(C.c_void_p)))
+        return rn
+
+    # ---- kernel-level entry points
+    def predict_batch(self, windows, uids, attempts, is_read1):
+        """Profile::predict for a batch of windows (n x L uint8 codes).  Returns (list of bases, list of quals)."""
+        np = self._np
+        w = np.ascontiguousarray(windows, np.uint8)
+        n, L = w.shape
+        assert L == self.read_length
+        stride = ((L + 64 + 63) // 64) * 64
+        u = np.ascontiguousarray(uids, np.uint64)
+        a = np.ascontiguousarray(attempts, np.uint32)
+        r = np.ascontiguousarray(is_read1, np.uint8)
+        ob = np.zeros((n, stride), np.uint8)
+        oq = np.zeros((n, stride), np.uint8)
+        ol = np.zeros(n, np.int32)
+        ptr = lambda x: x.ctypes.data_as(C.c_void_p)
+        self._ck(self._L.scs_predict_batch(self._ctx, ptr(w), n, ptr(u), ptr(a), ptr(r), ptr(ob), ptr(oq), ptr(ol), stride))
+        return [bytes(ob[i, :ol[i]]) for i in range(n)], [bytes(oq[i, :ol[i]]) for i in range(n)]
+
+    def philox(self, ctr, key):
+        np = self._np
+        c = np.ascontiguousarray(ctr, np.uint32).reshape(-1, 4)
+        k = np.ascontiguousarray(key, np.uint32)
+        out = np.zeros_like(c)
+        self._ck(self._L.scs_philox_batch(self._ctx, c.ctypes.data_as(C.c_void_p), c.shape[0], k.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def det_log(self, x):
+        np = self._np
+        x = np.ascontiguousarray(x, np.float64)
+        out = np.zeros_like(x)
+        self._ck(self._L.scs_detlog_batch(self._ctx, x.ctypes.data_as(C.c_void_p), x.size, out.ctypes.data_as(C.c_void_p)))
+        return out

@@ -1,0 +1,109 @@
+// scs_common.h -- definitions shared by host code and gfx950 kernels.
+//
+// Counter-RNG remapping (DESIGN.md "RNG remapping"): every random draw of the
+// reference's hot path is keyed by logical ids instead of being pulled from a
+// per-thread sequential stream (reference: lib/threadpool/ThreadPool.cpp:41-47,
+// 203-212).  One Philox4x32-10 block = 4 draws:
+//     counter = (idx, uid_lo, uid_hi, stage | aux << 8)     key = (seed_lo, seed_hi)
+// The stage list and the meaning of idx/aux/word per draw site are below.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define SCS_HD __host__ __device__ __forceinline__
+#else
+#define SCS_HD inline
+#endif
+
+namespace scs {
+
+enum Stage : uint32_t {
+    ST_FRAGSPLIT   = 1,   // uid = record index, idx = k-th fragment of the record, word 0     (Genome.cpp:760)
+    ST_POISSON     = 2,   // uid = template uid, aux = kind | call<<1, draw t -> idx t/4 word t%4 (MyDefine.cpp:69-80)
+    ST_ATTACH      = 3,   // uid = template uid, aux = kind | pass<<1, idx = primer<<6 | try, word0 spos, word1 length
+    ST_ERR         = 4,   // uid = NEW amplicon uid, aux = kind, base j -> idx j/4 word j%4     (Fragment.cpp:102-104)
+    ST_ERRALT      = 5,   // uid = NEW amplicon uid, aux = kind, idx = j | (a/4)<<16, word a%4  (Fragment.cpp:107-110)
+    ST_WEIGHT      = 6,   // uid = full uid, idx = attempt, words 0,1                           (Profile.cpp:1503-1513)
+    ST_ALLOC_TOP   = 7,   // uid = 0, idx = t, word 0                                           (MyDefine.cpp:242-245)
+    ST_ALLOC_CHUNK = 8,   // uid = chunk, idx = t, word 0                                       (MyDefine.cpp:191-201)
+    ST_PAIR        = 9,   // uid = full uid, idx = attempt, word0 insert size, word1 position   (Amplicon.cpp:483-491)
+    ST_INDEL       = 10,  // uid = full uid, aux = rd | attempt<<1, idx = j, word0 p1, word1 p2, word2 length
+    ST_INDEL_INS   = 11,  // same aux, idx = j | (t/4)<<16, word t%4 : t-th inserted base       (Profile.cpp:1560)
+    ST_BASE        = 12   // same aux, idx = out position j, word0 substitution, word1 quality, word2 random quality
+};
+
+SCS_HD uint32_t stage_word(uint32_t stage, uint32_t aux) { return stage | (aux << 8); }
+
+// lineage uids: order-free and shard-free
+SCS_HD uint64_t semi_uid(uint64_t frag, uint32_t pass, uint32_t i) { return (frag << 23) | ((uint64_t)pass << 20) | i; }
+SCS_HD uint64_t full_uid(uint64_t semi, uint32_t cyc, uint32_t i) { return (semi << 15) | ((uint64_t)cyc << 12) | i; }
+
+struct U4 { uint32_t w[4]; };
+
+SCS_HD uint32_t mulhi32(uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umulhi(a, b);
+#else
+    return (uint32_t)(((uint64_t)a * b) >> 32);
+#endif
+}
+
+// Philox4x32-10 (Salmon, Moraes, Dror, Shaw, SC'11)
+SCS_HD U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = mulhi32(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = mulhi32(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    U4 o; o.w[0] = c0; o.w[1] = c1; o.w[2] = c2; o.w[3] = c3;
+    return o;
+}
+
+struct RngKey { uint32_t k0, k1; };
+
+SCS_HD U4 draw4(RngKey key, uint32_t stage, uint32_t aux, uint64_t uid, uint32_t idx) {
+    return philox4x32_10(idx, (uint32_t)uid, (uint32_t)(uid >> 32), stage_word(stage, aux), key.k0, key.k1);
+}
+
+// randomInteger(s,e) / truncating randomDouble(s,e) of ThreadPool.cpp:203-212 for a 32-bit draw x:
+// trunc(s + (e-s) * x/2^32).  For (e-s) < 2^21 the double expression is exact, so this integer form
+// returns the same value as the reference's double arithmetic.
+SCS_HD uint32_t scale_draw(uint32_t x, uint32_t start, uint32_t span) {
+    return start + (uint32_t)(((uint64_t)span * x) >> 32);
+}
+
+// base codes: 0..3 = ACGT, 4 = N / anything else (MyDefine.cpp:352-367: complement of non-ACGT is 'N')
+SCS_HD uint8_t comp_code(uint8_t c) { return c < 4 ? (uint8_t)(3 - c) : (uint8_t)4; }
+SCS_HD bool is_gc(uint32_t c) { return c == 1 || c == 2; }
+
+// packed amplicon record (reference: Amplicon::data[8], lib/amplicon/Amplicon.cpp:47-154)
+//   pk0 = spos (17 bits) | len (11 bits) << 17          pk1 = gc (11 bits) | primers (12 bits) << 11
+SCS_HD uint32_t pack_sl(uint32_t spos, uint32_t len) { return spos | (len << 17); }
+SCS_HD uint32_t sl_spos(uint32_t p) { return p & 0x1FFFFu; }
+SCS_HD uint32_t sl_len(uint32_t p) { return p >> 17; }
+
+// amplification error entry (reference: AmpError, Amplicon.cpp:13-45): u16 = pos (11 bits) | alt (2 bits) << 11, 0 = empty
+// an amplicon keeps up to 4 inline in a uint64; bit 63 set = overflow: bits 0..31 pool offset, 32..47 count
+SCS_HD uint32_t err_pack(uint32_t pos, uint32_t alt) { return pos | (alt << 11); }
+SCS_HD uint32_t err_pos(uint32_t e) { return e & 0x7FFu; }
+SCS_HD uint32_t err_alt(uint32_t e) { return (e >> 11) & 3u; }
+static const uint64_t ERR_OVERFLOW_BIT = 1ull << 63;
+
+static const int NQ = 94;          // Phred chars 33..126 (Profile.cpp:172-173)
+static const int NKMER = 84;       // 4 + 16 + 64 (Profile.cpp:69-123)
+
+// k-mer row of the substitution table for the context (a, b, c); 5 = 'X' (before read start), 4 = N.
+// -1 = not in the table -> base kept (Profile.cpp:1523-1530)
+SCS_HD int kmer_index(uint32_t a, uint32_t b, uint32_t c) {
+    if (c > 3) return -1;
+    if (a == 5 && b == 5) return (int)c;
+    if (a == 5 && b < 4) return (int)(4 + b * 4 + c);
+    if (a < 4 && b < 4) return (int)(20 + a * 16 + b * 4 + c);
+    return -1;
+}
+
+}  // namespace scs

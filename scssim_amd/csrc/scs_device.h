@@ -1,0 +1,97 @@
+// scs_device.h -- device-side data layout (SoA in HBM) and kernel launch wrappers.
+#pragma once
+#include <stdint.h>
+#include <hip/hip_runtime.h>
+#include "scs_common.h"
+
+namespace scs {
+
+// ---- genome + fragments (reference: Fragment, lib/fragment/Fragment.h:20-31) ---------------------
+// The genome stays resident once, 1 byte per base (codes 0..3, 4 = N).  A fragment is an index map
+// into it, never a copy: template strand T_f[i] = strand>0 ? comp(G[goff+len-1-i]) : G[goff+i]
+// (Fragment::createSequence + the complement taken in Fragment::amplify, Fragment.cpp:40-50,65-68).
+struct DevFrags {
+    const uint64_t* goff;      // offset of the slice start in the genome array
+    const uint32_t* len;
+    const int8_t*   strand;    // +1 / -1
+    const uint32_t* primers;   // budget of the current pass (Fragment::primerNum)
+    uint32_t n;
+    uint64_t gidx_base;        // global index of local fragment 0 (sharding)
+};
+
+// ---- amplicons (reference: Amplicon + AmpliconNode list, lib/amplicon/Amplicon.h:47-76) -----------
+// Flat SoA, index = position in the reference's -t 1 list order.
+struct DevAmps {
+    uint32_t* parent;          // semis: local fragment index; fulls: semi index
+    uint32_t* sl;              // pack_sl(spos, len)
+    uint16_t* gc;
+    uint16_t* primers;         // semis: 12-bit budget of the current cycle (Amplicon.cpp:76-79)
+    uint64_t* uid;             // lineage uid (counter-RNG key)
+    uint64_t* errs;            // 4 inline u16 entries or overflow reference
+};
+
+struct DevErrPool { uint32_t* data; uint32_t* head; uint32_t cap; };
+
+// view of a template strand as an index map into the genome: T[i] = maybe_comp(G[base + dir*i])
+struct View { int64_t base; int32_t dir; uint32_t comp; };
+
+struct DevTables {
+    int L, bins;
+    uint32_t t_insert, t_delete, t_ber;
+    const uint32_t* subs1; const uint32_t* subs2;   // [84][bins][4] thresholds (uint4 rows)
+    const uint32_t* qual;                            // [16][bins][94]
+    const uint32_t* ins_t; int n_ins;
+    const uint32_t* del_t; int n_del;
+    const uint32_t* isize_t; int n_isize; int isize_min;
+    const double* subs1_d; const double* subs2_d; const double* qual_d;   // slow path (x == 0xFFFFFFFF)
+    const double* ins_d; const double* del_d; const double* isize_d;
+    const double* gc_means; double gc_std;
+};
+
+struct AmplifyParams {
+    RngKey key;
+    uint32_t pass;             // fragment pass 0..4 / semi cycle 0..4
+    uint32_t amp_min, amp_max; // 1000, 2000
+    uint32_t t_ber;
+};
+
+// error flags raised by kernels (never silent): bit 0 error-list cap, 1 error pool, 2 read slot, 3 other
+enum DevFlag : uint32_t { FLAG_ERRCAP = 1, FLAG_ERRPOOL = 2, FLAG_READSLOT = 4, FLAG_INTERNAL = 8 };
+
+struct PairRec { uint32_t amp; uint32_t att; uint32_t pos; uint32_t isz; };   // isz == 0: hole
+
+// ---- launch wrappers (scs_kernels.hip) --------------------------------------------------------------
+void launch_attach_frags(hipStream_t s, const uint8_t* g, DevFrags fr, const uint32_t* slot_off, uint32_t* slots,
+                         uint32_t* slot_tmpl, uint32_t* valid, const int64_t* primer_cnt, uint32_t* primer_delta, AmplifyParams p);
+void launch_attach_semis(hipStream_t s, const uint8_t* g, DevFrags fr, DevAmps semis, uint32_t n_semis, DevErrPool spool,
+                         const uint32_t* slot_off, uint32_t* slots, uint32_t* slot_tmpl, uint32_t* valid,
+                         const int64_t* primer_cnt, uint32_t* primer_delta, AmplifyParams p);
+void launch_errscan_frags(hipStream_t s, const uint8_t* g, DevFrags fr, uint32_t n_slots, const uint32_t* slot_off,
+                          const uint32_t* slots, const uint32_t* slot_tmpl, const uint32_t* valid_off,
+                          DevAmps out, uint32_t out_base, DevErrPool pool, uint32_t* flags, AmplifyParams p);
+void launch_errscan_semis(hipStream_t s, const uint8_t* g, DevFrags fr, DevAmps semis, uint32_t n_semis, DevErrPool spool,
+                          uint32_t n_slots, const uint32_t* slot_off, const uint32_t* slots, const uint32_t* slot_tmpl,
+                          const uint32_t* valid_off, DevAmps out, uint32_t out_base, DevErrPool pool, uint32_t* flags, AmplifyParams p);
+void launch_primer_update(hipStream_t s, int64_t* primer_cnt, uint32_t* primer_delta);
+void launch_weights(hipStream_t s, DevAmps fulls, uint32_t n, DevTables tb, RngKey key, uint32_t frag_size, double* w);
+void launch_plan_pairs(hipStream_t s, DevAmps fulls, uint32_t n_fulls, const uint32_t* read_numbers, const uint32_t* pair_off,
+                       DevTables tb, RngKey key, int paired, PairRec* pairs);
+// reads of pairs [p0, p0+np): slot layout [2*np][slot] bases / quals (SE: [np][slot])
+void launch_reads(hipStream_t s, const uint8_t* g, DevFrags fr, DevAmps semis, DevErrPool spool, DevAmps fulls, DevErrPool fpool,
+                  const PairRec* pairs, uint32_t np, uint32_t amp_index_base, DevTables tb, RngKey key, int paired, uint32_t slot,
+                  char* slot_b, char* slot_q, uint32_t* lens, uint32_t* sizes1, uint32_t* sizes2, uint32_t* flags);
+void launch_predict_windows(hipStream_t s, const uint8_t* windows, uint32_t n_reads, const uint64_t* uids, const uint32_t* atts,
+                            const uint8_t* is_read1, DevTables tb, RngKey key, uint32_t slot, char* slot_b, char* slot_q,
+                            uint32_t* lens, uint32_t* flags);
+void launch_format(hipStream_t s, const PairRec* pairs, uint32_t np, uint32_t amp_index_base, int paired, uint32_t slot,
+                   const char* slot_b, const char* slot_q, const uint32_t* lens, const uint64_t* off1, const uint64_t* off2,
+                   char* out1, char* out2);
+void launch_philox(hipStream_t s, const uint32_t* ctr, uint32_t n, RngKey key, uint32_t* out);
+void launch_detlog(hipStream_t s, const double* x, uint32_t n, double* out);
+
+// device-wide exclusive scans (n inputs -> n+1 outputs, last = total)
+size_t scan_temp_bytes(size_t n);
+void exclusive_scan_u32(hipStream_t s, const uint32_t* in, uint32_t* out, size_t n, void* temp, size_t temp_bytes);
+void exclusive_scan_u32_to_u64(hipStream_t s, const uint32_t* in, uint64_t* out, size_t n, void* temp, size_t temp_bytes);
+
+}  // namespace scs

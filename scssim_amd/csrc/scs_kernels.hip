@@ -1,0 +1,674 @@
+// scs_kernels.hip -- gfx950 (CDNA4, wave64) kernels of the genreads hot path.
+// Integer / byte work bounded by HBM and the per-lane Philox rate; no MFMA by design.
+// Built with -ffp-contract=off: the few fp64 expressions must round exactly like the CPU oracle.
+#include "scs_device.h"
+
+#include <cstring>
+#include <rocprim/rocprim.hpp>
+
+namespace scs {
+
+#define WAVE 64
+
+// ------------------------------------------------------------------------------------------------
+// wave helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) { uint32_t t = __shfl_up(v, d); if (lane >= d) v += t; }
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
+    return v;
+}
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// views (reference Amplicon::getSequence, lib/amplicon/Amplicon.cpp:255-382)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ View frag_view(uint64_t goff, uint32_t len, int strand) {
+    View v;
+    if (strand > 0) { v.base = (int64_t)goff + len - 1; v.dir = -1; v.comp = 1; }
+    else { v.base = (int64_t)goff; v.dir = 1; v.comp = 0; }
+    return v;
+}
+// template strand c(S) of a semi amplicon (s, l) made on a template with view fv
+__device__ __forceinline__ View semi_tmpl_view(View fv, uint32_t s, uint32_t l) {
+    View v; v.base = fv.base + (int64_t)fv.dir * (int64_t)(s + l - 1); v.dir = -fv.dir; v.comp = fv.comp ^ 1u; return v;
+}
+__device__ __forceinline__ View shift_view(View v, uint32_t s) { v.base += (int64_t)v.dir * (int64_t)s; return v; }
+__device__ __forceinline__ uint32_t view_base(const uint8_t* __restrict__ g, View v, uint32_t i) {
+    uint32_t c = g[v.base + (int64_t)v.dir * (int64_t)i];
+    return v.comp ? (uint32_t)comp_code((uint8_t)c) : c;
+}
+
+// iterate the error entries of an amplicon (inline u16 x4, or overflow list)
+template <class F>
+__device__ __forceinline__ void for_each_err(uint64_t e, const uint32_t* __restrict__ pool, F f) {
+    if (e == 0) return;
+    if (e & ERR_OVERFLOW_BIT) {
+        const uint32_t off = (uint32_t)e, cnt = (uint32_t)(e >> 32) & 0xFFFFu;
+        for (uint32_t i = 0; i < cnt; ++i) f(pool[off + i]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { uint32_t v = (uint32_t)(e >> (16 * k)) & 0xFFFFu; if (v) f(v); }
+    }
+}
+
+// base t of the template strand c(S) of a semi: view + the semi's own substitutions
+//   S'[j] = alt  =>  c(S)[l-1-j] = comp(alt)
+__device__ __forceinline__ uint32_t semi_tmpl_base(const uint8_t* __restrict__ g, View stv, uint32_t l, uint64_t errs,
+                                                   const uint32_t* __restrict__ pool, uint32_t t) {
+    uint32_t c = view_base(g, stv, t);
+    for_each_err(errs, pool, [&](uint32_t e) { if (l - 1 - err_pos(e) == t) c = 3u - err_alt(e); });
+    return c;
+}
+
+// ------------------------------------------------------------------------------------------------
+// table lookups: randIndx(cdf, ac) (lib/mydefine/MyDefine.cpp:274-282) on integer thresholds
+// ------------------------------------------------------------------------------------------------
+__device__ __noinline__ uint32_t rand_indx_slow(const double* __restrict__ cdf, uint32_t ac, uint32_t x) {
+    const double r = 2.2204e-16 + (1 - 2.2204e-16) * ((double)x / 4294967296.0);
+    for (uint32_t k = 0; k < ac; ++k) if (r <= cdf[k]) return k;
+    return ac - 1;
+}
+// first k with x < T[k], else ac-1 (T non-decreasing)
+__device__ __forceinline__ uint32_t rand_indx_thr(const uint32_t* __restrict__ T, const double* __restrict__ cdf, uint32_t ac, uint32_t x) {
+    if (x == 0xFFFFFFFFu) return rand_indx_slow(cdf, ac, x);
+    uint32_t lo = 0, hi = ac;                 // lower bound of "x < T[k]"
+    while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (x < T[mid]) hi = mid; else lo = mid + 1; }
+    return lo < ac ? lo : ac - 1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1a  attach: one thread per template runs the reference's sequential primer loop
+//      (Fragment::amplify lib/fragment/Fragment.cpp:73-95, Amplicon::amplify Amplicon.cpp:176-198)
+// ------------------------------------------------------------------------------------------------
+template <bool FROM_FRAG>
+__global__ void __launch_bounds__(64) k_attach(const uint8_t* __restrict__ g, DevFrags fr, DevAmps semis, uint32_t n_semis,
+                                               DevErrPool spool, const uint32_t* __restrict__ slot_off, uint32_t* __restrict__ slots,
+                                               uint32_t* __restrict__ slot_tmpl, uint32_t* __restrict__ valid,
+                                               const int64_t* __restrict__ primer_cnt, uint32_t* __restrict__ primer_delta, AmplifyParams p) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t nt = FROM_FRAG ? fr.n : n_semis;
+    if (t >= nt) return;
+    uint32_t len, budget; uint64_t tuid, errs = 0; View tv;
+    if (FROM_FRAG) {
+        len = fr.len[t]; budget = fr.primers[t]; tuid = fr.gidx_base + t;
+        tv = frag_view(fr.goff[t], len, fr.strand[t]);
+    } else {
+        const uint32_t f = semis.parent[t], sl = semis.sl[t];
+        len = sl_len(sl); budget = semis.primers[t]; tuid = semis.uid[t]; errs = semis.errs[t];
+        tv = semi_tmpl_view(frag_view(fr.goff[f], fr.len[f], fr.strand[f]), sl_spos(sl), len);
+    }
+    uint32_t v = 0;
+    if (len >= p.amp_min + 27 && budget > 0) {
+        const uint32_t base_slot = slot_off[t];
+        const uint32_t aux = (FROM_FRAG ? 0u : 1u) | (p.pass << 1);
+        for (uint32_t i = 0; i < budget; ++i) {
+            uint32_t tries = 0, spos = 0, alen = 0;
+            for (;;) {
+                const U4 d = draw4(p.key, ST_ATTACH, aux, tuid, (i << 6) | tries);
+                spos = scale_draw(d.w[0], 27, len - 27);                         // randomInteger(27, length)
+                alen = scale_draw(d.w[1], p.amp_min, p.amp_max + 1 - p.amp_min);  // (uint) randomDouble(minLen, maxLen+1)
+                ++tries;
+                if (tries > 50) break;
+                if (spos + alen > len) continue;
+                bool taken = false;                                              // posAttached[spos]
+                for (uint32_t q = 0; q < v; ++q) if (sl_spos(slots[base_slot + q]) == spos) { taken = true; break; }
+                if (taken) continue;
+                uint32_t idx = 0; bool hasN = false;                             // primer 8-mer of the template strand
+                for (uint32_t k = 0; k < 8; ++k) {
+                    const uint32_t c = FROM_FRAG ? view_base(g, tv, spos + k) : semi_tmpl_base(g, tv, len, errs, spool.data, spos + k);
+                    hasN |= c > 3; idx = (idx << 2) | (c & 3u);
+                }
+                if (hasN) continue;                                              // no stock for N-containing 8-mers
+                if (primer_cnt[idx] <= 0) continue;                              // [REMAP] stock as of pass start
+                atomicAdd(&primer_delta[idx], 1u);
+                break;
+            }
+            if (tries > 50) break;                                               // abandons the remaining primers
+            slots[base_slot + v] = pack_sl(spos, alen);
+            slot_tmpl[base_slot + v] = t;
+            ++v;
+        }
+    }
+    valid[t] = v;
+}
+
+__global__ void k_primer_update(int64_t* __restrict__ cnt, uint32_t* __restrict__ delta) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 65536) return;
+    int64_t c = cnt[i] - (int64_t)delta[i];
+    cnt[i] = c < 0 ? 0 : c;                                                      // [REMAP] clamp at pass end
+    delta[i] = 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1b  errscan: one wave per new amplicon -- GC count of the window, Bernoulli(ber) per base,
+//      alt-base draws, packed record written at its final (reference -t 1 list) position.
+//      (Fragment.cpp:97-133, Amplicon.cpp:200-236)
+// ------------------------------------------------------------------------------------------------
+#define ERR_CAP 48
+template <bool FROM_FRAG>
+__global__ void __launch_bounds__(256) k_errscan(const uint8_t* __restrict__ g, DevFrags fr, DevAmps semis, DevErrPool spool,
+                                                 uint32_t n_slots, const uint32_t* __restrict__ slot_off, const uint32_t* __restrict__ slots,
+                                                 const uint32_t* __restrict__ slot_tmpl, const uint32_t* __restrict__ valid_off, uint32_t n_tmpl,
+                                                 DevAmps out, uint32_t out_base, DevErrPool pool, uint32_t* __restrict__ flags, AmplifyParams p) {
+    __shared__ uint16_t s_err[4][ERR_CAP];
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    const uint32_t w = blockIdx.x * 4 + wib;
+    if (w >= n_slots) return;
+    const uint32_t t = slot_tmpl[w];
+    if (t == 0xFFFFFFFFu) return;                      // reserved but unused slot (aborted template)
+    const uint32_t i = w - slot_off[t];
+    const uint32_t n_fwd = valid_off[t] + i, n_new = valid_off[n_tmpl];
+    const uint32_t sl = slots[w], spos = sl_spos(sl), alen = sl_len(sl);
+    View tv; uint64_t perrs = 0, nuid; uint32_t plen = 0;
+    if (FROM_FRAG) {
+        tv = shift_view(frag_view(fr.goff[t], fr.len[t], fr.strand[t]), spos);
+        nuid = semi_uid(fr.gidx_base + t, p.pass, i);
+    } else {
+        const uint32_t f = semis.parent[t], psl = semis.sl[t];
+        plen = sl_len(psl); perrs = semis.errs[t];
+        tv = shift_view(semi_tmpl_view(frag_view(fr.goff[f], fr.len[f], fr.strand[f]), sl_spos(psl), plen), spos);
+        nuid = full_uid(semis.uid[t], p.pass, i);
+    }
+    const uint32_t kind = FROM_FRAG ? 0u : 1u;
+    int gc = 0, delta = 0; uint32_t hasN = 0, nerr = 0;
+    const uint32_t nblk = (alen + 3) >> 2;
+    for (uint32_t b0 = 0; b0 < nblk; b0 += WAVE) {
+        const uint32_t b = b0 + lane;
+        uint32_t c[4] = {4, 4, 4, 4}; uint32_t emask = 0;
+        if (b < nblk) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t j = 4 * b + k;
+                if (j < alen) {
+                    uint32_t cc = view_base(g, tv, j);
+                    if (!FROM_FRAG) for_each_err(perrs, spool.data, [&](uint32_t e) { if (plen - 1 - err_pos(e) == spos + j) cc = 3u - err_alt(e); });
+                    c[k] = cc; gc += is_gc(cc) ? 1 : 0; hasN |= cc > 3;
+                }
+            }
+            if (b >= 2) {                                                          // j starts at 8
+                const U4 d = draw4(p.key, ST_ERR, kind, nuid, b);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) if (4 * b + k < alen && d.w[k] < p.t_ber) emask |= 1u << k;
+            }
+        }
+        if (__ballot(emask != 0)) {                                               // rare: some lane drew an error
+            const uint32_t cnt = __popc(emask);
+            const uint32_t excl = wave_incl_scan(cnt, lane) - cnt;
+            uint32_t slot = nerr + excl;
+            for (int k = 0; k < 4; ++k) if (emask & (1u << k)) {
+                const uint32_t j = 4 * b + k, base = c[k];
+                uint32_t alt, a = 0;
+                do {                                                               // do { n = rand } while (bases[n] == base)
+                    const U4 e = draw4(p.key, ST_ERRALT, kind, nuid, j | ((a >> 2) << 16));
+                    alt = e.w[a & 3] >> 30; ++a;                                   // trunc(4 * x / 2^32)
+                } while (alt == base);
+                delta += (is_gc(alt) ? 1 : 0) - (is_gc(base) ? 1 : 0);
+                if (slot < ERR_CAP) s_err[wib][slot] = (uint16_t)err_pack(j, alt);
+                ++slot;
+            }
+            nerr += wave_sum(cnt);
+        }
+    }
+    gc = wave_sum_i(gc); delta = wave_sum_i(delta);
+    hasN = __ballot(hasN != 0) != 0;
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+        int gcn = (hasN ? 0 : gc) + delta; if (gcn < 0) gcn = 0;                  // countGC: 0 if any N; max(0, gcNum)
+        uint64_t packed = 0;
+        if (nerr > ERR_CAP) { atomicOr(flags, (uint32_t)FLAG_ERRCAP); nerr = ERR_CAP; }
+        if (nerr <= 4) { for (uint32_t k = 0; k < nerr; ++k) packed |= (uint64_t)s_err[wib][k] << (16 * k); }
+        else {
+            const uint32_t off = atomicAdd(pool.head, nerr);
+            if (off + nerr > pool.cap) { atomicOr(flags, (uint32_t)FLAG_ERRPOOL); }
+            else { for (uint32_t k = 0; k < nerr; ++k) pool.data[off + k] = s_err[wib][k]; packed = ERR_OVERFLOW_BIT | ((uint64_t)nerr << 32) | off; }
+        }
+        const uint32_t dst = out_base + (n_new - 1 - n_fwd);                      // reversed within the pass: insertLinkList prepends
+        out.parent[dst] = t; out.sl[dst] = pack_sl(spos, alen); out.gc[dst] = (uint16_t)gcn; out.primers[dst] = 0;
+        out.uid[dst] = nuid; out.errs[dst] = packed;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// deterministic log (same operation sequence as oracle/scs_oracle.cpp det_log; IEEE + - * / only)
+// ------------------------------------------------------------------------------------------------
+__device__ double det_log(double x) {
+    const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
+    const double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01,
+                 Lg4 = 2.222219843214978396e-01, Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+                 Lg7 = 1.479819860511658591e-01;
+    if (x != x) return x;
+    if (x < 0) return __longlong_as_double(0x7ff8000000000000LL);
+    if (x == 0) return __longlong_as_double(0xfff0000000000000LL);
+    unsigned long long b = (unsigned long long)__double_as_longlong(x);
+    int k = 0;
+    if ((b >> 52) == 0) { x *= 18014398509481984.0; b = (unsigned long long)__double_as_longlong(x); k = -54; }
+    if ((b >> 52) == 0x7ff) return x;
+    k += (int)(b >> 52) - 1023;
+    b = (b & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL;
+    double m = __longlong_as_double((long long)b);
+    if (m >= 1.4142135623730951) { m = m * 0.5; k += 1; }
+    const double f = m - 1.0;
+    const double s = f / (2.0 + f);
+    const double z = s * s, w = z * z;
+    const double t1 = w * (Lg2 + w * (Lg4 + w * Lg6));
+    const double t2 = z * (Lg1 + w * (Lg3 + w * (Lg5 + w * Lg7)));
+    const double R = t2 + t1;
+    const double hfsq = 0.5 * f * f;
+    const double dk = (double)k;
+    return dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
+}
+
+// K2  weights: Amplicon::getWeightedLength (Amplicon.cpp:396-400) x Profile::getGCFactor (Profile.cpp:1503-1513)
+__global__ void k_weights(DevAmps fulls, uint32_t n, DevTables tb, RngKey key, uint32_t frag_size, double* __restrict__ w) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t len = sl_len(fulls.sl[i]);
+    const uint32_t gcp = 100u * fulls.gc[i] / len;
+    const uint64_t uid = fulls.uid[i];
+    double v = 0;
+    if (gcp <= 100) {
+        const double mean = tb.gc_means[gcp], sd = tb.gc_std;
+        for (uint32_t a = 0;; ++a) {                                              // [REMAP] Marsaglia polar, keyed
+            const U4 d = draw4(key, ST_WEIGHT, 0, uid, a);
+            const double x = 2.0 * (((double)d.w[0] + 0.5) / 4294967296.0) - 1.0;
+            const double y = 2.0 * (((double)d.w[1] + 0.5) / 4294967296.0) - 1.0;
+            const double r2 = x * x + y * y;
+            if (r2 > 1.0 || r2 == 0.0) continue;
+            const double mult = __dsqrt_rn(-2.0 * det_log(r2) / r2);
+            v = mean + sd * (y * mult);
+            if (v < 0) continue;
+            break;
+        }
+    }
+    w[i] = v * (double)len / (double)(frag_size * frag_size);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4a  plan pairs: one thread per full amplicon runs the attempt loop of Amplicon::yieldReads
+//      (Amplicon.cpp:448-491): insert size, rejection, position.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_plan_pairs(DevAmps fulls, uint32_t n_fulls, const uint32_t* __restrict__ read_numbers,
+                             const uint32_t* __restrict__ pair_off, DevTables tb, RngKey key, int paired, PairRec* __restrict__ pairs) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_fulls) return;
+    int n = (int)read_numbers[i];
+    if (n == 0) return;
+    const uint32_t want = pair_off[i + 1] - pair_off[i];
+    PairRec* dst = pairs + pair_off[i];
+    const uint32_t amp_len = sl_len(fulls.sl[i]);
+    const uint64_t uid = fulls.uid[i];
+    const uint32_t L = (uint32_t)tb.L;
+    uint32_t made = 0;
+    if (amp_len >= L) {
+        uint32_t att = 0, fails = 0;
+        while (n > 0 && made < want) {
+            const U4 d = draw4(key, ST_PAIR, 0, uid, att);
+            if (!paired) {
+                PairRec r; r.amp = i; r.att = att; r.pos = scale_draw(d.w[1], 0, amp_len - L + 1); r.isz = L;
+                dst[made++] = r; ++att; --n; continue;
+            }
+            const uint32_t isz = (uint32_t)tb.isize_min + rand_indx_thr(tb.isize_t, tb.isize_d, (uint32_t)tb.n_isize, d.w[0]);
+            if (isz < L || isz > amp_len) { ++att; if (++fails > 1000) break; continue; }
+            PairRec r; r.amp = i; r.att = att; r.pos = scale_draw(d.w[1], 0, amp_len - isz + 1); r.isz = isz;
+            dst[made++] = r; ++att; n -= 2;
+        }
+    }
+    for (uint32_t q = made; q < want; ++q) { PairRec r; r.amp = i; r.att = 0; r.pos = 0; r.isz = 0; dst[q] = r; }   // holes
+}
+
+// ------------------------------------------------------------------------------------------------
+// K5  inject_errors = Profile::predict (lib/profile/Profile.cpp:1582-1697), one wave per read.
+//     lanes = bases; indel events drawn per input base, deletion spans resolved in order, wave
+//     prefix sum gives the output offsets, then k-mer-conditioned substitution + quality per
+//     output base.  MAXCH chunks of 64 lanes cover reads up to 256 bases.
+// ------------------------------------------------------------------------------------------------
+#define MAXCH 4
+#define SRC_CAP 512
+
+struct ReadJob { uint64_t uid; uint32_t att; uint32_t rd; };   // rd: 0 = read 1, 1 = read 2
+
+__device__ __forceinline__ void predict_wave(const uint8_t* s_win, uint8_t* s_src, int lane, ReadJob job, const DevTables& tb, RngKey key,
+                                             uint32_t slot, char* __restrict__ out_b, char* __restrict__ out_q,
+                                             uint32_t* __restrict__ out_len, uint32_t* __restrict__ flags) {
+    const int n = tb.L;
+    const uint32_t aux = job.rd | (job.att << 1);
+    const int nch = (n + WAVE - 1) / WAVE;
+    // ---- indel events per input base (getIndelSeq, Profile.cpp:1552-1570)
+    uint32_t ev[MAXCH], evk[MAXCH];               // 0 none, 1 insertion, 2 deletion ; length
+    bool any = false;
+#pragma unroll
+    for (int c = 0; c < MAXCH; ++c) {
+        ev[c] = 0; evk[c] = 0;
+        const int j = c * WAVE + lane;
+        if (c < nch && j < n) {
+            const U4 d = draw4(key, ST_INDEL, aux, job.uid, (uint32_t)j);
+            if (d.w[0] < tb.t_insert) {                                            // p <= insertRate
+                const uint32_t k = rand_indx_thr(tb.ins_t, tb.ins_d, (uint32_t)tb.n_ins, d.w[2]);
+                if (k > 0) { ev[c] = 1; evk[c] = k; }
+            } else if (d.w[1] < tb.t_delete) {                                     // p < delRate/(1-insertRate)
+                const uint32_t k = rand_indx_thr(tb.del_t, tb.del_d, (uint32_t)tb.n_del, d.w[2]);
+                if (k > 0) { ev[c] = 2; evk[c] = k; }
+            }
+            any |= ev[c] != 0;
+        }
+    }
+    int n_out = n;
+    uint32_t off[MAXCH];
+    const bool anyw = __ballot(any) != 0;
+    if (anyw) {
+        // ---- visit order: a deletion of length k at j skips j+1..j+k-1 (Profile.cpp:1606-1622)
+        int until = 0;
+#pragma unroll
+        for (int c = 0; c < MAXCH; ++c) {
+            if (c >= nch) break;
+            unsigned long long m = __ballot(ev[c] != 0);
+            bool dead = false;
+            while (m) {
+                const int l = __ffsll((long long)m) - 1; m &= m - 1;
+                const int j = c * WAVE + l;
+                const uint32_t e = __shfl(ev[c], l), k = __shfl(evk[c], l);
+                if (j < until) { if (lane == l) dead = true; continue; }             // inside an earlier deletion: never visited
+                if (e == 2) { int kk = (int)k < n - j ? (int)k : n - j; until = j + kk; if (lane == l) evk[c] = (uint32_t)kk; }
+            }
+            if (dead) { ev[c] = 0; evk[c] = 0; }
+        }
+        // a lane is deleted if it lies in a live deletion span; recompute by a second ordered sweep
+        uint32_t olen[MAXCH];
+#pragma unroll
+        for (int c = 0; c < MAXCH; ++c) olen[c] = (c < nch && c * WAVE + lane < n) ? 1u : 0u;
+#pragma unroll
+        for (int c = 0; c < MAXCH; ++c) {
+            if (c >= nch) break;
+            unsigned long long m = __ballot(ev[c] == 2);
+            while (m) {
+                const int l = __ffsll((long long)m) - 1; m &= m - 1;
+                const int js = c * WAVE + l, je = js + (int)__shfl(evk[c], l);
+#pragma unroll
+                for (int c2 = 0; c2 < MAXCH; ++c2) { const int j2 = c2 * WAVE + lane; if (j2 >= js && j2 < je) olen[c2] = 0; }
+            }
+        }
+        int delta = 0;
+#pragma unroll
+        for (int c = 0; c < MAXCH; ++c) {
+            if (ev[c] == 1) { olen[c] += evk[c]; delta += (int)evk[c]; }
+            if (ev[c] == 2) delta -= (int)evk[c];
+        }
+        delta = wave_sum_i(delta);
+        if (n + delta < 50) {                                                       // Profile.cpp:1623-1630: drop all indels
+#pragma unroll
+            for (int c = 0; c < MAXCH; ++c) { ev[c] = 0; evk[c] = 0; olen[c] = (c < nch && c * WAVE + lane < n) ? 1u : 0u; }
+            delta = 0;
+        }
+        n_out = n + delta;
+        // ---- wavefront prefix sum of the per-base output lengths -> offsets in the source sequence
+        uint32_t carry = 0;
+#pragma unroll
+        for (int c = 0; c < MAXCH; ++c) {
+            const uint32_t inc = wave_incl_scan(olen[c], lane);
+            off[c] = carry + inc - olen[c];
+            carry += __shfl(inc, WAVE - 1);
+        }
+        if (n_out > (int)slot || n_out > SRC_CAP) { if (lane == 0) atomicOr(flags, (uint32_t)FLAG_READSLOT); n_out = 0; }
+        else {
+#pragma unroll
+            for (int c = 0; c < MAXCH; ++c) {
+                const int j = c * WAVE + lane;
+                if (c < nch && j < n && olen[c] > 0) {
+                    s_src[off[c]] = s_win[j];
+                    if (ev[c] == 1) for (uint32_t t = 0; t < evk[c]; ++t) {           // inserted bases: randomInteger(0, N-1) -> never 'T'
+                        const U4 d = draw4(key, ST_INDEL_INS, aux, job.uid, (uint32_t)j | ((t >> 2) << 16));
+                        s_src[off[c] + 1 + t] = (uint8_t)scale_draw(d.w[t & 3], 0, 3);
+                    }
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < MAXCH; ++c) { const int j = c * WAVE + lane; if (c < nch && j < n) s_src[j] = s_win[j]; }
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    // ---- per output base: substitution conditioned on the 3-mer ending here, then quality (Profile.cpp:1666-1694)
+    const uint32_t* __restrict__ subs = (job.rd == 0 || tb.subs2 == nullptr) ? tb.subs1 : tb.subs2;
+    const double* __restrict__ subs_d = (job.rd == 0 || tb.subs2 == nullptr) ? tb.subs1_d : tb.subs2_d;
+    const int B = tb.bins;
+    for (int j = lane; j < n_out; j += WAVE) {
+        const uint32_t c2 = s_src[j], c1 = j >= 1 ? s_src[j - 1] : 5u, c0 = j >= 2 ? s_src[j - 2] : 5u;
+        const int bin = j * B / n_out;
+        const int ki = kmer_index(c0, c1, c2);
+        const U4 d = draw4(key, ST_BASE, aux, job.uid, (uint32_t)j);
+        int k;
+        if (ki < 0) k = c2 < 4 ? (int)c2 : -1;
+        else {
+            const size_t row = ((size_t)ki * B + bin) * 4;
+            const uint32_t x = d.w[0];
+            if (x == 0xFFFFFFFFu) k = (int)rand_indx_slow(subs_d + row, 4, x);
+            else { const uint4 T = *reinterpret_cast<const uint4*>(subs + row); k = (x >= T.x) + (x >= T.y) + (x >= T.z); }
+        }
+        char bc, qc;
+        if (k < 0) { bc = 'N'; qc = (char)(33 + scale_draw(d.w[2], 0, 20)); }       // getRandBaseQuality
+        else {
+            bc = "ACGT"[k];
+            const size_t row = ((size_t)(c2 * 4 + (uint32_t)k) * B + bin) * NQ;
+            qc = (char)(33 + rand_indx_thr(tb.qual + row, tb.qual_d + row, NQ, d.w[1]));
+        }
+        out_b[j] = bc; out_q[j] = qc;
+    }
+    if (lane == 0) *out_len = (uint32_t)n_out;
+}
+
+__device__ __forceinline__ uint32_t dec_digits(uint32_t v) {
+    return v < 10u ? 1u : v < 100u ? 2u : v < 1000u ? 3u : v < 10000u ? 4u : v < 100000u ? 5u : v < 1000000u ? 6u :
+           v < 10000000u ? 7u : v < 100000000u ? 8u : v < 1000000000u ? 9u : 10u;
+}
+
+// K4b+K5: window extraction through the index maps (no amplicon is ever materialised) + predict
+__global__ void __launch_bounds__(256) k_reads(const uint8_t* __restrict__ g, DevFrags fr, DevAmps semis, DevErrPool spool, DevAmps fulls,
+                                               DevErrPool fpool, const PairRec* __restrict__ pairs, uint32_t np, uint32_t amp_index_base,
+                                               DevTables tb, RngKey key, int paired, uint32_t slot, char* __restrict__ slot_b,
+                                               char* __restrict__ slot_q, uint32_t* __restrict__ lens, uint32_t* __restrict__ sizes1,
+                                               uint32_t* __restrict__ sizes2, uint32_t* __restrict__ flags) {
+    __shared__ uint8_t s_win[4][256];
+    __shared__ uint8_t s_src[4][SRC_CAP];
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    const uint32_t nreads = paired ? 2 * np : np;
+    const uint32_t nwaves = gridDim.x * 4;
+    for (uint32_t r = blockIdx.x * 4 + wib; r < nreads; r += nwaves) {
+        const uint32_t pi = paired ? r >> 1 : r, rd = paired ? (r & 1u) : 0u;
+        const PairRec pr = pairs[pi];
+        uint32_t* sz = rd ? sizes2 : sizes1;
+        if (pr.isz == 0) { if (lane == 0) { lens[r] = 0; sz[pi] = 0; } continue; }
+        const uint32_t a = pr.amp;
+        const uint32_t fsl = fulls.sl[a], s2 = sl_spos(fsl);
+        const uint32_t sm = fulls.parent[a];
+        const uint32_t ssl = semis.sl[sm], s1 = sl_spos(ssl), l1 = sl_len(ssl);
+        const uint32_t f = semis.parent[sm];
+        const uint64_t e1 = semis.errs[sm], e2 = fulls.errs[a];
+        const View uv = shift_view(semi_tmpl_view(frag_view(fr.goff[f], fr.len[f], fr.strand[f]), s1, l1), s2);
+        const int L = tb.L;
+        for (int k = lane; k < L; k += WAVE) {
+            const uint32_t t = rd ? pr.pos + pr.isz - 1 - (uint32_t)k : pr.pos + (uint32_t)k;   // read 2 = revcomp of the far end
+            uint32_t c = view_base(g, uv, t);
+            for_each_err(e1, spool.data, [&](uint32_t e) { if (l1 - 1 - err_pos(e) == s2 + t) c = 3u - err_alt(e); });
+            for_each_err(e2, fpool.data, [&](uint32_t e) { if (err_pos(e) == t) c = err_alt(e); });
+            s_win[wib][k] = (uint8_t)(rd ? comp_code((uint8_t)c) : c);
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        ReadJob job; job.uid = fulls.uid[a]; job.att = pr.att; job.rd = rd;
+        predict_wave(s_win[wib], s_src[wib], lane, job, tb, key, slot, slot_b + (size_t)r * slot, slot_q + (size_t)r * slot, &lens[r], flags);
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) {
+            const uint32_t nl = lens[r];
+            // "@<ampIdx>#<fragCount>[/1|/2]\n" + seq + "\n+\n" + qual + "\n"   (Amplicon.cpp:459-466,497-504)
+            sz[pi] = nl == 0 ? 0u : 1u + dec_digits(amp_index_base + a) + 1u + dec_digits(pr.att + 1) + (paired ? 2u : 0u) + 1u + 2u * nl + 4u;
+        }
+    }
+}
+
+// kernel-level entry for parity tests: windows given explicitly
+__global__ void __launch_bounds__(256) k_predict_windows(const uint8_t* __restrict__ windows, uint32_t n_reads, const uint64_t* __restrict__ uids,
+                                                         const uint32_t* __restrict__ atts, const uint8_t* __restrict__ is_read1, DevTables tb,
+                                                         RngKey key, uint32_t slot, char* __restrict__ slot_b, char* __restrict__ slot_q,
+                                                         uint32_t* __restrict__ lens, uint32_t* __restrict__ flags) {
+    __shared__ uint8_t s_win[4][256];
+    __shared__ uint8_t s_src[4][SRC_CAP];
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    const uint32_t nwaves = gridDim.x * 4;
+    for (uint32_t r = blockIdx.x * 4 + wib; r < n_reads; r += nwaves) {
+        for (int k = lane; k < tb.L; k += WAVE) s_win[wib][k] = windows[(size_t)r * tb.L + k];
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        ReadJob job; job.uid = uids[r]; job.att = atts[r]; job.rd = is_read1[r] ? 0u : 1u;
+        predict_wave(s_win[wib], s_src[wib], lane, job, tb, key, slot, slot_b + (size_t)r * slot, slot_q + (size_t)r * slot, &lens[r], flags);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K6  format: one wave per FASTQ record, coalesced copy from the slot buffer to its final offset
+//     (record layout of Amplicon::yieldReads, Amplicon.cpp:459-466 / 497-525; sink = SeqWriter)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t put_dec(char* dst, uint32_t v) {
+    const uint32_t nd = dec_digits(v);
+    for (uint32_t k = 0; k < nd; ++k) { dst[nd - 1 - k] = (char)('0' + v % 10u); v /= 10u; }
+    return nd;
+}
+__global__ void __launch_bounds__(256) k_format(const PairRec* __restrict__ pairs, uint32_t np, uint32_t amp_index_base, int paired, uint32_t slot,
+                                                const char* __restrict__ slot_b, const char* __restrict__ slot_q, const uint32_t* __restrict__ lens,
+                                                const uint64_t* __restrict__ off1, const uint64_t* __restrict__ off2,
+                                                char* __restrict__ out1, char* __restrict__ out2) {
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    const uint32_t nreads = paired ? 2 * np : np;
+    const uint32_t nwaves = gridDim.x * 4;
+    for (uint32_t r = blockIdx.x * 4 + wib; r < nreads; r += nwaves) {
+        const uint32_t pi = paired ? r >> 1 : r, rd = paired ? (r & 1u) : 0u;
+        const uint32_t nl = lens[r];
+        if (nl == 0) continue;
+        const PairRec pr = pairs[pi];
+        char* dst = (rd ? out2 : out1) + (rd ? off2[pi] : off1[pi]);
+        uint32_t h = 0;
+        if (lane == 0) {
+            dst[h++] = '@'; h += put_dec(dst + h, amp_index_base + pr.amp); dst[h++] = '#'; h += put_dec(dst + h, pr.att + 1);
+            if (paired) { dst[h++] = '/'; dst[h++] = rd ? '2' : '1'; }
+            dst[h++] = '\n';
+        }
+        h = __shfl(h, 0);
+        const char* sb = slot_b + (size_t)r * slot; const char* sq = slot_q + (size_t)r * slot;
+        for (uint32_t k = lane; k < nl; k += WAVE) { dst[h + k] = sb[k]; dst[h + nl + 3 + k] = sq[k]; }
+        if (lane == 0) { dst[h + nl] = '\n'; dst[h + nl + 1] = '+'; dst[h + nl + 2] = '\n'; dst[h + 2 * nl + 3] = '\n'; }
+    }
+}
+
+__global__ void k_philox(const uint32_t* __restrict__ ctr, uint32_t n, RngKey key, uint32_t* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const U4 o = philox4x32_10(ctr[4 * i], ctr[4 * i + 1], ctr[4 * i + 2], ctr[4 * i + 3], key.k0, key.k1);
+    out[4 * i] = o.w[0]; out[4 * i + 1] = o.w[1]; out[4 * i + 2] = o.w[2]; out[4 * i + 3] = o.w[3];
+}
+__global__ void k_detlog(const double* __restrict__ x, uint32_t n, double* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = det_log(x[i]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// launch wrappers.  Grids: >> 256 workgroups wherever the unit count allows; grid-stride kernels
+// are capped at 256 CUs x 8 workgroups.
+// ------------------------------------------------------------------------------------------------
+static inline uint32_t cdiv(uint64_t a, uint32_t b) { return (uint32_t)((a + b - 1) / b); }
+static const uint32_t kMaxStrideGrid = 256 * 8;
+
+void launch_attach_frags(hipStream_t s, const uint8_t* g, DevFrags fr, const uint32_t* slot_off, uint32_t* slots, uint32_t* slot_tmpl,
+                         uint32_t* valid, const int64_t* primer_cnt, uint32_t* primer_delta, AmplifyParams p) {
+    if (fr.n == 0) return;
+    DevAmps none{}; DevErrPool np{};
+    hipLaunchKernelGGL(k_attach<true>, dim3(cdiv(fr.n, 64)), dim3(64), 0, s, g, fr, none, 0u, np, slot_off, slots, slot_tmpl, valid, primer_cnt, primer_delta, p);
+}
+void launch_attach_semis(hipStream_t s, const uint8_t* g, DevFrags fr, DevAmps semis, uint32_t n_semis, DevErrPool spool,
+                         const uint32_t* slot_off, uint32_t* slots, uint32_t* slot_tmpl, uint32_t* valid,
+                         const int64_t* primer_cnt, uint32_t* primer_delta, AmplifyParams p) {
+    if (n_semis == 0) return;
+    hipLaunchKernelGGL(k_attach<false>, dim3(cdiv(n_semis, 64)), dim3(64), 0, s, g, fr, semis, n_semis, spool, slot_off, slots, slot_tmpl, valid, primer_cnt, primer_delta, p);
+}
+void launch_errscan_frags(hipStream_t s, const uint8_t* g, DevFrags fr, uint32_t n_slots, const uint32_t* slot_off, const uint32_t* slots,
+                          const uint32_t* slot_tmpl, const uint32_t* valid_off, DevAmps out, uint32_t out_base, DevErrPool pool, uint32_t* flags, AmplifyParams p) {
+    if (n_slots == 0) return;
+    DevAmps none{}; DevErrPool np{};
+    hipLaunchKernelGGL(k_errscan<true>, dim3(cdiv(n_slots, 4)), dim3(256), 0, s, g, fr, none, np, n_slots, slot_off, slots, slot_tmpl, valid_off, fr.n, out, out_base, pool, flags, p);
+}
+void launch_errscan_semis(hipStream_t s, const uint8_t* g, DevFrags fr, DevAmps semis, uint32_t n_semis, DevErrPool spool, uint32_t n_slots,
+                          const uint32_t* slot_off, const uint32_t* slots, const uint32_t* slot_tmpl, const uint32_t* valid_off,
+                          DevAmps out, uint32_t out_base, DevErrPool pool, uint32_t* flags, AmplifyParams p) {
+    if (n_slots == 0) return;
+    hipLaunchKernelGGL(k_errscan<false>, dim3(cdiv(n_slots, 4)), dim3(256), 0, s, g, fr, semis, spool, n_slots, slot_off, slots, slot_tmpl, valid_off, n_semis, out, out_base, pool, flags, p);
+}
+void launch_primer_update(hipStream_t s, int64_t* primer_cnt, uint32_t* primer_delta) {
+    hipLaunchKernelGGL(k_primer_update, dim3(256), dim3(256), 0, s, primer_cnt, primer_delta);
+}
+void launch_weights(hipStream_t s, DevAmps fulls, uint32_t n, DevTables tb, RngKey key, uint32_t frag_size, double* w) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_weights, dim3(cdiv(n, 256)), dim3(256), 0, s, fulls, n, tb, key, frag_size, w);
+}
+void launch_plan_pairs(hipStream_t s, DevAmps fulls, uint32_t n_fulls, const uint32_t* read_numbers, const uint32_t* pair_off,
+                       DevTables tb, RngKey key, int paired, PairRec* pairs) {
+    if (n_fulls == 0) return;
+    hipLaunchKernelGGL(k_plan_pairs, dim3(cdiv(n_fulls, 256)), dim3(256), 0, s, fulls, n_fulls, read_numbers, pair_off, tb, key, paired, pairs);
+}
+void launch_reads(hipStream_t s, const uint8_t* g, DevFrags fr, DevAmps semis, DevErrPool spool, DevAmps fulls, DevErrPool fpool,
+                  const PairRec* pairs, uint32_t np, uint32_t amp_index_base, DevTables tb, RngKey key, int paired, uint32_t slot,
+                  char* slot_b, char* slot_q, uint32_t* lens, uint32_t* sizes1, uint32_t* sizes2, uint32_t* flags) {
+    if (np == 0) return;
+    const uint64_t nreads = paired ? 2ull * np : np;
+    uint32_t grid = cdiv(nreads, 4); if (grid > kMaxStrideGrid * 4) grid = kMaxStrideGrid * 4;
+    hipLaunchKernelGGL(k_reads, dim3(grid), dim3(256), 0, s, g, fr, semis, spool, fulls, fpool, pairs, np, amp_index_base, tb, key, paired, slot,
+                       slot_b, slot_q, lens, sizes1, sizes2, flags);
+}
+void launch_predict_windows(hipStream_t s, const uint8_t* windows, uint32_t n_reads, const uint64_t* uids, const uint32_t* atts,
+                            const uint8_t* is_read1, DevTables tb, RngKey key, uint32_t slot, char* slot_b, char* slot_q, uint32_t* lens, uint32_t* flags) {
+    if (n_reads == 0) return;
+    uint32_t grid = cdiv(n_reads, 4); if (grid > kMaxStrideGrid * 4) grid = kMaxStrideGrid * 4;
+    hipLaunchKernelGGL(k_predict_windows, dim3(grid), dim3(256), 0, s, windows, n_reads, uids, atts, is_read1, tb, key, slot, slot_b, slot_q, lens, flags);
+}
+void launch_format(hipStream_t s, const PairRec* pairs, uint32_t np, uint32_t amp_index_base, int paired, uint32_t slot, const char* slot_b,
+                   const char* slot_q, const uint32_t* lens, const uint64_t* off1, const uint64_t* off2, char* out1, char* out2) {
+    if (np == 0) return;
+    const uint64_t nreads = paired ? 2ull * np : np;
+    uint32_t grid = cdiv(nreads, 4); if (grid > kMaxStrideGrid * 4) grid = kMaxStrideGrid * 4;
+    hipLaunchKernelGGL(k_format, dim3(grid), dim3(256), 0, s, pairs, np, amp_index_base, paired, slot, slot_b, slot_q, lens, off1, off2, out1, out2);
+}
+void launch_philox(hipStream_t s, const uint32_t* ctr, uint32_t n, RngKey key, uint32_t* out) {
+    if (n) hipLaunchKernelGGL(k_philox, dim3(cdiv(n, 256)), dim3(256), 0, s, ctr, n, key, out);
+}
+void launch_detlog(hipStream_t s, const double* x, uint32_t n, double* out) {
+    if (n) hipLaunchKernelGGL(k_detlog, dim3(cdiv(n, 256)), dim3(256), 0, s, x, n, out);
+}
+
+// ---- device-wide scans (rocPRIM; plumbing between the hand-written kernels) --------------------------
+struct Widen { __host__ __device__ uint64_t operator()(uint32_t v) const { return (uint64_t)v; } };
+size_t scan_temp_bytes(size_t n) {
+    size_t a = 0, b = 0;
+    (void)rocprim::exclusive_scan(nullptr, a, (const uint32_t*)nullptr, (uint32_t*)nullptr, 0u, n + 1, rocprim::plus<uint32_t>());
+    (void)rocprim::exclusive_scan(nullptr, b, rocprim::make_transform_iterator((const uint32_t*)nullptr, Widen()),
+                                  (uint64_t*)nullptr, (uint64_t)0, n + 1, rocprim::plus<uint64_t>());
+    return (a > b ? a : b) + 256;
+}
+// NOTE: `in` must have n+1 readable entries (the last one is ignored by an exclusive scan but read).
+void exclusive_scan_u32(hipStream_t s, const uint32_t* in, uint32_t* out, size_t n, void* temp, size_t temp_bytes) {
+    (void)rocprim::exclusive_scan(temp, temp_bytes, in, out, 0u, n + 1, rocprim::plus<uint32_t>(), s);
+}
+void exclusive_scan_u32_to_u64(hipStream_t s, const uint32_t* in, uint64_t* out, size_t n, void* temp, size_t temp_bytes) {
+    (void)rocprim::exclusive_scan(temp, temp_bytes, rocprim::make_transform_iterator(in, Widen()), out, (uint64_t)0, n + 1, rocprim::plus<uint64_t>(), s);
+}
+
+}  // namespace scs

@@ -1,0 +1,690 @@
+// scs_pipeline.cpp -- host orchestration behind the C ABI (include/scssim_hip.h).
+// One scs_ctx = one HIP device + one stream; all amplicon state lives in HBM as flat SoA arrays.
+// Reference call sequence reproduced: src/scssim.cpp:46-67 (genreads branch of main()).
+#include "../../include/scssim_hip.h"
+#include "scs_device.h"
+#include "scs_tables.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+using namespace scs;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct ScsError : std::runtime_error { int code; ScsError(int c, const std::string& m) : std::runtime_error(m), code(c) {} };
+
+#define HIP_OK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) \
+    throw ScsError(SCS_EDEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
+
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// growable device buffer
+struct DevBuf {
+    void* p = nullptr; size_t cap = 0;
+    void reserve(size_t bytes, hipStream_t s, size_t keep_bytes = 0) {
+        if (bytes <= cap) return;
+        size_t ncap = std::max(bytes, cap + cap / 2);
+        void* np = nullptr;
+        HIP_OK(hipMalloc(&np, ncap));
+        if (p && keep_bytes) { HIP_OK(hipMemcpyAsync(np, p, keep_bytes, hipMemcpyDeviceToDevice, s)); HIP_OK(hipStreamSynchronize(s)); }
+        if (p) HIP_OK(hipFree(p));
+        p = np; cap = ncap;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T* as() const { return (T*)p; }
+};
+
+struct AmpStore {            // SoA amplicon arrays (DevAmps) with capacity management
+    DevBuf parent, sl, gc, primers, uid, errs; uint32_t n = 0, cap = 0;
+    DevBuf pool, pool_head; uint32_t pool_cap = 0;
+    void reserve(uint64_t want, hipStream_t s) {
+        if (want > 0xFFFFFFF0ull) throw ScsError(SCS_EOVERFLOW, "amplicon count exceeds 2^32 (reference limit: Malbac.cpp:376,386)");
+        if (want <= cap) return;
+        uint64_t ncap = std::max<uint64_t>(want, (uint64_t)cap + cap / 2);
+        ncap = std::min<uint64_t>(std::max<uint64_t>(ncap, 1u << 16), 0xFFFFFFF0ull);
+        parent.reserve(ncap * 4, s, (size_t)n * 4); sl.reserve(ncap * 4, s, (size_t)n * 4);
+        gc.reserve(ncap * 2, s, (size_t)n * 2); primers.reserve(ncap * 2, s, (size_t)n * 2);
+        uid.reserve(ncap * 8, s, (size_t)n * 8); errs.reserve(ncap * 8, s, (size_t)n * 8);
+        cap = (uint32_t)ncap;
+    }
+    void reserve_pool(uint32_t entries, hipStream_t s) {
+        if (!pool_head.p) { pool_head.reserve(256, s); HIP_OK(hipMemsetAsync(pool_head.p, 0, 4, s)); }
+        if (entries > pool_cap) {
+            uint32_t used = 0;
+            if (pool_cap) { HIP_OK(hipMemcpyAsync(&used, pool_head.p, 4, hipMemcpyDeviceToHost, s)); HIP_OK(hipStreamSynchronize(s)); used = std::min(used, pool_cap); }
+            pool.reserve((size_t)entries * 4, s, (size_t)used * 4); pool_cap = entries;
+        }
+    }
+    DevAmps view() const { return DevAmps{parent.as<uint32_t>(), sl.as<uint32_t>(), gc.as<uint16_t>(), primers.as<uint16_t>(), uid.as<uint64_t>(), errs.as<uint64_t>()}; }
+    DevErrPool pool_view() const { return DevErrPool{pool.as<uint32_t>(), pool_head.as<uint32_t>(), pool_cap}; }
+    void reset(hipStream_t s) { n = 0; if (pool_head.p) HIP_OK(hipMemsetAsync(pool_head.p, 0, 4, s)); }
+    void release() { parent.release(); sl.release(); gc.release(); primers.release(); uid.release(); errs.release(); pool.release(); pool_head.release(); n = cap = pool_cap = 0; }
+};
+
+struct KernelTimer {         // HIP events on the ctx stream around the launches of one kernel
+    const char* name; std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; size_t used = 0; double ms = 0; uint64_t launches = 0; uint64_t units = 0;
+    void begin(hipStream_t s) {
+        if (used == ev.size()) { hipEvent_t a, b; HIP_OK(hipEventCreate(&a)); HIP_OK(hipEventCreate(&b)); ev.push_back({a, b}); }
+        HIP_OK(hipEventRecord(ev[used].first, s));
+    }
+    void end(hipStream_t s) { HIP_OK(hipEventRecord(ev[used].second, s)); ++used; }
+    void collect() {         // call after a stream sync
+        for (size_t i = 0; i < used; ++i) { float t = 0; HIP_OK(hipEventElapsedTime(&t, ev[i].first, ev[i].second)); ms += t; ++launches; }
+        used = 0;
+    }
+    void reset() { ms = 0; launches = 0; units = 0; used = 0; }
+    void release() { for (auto& e : ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); } ev.clear(); }
+};
+
+}  // namespace
+
+struct scs_ctx {
+    scs_config cfg; std::string err;
+    hipStream_t stream = nullptr; bool own_stream = false;
+    RngKey key{0, 0};
+    // model
+    ProfileTables prof; bool have_profile = false; DevTables dtb{};
+    DevBuf t_subs1, t_subs2, t_qual, t_ins, t_del, t_isize, d_subs1, d_subs2, d_qual, d_ins, d_del, d_isize, d_gcmeans;
+    // genome + fragments
+    std::vector<FastaRecord> recs; bool have_genome = false; DevBuf genome; std::vector<uint64_t> rec_off; uint64_t genome_bases = 0;
+    std::vector<uint64_t> f_goff; std::vector<uint32_t> f_len; std::vector<int8_t> f_strand; std::vector<uint32_t> f_primers;
+    uint64_t f_gidx_base = 0; bool have_frags = false;
+    DevBuf df_goff, df_len, df_strand, df_primers;
+    // amplicons
+    AmpStore semis, fulls; std::vector<uint32_t> h_semi_len; std::vector<uint64_t> h_semi_uid; std::vector<uint32_t> h_budget;
+    DevBuf primer_cnt, primer_delta; uint64_t total_primers = 0; bool amplified = false;
+    DevBuf budget, slot_off, slots, slot_tmpl, valid, valid_off, scan_tmp, flags;
+    // allocation + reads
+    DevBuf weights, read_numbers, pair_off, pairs; std::vector<uint32_t> h_read_numbers; uint64_t reads_requested = 0, n_pairs_planned = 0; bool allocated = false;
+    DevBuf slot_b, slot_q, lens, sizes1, sizes2, off1, off2, out1, out2; std::vector<char> h_out1, h_out2;
+    scs_stats st{};
+    KernelTimer tm_errscan{"k_errscan<semi->full>"}, tm_errscan_f{"k_errscan<frag->semi>"}, tm_reads{"k_reads"}, tm_attach{"k_attach"}, tm_format{"k_format"};
+
+    DevFrags frags_view() const {
+        return DevFrags{df_goff.as<uint64_t>(), df_len.as<uint32_t>(), df_strand.as<int8_t>(), df_primers.as<uint32_t>(), (uint32_t)f_len.size(), f_gidx_base};
+    }
+};
+
+namespace {
+
+void check_flags(scs_ctx* c) {
+    uint32_t f = 0;
+    HIP_OK(hipMemcpyAsync(&f, c->flags.p, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_OK(hipStreamSynchronize(c->stream));
+    if (f) {
+        HIP_OK(hipMemsetAsync(c->flags.p, 0, 4, c->stream));
+        std::string m = "device work buffer overflow:";
+        if (f & FLAG_ERRCAP) m += " per-amplicon error list";
+        if (f & FLAG_ERRPOOL) m += " error overflow pool";
+        if (f & FLAG_READSLOT) m += " read slot (indel-extended read longer than the slot)";
+        if (f & FLAG_INTERNAL) m += " internal";
+        throw ScsError(SCS_EOVERFLOW, m);
+    }
+}
+
+template <class T>
+void upload(DevBuf& b, const std::vector<T>& v, hipStream_t s, size_t extra = 0) {
+    b.reserve(std::max<size_t>((v.size() + extra) * sizeof(T), 16), s);
+    if (!v.empty()) HIP_OK(hipMemcpyAsync(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s));
+}
+
+// ---------------------------------------------------------------- profile
+void do_load_profile(scs_ctx* c, const char* path) {
+    load_profile(path, c->cfg.paired != 0, c->cfg.isize, c->prof);
+    ProfileTables& P = c->prof; hipStream_t s = c->stream;
+    upload(c->t_subs1, P.subs1_t, s); upload(c->t_subs2, P.subs2_t, s); upload(c->t_qual, P.qual_t, s);
+    upload(c->t_ins, P.ins_t, s); upload(c->t_del, P.del_t, s); upload(c->t_isize, P.isize_t, s);
+    upload(c->d_subs1, P.subs1, s); upload(c->d_subs2, P.subs2, s); upload(c->d_qual, P.qual, s);
+    upload(c->d_ins, P.ins_cdf, s); upload(c->d_del, P.del_cdf, s); upload(c->d_isize, P.isize_cdf, s);
+    std::vector<double> gm(P.gc_means, P.gc_means + 101); upload(c->d_gcmeans, gm, s);
+    HIP_OK(hipStreamSynchronize(s));
+    DevTables& t = c->dtb;
+    t.L = P.read_length; t.bins = P.bins; t.t_insert = P.t_insert; t.t_delete = P.t_delete; t.t_ber = threshold_lt(c->cfg.ber);
+    t.subs1 = c->t_subs1.as<uint32_t>(); t.subs2 = P.have_cdf2 ? c->t_subs2.as<uint32_t>() : nullptr; t.qual = c->t_qual.as<uint32_t>();
+    t.ins_t = c->t_ins.as<uint32_t>(); t.n_ins = (int)P.ins_t.size(); t.del_t = c->t_del.as<uint32_t>(); t.n_del = (int)P.del_t.size();
+    t.isize_t = c->t_isize.as<uint32_t>(); t.n_isize = (int)P.isize_t.size(); t.isize_min = P.isize_min;
+    t.subs1_d = c->d_subs1.as<double>(); t.subs2_d = P.have_cdf2 ? c->d_subs2.as<double>() : nullptr; t.qual_d = c->d_qual.as<double>();
+    t.ins_d = c->d_ins.as<double>(); t.del_d = c->d_del.as<double>(); t.isize_d = c->d_isize.as<double>();
+    t.gc_means = c->d_gcmeans.as<double>(); t.gc_std = P.gc_std;
+    if (P.read_length > 256) throw ScsError(SCS_EINVAL, "read length > 256 not supported by the inject_errors kernel");
+    c->have_profile = true;
+    if (c->cfg.verbose) fprintf(stderr, "profile was loaded from file %s\n", path);
+}
+
+// ---------------------------------------------------------------- genome
+void stage_genome(scs_ctx* c) {
+    c->rec_off.clear(); uint64_t tot = 0;
+    for (auto& r : c->recs) { c->rec_off.push_back(tot); tot += r.code.size(); }
+    c->genome_bases = tot;
+    c->genome.reserve(std::max<uint64_t>(tot, 16), c->stream);
+    for (size_t i = 0; i < c->recs.size(); ++i)
+        if (!c->recs[i].code.empty())
+            HIP_OK(hipMemcpyAsync((uint8_t*)c->genome.p + c->rec_off[i], c->recs[i].code.data(), c->recs[i].code.size(), hipMemcpyHostToDevice, c->stream));
+    HIP_OK(hipStreamSynchronize(c->stream));
+    c->have_genome = true; c->have_frags = false; c->amplified = false; c->allocated = false;
+    c->st.records = c->recs.size(); c->st.genome_bases = tot;
+}
+
+// ---------------------------------------------------------------- a1: Genome::splitToFrags (Genome.cpp:753-782)
+void do_create_frags(scs_ctx* c) {
+    if (!c->have_genome) throw ScsError(SCS_EINVAL, "scs_create_frags: no genome loaded");
+    const scs_config& cf = c->cfg;
+    std::vector<uint64_t> goff; std::vector<uint32_t> len; std::vector<int8_t> strand;
+    for (size_t r = 0; r < c->recs.size(); ++r) {
+        const int64_t chr_len = (int64_t)c->recs[r].code.size(); int64_t pos = 1; uint32_t k = 0;
+        while (pos <= chr_len) {
+            const U4 d = draw4(c->key, ST_FRAGSPLIT, 0, r, k++);
+            const int64_t fl = scale_draw(d.w[0], (uint32_t)cf.frag_min, (uint32_t)(cf.frag_max + 1 - cf.frag_min));   // randomInteger(minSize, maxSize+1)
+            if (pos + fl - 1 > chr_len) break;
+            for (int sgn : {1, -1}) { goff.push_back(c->rec_off[r] + (uint64_t)(pos - 1)); len.push_back((uint32_t)fl); strand.push_back((int8_t)sgn); }
+            pos += fl;
+        }
+        if (pos <= chr_len)                                                     // tail: emitted twice, both strand +1 (Genome.cpp:772-777)
+            for (int rep = 0; rep < 2; ++rep) { goff.push_back(c->rec_off[r] + (uint64_t)(pos - 1)); len.push_back((uint32_t)(chr_len - pos + 1)); strand.push_back(1); }
+    }
+    // fragment-lineage sharding: contiguous fragment ranges balanced by bases
+    size_t lo = 0, hi = len.size();
+    if (cf.shard_count > 1) {
+        uint64_t tot = 0; for (auto l : len) tot += l;
+        std::vector<size_t> cut(cf.shard_count + 1, len.size()); cut[0] = 0;
+        uint64_t acc = 0; int sh = 1;
+        for (size_t i = 0; i < len.size() && sh < cf.shard_count; ++i) { acc += len[i]; while (sh < cf.shard_count && acc * cf.shard_count >= tot * (uint64_t)sh) cut[sh++] = i + 1; }
+        lo = cut[cf.shard_rank]; hi = cut[cf.shard_rank + 1];
+    }
+    c->f_goff.assign(goff.begin() + lo, goff.begin() + hi); c->f_len.assign(len.begin() + lo, len.begin() + hi);
+    c->f_strand.assign(strand.begin() + lo, strand.begin() + hi); c->f_primers.assign(hi - lo, 0); c->f_gidx_base = lo;
+    upload(c->df_goff, c->f_goff, c->stream); upload(c->df_len, c->f_len, c->stream); upload(c->df_strand, c->f_strand, c->stream);
+    c->df_primers.reserve(std::max<size_t>(c->f_len.size() * 4, 16), c->stream);
+    HIP_OK(hipStreamSynchronize(c->stream));
+    c->have_frags = true; c->amplified = false; c->allocated = false;
+    c->st.fragments = c->f_len.size();
+}
+
+// ---------------------------------------------------------------- a3: Malbac::setPrimers (Malbac.cpp:236-283), poissRand (MyDefine.cpp:69-80)
+uint64_t poisson_keyed(RngKey key, double lambda, uint32_t aux, uint64_t tuid) {
+    long x = -1; double log1 = 0; const double log2 = -lambda; uint32_t t = 0; U4 d{};
+    do {
+        if ((t & 3) == 0) d = draw4(key, ST_POISSON, aux, tuid, t >> 2);
+        const double u = d.w[t & 3] / 4294967296.0; ++t;
+        log1 += log(u); x++;
+    } while (log1 >= log2);
+    return (uint64_t)x;
+}
+void set_primers(scs_ctx* c, bool only_frags, uint32_t call) {
+    if (c->cfg.shard_count > 1) throw ScsError(SCS_EINVAL, "sharded setPrimers needs the all-reduce hook (not wired in this build)");
+    uint64_t template_num = c->f_len.size(); double total_len = 0;
+    for (uint32_t l : c->f_len) total_len += l;
+    if (!only_frags) { template_num += c->h_semi_len.size(); for (uint32_t l : c->h_semi_len) total_len += l; }
+    const uint64_t expected = (uint64_t)(c->total_primers * c->cfg.gamma * template_num);
+    uint64_t count = 0;
+    for (size_t i = 0; i < c->f_len.size(); ++i) {
+        const double lambda = expected * (1.0 * c->f_len[i] / total_len);
+        const uint64_t k = poisson_keyed(c->key, lambda, 0u | (call << 1), c->f_gidx_base + i);
+        count += k; c->f_primers[i] = (uint32_t)(int)k;
+    }
+    if (!only_frags) {
+        c->h_budget.resize(c->h_semi_len.size());
+        for (size_t i = 0; i < c->h_semi_len.size(); ++i) {
+            const double lambda = expected * (1.0 * c->h_semi_len[i] / total_len);
+            const uint64_t k = poisson_keyed(c->key, lambda, 1u | (call << 1), c->h_semi_uid[i]);
+            count += k; c->h_budget[i] = (uint32_t)(k & 0xFFF);                    // 12-bit field (Amplicon.cpp:76-79)
+        }
+    }
+    c->total_primers -= count;
+}
+
+// ---------------------------------------------------------------- one amplification pass (a4 / a5)
+void amplify_pass(scs_ctx* c, bool from_frag, uint32_t pass) {
+    hipStream_t s = c->stream;
+    const std::vector<uint32_t>& budget = from_frag ? c->f_primers : c->h_budget;
+    const uint32_t nt = (uint32_t)budget.size();
+    if (nt == 0) return;
+    uint64_t n_slots64 = 0; for (uint32_t b : budget) n_slots64 += b;
+    if (n_slots64 > 0xFFFFFFF0ull) throw ScsError(SCS_EOVERFLOW, "primer budget of one pass exceeds 2^32");
+    const uint32_t n_slots = (uint32_t)n_slots64;
+    upload(c->budget, budget, s, 1);
+    if (from_frag) HIP_OK(hipMemcpyAsync(c->df_primers.p, budget.data(), (size_t)nt * 4, hipMemcpyHostToDevice, s));
+    c->slot_off.reserve(((size_t)nt + 1) * 4, s); c->valid.reserve(((size_t)nt + 1) * 4, s); c->valid_off.reserve(((size_t)nt + 1) * 4, s);
+    c->slots.reserve(std::max<size_t>((size_t)n_slots * 4, 16), s); c->slot_tmpl.reserve(std::max<size_t>((size_t)n_slots * 4, 16), s);
+    c->scan_tmp.reserve(scan_temp_bytes(nt), s);
+    HIP_OK(hipMemsetAsync(c->slot_tmpl.p, 0xFF, std::max<size_t>((size_t)n_slots * 4, 16), s));
+    exclusive_scan_u32(s, c->budget.as<uint32_t>(), c->slot_off.as<uint32_t>(), nt, c->scan_tmp.p, c->scan_tmp.cap);
+    AmpStore& out = from_frag ? c->semis : c->fulls;
+    out.reserve((uint64_t)out.n + n_slots, s);
+    out.reserve_pool(std::max<uint32_t>(1u << 16, (uint32_t)std::min<uint64_t>(((uint64_t)out.n + n_slots) / 256 + 4096, 0xFFFFFFF0ull)), s);
+    AmplifyParams p; p.key = c->key; p.pass = pass; p.amp_min = (uint32_t)c->cfg.amplicon_min_len; p.amp_max = (uint32_t)c->cfg.amplicon_max_len; p.t_ber = c->dtb.t_ber;
+    DevFrags fr = c->frags_view(); fr.primers = c->budget.as<uint32_t>();
+    const uint8_t* g = c->genome.as<uint8_t>();
+    c->tm_attach.begin(s);
+    if (from_frag) launch_attach_frags(s, g, fr, c->slot_off.as<uint32_t>(), c->slots.as<uint32_t>(), c->slot_tmpl.as<uint32_t>(), c->valid.as<uint32_t>(),
+                                       c->primer_cnt.as<int64_t>(), c->primer_delta.as<uint32_t>(), p);
+    else {
+        // budgets of this cycle live in the semis' packed record too (Amplicon::setPrimers)
+        DevAmps sv = c->semis.view();
+        std::vector<uint16_t> b16(nt); for (uint32_t i = 0; i < nt; ++i) b16[i] = (uint16_t)budget[i];
+        HIP_OK(hipMemcpyAsync(sv.primers, b16.data(), (size_t)nt * 2, hipMemcpyHostToDevice, s));
+        HIP_OK(hipStreamSynchronize(s));
+        launch_attach_semis(s, g, fr, sv, nt, c->semis.pool_view(), c->slot_off.as<uint32_t>(), c->slots.as<uint32_t>(), c->slot_tmpl.as<uint32_t>(),
+                            c->valid.as<uint32_t>(), c->primer_cnt.as<int64_t>(), c->primer_delta.as<uint32_t>(), p);
+    }
+    c->tm_attach.end(s);
+    exclusive_scan_u32(s, c->valid.as<uint32_t>(), c->valid_off.as<uint32_t>(), nt, c->scan_tmp.p, c->scan_tmp.cap);
+    KernelTimer& tm = from_frag ? c->tm_errscan_f : c->tm_errscan;
+    tm.begin(s);
+    if (from_frag) launch_errscan_frags(s, g, fr, n_slots, c->slot_off.as<uint32_t>(), c->slots.as<uint32_t>(), c->slot_tmpl.as<uint32_t>(),
+                                        c->valid_off.as<uint32_t>(), out.view(), out.n, out.pool_view(), c->flags.as<uint32_t>(), p);
+    else launch_errscan_semis(s, g, fr, c->semis.view(), nt, c->semis.pool_view(), n_slots, c->slot_off.as<uint32_t>(), c->slots.as<uint32_t>(),
+                              c->slot_tmpl.as<uint32_t>(), c->valid_off.as<uint32_t>(), out.view(), out.n, out.pool_view(), c->flags.as<uint32_t>(), p);
+    tm.end(s);
+    launch_primer_update(s, c->primer_cnt.as<int64_t>(), c->primer_delta.as<uint32_t>());
+    uint32_t n_new = 0;
+    HIP_OK(hipMemcpyAsync(&n_new, c->valid_off.as<uint32_t>() + nt, 4, hipMemcpyDeviceToHost, s));
+    HIP_OK(hipStreamSynchronize(s));
+    tm.units += n_new;
+    const uint32_t old_n = out.n; out.n += n_new;
+    if (from_frag && n_new) {                                                    // host mirror for the next setPrimers
+        std::vector<uint32_t> sl(n_new); c->h_semi_uid.resize(out.n); c->h_semi_len.resize(out.n);
+        HIP_OK(hipMemcpyAsync(sl.data(), out.view().sl + old_n, (size_t)n_new * 4, hipMemcpyDeviceToHost, s));
+        HIP_OK(hipMemcpyAsync(c->h_semi_uid.data() + old_n, out.view().uid + old_n, (size_t)n_new * 8, hipMemcpyDeviceToHost, s));
+        HIP_OK(hipStreamSynchronize(s));
+        for (uint32_t i = 0; i < n_new; ++i) c->h_semi_len[old_n + i] = sl_len(sl[i]);
+    }
+}
+
+// ---------------------------------------------------------------- Malbac::amplify (Malbac.cpp:173-201)
+void do_amplify(scs_ctx* c) {
+    if (!c->have_frags) throw ScsError(SCS_EINVAL, "scs_amplify: call scs_create_frags first");
+    if (!c->have_profile) throw ScsError(SCS_EINVAL, "scs_amplify: load a profile first");
+    hipStream_t s = c->stream;
+    if (c->cfg.verbose) fprintf(stderr, "\nMALBAC amplification...\n");
+    c->semis.reset(s); c->fulls.reset(s); c->h_semi_len.clear(); c->h_semi_uid.clear(); c->h_budget.clear();
+    c->tm_errscan.reset(); c->tm_errscan_f.reset(); c->tm_attach.reset();
+    std::vector<int64_t> stock(65536, (int64_t)c->cfg.primers);                    // createPrimers: 4^8 types x `primers` copies
+    upload(c->primer_cnt, stock, s);
+    c->primer_delta.reserve(65536 * 4, s); HIP_OK(hipMemsetAsync(c->primer_delta.p, 0, 65536 * 4, s));
+    HIP_OK(hipMemsetAsync(c->flags.p, 0, 4, s));
+    c->total_primers = 65536ull * (uint64_t)c->cfg.primers;
+    set_primers(c, true, 0);
+    amplify_pass(c, true, 0);
+    for (uint32_t i = 0; i < 5; ++i) {
+        if (c->total_primers == 0) break;
+        if (c->cfg.verbose) fprintf(stderr, "cycle number: %u\n", i + 1);
+        set_primers(c, false, i + 1);
+        amplify_pass(c, false, i);
+        if (c->cfg.verbose) fprintf(stderr, "semi amplicon amplification done!\n");
+        if (i < 4) { amplify_pass(c, true, i + 1); if (c->cfg.verbose) fprintf(stderr, "fragment amplification done!\n"); }
+    }
+    check_flags(c);
+    c->tm_errscan.collect(); c->tm_errscan_f.collect(); c->tm_attach.collect();
+    c->amplified = true; c->allocated = false;
+    c->st.semi_amplicons = c->semis.n; c->st.full_amplicons = c->fulls.n; c->st.primers_left = c->total_primers;
+}
+
+// ---------------------------------------------------------------- a8 + a9: Malbac::setReadCounts (Malbac.cpp:370-408)
+inline uint32_t first_le(const double* cdf, size_t n, double r) {               // randIndx's linear scan == lower bound on a non-decreasing row
+    size_t lo = 0, hi = n;
+    while (lo < hi) { size_t mid = (lo + hi) >> 1; if (r <= cdf[mid]) hi = mid; else lo = mid + 1; }
+    return (uint32_t)(lo < n ? lo : n - 1);
+}
+void do_allocate(scs_ctx* c, uint64_t reads) {
+    if (!c->amplified) throw ScsError(SCS_EINVAL, "scs_allocate_reads: call scs_amplify first");
+    hipStream_t s = c->stream;
+    if (reads == 0) {                                                             // Malbac::yieldReads, Malbac.cpp:413-420
+        uint64_t ref_len = 0;
+        for (auto& r : c->recs) { size_t p = r.name.rfind('_'); ref_len += (uint64_t)atoi(r.name.c_str() + (p == std::string::npos ? 0 : p + 1)); }
+        ref_len /= 2;
+        reads = (uint64_t)(ref_len * c->cfg.coverage / (long)c->prof.read_length);
+        if (c->cfg.shard_count > 1) throw ScsError(SCS_EINVAL, "sharded read allocation needs the all-reduce hook (not wired in this build)");
+    }
+    if (c->cfg.verbose) fprintf(stderr, "\nNumber of reads to generate: %llu\n", (unsigned long long)reads);
+    c->reads_requested = reads; c->st.reads_requested = reads;
+    const uint32_t ac = c->fulls.n;
+    double t0 = now_s();
+    c->weights.reserve(std::max<size_t>((size_t)ac * 8, 16), s);
+    launch_weights(s, c->fulls.view(), ac, c->dtb, c->key, (uint32_t)c->cfg.frag_size, c->weights.as<double>());
+    std::vector<double> w(ac);
+    if (ac) HIP_OK(hipMemcpyAsync(w.data(), c->weights.p, (size_t)ac * 8, hipMemcpyDeviceToHost, s));
+    HIP_OK(hipStreamSynchronize(s));
+    double t1 = now_s(); c->st.t_stage[3] = t1 - t0;
+    const double ZF = 2.2204e-16; const size_t chunk = 1000;
+    std::vector<uint32_t>& rn = c->h_read_numbers; rn.assign(ac, 0);
+    if (ac) {
+        double total = 0;                                                          // [REMAP] per-1000 partial sums, then partials in order
+        for (size_t b = 0; b < ac; b += chunk) { double part = 0; const size_t e = std::min<size_t>(ac, b + chunk); for (size_t i = b; i < e; ++i) part += w[i]; total += part; }
+        const double den = ZF + total;
+        uint64_t sum = 0;
+        for (size_t i = 0; i < ac; ++i) { w[i] /= den; const uint32_t r = (uint32_t)(w[i] * (long)reads); rn[i] = r; sum += r; }
+        uint64_t n = reads - sum;                                                  // randIndx_hp (MyDefine.cpp:203-272)
+        const size_t nchunks = (ac + chunk - 1) / chunk;
+        std::vector<double> tp(nchunks); std::vector<uint32_t> quota(nchunks); uint64_t count = 0;
+        for (size_t ci = 0; ci < nchunks; ++ci) {
+            const size_t b = ci * chunk, e = std::min<size_t>(ac, b + chunk); double t = 0;
+            for (size_t i = b; i < e; ++i) t += w[i];
+            tp[ci] = t; quota[ci] = (uint32_t)(t * n); count += quota[ci];
+        }
+        n -= count;
+        if (n > 0) {
+            std::vector<double> probs(nchunks); probs[0] = tp[0];
+            for (size_t i = 1; i < nchunks; ++i) probs[i] = probs[i - 1] + tp[i];
+            for (uint32_t t = 0; t < n; ++t) {
+                const U4 d = draw4(c->key, ST_ALLOC_TOP, 0, 0, t);
+                const double r = ZF + (1 - ZF) * (d.w[0] / 4294967296.0);
+                quota[first_le(probs.data(), nchunks, r)] += 1;
+            }
+        }
+        std::vector<double> cdf(chunk);
+        for (size_t ci = 0; ci < nchunks; ++ci) {                                  // batchSampling (MyDefine.cpp:191-201)
+            if (!quota[ci]) continue;
+            const size_t b = ci * chunk, e = std::min<size_t>(ac, b + chunk); double run = 0;
+            for (size_t i = b; i < e; ++i) { run = run + w[i] / tp[ci]; cdf[i - b] = run; }
+            for (uint32_t t = 0; t < quota[ci]; ++t) {
+                const U4 d = draw4(c->key, ST_ALLOC_CHUNK, 0, ci, t);
+                const double r = ZF + (1 - ZF) * (d.w[0] / 4294967296.0);
+                rn[b + first_le(cdf.data(), e - b, r)] += 1;
+            }
+        }
+        if (c->cfg.paired) { int k = 1; for (size_t i = 0; i < ac; ++i) if (rn[i] & 1u) { rn[i] += k; k = -k; } }   // Malbac.cpp:399-407
+    }
+    std::vector<uint32_t> poff((size_t)ac + 1); uint64_t acc = 0;
+    for (size_t i = 0; i < ac; ++i) { poff[i] = (uint32_t)acc; acc += c->cfg.paired ? (rn[i] + 1) / 2 : rn[i]; if (acc > 0xFFFFFFF0ull) throw ScsError(SCS_EOVERFLOW, "more than 2^32 pairs"); }
+    poff[ac] = (uint32_t)acc; c->n_pairs_planned = acc;
+    upload(c->read_numbers, rn, s, 1); upload(c->pair_off, poff, s);
+    HIP_OK(hipStreamSynchronize(s));
+    c->st.t_stage[4] = now_s() - t1;
+    c->allocated = true;
+}
+
+// ---------------------------------------------------------------- a10/a11/a13/a16: yieldReads
+struct OutTarget { bool device; char* d1; char* d2; size_t cap1, cap2; scs_sink_fn sink; void* user; };
+
+void do_yield(scs_ctx* c, const OutTarget& tg, uint64_t* n1_out, uint64_t* n2_out, uint64_t* pairs_out) {
+    if (!c->allocated) throw ScsError(SCS_EINVAL, "scs_yield_reads: call scs_allocate_reads first");
+    hipStream_t s = c->stream; const int paired = c->cfg.paired != 0;
+    if (c->cfg.verbose) fprintf(stderr, "\n*****Producing reads*****\n");
+    c->tm_reads.reset(); c->tm_format.reset();
+    const uint64_t P = c->n_pairs_planned;
+    const uint32_t L = (uint32_t)c->prof.read_length, slot = ((L + 64 + 63) / 64) * 64;
+    c->pairs.reserve(std::max<size_t>(P * sizeof(PairRec), 16), s);
+    launch_plan_pairs(s, c->fulls.view(), c->fulls.n, c->read_numbers.as<uint32_t>(), c->pair_off.as<uint32_t>(), c->dtb, c->key, paired, c->pairs.as<PairRec>());
+    const uint64_t batch = std::min<uint64_t>(std::max<uint64_t>(P, 1), 1ull << 21);
+    const uint64_t nreads_b = paired ? 2 * batch : batch;
+    c->slot_b.reserve(nreads_b * slot, s); c->slot_q.reserve(nreads_b * slot, s); c->lens.reserve(nreads_b * 4, s);
+    c->sizes1.reserve((batch + 1) * 4, s); c->sizes2.reserve((batch + 1) * 4, s); c->off1.reserve((batch + 1) * 8, s); c->off2.reserve((batch + 1) * 8, s);
+    c->scan_tmp.reserve(scan_temp_bytes(batch), s);
+    uint64_t tot1 = 0, tot2 = 0, pairs_written = 0;
+    for (uint64_t p0 = 0; p0 < P; p0 += batch) {
+        const uint32_t np = (uint32_t)std::min<uint64_t>(batch, P - p0);
+        const PairRec* pr = c->pairs.as<PairRec>() + p0;
+        c->tm_reads.begin(s);
+        launch_reads(s, c->genome.as<uint8_t>(), c->frags_view(), c->semis.view(), c->semis.pool_view(), c->fulls.view(), c->fulls.pool_view(), pr, np, 0,
+                     c->dtb, c->key, paired, slot, c->slot_b.as<char>(), c->slot_q.as<char>(), c->lens.as<uint32_t>(), c->sizes1.as<uint32_t>(),
+                     c->sizes2.as<uint32_t>(), c->flags.as<uint32_t>());
+        c->tm_reads.end(s);
+        c->tm_reads.units += np;
+        exclusive_scan_u32_to_u64(s, c->sizes1.as<uint32_t>(), c->off1.as<uint64_t>(), np, c->scan_tmp.p, c->scan_tmp.cap);
+        if (paired) exclusive_scan_u32_to_u64(s, c->sizes2.as<uint32_t>(), c->off2.as<uint64_t>(), np, c->scan_tmp.p, c->scan_tmp.cap);
+        uint64_t b1 = 0, b2 = 0;
+        HIP_OK(hipMemcpyAsync(&b1, c->off1.as<uint64_t>() + np, 8, hipMemcpyDeviceToHost, s));
+        if (paired) HIP_OK(hipMemcpyAsync(&b2, c->off2.as<uint64_t>() + np, 8, hipMemcpyDeviceToHost, s));
+        HIP_OK(hipStreamSynchronize(s));
+        char *o1, *o2;
+        if (tg.device) {
+            if (tot1 + b1 > tg.cap1 || tot2 + b2 > tg.cap2) throw ScsError(SCS_EOVERFLOW, "scs_yield_reads_device: output buffer too small");
+            o1 = tg.d1 + tot1; o2 = tg.d2 ? tg.d2 + tot2 : nullptr;
+        } else {
+            c->out1.reserve(std::max<uint64_t>(b1, 16), s); c->out2.reserve(std::max<uint64_t>(b2, 16), s);
+            o1 = c->out1.as<char>(); o2 = c->out2.as<char>();
+        }
+        c->tm_format.begin(s);
+        launch_format(s, pr, np, 0, paired, slot, c->slot_b.as<char>(), c->slot_q.as<char>(), c->lens.as<uint32_t>(), c->off1.as<uint64_t>(), c->off2.as<uint64_t>(), o1, o2);
+        c->tm_format.end(s);
+        if (!tg.device && tg.sink) {
+            c->h_out1.resize(b1); c->h_out2.resize(b2);
+            if (b1) HIP_OK(hipMemcpyAsync(c->h_out1.data(), o1, b1, hipMemcpyDeviceToHost, s));
+            if (b2) HIP_OK(hipMemcpyAsync(c->h_out2.data(), o2, b2, hipMemcpyDeviceToHost, s));
+            HIP_OK(hipStreamSynchronize(s));
+            if (tg.sink(tg.user, c->h_out1.data(), b1, paired ? c->h_out2.data() : nullptr, b2)) throw ScsError(SCS_EIO, "sink aborted");
+        }
+        tot1 += b1; tot2 += b2;
+    }
+    // count produced pairs (holes have isz == 0); cheap host pass over the lengths is avoided: holes only
+    // arise when >1000 insert sizes in a row miss [readLength, ampliconLen] (Amplicon.cpp:484-489).
+    {
+        std::vector<PairRec> hp;   // only inspect when the insert range can miss
+        const bool can_miss = paired && (c->prof.isize_min + (int)c->prof.isize_t.size() - 1 > c->cfg.amplicon_min_len);
+        if (can_miss && P) { hp.resize(P); HIP_OK(hipMemcpyAsync(hp.data(), c->pairs.p, P * sizeof(PairRec), hipMemcpyDeviceToHost, s)); HIP_OK(hipStreamSynchronize(s));
+                             for (auto& r : hp) pairs_written += r.isz != 0; }
+        else pairs_written = P;
+    }
+    HIP_OK(hipStreamSynchronize(s));
+    check_flags(c);
+    c->tm_reads.collect(); c->tm_format.collect();
+    c->st.pairs_written = pairs_written; c->st.reads_written = paired ? 2 * pairs_written : pairs_written;
+    c->st.fastq_bytes[0] = tot1; c->st.fastq_bytes[1] = tot2;
+    // 1526 B per created amplicon + per pair (insert size + FASTQ bytes of both records)
+    const uint64_t per_pair_tmpl = paired ? (uint64_t)(c->cfg.isize + 1) : (uint64_t)L;
+    c->st.algorithmic_bytes = 1526ull * (c->st.semi_amplicons + c->st.full_amplicons) + pairs_written * per_pair_tmpl + tot1 + tot2;
+    if (n1_out) *n1_out = tot1; if (n2_out) *n2_out = tot2; if (pairs_out) *pairs_out = pairs_written;
+    if (c->cfg.verbose) fprintf(stderr, "\nReads generation done!\n");
+}
+
+template <class F>
+int guarded(scs_ctx* c, F f) {
+    if (!c) return SCS_EINVAL;
+    try { if (c->cfg.device >= 0) (void)hipSetDevice(c->cfg.device); f(); return SCS_OK; }
+    catch (const ScsError& e) { c->err = e.what(); return e.code; }
+    catch (const std::exception& e) { c->err = e.what(); return SCS_EIO; }
+}
+
+}  // namespace
+
+// =================================================================== C ABI
+extern "C" {
+
+void scs_default_config(scs_config* cfg) {
+    memset(cfg, 0, sizeof *cfg);
+    cfg->device = 0; cfg->stream = nullptr; cfg->seed = 1;
+    cfg->primers = 100000; cfg->gamma = 1e-9; cfg->coverage = 5; cfg->isize = 260; cfg->paired = 1;
+    cfg->ber = 3.4e-4; cfg->amplicon_min_len = 1000; cfg->amplicon_max_len = 2000; cfg->frag_size = 1000;
+    cfg->frag_min = 10000; cfg->frag_max = 100000; cfg->shard_rank = 0; cfg->shard_count = 1; cfg->verbose = 0;
+}
+
+int scs_create(const scs_config* cfg, scs_ctx** out) {
+    if (!cfg || !out) { g_create_error = "scs_create: null argument"; return SCS_EINVAL; }
+    *out = nullptr;
+    if (cfg->primers < 1000) { g_create_error = "Error: the value of parameter \"primers\" should be at least 1000!"; return SCS_EINVAL; }
+    if (cfg->gamma <= 0 || cfg->gamma > 1e-8) { g_create_error = "Error: the value of parameter \"gamma\" should be in 0~1e-8!"; return SCS_EINVAL; }
+    if (cfg->coverage <= 0) { g_create_error = "Error: sequencing coverage not properly specified!"; return SCS_EINVAL; }
+    if (cfg->shard_count < 1 || cfg->shard_rank < 0 || cfg->shard_rank >= cfg->shard_count) { g_create_error = "scs_create: bad shard rank/count"; return SCS_EINVAL; }
+    if (cfg->amplicon_max_len > 2047 || cfg->frag_max > 131071 || cfg->amplicon_min_len < 64) { g_create_error = "scs_create: amplicon/fragment size outside the packed-record limits"; return SCS_EINVAL; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= cfg->device) {
+        g_create_error = "scs_create: no HIP device " + std::to_string(cfg->device) + " (this library has no CPU fallback)"; return SCS_EDEVICE;
+    }
+    scs_ctx* c = new scs_ctx; c->cfg = *cfg;
+    try {
+        HIP_OK(hipSetDevice(cfg->device));
+        if (cfg->stream) c->stream = (hipStream_t)cfg->stream; else { HIP_OK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
+        c->key = RngKey{(uint32_t)cfg->seed, (uint32_t)(cfg->seed >> 32)};
+        c->flags.reserve(256, c->stream); HIP_OK(hipMemsetAsync(c->flags.p, 0, 256, c->stream));
+        HIP_OK(hipStreamSynchronize(c->stream));
+    } catch (const std::exception& e) { g_create_error = e.what(); delete c; return SCS_EDEVICE; }
+    *out = c; return SCS_OK;
+}
+
+void scs_destroy(scs_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->cfg.device);
+    (void)hipStreamSynchronize(c->stream);
+    for (DevBuf* b : {&c->t_subs1, &c->t_subs2, &c->t_qual, &c->t_ins, &c->t_del, &c->t_isize, &c->d_subs1, &c->d_subs2, &c->d_qual, &c->d_ins, &c->d_del,
+                      &c->d_isize, &c->d_gcmeans, &c->genome, &c->df_goff, &c->df_len, &c->df_strand, &c->df_primers, &c->primer_cnt, &c->primer_delta,
+                      &c->budget, &c->slot_off, &c->slots, &c->slot_tmpl, &c->valid, &c->valid_off, &c->scan_tmp, &c->flags, &c->weights, &c->read_numbers,
+                      &c->pair_off, &c->pairs, &c->slot_b, &c->slot_q, &c->lens, &c->sizes1, &c->sizes2, &c->off1, &c->off2, &c->out1, &c->out2}) b->release();
+    c->semis.release(); c->fulls.release();
+    for (KernelTimer* t : {&c->tm_errscan, &c->tm_errscan_f, &c->tm_reads, &c->tm_attach, &c->tm_format}) t->release();
+    if (c->own_stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* scs_last_error(const scs_ctx* c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+
+int scs_set_seed(scs_ctx* c, uint64_t seed) {
+    if (!c) return SCS_EINVAL;
+    c->cfg.seed = seed; c->key = RngKey{(uint32_t)seed, (uint32_t)(seed >> 32)}; return SCS_OK;
+}
+
+int scs_load_profile(scs_ctx* c, const char* path) { return guarded(c, [&] { if (!path) throw ScsError(SCS_EINVAL, "null path"); do_load_profile(c, path); }); }
+int scs_read_length(const scs_ctx* c) { return c && c->have_profile ? c->prof.read_length : -1; }
+
+int scs_load_genome_fasta(scs_ctx* c, const char* path) {
+    return guarded(c, [&] {
+        if (!path) throw ScsError(SCS_EINVAL, "null path");
+        load_fasta(path, c->recs); stage_genome(c);
+        if (c->cfg.verbose) fprintf(stderr, "\nReference sequence was loaded from file %s\n", path);
+    });
+}
+int scs_upload_genome(scs_ctx* c, int n, const char* const* names, const char* const* seqs, const uint64_t* lens) {
+    return guarded(c, [&] {
+        if (n <= 0 || !names || !seqs || !lens) throw ScsError(SCS_EINVAL, "scs_upload_genome: bad arguments");
+        c->recs.resize(n);
+        for (int i = 0; i < n; ++i) encode_record(names[i], seqs[i], lens[i], c->recs[i]);
+        stage_genome(c);
+    });
+}
+int scs_create_frags(scs_ctx* c) { return guarded(c, [&] { double t = now_s(); do_create_frags(c); c->st.t_stage[1] = now_s() - t; }); }
+int scs_amplify(scs_ctx* c) { return guarded(c, [&] { double t = now_s(); do_amplify(c); c->st.t_stage[2] = now_s() - t; }); }
+int scs_allocate_reads(scs_ctx* c, uint64_t reads) { return guarded(c, [&] { do_allocate(c, reads); }); }
+int scs_yield_reads(scs_ctx* c, scs_sink_fn sink, void* user) {
+    return guarded(c, [&] { double t = now_s(); OutTarget tg{false, nullptr, nullptr, 0, 0, sink, user}; do_yield(c, tg, nullptr, nullptr, nullptr); c->st.t_stage[5] = now_s() - t; });
+}
+int scs_yield_reads_device(scs_ctx* c, void* d1, size_t cap1, void* d2, size_t cap2, uint64_t* n1, uint64_t* n2, uint64_t* pairs) {
+    return guarded(c, [&] {
+        if (!d1 || (c->cfg.paired && !d2)) throw ScsError(SCS_EINVAL, "scs_yield_reads_device: null output buffer");
+        double t = now_s(); OutTarget tg{true, (char*)d1, (char*)d2, cap1, cap2, nullptr, nullptr}; do_yield(c, tg, n1, n2, pairs); c->st.t_stage[5] = now_s() - t;
+    });
+}
+int scs_run_genreads(scs_ctx* c, scs_sink_fn sink, void* user) {
+    int rc; double t = now_s();
+    if ((rc = scs_create_frags(c))) return rc;
+    if ((rc = scs_amplify(c))) return rc;
+    if ((rc = scs_allocate_reads(c, 0))) return rc;
+    if ((rc = scs_yield_reads(c, sink, user))) return rc;
+    c->st.t_stage[7] = now_s() - t; return SCS_OK;
+}
+int scs_get_stats(const scs_ctx* c, scs_stats* out) { if (!c || !out) return SCS_EINVAL; *out = c->st; return SCS_OK; }
+
+int scs_kernel_time(const scs_ctx* c, int which, const char** name, uint64_t* launches, double* ms) {
+    if (!c) return SCS_EINVAL;
+    const KernelTimer* t[] = {&c->tm_errscan, &c->tm_errscan_f, &c->tm_reads, &c->tm_attach, &c->tm_format};
+    if (which < 0 || which >= 5) return SCS_EINVAL;
+    if (name) *name = t[which]->name; if (launches) *launches = t[which]->launches; if (ms) *ms = t[which]->ms;
+    return SCS_OK;
+}
+
+int scs_predict_batch(scs_ctx* c, const uint8_t* windows, size_t n_reads, const uint64_t* uids, const uint32_t* attempts, const uint8_t* is_read1,
+                      char* out_bases, char* out_quals, int32_t* out_len, int out_stride) {
+    return guarded(c, [&] {
+        if (!c->have_profile) throw ScsError(SCS_EINVAL, "scs_predict_batch: load a profile first");
+        if (n_reads > 0x7FFFFFFFull) throw ScsError(SCS_EINVAL, "too many reads");
+        hipStream_t s = c->stream; const uint32_t L = (uint32_t)c->prof.read_length, slot = ((L + 64 + 63) / 64) * 64, n = (uint32_t)n_reads;
+        if (out_stride < (int)slot) throw ScsError(SCS_EINVAL, "out_stride must be >= " + std::to_string(slot));
+        DevBuf dw, du, da, dr; dw.reserve(std::max<size_t>((size_t)n * L, 16), s); du.reserve(std::max<size_t>((size_t)n * 8, 16), s);
+        da.reserve(std::max<size_t>((size_t)n * 4, 16), s); dr.reserve(std::max<size_t>(n, 16), s);
+        HIP_OK(hipMemcpyAsync(dw.p, windows, (size_t)n * L, hipMemcpyHostToDevice, s)); HIP_OK(hipMemcpyAsync(du.p, uids, (size_t)n * 8, hipMemcpyHostToDevice, s));
+        HIP_OK(hipMemcpyAsync(da.p, attempts, (size_t)n * 4, hipMemcpyHostToDevice, s)); HIP_OK(hipMemcpyAsync(dr.p, is_read1, n, hipMemcpyHostToDevice, s));
+        c->slot_b.reserve((size_t)n * slot, s); c->slot_q.reserve((size_t)n * slot, s); c->lens.reserve(std::max<size_t>((size_t)n * 4, 16), s);
+        launch_predict_windows(s, dw.as<uint8_t>(), n, du.as<uint64_t>(), da.as<uint32_t>(), dr.as<uint8_t>(), c->dtb, c->key, slot, c->slot_b.as<char>(),
+                               c->slot_q.as<char>(), c->lens.as<uint32_t>(), c->flags.as<uint32_t>());
+        std::vector<char> hb((size_t)n * slot), hq((size_t)n * slot); std::vector<uint32_t> hl(n);
+        HIP_OK(hipMemcpyAsync(hb.data(), c->slot_b.p, hb.size(), hipMemcpyDeviceToHost, s)); HIP_OK(hipMemcpyAsync(hq.data(), c->slot_q.p, hq.size(), hipMemcpyDeviceToHost, s));
+        HIP_OK(hipMemcpyAsync(hl.data(), c->lens.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+        HIP_OK(hipStreamSynchronize(s));
+        dw.release(); du.release(); da.release(); dr.release();
+        check_flags(c);
+        for (uint32_t i = 0; i < n; ++i) { out_len[i] = (int32_t)hl[i]; memcpy(out_bases + (size_t)i * out_stride, hb.data() + (size_t)i * slot, hl[i]); memcpy(out_quals + (size_t)i * out_stride, hq.data() + (size_t)i * slot, hl[i]); }
+    });
+}
+
+int scs_philox_batch(scs_ctx* c, const uint32_t* ctr, size_t n, const uint32_t* key, uint32_t* out) {
+    return guarded(c, [&] {
+        hipStream_t s = c->stream; DevBuf a, b; a.reserve(std::max<size_t>(n * 16, 16), s); b.reserve(std::max<size_t>(n * 16, 16), s);
+        HIP_OK(hipMemcpyAsync(a.p, ctr, n * 16, hipMemcpyHostToDevice, s));
+        launch_philox(s, a.as<uint32_t>(), (uint32_t)n, RngKey{key[0], key[1]}, b.as<uint32_t>());
+        HIP_OK(hipMemcpyAsync(out, b.p, n * 16, hipMemcpyDeviceToHost, s)); HIP_OK(hipStreamSynchronize(s)); a.release(); b.release();
+    });
+}
+int scs_detlog_batch(scs_ctx* c, const double* x, size_t n, double* out) {
+    return guarded(c, [&] {
+        hipStream_t s = c->stream; DevBuf a, b; a.reserve(std::max<size_t>(n * 8, 16), s); b.reserve(std::max<size_t>(n * 8, 16), s);
+        HIP_OK(hipMemcpyAsync(a.p, x, n * 8, hipMemcpyHostToDevice, s));
+        launch_detlog(s, a.as<double>(), (uint32_t)n, b.as<double>());
+        HIP_OK(hipMemcpyAsync(out, b.p, n * 8, hipMemcpyDeviceToHost, s)); HIP_OK(hipStreamSynchronize(s)); a.release(); b.release();
+    });
+}
+
+int scs_download_amplicons(scs_ctx* c, int kind, uint32_t* parent, uint32_t* spos, uint32_t* len, uint32_t* gc, uint32_t* primers, uint64_t* uid,
+                           uint32_t* errs, uint32_t* nerr) {
+    return guarded(c, [&] {
+        if (!c->amplified) throw ScsError(SCS_EINVAL, "scs_download_amplicons: call scs_amplify first");
+        AmpStore& A = kind == 0 ? c->semis : c->fulls; const uint32_t n = A.n; hipStream_t s = c->stream; DevAmps v = A.view();
+        std::vector<uint32_t> hsl(n), hp(n); std::vector<uint16_t> hgc(n), hpr(n); std::vector<uint64_t> hu(n), he(n);
+        if (n) {
+            HIP_OK(hipMemcpyAsync(hp.data(), v.parent, (size_t)n * 4, hipMemcpyDeviceToHost, s)); HIP_OK(hipMemcpyAsync(hsl.data(), v.sl, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+            HIP_OK(hipMemcpyAsync(hgc.data(), v.gc, (size_t)n * 2, hipMemcpyDeviceToHost, s)); HIP_OK(hipMemcpyAsync(hpr.data(), v.primers, (size_t)n * 2, hipMemcpyDeviceToHost, s));
+            HIP_OK(hipMemcpyAsync(hu.data(), v.uid, (size_t)n * 8, hipMemcpyDeviceToHost, s)); HIP_OK(hipMemcpyAsync(he.data(), v.errs, (size_t)n * 8, hipMemcpyDeviceToHost, s));
+        }
+        uint32_t used = 0; HIP_OK(hipMemcpyAsync(&used, A.pool_head.p, 4, hipMemcpyDeviceToHost, s)); HIP_OK(hipStreamSynchronize(s));
+        std::vector<uint32_t> pool(std::min(used, A.pool_cap));
+        if (!pool.empty()) { HIP_OK(hipMemcpyAsync(pool.data(), A.pool.p, pool.size() * 4, hipMemcpyDeviceToHost, s)); HIP_OK(hipStreamSynchronize(s)); }
+        for (uint32_t i = 0; i < n; ++i) {
+            if (parent) parent[i] = hp[i]; if (spos) spos[i] = sl_spos(hsl[i]); if (len) len[i] = sl_len(hsl[i]); if (gc) gc[i] = hgc[i];
+            if (primers) primers[i] = hpr[i]; if (uid) uid[i] = hu[i];
+            uint32_t cnt = 0; uint32_t e4[4] = {0, 0, 0, 0};
+            if (he[i] & ERR_OVERFLOW_BIT) { const uint32_t off = (uint32_t)he[i]; cnt = (uint32_t)(he[i] >> 32) & 0xFFFF; for (uint32_t k = 0; k < std::min(cnt, 4u); ++k) { uint32_t e = pool[off + k]; e4[k] = (err_pos(e) << 3) | err_alt(e); } }
+            else for (int k = 0; k < 4; ++k) { uint32_t e = (uint32_t)(he[i] >> (16 * k)) & 0xFFFF; if (e) e4[cnt++] = (err_pos(e) << 3) | err_alt(e); }
+            if (errs) memcpy(errs + 4 * (size_t)i, e4, 16); if (nerr) nerr[i] = cnt;
+        }
+    });
+}
+int scs_download_read_numbers(scs_ctx* c, uint32_t* rn) {
+    return guarded(c, [&] { if (!c->allocated) throw ScsError(SCS_EINVAL, "call scs_allocate_reads first"); memcpy(rn, c->h_read_numbers.data(), c->h_read_numbers.size() * 4); });
+}
+
+int scs_profile_open(const char* path, int paired, int isize, void** handle, char* errbuf, size_t errlen) {
+    if (!path || !handle) return SCS_EINVAL;
+    ProfileTables* T = new ProfileTables;
+    try { load_profile(path, paired != 0, isize, *T); }
+    catch (const std::exception& e) { if (errbuf && errlen) { strncpy(errbuf, e.what(), errlen - 1); errbuf[errlen - 1] = 0; } delete T; *handle = nullptr; return SCS_EIO; }
+    *handle = T; return SCS_OK;
+}
+int scs_profile_table(void* handle, int which, const uint32_t** thr, const double** cdf, size_t* n) {
+    if (!handle) return SCS_EINVAL;
+    ProfileTables* T = (ProfileTables*)handle;
+    const std::vector<uint32_t>* t; const std::vector<double>* d;
+    switch (which) {
+        case 0: t = &T->subs1_t; d = &T->subs1; break; case 1: t = &T->subs2_t; d = &T->subs2; break; case 2: t = &T->qual_t; d = &T->qual; break;
+        case 3: t = &T->ins_t; d = &T->ins_cdf; break; case 4: t = &T->del_t; d = &T->del_cdf; break; case 5: t = &T->isize_t; d = &T->isize_cdf; break;
+        default: return SCS_EINVAL;
+    }
+    if (thr) *thr = t->data(); if (cdf) *cdf = d->data(); if (n) *n = t->size();
+    return SCS_OK;
+}
+int scs_profile_scalars(void* handle, double* out) {
+    if (!handle || !out) return SCS_EINVAL;
+    ProfileTables* T = (ProfileTables*)handle;
+    out[0] = T->read_length; out[1] = T->bins; out[2] = T->t_insert; out[3] = T->t_delete; out[4] = T->isize_min; out[5] = T->have_cdf2; out[6] = T->insert_rate; out[7] = T->del_rate;
+    return SCS_OK;
+}
+void scs_profile_close(void* handle) { delete (ProfileTables*)handle; }
+
+}  // extern "C"

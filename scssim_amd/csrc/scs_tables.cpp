@@ -1,0 +1,261 @@
+// scs_tables.cpp -- .profile loader, table builder and FASTA staging (host).
+// Reference behaviour followed: lib/profile/Profile.cpp:930-1234 (load), 832-863 + 897-927
+// (normParas(true)), 1363-1430 (initCDFs), lib/matrix/Matrix.h:483-522 (normalize, cumsum),
+// lib/mydefine/MyDefine.cpp:54-57 (normpdf), 274-282 (randIndx), 337-349 (getNextLine);
+// lib/fastahack/Fasta.cpp:45-215 + lib/genome/Genome.cpp:176-195,272-278 (FASTA).
+#include "scs_tables.h"
+#include "scs_common.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <stdexcept>
+
+namespace scs {
+
+static const double kZeroFinal = 2.2204e-16;      // MyDefine.cpp:20 / Matrix.h:86
+
+// ---------------------------------------------------------------- exact thresholds
+template <class Pred>   // pred(x) monotone: true for x < T, false from T on; returns T clamped to 2^32-1
+static uint32_t count_true(Pred pred) {
+    uint64_t lo = 0, hi = 1ull << 32;           // invariant: pred true below lo, false from hi on
+    while (lo < hi) {
+        uint64_t mid = (lo + hi) >> 1;
+        if (pred((uint32_t)mid)) lo = mid + 1; else hi = mid;
+    }
+    return lo > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)lo;
+}
+uint32_t threshold_lt(double c) { return count_true([c](uint32_t x) { return (x / 4294967296.0) < c; }); }
+uint32_t threshold_le(double c) { return count_true([c](uint32_t x) { return (x / 4294967296.0) <= c; }); }
+uint32_t threshold_cdf(double c) {
+    return count_true([c](uint32_t x) { double r = kZeroFinal + (1 - kZeroFinal) * (x / 4294967296.0); return r <= c; });
+}
+
+// ---------------------------------------------------------------- small text helpers
+static std::string strip(const std::string& s) {
+    size_t a = 0, b = s.size();
+    while (a < b && strchr(" \t\r\n", s[a])) ++a;
+    while (b > a && strchr(" \t\r\n", s[b - 1])) --b;
+    return s.substr(a, b - a);
+}
+static void split_on(const std::string& s, char d, std::vector<std::string>& out) {
+    out.clear();
+    size_t p = 0;
+    if (s.empty()) return;
+    for (;;) {
+        size_t q = s.find(d, p);
+        if (q == std::string::npos) { out.push_back(s.substr(p)); break; }
+        out.push_back(s.substr(p, q - p));
+        p = q + 1;
+        if (p == s.size()) break;               // std::getline semantics: no trailing empty field
+    }
+}
+
+namespace {
+struct ProfileReader {
+    std::ifstream ifs; std::string path; int line_no = 0;
+    explicit ProfileReader(const std::string& p) : ifs(p), path(p) {
+        if (!ifs.is_open()) throw std::runtime_error("can not open file " + p);
+    }
+    bool next(std::string& line) {               // skips blank lines and '#' comments
+        while (std::getline(ifs, line)) { ++line_no; if (!line.empty() && line[0] != '#') return true; }
+        line.clear(); return false;
+    }
+    std::string need() { std::string l; if (!next(l)) bad("unexpected end of file"); return l; }
+    [[noreturn]] void bad(const std::string& why) {
+        throw std::runtime_error("Error: malformed model file " + path + " @line " + std::to_string(line_no) + ": " + why);
+    }
+    void row(std::vector<double>& dst, size_t expect) {
+        std::string l = need(); std::vector<std::string> f; split_on(l, '\t', f);
+        if (expect && f.size() != expect) bad("wrong number of columns");
+        dst.resize(f.size());
+        for (size_t i = 0; i < f.size(); ++i) dst[i] = atof(strip(f[i]).c_str());
+    }
+};
+}  // namespace
+
+static void normalize_rows(double* m, size_t rows, size_t cols) {
+    for (size_t r = 0; r < rows; ++r) {
+        double* p = m + r * cols; double sum = 0;
+        for (size_t c = 0; c < cols; ++c) sum += p[c];
+        const double den = kZeroFinal + sum;
+        for (size_t c = 0; c < cols; ++c) p[c] /= den;
+    }
+}
+static void cumsum_rows(double* m, size_t rows, size_t cols) {
+    for (size_t r = 0; r < rows; ++r) { double* p = m + r * cols; for (size_t c = 1; c < cols; ++c) p[c] = p[c] + p[c - 1]; }
+}
+static int kmer_row(const std::string& k) {       // order of Profile::initKmers (Profile.cpp:69-123)
+    auto code = [](char c) { switch (c) { case 'A': return 0; case 'C': return 1; case 'G': return 2; case 'T': return 3; case 'X': return 5; } return -1; };
+    if (k.size() != 3) return -1;
+    int a = code(k[0]), b = code(k[1]), c = code(k[2]);
+    if (c < 0 || c > 3) return -1;
+    if (a == 5 && b == 5) return c;
+    if (a == 5 && b >= 0 && b < 4) return 4 + b * 4 + c;
+    if (a >= 0 && a < 4 && b >= 0 && b < 4) return 20 + a * 16 + b * 4 + c;
+    return -1;
+}
+
+void load_profile(const std::string& path, bool paired, int isize, ProfileTables& T) {
+    ProfileReader rd(path);
+    std::string bases, line; int bin_count = -1, kmer = -1, read_len = -1;
+    std::vector<std::string> f;
+    while (rd.next(line)) {                        // header: four "key: value" lines in any order
+        split_on(line, ':', f);
+        if (f.size() != 2) rd.bad(line);
+        const std::string k = strip(f[0]), v = strip(f[1]);
+        if (k == "bases") bases = v; else if (k == "binCount") bin_count = atoi(v.c_str());
+        else if (k == "kmer") kmer = atoi(v.c_str()); else if (k == "readLength") read_len = atoi(v.c_str());
+        else rd.bad(line);
+        if (!bases.empty() && bin_count > 0 && kmer > 0 && read_len > 0) break;
+    }
+    if (bases.empty() || bin_count <= 0 || kmer <= 0 || read_len <= 0) throw std::runtime_error("Error: malformed model file " + path);
+    if (bases != "ACGT" || kmer != 3) throw std::runtime_error("Error: only bases ACGT / kmer 3 profiles are supported: " + path);
+    // Profile::init sets bins := readLength (Profile.cpp:183) while load() reads binCount rows; the
+    // reference is only well-defined when both agree (all shipped profiles do).
+    if (bin_count != read_len) throw std::runtime_error("Error: profile binCount must equal readLength: " + path);
+    const size_t B = (size_t)read_len;
+    T.read_length = read_len; T.bins = read_len;
+    T.subs1.assign(NKMER * B * 4, 0.0); T.subs2.assign(NKMER * B * 4, 0.0); T.qual.assign(16 * B * 94, 0.0);
+    std::vector<double> ins_f(1, 0.0), del_f(1, 0.0), tmp;
+    int sections = 0;
+    while (rd.next(line)) {
+        if (line == "[Insert Rate]") { T.insert_rate = atof(strip(rd.need()).c_str()); ++sections; }
+        else if (line == "[Insert Frequency]") { rd.row(ins_f, 0); ++sections; }
+        else if (line == "[Deletion Rate]") { T.del_rate = atof(strip(rd.need()).c_str()); ++sections; }
+        else if (line == "[Deletion Frequency]") { rd.row(del_f, 0); ++sections; }
+        else if (line == "[Substitution Probs]") {
+            for (int i = 0; i < NKMER; ++i) {
+                split_on(rd.need(), ':', f);
+                if (f.size() != 2 || strip(f[0]) != "kmer") rd.bad("expected kmer header");
+                const int row = kmer_row(strip(f[1]));
+                if (row < 0) rd.bad("unrecognized kmer");
+                for (size_t j = 0; j < 2 * B; ++j) {
+                    rd.row(tmp, 4);
+                    double* dst = (j < B ? T.subs1.data() : T.subs2.data()) + ((size_t)row * B + (j < B ? j : j - B)) * 4;
+                    memcpy(dst, tmp.data(), 4 * sizeof(double));
+                }
+            }
+            ++sections;
+        }
+        else if (line == "[Base Quality Distribution]") {
+            for (int i = 0; i < 16; ++i) {
+                split_on(rd.need(), ':', f);
+                if (f.size() != 2 || strip(f[0]) != "basePairIndx") rd.bad("expected basePairIndx header");
+                const int bp = atoi(strip(f[1]).c_str());
+                if (bp < 0 || bp > 15) rd.bad("unrecognized basePairIndx");
+                for (size_t j = 0; j < B; ++j) { rd.row(tmp, 94); memcpy(T.qual.data() + ((size_t)bp * B + j) * 94, tmp.data(), 94 * sizeof(double)); }
+            }
+            ++sections;
+        }
+        else if (line == "[Insert Size Standard Deviation]") { T.std_isize = atof(strip(rd.need()).c_str()); ++sections; }
+        else if (line == "[Log Ratio Mean Value]") {
+            for (int j = 0; j < 101; ++j) {
+                split_on(rd.need(), '\t', f);
+                if (f.size() != 2) rd.bad("expected gc<TAB>mean");
+                const int gc = atoi(f[0].c_str());
+                if (gc < 0 || gc > 100) rd.bad("gc out of range");
+                T.gc_means[gc] = atof(f[1].c_str());
+            }
+            ++sections;
+        }
+        else if (line == "[Log Ratio Standard Deviation]") { T.gc_std = atof(strip(rd.need()).c_str()); ++sections; }
+    }
+    if (sections < 9) throw std::runtime_error("Error: corrupted model file " + path + ", failed to load some parameters!");
+
+    // normParas(true): row-normalise; all-zero rows get probability 1 on the k-mer's own last base
+    for (int i = 0; i < NKMER; ++i) {
+        const int own = i < 4 ? i : (i - 4) % 4;     // (i-20)%4 == (i-4)%4
+        for (std::vector<double>* M : {&T.subs1, &T.subs2}) {
+            double* m = M->data() + (size_t)i * B * 4;
+            normalize_rows(m, B, 4);
+            for (size_t j = 0; j < B; ++j) { double s = 0; for (int k = 0; k < 4; ++k) s += m[j * 4 + k]; if (s < kZeroFinal) m[j * 4 + own] = 1; }
+        }
+    }
+    normalize_rows(T.qual.data(), 16 * B, 94);       // normParas ...
+    normalize_rows(T.qual.data(), 16 * B, 94);       // ... and again in initCDFs (Profile.cpp:1393)
+    cumsum_rows(T.qual.data(), 16 * B, 94);
+    cumsum_rows(T.subs1.data(), NKMER * B, 4);
+    T.have_cdf2 = paired && T.std_isize > 0;
+    if (T.have_cdf2) cumsum_rows(T.subs2.data(), NKMER * B, 4); else T.subs2.clear();
+    T.ins_cdf = ins_f; cumsum_rows(T.ins_cdf.data(), 1, T.ins_cdf.size());
+    T.del_cdf = del_f; cumsum_rows(T.del_cdf.data(), 1, T.del_cdf.size());
+    T.isize_cdf.clear(); T.isize_min = 0;
+    if (paired && T.std_isize > 0) {                 // insert-size alphabet + discretised normal (Profile.cpp:908-926)
+        const int mean = isize + 1, interval = (int)(6 * T.std_isize);
+        const int lo = std::max(mean - interval / 2, read_len), hi = 2 * mean - lo;
+        const double PI = 3.1415926;
+        for (int x = lo; x <= hi; ++x)
+            T.isize_cdf.push_back(exp(-pow((double)x - mean, 2) / (2 * pow(T.std_isize, 2))) / (sqrt(2 * PI) * T.std_isize));
+        if (T.isize_cdf.empty()) throw std::runtime_error("Error: empty insert size range (isize too small for this profile)");
+        normalize_rows(T.isize_cdf.data(), 1, T.isize_cdf.size());
+        cumsum_rows(T.isize_cdf.data(), 1, T.isize_cdf.size());
+        T.isize_min = lo;
+    }
+    auto to_thr = [](const std::vector<double>& c, std::vector<uint32_t>& t) { t.resize(c.size()); for (size_t i = 0; i < c.size(); ++i) t[i] = threshold_cdf(c[i]); };
+    to_thr(T.subs1, T.subs1_t); to_thr(T.subs2, T.subs2_t); to_thr(T.qual, T.qual_t);
+    to_thr(T.ins_cdf, T.ins_t); to_thr(T.del_cdf, T.del_t); to_thr(T.isize_cdf, T.isize_t);
+    T.t_insert = threshold_le(T.insert_rate);
+    T.t_delete = threshold_lt(T.del_rate / (1 - T.insert_rate));
+}
+
+// ---------------------------------------------------------------- FASTA
+static inline uint8_t base_code(char c) {
+    switch (c) { case 'A': case 'a': return 0; case 'C': case 'c': return 1; case 'G': case 'g': return 2; case 'T': case 't': return 3; default: return 4; }
+}
+static std::string index_name(const std::string& header) {      // Fasta.cpp:56-68: first token, "chrom"/"chr" prefix dropped
+    std::string nm = header;
+    size_t e = nm.find_first_of(" \t");
+    if (e != std::string::npos) nm.resize(e);
+    size_t i = nm.find("chrom");
+    if (i != std::string::npos) return nm.substr(i + 5);
+    i = nm.find("chr");
+    if (i != std::string::npos) return nm.substr(i + 3);
+    return nm;
+}
+void encode_record(const char* name, const char* seq, uint64_t len, FastaRecord& out) {
+    out.name = index_name(name);
+    out.code.resize(len);
+    for (uint64_t i = 0; i < len; ++i) out.code[i] = base_code(seq[i]);
+}
+void load_fasta(const std::string& path_in, std::vector<FastaRecord>& out) {
+    std::string path = path_in;
+    if (path.empty()) throw std::runtime_error("reference sequence file not specified!");
+    if (path.size() > 3 && path.compare(path.size() - 3, 3, ".gz") == 0) {      // Genome.cpp:183-187
+        const std::string plain = path.substr(0, path.size() - 3);
+        const std::string cmd = "gzip -cd " + path + " > " + plain;
+        if (system(cmd.c_str()) != 0) throw std::runtime_error("could not inflate " + path);
+        path = plain;
+    }
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) throw std::runtime_error("could not open " + path);
+    out.clear();
+    std::vector<char> buf(1 << 22);
+    std::string header; bool in_header = false, line_start = true, skip_line = false;
+    size_t n;
+    while ((n = fread(buf.data(), 1, buf.size(), f)) > 0) {
+        for (size_t i = 0; i < n; ++i) {
+            const char c = buf[i];
+            if (c == '\n') {
+                if (in_header) { out.push_back(FastaRecord{index_name(header), {}}); header.clear(); in_header = false; }
+                line_start = true; skip_line = false; continue;
+            }
+            if (line_start) {
+                line_start = false;
+                if (c == '>') { in_header = true; continue; }
+                if (c == ';') { skip_line = true; continue; }
+            }
+            if (in_header) { header.push_back(c); continue; }
+            if (skip_line || c == '\r') continue;
+            if (out.empty()) { fclose(f); throw std::runtime_error("malformed FASTA (sequence before header): " + path); }
+            out.back().code.push_back(base_code(c));
+        }
+    }
+    fclose(f);
+    if (in_header) out.push_back(FastaRecord{index_name(header), {}});
+    if (out.empty()) throw std::runtime_error("ERROR: reference sequence cannot be empty!");
+}
+
+}  // namespace scs

@@ -1,0 +1,43 @@
+// scs_tables.h -- host side of the .profile model: parse, normalise, CDFs, exact integer thresholds.
+// Mirrors Profile::train(file) = load + normParas(true) + initCDFs (reference lib/profile/Profile.cpp:
+// 930-1234, 832-863/897-927, 1363-1430) and Matrix::normalize/cumsum (lib/matrix/Matrix.h:483-522).
+#pragma once
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+namespace scs {
+
+struct ProfileTables {
+    int read_length = 0, bins = 0;
+    double insert_rate = 0, del_rate = 0, std_isize = 0, gc_std = 0;
+    double gc_means[101];
+    bool have_cdf2 = false;              // read 2 has its own substitution table (PE and sigma_isize > 0)
+    // CDFs in double, exactly as the reference holds them (ground truth; also the device slow path)
+    std::vector<double> subs1, subs2;    // [84][bins][4]
+    std::vector<double> qual;            // [16][bins][94]
+    std::vector<double> ins_cdf, del_cdf, isize_cdf;
+    int isize_min = 0;                   // iSizeAlphabet[k] = isize_min + k
+    // Every CDF lookup in the reference is `r <= cdf[k]` with r = 2.2204e-16 + (1-2.2204e-16) * x/2^32
+    // (MyDefine.cpp:274-282), monotone in the 32-bit draw x.  T[k] = #{x : r(x) <= cdf[k]} clamped to
+    // 2^32-1, so the lookup is `x < T[k]`; exact for every x except x == 0xFFFFFFFF, which the kernels
+    // route to the double tables.
+    std::vector<uint32_t> subs1_t, subs2_t, qual_t, ins_t, del_t, isize_t;
+    uint32_t t_insert = 0;               // p <= insertRate            (Profile.cpp:1557)
+    uint32_t t_delete = 0;               // p <  delRate/(1-insertRate) (Profile.cpp:1565-1566)
+};
+
+// count of 32-bit draws x with (x / 2^32) < c  resp. <= c, clamped to 2^32-1
+uint32_t threshold_lt(double c);
+uint32_t threshold_le(double c);
+// count of x with r(x) <= c for the randIndx mapping, clamped to 2^32-1
+uint32_t threshold_cdf(double c);
+
+// Throws std::runtime_error with the reference's message where it has one.
+void load_profile(const std::string& path, bool paired, int isize, ProfileTables& out);
+
+struct FastaRecord { std::string name; std::vector<uint8_t> code; };   // codes 0..3 ACGT, 4 other
+void load_fasta(const std::string& path, std::vector<FastaRecord>& out);
+void encode_record(const char* name, const char* seq, uint64_t len, FastaRecord& out);
+
+}  // namespace scs

@@ -1,0 +1,194 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle in counter mode.
+Bit-exact: integer / byte work.  Run with `-m gpu` on the MI355X box."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+import scssim_amd
+
+pytestmark = pytest.mark.gpu
+
+MODELS = ["Illumina_HiSeq2500", "Illumina_HiSeqXTen", "Illumina_HiSeq2000", "Illumina_GenomeAnalyzerIIx"]
+
+
+def _oracle_run(oracle_bin, fasta, profile, prefix, args, seed, dump=None, threads=8):
+    cmd = [oracle_bin, "genreads", "-i", fasta, "-m", profile, "-o", prefix, "--rng", "counter", "--seed", str(seed),
+           "-t", str(threads), "-q"] + args
+    if dump:
+        cmd += ["--dump", dump]
+    subprocess.check_call(cmd)
+
+
+def test_philox_device_matches_oracle(oracle_lib):
+    g = scssim_amd.GenReads()
+    rng = np.random.default_rng(1)
+    ctr = rng.integers(0, 1 << 32, size=(4096, 4), dtype=np.uint64).astype(np.uint32)
+    ctr[0] = 0
+    ctr[1] = 0xFFFFFFFF
+    key = np.array([0xa4093822, 0x299f31d0], np.uint32)
+    got = g.philox(ctr, key)
+    want = np.zeros_like(ctr)
+    k = (ctypes.c_uint32 * 2)(*key.tolist())
+    for i in range(ctr.shape[0]):
+        c = (ctypes.c_uint32 * 4)(*ctr[i].tolist())
+        o = (ctypes.c_uint32 * 4)()
+        oracle_lib.scso_philox4x32_10(c, k, o)
+        want[i] = list(o)
+    assert np.array_equal(got, want)
+
+
+def test_det_log_device_bitwise(oracle_lib):
+    oracle_lib.scso_det_log.restype = ctypes.c_double
+    oracle_lib.scso_det_log.argtypes = [ctypes.c_double]
+    g = scssim_amd.GenReads()
+    rng = np.random.default_rng(2)
+    x = np.concatenate([rng.random(20000), 10 ** rng.uniform(-300, 300, 5000), [1.0, 2.0, 0.5, 1e-310, 5e-324, 1.4142135623730951]])
+    got = g.det_log(x)
+    want = np.array([oracle_lib.scso_det_log(float(v)) for v in x])
+    assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
+
+
+@pytest.mark.parametrize("model", MODELS)
+def test_predict_batch_matches_oracle(model, models, oracle_lib):
+    """Profile::predict (Profile.cpp:1582-1697) per read: indels, substitutions, qualities, N handling."""
+    oracle_lib.scso_profile_load.restype = ctypes.c_void_p
+    oracle_lib.scso_profile_load.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int]
+    oracle_lib.scso_predict_counter.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_uint64,
+                                                ctypes.c_uint64, ctypes.c_uint32, ctypes.c_char_p, ctypes.c_char_p]
+    seed = 0x1234567890ABCDEF
+    g = scssim_amd.GenReads(profile=models[model], seed=seed)
+    L = g.read_length
+    h = oracle_lib.scso_profile_load(models[model].encode(), 1, 260)
+    rng = np.random.default_rng(7)
+    n = 6000
+    win = rng.integers(0, 4, size=(n, L), dtype=np.uint8)
+    win[rng.random((n, L)) < 0.004] = 4                 # sprinkle N
+    win[5, :] = 4                                       # all-N read
+    win[6, :3] = 4                                      # N in the leading context
+    uids = rng.integers(0, 1 << 62, size=n, dtype=np.uint64)
+    atts = rng.integers(0, 1 << 20, size=n, dtype=np.uint64).astype(np.uint32)
+    rd1 = (rng.random(n) < 0.5).astype(np.uint8)
+    gb, gq = g.predict_batch(win, uids, atts, rd1)
+    ob = ctypes.create_string_buffer(4 * L + 256)
+    oq = ctypes.create_string_buffer(4 * L + 256)
+    lens = set()
+    for i in range(n):
+        m = oracle_lib.scso_predict_counter(h, win[i].ctypes.data_as(ctypes.c_void_p), L, int(rd1[i]), seed, int(uids[i]), int(atts[i]), ob, oq)
+        assert m > 0
+        lens.add(m)
+        assert gb[i] == ob.raw[:m], "bases differ for read %d" % i
+        assert gq[i] == oq.raw[:m], "qualities differ for read %d" % i
+    assert len(lens) > 3, "indels did not occur; the test would not exercise the prefix-sum path"
+
+
+CASES = [("g1_hiseq2500_pe", "Illumina_HiSeq2500", ["-c", "3"], "PE", 3.0, 260, {}),
+         ("g2_xten_pe_nblock", "Illumina_HiSeqXTen", ["-c", "4", "-s", "300"], "PE", 4.0, 300, {}),
+         ("g3_hiseq2000_se", "Illumina_HiSeq2000", ["-c", "2", "-l", "SE"], "SE", 2.0, 260, {}),
+         ("g4_gaiix_pe_lowprimers", "Illumina_GenomeAnalyzerIIx", ["-c", "2", "-p", "1000", "-r", "1e-8"], "PE", 2.0, 260,
+          dict(primers=1000, gamma=1e-8))]
+
+
+def _load_dump(path):
+    rows = []
+    for line in open(path):
+        f = line.rstrip("\n").split("\t")
+        errs = [tuple(int(v) for v in e.split(":")) for e in f[7].split(",")] if len(f) > 7 and f[7] else []
+        rows.append((int(f[1]), int(f[2]), int(f[3]), int(f[4]), int(f[5]), int(f[6]), errs))
+    return rows
+
+
+@pytest.mark.parametrize("case,model,oargs,layout,cov,isize,extra", CASES)
+def test_full_pipeline_fastq_bit_exact(case, model, oargs, layout, cov, isize, extra, oracle_bin, models, golden_inputs, tmp_path):
+    """End to end: fragments -> MALBAC cycles -> read allocation -> FASTQ, byte-identical to the oracle;
+    intermediate amplicon tables are compared too so a mismatch points at its stage."""
+    seed = 20240 + len(case)
+    prefix = str(tmp_path / "orc")
+    _oracle_run(oracle_bin, golden_inputs[case], models[model], prefix, oargs, seed, dump=prefix)
+    g = scssim_amd.GenReads(profile=models[model], input_fasta=golden_inputs[case], coverage=cov, isize=isize, layout=layout, seed=seed, **extra)
+    g.create_frags()
+    g.amplify()
+    for kind, name in ((0, "semis"), (1, "fulls")):
+        want = _load_dump(prefix + "." + name + ".tsv")
+        a = g.download_amplicons(kind)
+        assert len(want) == a["parent"].size, "%s count" % name
+        w = np.array([r[:6] for r in want], dtype=np.uint64).reshape(-1, 6)
+        for col, key in enumerate(("parent", "spos", "len", "gc")):
+            assert np.array_equal(a[key].astype(np.uint64), w[:, col]), "%s.%s" % (name, key)
+        assert np.array_equal(a["uid"], w[:, 5]), name + ".uid"
+        if kind == 0:
+            assert np.array_equal(a["primers"].astype(np.uint64), w[:, 4]), "semis.primers (last cycle budgets)"
+        for i, r in enumerate(want):
+            assert a["nerr"][i] == len(r[6]), "%s[%d] error count" % (name, i)
+            for k, (pos, alt) in enumerate(r[6][:4]):
+                assert a["errs"][i, k] == (pos << 3 | alt), "%s[%d] error %d" % (name, i, k)
+    g.allocate_reads(0)
+    rn = g.download_read_numbers()
+    want_rn = np.zeros_like(rn)
+    for line in open(prefix + ".readnum.tsv"):
+        i, v = line.split()
+        want_rn[int(i)] = int(v)
+    assert np.array_equal(rn, want_rn), "read allocation differs"
+    fq1, fq2 = g.yield_reads()
+    if layout == "PE":
+        assert fq1 == open(prefix + "_1.fq", "rb").read()
+        assert fq2 == open(prefix + "_2.fq", "rb").read()
+    else:
+        assert fq1 == open(prefix + ".fq", "rb").read()
+    st = g.stats()
+    assert st["pairs_written"] == fq1.count(b"\n") // 4
+    assert st["fastq_bytes"][0] == len(fq1) and st["fastq_bytes"][1] == len(fq2)
+    # re-running the same ctx with the same seed must reproduce the bytes (buffers are reused)
+    again1, again2 = g.run()
+    assert (again1, again2) == (fq1, fq2)
+
+
+def test_cli_drop_in(oracle_bin, models, golden_inputs, tmp_path):
+    """`scssim genreads` (the reference's CLI surface) writes the same files as the oracle CLI."""
+    exe = os.path.join(ROOT, "scssim_amd", "bin", "scssim")
+    out = str(tmp_path / "cli")
+    r = subprocess.run([exe, "genreads", "-i", golden_inputs["g1_hiseq2500_pe"], "-m", models["Illumina_HiSeq2500"], "-c", "2",
+                        "-o", out, "--seed", "99"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "MALBAC amplification..." in r.stderr and "Reads generation done!" in r.stderr
+    prefix = str(tmp_path / "orc")
+    _oracle_run(oracle_bin, golden_inputs["g1_hiseq2500_pe"], models["Illumina_HiSeq2500"], prefix, ["-c", "2"], 99)
+    assert open(out + "_1.fq", "rb").read() == open(prefix + "_1.fq", "rb").read()
+    assert open(out + "_2.fq", "rb").read() == open(prefix + "_2.fq", "rb").read()
+    bad = subprocess.run([exe, "genreads", "-i", "x.fa", "-m", "y", "-o", "z", "-p", "10"], capture_output=True, text=True)
+    assert bad.returncode == 1 and "should be at least 1000" in bad.stderr
+    ver = subprocess.run([exe, "-v"], capture_output=True, text=True)
+    assert "SCSsim version 1.0" in ver.stderr
+
+
+def test_full_size_properties(models, tmp_path):
+    """BASELINE config sized run (1 Mb, 30x): size-independent invariants instead of an oracle diff."""
+    fa = str(tmp_path / "simu.fa")
+    subprocess.check_call(["python3", os.path.join(ROOT, "tools", "make_genome.py"), "--lengths", "1000000", "--seed", "1", "--simu-out", fa])
+    g = scssim_amd.GenReads(profile=models["Illumina_HiSeq2500"], input_fasta=fa, coverage=30, seed=5)
+    fq1, fq2 = g.run()
+    st = g.stats()
+    L = g.read_length
+    assert st["reads_requested"] == 1000000 * 30 // L
+    assert abs(st["pairs_written"] * 2 - st["reads_requested"]) <= 2
+    assert 350000 < st["full_amplicons"] < 470000 and 35000 < st["semi_amplicons"] < 55000     # ~4.1e5 / ~4.5e4 per Mb
+    l1, l2 = fq1.split(b"\n"), fq2.split(b"\n")
+    assert len(l1) == len(l2) == 4 * st["pairs_written"] + 1
+    names1, names2 = l1[0::4][:-1], l2[0::4][:-1]
+    assert all(a[:-1] == b[:-1] and a.endswith(b"/1") and b.endswith(b"/2") for a, b in zip(names1, names2))
+    idx = np.array([int(n[1:n.index(b"#")]) for n in names1])
+    assert (np.diff(idx) >= 0).all(), "records must come in amplicon order"
+    lens = np.array([len(s) for s in l1[1::4]])
+    assert lens.min() >= 50 and abs(lens.mean() - L) < 1.0 and (lens != L).mean() < 0.3
+    assert all(len(s) == len(q) for s, q in zip(l1[1::4], l1[3::4]))
+    q = np.frombuffer(b"".join(l1[3::4]), np.uint8)
+    assert q.min() >= 33 and q.max() <= 126
+    # same seed -> same bytes; different seed -> different bytes
+    g2 = scssim_amd.GenReads(profile=models["Illumina_HiSeq2500"], input_fasta=fa, coverage=30, seed=5)
+    assert g2.run() == (fq1, fq2)
+    g2.set_seed(6)
+    assert g2.run()[0] != fq1

@@ -1,0 +1,110 @@
+"""CPU-only checks of the product's host logic and of the C-ABI surface (no compute calls without a GPU)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+import scssim_amd
+
+ZF = 2.2204e-16
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "scssim_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = set(re.findall(r"\b(scs_[a-z_0-9]+)\s*\(", hdr)) - {"scs_sink_fn"}
+    assert len(names) >= 20
+    lib = scssim_amd.load_library()
+    for n in sorted(names):
+        assert hasattr(lib, n), "libscssim_hip.so does not export %s" % n
+
+
+def test_no_cpu_fallback_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(scssim_amd.ScsError) as e:
+        scssim_amd.GenReads()
+    assert "no HIP device" in str(e.value)
+
+
+def _r(x):
+    return ZF + (1 - ZF) * (x.astype(np.float64) / 4294967296.0)
+
+
+@pytest.mark.parametrize("model", ["Illumina_HiSeq2500", "Illumina_HiSeqXTen", "Illumina_HiSeq2000", "Illumina_GenomeAnalyzerIIx"])
+def test_thresholds_equal_the_reference_double_comparison(model, models, oracle_lib):
+    """`x < T[k]` must equal the reference's `r(x) <= cdf[k]` (MyDefine.cpp:274-282) for the oracle's
+    independently built CDF tables: checked at both sides of every threshold and at random draws."""
+    P = scssim_amd.Profile(models[model], paired=True, isize=260)
+    oracle_lib.scso_profile_load.restype = ctypes.c_void_p
+    oracle_lib.scso_profile_load.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int]
+    oracle_lib.scso_profile_table.restype = ctypes.c_size_t
+    oracle_lib.scso_profile_table.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.POINTER(ctypes.c_double))]
+    h = oracle_lib.scso_profile_load(models[model].encode(), 1, 260)
+    assert h
+    rng = np.random.default_rng(5)
+    for name, which in (("subs1", 0), ("subs2", 1), ("qual", 2), ("ins", 3), ("del", 4), ("isize", 5)):
+        thr, cdf = P.table(name)
+        p = ctypes.POINTER(ctypes.c_double)()
+        n = oracle_lib.scso_profile_table(h, which, ctypes.byref(p))
+        ocdf = np.ctypeslib.as_array(p, (n,)).copy()
+        assert n == thr.size, name
+        assert np.array_equal(ocdf, cdf), "%s: product CDF differs from the oracle's" % name
+        t = thr.astype(np.uint64)
+        below = np.where(t > 0, t - 1, 0)                  # largest x that must satisfy (when T > 0)
+        ok_below = (_r(below) <= ocdf) | (t == 0)
+        assert ok_below.all(), name
+        at = np.minimum(t, 0xFFFFFFFF)                     # first x that must fail (unless clamped)
+        fails = ~(_r(at) <= ocdf)
+        clamped = t == 0xFFFFFFFF
+        assert (fails | clamped).all(), name
+        x = rng.integers(0, 1 << 32, size=thr.size, dtype=np.uint64)
+        x = np.minimum(x, 0xFFFFFFFE)
+        assert np.array_equal(x < t, _r(x) <= ocdf), name
+    oracle_lib.scso_profile_free.argtypes = [ctypes.c_void_p]
+    oracle_lib.scso_profile_free(h)
+    assert P.read_length in (74, 75, 125, 151) and P.bins == P.read_length
+    # rate thresholds: p <= insertRate / p < delRate/(1-insertRate) with p = x/2^32
+    ti, td = P.t_insert, P.t_delete
+    assert ((ti - 1) / 4294967296.0 <= P.insert_rate) and not (ti / 4294967296.0 <= P.insert_rate)
+    c = P.del_rate / (1 - P.insert_rate)
+    assert ((td - 1) / 4294967296.0 < c) and not (td / 4294967296.0 < c)
+
+
+def test_profile_errors_are_reported(tmp_path):
+    bad = tmp_path / "bad.profile"
+    bad.write_text("bases: ACGT\nreadLength: 10\nbinCount: 10\nkmer: 3\n[Insert Rate]\n0.1\n")
+    with pytest.raises(scssim_amd.ScsError) as e:
+        scssim_amd.Profile(str(bad))
+    assert "corrupted model file" in str(e.value)
+    with pytest.raises(scssim_amd.ScsError):
+        scssim_amd.Profile(str(tmp_path / "missing.profile"))
+
+
+def test_philox_known_answers(oracle_lib):
+    """Random123 known-answer vectors for Philox4x32-10."""
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0), (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in kat:
+        c = (ctypes.c_uint32 * 4)(*ctr)
+        k = (ctypes.c_uint32 * 2)(*key)
+        o = (ctypes.c_uint32 * 4)()
+        oracle_lib.scso_philox4x32_10(c, k, o)
+        assert tuple(o) == want
+
+
+def test_det_log_is_accurate(oracle_lib):
+    import math
+    oracle_lib.scso_det_log.restype = ctypes.c_double
+    oracle_lib.scso_det_log.argtypes = [ctypes.c_double]
+    rng = np.random.default_rng(3)
+    xs = np.concatenate([rng.random(2000), 10 ** rng.uniform(-300, 300, 2000), [1.0, 2.0, 0.5, 1e-310]])
+    for x in xs:
+        got, want = oracle_lib.scso_det_log(float(x)), math.log(float(x))
+        assert abs(got - want) <= 4.5e-16 * max(1.0, abs(want)), x
