@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""bench.py -- genreads hot path on N MI355X (one process per GPU).
+
+Metric (BASELINE.json): paired-end read pairs/s, whole job, inputs resident in HBM, plus the HBM
+roofline fraction of the dominant kernel and the CPU path timed on this box's host cores.
+
+Workload at N=1 = BASELINE configs[1]: 1 Mb synthetic reference (i.i.d. 30/20/20/30 % A/C/G/T, seed 1,
+diploid simuvars-style FASTA), PE150 at 30x, HiSeq2500 model.  The reference ships no 150 bp model and
+takes the read length from the profile only, so "PE150" = the shipped HiSeq2500 profile with its bin
+axis resampled 125 -> 150 (tools/make_profile.py).  One step = one complete job
+(fragment split, 1+5 MALBAC cycles, read allocation, fragment sampling, error/quality injection,
+FASTQ formatting into an HBM pool) with a fresh seed.  N>1: weak scaling, each rank runs the same
+workload on its own 1 Mb record (fragment-lineage shard = one record per rank, no data-path
+collective), then the FASTQ pools are gathered on the writer rank over RCCL.
+"""
+import argparse
+import gzip
+import json
+import os
+import re
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def make_inputs(td, rank):
+    fa = os.path.join(td, "simu_%d.fa" % rank)
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "make_genome.py"), "--lengths", "1000000",
+                           "--seed", str(1 + rank), "--first-chr", str(20 + rank), "--simu-out", fa])
+    src = os.path.join(td, "hiseq2500_%d.profile" % rank)
+    open(src, "wb").write(gzip.open(os.path.join(ROOT, "tests", "golden", "models", "Illumina_HiSeq2500.profile.gz")).read())
+    prof = os.path.join(td, "pe150_%d.profile" % rank)
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "make_profile.py"), src, prof, "--read-length", "150"])
+    return fa, prof
+
+
+def cpu_baseline(fa, prof, seed):
+    """The oracle (CPU restatement, counter mode, thread pool) on this box's host cores: the same
+    workload, one step.  Checker code timed as a baseline -- never the thing shipped."""
+    oracle = os.path.join(ROOT, "oracle", "_build", "scs_oracle")
+    if not os.path.exists(oracle):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
+    cores = os.cpu_count() or 1
+    r = subprocess.run([oracle, "genreads", "-i", fa, "-m", prof, "-c", "30", "-t", str(cores), "-o", fa + ".cpu",
+                        "--rng", "counter", "--seed", str(seed)], capture_output=True, text=True, check=True)
+    m = re.search(r"pairs=(\d+) \| load ([\d.]+)s frag ([\d.]+)s amplify ([\d.]+)s alloc ([\d.]+)s readgen ([\d.]+)s", r.stderr)
+    pairs = int(m.group(1))
+    secs = sum(float(m.group(i)) for i in (3, 4, 5, 6))
+    for suf in ("_1.fq", "_2.fq"):
+        try:
+            os.remove(fa + ".cpu" + suf)
+        except OSError:
+            pass
+    return dict(value=pairs / secs, unit="pairs/s", cores=cores, kind="port",
+                sample="the full N=1 workload, 1 step (%d pairs in %.2f s: amplify %.2f, allocate %.2f, readgen %.2f)" %
+                       (pairs, secs, float(m.group(4)), float(m.group(5)), float(m.group(6))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import scssim_amd
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            sys.exit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d bench.py --gpus %d ..." % (a.gpus, a.gpus))
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    dev = torch.device("cuda", local)
+
+    td = tempfile.mkdtemp(prefix="scsbench_")
+    fa, prof = make_inputs(td, rank)
+    g = scssim_amd.GenReads(profile=prof, input_fasta=fa, coverage=30.0, isize=260, layout="PE", seed=1, device=local)
+    cap = 96 << 20
+    pool1 = torch.empty(cap, dtype=torch.uint8, device=dev)
+    pool2 = torch.empty(cap, dtype=torch.uint8, device=dev)
+    gathered = [torch.empty(cap, dtype=torch.uint8, device=dev) for _ in range(2 * (world - 1))] if (world > 1 and rank == 0) else []
+    ktimes = {}
+
+    def step(i, record):
+        g.set_seed(1000 + i)
+        g.create_frags()
+        g.amplify()
+        if record:
+            acc(g.kernel_times(), ("k_errscan<semi->full>", "k_errscan<frag->semi>", "k_attach"))
+        g.allocate_reads(0)
+        n1, n2, pairs = g.yield_reads_device(pool1.data_ptr(), cap, pool2.data_ptr(), cap)
+        if record:
+            acc(g.kernel_times(), ("k_reads", "k_format"))
+        if world > 1:                                   # read pool -> writer rank (RCCL point-to-point over xGMI)
+            sizes = torch.tensor([n1, n2], dtype=torch.int64, device=dev)
+            allsz = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in range(world)]
+            dist.all_gather(allsz, sizes)
+            ops = []
+            if rank == 0:
+                for r in range(1, world):
+                    s1, s2 = int(allsz[r][0]), int(allsz[r][1])
+                    ops.append(dist.P2POp(dist.irecv, gathered[2 * (r - 1)][:s1], r))
+                    ops.append(dist.P2POp(dist.irecv, gathered[2 * (r - 1) + 1][:s2], r))
+            else:
+                ops.append(dist.P2POp(dist.isend, pool1[:n1], 0))
+                ops.append(dist.P2POp(dist.isend, pool2[:n2], 0))
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        return pairs, g.stats()
+
+    def acc(kt, names):
+        for k in names:
+            d = ktimes.setdefault(k, dict(launches=0, ms=0.0, units=0))
+            for f in ("launches", "ms", "units"):
+                d[f] += kt[k][f]
+
+    for i in range(a.warmup):
+        step(i, False)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    pairs_total, fq_bytes, alg_bytes, last = 0, 0, 0, None
+    for i in range(a.steps):
+        p, last = step(a.warmup + i, True)
+        pairs_total += p
+        fq_bytes += sum(last["fastq_bytes"])
+        alg_bytes += last["algorithmic_bytes"]
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t[0])
+        pt = torch.tensor([pairs_total], dtype=torch.int64, device=dev)
+        dist.all_reduce(pt)
+        pairs_total = int(pt[0])
+
+    if rank == 0:
+        dom = max(ktimes, key=lambda k: ktimes[k]["ms"])
+        kd = ktimes[dom]
+        if dom.startswith("k_errscan"):
+            # 1526 algorithmic bytes per created amplicon (template window read once + descriptor
+            # write + primer-counter RMW + error entries) x amplicons created by these launches
+            alg = 1526.0 * kd["units"]
+            note = "1526 B x %d amplicons created over %d launches" % (kd["units"], kd["launches"])
+        else:
+            # per pair: insert-size template bytes + FASTQ bytes of both records
+            alg = 261.0 * kd["units"] + fq_bytes
+            note = "(261 B template + FASTQ bytes) x %d pairs over %d launches" % (kd["units"], kd["launches"])
+        achieved = alg / (kd["ms"] * 1e-3) / 1e9 if kd["ms"] > 0 else 0.0
+        out = {
+            "metric": "paired-end read pairs/s (whole genreads job: MALBAC amplification + read allocation + read generation)",
+            "value": pairs_total / elapsed, "unit": "pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8/u32 (integer draws, byte sequences; fp64 only in the GC-weight draw)", "data": "synthetic",
+            "config": {"workload": "configs[1]: 1 Mb synthetic reference (diploid simuvars FASTA), PE150 30x, HiSeq2500 model resampled to 150 bins, -p 100000 -r 1e-9 -s 260",
+                       "pairs_per_step_per_gpu": last["pairs_written"], "full_amplicons_per_step": last["full_amplicons"],
+                       "semi_amplicons_per_step": last["semi_amplicons"], "sharding": "one 1 Mb record per rank; read pool gathered on rank 0 over RCCL" if world > 1 else "single GPU"},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "algorithmic_bytes": note, "avg_launch_ms": kd["ms"] / max(1, kd["launches"])},
+            "kernels_ms_per_step": {k: v["ms"] / a.steps for k, v in ktimes.items()},
+            "whole_job_algorithmic_GBps": alg_bytes / elapsed / 1e9,
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(fa, prof, 1000 + a.warmup)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

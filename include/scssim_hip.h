@@ -144,9 +144,11 @@ int         scs_profile_table(void* handle, int which, const uint32_t** thr, con
 int         scs_profile_scalars(void* handle, double* out);
 void        scs_profile_close(void* handle);
 
-/* Timing of the dominant kernel (HIP events on the ctx stream, accumulated over the last
- * scs_yield_reads / scs_amplify call): name, launches, total milliseconds. */
-int         scs_kernel_time(const scs_ctx* ctx, int which, const char** name, uint64_t* launches, double* ms);
+/* Per-kernel timing (HIP events recorded on the ctx stream around every launch, accumulated over the
+ * last scs_amplify / scs_yield_reads call): name, launches, total milliseconds, and the units the
+ * launches processed (amplicons created for the errscan kernels, read pairs for k_reads/k_format,
+ * templates for k_attach).  which = 0..4. */
+int         scs_kernel_time(const scs_ctx* ctx, int which, const char** name, uint64_t* launches, double* ms, uint64_t* units);
 
 #ifdef __cplusplus
 }

@@ -65,7 +65,7 @@ def load_library():
     L.scs_yield_reads_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                          C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.scs_get_stats.argtypes = [C.c_void_p, C.POINTER(_Stats)]
-    L.scs_kernel_time.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
+    L.scs_kernel_time.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_uint64), C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     L.scs_predict_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     L.scs_philox_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
@@ -241,9 +241,9 @@ class GenReads:
     def kernel_times(self):
         out = {}
         for i in range(5):
-            name, n, ms = C.c_char_p(), C.c_uint64(), C.c_double()
-            self._ck(self._L.scs_kernel_time(self._ctx, i, C.byref(name), C.byref(n), C.byref(ms)))
-            out[name.value.decode()] = dict(launches=n.value, ms=ms.value)
+            name, n, ms, units = C.c_char_p(), C.c_uint64(), C.c_double(), C.c_uint64()
+            self._ck(self._L.scs_kernel_time(self._ctx, i, C.byref(name), C.byref(n), C.byref(ms), C.byref(units)))
+            out[name.value.decode()] = dict(launches=n.value, ms=ms.value, units=units.value)
         return out
 
     def download_amplicons(self, kind):

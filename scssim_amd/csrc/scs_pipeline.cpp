@@ -278,6 +278,7 @@ void amplify_pass(scs_ctx* c, bool from_frag, uint32_t pass) {
                             c->valid.as<uint32_t>(), c->primer_cnt.as<int64_t>(), c->primer_delta.as<uint32_t>(), p);
     }
     c->tm_attach.end(s);
+    c->tm_attach.units += nt;
     exclusive_scan_u32(s, c->valid.as<uint32_t>(), c->valid_off.as<uint32_t>(), nt, c->scan_tmp.p, c->scan_tmp.cap);
     KernelTimer& tm = from_frag ? c->tm_errscan_f : c->tm_errscan;
     tm.begin(s);
@@ -448,6 +449,7 @@ void do_yield(scs_ctx* c, const OutTarget& tg, uint64_t* n1_out, uint64_t* n2_ou
         c->tm_format.begin(s);
         launch_format(s, pr, np, 0, paired, slot, c->slot_b.as<char>(), c->slot_q.as<char>(), c->lens.as<uint32_t>(), c->off1.as<uint64_t>(), c->off2.as<uint64_t>(), o1, o2);
         c->tm_format.end(s);
+        c->tm_format.units += np;
         if (!tg.device && tg.sink) {
             c->h_out1.resize(b1); c->h_out2.resize(b2);
             if (b1) HIP_OK(hipMemcpyAsync(c->h_out1.data(), o1, b1, hipMemcpyDeviceToHost, s));
@@ -583,11 +585,11 @@ int scs_run_genreads(scs_ctx* c, scs_sink_fn sink, void* user) {
 }
 int scs_get_stats(const scs_ctx* c, scs_stats* out) { if (!c || !out) return SCS_EINVAL; *out = c->st; return SCS_OK; }
 
-int scs_kernel_time(const scs_ctx* c, int which, const char** name, uint64_t* launches, double* ms) {
+int scs_kernel_time(const scs_ctx* c, int which, const char** name, uint64_t* launches, double* ms, uint64_t* units) {
     if (!c) return SCS_EINVAL;
     const KernelTimer* t[] = {&c->tm_errscan, &c->tm_errscan_f, &c->tm_reads, &c->tm_attach, &c->tm_format};
     if (which < 0 || which >= 5) return SCS_EINVAL;
-    if (name) *name = t[which]->name; if (launches) *launches = t[which]->launches; if (ms) *ms = t[which]->ms;
+    if (name) *name = t[which]->name; if (launches) *launches = t[which]->launches; if (ms) *ms = t[which]->ms; if (units) *units = t[which]->units;
     return SCS_OK;
 }
 
