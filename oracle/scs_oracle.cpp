@@ -10,8 +10,8 @@
 //   counter : Philox4x32-10 keyed by logical ids (DESIGN.md "RNG remapping").
 // Apart from where a draw comes from, the two modes differ only in the three
 // places marked [REMAP] below (primer-pool snapshot per pass, chunked weight
-// sum, GC-factor normal sampler) -- each is order-free so that any thread /
-// GPU schedule gives the same bytes.
+// sum, GC-factor normal sampler, software log in the Poisson sampler) -- each is
+// order-free / libm-free so that any thread / GPU schedule gives the same bytes.
 #include "scs_oracle.h"
 
 #include <algorithm>
@@ -544,7 +544,8 @@ long poiss_rand(Sim& S, double lambda, uint32_t call, uint32_t kind, uint64_t tu
     long x = -1; double log1 = 0, log2 = -lambda; uint32_t t = 0;
     do {
         double u = S.rng.grand(mk(ST_POISSON, kind | (call << 1), tuid, t / 4, t % 4)); t++;
-        log1 += log(u); x++;
+        log1 += S.prm.counter ? det_log(u) : log(u);      // [REMAP] counter mode: software log a GPU reproduces bit for bit
+        x++;
     } while (log1 >= log2);
     return x;
 }

@@ -55,6 +55,12 @@ struct AmplifyParams {
     uint32_t t_ber;
 };
 
+struct PoissonParams {
+    RngKey key; uint32_t call; double gamma;
+    uint64_t total_primers, total_len, template_num;   // Malbac::setPrimers inputs (Malbac.cpp:236-262)
+};
+struct AllocState { double total; unsigned long long sum_rn, sum_quota; };
+
 // error flags raised by kernels (never silent): bit 0 error-list cap, 1 error pool, 2 read slot, 3 other
 enum DevFlag : uint32_t { FLAG_ERRCAP = 1, FLAG_ERRPOOL = 2, FLAG_READSLOT = 4, FLAG_INTERNAL = 8 };
 
@@ -62,7 +68,13 @@ struct PairRec { uint32_t amp; uint32_t att; uint32_t pos; uint32_t isz; };   //
 
 // ---- launch wrappers (scs_kernels.hip) --------------------------------------------------------------
 void launch_attach_frags(hipStream_t s, const uint8_t* g, DevFrags fr, const uint32_t* slot_off, uint32_t* slots,
-                         uint32_t* slot_tmpl, uint32_t* valid, const int64_t* primer_cnt, uint32_t* primer_delta, AmplifyParams p);
+                         uint32_t* slot_tmpl, uint32_t* valid, const int64_t* primer_cnt, uint32_t* primer_delta,
+                         unsigned long long* len_sum, AmplifyParams p);
+void launch_poisson(hipStream_t s, DevFrags fr, DevAmps semis, uint32_t n_semis, PoissonParams p, uint32_t* budget_f, uint32_t* budget_s,
+                    unsigned long long* sums);
+// whole read allocation on the device; rn / pair_cnt_off need ac+1 entries, scan temp from scan_temp_bytes(ac)
+void launch_alloc(hipStream_t s, double* w, uint32_t ac, unsigned long long reads, RngKey key, int paired, AllocState* st, double* part, double* tp,
+                  double* probs, uint32_t* quota, uint32_t* rn, uint32_t* odd_before, uint32_t* pair_cnt_off, void* temp, size_t temp_bytes);
 void launch_attach_semis(hipStream_t s, const uint8_t* g, DevFrags fr, DevAmps semis, uint32_t n_semis, DevErrPool spool,
                          const uint32_t* slot_off, uint32_t* slots, uint32_t* slot_tmpl, uint32_t* valid,
                          const int64_t* primer_cnt, uint32_t* primer_delta, AmplifyParams p);

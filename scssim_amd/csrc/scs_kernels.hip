@@ -583,6 +583,216 @@ __global__ void k_detlog(const double* __restrict__ x, uint32_t n, double* __res
 }
 
 // ------------------------------------------------------------------------------------------------
+// block-level helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
+    return v;
+}
+// every thread of the block must call this exactly once (contains __syncthreads)
+__device__ __forceinline__ void block_add_u64(unsigned long long v, unsigned long long* __restrict__ dst) {
+    __shared__ unsigned long long s_acc;
+    if (threadIdx.x == 0) s_acc = 0;
+    __syncthreads();
+    v = wave_sum_u64(v);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(&s_acc, v);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_acc) atomicAdd(dst, s_acc);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K0  primer budgets: Malbac::setPrimers (lib/malbac/Malbac.cpp:236-283) with poissRand
+//     (lib/mydefine/MyDefine.cpp:69-80: Knuth, sum of logs of uniforms) -- one thread per template.
+//     sums[0] += sum of k over fragments, sums[1] += sum of UNTRUNCATED k over semis (Malbac.cpp:282).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_poisson(DevFrags fr, DevAmps semis, uint32_t n_semis, PoissonParams p,
+                                                 uint32_t* __restrict__ budget_f, uint32_t* __restrict__ budget_s,
+                                                 unsigned long long* __restrict__ sums) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t nf = fr.n;
+    unsigned long long kf = 0, ks = 0;
+    if (t < nf + n_semis) {
+        const bool isf = t < nf;
+        const uint32_t i = isf ? t : t - nf;
+        const uint32_t len = isf ? fr.len[i] : sl_len(semis.sl[i]);
+        const uint64_t tuid = isf ? fr.gidx_base + i : semis.uid[i];
+        const uint32_t aux = (isf ? 0u : 1u) | (p.call << 1);
+        const unsigned long long expected = (unsigned long long)((double)p.total_primers * p.gamma * (double)p.template_num);
+        const double lambda = (double)expected * (1.0 * (double)len / (double)p.total_len);
+        long x = -1; double log1 = 0; const double log2 = -lambda; uint32_t n = 0; U4 d;
+        do {
+            if ((n & 3) == 0) d = draw4(p.key, ST_POISSON, aux, tuid, n >> 2);
+            const double u = (double)d.w[n & 3] / 4294967296.0; ++n;
+            log1 += det_log(u); ++x;
+        } while (log1 >= log2);
+        if (isf) { budget_f[i] = (uint32_t)(int)x; kf = (unsigned long long)x; }
+        else { budget_s[i] = (uint32_t)x & 0xFFFu; semis.primers[i] = (uint16_t)((uint32_t)x & 0xFFFu); ks = (unsigned long long)x; }
+    }
+    block_add_u64(kf, &sums[0]);
+    block_add_u64(ks, &sums[1]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1a' attach for fragments: one wave per fragment.  Budgets run to hundreds of primers per
+//      fragment and the reference's loop is sequential in the primer index (posAttached[] and the
+//      >50-tries abort), so the wave evaluates 64 primers speculatively and commits them in index
+//      order: a primer commits only when every lower primer has; one whose proposal hits a
+//      committed position moves on to its next try exactly as the sequential loop would.  Results
+//      are identical to the thread-per-template loop of k_attach.
+// ------------------------------------------------------------------------------------------------
+#define BITMAP_WORDS 4096      // 131072 positions (packed-record limit of spos)
+__global__ void __launch_bounds__(64) k_attach_frags_wave(const uint8_t* __restrict__ g, DevFrags fr, const uint32_t* __restrict__ slot_off,
+                                                          uint32_t* __restrict__ slots, uint32_t* __restrict__ slot_tmpl, uint32_t* __restrict__ valid,
+                                                          const int64_t* __restrict__ primer_cnt, uint32_t* __restrict__ primer_delta,
+                                                          unsigned long long* __restrict__ len_sum, AmplifyParams p) {
+    __shared__ uint32_t s_bits[BITMAP_WORDS];
+    const uint32_t t = blockIdx.x; const int lane = threadIdx.x;
+    const uint32_t len = fr.len[t], budget = fr.primers[t];
+    if (len < p.amp_min + 27 || budget == 0) { if (lane == 0) valid[t] = 0; return; }
+    for (uint32_t w = lane; w < (len + 31) / 32; w += WAVE) s_bits[w] = 0;
+    __builtin_amdgcn_wave_barrier();
+    const View tv = frag_view(fr.goff[t], len, fr.strand[t]);
+    const uint64_t tuid = fr.gidx_base + t;
+    const uint32_t base_slot = slot_off[t], aux = 0u | (p.pass << 1);
+    uint32_t v = 0; bool aborted = false; unsigned long long lsum = 0;
+    for (uint32_t c0 = 0; c0 < budget && !aborted; c0 += WAVE) {
+        const uint32_t i = c0 + lane;
+        bool unresolved = i < budget, need = unresolved, dead = false;
+        uint32_t tries = 0, spos = 0, alen = 0, pidx = 0;
+        while (__ballot(unresolved)) {
+            if (unresolved && !dead) {
+                if (!need && ((s_bits[spos >> 5] >> (spos & 31)) & 1u)) need = true;     // a lower primer took this position meanwhile
+                while (need) {
+                    const U4 d = draw4(p.key, ST_ATTACH, aux, tuid, (i << 6) | tries);
+                    spos = scale_draw(d.w[0], 27, len - 27);
+                    alen = scale_draw(d.w[1], p.amp_min, p.amp_max + 1 - p.amp_min);
+                    ++tries;
+                    if (tries > 50) { dead = true; break; }
+                    if (spos + alen > len) continue;
+                    if ((s_bits[spos >> 5] >> (spos & 31)) & 1u) continue;
+                    uint32_t idx = 0; bool hasN = false;
+                    for (uint32_t k = 0; k < 8; ++k) { const uint32_t c = view_base(g, tv, spos + k); hasN |= c > 3; idx = (idx << 2) | (c & 3u); }
+                    if (hasN || primer_cnt[idx] <= 0) continue;
+                    pidx = idx; need = false;
+                }
+            }
+            // blocked = some lower unresolved live lane proposes the same position
+            bool blocked = false;
+            const unsigned long long um = __ballot(unresolved && !dead);
+            for (unsigned long long m = um; m; m &= m - 1) {
+                const int j = __ffsll((long long)m) - 1;
+                const uint32_t sj = __shfl(spos, j);
+                if (j < lane && unresolved && !dead && sj == spos) blocked = true;
+            }
+            const unsigned long long bm = __ballot(unresolved && blocked), dm = __ballot(unresolved && dead);
+            const int first_blocked = bm ? __ffsll((long long)bm) - 1 : 64, first_dead = dm ? __ffsll((long long)dm) - 1 : 64;
+            const int commit_end = first_blocked < first_dead ? first_blocked : first_dead;
+            if (unresolved && lane < commit_end) {                                       // commit, in primer order
+                atomicOr(&s_bits[spos >> 5], 1u << (spos & 31));
+                atomicAdd(&primer_delta[pidx], 1u);
+                slots[base_slot + i] = pack_sl(spos, alen); slot_tmpl[base_slot + i] = t;
+                lsum += alen; unresolved = false;
+            }
+            if (first_dead <= first_blocked && first_dead < 64) { aborted = true; unresolved = false; }
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (!aborted) v = (c0 + WAVE < budget) ? c0 + WAVE : budget;
+        else {
+            // number committed = index of the aborting primer
+            const unsigned long long dm = __ballot(dead);
+            v = c0 + (uint32_t)(__ffsll((long long)dm) - 1);
+        }
+    }
+    lsum = wave_sum_u64(lsum);
+    if (lane == 0) { valid[t] = v; if (lsum) atomicAdd(len_sum, lsum); }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3  read allocation: Malbac::setReadCounts (lib/malbac/Malbac.cpp:370-408) with randIndx_hp /
+//     batchSampling (lib/mydefine/MyDefine.cpp:191-272), chunk = 1000 amplicons (loadPerThread at -t 1).
+//     All sums run in the oracle's order (sequential inside a chunk, chunks in order).
+// ------------------------------------------------------------------------------------------------
+#define ALLOC_CHUNK 1000u
+__global__ void k_alloc_chunk_sum(const double* __restrict__ w, uint32_t ac, double* __restrict__ part) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x, nch = (ac + ALLOC_CHUNK - 1) / ALLOC_CHUNK;
+    if (c >= nch) return;
+    const uint32_t b = c * ALLOC_CHUNK, e = min(ac, b + ALLOC_CHUNK);
+    double s = 0; for (uint32_t i = b; i < e; ++i) s += w[i];
+    part[c] = s;
+}
+__global__ void k_alloc_total(const double* __restrict__ part, uint32_t nch, AllocState* __restrict__ st) {
+    if (blockIdx.x || threadIdx.x) return;
+    double t = 0; for (uint32_t c = 0; c < nch; ++c) t += part[c];                       // [REMAP] partials in order
+    st->total = t; st->sum_rn = 0; st->sum_quota = 0;
+}
+__global__ void __launch_bounds__(256) k_alloc_floor(double* __restrict__ w, uint32_t ac, unsigned long long reads, AllocState* __restrict__ st,
+                                                     uint32_t* __restrict__ rn) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long r = 0;
+    if (i < ac) {
+        const double p = w[i] / (2.2204e-16 + st->total);                                // wls.normalize(0)
+        w[i] = p;
+        const uint32_t c = (uint32_t)(p * (double)(long long)reads);                     // unsigned readCount = wls.get(0,i)*reads
+        rn[i] = c; r = c;
+    }
+    block_add_u64(r, &st->sum_rn);
+}
+__global__ void __launch_bounds__(256) k_alloc_quota(double* __restrict__ w, uint32_t ac, unsigned long long reads, AllocState* __restrict__ st,
+                                                     double* __restrict__ tp, uint32_t* __restrict__ quota) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x, nch = (ac + ALLOC_CHUNK - 1) / ALLOC_CHUNK;
+    unsigned long long q = 0;
+    if (c < nch) {
+        const unsigned long long n = reads - st->sum_rn;
+        const uint32_t b = c * ALLOC_CHUNK, e = min(ac, b + ALLOC_CHUNK);
+        double t = 0; for (uint32_t i = b; i < e; ++i) t += w[i];
+        double run = 0; for (uint32_t i = b; i < e; ++i) { run = run + w[i] / t; w[i] = run; }   // chunk-local CDF in place
+        tp[c] = t;
+        const uint32_t qq = (uint32_t)(t * (double)n);
+        quota[c] = qq; q = qq;
+    }
+    block_add_u64(q, &st->sum_quota);
+}
+__global__ void k_alloc_top_prefix(const double* __restrict__ tp, uint32_t nch, double* __restrict__ probs) {
+    if (blockIdx.x || threadIdx.x) return;
+    double run = 0; for (uint32_t c = 0; c < nch; ++c) { run = c ? run + tp[c] : tp[0]; probs[c] = run; }
+}
+__device__ __forceinline__ uint32_t first_le(const double* __restrict__ cdf, uint32_t n, double r) {
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (r <= cdf[mid]) hi = mid; else lo = mid + 1; }
+    return lo < n ? lo : n - 1;
+}
+__global__ void k_alloc_top_draws(const double* __restrict__ probs, uint32_t nch, unsigned long long reads, const AllocState* __restrict__ st,
+                                  RngKey key, uint32_t* __restrict__ quota) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned long long n = reads - st->sum_rn - st->sum_quota;                     // leftover after the per-chunk quotas (< nch)
+    if (t >= n) return;
+    const U4 d = draw4(key, ST_ALLOC_TOP, 0, 0, t);
+    const double r = 2.2204e-16 + (1 - 2.2204e-16) * ((double)d.w[0] / 4294967296.0);
+    atomicAdd(&quota[first_le(probs, nch, r)], 1u);
+}
+__global__ void __launch_bounds__(256) k_alloc_sample(const double* __restrict__ cdf, uint32_t ac, const uint32_t* __restrict__ quota, RngKey key,
+                                                      uint32_t* __restrict__ rn) {
+    const uint32_t c = blockIdx.x;                                                        // one workgroup per chunk
+    const uint32_t b = c * ALLOC_CHUNK, e = min(ac, b + ALLOC_CHUNK), q = quota[c];
+    for (uint32_t t = threadIdx.x; t < q; t += blockDim.x) {
+        const U4 d = draw4(key, ST_ALLOC_CHUNK, 0, c, t);
+        const double r = 2.2204e-16 + (1 - 2.2204e-16) * ((double)d.w[0] / 4294967296.0);
+        atomicAdd(&rn[b + first_le(cdf + b, e - b, r)], 1u);
+    }
+}
+// PE parity fix (Malbac.cpp:399-407): the j-th odd entry gets +1 for even j, -1 for odd j.
+__global__ void k_alloc_parity(uint32_t* __restrict__ rn, const uint32_t* __restrict__ odd_before, uint32_t ac) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ac) return;
+    const uint32_t v = rn[i];
+    if (v & 1u) rn[i] = (odd_before[i] & 1u) ? v - 1u : v + 1u;
+}
+
+struct OddBit { __host__ __device__ uint32_t operator()(uint32_t v) const { return v & 1u; } };
+struct HalfUp { __host__ __device__ uint32_t operator()(uint32_t v) const { return (v + 1u) >> 1; } };
+
+// ------------------------------------------------------------------------------------------------
 // launch wrappers.  Grids: >> 256 workgroups wherever the unit count allows; grid-stride kernels
 // are capped at 256 CUs x 8 workgroups.
 // ------------------------------------------------------------------------------------------------
@@ -590,10 +800,34 @@ static inline uint32_t cdiv(uint64_t a, uint32_t b) { return (uint32_t)((a + b -
 static const uint32_t kMaxStrideGrid = 256 * 8;
 
 void launch_attach_frags(hipStream_t s, const uint8_t* g, DevFrags fr, const uint32_t* slot_off, uint32_t* slots, uint32_t* slot_tmpl,
-                         uint32_t* valid, const int64_t* primer_cnt, uint32_t* primer_delta, AmplifyParams p) {
+                         uint32_t* valid, const int64_t* primer_cnt, uint32_t* primer_delta, unsigned long long* len_sum, AmplifyParams p) {
     if (fr.n == 0) return;
-    DevAmps none{}; DevErrPool np{};
-    hipLaunchKernelGGL(k_attach<true>, dim3(cdiv(fr.n, 64)), dim3(64), 0, s, g, fr, none, 0u, np, slot_off, slots, slot_tmpl, valid, primer_cnt, primer_delta, p);
+    hipLaunchKernelGGL(k_attach_frags_wave, dim3(fr.n), dim3(64), 0, s, g, fr, slot_off, slots, slot_tmpl, valid, primer_cnt, primer_delta, len_sum, p);
+}
+void launch_poisson(hipStream_t s, DevFrags fr, DevAmps semis, uint32_t n_semis, PoissonParams p, uint32_t* budget_f, uint32_t* budget_s,
+                    unsigned long long* sums) {
+    const uint64_t n = (uint64_t)fr.n + n_semis;
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_poisson, dim3(cdiv(n, 256)), dim3(256), 0, s, fr, semis, n_semis, p, budget_f, budget_s, sums);
+}
+void launch_alloc(hipStream_t s, double* w, uint32_t ac, unsigned long long reads, RngKey key, int paired, AllocState* st, double* part, double* tp,
+                  double* probs, uint32_t* quota, uint32_t* rn, uint32_t* odd_before, uint32_t* pair_cnt_off, void* temp, size_t temp_bytes) {
+    if (ac == 0) return;
+    const uint32_t nch = (ac + ALLOC_CHUNK - 1) / ALLOC_CHUNK;
+    hipLaunchKernelGGL(k_alloc_chunk_sum, dim3(cdiv(nch, 64)), dim3(64), 0, s, w, ac, part);
+    hipLaunchKernelGGL(k_alloc_total, dim3(1), dim3(64), 0, s, part, nch, st);
+    hipLaunchKernelGGL(k_alloc_floor, dim3(cdiv(ac, 256)), dim3(256), 0, s, w, ac, reads, st, rn);
+    hipLaunchKernelGGL(k_alloc_quota, dim3(cdiv(nch, 256)), dim3(256), 0, s, w, ac, reads, st, tp, quota);
+    hipLaunchKernelGGL(k_alloc_top_prefix, dim3(1), dim3(64), 0, s, tp, nch, probs);
+    hipLaunchKernelGGL(k_alloc_top_draws, dim3(cdiv((uint64_t)nch + 1024, 256)), dim3(256), 0, s, probs, nch, reads, st, key, quota);
+    hipLaunchKernelGGL(k_alloc_sample, dim3(nch), dim3(256), 0, s, w, ac, quota, key, rn);
+    if (paired) {
+        (void)rocprim::exclusive_scan(temp, temp_bytes, rocprim::make_transform_iterator(rn, OddBit()), odd_before, 0u, (size_t)ac + 1, rocprim::plus<uint32_t>(), s);
+        hipLaunchKernelGGL(k_alloc_parity, dim3(cdiv(ac, 256)), dim3(256), 0, s, rn, odd_before, ac);
+        (void)rocprim::exclusive_scan(temp, temp_bytes, rocprim::make_transform_iterator(rn, HalfUp()), pair_cnt_off, 0u, (size_t)ac + 1, rocprim::plus<uint32_t>(), s);
+    } else {
+        (void)rocprim::exclusive_scan(temp, temp_bytes, rn, pair_cnt_off, 0u, (size_t)ac + 1, rocprim::plus<uint32_t>(), s);
+    }
 }
 void launch_attach_semis(hipStream_t s, const uint8_t* g, DevFrags fr, DevAmps semis, uint32_t n_semis, DevErrPool spool,
                          const uint32_t* slot_off, uint32_t* slots, uint32_t* slot_tmpl, uint32_t* valid,

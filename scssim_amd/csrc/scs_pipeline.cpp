@@ -101,11 +101,13 @@ struct scs_ctx {
     uint64_t f_gidx_base = 0; bool have_frags = false;
     DevBuf df_goff, df_len, df_strand, df_primers;
     // amplicons
-    AmpStore semis, fulls; std::vector<uint32_t> h_semi_len; std::vector<uint64_t> h_semi_uid; std::vector<uint32_t> h_budget;
+    AmpStore semis, fulls;
+    DevBuf budget_f, budget_s, slot_off_f, slot_off_s, dsums; uint64_t* h_rb = nullptr;   // dsums: device scalars; h_rb: pinned read-back slots
+    uint64_t frag_total_len = 0, semi_total_len = 0; uint32_t slots_f = 0, slots_s = 0, budget_ns = 0;
     DevBuf primer_cnt, primer_delta; uint64_t total_primers = 0; bool amplified = false;
-    DevBuf budget, slot_off, slots, slot_tmpl, valid, valid_off, scan_tmp, flags;
+    DevBuf slots, slot_tmpl, valid, valid_off, scan_tmp, flags;
     // allocation + reads
-    DevBuf weights, read_numbers, pair_off, pairs; std::vector<uint32_t> h_read_numbers; uint64_t reads_requested = 0, n_pairs_planned = 0; bool allocated = false;
+    DevBuf weights, read_numbers, pair_off, pairs, odd_before, a_part, a_tp, a_probs, a_quota; std::vector<uint32_t> h_read_numbers; uint64_t reads_requested = 0, n_pairs_planned = 0; bool allocated = false;
     DevBuf slot_b, slot_q, lens, sizes1, sizes2, off1, off2, out1, out2; std::vector<char> h_out1, h_out2;
     scs_stats st{};
     KernelTimer tm_errscan{"k_errscan<semi->full>"}, tm_errscan_f{"k_errscan<frag->semi>"}, tm_reads{"k_reads"}, tm_attach{"k_attach"}, tm_format{"k_format"};
@@ -210,96 +212,77 @@ void do_create_frags(scs_ctx* c) {
     c->st.fragments = c->f_len.size();
 }
 
-// ---------------------------------------------------------------- a3: Malbac::setPrimers (Malbac.cpp:236-283), poissRand (MyDefine.cpp:69-80)
-uint64_t poisson_keyed(RngKey key, double lambda, uint32_t aux, uint64_t tuid) {
-    long x = -1; double log1 = 0; const double log2 = -lambda; uint32_t t = 0; U4 d{};
-    do {
-        if ((t & 3) == 0) d = draw4(key, ST_POISSON, aux, tuid, t >> 2);
-        const double u = d.w[t & 3] / 4294967296.0; ++t;
-        log1 += log(u); x++;
-    } while (log1 >= log2);
-    return (uint64_t)x;
-}
+// ---------------------------------------------------------------- a3: Malbac::setPrimers (Malbac.cpp:236-283) on the device
+// One launch gives every template (fragments, then all semis so far) its Poisson budget; the scans
+// turn budgets into slot offsets.  One host sync: the sums feed totalPrimers and the buffer sizes.
 void set_primers(scs_ctx* c, bool only_frags, uint32_t call) {
     if (c->cfg.shard_count > 1) throw ScsError(SCS_EINVAL, "sharded setPrimers needs the all-reduce hook (not wired in this build)");
-    uint64_t template_num = c->f_len.size(); double total_len = 0;
-    for (uint32_t l : c->f_len) total_len += l;
-    if (!only_frags) { template_num += c->h_semi_len.size(); for (uint32_t l : c->h_semi_len) total_len += l; }
-    const uint64_t expected = (uint64_t)(c->total_primers * c->cfg.gamma * template_num);
-    uint64_t count = 0;
-    for (size_t i = 0; i < c->f_len.size(); ++i) {
-        const double lambda = expected * (1.0 * c->f_len[i] / total_len);
-        const uint64_t k = poisson_keyed(c->key, lambda, 0u | (call << 1), c->f_gidx_base + i);
-        count += k; c->f_primers[i] = (uint32_t)(int)k;
-    }
-    if (!only_frags) {
-        c->h_budget.resize(c->h_semi_len.size());
-        for (size_t i = 0; i < c->h_semi_len.size(); ++i) {
-            const double lambda = expected * (1.0 * c->h_semi_len[i] / total_len);
-            const uint64_t k = poisson_keyed(c->key, lambda, 1u | (call << 1), c->h_semi_uid[i]);
-            count += k; c->h_budget[i] = (uint32_t)(k & 0xFFF);                    // 12-bit field (Amplicon.cpp:76-79)
-        }
-    }
-    c->total_primers -= count;
+    hipStream_t s = c->stream;
+    const uint32_t nf = (uint32_t)c->f_len.size(), ns = only_frags ? 0u : c->semis.n;
+    PoissonParams p; p.key = c->key; p.call = call; p.gamma = c->cfg.gamma; p.total_primers = c->total_primers;
+    p.total_len = c->frag_total_len + (only_frags ? 0 : c->semi_total_len); p.template_num = (uint64_t)nf + ns;
+    c->budget_f.reserve(((size_t)nf + 1) * 4, s); c->budget_s.reserve(((size_t)ns + 1) * 4, s);
+    c->slot_off_f.reserve(((size_t)nf + 1) * 4, s); c->slot_off_s.reserve(((size_t)ns + 1) * 4, s);
+    c->scan_tmp.reserve(scan_temp_bytes(std::max(nf, ns)), s);
+    HIP_OK(hipMemsetAsync(c->dsums.p, 0, 64, s));
+    launch_poisson(s, c->frags_view(), c->semis.view(), ns, p, c->budget_f.as<uint32_t>(), c->budget_s.as<uint32_t>(), c->dsums.as<unsigned long long>());
+    exclusive_scan_u32(s, c->budget_f.as<uint32_t>(), c->slot_off_f.as<uint32_t>(), nf, c->scan_tmp.p, c->scan_tmp.cap);
+    if (ns) exclusive_scan_u32(s, c->budget_s.as<uint32_t>(), c->slot_off_s.as<uint32_t>(), ns, c->scan_tmp.p, c->scan_tmp.cap);
+    uint64_t* rb = c->h_rb;
+    HIP_OK(hipMemcpyAsync(rb, c->dsums.p, 16, hipMemcpyDeviceToHost, s));
+    rb[2] = rb[3] = 0;
+    HIP_OK(hipMemcpyAsync(&rb[2], c->slot_off_f.as<uint32_t>() + nf, 4, hipMemcpyDeviceToHost, s));
+    if (ns) HIP_OK(hipMemcpyAsync(&rb[3], c->slot_off_s.as<uint32_t>() + ns, 4, hipMemcpyDeviceToHost, s));
+    HIP_OK(hipStreamSynchronize(s));
+    c->total_primers -= rb[0] + rb[1];
+    c->slots_f = (uint32_t)rb[2]; c->slots_s = (uint32_t)rb[3]; c->budget_ns = ns;
 }
 
-// ---------------------------------------------------------------- one amplification pass (a4 / a5)
-void amplify_pass(scs_ctx* c, bool from_frag, uint32_t pass) {
+// ---------------------------------------------------------------- one amplification pass (a4 / a5): launches only, no host sync.
+// rb_slot: where the number of amplicons created is read back to (pinned host memory, stream-ordered).
+void launch_pass(scs_ctx* c, bool from_frag, uint32_t pass, int rb_slot) {
     hipStream_t s = c->stream;
-    const std::vector<uint32_t>& budget = from_frag ? c->f_primers : c->h_budget;
-    const uint32_t nt = (uint32_t)budget.size();
-    if (nt == 0) return;
-    uint64_t n_slots64 = 0; for (uint32_t b : budget) n_slots64 += b;
-    if (n_slots64 > 0xFFFFFFF0ull) throw ScsError(SCS_EOVERFLOW, "primer budget of one pass exceeds 2^32");
-    const uint32_t n_slots = (uint32_t)n_slots64;
-    upload(c->budget, budget, s, 1);
-    if (from_frag) HIP_OK(hipMemcpyAsync(c->df_primers.p, budget.data(), (size_t)nt * 4, hipMemcpyHostToDevice, s));
-    c->slot_off.reserve(((size_t)nt + 1) * 4, s); c->valid.reserve(((size_t)nt + 1) * 4, s); c->valid_off.reserve(((size_t)nt + 1) * 4, s);
-    c->slots.reserve(std::max<size_t>((size_t)n_slots * 4, 16), s); c->slot_tmpl.reserve(std::max<size_t>((size_t)n_slots * 4, 16), s);
+    const uint32_t nt = from_frag ? (uint32_t)c->f_len.size() : c->budget_ns;
+    const uint32_t n_slots = from_frag ? c->slots_f : c->slots_s;
+    c->h_rb[rb_slot] = 0;
+    if (nt == 0 || n_slots == 0) return;
+    const uint32_t* slot_off = (from_frag ? c->slot_off_f : c->slot_off_s).as<uint32_t>();
+    c->valid.reserve(((size_t)nt + 1) * 4, s); c->valid_off.reserve(((size_t)nt + 1) * 4, s);
+    c->slots.reserve((size_t)n_slots * 4, s); c->slot_tmpl.reserve((size_t)n_slots * 4, s);
     c->scan_tmp.reserve(scan_temp_bytes(nt), s);
-    HIP_OK(hipMemsetAsync(c->slot_tmpl.p, 0xFF, std::max<size_t>((size_t)n_slots * 4, 16), s));
-    exclusive_scan_u32(s, c->budget.as<uint32_t>(), c->slot_off.as<uint32_t>(), nt, c->scan_tmp.p, c->scan_tmp.cap);
+    HIP_OK(hipMemsetAsync(c->slot_tmpl.p, 0xFF, (size_t)n_slots * 4, s));
     AmpStore& out = from_frag ? c->semis : c->fulls;
     out.reserve((uint64_t)out.n + n_slots, s);
     out.reserve_pool(std::max<uint32_t>(1u << 16, (uint32_t)std::min<uint64_t>(((uint64_t)out.n + n_slots) / 256 + 4096, 0xFFFFFFF0ull)), s);
     AmplifyParams p; p.key = c->key; p.pass = pass; p.amp_min = (uint32_t)c->cfg.amplicon_min_len; p.amp_max = (uint32_t)c->cfg.amplicon_max_len; p.t_ber = c->dtb.t_ber;
-    DevFrags fr = c->frags_view(); fr.primers = c->budget.as<uint32_t>();
+    DevFrags fr = c->frags_view(); fr.primers = c->budget_f.as<uint32_t>();
     const uint8_t* g = c->genome.as<uint8_t>();
     c->tm_attach.begin(s);
-    if (from_frag) launch_attach_frags(s, g, fr, c->slot_off.as<uint32_t>(), c->slots.as<uint32_t>(), c->slot_tmpl.as<uint32_t>(), c->valid.as<uint32_t>(),
-                                       c->primer_cnt.as<int64_t>(), c->primer_delta.as<uint32_t>(), p);
-    else {
-        // budgets of this cycle live in the semis' packed record too (Amplicon::setPrimers)
-        DevAmps sv = c->semis.view();
-        std::vector<uint16_t> b16(nt); for (uint32_t i = 0; i < nt; ++i) b16[i] = (uint16_t)budget[i];
-        HIP_OK(hipMemcpyAsync(sv.primers, b16.data(), (size_t)nt * 2, hipMemcpyHostToDevice, s));
-        HIP_OK(hipStreamSynchronize(s));
-        launch_attach_semis(s, g, fr, sv, nt, c->semis.pool_view(), c->slot_off.as<uint32_t>(), c->slots.as<uint32_t>(), c->slot_tmpl.as<uint32_t>(),
-                            c->valid.as<uint32_t>(), c->primer_cnt.as<int64_t>(), c->primer_delta.as<uint32_t>(), p);
-    }
+    if (from_frag) launch_attach_frags(s, g, fr, slot_off, c->slots.as<uint32_t>(), c->slot_tmpl.as<uint32_t>(), c->valid.as<uint32_t>(),
+                                       c->primer_cnt.as<int64_t>(), c->primer_delta.as<uint32_t>(), c->dsums.as<unsigned long long>() + 4, p);
+    else launch_attach_semis(s, g, fr, c->semis.view(), nt, c->semis.pool_view(), slot_off, c->slots.as<uint32_t>(), c->slot_tmpl.as<uint32_t>(),
+                             c->valid.as<uint32_t>(), c->primer_cnt.as<int64_t>(), c->primer_delta.as<uint32_t>(), p);
     c->tm_attach.end(s);
     c->tm_attach.units += nt;
     exclusive_scan_u32(s, c->valid.as<uint32_t>(), c->valid_off.as<uint32_t>(), nt, c->scan_tmp.p, c->scan_tmp.cap);
     KernelTimer& tm = from_frag ? c->tm_errscan_f : c->tm_errscan;
     tm.begin(s);
-    if (from_frag) launch_errscan_frags(s, g, fr, n_slots, c->slot_off.as<uint32_t>(), c->slots.as<uint32_t>(), c->slot_tmpl.as<uint32_t>(),
+    if (from_frag) launch_errscan_frags(s, g, fr, n_slots, slot_off, c->slots.as<uint32_t>(), c->slot_tmpl.as<uint32_t>(),
                                         c->valid_off.as<uint32_t>(), out.view(), out.n, out.pool_view(), c->flags.as<uint32_t>(), p);
-    else launch_errscan_semis(s, g, fr, c->semis.view(), nt, c->semis.pool_view(), n_slots, c->slot_off.as<uint32_t>(), c->slots.as<uint32_t>(),
+    else launch_errscan_semis(s, g, fr, c->semis.view(), nt, c->semis.pool_view(), n_slots, slot_off, c->slots.as<uint32_t>(),
                               c->slot_tmpl.as<uint32_t>(), c->valid_off.as<uint32_t>(), out.view(), out.n, out.pool_view(), c->flags.as<uint32_t>(), p);
     tm.end(s);
     launch_primer_update(s, c->primer_cnt.as<int64_t>(), c->primer_delta.as<uint32_t>());
-    uint32_t n_new = 0;
-    HIP_OK(hipMemcpyAsync(&n_new, c->valid_off.as<uint32_t>() + nt, 4, hipMemcpyDeviceToHost, s));
+    HIP_OK(hipMemcpyAsync(&c->h_rb[rb_slot], c->valid_off.as<uint32_t>() + nt, 4, hipMemcpyDeviceToHost, s));
+}
+// host sync closing a group of passes: counts of new amplicons, total length of the semis
+void collect_passes(scs_ctx* c, int rb_fulls, int rb_semis) {
+    hipStream_t s = c->stream;
+    HIP_OK(hipMemcpyAsync(&c->h_rb[8], c->dsums.as<unsigned long long>() + 4, 8, hipMemcpyDeviceToHost, s));
     HIP_OK(hipStreamSynchronize(s));
-    tm.units += n_new;
-    const uint32_t old_n = out.n; out.n += n_new;
-    if (from_frag && n_new) {                                                    // host mirror for the next setPrimers
-        std::vector<uint32_t> sl(n_new); c->h_semi_uid.resize(out.n); c->h_semi_len.resize(out.n);
-        HIP_OK(hipMemcpyAsync(sl.data(), out.view().sl + old_n, (size_t)n_new * 4, hipMemcpyDeviceToHost, s));
-        HIP_OK(hipMemcpyAsync(c->h_semi_uid.data() + old_n, out.view().uid + old_n, (size_t)n_new * 8, hipMemcpyDeviceToHost, s));
-        HIP_OK(hipStreamSynchronize(s));
-        for (uint32_t i = 0; i < n_new; ++i) c->h_semi_len[old_n + i] = sl_len(sl[i]);
-    }
+    if (rb_fulls >= 0) { c->fulls.n += (uint32_t)c->h_rb[rb_fulls]; c->tm_errscan.units += c->h_rb[rb_fulls]; }
+    if (rb_semis >= 0) { c->semis.n += (uint32_t)c->h_rb[rb_semis]; c->tm_errscan_f.units += c->h_rb[rb_semis]; }
+    c->semi_total_len = c->h_rb[8];
 }
 
 // ---------------------------------------------------------------- Malbac::amplify (Malbac.cpp:173-201)
@@ -308,22 +291,27 @@ void do_amplify(scs_ctx* c) {
     if (!c->have_profile) throw ScsError(SCS_EINVAL, "scs_amplify: load a profile first");
     hipStream_t s = c->stream;
     if (c->cfg.verbose) fprintf(stderr, "\nMALBAC amplification...\n");
-    c->semis.reset(s); c->fulls.reset(s); c->h_semi_len.clear(); c->h_semi_uid.clear(); c->h_budget.clear();
+    c->semis.reset(s); c->fulls.reset(s);
     c->tm_errscan.reset(); c->tm_errscan_f.reset(); c->tm_attach.reset();
     std::vector<int64_t> stock(65536, (int64_t)c->cfg.primers);                    // createPrimers: 4^8 types x `primers` copies
     upload(c->primer_cnt, stock, s);
     c->primer_delta.reserve(65536 * 4, s); HIP_OK(hipMemsetAsync(c->primer_delta.p, 0, 65536 * 4, s));
     HIP_OK(hipMemsetAsync(c->flags.p, 0, 4, s));
+    HIP_OK(hipMemsetAsync(c->dsums.p, 0, 64, s));
     c->total_primers = 65536ull * (uint64_t)c->cfg.primers;
+    c->frag_total_len = 0; for (uint32_t l : c->f_len) c->frag_total_len += l;
+    c->semi_total_len = 0;
     set_primers(c, true, 0);
-    amplify_pass(c, true, 0);
+    launch_pass(c, true, 0, 5);
+    collect_passes(c, -1, 5);
     for (uint32_t i = 0; i < 5; ++i) {
         if (c->total_primers == 0) break;
         if (c->cfg.verbose) fprintf(stderr, "cycle number: %u\n", i + 1);
         set_primers(c, false, i + 1);
-        amplify_pass(c, false, i);
-        if (c->cfg.verbose) fprintf(stderr, "semi amplicon amplification done!\n");
-        if (i < 4) { amplify_pass(c, true, i + 1); if (c->cfg.verbose) fprintf(stderr, "fragment amplification done!\n"); }
+        launch_pass(c, false, i, 4);
+        if (i < 4) launch_pass(c, true, i + 1, 5);
+        collect_passes(c, 4, i < 4 ? 5 : -1);
+        if (c->cfg.verbose) { fprintf(stderr, "semi amplicon amplification done!\n"); if (i < 4) fprintf(stderr, "fragment amplification done!\n"); }
     }
     check_flags(c);
     c->tm_errscan.collect(); c->tm_errscan_f.collect(); c->tm_attach.collect();
@@ -331,12 +319,7 @@ void do_amplify(scs_ctx* c) {
     c->st.semi_amplicons = c->semis.n; c->st.full_amplicons = c->fulls.n; c->st.primers_left = c->total_primers;
 }
 
-// ---------------------------------------------------------------- a8 + a9: Malbac::setReadCounts (Malbac.cpp:370-408)
-inline uint32_t first_le(const double* cdf, size_t n, double r) {               // randIndx's linear scan == lower bound on a non-decreasing row
-    size_t lo = 0, hi = n;
-    while (lo < hi) { size_t mid = (lo + hi) >> 1; if (r <= cdf[mid]) hi = mid; else lo = mid + 1; }
-    return (uint32_t)(lo < n ? lo : n - 1);
-}
+// ---------------------------------------------------------------- a8 + a9: Malbac::setReadCounts (Malbac.cpp:370-408) on the device
 void do_allocate(scs_ctx* c, uint64_t reads) {
     if (!c->amplified) throw ScsError(SCS_EINVAL, "scs_allocate_reads: call scs_amplify first");
     hipStream_t s = c->stream;
@@ -349,59 +332,22 @@ void do_allocate(scs_ctx* c, uint64_t reads) {
     }
     if (c->cfg.verbose) fprintf(stderr, "\nNumber of reads to generate: %llu\n", (unsigned long long)reads);
     c->reads_requested = reads; c->st.reads_requested = reads;
-    const uint32_t ac = c->fulls.n;
+    const uint32_t ac = c->fulls.n; const uint32_t nch = (ac + 999) / 1000;
     double t0 = now_s();
     c->weights.reserve(std::max<size_t>((size_t)ac * 8, 16), s);
+    c->read_numbers.reserve(((size_t)ac + 1) * 4, s); c->odd_before.reserve(((size_t)ac + 1) * 4, s); c->pair_off.reserve(((size_t)ac + 1) * 4, s);
+    c->a_part.reserve(std::max<size_t>((size_t)nch * 8, 16), s); c->a_tp.reserve(std::max<size_t>((size_t)nch * 8, 16), s);
+    c->a_probs.reserve(std::max<size_t>((size_t)nch * 8, 16), s); c->a_quota.reserve(std::max<size_t>((size_t)nch * 4, 16), s);
+    c->scan_tmp.reserve(scan_temp_bytes(ac), s);
     launch_weights(s, c->fulls.view(), ac, c->dtb, c->key, (uint32_t)c->cfg.frag_size, c->weights.as<double>());
-    std::vector<double> w(ac);
-    if (ac) HIP_OK(hipMemcpyAsync(w.data(), c->weights.p, (size_t)ac * 8, hipMemcpyDeviceToHost, s));
+    launch_alloc(s, c->weights.as<double>(), ac, reads, c->key, c->cfg.paired != 0, (AllocState*)((char*)c->dsums.p + 128), c->a_part.as<double>(), c->a_tp.as<double>(),
+                 c->a_probs.as<double>(), c->a_quota.as<uint32_t>(), c->read_numbers.as<uint32_t>(), c->odd_before.as<uint32_t>(), c->pair_off.as<uint32_t>(),
+                 c->scan_tmp.p, c->scan_tmp.cap);
+    c->h_rb[0] = 0;
+    if (ac) HIP_OK(hipMemcpyAsync(&c->h_rb[0], c->pair_off.as<uint32_t>() + ac, 4, hipMemcpyDeviceToHost, s));
     HIP_OK(hipStreamSynchronize(s));
-    double t1 = now_s(); c->st.t_stage[3] = t1 - t0;
-    const double ZF = 2.2204e-16; const size_t chunk = 1000;
-    std::vector<uint32_t>& rn = c->h_read_numbers; rn.assign(ac, 0);
-    if (ac) {
-        double total = 0;                                                          // [REMAP] per-1000 partial sums, then partials in order
-        for (size_t b = 0; b < ac; b += chunk) { double part = 0; const size_t e = std::min<size_t>(ac, b + chunk); for (size_t i = b; i < e; ++i) part += w[i]; total += part; }
-        const double den = ZF + total;
-        uint64_t sum = 0;
-        for (size_t i = 0; i < ac; ++i) { w[i] /= den; const uint32_t r = (uint32_t)(w[i] * (long)reads); rn[i] = r; sum += r; }
-        uint64_t n = reads - sum;                                                  // randIndx_hp (MyDefine.cpp:203-272)
-        const size_t nchunks = (ac + chunk - 1) / chunk;
-        std::vector<double> tp(nchunks); std::vector<uint32_t> quota(nchunks); uint64_t count = 0;
-        for (size_t ci = 0; ci < nchunks; ++ci) {
-            const size_t b = ci * chunk, e = std::min<size_t>(ac, b + chunk); double t = 0;
-            for (size_t i = b; i < e; ++i) t += w[i];
-            tp[ci] = t; quota[ci] = (uint32_t)(t * n); count += quota[ci];
-        }
-        n -= count;
-        if (n > 0) {
-            std::vector<double> probs(nchunks); probs[0] = tp[0];
-            for (size_t i = 1; i < nchunks; ++i) probs[i] = probs[i - 1] + tp[i];
-            for (uint32_t t = 0; t < n; ++t) {
-                const U4 d = draw4(c->key, ST_ALLOC_TOP, 0, 0, t);
-                const double r = ZF + (1 - ZF) * (d.w[0] / 4294967296.0);
-                quota[first_le(probs.data(), nchunks, r)] += 1;
-            }
-        }
-        std::vector<double> cdf(chunk);
-        for (size_t ci = 0; ci < nchunks; ++ci) {                                  // batchSampling (MyDefine.cpp:191-201)
-            if (!quota[ci]) continue;
-            const size_t b = ci * chunk, e = std::min<size_t>(ac, b + chunk); double run = 0;
-            for (size_t i = b; i < e; ++i) { run = run + w[i] / tp[ci]; cdf[i - b] = run; }
-            for (uint32_t t = 0; t < quota[ci]; ++t) {
-                const U4 d = draw4(c->key, ST_ALLOC_CHUNK, 0, ci, t);
-                const double r = ZF + (1 - ZF) * (d.w[0] / 4294967296.0);
-                rn[b + first_le(cdf.data(), e - b, r)] += 1;
-            }
-        }
-        if (c->cfg.paired) { int k = 1; for (size_t i = 0; i < ac; ++i) if (rn[i] & 1u) { rn[i] += k; k = -k; } }   // Malbac.cpp:399-407
-    }
-    std::vector<uint32_t> poff((size_t)ac + 1); uint64_t acc = 0;
-    for (size_t i = 0; i < ac; ++i) { poff[i] = (uint32_t)acc; acc += c->cfg.paired ? (rn[i] + 1) / 2 : rn[i]; if (acc > 0xFFFFFFF0ull) throw ScsError(SCS_EOVERFLOW, "more than 2^32 pairs"); }
-    poff[ac] = (uint32_t)acc; c->n_pairs_planned = acc;
-    upload(c->read_numbers, rn, s, 1); upload(c->pair_off, poff, s);
-    HIP_OK(hipStreamSynchronize(s));
-    c->st.t_stage[4] = now_s() - t1;
+    c->n_pairs_planned = (uint32_t)c->h_rb[0];
+    c->st.t_stage[3] = 0; c->st.t_stage[4] = now_s() - t0;
     c->allocated = true;
 }
 
@@ -519,6 +465,8 @@ int scs_create(const scs_config* cfg, scs_ctx** out) {
         if (cfg->stream) c->stream = (hipStream_t)cfg->stream; else { HIP_OK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
         c->key = RngKey{(uint32_t)cfg->seed, (uint32_t)(cfg->seed >> 32)};
         c->flags.reserve(256, c->stream); HIP_OK(hipMemsetAsync(c->flags.p, 0, 256, c->stream));
+        c->dsums.reserve(256, c->stream); HIP_OK(hipMemsetAsync(c->dsums.p, 0, 256, c->stream));
+        HIP_OK(hipHostMalloc((void**)&c->h_rb, 256, hipHostMallocDefault)); memset(c->h_rb, 0, 256);
         HIP_OK(hipStreamSynchronize(c->stream));
     } catch (const std::exception& e) { g_create_error = e.what(); delete c; return SCS_EDEVICE; }
     *out = c; return SCS_OK;
@@ -530,10 +478,12 @@ void scs_destroy(scs_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     for (DevBuf* b : {&c->t_subs1, &c->t_subs2, &c->t_qual, &c->t_ins, &c->t_del, &c->t_isize, &c->d_subs1, &c->d_subs2, &c->d_qual, &c->d_ins, &c->d_del,
                       &c->d_isize, &c->d_gcmeans, &c->genome, &c->df_goff, &c->df_len, &c->df_strand, &c->df_primers, &c->primer_cnt, &c->primer_delta,
-                      &c->budget, &c->slot_off, &c->slots, &c->slot_tmpl, &c->valid, &c->valid_off, &c->scan_tmp, &c->flags, &c->weights, &c->read_numbers,
-                      &c->pair_off, &c->pairs, &c->slot_b, &c->slot_q, &c->lens, &c->sizes1, &c->sizes2, &c->off1, &c->off2, &c->out1, &c->out2}) b->release();
+                      &c->slots, &c->slot_tmpl, &c->valid, &c->valid_off, &c->scan_tmp, &c->flags, &c->weights, &c->read_numbers,
+                      &c->pair_off, &c->pairs, &c->odd_before, &c->a_part, &c->a_tp, &c->a_probs, &c->a_quota, &c->budget_f, &c->budget_s, &c->slot_off_f,
+                      &c->slot_off_s, &c->dsums, &c->slot_b, &c->slot_q, &c->lens, &c->sizes1, &c->sizes2, &c->off1, &c->off2, &c->out1, &c->out2}) b->release();
     c->semis.release(); c->fulls.release();
     for (KernelTimer* t : {&c->tm_errscan, &c->tm_errscan_f, &c->tm_reads, &c->tm_attach, &c->tm_format}) t->release();
+    if (c->h_rb) (void)hipHostFree(c->h_rb);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -659,7 +609,11 @@ int scs_download_amplicons(scs_ctx* c, int kind, uint32_t* parent, uint32_t* spo
     });
 }
 int scs_download_read_numbers(scs_ctx* c, uint32_t* rn) {
-    return guarded(c, [&] { if (!c->allocated) throw ScsError(SCS_EINVAL, "call scs_allocate_reads first"); memcpy(rn, c->h_read_numbers.data(), c->h_read_numbers.size() * 4); });
+    return guarded(c, [&] {
+        if (!c->allocated) throw ScsError(SCS_EINVAL, "call scs_allocate_reads first");
+        if (c->fulls.n) HIP_OK(hipMemcpyAsync(rn, c->read_numbers.p, (size_t)c->fulls.n * 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_OK(hipStreamSynchronize(c->stream));
+    });
 }
 
 int scs_profile_open(const char* path, int paired, int isize, void** handle, char* errbuf, size_t errlen) {
