@@ -224,7 +224,7 @@ void set_primers(scs_ctx* c, bool only_frags, uint32_t call) {
     c->budget_f.reserve(((size_t)nf + 1) * 4, s); c->budget_s.reserve(((size_t)ns + 1) * 4, s);
     c->slot_off_f.reserve(((size_t)nf + 1) * 4, s); c->slot_off_s.reserve(((size_t)ns + 1) * 4, s);
     c->scan_tmp.reserve(scan_temp_bytes(std::max(nf, ns)), s);
-    HIP_OK(hipMemsetAsync(c->dsums.p, 0, 64, s));
+    HIP_OK(hipMemsetAsync(c->dsums.p, 0, 16, s));                                   // sums[0..1]; [4] keeps the running semi length total
     launch_poisson(s, c->frags_view(), c->semis.view(), ns, p, c->budget_f.as<uint32_t>(), c->budget_s.as<uint32_t>(), c->dsums.as<unsigned long long>());
     exclusive_scan_u32(s, c->budget_f.as<uint32_t>(), c->slot_off_f.as<uint32_t>(), nf, c->scan_tmp.p, c->scan_tmp.cap);
     if (ns) exclusive_scan_u32(s, c->budget_s.as<uint32_t>(), c->slot_off_s.as<uint32_t>(), ns, c->scan_tmp.p, c->scan_tmp.cap);
