@@ -86,62 +86,6 @@ __device__ __forceinline__ uint32_t rand_indx_thr(const uint32_t* __restrict__ T
     return lo < ac ? lo : ac - 1;
 }
 
-// ------------------------------------------------------------------------------------------------
-// K1a  attach: one thread per template runs the reference's sequential primer loop
-//      (Fragment::amplify lib/fragment/Fragment.cpp:73-95, Amplicon::amplify Amplicon.cpp:176-198)
-// ------------------------------------------------------------------------------------------------
-template <bool FROM_FRAG>
-__global__ void __launch_bounds__(64) k_attach(const uint8_t* __restrict__ g, DevFrags fr, DevAmps semis, uint32_t n_semis,
-                                               DevErrPool spool, const uint32_t* __restrict__ slot_off, uint32_t* __restrict__ slots,
-                                               uint32_t* __restrict__ slot_tmpl, uint32_t* __restrict__ valid,
-                                               const int64_t* __restrict__ primer_cnt, uint32_t* __restrict__ primer_delta, AmplifyParams p) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t nt = FROM_FRAG ? fr.n : n_semis;
-    if (t >= nt) return;
-    uint32_t len, budget; uint64_t tuid, errs = 0; View tv;
-    if (FROM_FRAG) {
-        len = fr.len[t]; budget = fr.primers[t]; tuid = fr.gidx_base + t;
-        tv = frag_view(fr.goff[t], len, fr.strand[t]);
-    } else {
-        const uint32_t f = semis.parent[t], sl = semis.sl[t];
-        len = sl_len(sl); budget = semis.primers[t]; tuid = semis.uid[t]; errs = semis.errs[t];
-        tv = semi_tmpl_view(frag_view(fr.goff[f], fr.len[f], fr.strand[f]), sl_spos(sl), len);
-    }
-    uint32_t v = 0;
-    if (len >= p.amp_min + 27 && budget > 0) {
-        const uint32_t base_slot = slot_off[t];
-        const uint32_t aux = (FROM_FRAG ? 0u : 1u) | (p.pass << 1);
-        for (uint32_t i = 0; i < budget; ++i) {
-            uint32_t tries = 0, spos = 0, alen = 0;
-            for (;;) {
-                const U4 d = draw4(p.key, ST_ATTACH, aux, tuid, (i << 6) | tries);
-                spos = scale_draw(d.w[0], 27, len - 27);                         // randomInteger(27, length)
-                alen = scale_draw(d.w[1], p.amp_min, p.amp_max + 1 - p.amp_min);  // (uint) randomDouble(minLen, maxLen+1)
-                ++tries;
-                if (tries > 50) break;
-                if (spos + alen > len) continue;
-                bool taken = false;                                              // posAttached[spos]
-                for (uint32_t q = 0; q < v; ++q) if (sl_spos(slots[base_slot + q]) == spos) { taken = true; break; }
-                if (taken) continue;
-                uint32_t idx = 0; bool hasN = false;                             // primer 8-mer of the template strand
-                for (uint32_t k = 0; k < 8; ++k) {
-                    const uint32_t c = FROM_FRAG ? view_base(g, tv, spos + k) : semi_tmpl_base(g, tv, len, errs, spool.data, spos + k);
-                    hasN |= c > 3; idx = (idx << 2) | (c & 3u);
-                }
-                if (hasN) continue;                                              // no stock for N-containing 8-mers
-                if (primer_cnt[idx] <= 0) continue;                              // [REMAP] stock as of pass start
-                atomicAdd(&primer_delta[idx], 1u);
-                break;
-            }
-            if (tries > 50) break;                                               // abandons the remaining primers
-            slots[base_slot + v] = pack_sl(spos, alen);
-            slot_tmpl[base_slot + v] = t;
-            ++v;
-        }
-    }
-    valid[t] = v;
-}
-
 __global__ void k_primer_update(int64_t* __restrict__ cnt, uint32_t* __restrict__ delta) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= 65536) return;
@@ -606,106 +550,148 @@ __device__ __forceinline__ void block_add_u64(unsigned long long v, unsigned lon
 //     (lib/mydefine/MyDefine.cpp:69-80: Knuth, sum of logs of uniforms) -- one thread per template.
 //     sums[0] += sum of k over fragments, sums[1] += sum of UNTRUNCATED k over semis (Malbac.cpp:282).
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_poisson(DevFrags fr, DevAmps semis, uint32_t n_semis, PoissonParams p,
-                                                 uint32_t* __restrict__ budget_f, uint32_t* __restrict__ budget_s,
-                                                 unsigned long long* __restrict__ sums) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t nf = fr.n;
-    unsigned long long kf = 0, ks = 0;
-    if (t < nf + n_semis) {
-        const bool isf = t < nf;
-        const uint32_t i = isf ? t : t - nf;
-        const uint32_t len = isf ? fr.len[i] : sl_len(semis.sl[i]);
-        const uint64_t tuid = isf ? fr.gidx_base + i : semis.uid[i];
-        const uint32_t aux = (isf ? 0u : 1u) | (p.call << 1);
-        const unsigned long long expected = (unsigned long long)((double)p.total_primers * p.gamma * (double)p.template_num);
-        const double lambda = (double)expected * (1.0 * (double)len / (double)p.total_len);
-        long x = -1; double log1 = 0; const double log2 = -lambda; uint32_t n = 0; U4 d;
+__device__ __forceinline__ double poisson_lambda(const PoissonParams& p, uint32_t len) {
+    const unsigned long long expected = (unsigned long long)((double)p.total_primers * p.gamma * (double)p.template_num);
+    return (double)expected * (1.0 * (double)len / (double)p.total_len);
+}
+// semis: lambda ~ 6 -> one thread per semi amplicon
+__global__ void __launch_bounds__(256) k_poisson_semis(DevAmps semis, uint32_t n_semis, PoissonParams p, uint32_t* __restrict__ budget_s,
+                                                       unsigned long long* __restrict__ sums) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long ks = 0;
+    if (i < n_semis) {
+        const double log2 = -poisson_lambda(p, sl_len(semis.sl[i]));
+        const uint64_t tuid = semis.uid[i];
+        const uint32_t aux = 1u | (p.call << 1);
+        long x = -1; double log1 = 0; uint32_t n = 0; U4 d;
         do {
             if ((n & 3) == 0) d = draw4(p.key, ST_POISSON, aux, tuid, n >> 2);
             const double u = (double)d.w[n & 3] / 4294967296.0; ++n;
             log1 += det_log(u); ++x;
         } while (log1 >= log2);
-        if (isf) { budget_f[i] = (uint32_t)(int)x; kf = (unsigned long long)x; }
-        else { budget_s[i] = (uint32_t)x & 0xFFFu; semis.primers[i] = (uint16_t)((uint32_t)x & 0xFFFu); ks = (unsigned long long)x; }
+        budget_s[i] = (uint32_t)x & 0xFFFu; semis.primers[i] = (uint16_t)((uint32_t)x & 0xFFFu);      // 12-bit field (Amplicon.cpp:76-79)
+        ks = (unsigned long long)x;
     }
-    block_add_u64(kf, &sums[0]);
     block_add_u64(ks, &sums[1]);
+}
+// fragments: lambda in the hundreds -> one wave per fragment; 64 logs at a time, accumulated in draw order
+__global__ void __launch_bounds__(64) k_poisson_frags(DevFrags fr, PoissonParams p, uint32_t* __restrict__ budget_f, unsigned long long* __restrict__ sums) {
+    const uint32_t t = blockIdx.x; const int lane = threadIdx.x;
+    const double log2 = -poisson_lambda(p, fr.len[t]);
+    const uint64_t tuid = fr.gidx_base + t;
+    const uint32_t aux = 0u | (p.call << 1);
+    long x = -1; double log1 = 0; bool more = true;
+    for (uint32_t c = 0; more; ++c) {
+        const uint32_t n = c * WAVE + lane;
+        const U4 d = draw4(p.key, ST_POISSON, aux, tuid, n >> 2);
+        const double lg = det_log((double)d.w[n & 3] / 4294967296.0);
+        for (int l = 0; l < WAVE; ++l) {                       // log1 += log(u) in draw order: same rounding as the serial loop
+            log1 += __shfl(lg, l); ++x;
+            if (!(log1 >= log2)) { more = false; break; }
+        }
+    }
+    if (lane == 0) { budget_f[t] = (uint32_t)(int)x; atomicAdd(&sums[0], (unsigned long long)x); }
 }
 
 // ------------------------------------------------------------------------------------------------
-// K1a' attach for fragments: one wave per fragment.  Budgets run to hundreds of primers per
-//      fragment and the reference's loop is sequential in the primer index (posAttached[] and the
-//      >50-tries abort), so the wave evaluates 64 primers speculatively and commits them in index
-//      order: a primer commits only when every lower primer has; one whose proposal hits a
-//      committed position moves on to its next try exactly as the sequential loop would.  Results
-//      are identical to the thread-per-template loop of k_attach.
+// K1a  attach: the primer loop of Fragment::amplify (lib/fragment/Fragment.cpp:73-95) and
+//      Amplicon::amplify (lib/amplicon/Amplicon.cpp:176-198).  The reference's loop is sequential
+//      in the primer index (posAttached[] and the >50-tries abort).  Here a group of G lanes owns
+//      one template (G = 64: one wave per fragment, budgets of hundreds; G = 16: four semi
+//      amplicons per wave, budgets of ~6): the lanes evaluate G primers speculatively and commit
+//      them in index order -- a primer commits only when every lower primer has; one whose
+//      proposal hits a committed position moves on to its next try exactly as the sequential loop
+//      would.  The result is identical to running the sequential loop.
 // ------------------------------------------------------------------------------------------------
-#define BITMAP_WORDS 4096      // 131072 positions (packed-record limit of spos)
-__global__ void __launch_bounds__(64) k_attach_frags_wave(const uint8_t* __restrict__ g, DevFrags fr, const uint32_t* __restrict__ slot_off,
-                                                          uint32_t* __restrict__ slots, uint32_t* __restrict__ slot_tmpl, uint32_t* __restrict__ valid,
-                                                          const int64_t* __restrict__ primer_cnt, uint32_t* __restrict__ primer_delta,
-                                                          unsigned long long* __restrict__ len_sum, AmplifyParams p) {
-    __shared__ uint32_t s_bits[BITMAP_WORDS];
-    const uint32_t t = blockIdx.x; const int lane = threadIdx.x;
-    const uint32_t len = fr.len[t], budget = fr.primers[t];
-    if (len < p.amp_min + 27 || budget == 0) { if (lane == 0) valid[t] = 0; return; }
-    for (uint32_t w = lane; w < (len + 31) / 32; w += WAVE) s_bits[w] = 0;
+template <bool FROM_FRAG, int G>
+__global__ void __launch_bounds__(64) k_attach(const uint8_t* __restrict__ g, DevFrags fr, DevAmps semis, uint32_t n_semis, DevErrPool spool,
+                                               const uint32_t* __restrict__ slot_off, uint32_t* __restrict__ slots, uint32_t* __restrict__ slot_tmpl,
+                                               uint32_t* __restrict__ valid, const int64_t* __restrict__ primer_cnt, uint32_t* __restrict__ primer_delta,
+                                               unsigned long long* __restrict__ len_sum, AmplifyParams p) {
+    constexpr int TPB = 64 / G;                              // templates per wave
+    constexpr int WORDS = FROM_FRAG ? 4096 : 64;             // position bitmap: 131072 / 2048 positions (packed-record limits)
+    __shared__ uint32_t s_bits[TPB * WORDS];
+    const int lane = threadIdx.x, gi = lane / G, gl = lane % G;
+    const unsigned long long gmask = G == 64 ? ~0ull : (((1ull << (G & 63)) - 1ull) << (gi * G));
+    const uint32_t nt = FROM_FRAG ? fr.n : n_semis;
+    const uint32_t t = blockIdx.x * TPB + gi;
+    uint32_t len = 0, budget = 0; uint64_t tuid = 0, errs = 0; View tv{0, 1, 0};
+    if (t < nt) {
+        if (FROM_FRAG) { len = fr.len[t]; budget = fr.primers[t]; tuid = fr.gidx_base + t; tv = frag_view(fr.goff[t], len, fr.strand[t]); }
+        else {
+            const uint32_t f = semis.parent[t], sl = semis.sl[t];
+            len = sl_len(sl); budget = semis.primers[t]; tuid = semis.uid[t]; errs = semis.errs[t];
+            tv = semi_tmpl_view(frag_view(fr.goff[f], fr.len[f], fr.strand[f]), sl_spos(sl), len);
+        }
+    }
+    uint32_t* bits = s_bits + gi * WORDS;
+    bool group_done = !(t < nt && len >= p.amp_min + 27 && budget > 0);
+    if (!group_done) for (uint32_t w = gl; w < (len + 31) / 32; w += G) bits[w] = 0;
     __builtin_amdgcn_wave_barrier();
-    const View tv = frag_view(fr.goff[t], len, fr.strand[t]);
-    const uint64_t tuid = fr.gidx_base + t;
-    const uint32_t base_slot = slot_off[t], aux = 0u | (p.pass << 1);
-    uint32_t v = 0; bool aborted = false; unsigned long long lsum = 0;
-    for (uint32_t c0 = 0; c0 < budget && !aborted; c0 += WAVE) {
-        const uint32_t i = c0 + lane;
-        bool unresolved = i < budget, need = unresolved, dead = false;
-        uint32_t tries = 0, spos = 0, alen = 0, pidx = 0;
-        while (__ballot(unresolved)) {
+    const uint32_t base_slot = t < nt ? slot_off[t] : 0, aux = (FROM_FRAG ? 0u : 1u) | (p.pass << 1);
+    uint32_t v = 0, c0 = 0, i = 0, tries = 0, spos = 0, alen = 0, pidx = 0;
+    bool fresh = true, unresolved = false, need = false, dead = false;
+    unsigned long long lsum = 0;
+    while (__ballot(!group_done)) {
+        if (!group_done) {
+            if (fresh) { i = c0 + gl; unresolved = i < budget; need = unresolved; dead = false; tries = 0; fresh = false; }
             if (unresolved && !dead) {
-                if (!need && ((s_bits[spos >> 5] >> (spos & 31)) & 1u)) need = true;     // a lower primer took this position meanwhile
+                if (!need && ((bits[spos >> 5] >> (spos & 31)) & 1u)) need = true;       // a lower primer took this position meanwhile
                 while (need) {
                     const U4 d = draw4(p.key, ST_ATTACH, aux, tuid, (i << 6) | tries);
-                    spos = scale_draw(d.w[0], 27, len - 27);
-                    alen = scale_draw(d.w[1], p.amp_min, p.amp_max + 1 - p.amp_min);
+                    spos = scale_draw(d.w[0], 27, len - 27);                             // randomInteger(27, length)
+                    alen = scale_draw(d.w[1], p.amp_min, p.amp_max + 1 - p.amp_min);      // (uint) randomDouble(minLen, maxLen+1)
                     ++tries;
                     if (tries > 50) { dead = true; break; }
                     if (spos + alen > len) continue;
-                    if ((s_bits[spos >> 5] >> (spos & 31)) & 1u) continue;
-                    uint32_t idx = 0; bool hasN = false;
-                    for (uint32_t k = 0; k < 8; ++k) { const uint32_t c = view_base(g, tv, spos + k); hasN |= c > 3; idx = (idx << 2) | (c & 3u); }
-                    if (hasN || primer_cnt[idx] <= 0) continue;
+                    if ((bits[spos >> 5] >> (spos & 31)) & 1u) continue;                  // posAttached[spos]
+                    uint32_t idx = 0; bool hasN = false;                                 // primer 8-mer of the template strand
+                    for (uint32_t k = 0; k < 8; ++k) {
+                        const uint32_t c = FROM_FRAG ? view_base(g, tv, spos + k) : semi_tmpl_base(g, tv, len, errs, spool.data, spos + k);
+                        hasN |= c > 3; idx = (idx << 2) | (c & 3u);
+                    }
+                    if (hasN || primer_cnt[idx] <= 0) continue;                          // no stock for N 8-mers; [REMAP] stock as of pass start
                     pidx = idx; need = false;
                 }
             }
-            // blocked = some lower unresolved live lane proposes the same position
-            bool blocked = false;
-            const unsigned long long um = __ballot(unresolved && !dead);
+        }
+        // blocked = a lower unresolved live lane of my group proposes the same position
+        const bool live = !group_done && unresolved && !dead;
+        const unsigned long long um = __ballot(live);
+        bool blocked = false;
+        if (G == 64) {
             for (unsigned long long m = um; m; m &= m - 1) {
                 const int j = __ffsll((long long)m) - 1;
                 const uint32_t sj = __shfl(spos, j);
-                if (j < lane && unresolved && !dead && sj == spos) blocked = true;
+                if (j < lane && live && sj == spos) blocked = true;
             }
-            const unsigned long long bm = __ballot(unresolved && blocked), dm = __ballot(unresolved && dead);
-            const int first_blocked = bm ? __ffsll((long long)bm) - 1 : 64, first_dead = dm ? __ffsll((long long)dm) - 1 : 64;
-            const int commit_end = first_blocked < first_dead ? first_blocked : first_dead;
-            if (unresolved && lane < commit_end) {                                       // commit, in primer order
-                atomicOr(&s_bits[spos >> 5], 1u << (spos & 31));
-                atomicAdd(&primer_delta[pidx], 1u);
-                slots[base_slot + i] = pack_sl(spos, alen); slot_tmpl[base_slot + i] = t;
-                lsum += alen; unresolved = false;
+        } else {
+#pragma unroll
+            for (int j = 0; j < G; ++j) {
+                const uint32_t sj = __shfl(spos, gi * G + j);
+                if (j < gl && live && ((um >> (gi * G + j)) & 1ull) && sj == spos) blocked = true;
             }
-            if (first_dead <= first_blocked && first_dead < 64) { aborted = true; unresolved = false; }
-            __builtin_amdgcn_wave_barrier();
         }
-        if (!aborted) v = (c0 + WAVE < budget) ? c0 + WAVE : budget;
-        else {
-            // number committed = index of the aborting primer
-            const unsigned long long dm = __ballot(dead);
-            v = c0 + (uint32_t)(__ffsll((long long)dm) - 1);
+        const unsigned long long bm = __ballot(live && blocked) & gmask, dm = __ballot(!group_done && unresolved && dead) & gmask;
+        const int first_blocked = bm ? __ffsll((long long)bm) - 1 - gi * G : G, first_dead = dm ? __ffsll((long long)dm) - 1 - gi * G : G;
+        const int commit_end = first_blocked < first_dead ? first_blocked : first_dead;
+        if (live && gl < commit_end) {                                                   // commit, in primer order
+            atomicOr(&bits[spos >> 5], 1u << (spos & 31));
+            atomicAdd(&primer_delta[pidx], 1u);
+            slots[base_slot + i] = pack_sl(spos, alen); slot_tmpl[base_slot + i] = t;
+            lsum += alen; unresolved = false;
         }
+        __builtin_amdgcn_wave_barrier();
+        if (!group_done) {
+            if (first_dead <= first_blocked && first_dead < G) { group_done = true; v = c0 + (uint32_t)first_dead; }   // abandons the remaining primers
+            else if ((__ballot(unresolved) & gmask) == 0) {                              // chunk finished
+                c0 += G;
+                if (c0 >= budget) { group_done = true; v = budget; } else fresh = true;
+            }
+        } else (void)__ballot(false);
     }
-    lsum = wave_sum_u64(lsum);
-    if (lane == 0) { valid[t] = v; if (lsum) atomicAdd(len_sum, lsum); }
+    if (FROM_FRAG) { lsum = wave_sum_u64(lsum); if (lane == 0 && lsum) atomicAdd(len_sum, lsum); }
+    if (gl == 0 && t < nt) valid[t] = v;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -714,12 +700,13 @@ __global__ void __launch_bounds__(64) k_attach_frags_wave(const uint8_t* __restr
 //     All sums run in the oracle's order (sequential inside a chunk, chunks in order).
 // ------------------------------------------------------------------------------------------------
 #define ALLOC_CHUNK 1000u
-__global__ void k_alloc_chunk_sum(const double* __restrict__ w, uint32_t ac, double* __restrict__ part) {
-    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x, nch = (ac + ALLOC_CHUNK - 1) / ALLOC_CHUNK;
-    if (c >= nch) return;
-    const uint32_t b = c * ALLOC_CHUNK, e = min(ac, b + ALLOC_CHUNK);
-    double s = 0; for (uint32_t i = b; i < e; ++i) s += w[i];
-    part[c] = s;
+// one wave per chunk: coalesced load into LDS, then lane 0 adds in index order (the oracle's order)
+__global__ void __launch_bounds__(64) k_alloc_chunk_sum(const double* __restrict__ w, uint32_t ac, double* __restrict__ part) {
+    __shared__ double s_w[ALLOC_CHUNK];
+    const uint32_t c = blockIdx.x, b = c * ALLOC_CHUNK, e = min(ac, b + ALLOC_CHUNK), n = e - b;
+    for (uint32_t i = threadIdx.x; i < n; i += WAVE) s_w[i] = w[b + i];
+    __builtin_amdgcn_wave_barrier();
+    if (threadIdx.x == 0) { double s = 0; for (uint32_t i = 0; i < n; ++i) s += s_w[i]; part[c] = s; }
 }
 __global__ void k_alloc_total(const double* __restrict__ part, uint32_t nch, AllocState* __restrict__ st) {
     if (blockIdx.x || threadIdx.x) return;
@@ -738,20 +725,27 @@ __global__ void __launch_bounds__(256) k_alloc_floor(double* __restrict__ w, uin
     }
     block_add_u64(r, &st->sum_rn);
 }
-__global__ void __launch_bounds__(256) k_alloc_quota(double* __restrict__ w, uint32_t ac, unsigned long long reads, AllocState* __restrict__ st,
-                                                     double* __restrict__ tp, uint32_t* __restrict__ quota) {
-    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x, nch = (ac + ALLOC_CHUNK - 1) / ALLOC_CHUNK;
-    unsigned long long q = 0;
-    if (c < nch) {
-        const unsigned long long n = reads - st->sum_rn;
-        const uint32_t b = c * ALLOC_CHUNK, e = min(ac, b + ALLOC_CHUNK);
-        double t = 0; for (uint32_t i = b; i < e; ++i) t += w[i];
-        double run = 0; for (uint32_t i = b; i < e; ++i) { run = run + w[i] / t; w[i] = run; }   // chunk-local CDF in place
-        tp[c] = t;
-        const uint32_t qq = (uint32_t)(t * (double)n);
-        quota[c] = qq; q = qq;
+__global__ void __launch_bounds__(64) k_alloc_quota(double* __restrict__ w, uint32_t ac, unsigned long long reads, AllocState* __restrict__ st,
+                                                    double* __restrict__ tp, uint32_t* __restrict__ quota) {
+    __shared__ double s_w[ALLOC_CHUNK];
+    __shared__ double s_t;
+    const uint32_t c = blockIdx.x, b = c * ALLOC_CHUNK, e = min(ac, b + ALLOC_CHUNK), n = e - b;
+    for (uint32_t i = threadIdx.x; i < n; i += WAVE) s_w[i] = w[b + i];
+    __builtin_amdgcn_wave_barrier();
+    if (threadIdx.x == 0) { double t = 0; for (uint32_t i = 0; i < n; ++i) t += s_w[i]; s_t = t; }
+    __builtin_amdgcn_wave_barrier();
+    const double t = s_t;
+    for (uint32_t i = threadIdx.x; i < n; i += WAVE) s_w[i] = s_w[i] / t;                 // p[i]/totalProb (MyDefine.cpp:224)
+    __builtin_amdgcn_wave_barrier();
+    if (threadIdx.x == 0) {
+        double run = 0; for (uint32_t i = 0; i < n; ++i) { run = run + s_w[i]; s_w[i] = run; }   // chunk-local CDF, in index order
+        const unsigned long long nres = reads - st->sum_rn;
+        const uint32_t q = (uint32_t)(t * (double)nres);
+        tp[c] = t; quota[c] = q;
+        if (q) atomicAdd(&st->sum_quota, (unsigned long long)q);
     }
-    block_add_u64(q, &st->sum_quota);
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t i = threadIdx.x; i < n; i += WAVE) w[b + i] = s_w[i];
 }
 __global__ void k_alloc_top_prefix(const double* __restrict__ tp, uint32_t nch, double* __restrict__ probs) {
     if (blockIdx.x || threadIdx.x) return;
@@ -802,22 +796,22 @@ static const uint32_t kMaxStrideGrid = 256 * 8;
 void launch_attach_frags(hipStream_t s, const uint8_t* g, DevFrags fr, const uint32_t* slot_off, uint32_t* slots, uint32_t* slot_tmpl,
                          uint32_t* valid, const int64_t* primer_cnt, uint32_t* primer_delta, unsigned long long* len_sum, AmplifyParams p) {
     if (fr.n == 0) return;
-    hipLaunchKernelGGL(k_attach_frags_wave, dim3(fr.n), dim3(64), 0, s, g, fr, slot_off, slots, slot_tmpl, valid, primer_cnt, primer_delta, len_sum, p);
+    DevAmps none{}; DevErrPool np{};
+    hipLaunchKernelGGL((k_attach<true, 64>), dim3(fr.n), dim3(64), 0, s, g, fr, none, 0u, np, slot_off, slots, slot_tmpl, valid, primer_cnt, primer_delta, len_sum, p);
 }
 void launch_poisson(hipStream_t s, DevFrags fr, DevAmps semis, uint32_t n_semis, PoissonParams p, uint32_t* budget_f, uint32_t* budget_s,
                     unsigned long long* sums) {
-    const uint64_t n = (uint64_t)fr.n + n_semis;
-    if (n == 0) return;
-    hipLaunchKernelGGL(k_poisson, dim3(cdiv(n, 256)), dim3(256), 0, s, fr, semis, n_semis, p, budget_f, budget_s, sums);
+    if (fr.n) hipLaunchKernelGGL(k_poisson_frags, dim3(fr.n), dim3(64), 0, s, fr, p, budget_f, sums);
+    if (n_semis) hipLaunchKernelGGL(k_poisson_semis, dim3(cdiv(n_semis, 256)), dim3(256), 0, s, semis, n_semis, p, budget_s, sums);
 }
 void launch_alloc(hipStream_t s, double* w, uint32_t ac, unsigned long long reads, RngKey key, int paired, AllocState* st, double* part, double* tp,
                   double* probs, uint32_t* quota, uint32_t* rn, uint32_t* odd_before, uint32_t* pair_cnt_off, void* temp, size_t temp_bytes) {
     if (ac == 0) return;
     const uint32_t nch = (ac + ALLOC_CHUNK - 1) / ALLOC_CHUNK;
-    hipLaunchKernelGGL(k_alloc_chunk_sum, dim3(cdiv(nch, 64)), dim3(64), 0, s, w, ac, part);
+    hipLaunchKernelGGL(k_alloc_chunk_sum, dim3(nch), dim3(64), 0, s, w, ac, part);
     hipLaunchKernelGGL(k_alloc_total, dim3(1), dim3(64), 0, s, part, nch, st);
     hipLaunchKernelGGL(k_alloc_floor, dim3(cdiv(ac, 256)), dim3(256), 0, s, w, ac, reads, st, rn);
-    hipLaunchKernelGGL(k_alloc_quota, dim3(cdiv(nch, 256)), dim3(256), 0, s, w, ac, reads, st, tp, quota);
+    hipLaunchKernelGGL(k_alloc_quota, dim3(nch), dim3(64), 0, s, w, ac, reads, st, tp, quota);
     hipLaunchKernelGGL(k_alloc_top_prefix, dim3(1), dim3(64), 0, s, tp, nch, probs);
     hipLaunchKernelGGL(k_alloc_top_draws, dim3(cdiv((uint64_t)nch + 1024, 256)), dim3(256), 0, s, probs, nch, reads, st, key, quota);
     hipLaunchKernelGGL(k_alloc_sample, dim3(nch), dim3(256), 0, s, w, ac, quota, key, rn);
@@ -833,7 +827,8 @@ void launch_attach_semis(hipStream_t s, const uint8_t* g, DevFrags fr, DevAmps s
                          const uint32_t* slot_off, uint32_t* slots, uint32_t* slot_tmpl, uint32_t* valid,
                          const int64_t* primer_cnt, uint32_t* primer_delta, AmplifyParams p) {
     if (n_semis == 0) return;
-    hipLaunchKernelGGL(k_attach<false>, dim3(cdiv(n_semis, 64)), dim3(64), 0, s, g, fr, semis, n_semis, spool, slot_off, slots, slot_tmpl, valid, primer_cnt, primer_delta, p);
+    hipLaunchKernelGGL((k_attach<false, 16>), dim3(cdiv(n_semis, 4)), dim3(64), 0, s, g, fr, semis, n_semis, spool, slot_off, slots, slot_tmpl, valid,
+                       primer_cnt, primer_delta, (unsigned long long*)nullptr, p);
 }
 void launch_errscan_frags(hipStream_t s, const uint8_t* g, DevFrags fr, uint32_t n_slots, const uint32_t* slot_off, const uint32_t* slots,
                           const uint32_t* slot_tmpl, const uint32_t* valid_off, DevAmps out, uint32_t out_base, DevErrPool pool, uint32_t* flags, AmplifyParams p) {
