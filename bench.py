@@ -100,7 +100,7 @@ def main():
         g.create_frags()
         g.amplify()
         if record:
-            acc(g.kernel_times(), ("k_errscan<semi->full>", "k_errscan<frag->semi>", "k_attach"))
+            acc(g.kernel_times(), ("k_errs<semi->full>", "k_errs<frag->semi>", "k_attach"))
         g.allocate_reads(0)
         n1, n2, pairs = g.yield_reads_device(pool1.data_ptr(), cap, pool2.data_ptr(), cap)
         if record:
@@ -155,7 +155,7 @@ def main():
     if rank == 0:
         dom = max(ktimes, key=lambda k: ktimes[k]["ms"])
         kd = ktimes[dom]
-        if dom.startswith("k_errscan"):
+        if dom.startswith("k_errs"):
             # 1526 algorithmic bytes per created amplicon (template window read once + descriptor
             # write + primer-counter RMW + error entries) x amplicons created by these launches
             alg = 1526.0 * kd["units"]

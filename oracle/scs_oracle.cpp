@@ -10,8 +10,9 @@
 //   counter : Philox4x32-10 keyed by logical ids (DESIGN.md "RNG remapping").
 // Apart from where a draw comes from, the two modes differ only in the three
 // places marked [REMAP] below (primer-pool snapshot per pass, chunked weight
-// sum, GC-factor normal sampler, software log in the Poisson sampler) -- each is
-// order-free / libm-free so that any thread / GPU schedule gives the same bytes.
+// sum, GC-factor normal sampler, software log in the Poisson sampler, binomial
+// count + positions for the amplification errors) -- each is order-free /
+// libm-free so that any thread / GPU schedule gives the same bytes.
 #include "scs_oracle.h"
 
 #include <algorithm>
@@ -99,8 +100,11 @@ double det_log(double x) {
 // ---------------------------------------------------------------------------
 enum Stage : uint32_t {
     ST_FRAGSPLIT = 1, ST_POISSON = 2, ST_ATTACH = 3, ST_ERR = 4, ST_ERRALT = 5, ST_WEIGHT = 6,
-    ST_ALLOC_TOP = 7, ST_ALLOC_CHUNK = 8, ST_PAIR = 9, ST_INDEL = 10, ST_INDEL_INS = 11, ST_BASE = 12
+    ST_ALLOC_TOP = 7, ST_ALLOC_CHUNK = 8, ST_PAIR = 9, ST_READ = 10, ST_INDEL_INS = 11, ST_INDEL_LEN = 12
 };
+// ST_READ block j of a read: word0 = insertion test of input base j, word1 = deletion test of input
+// base j, word2 = substitution draw of OUTPUT base j, word3 = quality draw of OUTPUT base j (or the
+// random quality when that base is N).  One Philox block per base index serves both passes.
 
 struct Key { uint32_t idx; uint64_t uid; uint32_t stage_word; int word; };
 inline Key mk(uint32_t stage, uint32_t aux, uint64_t uid, uint32_t idx, int word) {
@@ -382,18 +386,18 @@ int predict(const Profile& P, Rng& rng, const uint8_t* win, int n, bool isRead1,
     int indelLength = 0;
     for (int j = 0; j < n;) {                                                  // 1606-1622
         int k = 0; bool isIns = false;
-        double p = rng.real(mk(ST_INDEL, aux, uid, j, 0));                      // getIndelSeq 1552-1570
+        double p = rng.real(mk(ST_READ, aux, uid, j, 0));                       // getIndelSeq 1552-1570
         if (p <= P.insertRate) {
-            k = rand_indx(P.insCdf.data(), P.insCdf.size(), rng.real(mk(ST_INDEL, aux, uid, j, 2)));
+            k = rand_indx(P.insCdf.data(), P.insCdf.size(), rng.real(mk(ST_INDEL_LEN, aux, uid, j, 0)));
             for (int t = 0; t < k; ++t) {
                 double u = rng.integer(mk(ST_INDEL_INS, aux, uid, (uint32_t)j | ((uint32_t)(t / 4) << 16), t % 4));
                 ins[j].push_back((uint8_t)(long)(0 + (P.N - 1 - 0) * u));       // randomInteger(0, N-1): never 'T'
             }
             isIns = !ins[j].empty();
         } else {
-            p = rng.real(mk(ST_INDEL, aux, uid, j, 1));
+            p = rng.real(mk(ST_READ, aux, uid, j, 1));
             if (p < P.delRate / (1 - P.insertRate))
-                k = rand_indx(P.delCdf.data(), P.delCdf.size(), rng.real(mk(ST_INDEL, aux, uid, j, 2)));
+                k = rand_indx(P.delCdf.data(), P.delCdf.size(), rng.real(mk(ST_INDEL_LEN, aux, uid, j, 0)));
         }
         if (!isIns && k > 0) {                                                  // deletion
             k = std::min(n - j, k);
@@ -428,14 +432,14 @@ int predict(const Profile& P, Rng& rng, const uint8_t* win, int n, bool isRead1,
         int ki = kmer_index(c0, c1, c2);
         int k;
         if (ki < 0) k = refIndx;
-        else k = rand_indx(&subs[((size_t)ki * B + bin) * 4], 4, rng.real(mk(ST_BASE, aux, uid, j, 0)));
+        else k = rand_indx(&subs[((size_t)ki * B + bin) * 4], 4, rng.real(mk(ST_READ, aux, uid, j, 2)));
         if (k < 0) {
             out_b[j] = 'N';
-            out_q[j] = (char)(long)(33 + (53 - 33) * rng.integer(mk(ST_BASE, aux, uid, j, 2)));   // getRandBaseQuality 1578-1580
+            out_q[j] = (char)(long)(33 + (53 - 33) * rng.integer(mk(ST_READ, aux, uid, j, 3)));   // getRandBaseQuality 1578-1580
         } else {
             out_b[j] = BASES[k];
             int bp = refIndx * 4 + k;
-            out_q[j] = (char)(33 + rand_indx(&P.qual[((size_t)bp * B + bin) * 94], 94, rng.real(mk(ST_BASE, aux, uid, j, 1))));
+            out_q[j] = (char)(33 + rand_indx(&P.qual[((size_t)bp * B + bin) * 94], 94, rng.real(mk(ST_READ, aux, uid, j, 3))));
         }
     }
     return m;
@@ -473,6 +477,7 @@ struct Sim {
     std::vector<Frag> frags; AmpList semis, fulls;
     std::vector<long> primerCount;          // 65536 counters (Malbac.cpp:36-81; flat instead of trie)
     std::vector<long> primerPending;        // [REMAP] counter mode: decrements applied at pass end
+    std::vector<uint64_t> binom;            // [REMAP] counter mode: error-count thresholds
     unsigned long totalPrimers = 0;
     std::vector<unsigned> readNumbers;
     // GC-factor engines (ref mode): Profile.cpp:1405-1411
@@ -569,6 +574,26 @@ void set_primers(Sim& S, bool onlyFrags, uint32_t call) {
     S.totalPrimers -= count;
 }
 
+// [REMAP] counter mode draws the amplification errors of one new amplicon as K ~ Binomial(l-8, ber)
+// followed by K distinct uniform positions -- the same distribution as the reference's one
+// Bernoulli(ber) draw per base (Fragment.cpp:100-104, Amplicon.cpp:203-207) at ~4 draws per amplicon
+// instead of ~1500.  T[n][k] = floor(CDF_n(k) * 2^64); IEEE * + / only, so every build gets the same table.
+const int BINOM_KMAX = 16;
+std::vector<uint64_t> binom_table(double ber, int n_min, int n_max) {
+    std::vector<uint64_t> T((size_t)(n_max - n_min + 1) * BINOM_KMAX);
+    const double q = 1 - ber, ratio = ber / q;
+    for (int n = n_min; n <= n_max; ++n) {
+        double pmf = 1, b = q; for (unsigned e = (unsigned)n; e; e >>= 1) { if (e & 1) pmf = pmf * b; b = b * b; }
+        double cdf = 0;
+        for (int k = 0; k < BINOM_KMAX; ++k) {
+            cdf += pmf;
+            T[(size_t)(n - n_min) * BINOM_KMAX + k] = cdf >= 1.0 ? ~0ull : (uint64_t)(cdf * 18446744073709551616.0);
+            pmf = pmf * (double)(n - k) / (double)(k + 1) * ratio;
+        }
+    }
+    return T;
+}
+
 // ---- a4/a5: Fragment::amplify (Fragment.cpp:52-137) / Amplicon::amplify (Amplicon.cpp:156-240) --
 // T = template strand (c(F) or c(S)); appends created amplicons in creation order.
 void amplify_template(Sim& S, Rng& rng, PrimerPool& pool, bool fromFrag, uint64_t tuid, uint32_t parent,
@@ -596,19 +621,35 @@ void amplify_template(Sim& S, Rng& rng, PrimerPool& pool, bool fromFrag, uint64_
         if (hasN) gc = 0;
         const uint64_t nuid = fromFrag ? semi_uid(tuid, pass, i) : full_uid(tuid, pass, i);
         uint32_t off = (uint32_t)out.errs.size();
-        for (unsigned j = 8; j < alen; ++j) {
-            double pr = rng.real(mk(ST_ERR, kind, nuid, j / 4, j % 4));
-            if (pr < p.ber) {
-                uint8_t base = T[spos + j]; unsigned n; uint32_t a = 0;
-                do {
-                    Key k = mk(ST_ERRALT, kind, nuid, j | ((a / 4) << 16), a % 4); a++;
-                    // Fragment.cpp:110 draws from the int stream, Amplicon.cpp:213 from the real stream
-                    n = fromFrag ? (unsigned)(long)(0 + (4 - 0) * rng.integer(k)) : (unsigned)(0 + (4 - 0) * rng.real(k));
-                } while (n == base);
-                if (is_gc((uint8_t)n)) gc++;
-                if (is_gc(base)) gc--;
-                out.errs.push_back((j << 3) | n);
+        auto add_error = [&](unsigned j) {
+            uint8_t base = T[spos + j]; unsigned n; uint32_t a = 0;
+            do {
+                Key k = mk(ST_ERRALT, kind, nuid, j | ((a / 4) << 16), a % 4); a++;
+                // Fragment.cpp:110 draws from the int stream, Amplicon.cpp:213 from the real stream
+                n = fromFrag ? (unsigned)(long)(0 + (4 - 0) * rng.integer(k)) : (unsigned)(0 + (4 - 0) * rng.real(k));
+            } while (n == base);
+            if (is_gc((uint8_t)n)) gc++;
+            if (is_gc(base)) gc--;
+            out.errs.push_back((j << 3) | n);
+        };
+        if (!p.counter) {
+            for (unsigned j = 8; j < alen; ++j) if (rng.real(mk(ST_ERR, kind, nuid, 0, 0)) < p.ber) add_error(j);
+        } else {                                                                   // [REMAP] binomial count + distinct positions
+            const unsigned ntr = alen - 8;
+            uint32_t c[4] = {0, (uint32_t)nuid, (uint32_t)(nuid >> 32), ST_ERR | (kind << 8)}, o[4];
+            philox(c, rng.key, o);
+            const uint64_t x64 = ((uint64_t)o[0] << 32) | o[1];
+            const uint64_t* Tn = &S.binom[(size_t)(ntr - (p.ampMin - 8)) * BINOM_KMAX];
+            unsigned K = 0; while (K < (unsigned)BINOM_KMAX && x64 >= Tn[K]) ++K;
+            unsigned pos[BINOM_KMAX], cnt = 0, q = 0;
+            while (cnt < K) {
+                if ((q & 3) == 0) { c[0] = 1 + (q >> 2); philox(c, rng.key, o); }
+                const unsigned cand = 8 + (unsigned)(((uint64_t)ntr * o[q & 3]) >> 32); ++q;
+                bool dup = false; for (unsigned z = 0; z < cnt; ++z) dup |= pos[z] == cand;
+                if (!dup) pos[cnt++] = cand;
             }
+            std::sort(pos, pos + cnt);
+            for (unsigned z = 0; z < cnt; ++z) add_error(pos[z]);
         }
         out.a.push_back(Amp{parent, spos, alen, (uint32_t)std::max(0, gc), 0, nuid, off, (uint32_t)out.errs.size() - off});
     }
@@ -693,6 +734,7 @@ void amplify_semis(Sim& S, uint32_t cyc) {
 void amplify(Sim& S) {
     if (S.prm.verbose) fprintf(stderr, "\nMALBAC amplification...\n");
     S.primerCount.assign(65536, S.prm.primers);
+    if (S.prm.counter) S.binom = binom_table(S.prm.ber, S.prm.ampMin - 8, S.prm.ampMax - 8);
     S.totalPrimers = 65536UL * (unsigned long)S.prm.primers;
     set_primers(S, true, 0);
     amplify_frags(S, 0);

@@ -22,15 +22,17 @@ enum Stage : uint32_t {
     ST_FRAGSPLIT   = 1,   // uid = record index, idx = k-th fragment of the record, word 0     (Genome.cpp:760)
     ST_POISSON     = 2,   // uid = template uid, aux = kind | call<<1, draw t -> idx t/4 word t%4 (MyDefine.cpp:69-80)
     ST_ATTACH      = 3,   // uid = template uid, aux = kind | pass<<1, idx = primer<<6 | try, word0 spos, word1 length
-    ST_ERR         = 4,   // uid = NEW amplicon uid, aux = kind, base j -> idx j/4 word j%4     (Fragment.cpp:102-104)
+    ST_ERR         = 4,   // uid = NEW amplicon uid, aux = kind; block 0: words 0,1 = 64-bit draw for the error COUNT
+                          //   (binomial thresholds); blocks 1.. : candidate error positions, one word each   [REMAP of Fragment.cpp:100-104]
     ST_ERRALT      = 5,   // uid = NEW amplicon uid, aux = kind, idx = j | (a/4)<<16, word a%4  (Fragment.cpp:107-110)
     ST_WEIGHT      = 6,   // uid = full uid, idx = attempt, words 0,1                           (Profile.cpp:1503-1513)
     ST_ALLOC_TOP   = 7,   // uid = 0, idx = t, word 0                                           (MyDefine.cpp:242-245)
     ST_ALLOC_CHUNK = 8,   // uid = chunk, idx = t, word 0                                       (MyDefine.cpp:191-201)
     ST_PAIR        = 9,   // uid = full uid, idx = attempt, word0 insert size, word1 position   (Amplicon.cpp:483-491)
-    ST_INDEL       = 10,  // uid = full uid, aux = rd | attempt<<1, idx = j, word0 p1, word1 p2, word2 length
+    ST_READ        = 10,  // uid = full uid, aux = rd | attempt<<1, idx = j: word0 insertion test and word1 deletion test of
+                          //   INPUT base j; word2 substitution and word3 quality (or random quality of an N) of OUTPUT base j
     ST_INDEL_INS   = 11,  // same aux, idx = j | (t/4)<<16, word t%4 : t-th inserted base       (Profile.cpp:1560)
-    ST_BASE        = 12   // same aux, idx = out position j, word0 substitution, word1 quality, word2 random quality
+    ST_INDEL_LEN   = 12   // same aux, idx = j, word0 : insertion / deletion length             (Profile.cpp:1515-1521)
 };
 
 SCS_HD uint32_t stage_word(uint32_t stage, uint32_t aux) { return stage | (aux << 8); }
@@ -93,6 +95,7 @@ SCS_HD uint32_t err_pos(uint32_t e) { return e & 0x7FFu; }
 SCS_HD uint32_t err_alt(uint32_t e) { return (e >> 11) & 3u; }
 static const uint64_t ERR_OVERFLOW_BIT = 1ull << 63;
 
+static const int BINOM_KMAX = 16;  // error-count thresholds per window length ([REMAP], scs_tables.cpp binom_table)
 static const int NQ = 94;          // Phred chars 33..126 (Profile.cpp:172-173)
 static const int NKMER = 84;       // 4 + 16 + 64 (Profile.cpp:69-123)
 

@@ -30,6 +30,9 @@ struct DevAmps {
     uint64_t* errs;            // 4 inline u16 entries or overflow reference
 };
 
+// genome bit index (k_genome_bits): per 64-base word, G/C and N masks + counts before the word
+struct DevGenomeIdx { const unsigned long long* gc_bits; const unsigned long long* n_bits; const uint64_t* gc_pref; const uint64_t* n_pref; };
+
 struct DevErrPool { uint32_t* data; uint32_t* head; uint32_t cap; };
 
 // view of a template strand as an index map into the genome: T[i] = maybe_comp(G[base + dir*i])
@@ -78,12 +81,14 @@ void launch_alloc(hipStream_t s, double* w, uint32_t ac, unsigned long long read
 void launch_attach_semis(hipStream_t s, const uint8_t* g, DevFrags fr, DevAmps semis, uint32_t n_semis, DevErrPool spool,
                          const uint32_t* slot_off, uint32_t* slots, uint32_t* slot_tmpl, uint32_t* valid,
                          const int64_t* primer_cnt, uint32_t* primer_delta, AmplifyParams p);
-void launch_errscan_frags(hipStream_t s, const uint8_t* g, DevFrags fr, uint32_t n_slots, const uint32_t* slot_off,
-                          const uint32_t* slots, const uint32_t* slot_tmpl, const uint32_t* valid_off,
-                          DevAmps out, uint32_t out_base, DevErrPool pool, uint32_t* flags, AmplifyParams p);
-void launch_errscan_semis(hipStream_t s, const uint8_t* g, DevFrags fr, DevAmps semis, uint32_t n_semis, DevErrPool spool,
-                          uint32_t n_slots, const uint32_t* slot_off, const uint32_t* slots, const uint32_t* slot_tmpl,
-                          const uint32_t* valid_off, DevAmps out, uint32_t out_base, DevErrPool pool, uint32_t* flags, AmplifyParams p);
+void launch_errs_frags(hipStream_t s, const uint8_t* g, DevGenomeIdx gx, DevFrags fr, uint32_t n_slots, const uint32_t* slot_off, const uint32_t* slots,
+                       const uint32_t* slot_tmpl, const uint32_t* valid_off, DevAmps out, uint32_t out_base, DevErrPool pool, uint32_t* flags,
+                       const unsigned long long* binom, AmplifyParams p);
+void launch_errs_semis(hipStream_t s, const uint8_t* g, DevGenomeIdx gx, DevFrags fr, DevAmps semis, uint32_t n_semis, DevErrPool spool, uint32_t n_slots,
+                       const uint32_t* slot_off, const uint32_t* slots, const uint32_t* slot_tmpl, const uint32_t* valid_off,
+                       DevAmps out, uint32_t out_base, DevErrPool pool, uint32_t* flags, const unsigned long long* binom, AmplifyParams p);
+void launch_genome_bits(hipStream_t s, const uint8_t* g, uint64_t n, uint64_t nwords, unsigned long long* gc_bits, unsigned long long* n_bits,
+                        uint32_t* gc_cnt, uint32_t* n_cnt, uint64_t* gc_pref, uint64_t* n_pref, void* temp, size_t temp_bytes);
 void launch_primer_update(hipStream_t s, int64_t* primer_cnt, uint32_t* primer_delta);
 void launch_weights(hipStream_t s, DevAmps fulls, uint32_t n, DevTables tb, RngKey key, uint32_t frag_size, double* w);
 void launch_plan_pairs(hipStream_t s, DevAmps fulls, uint32_t n_fulls, const uint32_t* read_numbers, const uint32_t* pair_off,

@@ -95,19 +95,40 @@ __global__ void k_primer_update(int64_t* __restrict__ cnt, uint32_t* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------------
-// K1b  errscan: one wave per new amplicon -- GC count of the window, Bernoulli(ber) per base,
-//      alt-base draws, packed record written at its final (reference -t 1 list) position.
-//      (Fragment.cpp:97-133, Amplicon.cpp:200-236)
+// genome bit index: per 64-base word a G/C mask and an N mask plus running counts, so the GC count
+// and the any-N test of ANY window are O(1) (countGC, lib/mydefine/MyDefine.cpp:434-452, without
+// re-reading the 1-2 kb window per amplicon; GC-ness and N-ness are strand-invariant).
 // ------------------------------------------------------------------------------------------------
-#define ERR_CAP 48
+__global__ void k_genome_bits(const uint8_t* __restrict__ g, uint64_t n, uint64_t nwords, unsigned long long* __restrict__ gc_bits,
+                              unsigned long long* __restrict__ n_bits, uint32_t* __restrict__ gc_cnt, uint32_t* __restrict__ n_cnt) {
+    const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w > nwords) return;
+    unsigned long long gm = 0, nm = 0;
+    if (w < nwords) {
+        const uint64_t b0 = w * 64;
+        for (int k = 0; k < 64; ++k) { const uint64_t i = b0 + k; if (i < n) { const uint32_t c = g[i]; gm |= (unsigned long long)is_gc(c) << k; nm |= (unsigned long long)(c > 3) << k; } }
+    }
+    gc_bits[w] = gm; n_bits[w] = nm; gc_cnt[w] = __popcll(gm); n_cnt[w] = __popcll(nm);
+}
+__device__ __forceinline__ uint64_t bit_rank(const unsigned long long* __restrict__ bits, const uint64_t* __restrict__ pref, uint64_t x) {
+    const uint64_t w = x >> 6; const uint32_t r = (uint32_t)(x & 63);
+    return pref[w] + (uint64_t)__popcll(bits[w] & ((1ull << r) - 1ull));
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1b  new amplicon records: one thread per attached primer.  GC content of the window from the bit
+//      index (+ the parent semi's substitutions), amplification errors as K ~ Binomial(l-8, ber) and K
+//      distinct positions ([REMAP] of the per-base Bernoulli loop, Fragment.cpp:97-123 /
+//      Amplicon.cpp:200-226), alt-base rejection draws, packed record written at its final
+//      (reference -t 1 list) position.
+// ------------------------------------------------------------------------------------------------
 template <bool FROM_FRAG>
-__global__ void __launch_bounds__(256) k_errscan(const uint8_t* __restrict__ g, DevFrags fr, DevAmps semis, DevErrPool spool,
-                                                 uint32_t n_slots, const uint32_t* __restrict__ slot_off, const uint32_t* __restrict__ slots,
-                                                 const uint32_t* __restrict__ slot_tmpl, const uint32_t* __restrict__ valid_off, uint32_t n_tmpl,
-                                                 DevAmps out, uint32_t out_base, DevErrPool pool, uint32_t* __restrict__ flags, AmplifyParams p) {
-    __shared__ uint16_t s_err[4][ERR_CAP];
-    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
-    const uint32_t w = blockIdx.x * 4 + wib;
+__global__ void __launch_bounds__(256) k_errs(const uint8_t* __restrict__ g, DevGenomeIdx gx, DevFrags fr, DevAmps semis, DevErrPool spool,
+                                              uint32_t n_slots, const uint32_t* __restrict__ slot_off, const uint32_t* __restrict__ slots,
+                                              const uint32_t* __restrict__ slot_tmpl, const uint32_t* __restrict__ valid_off, uint32_t n_tmpl,
+                                              DevAmps out, uint32_t out_base, DevErrPool pool, uint32_t* __restrict__ flags,
+                                              const unsigned long long* __restrict__ binom, AmplifyParams p) {
+    const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= n_slots) return;
     const uint32_t t = slot_tmpl[w];
     if (t == 0xFFFFFFFFu) return;                      // reserved but unused slot (aborted template)
@@ -115,72 +136,73 @@ __global__ void __launch_bounds__(256) k_errscan(const uint8_t* __restrict__ g, 
     const uint32_t n_fwd = valid_off[t] + i, n_new = valid_off[n_tmpl];
     const uint32_t sl = slots[w], spos = sl_spos(sl), alen = sl_len(sl);
     View tv; uint64_t perrs = 0, nuid; uint32_t plen = 0;
-    if (FROM_FRAG) {
-        tv = shift_view(frag_view(fr.goff[t], fr.len[t], fr.strand[t]), spos);
-        nuid = semi_uid(fr.gidx_base + t, p.pass, i);
-    } else {
+    if (FROM_FRAG) { tv = frag_view(fr.goff[t], fr.len[t], fr.strand[t]); nuid = semi_uid(fr.gidx_base + t, p.pass, i); }
+    else {
         const uint32_t f = semis.parent[t], psl = semis.sl[t];
         plen = sl_len(psl); perrs = semis.errs[t];
-        tv = shift_view(semi_tmpl_view(frag_view(fr.goff[f], fr.len[f], fr.strand[f]), sl_spos(psl), plen), spos);
+        tv = semi_tmpl_view(frag_view(fr.goff[f], fr.len[f], fr.strand[f]), sl_spos(psl), plen);
         nuid = full_uid(semis.uid[t], p.pass, i);
     }
     const uint32_t kind = FROM_FRAG ? 0u : 1u;
-    int gc = 0, delta = 0; uint32_t hasN = 0, nerr = 0;
-    const uint32_t nblk = (alen + 3) >> 2;
-    for (uint32_t b0 = 0; b0 < nblk; b0 += WAVE) {
-        const uint32_t b = b0 + lane;
-        uint32_t c[4] = {4, 4, 4, 4}; uint32_t emask = 0;
-        if (b < nblk) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const uint32_t j = 4 * b + k;
-                if (j < alen) {
-                    uint32_t cc = view_base(g, tv, j);
-                    if (!FROM_FRAG) for_each_err(perrs, spool.data, [&](uint32_t e) { if (plen - 1 - err_pos(e) == spos + j) cc = 3u - err_alt(e); });
-                    c[k] = cc; gc += is_gc(cc) ? 1 : 0; hasN |= cc > 3;
-                }
-            }
-            if (b >= 2) {                                                          // j starts at 8
-                const U4 d = draw4(p.key, ST_ERR, kind, nuid, b);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) if (4 * b + k < alen && d.w[k] < p.t_ber) emask |= 1u << k;
+    // ---- GC / N of the template window [spos, spos+alen)
+    const int64_t first = tv.base + (int64_t)tv.dir * (int64_t)spos;
+    const uint64_t ga = (uint64_t)(tv.dir > 0 ? first : first - (int64_t)(alen - 1)), gb = ga + alen;
+    int gc = (int)(bit_rank(gx.gc_bits, gx.gc_pref, gb) - bit_rank(gx.gc_bits, gx.gc_pref, ga));
+    int nn = (int)(bit_rank(gx.n_bits, gx.n_pref, gb) - bit_rank(gx.n_bits, gx.n_pref, ga));
+    if (!FROM_FRAG) for_each_err(perrs, spool.data, [&](uint32_t e) {
+        const uint32_t tp = plen - 1 - err_pos(e);
+        if (tp >= spos && tp < spos + alen) {
+            const uint32_t orig = g[tv.base + (int64_t)tv.dir * (int64_t)tp];
+            if (orig > 3) --nn; else gc -= is_gc(orig) ? 1 : 0;
+            gc += is_gc(err_alt(e)) ? 1 : 0;                                       // complement keeps GC-ness
+        }
+    });
+    int gcn = nn > 0 ? 0 : gc;                                                     // countGC: 0 if any N
+    // ---- error count and positions
+    const uint32_t ntr = alen - 8;
+    const U4 d0 = draw4(p.key, ST_ERR, kind, nuid, 0);
+    const unsigned long long x64 = ((unsigned long long)d0.w[0] << 32) | d0.w[1];
+    const unsigned long long* __restrict__ Tn = binom + (size_t)(ntr - (p.amp_min - 8)) * BINOM_KMAX;
+    uint32_t K = 0;
+    while (K < (uint32_t)BINOM_KMAX && x64 >= Tn[K]) ++K;
+    uint64_t packed = 0;
+    if (K) {
+        uint32_t pos[BINOM_KMAX]; uint32_t cnt = 0, q = 0; U4 d = d0;
+        while (cnt < K) {
+            if ((q & 3) == 0) d = draw4(p.key, ST_ERR, kind, nuid, 1 + (q >> 2));
+            const uint32_t cand = 8 + scale_draw(d.w[q & 3], 0, ntr); ++q;
+            bool dup = false;
+            for (uint32_t z = 0; z < cnt; ++z) dup |= pos[z] == cand;
+            if (!dup) {                                                            // insert sorted
+                uint32_t z = cnt++;
+                while (z > 0 && pos[z - 1] > cand) { pos[z] = pos[z - 1]; --z; }
+                pos[z] = cand;
             }
         }
-        if (__ballot(emask != 0)) {                                               // rare: some lane drew an error
-            const uint32_t cnt = __popc(emask);
-            const uint32_t excl = wave_incl_scan(cnt, lane) - cnt;
-            uint32_t slot = nerr + excl;
-            for (int k = 0; k < 4; ++k) if (emask & (1u << k)) {
-                const uint32_t j = 4 * b + k, base = c[k];
-                uint32_t alt, a = 0;
-                do {                                                               // do { n = rand } while (bases[n] == base)
-                    const U4 e = draw4(p.key, ST_ERRALT, kind, nuid, j | ((a >> 2) << 16));
-                    alt = e.w[a & 3] >> 30; ++a;                                   // trunc(4 * x / 2^32)
-                } while (alt == base);
-                delta += (is_gc(alt) ? 1 : 0) - (is_gc(base) ? 1 : 0);
-                if (slot < ERR_CAP) s_err[wib][slot] = (uint16_t)err_pack(j, alt);
-                ++slot;
-            }
-            nerr += wave_sum(cnt);
+        uint32_t ent[BINOM_KMAX]; int delta = 0;
+        for (uint32_t z = 0; z < K; ++z) {
+            const uint32_t j = pos[z];
+            const uint32_t base = FROM_FRAG ? view_base(g, tv, spos + j) : semi_tmpl_base(g, tv, plen, perrs, spool.data, spos + j);
+            uint32_t alt, a = 0;
+            do {                                                                   // do { n = rand } while (bases[n] == base)
+                const U4 e = draw4(p.key, ST_ERRALT, kind, nuid, j | ((a >> 2) << 16));
+                alt = e.w[a & 3] >> 30; ++a;                                       // trunc(4 * x / 2^32)
+            } while (alt == base);
+            delta += (is_gc(alt) ? 1 : 0) - (is_gc(base) ? 1 : 0);
+            ent[z] = err_pack(j, alt);
         }
-    }
-    gc = wave_sum_i(gc); delta = wave_sum_i(delta);
-    hasN = __ballot(hasN != 0) != 0;
-    __builtin_amdgcn_wave_barrier();
-    if (lane == 0) {
-        int gcn = (hasN ? 0 : gc) + delta; if (gcn < 0) gcn = 0;                  // countGC: 0 if any N; max(0, gcNum)
-        uint64_t packed = 0;
-        if (nerr > ERR_CAP) { atomicOr(flags, (uint32_t)FLAG_ERRCAP); nerr = ERR_CAP; }
-        if (nerr <= 4) { for (uint32_t k = 0; k < nerr; ++k) packed |= (uint64_t)s_err[wib][k] << (16 * k); }
+        gcn += delta;
+        if (K <= 4) { for (uint32_t z = 0; z < K; ++z) packed |= (uint64_t)ent[z] << (16 * z); }
         else {
-            const uint32_t off = atomicAdd(pool.head, nerr);
-            if (off + nerr > pool.cap) { atomicOr(flags, (uint32_t)FLAG_ERRPOOL); }
-            else { for (uint32_t k = 0; k < nerr; ++k) pool.data[off + k] = s_err[wib][k]; packed = ERR_OVERFLOW_BIT | ((uint64_t)nerr << 32) | off; }
+            const uint32_t off = atomicAdd(pool.head, K);
+            if (off + K > pool.cap) atomicOr(flags, (uint32_t)FLAG_ERRPOOL);
+            else { for (uint32_t z = 0; z < K; ++z) pool.data[off + z] = ent[z]; packed = ERR_OVERFLOW_BIT | ((uint64_t)K << 32) | off; }
         }
-        const uint32_t dst = out_base + (n_new - 1 - n_fwd);                      // reversed within the pass: insertLinkList prepends
-        out.parent[dst] = t; out.sl[dst] = pack_sl(spos, alen); out.gc[dst] = (uint16_t)gcn; out.primers[dst] = 0;
-        out.uid[dst] = nuid; out.errs[dst] = packed;
     }
+    if (gcn < 0) gcn = 0;                                                          // max(0, gcNum)
+    const uint32_t dst = out_base + (n_new - 1 - n_fwd);                          // reversed within the pass: insertLinkList prepends
+    out.parent[dst] = t; out.sl[dst] = pack_sl(spos, alen); out.gc[dst] = (uint16_t)gcn; out.primers[dst] = 0;
+    out.uid[dst] = nuid; out.errs[dst] = packed;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -288,20 +310,22 @@ __device__ __forceinline__ void predict_wave(const uint8_t* s_win, uint8_t* s_sr
     const int n = tb.L;
     const uint32_t aux = job.rd | (job.att << 1);
     const int nch = (n + WAVE - 1) / WAVE;
-    // ---- indel events per input base (getIndelSeq, Profile.cpp:1552-1570)
-    uint32_t ev[MAXCH], evk[MAXCH];               // 0 none, 1 insertion, 2 deletion ; length
+    // ---- indel events per input base (getIndelSeq, Profile.cpp:1552-1570).  One ST_READ block per base index:
+    //      words 0,1 feed the indel tests of input base j, words 2,3 the substitution/quality of output base j.
+    uint32_t ev[MAXCH], evk[MAXCH], wsub[MAXCH], wql[MAXCH];     // 0 none, 1 insertion, 2 deletion ; length
     bool any = false;
 #pragma unroll
     for (int c = 0; c < MAXCH; ++c) {
-        ev[c] = 0; evk[c] = 0;
+        ev[c] = 0; evk[c] = 0; wsub[c] = 0; wql[c] = 0;
         const int j = c * WAVE + lane;
         if (c < nch && j < n) {
-            const U4 d = draw4(key, ST_INDEL, aux, job.uid, (uint32_t)j);
+            const U4 d = draw4(key, ST_READ, aux, job.uid, (uint32_t)j);
+            wsub[c] = d.w[2]; wql[c] = d.w[3];
             if (d.w[0] < tb.t_insert) {                                            // p <= insertRate
-                const uint32_t k = rand_indx_thr(tb.ins_t, tb.ins_d, (uint32_t)tb.n_ins, d.w[2]);
+                const uint32_t k = rand_indx_thr(tb.ins_t, tb.ins_d, (uint32_t)tb.n_ins, draw4(key, ST_INDEL_LEN, aux, job.uid, (uint32_t)j).w[0]);
                 if (k > 0) { ev[c] = 1; evk[c] = k; }
             } else if (d.w[1] < tb.t_delete) {                                     // p < delRate/(1-insertRate)
-                const uint32_t k = rand_indx_thr(tb.del_t, tb.del_d, (uint32_t)tb.n_del, d.w[2]);
+                const uint32_t k = rand_indx_thr(tb.del_t, tb.del_d, (uint32_t)tb.n_del, draw4(key, ST_INDEL_LEN, aux, job.uid, (uint32_t)j).w[0]);
                 if (k > 0) { ev[c] = 2; evk[c] = k; }
             }
             any |= ev[c] != 0;
@@ -387,25 +411,29 @@ __device__ __forceinline__ void predict_wave(const uint8_t* s_win, uint8_t* s_sr
     const uint32_t* __restrict__ subs = (job.rd == 0 || tb.subs2 == nullptr) ? tb.subs1 : tb.subs2;
     const double* __restrict__ subs_d = (job.rd == 0 || tb.subs2 == nullptr) ? tb.subs1_d : tb.subs2_d;
     const int B = tb.bins;
-    for (int j = lane; j < n_out; j += WAVE) {
+#pragma unroll
+    for (int c = 0; c <= MAXCH; ++c) {
+        const int j = c * WAVE + lane;
+        if (j >= n_out) continue;
         const uint32_t c2 = s_src[j], c1 = j >= 1 ? s_src[j - 1] : 5u, c0 = j >= 2 ? s_src[j - 2] : 5u;
         const int bin = j * B / n_out;
         const int ki = kmer_index(c0, c1, c2);
-        const U4 d = draw4(key, ST_BASE, aux, job.uid, (uint32_t)j);
+        uint32_t xs, xq;
+        if (c < MAXCH && c < nch && j < n) { xs = wsub[c < MAXCH ? c : 0]; xq = wql[c < MAXCH ? c : 0]; }
+        else { const U4 d = draw4(key, ST_READ, aux, job.uid, (uint32_t)j); xs = d.w[2]; xq = d.w[3]; }     // output longer than the input
         int k;
         if (ki < 0) k = c2 < 4 ? (int)c2 : -1;
         else {
             const size_t row = ((size_t)ki * B + bin) * 4;
-            const uint32_t x = d.w[0];
-            if (x == 0xFFFFFFFFu) k = (int)rand_indx_slow(subs_d + row, 4, x);
-            else { const uint4 T = *reinterpret_cast<const uint4*>(subs + row); k = (x >= T.x) + (x >= T.y) + (x >= T.z); }
+            if (xs == 0xFFFFFFFFu) k = (int)rand_indx_slow(subs_d + row, 4, xs);
+            else { const uint4 T = *reinterpret_cast<const uint4*>(subs + row); k = (xs >= T.x) + (xs >= T.y) + (xs >= T.z); }
         }
         char bc, qc;
-        if (k < 0) { bc = 'N'; qc = (char)(33 + scale_draw(d.w[2], 0, 20)); }       // getRandBaseQuality
+        if (k < 0) { bc = 'N'; qc = (char)(33 + scale_draw(xq, 0, 20)); }           // getRandBaseQuality
         else {
             bc = "ACGT"[k];
             const size_t row = ((size_t)(c2 * 4 + (uint32_t)k) * B + bin) * NQ;
-            qc = (char)(33 + rand_indx_thr(tb.qual + row, tb.qual_d + row, NQ, d.w[1]));
+            qc = (char)(33 + rand_indx_thr(tb.qual + row, tb.qual_d + row, NQ, xq));
         }
         out_b[j] = bc; out_q[j] = qc;
     }
@@ -783,6 +811,7 @@ __global__ void k_alloc_parity(uint32_t* __restrict__ rn, const uint32_t* __rest
     if (v & 1u) rn[i] = (odd_before[i] & 1u) ? v - 1u : v + 1u;
 }
 
+struct Widen { __host__ __device__ uint64_t operator()(uint32_t v) const { return (uint64_t)v; } };
 struct OddBit { __host__ __device__ uint32_t operator()(uint32_t v) const { return v & 1u; } };
 struct HalfUp { __host__ __device__ uint32_t operator()(uint32_t v) const { return (v + 1u) >> 1; } };
 
@@ -830,17 +859,24 @@ void launch_attach_semis(hipStream_t s, const uint8_t* g, DevFrags fr, DevAmps s
     hipLaunchKernelGGL((k_attach<false, 16>), dim3(cdiv(n_semis, 4)), dim3(64), 0, s, g, fr, semis, n_semis, spool, slot_off, slots, slot_tmpl, valid,
                        primer_cnt, primer_delta, (unsigned long long*)nullptr, p);
 }
-void launch_errscan_frags(hipStream_t s, const uint8_t* g, DevFrags fr, uint32_t n_slots, const uint32_t* slot_off, const uint32_t* slots,
-                          const uint32_t* slot_tmpl, const uint32_t* valid_off, DevAmps out, uint32_t out_base, DevErrPool pool, uint32_t* flags, AmplifyParams p) {
+void launch_errs_frags(hipStream_t s, const uint8_t* g, DevGenomeIdx gx, DevFrags fr, uint32_t n_slots, const uint32_t* slot_off, const uint32_t* slots,
+                       const uint32_t* slot_tmpl, const uint32_t* valid_off, DevAmps out, uint32_t out_base, DevErrPool pool, uint32_t* flags,
+                       const unsigned long long* binom, AmplifyParams p) {
     if (n_slots == 0) return;
     DevAmps none{}; DevErrPool np{};
-    hipLaunchKernelGGL(k_errscan<true>, dim3(cdiv(n_slots, 4)), dim3(256), 0, s, g, fr, none, np, n_slots, slot_off, slots, slot_tmpl, valid_off, fr.n, out, out_base, pool, flags, p);
+    hipLaunchKernelGGL(k_errs<true>, dim3(cdiv(n_slots, 256)), dim3(256), 0, s, g, gx, fr, none, np, n_slots, slot_off, slots, slot_tmpl, valid_off, fr.n, out, out_base, pool, flags, binom, p);
 }
-void launch_errscan_semis(hipStream_t s, const uint8_t* g, DevFrags fr, DevAmps semis, uint32_t n_semis, DevErrPool spool, uint32_t n_slots,
-                          const uint32_t* slot_off, const uint32_t* slots, const uint32_t* slot_tmpl, const uint32_t* valid_off,
-                          DevAmps out, uint32_t out_base, DevErrPool pool, uint32_t* flags, AmplifyParams p) {
+void launch_errs_semis(hipStream_t s, const uint8_t* g, DevGenomeIdx gx, DevFrags fr, DevAmps semis, uint32_t n_semis, DevErrPool spool, uint32_t n_slots,
+                       const uint32_t* slot_off, const uint32_t* slots, const uint32_t* slot_tmpl, const uint32_t* valid_off,
+                       DevAmps out, uint32_t out_base, DevErrPool pool, uint32_t* flags, const unsigned long long* binom, AmplifyParams p) {
     if (n_slots == 0) return;
-    hipLaunchKernelGGL(k_errscan<false>, dim3(cdiv(n_slots, 4)), dim3(256), 0, s, g, fr, semis, spool, n_slots, slot_off, slots, slot_tmpl, valid_off, n_semis, out, out_base, pool, flags, p);
+    hipLaunchKernelGGL(k_errs<false>, dim3(cdiv(n_slots, 256)), dim3(256), 0, s, g, gx, fr, semis, spool, n_slots, slot_off, slots, slot_tmpl, valid_off, n_semis, out, out_base, pool, flags, binom, p);
+}
+void launch_genome_bits(hipStream_t s, const uint8_t* g, uint64_t n, uint64_t nwords, unsigned long long* gc_bits, unsigned long long* n_bits,
+                        uint32_t* gc_cnt, uint32_t* n_cnt, uint64_t* gc_pref, uint64_t* n_pref, void* temp, size_t temp_bytes) {
+    hipLaunchKernelGGL(k_genome_bits, dim3(cdiv(nwords + 1, 256)), dim3(256), 0, s, g, n, nwords, gc_bits, n_bits, gc_cnt, n_cnt);
+    (void)rocprim::exclusive_scan(temp, temp_bytes, rocprim::make_transform_iterator((const uint32_t*)gc_cnt, Widen()), gc_pref, (uint64_t)0, nwords + 1, rocprim::plus<uint64_t>(), s);
+    (void)rocprim::exclusive_scan(temp, temp_bytes, rocprim::make_transform_iterator((const uint32_t*)n_cnt, Widen()), n_pref, (uint64_t)0, nwords + 1, rocprim::plus<uint64_t>(), s);
 }
 void launch_primer_update(hipStream_t s, int64_t* primer_cnt, uint32_t* primer_delta) {
     hipLaunchKernelGGL(k_primer_update, dim3(256), dim3(256), 0, s, primer_cnt, primer_delta);
@@ -884,7 +920,6 @@ void launch_detlog(hipStream_t s, const double* x, uint32_t n, double* out) {
 }
 
 // ---- device-wide scans (rocPRIM; plumbing between the hand-written kernels) --------------------------
-struct Widen { __host__ __device__ uint64_t operator()(uint32_t v) const { return (uint64_t)v; } };
 size_t scan_temp_bytes(size_t n) {
     size_t a = 0, b = 0;
     (void)rocprim::exclusive_scan(nullptr, a, (const uint32_t*)nullptr, (uint32_t*)nullptr, 0u, n + 1, rocprim::plus<uint32_t>());

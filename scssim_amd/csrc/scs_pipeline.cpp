@@ -96,6 +96,7 @@ struct scs_ctx {
     ProfileTables prof; bool have_profile = false; DevTables dtb{};
     DevBuf t_subs1, t_subs2, t_qual, t_ins, t_del, t_isize, d_subs1, d_subs2, d_qual, d_ins, d_del, d_isize, d_gcmeans;
     // genome + fragments
+    DevBuf gx_gc_bits, gx_n_bits, gx_gc_cnt, gx_n_cnt, gx_gc_pref, gx_n_pref, d_binom;
     std::vector<FastaRecord> recs; bool have_genome = false; DevBuf genome; std::vector<uint64_t> rec_off; uint64_t genome_bases = 0;
     std::vector<uint64_t> f_goff; std::vector<uint32_t> f_len; std::vector<int8_t> f_strand; std::vector<uint32_t> f_primers;
     uint64_t f_gidx_base = 0; bool have_frags = false;
@@ -110,7 +111,7 @@ struct scs_ctx {
     DevBuf weights, read_numbers, pair_off, pairs, odd_before, a_part, a_tp, a_probs, a_quota; std::vector<uint32_t> h_read_numbers; uint64_t reads_requested = 0, n_pairs_planned = 0; bool allocated = false;
     DevBuf slot_b, slot_q, lens, sizes1, sizes2, off1, off2, out1, out2; std::vector<char> h_out1, h_out2;
     scs_stats st{};
-    KernelTimer tm_errscan{"k_errscan<semi->full>"}, tm_errscan_f{"k_errscan<frag->semi>"}, tm_reads{"k_reads"}, tm_attach{"k_attach"}, tm_format{"k_format"};
+    KernelTimer tm_errscan{"k_errs<semi->full>"}, tm_errscan_f{"k_errs<frag->semi>"}, tm_reads{"k_reads"}, tm_attach{"k_attach"}, tm_format{"k_format"};
 
     DevFrags frags_view() const {
         return DevFrags{df_goff.as<uint64_t>(), df_len.as<uint32_t>(), df_strand.as<int8_t>(), df_primers.as<uint32_t>(), (uint32_t)f_len.size(), f_gidx_base};
@@ -172,6 +173,13 @@ void stage_genome(scs_ctx* c) {
     for (size_t i = 0; i < c->recs.size(); ++i)
         if (!c->recs[i].code.empty())
             HIP_OK(hipMemcpyAsync((uint8_t*)c->genome.p + c->rec_off[i], c->recs[i].code.data(), c->recs[i].code.size(), hipMemcpyHostToDevice, c->stream));
+    {   // bit index: GC count / any-N of any window in O(1)
+        hipStream_t s = c->stream; const uint64_t nw = (tot + 63) / 64;
+        c->gx_gc_bits.reserve((nw + 1) * 8, s); c->gx_n_bits.reserve((nw + 1) * 8, s); c->gx_gc_cnt.reserve((nw + 2) * 4, s); c->gx_n_cnt.reserve((nw + 2) * 4, s);
+        c->gx_gc_pref.reserve((nw + 2) * 8, s); c->gx_n_pref.reserve((nw + 2) * 8, s); c->scan_tmp.reserve(scan_temp_bytes(nw + 1), s);
+        launch_genome_bits(s, c->genome.as<uint8_t>(), tot, nw, c->gx_gc_bits.as<unsigned long long>(), c->gx_n_bits.as<unsigned long long>(), c->gx_gc_cnt.as<uint32_t>(),
+                           c->gx_n_cnt.as<uint32_t>(), c->gx_gc_pref.as<uint64_t>(), c->gx_n_pref.as<uint64_t>(), c->scan_tmp.p, c->scan_tmp.cap);
+    }
     HIP_OK(hipStreamSynchronize(c->stream));
     c->have_genome = true; c->have_frags = false; c->amplified = false; c->allocated = false;
     c->st.records = c->recs.size(); c->st.genome_bases = tot;
@@ -267,10 +275,11 @@ void launch_pass(scs_ctx* c, bool from_frag, uint32_t pass, int rb_slot) {
     exclusive_scan_u32(s, c->valid.as<uint32_t>(), c->valid_off.as<uint32_t>(), nt, c->scan_tmp.p, c->scan_tmp.cap);
     KernelTimer& tm = from_frag ? c->tm_errscan_f : c->tm_errscan;
     tm.begin(s);
-    if (from_frag) launch_errscan_frags(s, g, fr, n_slots, slot_off, c->slots.as<uint32_t>(), c->slot_tmpl.as<uint32_t>(),
-                                        c->valid_off.as<uint32_t>(), out.view(), out.n, out.pool_view(), c->flags.as<uint32_t>(), p);
-    else launch_errscan_semis(s, g, fr, c->semis.view(), nt, c->semis.pool_view(), n_slots, slot_off, c->slots.as<uint32_t>(),
-                              c->slot_tmpl.as<uint32_t>(), c->valid_off.as<uint32_t>(), out.view(), out.n, out.pool_view(), c->flags.as<uint32_t>(), p);
+    const DevGenomeIdx gx{c->gx_gc_bits.as<unsigned long long>(), c->gx_n_bits.as<unsigned long long>(), c->gx_gc_pref.as<uint64_t>(), c->gx_n_pref.as<uint64_t>()};
+    if (from_frag) launch_errs_frags(s, g, gx, fr, n_slots, slot_off, c->slots.as<uint32_t>(), c->slot_tmpl.as<uint32_t>(), c->valid_off.as<uint32_t>(),
+                                     out.view(), out.n, out.pool_view(), c->flags.as<uint32_t>(), c->d_binom.as<unsigned long long>(), p);
+    else launch_errs_semis(s, g, gx, fr, c->semis.view(), nt, c->semis.pool_view(), n_slots, slot_off, c->slots.as<uint32_t>(), c->slot_tmpl.as<uint32_t>(),
+                           c->valid_off.as<uint32_t>(), out.view(), out.n, out.pool_view(), c->flags.as<uint32_t>(), c->d_binom.as<unsigned long long>(), p);
     tm.end(s);
     launch_primer_update(s, c->primer_cnt.as<int64_t>(), c->primer_delta.as<uint32_t>());
     HIP_OK(hipMemcpyAsync(&c->h_rb[rb_slot], c->valid_off.as<uint32_t>() + nt, 4, hipMemcpyDeviceToHost, s));
@@ -298,6 +307,10 @@ void do_amplify(scs_ctx* c) {
     c->primer_delta.reserve(65536 * 4, s); HIP_OK(hipMemsetAsync(c->primer_delta.p, 0, 65536 * 4, s));
     HIP_OK(hipMemsetAsync(c->flags.p, 0, 4, s));
     HIP_OK(hipMemsetAsync(c->dsums.p, 0, 64, s));
+    if (!c->d_binom.p) {   // [REMAP] error-count thresholds for every window length (cfg is fixed for the ctx lifetime)
+        std::vector<uint64_t> bt = binom_table(c->cfg.ber, c->cfg.amplicon_min_len - 8, c->cfg.amplicon_max_len - 8);
+        upload(c->d_binom, bt, s); HIP_OK(hipStreamSynchronize(s));
+    }
     c->total_primers = 65536ull * (uint64_t)c->cfg.primers;
     c->frag_total_len = 0; for (uint32_t l : c->f_len) c->frag_total_len += l;
     c->semi_total_len = 0;
@@ -477,7 +490,7 @@ void scs_destroy(scs_ctx* c) {
     (void)hipSetDevice(c->cfg.device);
     (void)hipStreamSynchronize(c->stream);
     for (DevBuf* b : {&c->t_subs1, &c->t_subs2, &c->t_qual, &c->t_ins, &c->t_del, &c->t_isize, &c->d_subs1, &c->d_subs2, &c->d_qual, &c->d_ins, &c->d_del,
-                      &c->d_isize, &c->d_gcmeans, &c->genome, &c->df_goff, &c->df_len, &c->df_strand, &c->df_primers, &c->primer_cnt, &c->primer_delta,
+                      &c->d_isize, &c->d_gcmeans, &c->genome, &c->gx_gc_bits, &c->gx_n_bits, &c->gx_gc_cnt, &c->gx_n_cnt, &c->gx_gc_pref, &c->gx_n_pref, &c->d_binom, &c->df_goff, &c->df_len, &c->df_strand, &c->df_primers, &c->primer_cnt, &c->primer_delta,
                       &c->slots, &c->slot_tmpl, &c->valid, &c->valid_off, &c->scan_tmp, &c->flags, &c->weights, &c->read_numbers,
                       &c->pair_off, &c->pairs, &c->odd_before, &c->a_part, &c->a_tp, &c->a_probs, &c->a_quota, &c->budget_f, &c->budget_s, &c->slot_off_f,
                       &c->slot_off_s, &c->dsums, &c->slot_b, &c->slot_q, &c->lens, &c->sizes1, &c->sizes2, &c->off1, &c->off2, &c->out1, &c->out2}) b->release();

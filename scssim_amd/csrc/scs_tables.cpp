@@ -33,6 +33,23 @@ uint32_t threshold_cdf(double c) {
     return count_true([c](uint32_t x) { double r = kZeroFinal + (1 - kZeroFinal) * (x / 4294967296.0); return r <= c; });
 }
 
+std::vector<uint64_t> binom_table(double ber, int n_min, int n_max) {
+    std::vector<uint64_t> T((size_t)(n_max - n_min + 1) * BINOM_KMAX);
+    const double q = 1 - ber, ratio = ber / q;
+    for (int n = n_min; n <= n_max; ++n) {
+        double pmf = 1, b = q;                                   // q^n by repeated squaring
+        for (unsigned e = (unsigned)n; e; e >>= 1) { if (e & 1) pmf = pmf * b; b = b * b; }
+        double cdf = 0;
+        uint64_t* row = &T[(size_t)(n - n_min) * BINOM_KMAX];
+        for (int k = 0; k < BINOM_KMAX; ++k) {
+            cdf += pmf;
+            row[k] = cdf >= 1.0 ? ~0ull : (uint64_t)(cdf * 18446744073709551616.0);
+            pmf = pmf * (double)(n - k) / (double)(k + 1) * ratio;
+        }
+    }
+    return T;
+}
+
 // ---------------------------------------------------------------- small text helpers
 static std::string strip(const std::string& s) {
     size_t a = 0, b = s.size();

@@ -33,6 +33,11 @@ uint32_t threshold_le(double c);
 // count of x with r(x) <= c for the randIndx mapping, clamped to 2^32-1
 uint32_t threshold_cdf(double c);
 
+// [REMAP] thresholds of K ~ Binomial(n, ber), n = n_min..n_max: T[(n-n_min)*BINOM_KMAX + k] = floor(CDF_n(k) * 2^64).
+// Replaces the reference's one Bernoulli(ber) draw per amplified base (Fragment.cpp:100-104) by a count draw
+// plus K distinct positions (same distribution).  IEEE * + / only: every build computes the same table.
+std::vector<uint64_t> binom_table(double ber, int n_min, int n_max);
+
 // Throws std::runtime_error with the reference's message where it has one.
 void load_profile(const std::string& path, bool paired, int isize, ProfileTables& out);
 
