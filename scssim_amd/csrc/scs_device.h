@@ -43,6 +43,7 @@ struct DevTables {
     uint32_t t_insert, t_delete, t_ber;
     const uint32_t* subs1; const uint32_t* subs2;   // [84][bins][4] thresholds (uint4 rows)
     const uint32_t* qual;                            // [16][bins][94]
+    const uint8_t* qual_guide;                       // [16*bins][17]: #thresholds <= v<<28, v = 0..16 (search range per draw bucket)
     const uint32_t* ins_t; int n_ins;
     const uint32_t* del_t; int n_del;
     const uint32_t* isize_t; int n_isize; int isize_min;
@@ -67,7 +68,16 @@ struct AllocState { double total; unsigned long long sum_rn, sum_quota; };
 // error flags raised by kernels (never silent): bit 0 error-list cap, 1 error pool, 2 read slot, 3 other
 enum DevFlag : uint32_t { FLAG_ERRCAP = 1, FLAG_ERRPOOL = 2, FLAG_READSLOT = 4, FLAG_INTERNAL = 8 };
 
-struct PairRec { uint32_t amp; uint32_t att; uint32_t pos; uint32_t isz; };   // isz == 0: hole
+// one planned read pair (or SE read) with its amplicon already resolved to an index map into the genome:
+// U[t] = maybe_comp(G[base + dir*t]) patched by the semi's errors (at t = k1 - pos(e), value comp(alt))
+// and then the full amplicon's own (at t = pos(e), value alt).  64 bytes = one cache line per pair.
+struct PairRec {
+    uint32_t amp, att, pos, isz;      // isz == 0: hole
+    int64_t  base; uint32_t flags;    // flags: bit0 complement, bit1 direction is -1
+    int32_t  k1;                      // l_semi - 1 - spos_full
+    uint64_t e1, e2, uid;             // error words of the semi / the full amplicon; lineage uid
+    uint64_t pad;
+};
 
 // ---- launch wrappers (scs_kernels.hip) --------------------------------------------------------------
 void launch_attach_frags(hipStream_t s, const uint8_t* g, DevFrags fr, const uint32_t* slot_off, uint32_t* slots,
@@ -91,10 +101,10 @@ void launch_genome_bits(hipStream_t s, const uint8_t* g, uint64_t n, uint64_t nw
                         uint32_t* gc_cnt, uint32_t* n_cnt, uint64_t* gc_pref, uint64_t* n_pref, void* temp, size_t temp_bytes);
 void launch_primer_update(hipStream_t s, int64_t* primer_cnt, uint32_t* primer_delta);
 void launch_weights(hipStream_t s, DevAmps fulls, uint32_t n, DevTables tb, RngKey key, uint32_t frag_size, double* w);
-void launch_plan_pairs(hipStream_t s, DevAmps fulls, uint32_t n_fulls, const uint32_t* read_numbers, const uint32_t* pair_off,
+void launch_plan_pairs(hipStream_t s, DevFrags fr, DevAmps semis, DevAmps fulls, uint32_t n_fulls, const uint32_t* read_numbers, const uint32_t* pair_off,
                        DevTables tb, RngKey key, int paired, PairRec* pairs);
 // reads of pairs [p0, p0+np): slot layout [2*np][slot] bases / quals (SE: [np][slot])
-void launch_reads(hipStream_t s, const uint8_t* g, DevFrags fr, DevAmps semis, DevErrPool spool, DevAmps fulls, DevErrPool fpool,
+void launch_reads(hipStream_t s, const uint8_t* g, DevErrPool spool, DevErrPool fpool,
                   const PairRec* pairs, uint32_t np, uint32_t amp_index_base, DevTables tb, RngKey key, int paired, uint32_t slot,
                   char* slot_b, char* slot_q, uint32_t* lens, uint32_t* sizes1, uint32_t* sizes2, uint32_t* flags);
 void launch_predict_windows(hipStream_t s, const uint8_t* windows, uint32_t n_reads, const uint64_t* uids, const uint32_t* atts,

@@ -94,6 +94,16 @@ __global__ void k_primer_update(int64_t* __restrict__ cnt, uint32_t* __restrict_
     delta[i] = 0;
 }
 
+// quality lookup: the guide row (LDS) bounds the search to the thresholds that fall into the draw's
+// 1/16 bucket, so the usual 7-step search over 94 thresholds becomes 0-2 global loads.
+__device__ __forceinline__ uint32_t qual_lookup(const uint32_t* __restrict__ T, const double* __restrict__ cdf, const uint8_t* guide_row, uint32_t x) {
+    if (x == 0xFFFFFFFFu) return rand_indx_slow(cdf, NQ, x);
+    const uint32_t v = x >> 28;
+    uint32_t lo = guide_row[v], hi = guide_row[v + 1];          // answer in [lo, hi]
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (x < T[mid]) hi = mid; else lo = mid + 1; }
+    return lo < (uint32_t)NQ ? lo : (uint32_t)NQ - 1;
+}
+
 // ------------------------------------------------------------------------------------------------
 // genome bit index: per 64-base word a G/C mask and an N mask plus running counts, so the GC count
 // and the any-N test of ANY window are O(1) (countGC, lib/mydefine/MyDefine.cpp:434-452, without
@@ -264,7 +274,7 @@ __global__ void k_weights(DevAmps fulls, uint32_t n, DevTables tb, RngKey key, u
 // K4a  plan pairs: one thread per full amplicon runs the attempt loop of Amplicon::yieldReads
 //      (Amplicon.cpp:448-491): insert size, rejection, position.
 // ------------------------------------------------------------------------------------------------
-__global__ void k_plan_pairs(DevAmps fulls, uint32_t n_fulls, const uint32_t* __restrict__ read_numbers,
+__global__ void k_plan_pairs(DevFrags fr, DevAmps semis, DevAmps fulls, uint32_t n_fulls, const uint32_t* __restrict__ read_numbers,
                              const uint32_t* __restrict__ pair_off, DevTables tb, RngKey key, int paired, PairRec* __restrict__ pairs) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_fulls) return;
@@ -272,25 +282,30 @@ __global__ void k_plan_pairs(DevAmps fulls, uint32_t n_fulls, const uint32_t* __
     if (n == 0) return;
     const uint32_t want = pair_off[i + 1] - pair_off[i];
     PairRec* dst = pairs + pair_off[i];
-    const uint32_t amp_len = sl_len(fulls.sl[i]);
-    const uint64_t uid = fulls.uid[i];
+    const uint32_t fsl = fulls.sl[i], amp_len = sl_len(fsl), s2 = sl_spos(fsl);
     const uint32_t L = (uint32_t)tb.L;
+    // resolve U = full amplicon sequence to an index map once (Amplicon::getSequence, Amplicon.cpp:266-340, without the copies)
+    const uint32_t sm = fulls.parent[i], ssl = semis.sl[sm], l1 = sl_len(ssl), f = semis.parent[sm];
+    const View uv = shift_view(semi_tmpl_view(frag_view(fr.goff[f], fr.len[f], fr.strand[f]), sl_spos(ssl), l1), s2);
+    PairRec r; r.amp = i; r.base = uv.base; r.flags = (uv.comp & 1u) | (uv.dir < 0 ? 2u : 0u); r.k1 = (int32_t)(l1 - 1 - s2);
+    r.e1 = semis.errs[sm]; r.e2 = fulls.errs[i]; r.uid = fulls.uid[i]; r.pad = 0;
     uint32_t made = 0;
     if (amp_len >= L) {
         uint32_t att = 0, fails = 0;
         while (n > 0 && made < want) {
-            const U4 d = draw4(key, ST_PAIR, 0, uid, att);
+            const U4 d = draw4(key, ST_PAIR, 0, r.uid, att);
             if (!paired) {
-                PairRec r; r.amp = i; r.att = att; r.pos = scale_draw(d.w[1], 0, amp_len - L + 1); r.isz = L;
+                r.att = att; r.pos = scale_draw(d.w[1], 0, amp_len - L + 1); r.isz = L;
                 dst[made++] = r; ++att; --n; continue;
             }
             const uint32_t isz = (uint32_t)tb.isize_min + rand_indx_thr(tb.isize_t, tb.isize_d, (uint32_t)tb.n_isize, d.w[0]);
             if (isz < L || isz > amp_len) { ++att; if (++fails > 1000) break; continue; }
-            PairRec r; r.amp = i; r.att = att; r.pos = scale_draw(d.w[1], 0, amp_len - isz + 1); r.isz = isz;
+            r.att = att; r.pos = scale_draw(d.w[1], 0, amp_len - isz + 1); r.isz = isz;
             dst[made++] = r; ++att; n -= 2;
         }
     }
-    for (uint32_t q = made; q < want; ++q) { PairRec r; r.amp = i; r.att = 0; r.pos = 0; r.isz = 0; dst[q] = r; }   // holes
+    r.att = 0; r.pos = 0; r.isz = 0;
+    for (uint32_t q = made; q < want; ++q) dst[q] = r;                             // holes
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -304,7 +319,7 @@ __global__ void k_plan_pairs(DevAmps fulls, uint32_t n_fulls, const uint32_t* __
 
 struct ReadJob { uint64_t uid; uint32_t att; uint32_t rd; };   // rd: 0 = read 1, 1 = read 2
 
-__device__ __forceinline__ void predict_wave(const uint8_t* s_win, uint8_t* s_src, int lane, ReadJob job, const DevTables& tb, RngKey key,
+__device__ __forceinline__ void predict_wave(const uint8_t* s_win, uint8_t* s_src, const uint8_t* s_guide, int lane, ReadJob job, const DevTables& tb, RngKey key,
                                              uint32_t slot, char* __restrict__ out_b, char* __restrict__ out_q,
                                              uint32_t* __restrict__ out_len, uint32_t* __restrict__ flags) {
     const int n = tb.L;
@@ -433,7 +448,7 @@ __device__ __forceinline__ void predict_wave(const uint8_t* s_win, uint8_t* s_sr
         else {
             bc = "ACGT"[k];
             const size_t row = ((size_t)(c2 * 4 + (uint32_t)k) * B + bin) * NQ;
-            qc = (char)(33 + rand_indx_thr(tb.qual + row, tb.qual_d + row, NQ, xq));
+            qc = (char)(33 + qual_lookup(tb.qual + row, tb.qual_d + row, s_guide + ((size_t)(c2 * 4 + (uint32_t)k) * B + bin) * 17, xq));
         }
         out_b[j] = bc; out_q[j] = qc;
     }
@@ -445,65 +460,76 @@ __device__ __forceinline__ uint32_t dec_digits(uint32_t v) {
            v < 10000000u ? 7u : v < 100000000u ? 8u : v < 1000000000u ? 9u : 10u;
 }
 
-// K4b+K5: window extraction through the index maps (no amplicon is ever materialised) + predict
-__global__ void __launch_bounds__(256) k_reads(const uint8_t* __restrict__ g, DevFrags fr, DevAmps semis, DevErrPool spool, DevAmps fulls,
-                                               DevErrPool fpool, const PairRec* __restrict__ pairs, uint32_t np, uint32_t amp_index_base,
+// K4b+K5: window extraction through the index map of the pair record (no amplicon is ever
+// materialised) + predict.  512-thread workgroups: the quality guide table is staged into LDS once per
+// workgroup, each wave then walks reads with a grid stride.
+#define READS_WAVES 8
+__global__ void __launch_bounds__(64 * READS_WAVES) k_reads(const uint8_t* __restrict__ g, DevErrPool spool, DevErrPool fpool,
+                                               const PairRec* __restrict__ pairs, uint32_t np, uint32_t amp_index_base,
                                                DevTables tb, RngKey key, int paired, uint32_t slot, char* __restrict__ slot_b,
                                                char* __restrict__ slot_q, uint32_t* __restrict__ lens, uint32_t* __restrict__ sizes1,
                                                uint32_t* __restrict__ sizes2, uint32_t* __restrict__ flags) {
-    __shared__ uint8_t s_win[4][256];
-    __shared__ uint8_t s_src[4][SRC_CAP];
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
+    uint8_t* s_guide = s_dyn;                                              // [16*bins][17]
+    const uint32_t guide_bytes = (uint32_t)(16 * tb.bins * 17), guide_pad = (guide_bytes + 15u) & ~15u;
+    uint8_t* s_win_all = s_dyn + guide_pad;                                // [READS_WAVES][256]
+    uint8_t* s_src_all = s_win_all + READS_WAVES * 256;                    // [READS_WAVES][SRC_CAP]
+    for (uint32_t k = threadIdx.x * 4; k < guide_pad; k += blockDim.x * 4)
+        *reinterpret_cast<uint32_t*>(s_guide + k) = *reinterpret_cast<const uint32_t*>(tb.qual_guide + k);
+    __syncthreads();
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    uint8_t* s_win = s_win_all + wib * 256; uint8_t* s_src = s_src_all + wib * SRC_CAP;
     const uint32_t nreads = paired ? 2 * np : np;
-    const uint32_t nwaves = gridDim.x * 4;
-    for (uint32_t r = blockIdx.x * 4 + wib; r < nreads; r += nwaves) {
+    const uint32_t nwaves = gridDim.x * READS_WAVES;
+    for (uint32_t r = blockIdx.x * READS_WAVES + wib; r < nreads; r += nwaves) {
         const uint32_t pi = paired ? r >> 1 : r, rd = paired ? (r & 1u) : 0u;
         const PairRec pr = pairs[pi];
         uint32_t* sz = rd ? sizes2 : sizes1;
         if (pr.isz == 0) { if (lane == 0) { lens[r] = 0; sz[pi] = 0; } continue; }
-        const uint32_t a = pr.amp;
-        const uint32_t fsl = fulls.sl[a], s2 = sl_spos(fsl);
-        const uint32_t sm = fulls.parent[a];
-        const uint32_t ssl = semis.sl[sm], s1 = sl_spos(ssl), l1 = sl_len(ssl);
-        const uint32_t f = semis.parent[sm];
-        const uint64_t e1 = semis.errs[sm], e2 = fulls.errs[a];
-        const View uv = shift_view(semi_tmpl_view(frag_view(fr.goff[f], fr.len[f], fr.strand[f]), s1, l1), s2);
+        const int64_t dir = (pr.flags & 2u) ? -1 : 1; const bool comp = pr.flags & 1u;
         const int L = tb.L;
         for (int k = lane; k < L; k += WAVE) {
             const uint32_t t = rd ? pr.pos + pr.isz - 1 - (uint32_t)k : pr.pos + (uint32_t)k;   // read 2 = revcomp of the far end
-            uint32_t c = view_base(g, uv, t);
-            for_each_err(e1, spool.data, [&](uint32_t e) { if (l1 - 1 - err_pos(e) == s2 + t) c = 3u - err_alt(e); });
-            for_each_err(e2, fpool.data, [&](uint32_t e) { if (err_pos(e) == t) c = err_alt(e); });
-            s_win[wib][k] = (uint8_t)(rd ? comp_code((uint8_t)c) : c);
+            uint32_t c = g[pr.base + dir * (int64_t)t];
+            if (comp) c = comp_code((uint8_t)c);
+            for_each_err(pr.e1, spool.data, [&](uint32_t e) { if (pr.k1 - (int32_t)err_pos(e) == (int32_t)t) c = 3u - err_alt(e); });
+            for_each_err(pr.e2, fpool.data, [&](uint32_t e) { if (err_pos(e) == t) c = err_alt(e); });
+            s_win[k] = (uint8_t)(rd ? comp_code((uint8_t)c) : c);
         }
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        ReadJob job; job.uid = fulls.uid[a]; job.att = pr.att; job.rd = rd;
-        predict_wave(s_win[wib], s_src[wib], lane, job, tb, key, slot, slot_b + (size_t)r * slot, slot_q + (size_t)r * slot, &lens[r], flags);
+        ReadJob job; job.uid = pr.uid; job.att = pr.att; job.rd = rd;
+        predict_wave(s_win, s_src, s_guide, lane, job, tb, key, slot, slot_b + (size_t)r * slot, slot_q + (size_t)r * slot, &lens[r], flags);
         __builtin_amdgcn_wave_barrier();
         if (lane == 0) {
             const uint32_t nl = lens[r];
             // "@<ampIdx>#<fragCount>[/1|/2]\n" + seq + "\n+\n" + qual + "\n"   (Amplicon.cpp:459-466,497-504)
-            sz[pi] = nl == 0 ? 0u : 1u + dec_digits(amp_index_base + a) + 1u + dec_digits(pr.att + 1) + (paired ? 2u : 0u) + 1u + 2u * nl + 4u;
+            sz[pi] = nl == 0 ? 0u : 1u + dec_digits(amp_index_base + pr.amp) + 1u + dec_digits(pr.att + 1) + (paired ? 2u : 0u) + 1u + 2u * nl + 4u;
         }
     }
 }
 
 // kernel-level entry for parity tests: windows given explicitly
-__global__ void __launch_bounds__(256) k_predict_windows(const uint8_t* __restrict__ windows, uint32_t n_reads, const uint64_t* __restrict__ uids,
+__global__ void __launch_bounds__(64 * READS_WAVES) k_predict_windows(const uint8_t* __restrict__ windows, uint32_t n_reads, const uint64_t* __restrict__ uids,
                                                          const uint32_t* __restrict__ atts, const uint8_t* __restrict__ is_read1, DevTables tb,
                                                          RngKey key, uint32_t slot, char* __restrict__ slot_b, char* __restrict__ slot_q,
                                                          uint32_t* __restrict__ lens, uint32_t* __restrict__ flags) {
-    __shared__ uint8_t s_win[4][256];
-    __shared__ uint8_t s_src[4][SRC_CAP];
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
+    uint8_t* s_guide = s_dyn;
+    const uint32_t guide_bytes = (uint32_t)(16 * tb.bins * 17), guide_pad = (guide_bytes + 15u) & ~15u;
+    uint8_t* s_win_all = s_dyn + guide_pad; uint8_t* s_src_all = s_win_all + READS_WAVES * 256;
+    for (uint32_t k = threadIdx.x * 4; k < guide_pad; k += blockDim.x * 4)
+        *reinterpret_cast<uint32_t*>(s_guide + k) = *reinterpret_cast<const uint32_t*>(tb.qual_guide + k);
+    __syncthreads();
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
-    const uint32_t nwaves = gridDim.x * 4;
-    for (uint32_t r = blockIdx.x * 4 + wib; r < n_reads; r += nwaves) {
-        for (int k = lane; k < tb.L; k += WAVE) s_win[wib][k] = windows[(size_t)r * tb.L + k];
+    uint8_t* s_win = s_win_all + wib * 256; uint8_t* s_src = s_src_all + wib * SRC_CAP;
+    const uint32_t nwaves = gridDim.x * READS_WAVES;
+    for (uint32_t r = blockIdx.x * READS_WAVES + wib; r < n_reads; r += nwaves) {
+        for (int k = lane; k < tb.L; k += WAVE) s_win[k] = windows[(size_t)r * tb.L + k];
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         ReadJob job; job.uid = uids[r]; job.att = atts[r]; job.rd = is_read1[r] ? 0u : 1u;
-        predict_wave(s_win[wib], s_src[wib], lane, job, tb, key, slot, slot_b + (size_t)r * slot, slot_q + (size_t)r * slot, &lens[r], flags);
+        predict_wave(s_win, s_src, s_guide, lane, job, tb, key, slot, slot_b + (size_t)r * slot, slot_q + (size_t)r * slot, &lens[r], flags);
         __builtin_amdgcn_wave_barrier();
     }
 }
@@ -885,25 +911,29 @@ void launch_weights(hipStream_t s, DevAmps fulls, uint32_t n, DevTables tb, RngK
     if (n == 0) return;
     hipLaunchKernelGGL(k_weights, dim3(cdiv(n, 256)), dim3(256), 0, s, fulls, n, tb, key, frag_size, w);
 }
-void launch_plan_pairs(hipStream_t s, DevAmps fulls, uint32_t n_fulls, const uint32_t* read_numbers, const uint32_t* pair_off,
+void launch_plan_pairs(hipStream_t s, DevFrags fr, DevAmps semis, DevAmps fulls, uint32_t n_fulls, const uint32_t* read_numbers, const uint32_t* pair_off,
                        DevTables tb, RngKey key, int paired, PairRec* pairs) {
     if (n_fulls == 0) return;
-    hipLaunchKernelGGL(k_plan_pairs, dim3(cdiv(n_fulls, 256)), dim3(256), 0, s, fulls, n_fulls, read_numbers, pair_off, tb, key, paired, pairs);
+    hipLaunchKernelGGL(k_plan_pairs, dim3(cdiv(n_fulls, 256)), dim3(256), 0, s, fr, semis, fulls, n_fulls, read_numbers, pair_off, tb, key, paired, pairs);
 }
-void launch_reads(hipStream_t s, const uint8_t* g, DevFrags fr, DevAmps semis, DevErrPool spool, DevAmps fulls, DevErrPool fpool,
+static inline size_t reads_lds_bytes(const DevTables& tb) { return (((size_t)16 * tb.bins * 17 + 15) & ~(size_t)15) + READS_WAVES * (256 + SRC_CAP); }
+static inline uint32_t reads_grid(uint64_t nreads) {
+    uint32_t grid = cdiv(nreads, READS_WAVES * 2);                  // >= 2 reads per wave before more workgroups are added
+    const uint32_t cap = 256 * 3;                                   // 3 workgroups of 8 waves per CU hold the guide table in LDS
+    return grid < 1 ? 1 : (grid > cap ? cap : grid);
+}
+void launch_reads(hipStream_t s, const uint8_t* g, DevErrPool spool, DevErrPool fpool,
                   const PairRec* pairs, uint32_t np, uint32_t amp_index_base, DevTables tb, RngKey key, int paired, uint32_t slot,
                   char* slot_b, char* slot_q, uint32_t* lens, uint32_t* sizes1, uint32_t* sizes2, uint32_t* flags) {
     if (np == 0) return;
     const uint64_t nreads = paired ? 2ull * np : np;
-    uint32_t grid = cdiv(nreads, 4); if (grid > kMaxStrideGrid * 4) grid = kMaxStrideGrid * 4;
-    hipLaunchKernelGGL(k_reads, dim3(grid), dim3(256), 0, s, g, fr, semis, spool, fulls, fpool, pairs, np, amp_index_base, tb, key, paired, slot,
+    hipLaunchKernelGGL(k_reads, dim3(reads_grid(nreads)), dim3(64 * READS_WAVES), reads_lds_bytes(tb), s, g, spool, fpool, pairs, np, amp_index_base, tb, key, paired, slot,
                        slot_b, slot_q, lens, sizes1, sizes2, flags);
 }
 void launch_predict_windows(hipStream_t s, const uint8_t* windows, uint32_t n_reads, const uint64_t* uids, const uint32_t* atts,
                             const uint8_t* is_read1, DevTables tb, RngKey key, uint32_t slot, char* slot_b, char* slot_q, uint32_t* lens, uint32_t* flags) {
     if (n_reads == 0) return;
-    uint32_t grid = cdiv(n_reads, 4); if (grid > kMaxStrideGrid * 4) grid = kMaxStrideGrid * 4;
-    hipLaunchKernelGGL(k_predict_windows, dim3(grid), dim3(256), 0, s, windows, n_reads, uids, atts, is_read1, tb, key, slot, slot_b, slot_q, lens, flags);
+    hipLaunchKernelGGL(k_predict_windows, dim3(reads_grid(n_reads)), dim3(64 * READS_WAVES), reads_lds_bytes(tb), s, windows, n_reads, uids, atts, is_read1, tb, key, slot, slot_b, slot_q, lens, flags);
 }
 void launch_format(hipStream_t s, const PairRec* pairs, uint32_t np, uint32_t amp_index_base, int paired, uint32_t slot, const char* slot_b,
                    const char* slot_q, const uint32_t* lens, const uint64_t* off1, const uint64_t* off2, char* out1, char* out2) {

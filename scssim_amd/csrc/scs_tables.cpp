@@ -214,6 +214,11 @@ void load_profile(const std::string& path, bool paired, int isize, ProfileTables
     auto to_thr = [](const std::vector<double>& c, std::vector<uint32_t>& t) { t.resize(c.size()); for (size_t i = 0; i < c.size(); ++i) t[i] = threshold_cdf(c[i]); };
     to_thr(T.subs1, T.subs1_t); to_thr(T.subs2, T.subs2_t); to_thr(T.qual, T.qual_t);
     to_thr(T.ins_cdf, T.ins_t); to_thr(T.del_cdf, T.del_t); to_thr(T.isize_cdf, T.isize_t);
+    T.qual_guide.assign((size_t)16 * B * 17 + 16, 0);
+    for (size_t row = 0; row < 16 * B; ++row) {
+        const uint32_t* t = &T.qual_t[row * 94];
+        for (uint64_t v = 0; v <= 16; ++v) { uint32_t n = 0; while (n < 94 && (uint64_t)t[n] <= (v << 28)) ++n; T.qual_guide[row * 17 + v] = (uint8_t)n; }
+    }
     T.t_insert = threshold_le(T.insert_rate);
     T.t_delete = threshold_lt(T.del_rate / (1 - T.insert_rate));
 }

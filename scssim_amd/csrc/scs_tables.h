@@ -23,6 +23,9 @@ struct ProfileTables {
     // 2^32-1, so the lookup is `x < T[k]`; exact for every x except x == 0xFFFFFFFF, which the kernels
     // route to the double tables.
     std::vector<uint32_t> subs1_t, subs2_t, qual_t, ins_t, del_t, isize_t;
+    // per quality row (16*bins of them) 17 counts: guide[v] = #{k : qual_t[row][k] <= v << 28}, v = 0..16
+    // (a draw x with x >> 28 == v resolves to a symbol in [guide[v], guide[v+1]]).
+    std::vector<uint8_t> qual_guide;
     uint32_t t_insert = 0;               // p <= insertRate            (Profile.cpp:1557)
     uint32_t t_delete = 0;               // p <  delRate/(1-insertRate) (Profile.cpp:1565-1566)
 };
