@@ -606,9 +606,10 @@ void amplify_template(Sim& S, Rng& rng, PrimerPool& pool, bool fromFrag, uint64_
     for (unsigned i = 0; i < primerNum; ++i) {
         int tryTimes = 0; unsigned spos = 0, alen = 0;
         do {
-            uint32_t blk = (i << 6) | (uint32_t)tryTimes;
-            spos = (unsigned)(long)(27 + ((long)length - 27) * rng.integer(mk(ST_ATTACH, aux, tuid, blk, 0)));
-            alen = (unsigned)(p.ampMin + (double)(p.ampMax + 1 - p.ampMin) * rng.real(mk(ST_ATTACH, aux, tuid, blk, 1)));
+            // counter key: one block serves two consecutive tries (words 0,1 and 2,3)
+            const uint32_t blk = (i << 5) | ((uint32_t)tryTimes >> 1); const int w0 = 2 * (tryTimes & 1);
+            spos = (unsigned)(long)(27 + ((long)length - 27) * rng.integer(mk(ST_ATTACH, aux, tuid, blk, w0)));
+            alen = (unsigned)(p.ampMin + (double)(p.ampMax + 1 - p.ampMin) * rng.real(mk(ST_ATTACH, aux, tuid, blk, w0 + 1)));
             tryTimes++;
             if (tryTimes > 50) break;
             if (spos + alen > length || posAttached[spos] == 1) continue;

@@ -431,7 +431,7 @@ __device__ __forceinline__ void predict_wave(const uint8_t* s_win, uint8_t* s_sr
         const int j = c * WAVE + lane;
         if (j >= n_out) continue;
         const uint32_t c2 = s_src[j], c1 = j >= 1 ? s_src[j - 1] : 5u, c0 = j >= 2 ? s_src[j - 2] : 5u;
-        const int bin = j * B / n_out;
+        const int bin = n_out == B ? j : j * B / n_out;                             // binIndx = j*binCount/n
         const int ki = kmer_index(c0, c1, c2);
         uint32_t xs, xq;
         if (c < MAXCH && c < nch && j < n) { xs = wsub[c < MAXCH ? c : 0]; xq = wql[c < MAXCH ? c : 0]; }
@@ -439,7 +439,7 @@ __device__ __forceinline__ void predict_wave(const uint8_t* s_win, uint8_t* s_sr
         int k;
         if (ki < 0) k = c2 < 4 ? (int)c2 : -1;
         else {
-            const size_t row = ((size_t)ki * B + bin) * 4;
+            const uint32_t row = ((uint32_t)ki * (uint32_t)B + (uint32_t)bin) * 4u;
             if (xs == 0xFFFFFFFFu) k = (int)rand_indx_slow(subs_d + row, 4, xs);
             else { const uint4 T = *reinterpret_cast<const uint4*>(subs + row); k = (xs >= T.x) + (xs >= T.y) + (xs >= T.z); }
         }
@@ -447,8 +447,8 @@ __device__ __forceinline__ void predict_wave(const uint8_t* s_win, uint8_t* s_sr
         if (k < 0) { bc = 'N'; qc = (char)(33 + scale_draw(xq, 0, 20)); }           // getRandBaseQuality
         else {
             bc = "ACGT"[k];
-            const size_t row = ((size_t)(c2 * 4 + (uint32_t)k) * B + bin) * NQ;
-            qc = (char)(33 + qual_lookup(tb.qual + row, tb.qual_d + row, s_guide + ((size_t)(c2 * 4 + (uint32_t)k) * B + bin) * 17, xq));
+            const uint32_t qrow = (c2 * 4u + (uint32_t)k) * (uint32_t)B + (uint32_t)bin;
+            qc = (char)(33 + qual_lookup(tb.qual + qrow * (uint32_t)NQ, tb.qual_d + qrow * (uint32_t)NQ, s_guide + qrow * 17u, xq));
         }
         out_b[j] = bc; out_q[j] = qc;
     }
@@ -685,16 +685,16 @@ __global__ void __launch_bounds__(64) k_attach(const uint8_t* __restrict__ g, De
     const uint32_t base_slot = t < nt ? slot_off[t] : 0, aux = (FROM_FRAG ? 0u : 1u) | (p.pass << 1);
     uint32_t v = 0, c0 = 0, i = 0, tries = 0, spos = 0, alen = 0, pidx = 0;
     bool fresh = true, unresolved = false, need = false, dead = false;
-    unsigned long long lsum = 0;
+    unsigned long long lsum = 0; U4 dblk{};
     while (__ballot(!group_done)) {
         if (!group_done) {
             if (fresh) { i = c0 + gl; unresolved = i < budget; need = unresolved; dead = false; tries = 0; fresh = false; }
             if (unresolved && !dead) {
                 if (!need && ((bits[spos >> 5] >> (spos & 31)) & 1u)) need = true;       // a lower primer took this position meanwhile
                 while (need) {
-                    const U4 d = draw4(p.key, ST_ATTACH, aux, tuid, (i << 6) | tries);
-                    spos = scale_draw(d.w[0], 27, len - 27);                             // randomInteger(27, length)
-                    alen = scale_draw(d.w[1], p.amp_min, p.amp_max + 1 - p.amp_min);      // (uint) randomDouble(minLen, maxLen+1)
+                    if ((tries & 1u) == 0) dblk = draw4(p.key, ST_ATTACH, aux, tuid, (i << 5) | (tries >> 1));   // one block = two tries
+                    spos = scale_draw(dblk.w[2 * (tries & 1u)], 27, len - 27);                       // randomInteger(27, length)
+                    alen = scale_draw(dblk.w[2 * (tries & 1u) + 1], p.amp_min, p.amp_max + 1 - p.amp_min);   // (uint) randomDouble(minLen, maxLen+1)
                     ++tries;
                     if (tries > 50) { dead = true; break; }
                     if (spos + alen > len) continue;
