@@ -466,6 +466,7 @@ struct Params {
     int isize = 260; bool paired = true; int threads = 1;
     int ampMin = 1000, ampMax = 2000, fragSize = 1000, fragMin = 10000, fragMax = 100000;   // Config.cpp:35-48, Fragment.cpp:15-16
     bool counter = false; uint64_t seed = 1; long long fixed_time = 1234567890LL; bool verbose = true;
+    int shard_rank = 0, shard_count = 1; scso_allreduce_fn allreduce = nullptr; scso_allgatherv_fn allgatherv = nullptr; void* coll_user = nullptr;
 };
 
 inline uint64_t semi_uid(uint64_t frag, uint32_t pass, uint32_t i) { return (frag << 23) | ((uint64_t)pass << 20) | i; }
@@ -478,6 +479,16 @@ struct Sim {
     std::vector<long> primerCount;          // 65536 counters (Malbac.cpp:36-81; flat instead of trie)
     std::vector<long> primerPending;        // [REMAP] counter mode: decrements applied at pass end
     std::vector<uint64_t> binom;            // [REMAP] counter mode: error-count thresholds
+    // sharded mode: this shard owns fragments [frag_gbase, frag_gbase + frags.size()) of the global list
+    uint64_t frag_gbase = 0;
+    std::vector<size_t> semi_block_end;     // local semi count after each fragment pass (block p = semis made in pass p)
+    struct Seg { int c, p; size_t count; };
+    std::vector<Seg> full_segs;             // local fulls list = concatenation of these (cycle c asc, p desc)
+    std::vector<uint64_t> gidx;             // local full index -> global list index (empty = identity)
+    void allreduce(uint64_t* v, uint64_t n) {
+        if (prm.shard_count <= 1) return;
+        if (!prm.allreduce || prm.allreduce(prm.coll_user, v, n)) fail("sharded run: allreduce hook missing or failed");
+    }
     unsigned long totalPrimers = 0;
     std::vector<unsigned> readNumbers;
     // GC-factor engines (ref mode): Profile.cpp:1405-1411
@@ -517,6 +528,14 @@ void split_to_frags(Sim& S) {
             S.frags.push_back(Frag{(int)r, pos, (int)(chrLen - pos + 1), 1, 0, {}});
         }
     }
+    if (p.shard_count > 1) {                 // contiguous fragment ranges balanced by bases (same rule as the product)
+        uint64_t tot = 0; for (auto& f : S.frags) tot += (uint64_t)f.len;
+        std::vector<size_t> cut(p.shard_count + 1, S.frags.size()); cut[0] = 0;
+        uint64_t acc = 0; int sh = 1;
+        for (size_t i = 0; i < S.frags.size() && sh < p.shard_count; ++i) { acc += (uint64_t)S.frags[i].len; while (sh < p.shard_count && acc * p.shard_count >= tot * (uint64_t)sh) cut[sh++] = i + 1; }
+        const size_t lo = cut[p.shard_rank], hi = cut[p.shard_rank + 1];
+        S.frags = std::vector<Frag>(S.frags.begin() + lo, S.frags.begin() + hi); S.frag_gbase = lo;
+    }
     for (auto& f : S.frags) {
         const uint8_t* g = S.recs[f.rec].code.data() + (f.start - 1);
         f.T.resize(f.len);
@@ -555,15 +574,17 @@ long poiss_rand(Sim& S, double lambda, uint32_t call, uint32_t kind, uint64_t tu
     return x;
 }
 void set_primers(Sim& S, bool onlyFrags, uint32_t call) {
-    unsigned long templateNum = 0; double totalLen = 0;
-    for (auto& f : S.frags) totalLen += (unsigned)f.len;
-    templateNum += S.frags.size();
-    if (!onlyFrags) { templateNum += S.semis.a.size(); for (auto& a : S.semis.a) totalLen += a.len; }
+    uint64_t tot[2] = {0, 0};                                                      // {templateNum, totalLen}: integer sums, shard-order free
+    for (auto& f : S.frags) tot[1] += (unsigned)f.len;
+    tot[0] += S.frags.size();
+    if (!onlyFrags) { tot[0] += S.semis.a.size(); for (auto& a : S.semis.a) tot[1] += a.len; }
+    S.allreduce(tot, 2);
+    const unsigned long templateNum = tot[0]; const double totalLen = (double)tot[1];
     unsigned long expected = (unsigned long)(S.totalPrimers * S.prm.gamma * templateNum);
-    unsigned long count = 0;
+    uint64_t count = 0;
     for (size_t i = 0; i < S.frags.size(); ++i) {
         double lambda = expected * (1.0 * (unsigned)S.frags[i].len / totalLen);
-        unsigned long k = (unsigned long)poiss_rand(S, lambda, call, 0, i);
+        unsigned long k = (unsigned long)poiss_rand(S, lambda, call, 0, S.frag_gbase + i);
         count += k; S.frags[i].primers = (int)k;
     }
     if (!onlyFrags) for (auto& a : S.semis.a) {
@@ -571,6 +592,7 @@ void set_primers(Sim& S, bool onlyFrags, uint32_t call) {
         unsigned long k = (unsigned long)poiss_rand(S, lambda, call, 1, a.uid);
         count += k; a.primers = (uint32_t)(k & 0xFFF);
     }
+    S.allreduce(&count, 1);
     S.totalPrimers -= count;
 }
 
@@ -685,8 +707,10 @@ void append_reversed(AmpList& dst, AmpList& add) {
 
 void apply_pending(Sim& S, std::vector<std::vector<long>>& pend) {
     if (!S.prm.counter) return;
-    for (auto& v : pend) for (size_t i = 0; i < v.size(); ++i) if (v[i]) { S.primerCount[i] -= v[i]; }
-    for (auto& c : S.primerCount) if (c < 0) c = 0;                                // [REMAP] clamp at pass end
+    std::vector<uint64_t> sum(65536, 0);
+    for (auto& v : pend) for (size_t i = 0; i < v.size(); ++i) sum[i] += (uint64_t)v[i];
+    S.allreduce(sum.data(), sum.size());                                            // sharded: decrements of all shards
+    for (size_t i = 0; i < sum.size(); ++i) { S.primerCount[i] -= (long)sum[i]; if (S.primerCount[i] < 0) S.primerCount[i] = 0; }   // [REMAP] clamp at pass end
 }
 
 // Malbac::amplifyFrags (Malbac.cpp:318-343)
@@ -699,7 +723,7 @@ void amplify_frags(Sim& S, uint32_t pass) {
         pend[b].assign(65536, 0); PrimerPool pool{S, &pend[b]}; std::vector<uint8_t> pa; Rng rng = S.rng;
         for (size_t i = lo; i < hi; ++i) {
             Frag& f = S.frags[i];
-            amplify_template(S, rng, pool, true, i, (uint32_t)i, f.T.data(), f.len, f.primers, pass, pa, parts[b]);
+            amplify_template(S, rng, pool, true, S.frag_gbase + i, (uint32_t)i, f.T.data(), f.len, f.primers, pass, pa, parts[b]);
         }
     });
     AmpList all;
@@ -707,6 +731,7 @@ void amplify_frags(Sim& S, uint32_t pass) {
         for (uint32_t e = 0; e < a.err_cnt; ++e) all.errs.push_back(pt.errs[a.err_off + e]); a.err_off = off; all.a.push_back(a); } }
     apply_pending(S, pend);
     append_reversed(S.semis, all);
+    S.semi_block_end.push_back(S.semis.a.size());
 }
 // Malbac::amplifySemiAmplicons (Malbac.cpp:345-368)
 void amplify_semis(Sim& S, uint32_t cyc) {
@@ -728,6 +753,11 @@ void amplify_semis(Sim& S, uint32_t cyc) {
     for (auto& pt : parts) { for (auto a : pt.a) { uint32_t off = (uint32_t)all.errs.size();
         for (uint32_t e = 0; e < a.err_cnt; ++e) all.errs.push_back(pt.errs[a.err_off + e]); a.err_off = off; all.a.push_back(a); } }
     apply_pending(S, pend);
+    {   // segments of this cycle in stored (reversed) order: semis made in fragment pass p, p descending
+        std::vector<size_t> cnt(S.semi_block_end.size(), 0);
+        for (auto& a : all.a) { size_t pblk = 0; while (a.parent >= S.semi_block_end[pblk]) ++pblk; cnt[pblk]++; }
+        for (int pb = (int)cnt.size() - 1; pb >= 0; --pb) S.full_segs.push_back(Sim::Seg{(int)cyc, pb, cnt[pb]});
+    }
     append_reversed(S.fulls, all);
 }
 
@@ -772,9 +802,9 @@ double gc_factor(Sim& S, int gc, uint64_t uid) {
 }
 
 // ---- a9: Malbac::setReadCounts (Malbac.cpp:370-408) + randIndx_hp/batchSampling (MyDefine.cpp:191-272)
-void set_read_counts(Sim& S, long reads) {
+void compute_weights(Sim& S, std::vector<double>& w) {
     const size_t ac = S.fulls.a.size();
-    std::vector<double> w(ac);
+    w.assign(ac, 0.0);
     const unsigned fragSize = S.prm.fragSize;
     if (S.prm.counter) {
         parallel_blocks(ac, S.prm.threads, 4096, [&](size_t, size_t lo, size_t hi) {
@@ -784,15 +814,20 @@ void set_read_counts(Sim& S, long reads) {
         for (size_t i = 0; i < ac; ++i) { const Amp& a = S.fulls.a[i]; int gc = 100 * a.gc / a.len;
             w[i] = gc_factor(S, gc, a.uid) * a.len / (fragSize * fragSize); }
     }
+}
+
+// allocation over a weight vector in (global) list order -> read numbers
+void allocate_reads(Sim& S, std::vector<double>& w, long reads, std::vector<unsigned>& readNumbers) {
+    const size_t ac = w.size();
     const unsigned chunk = (unsigned)std::max<size_t>(1, std::min<size_t>(1000, ac / 1));   // loadPerThread at -t 1
     double total = 0;
     if (S.prm.counter) {        // [REMAP] chunked sum: per-1000 partials, then partials in order
         for (size_t s = 0; s < ac; s += chunk) { double part = 0; for (size_t i = s; i < std::min(ac, s + chunk); ++i) part += w[i]; total += part; }
     } else for (size_t i = 0; i < ac; ++i) total += w[i];
     for (size_t i = 0; i < ac; ++i) w[i] /= (ZERO_FINAL + total);                 // wls.normalize(0)
-    S.readNumbers.assign(ac, 0);
+    readNumbers.assign(ac, 0);
     unsigned long sum = 0;
-    for (size_t i = 0; i < ac; ++i) { unsigned rc = (unsigned)(w[i] * reads); S.readNumbers[i] = rc; sum += rc; }
+    for (size_t i = 0; i < ac; ++i) { unsigned rc = (unsigned)(w[i] * reads); readNumbers[i] = rc; sum += rc; }
     reads -= (long)sum;
     // randIndx_hp(wls, reads, readNumbers, true)
     unsigned long n = (unsigned long)reads;
@@ -818,10 +853,40 @@ void set_read_counts(Sim& S, long reads) {
         Chunk& ch = chunks[c];
         for (unsigned t = 0; t < ch.quota; ++t) {
             unsigned j = rand_indx(ch.cdf.data(), ch.cdf.size(), S.rng.real(mk(ST_ALLOC_CHUNK, 0, c, t, 0)));
-            S.readNumbers[ch.s + j] += 1;
+            readNumbers[ch.s + j] += 1;
         }
     }
-    if (S.prm.paired) { int k = 1; for (size_t i = 0; i < ac; ++i) if (S.readNumbers[i] % 2 == 1) { S.readNumbers[i] += k; k *= -1; } }
+    if (S.prm.paired) { int k = 1; for (size_t i = 0; i < ac; ++i) if (readNumbers[i] % 2 == 1) { readNumbers[i] += k; k *= -1; } }
+}
+
+void set_read_counts(Sim& S, long reads) {
+    std::vector<double> w;
+    compute_weights(S, w);
+    if (S.prm.shard_count <= 1) { allocate_reads(S, w, reads, S.readNumbers); return; }
+    // ---- sharded: assemble the GLOBAL weight vector in the reference's list order, allocate identically on every shard
+    const int R = S.prm.shard_count, NSEG = 5 * 6;
+    std::vector<uint64_t> segc((size_t)R * NSEG, 0);                                 // counts[r][c][p]
+    for (auto& sg : S.full_segs) segc[(size_t)S.prm.shard_rank * NSEG + sg.c * 6 + sg.p] = sg.count;
+    S.allreduce(segc.data(), segc.size());
+    uint64_t maxn = 0; std::vector<uint64_t> nloc(R, 0);
+    for (int r = 0; r < R; ++r) { for (int k = 0; k < NSEG; ++k) nloc[r] += segc[(size_t)r * NSEG + k]; maxn = std::max(maxn, nloc[r]); }
+    std::vector<double> all((size_t)R * std::max<uint64_t>(maxn, 1)); std::vector<uint64_t> sizes(R, 0);
+    if (!S.prm.allgatherv || S.prm.allgatherv(S.prm.coll_user, w.data(), w.size() * 8, all.data(), std::max<uint64_t>(maxn, 1) * 8, sizes.data()))
+        fail("sharded run: allgatherv hook missing or failed");
+    std::vector<uint64_t> loff(R, 0);                                                // running local offsets per shard
+    std::vector<double> gw; std::vector<std::pair<uint64_t, uint64_t>> mine;          // (global offset, count) of my segments, in local order
+    for (int c = 0; c < 5; ++c) for (int pb = 5; pb >= 0; --pb) for (int r = 0; r < R; ++r) {
+        const uint64_t n = segc[(size_t)r * NSEG + c * 6 + pb];
+        if (!n) continue;
+        if (r == S.prm.shard_rank) mine.push_back({gw.size(), n});
+        gw.insert(gw.end(), all.begin() + (size_t)r * std::max<uint64_t>(maxn, 1) + loff[r], all.begin() + (size_t)r * std::max<uint64_t>(maxn, 1) + loff[r] + n);
+        loff[r] += n;
+    }
+    std::vector<unsigned> grn;
+    allocate_reads(S, gw, reads, grn);
+    S.readNumbers.clear(); S.gidx.clear();
+    for (auto& m : mine) for (uint64_t k = 0; k < m.second; ++k) { S.readNumbers.push_back(grn[m.first + k]); S.gidx.push_back(m.first + k); }
+    if (S.readNumbers.size() != S.fulls.a.size()) fail("sharded allocation: segment bookkeeping mismatch");
 }
 
 // ---- a11: Amplicon::yieldReads (Amplicon.cpp:402-565) -----------------------------------------
@@ -836,6 +901,7 @@ void yield_reads_range(Sim& S, Rng& rng, size_t lo, size_t hi, ReadOut& out, boo
         int n = (int)S.readNumbers[i];
         if (n == 0) continue;
         const Amp& a = S.fulls.a[i];
+        const uint64_t gi = S.gidx.empty() ? i : S.gidx[i];                          // list index in the whole (unsharded) job
         full_sequence(S, a, scratch, seq);
         const int ampLen = (int)a.len;
         if (ampLen < L) continue;
@@ -846,7 +912,7 @@ void yield_reads_range(Sim& S, Rng& rng, size_t lo, size_t hi, ReadOut& out, boo
             if (!paired) {
                 long pos = (long)(0 + (double)(ampLen - L + 1 - 0) * rng.integer(mk(ST_PAIR, 0, a.uid, att, 1)));
                 int m = predict(P, rng, &seq[pos], L, true, a.uid, att, ob.data(), oq.data());
-                int k = snprintf(name, sizeof name, "@%d#%d\n", (int)i, fragCount);
+                int k = snprintf(name, sizeof name, "@%d#%d\n", (int)gi, fragCount);
                 out.f1.append(name, k); out.f1.append(ob.data(), m); out.f1.append("\n+\n"); out.f1.append(oq.data(), m); out.f1.push_back('\n');
                 out.pairs++; n--;
                 continue;
@@ -857,11 +923,11 @@ void yield_reads_range(Sim& S, Rng& rng, size_t lo, size_t hi, ReadOut& out, boo
             if (isz < L || isz > ampLen) { failCount++; if (failCount > 1000) break; continue; }
             long pos = (long)(0 + (double)(ampLen - isz + 1 - 0) * rng.integer(mk(ST_PAIR, 0, a.uid, att, 1)));
             int m1 = predict(P, rng, &seq[pos], L, true, a.uid, att, ob.data(), oq.data());
-            int k = snprintf(name, sizeof name, "@%d#%d/1\n", (int)i, fragCount);
+            int k = snprintf(name, sizeof name, "@%d#%d/1\n", (int)gi, fragCount);
             out.f1.append(name, k); out.f1.append(ob.data(), m1); out.f1.append("\n+\n"); out.f1.append(oq.data(), m1); out.f1.push_back('\n');
             for (int t = 0; t < L; ++t) win[t] = comp_code(seq[pos + isz - 1 - t]);    // revcomp of the far end
             int m2 = predict(P, rng, win.data(), L, false, a.uid, att, ob.data(), oq.data());
-            k = snprintf(name, sizeof name, "@%d#%d/2\n", (int)i, fragCount);
+            k = snprintf(name, sizeof name, "@%d#%d/2\n", (int)gi, fragCount);
             out.f2.append(name, k); out.f2.append(ob.data(), m2); out.f2.append("\n+\n"); out.f2.append(oq.data(), m2); out.f2.push_back('\n');
             if (dump) { char b[128]; int q = snprintf(b, sizeof b, "%zu\t%d\t%ld\t%d\t%d\t%d\n", i, fragCount, pos, isz, m1, m2); out.dump.append(b, q); }
             out.pairs++; n -= 2;
@@ -885,6 +951,8 @@ int genreads(const scso_params& q) {
     p.primers = q.primers; p.gamma = q.gamma; p.coverage = q.coverage; p.isize = q.isize; p.paired = q.paired != 0;
     p.threads = std::max(1, q.threads); p.counter = q.rng_mode == 1; p.seed = q.seed; p.fixed_time = q.fixed_time; p.verbose = q.verbose != 0;
     if (!p.counter) p.threads = 1;
+    p.shard_rank = q.shard_rank; p.shard_count = std::max(1, q.shard_count); p.allreduce = q.allreduce; p.allgatherv = q.allgatherv; p.coll_user = q.coll_user;
+    if (p.shard_count > 1 && !p.counter) fail("sharding needs --rng counter (the reference streams are sequential)");
     S.rng.counter = p.counter; S.rng.key[0] = (uint32_t)p.seed; S.rng.key[1] = (uint32_t)(p.seed >> 32); S.rng.ref = &S.streams;
     if (!p.counter) {
         srand((unsigned)p.fixed_time);                                                    // scssim.cpp:47
@@ -965,7 +1033,7 @@ void scso_last_timings(double out[6]) { for (int i = 0; i < 6; ++i) out[i] = g_t
 void scso_default_params(scso_params* p) {
     memset(p, 0, sizeof *p);
     p->primers = 100000; p->gamma = 1e-9; p->coverage = 5; p->isize = 260; p->paired = 1; p->threads = 1;
-    p->rng_mode = 1; p->seed = 1; p->fixed_time = 1234567890LL; p->verbose = 1;
+    p->rng_mode = 1; p->seed = 1; p->fixed_time = 1234567890LL; p->verbose = 1; p->shard_rank = 0; p->shard_count = 1;
 }
 
 int scso_genreads(const scso_params* p) {

@@ -29,6 +29,12 @@ double scso_det_log(double x);
 // is left in scso_last_error().  `rng_mode`: 0 = reference streams, 1 = counter.
 //   dump_prefix (nullable): writes <prefix>.frags.tsv / .semis.tsv / .fulls.tsv /
 //   .reads.tsv intermediate tables for stage-level parity tests.
+// Collectives for the sharded mode (fragment-lineage sharding of ONE job; world_size > 1 tests run them over
+// torch.distributed/gloo).  allreduce: element-wise sum of n uint64 in place across shards.  allgatherv: every shard
+// contributes send_bytes; recv holds shard_count slots of stride_bytes; sizes[r] = bytes received from shard r.
+typedef int (*scso_allreduce_fn)(void* user, uint64_t* vals, uint64_t n);
+typedef int (*scso_allgatherv_fn)(void* user, const void* send, uint64_t send_bytes, void* recv, uint64_t stride_bytes, uint64_t* sizes);
+
 struct scso_params {
     const char* input_fasta;
     const char* profile;
@@ -44,6 +50,10 @@ struct scso_params {
     uint64_t seed;               // counter-mode seed
     long long fixed_time;        // ref-mode pinned clock (seconds), = SCS_FIXED_TIME
     int    verbose;
+    int    shard_rank, shard_count;              // counter mode only; 0/1 = whole job
+    scso_allreduce_fn  allreduce;                // required when shard_count > 1
+    scso_allgatherv_fn allgatherv;
+    void*  coll_user;
 };
 void scso_default_params(scso_params* p);
 int  scso_genreads(const scso_params* p);

@@ -1,0 +1,93 @@
+"""Multi-process glue (one process per GPU / shard): collective hooks over torch.distributed and the
+merge of per-shard FASTQ pools into the single-job order.
+
+A job is sharded by fragment lineage.  What crosses shards:
+  * setPrimers: all-reduce of {template count, total template length} and of the budgets' sum  (3 scalars / cycle)
+  * each pass: all-reduce of the 65536 primer-stock decrements                                   (256-512 KB)
+  * read allocation: all-reduce of the 5x6 segment sizes + all-gather of the GC weights
+  * output: every record name carries the amplicon's index in the whole job's list, and each shard's pool is
+    already sorted by it, so the writer k-way merges the pools (`merge_fastq`).
+The hooks work on host buffers (numpy views of the C pointers); with the NCCL(=RCCL) backend they are staged through
+a device tensor, with gloo they stay on the CPU.
+"""
+import ctypes as C
+import heapq
+
+import numpy as np
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint64), C.c_uint64)
+ALLGATHERV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64))
+
+
+class Collectives:
+    """ctypes callbacks implementing the scso_* / scs_* collective hooks with torch.distributed."""
+
+    def __init__(self, device=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.device = device if device is not None else ("cuda" if dist.get_backend() == "nccl" else "cpu")
+        self.world = dist.get_world_size()
+        self.rank = dist.get_rank()
+        self.allreduce_cb = ALLREDUCE_FN(self._allreduce)
+        self.allgatherv_cb = ALLGATHERV_FN(self._allgatherv)
+        self.calls = dict(allreduce=0, allgatherv=0, bytes=0)
+
+    def _allreduce(self, _user, vals, n):
+        try:
+            a = np.ctypeslib.as_array(vals, (int(n),)).view(np.int64)
+            t = self.torch.from_numpy(a.copy()).to(self.device)
+            self.dist.all_reduce(t)
+            a[:] = t.cpu().numpy()
+            self.calls["allreduce"] += 1
+            self.calls["bytes"] += 8 * int(n)
+            return 0
+        except Exception as e:                                   # never let an exception cross the C boundary
+            print("allreduce hook failed:", e)
+            return 1
+
+    def _allgatherv(self, _user, send, send_bytes, recv, stride, sizes):
+        try:
+            torch, dist = self.torch, self.dist
+            n = int(send_bytes)
+            sz = torch.tensor([n], dtype=torch.int64, device=self.device)
+            allsz = [torch.zeros(1, dtype=torch.int64, device=self.device) for _ in range(self.world)]
+            dist.all_gather(allsz, sz)
+            mx = max(int(s[0]) for s in allsz)
+            buf = torch.zeros(max(mx, 1), dtype=torch.uint8)
+            if n:
+                buf[:n] = torch.from_numpy(np.ctypeslib.as_array(C.cast(send, C.POINTER(C.c_uint8)), (n,)).copy())
+            buf = buf.to(self.device)
+            outs = [torch.zeros_like(buf) for _ in range(self.world)]
+            dist.all_gather(outs, buf)
+            dst = np.ctypeslib.as_array(C.cast(recv, C.POINTER(C.c_uint8)), (int(stride) * self.world,))
+            for r in range(self.world):
+                k = int(allsz[r][0])
+                sizes[r] = k
+                if k:
+                    dst[r * int(stride): r * int(stride) + k] = outs[r][:k].cpu().numpy()
+            self.calls["allgatherv"] += 1
+            self.calls["bytes"] += mx * self.world
+            return 0
+        except Exception as e:
+            print("allgatherv hook failed:", e)
+            return 1
+
+
+def _records(buf):
+    """Yield (amplicon index, record bytes) for a FASTQ pool; records are 4 lines."""
+    pos, n = 0, len(buf)
+    while pos < n:
+        e = pos
+        for _ in range(4):
+            e = buf.index(b"\n", e) + 1
+        name_end = buf.index(b"#", pos)
+        yield int(buf[pos + 1:name_end]), buf[pos:e]
+        pos = e
+
+
+def merge_fastq(pools):
+    """k-way merge of per-shard FASTQ pools (each sorted by the amplicon's whole-job list index, which is the number
+    after '@' in the record name) into the order the unsharded job writes."""
+    its = [_records(p) for p in pools]
+    return b"".join(rec for _, rec in heapq.merge(*its, key=lambda kv: kv[0]))
