@@ -113,6 +113,19 @@ int         scs_run_genreads(scs_ctx* ctx, scs_sink_fn sink, void* user);
 
 int         scs_get_stats(const scs_ctx* ctx, scs_stats* out);
 
+/* ---- one job over several GPUs (scs_config.shard_rank / shard_count: fragment-lineage sharding) -------------
+ * The reference is single-process; these are the exchange steps its globals imply once fragments are split over
+ * ranks: Malbac::setPrimers totals (Malbac.cpp:242-262,282), the primer stock (Malbac.cpp:91-103) and the weight
+ * normalisation / chunked sampling of Malbac::setReadCounts (Malbac.cpp:370-408).  The caller supplies them
+ * (torch.distributed over RCCL or gloo: scssim_amd/dist.py); buffers are host memory.
+ *   allreduce : element-wise sum of n uint64 values in place over all shards
+ *   allgatherv: every shard sends send_bytes; recv has shard_count slots of stride_bytes; sizes[r] = bytes of shard r
+ * With the hooks set, a sharded job writes record names / read counts identical to the unsharded job; each shard's
+ * FASTQ pool is sorted by the amplicon index in the record name, so the writer k-way merges the pools. */
+typedef int (*scs_allreduce_fn)(void* user, uint64_t* vals, uint64_t n);
+typedef int (*scs_allgatherv_fn)(void* user, const void* send, uint64_t send_bytes, void* recv, uint64_t stride_bytes, uint64_t* sizes);
+int         scs_set_collectives(scs_ctx* ctx, scs_allreduce_fn allreduce, scs_allgatherv_fn allgatherv, void* user);
+
 /* ---- kernel-level entry points (unit parity tests; same kernels as the pipeline) ------------ */
 
 /* char* Profile::predict(char* refSeq, int isRead1)  (lib/profile/Profile.cpp:1582-1697) for a batch:

@@ -65,6 +65,7 @@ def load_library():
     L.scs_yield_reads_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                          C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.scs_get_stats.argtypes = [C.c_void_p, C.POINTER(_Stats)]
+    L.scs_set_collectives.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.scs_kernel_time.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_uint64), C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     L.scs_predict_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
@@ -184,6 +185,11 @@ class GenReads:
     @property
     def read_length(self):
         return self._L.scs_read_length(self._ctx)
+
+    def set_collectives(self, coll):
+        """Sharded single job (shard_count > 1): `coll` = scssim_amd.dist.Collectives (torch.distributed hooks)."""
+        self._coll = coll                      # keep the ctypes callbacks alive
+        self._ck(self._L.scs_set_collectives(self._ctx, C.cast(coll.allreduce_cb, C.c_void_p), C.cast(coll.allgatherv_cb, C.c_void_p), None))
 
     def set_seed(self, seed):
         self._ck(self._L.scs_set_seed(self._ctx, seed))

@@ -102,7 +102,8 @@ void launch_genome_bits(hipStream_t s, const uint8_t* g, uint64_t n, uint64_t nw
 void launch_primer_update(hipStream_t s, int64_t* primer_cnt, uint32_t* primer_delta);
 void launch_weights(hipStream_t s, DevAmps fulls, uint32_t n, DevTables tb, RngKey key, uint32_t frag_size, double* w);
 void launch_plan_pairs(hipStream_t s, DevFrags fr, DevAmps semis, DevAmps fulls, uint32_t n_fulls, const uint32_t* read_numbers, const uint32_t* pair_off,
-                       DevTables tb, RngKey key, int paired, PairRec* pairs);
+                       const uint32_t* gidx, DevTables tb, RngKey key, int paired, PairRec* pairs);
+void launch_pair_offsets(hipStream_t s, const uint32_t* rn, uint32_t ac, int paired, uint32_t* pair_cnt_off, void* temp, size_t temp_bytes);
 // reads of pairs [p0, p0+np): slot layout [2*np][slot] bases / quals (SE: [np][slot])
 void launch_reads(hipStream_t s, const uint8_t* g, DevErrPool spool, DevErrPool fpool,
                   const PairRec* pairs, uint32_t np, uint32_t amp_index_base, DevTables tb, RngKey key, int paired, uint32_t slot,

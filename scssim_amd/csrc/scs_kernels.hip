@@ -275,7 +275,8 @@ __global__ void k_weights(DevAmps fulls, uint32_t n, DevTables tb, RngKey key, u
 //      (Amplicon.cpp:448-491): insert size, rejection, position.
 // ------------------------------------------------------------------------------------------------
 __global__ void k_plan_pairs(DevFrags fr, DevAmps semis, DevAmps fulls, uint32_t n_fulls, const uint32_t* __restrict__ read_numbers,
-                             const uint32_t* __restrict__ pair_off, DevTables tb, RngKey key, int paired, PairRec* __restrict__ pairs) {
+                             const uint32_t* __restrict__ pair_off, const uint32_t* __restrict__ gidx, DevTables tb, RngKey key, int paired,
+                             PairRec* __restrict__ pairs) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_fulls) return;
     int n = (int)read_numbers[i];
@@ -287,7 +288,8 @@ __global__ void k_plan_pairs(DevFrags fr, DevAmps semis, DevAmps fulls, uint32_t
     // resolve U = full amplicon sequence to an index map once (Amplicon::getSequence, Amplicon.cpp:266-340, without the copies)
     const uint32_t sm = fulls.parent[i], ssl = semis.sl[sm], l1 = sl_len(ssl), f = semis.parent[sm];
     const View uv = shift_view(semi_tmpl_view(frag_view(fr.goff[f], fr.len[f], fr.strand[f]), sl_spos(ssl), l1), s2);
-    PairRec r; r.amp = i; r.base = uv.base; r.flags = (uv.comp & 1u) | (uv.dir < 0 ? 2u : 0u); r.k1 = (int32_t)(l1 - 1 - s2);
+    PairRec r; r.amp = gidx ? gidx[i] : i;                                         // index in the whole job's list (record names)
+    r.base = uv.base; r.flags = (uv.comp & 1u) | (uv.dir < 0 ? 2u : 0u); r.k1 = (int32_t)(l1 - 1 - s2);
     r.e1 = semis.errs[sm]; r.e2 = fulls.errs[i]; r.uid = fulls.uid[i]; r.pad = 0;
     uint32_t made = 0;
     if (amp_len >= L) {
@@ -912,9 +914,13 @@ void launch_weights(hipStream_t s, DevAmps fulls, uint32_t n, DevTables tb, RngK
     hipLaunchKernelGGL(k_weights, dim3(cdiv(n, 256)), dim3(256), 0, s, fulls, n, tb, key, frag_size, w);
 }
 void launch_plan_pairs(hipStream_t s, DevFrags fr, DevAmps semis, DevAmps fulls, uint32_t n_fulls, const uint32_t* read_numbers, const uint32_t* pair_off,
-                       DevTables tb, RngKey key, int paired, PairRec* pairs) {
+                       const uint32_t* gidx, DevTables tb, RngKey key, int paired, PairRec* pairs) {
     if (n_fulls == 0) return;
-    hipLaunchKernelGGL(k_plan_pairs, dim3(cdiv(n_fulls, 256)), dim3(256), 0, s, fr, semis, fulls, n_fulls, read_numbers, pair_off, tb, key, paired, pairs);
+    hipLaunchKernelGGL(k_plan_pairs, dim3(cdiv(n_fulls, 256)), dim3(256), 0, s, fr, semis, fulls, n_fulls, read_numbers, pair_off, gidx, tb, key, paired, pairs);
+}
+void launch_pair_offsets(hipStream_t s, const uint32_t* rn, uint32_t ac, int paired, uint32_t* pair_cnt_off, void* temp, size_t temp_bytes) {
+    if (paired) (void)rocprim::exclusive_scan(temp, temp_bytes, rocprim::make_transform_iterator(rn, HalfUp()), pair_cnt_off, 0u, (size_t)ac + 1, rocprim::plus<uint32_t>(), s);
+    else (void)rocprim::exclusive_scan(temp, temp_bytes, rn, pair_cnt_off, 0u, (size_t)ac + 1, rocprim::plus<uint32_t>(), s);
 }
 static inline size_t reads_lds_bytes(const DevTables& tb) { return (((size_t)16 * tb.bins * 17 + 15) & ~(size_t)15) + READS_WAVES * (256 + SRC_CAP); }
 static inline uint32_t reads_grid(uint64_t nreads) {

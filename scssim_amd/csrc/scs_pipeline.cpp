@@ -108,8 +108,19 @@ struct scs_ctx {
     DevBuf primer_cnt, primer_delta; uint64_t total_primers = 0; bool amplified = false;
     DevBuf slots, slot_tmpl, valid, valid_off, scan_tmp, flags;
     // allocation + reads
-    DevBuf weights, read_numbers, pair_off, pairs, odd_before, a_part, a_tp, a_probs, a_quota; std::vector<uint32_t> h_read_numbers; uint64_t reads_requested = 0, n_pairs_planned = 0; bool allocated = false;
+    DevBuf weights, read_numbers, pair_off, pairs, odd_before, a_part, a_tp, a_probs, a_quota, a_poff; std::vector<uint32_t> h_read_numbers; uint64_t reads_requested = 0, n_pairs_planned = 0; bool allocated = false;
     DevBuf slot_b, slot_q, lens, sizes1, sizes2, off1, off2, out1, out2; std::vector<char> h_out1, h_out2;
+    // sharded single job: collectives supplied by the caller + segment bookkeeping of the local amplicon lists
+    scs_allreduce_fn allreduce = nullptr; scs_allgatherv_fn allgatherv = nullptr; void* coll_user = nullptr;
+    std::vector<uint32_t> semi_block_end;                  // local semi count after each fragment pass
+    struct Seg { int c, p; uint32_t count; }; std::vector<Seg> full_segs;   // local fulls list = these, in order
+    DevBuf d_gidx, d_gw, d_grn; bool have_gidx = false;
+    int pending_seg_cycle = -1;
+    bool sharded() const { return cfg.shard_count > 1; }
+    void reduce(uint64_t* v, uint64_t n) {
+        if (!sharded()) return;
+        if (!allreduce || allreduce(coll_user, v, n)) throw ScsError(SCS_EINVAL, "sharded job: all-reduce hook missing or failed (scs_set_collectives)");
+    }
     scs_stats st{};
     KernelTimer tm_errscan{"k_errs<semi->full>"}, tm_errscan_f{"k_errs<frag->semi>"}, tm_reads{"k_reads"}, tm_attach{"k_attach"}, tm_format{"k_format"};
 
@@ -224,11 +235,12 @@ void do_create_frags(scs_ctx* c) {
 // One launch gives every template (fragments, then all semis so far) its Poisson budget; the scans
 // turn budgets into slot offsets.  One host sync: the sums feed totalPrimers and the buffer sizes.
 void set_primers(scs_ctx* c, bool only_frags, uint32_t call) {
-    if (c->cfg.shard_count > 1) throw ScsError(SCS_EINVAL, "sharded setPrimers needs the all-reduce hook (not wired in this build)");
     hipStream_t s = c->stream;
     const uint32_t nf = (uint32_t)c->f_len.size(), ns = only_frags ? 0u : c->semis.n;
     PoissonParams p; p.key = c->key; p.call = call; p.gamma = c->cfg.gamma; p.total_primers = c->total_primers;
-    p.total_len = c->frag_total_len + (only_frags ? 0 : c->semi_total_len); p.template_num = (uint64_t)nf + ns;
+    uint64_t tot[2] = {(uint64_t)nf + ns, c->frag_total_len + (only_frags ? 0 : c->semi_total_len)};   // {templateNum, totalLen}
+    c->reduce(tot, 2);                                                             // sharded: totals over all shards
+    p.template_num = tot[0]; p.total_len = tot[1];
     c->budget_f.reserve(((size_t)nf + 1) * 4, s); c->budget_s.reserve(((size_t)ns + 1) * 4, s);
     c->slot_off_f.reserve(((size_t)nf + 1) * 4, s); c->slot_off_s.reserve(((size_t)ns + 1) * 4, s);
     c->scan_tmp.reserve(scan_temp_bytes(std::max(nf, ns)), s);
@@ -242,7 +254,9 @@ void set_primers(scs_ctx* c, bool only_frags, uint32_t call) {
     HIP_OK(hipMemcpyAsync(&rb[2], c->slot_off_f.as<uint32_t>() + nf, 4, hipMemcpyDeviceToHost, s));
     if (ns) HIP_OK(hipMemcpyAsync(&rb[3], c->slot_off_s.as<uint32_t>() + ns, 4, hipMemcpyDeviceToHost, s));
     HIP_OK(hipStreamSynchronize(s));
-    c->total_primers -= rb[0] + rb[1];
+    uint64_t ksum = rb[0] + rb[1];
+    c->reduce(&ksum, 1);
+    c->total_primers -= ksum;
     c->slots_f = (uint32_t)rb[2]; c->slots_s = (uint32_t)rb[3]; c->budget_ns = ns;
 }
 
@@ -281,16 +295,41 @@ void launch_pass(scs_ctx* c, bool from_frag, uint32_t pass, int rb_slot) {
     else launch_errs_semis(s, g, gx, fr, c->semis.view(), nt, c->semis.pool_view(), n_slots, slot_off, c->slots.as<uint32_t>(), c->slot_tmpl.as<uint32_t>(),
                            c->valid_off.as<uint32_t>(), out.view(), out.n, out.pool_view(), c->flags.as<uint32_t>(), c->d_binom.as<unsigned long long>(), p);
     tm.end(s);
+    if (c->sharded()) {                                                           // stock decrements of all shards (host-staged, 65536 counters)
+        std::vector<uint32_t> d32(65536); std::vector<uint64_t> d64(65536);
+        HIP_OK(hipMemcpyAsync(d32.data(), c->primer_delta.p, 65536 * 4, hipMemcpyDeviceToHost, s)); HIP_OK(hipStreamSynchronize(s));
+        for (int i = 0; i < 65536; ++i) d64[i] = d32[i];
+        c->reduce(d64.data(), 65536);
+        for (int i = 0; i < 65536; ++i) d32[i] = (uint32_t)std::min<uint64_t>(d64[i], 0xFFFFFFFFull);
+        HIP_OK(hipMemcpyAsync(c->primer_delta.p, d32.data(), 65536 * 4, hipMemcpyHostToDevice, s)); HIP_OK(hipStreamSynchronize(s));
+    }
     launch_primer_update(s, c->primer_cnt.as<int64_t>(), c->primer_delta.as<uint32_t>());
     HIP_OK(hipMemcpyAsync(&c->h_rb[rb_slot], c->valid_off.as<uint32_t>() + nt, 4, hipMemcpyDeviceToHost, s));
+    if (!from_frag) {                                                             // fulls made from the semis of each fragment pass (segments)
+        for (size_t b = 0; b < c->semi_block_end.size() && b < 8; ++b) {
+            c->h_rb[16 + b] = 0;
+            HIP_OK(hipMemcpyAsync(&c->h_rb[16 + b], c->valid_off.as<uint32_t>() + std::min(c->semi_block_end[b], nt), 4, hipMemcpyDeviceToHost, s));
+        }
+        c->pending_seg_cycle = (int)pass;
+    }
 }
 // host sync closing a group of passes: counts of new amplicons, total length of the semis
 void collect_passes(scs_ctx* c, int rb_fulls, int rb_semis) {
     hipStream_t s = c->stream;
     HIP_OK(hipMemcpyAsync(&c->h_rb[8], c->dsums.as<unsigned long long>() + 4, 8, hipMemcpyDeviceToHost, s));
     HIP_OK(hipStreamSynchronize(s));
-    if (rb_fulls >= 0) { c->fulls.n += (uint32_t)c->h_rb[rb_fulls]; c->tm_errscan.units += c->h_rb[rb_fulls]; }
-    if (rb_semis >= 0) { c->semis.n += (uint32_t)c->h_rb[rb_semis]; c->tm_errscan_f.units += c->h_rb[rb_semis]; }
+    if (rb_fulls >= 0) {
+        c->fulls.n += (uint32_t)c->h_rb[rb_fulls]; c->tm_errscan.units += c->h_rb[rb_fulls];
+        if (c->pending_seg_cycle >= 0) {                                          // stored order within a cycle: fragment pass p descending
+            const size_t nb = std::min<size_t>(c->semi_block_end.size(), 8);
+            for (int b = (int)nb - 1; b >= 0; --b) {
+                const uint32_t hi = (uint32_t)c->h_rb[16 + b], lo = b ? (uint32_t)c->h_rb[16 + b - 1] : 0u;
+                c->full_segs.push_back(scs_ctx::Seg{c->pending_seg_cycle, b, hi - lo});
+            }
+            c->pending_seg_cycle = -1;
+        }
+    }
+    if (rb_semis >= 0) { c->semis.n += (uint32_t)c->h_rb[rb_semis]; c->tm_errscan_f.units += c->h_rb[rb_semis]; c->semi_block_end.push_back(c->semis.n); }
     c->semi_total_len = c->h_rb[8];
 }
 
@@ -300,7 +339,7 @@ void do_amplify(scs_ctx* c) {
     if (!c->have_profile) throw ScsError(SCS_EINVAL, "scs_amplify: load a profile first");
     hipStream_t s = c->stream;
     if (c->cfg.verbose) fprintf(stderr, "\nMALBAC amplification...\n");
-    c->semis.reset(s); c->fulls.reset(s);
+    c->semis.reset(s); c->fulls.reset(s); c->semi_block_end.clear(); c->full_segs.clear(); c->pending_seg_cycle = -1; c->have_gidx = false;
     c->tm_errscan.reset(); c->tm_errscan_f.reset(); c->tm_attach.reset();
     std::vector<int64_t> stock(65536, (int64_t)c->cfg.primers);                    // createPrimers: 4^8 types x `primers` copies
     upload(c->primer_cnt, stock, s);
@@ -341,21 +380,62 @@ void do_allocate(scs_ctx* c, uint64_t reads) {
         for (auto& r : c->recs) { size_t p = r.name.rfind('_'); ref_len += (uint64_t)atoi(r.name.c_str() + (p == std::string::npos ? 0 : p + 1)); }
         ref_len /= 2;
         reads = (uint64_t)(ref_len * c->cfg.coverage / (long)c->prof.read_length);
-        if (c->cfg.shard_count > 1) throw ScsError(SCS_EINVAL, "sharded read allocation needs the all-reduce hook (not wired in this build)");
     }
     if (c->cfg.verbose) fprintf(stderr, "\nNumber of reads to generate: %llu\n", (unsigned long long)reads);
     c->reads_requested = reads; c->st.reads_requested = reads;
-    const uint32_t ac = c->fulls.n; const uint32_t nch = (ac + 999) / 1000;
+    const uint32_t ac = c->fulls.n;
     double t0 = now_s();
     c->weights.reserve(std::max<size_t>((size_t)ac * 8, 16), s);
-    c->read_numbers.reserve(((size_t)ac + 1) * 4, s); c->odd_before.reserve(((size_t)ac + 1) * 4, s); c->pair_off.reserve(((size_t)ac + 1) * 4, s);
+    c->read_numbers.reserve(((size_t)ac + 1) * 4, s); c->pair_off.reserve(((size_t)ac + 1) * 4, s);
+    launch_weights(s, c->fulls.view(), ac, c->dtb, c->key, (uint32_t)c->cfg.frag_size, c->weights.as<double>());
+    double* d_w = c->weights.as<double>(); uint32_t* d_rn = c->read_numbers.as<uint32_t>(); uint32_t n_alloc = ac;
+    std::vector<std::pair<uint64_t, uint32_t>> mine;                              // (global offset, count) of my segments, local order
+    if (c->sharded()) {
+        // assemble the whole job's weight vector in list order: cycle c asc, fragment pass p desc, shard asc
+        const int R = c->cfg.shard_count, NSEG = 5 * 8;
+        std::vector<uint64_t> segc((size_t)R * NSEG, 0);
+        for (auto& sg : c->full_segs) segc[(size_t)c->cfg.shard_rank * NSEG + sg.c * 8 + sg.p] = sg.count;
+        c->reduce(segc.data(), segc.size());
+        uint64_t maxn = 1, total = 0; std::vector<uint64_t> nloc(R, 0);
+        for (int r = 0; r < R; ++r) { for (int k = 0; k < NSEG; ++k) nloc[r] += segc[(size_t)r * NSEG + k]; maxn = std::max(maxn, nloc[r]); total += nloc[r]; }
+        if (nloc[c->cfg.shard_rank] != ac) throw ScsError(SCS_EINVAL, "sharded allocation: segment bookkeeping mismatch");
+        if (total > 0xFFFFFFF0ull) throw ScsError(SCS_EOVERFLOW, "more than 2^32 amplicons in the whole job");
+        std::vector<double> w(ac), all((size_t)R * maxn), gw; std::vector<uint64_t> sizes(R, 0), loff(R, 0);
+        if (ac) HIP_OK(hipMemcpyAsync(w.data(), d_w, (size_t)ac * 8, hipMemcpyDeviceToHost, s));
+        HIP_OK(hipStreamSynchronize(s));
+        if (!c->allgatherv || c->allgatherv(c->coll_user, w.data(), (uint64_t)ac * 8, all.data(), maxn * 8, sizes.data()))
+            throw ScsError(SCS_EINVAL, "sharded job: all-gather hook missing or failed (scs_set_collectives)");
+        gw.reserve(total);
+        for (int cy = 0; cy < 5; ++cy) for (int pb = 7; pb >= 0; --pb) for (int r = 0; r < R; ++r) {
+            const uint64_t n = segc[(size_t)r * NSEG + cy * 8 + pb];
+            if (!n) continue;
+            if (r == c->cfg.shard_rank) mine.push_back({gw.size(), (uint32_t)n});
+            gw.insert(gw.end(), all.begin() + (size_t)r * maxn + loff[r], all.begin() + (size_t)r * maxn + loff[r] + n);
+            loff[r] += n;
+        }
+        n_alloc = (uint32_t)total;
+        c->d_gw.reserve(std::max<size_t>((size_t)n_alloc * 8, 16), s); c->d_grn.reserve(((size_t)n_alloc + 1) * 4, s);
+        if (n_alloc) HIP_OK(hipMemcpyAsync(c->d_gw.p, gw.data(), (size_t)n_alloc * 8, hipMemcpyHostToDevice, s));
+        HIP_OK(hipStreamSynchronize(s));
+        d_w = c->d_gw.as<double>(); d_rn = c->d_grn.as<uint32_t>();
+    }
+    const uint32_t nch = (n_alloc + 999) / 1000;
+    c->odd_before.reserve(((size_t)n_alloc + 1) * 4, s); c->a_poff.reserve(((size_t)n_alloc + 1) * 4, s);
     c->a_part.reserve(std::max<size_t>((size_t)nch * 8, 16), s); c->a_tp.reserve(std::max<size_t>((size_t)nch * 8, 16), s);
     c->a_probs.reserve(std::max<size_t>((size_t)nch * 8, 16), s); c->a_quota.reserve(std::max<size_t>((size_t)nch * 4, 16), s);
-    c->scan_tmp.reserve(scan_temp_bytes(ac), s);
-    launch_weights(s, c->fulls.view(), ac, c->dtb, c->key, (uint32_t)c->cfg.frag_size, c->weights.as<double>());
-    launch_alloc(s, c->weights.as<double>(), ac, reads, c->key, c->cfg.paired != 0, (AllocState*)((char*)c->dsums.p + 128), c->a_part.as<double>(), c->a_tp.as<double>(),
-                 c->a_probs.as<double>(), c->a_quota.as<uint32_t>(), c->read_numbers.as<uint32_t>(), c->odd_before.as<uint32_t>(), c->pair_off.as<uint32_t>(),
-                 c->scan_tmp.p, c->scan_tmp.cap);
+    c->scan_tmp.reserve(scan_temp_bytes(n_alloc), s);
+    launch_alloc(s, d_w, n_alloc, reads, c->key, c->cfg.paired != 0, (AllocState*)((char*)c->dsums.p + 128), c->a_part.as<double>(), c->a_tp.as<double>(),
+                 c->a_probs.as<double>(), c->a_quota.as<uint32_t>(), d_rn, c->odd_before.as<uint32_t>(), c->a_poff.as<uint32_t>(), c->scan_tmp.p, c->scan_tmp.cap);
+    if (c->sharded()) {                                                           // my amplicons' read numbers + their whole-job list index
+        std::vector<uint32_t> gidx; gidx.reserve(ac); uint32_t lo = 0;
+        for (auto& m : mine) {
+            HIP_OK(hipMemcpyAsync(c->read_numbers.as<uint32_t>() + lo, d_rn + m.first, (size_t)m.second * 4, hipMemcpyDeviceToDevice, s));
+            for (uint32_t k = 0; k < m.second; ++k) gidx.push_back((uint32_t)(m.first + k));
+            lo += m.second;
+        }
+        upload(c->d_gidx, gidx, s); HIP_OK(hipStreamSynchronize(s)); c->have_gidx = true;
+    }
+    launch_pair_offsets(s, c->read_numbers.as<uint32_t>(), ac, c->cfg.paired != 0, c->pair_off.as<uint32_t>(), c->scan_tmp.p, c->scan_tmp.cap);
     c->h_rb[0] = 0;
     if (ac) HIP_OK(hipMemcpyAsync(&c->h_rb[0], c->pair_off.as<uint32_t>() + ac, 4, hipMemcpyDeviceToHost, s));
     HIP_OK(hipStreamSynchronize(s));
@@ -375,7 +455,7 @@ void do_yield(scs_ctx* c, const OutTarget& tg, uint64_t* n1_out, uint64_t* n2_ou
     const uint64_t P = c->n_pairs_planned;
     const uint32_t L = (uint32_t)c->prof.read_length, slot = ((L + 64 + 63) / 64) * 64;
     c->pairs.reserve(std::max<size_t>(P * sizeof(PairRec), 16), s);
-    launch_plan_pairs(s, c->frags_view(), c->semis.view(), c->fulls.view(), c->fulls.n, c->read_numbers.as<uint32_t>(), c->pair_off.as<uint32_t>(), c->dtb, c->key, paired, c->pairs.as<PairRec>());
+    launch_plan_pairs(s, c->frags_view(), c->semis.view(), c->fulls.view(), c->fulls.n, c->read_numbers.as<uint32_t>(), c->pair_off.as<uint32_t>(), c->have_gidx ? c->d_gidx.as<uint32_t>() : nullptr, c->dtb, c->key, paired, c->pairs.as<PairRec>());
     const uint64_t batch = std::min<uint64_t>(std::max<uint64_t>(P, 1), 1ull << 21);
     const uint64_t nreads_b = paired ? 2 * batch : batch;
     c->slot_b.reserve(nreads_b * slot, s); c->slot_q.reserve(nreads_b * slot, s); c->lens.reserve(nreads_b * 4, s);
@@ -492,7 +572,7 @@ void scs_destroy(scs_ctx* c) {
     for (DevBuf* b : {&c->t_guide, &c->t_subs1, &c->t_subs2, &c->t_qual, &c->t_ins, &c->t_del, &c->t_isize, &c->d_subs1, &c->d_subs2, &c->d_qual, &c->d_ins, &c->d_del,
                       &c->d_isize, &c->d_gcmeans, &c->genome, &c->gx_gc_bits, &c->gx_n_bits, &c->gx_gc_cnt, &c->gx_n_cnt, &c->gx_gc_pref, &c->gx_n_pref, &c->d_binom, &c->df_goff, &c->df_len, &c->df_strand, &c->df_primers, &c->primer_cnt, &c->primer_delta,
                       &c->slots, &c->slot_tmpl, &c->valid, &c->valid_off, &c->scan_tmp, &c->flags, &c->weights, &c->read_numbers,
-                      &c->pair_off, &c->pairs, &c->odd_before, &c->a_part, &c->a_tp, &c->a_probs, &c->a_quota, &c->budget_f, &c->budget_s, &c->slot_off_f,
+                      &c->pair_off, &c->pairs, &c->odd_before, &c->a_part, &c->a_tp, &c->a_probs, &c->a_quota, &c->a_poff, &c->d_gidx, &c->d_gw, &c->d_grn, &c->budget_f, &c->budget_s, &c->slot_off_f,
                       &c->slot_off_s, &c->dsums, &c->slot_b, &c->slot_q, &c->lens, &c->sizes1, &c->sizes2, &c->off1, &c->off2, &c->out1, &c->out2}) b->release();
     c->semis.release(); c->fulls.release();
     for (KernelTimer* t : {&c->tm_errscan, &c->tm_errscan_f, &c->tm_reads, &c->tm_attach, &c->tm_format}) t->release();
@@ -545,6 +625,10 @@ int scs_run_genreads(scs_ctx* c, scs_sink_fn sink, void* user) {
     if ((rc = scs_allocate_reads(c, 0))) return rc;
     if ((rc = scs_yield_reads(c, sink, user))) return rc;
     c->st.t_stage[7] = now_s() - t; return SCS_OK;
+}
+int scs_set_collectives(scs_ctx* c, scs_allreduce_fn ar, scs_allgatherv_fn ag, void* user) {
+    if (!c) return SCS_EINVAL;
+    c->allreduce = ar; c->allgatherv = ag; c->coll_user = user; return SCS_OK;
 }
 int scs_get_stats(const scs_ctx* c, scs_stats* out) { if (!c || !out) return SCS_EINVAL; *out = c->st; return SCS_OK; }
 

@@ -1,0 +1,33 @@
+"""Worker for the sharded GPU test: one shard of one genreads job on the (shared) GPU, collectives over gloo."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    fasta, profile, prefix, coverage, layout, seed = sys.argv[1:7]
+    import torch.distributed as dist
+    import scssim_amd
+    from scssim_amd.dist import Collectives
+    dist.init_process_group("gloo")
+    coll = Collectives(device="cpu")
+    g = scssim_amd.GenReads(profile=profile, input_fasta=fasta, coverage=float(coverage), layout=layout, seed=int(seed), device=0,
+                            shard_rank=dist.get_rank(), shard_count=dist.get_world_size())
+    g.set_collectives(coll)
+    fq1, fq2 = g.run()
+    st = g.stats()
+    pre = "%s.r%d" % (prefix, dist.get_rank())
+    if layout == "PE":
+        open(pre + "_1.fq", "wb").write(fq1)
+        open(pre + "_2.fq", "wb").write(fq2)
+    else:
+        open(pre + ".fq", "wb").write(fq1)
+    print("rank %d: %d fragments, %d fulls, %d pairs, collectives %s" % (dist.get_rank(), st["fragments"], st["full_amplicons"], st["pairs_written"], coll.calls))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

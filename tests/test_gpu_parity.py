@@ -192,3 +192,28 @@ def test_full_size_properties(models, tmp_path):
     assert g2.run() == (fq1, fq2)
     g2.set_seed(6)
     assert g2.run()[0] != fq1
+
+
+@pytest.mark.parametrize("world,case,model,cov,layout", [(2, "g1_hiseq2500_pe", "Illumina_HiSeq2500", "3", "PE"),
+                                                         (3, "g2_xten_pe_nblock", "Illumina_HiSeqXTen", "2", "PE")])
+def test_sharded_gpu_job_equals_whole_job(world, case, model, cov, layout, oracle_bin, models, golden_inputs, tmp_path):
+    """ONE job sharded by fragment lineage over `world` processes (sharing this box's single GPU, collectives over gloo)
+    must merge to exactly the unsharded job's FASTQ -- which in turn is the oracle's."""
+    import socket
+    import sys
+    from scssim_amd.dist import merge_fastq
+    seed = "777"
+    whole = str(tmp_path / "whole")
+    _oracle_run(oracle_bin, golden_inputs[case], models[model], whole, ["-c", cov, "-l", layout], seed)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = str(s.getsockname()[1]); s.close()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=port, LOCAL_RANK="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_gpu_worker.py"), golden_inputs[case], models[model],
+                                       str(tmp_path / "shard"), cov, layout, seed], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    for suffix in ("_1.fq", "_2.fq"):
+        pools = [open(str(tmp_path / "shard") + ".r%d%s" % (r, suffix), "rb").read() for r in range(world)]
+        assert all(len(p) > 0 for p in pools)
+        assert merge_fastq(pools) == open(whole + suffix, "rb").read(), "sharded GPU job differs from the whole job (%s)" % suffix
