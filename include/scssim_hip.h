@@ -125,6 +125,13 @@ int         scs_get_stats(const scs_ctx* ctx, scs_stats* out);
 typedef int (*scs_allreduce_fn)(void* user, uint64_t* vals, uint64_t n);
 typedef int (*scs_allgatherv_fn)(void* user, const void* send, uint64_t send_bytes, void* recv, uint64_t stride_bytes, uint64_t* sizes);
 int         scs_set_collectives(scs_ctx* ctx, scs_allreduce_fn allreduce, scs_allgatherv_fn allgatherv, void* user);
+/* Device-memory variants, ordered on the ctx stream (no host sync): used for the per-cycle scalars, the per-pass
+ * primer-stock decrements and the weight gather when set; the host hooks above remain the fallback.
+ *   allreduce_dev: sum n elements of elem_bytes (4 = uint32, 8 = uint64) in place
+ *   allgather_dev: d_recv[r * bytes_per_rank ..] = shard r's d_send[0 .. bytes_per_rank) */
+typedef int (*scs_allreduce_dev_fn)(void* user, void* d_vals, uint64_t n, int elem_bytes);
+typedef int (*scs_allgather_dev_fn)(void* user, const void* d_send, void* d_recv, uint64_t bytes_per_rank);
+int         scs_set_collectives_device(scs_ctx* ctx, scs_allreduce_dev_fn allreduce_dev, scs_allgather_dev_fn allgather_dev, void* user);
 
 /* ---- kernel-level entry points (unit parity tests; same kernels as the pipeline) ------------ */
 

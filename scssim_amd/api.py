@@ -66,6 +66,7 @@ def load_library():
                                          C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.scs_get_stats.argtypes = [C.c_void_p, C.POINTER(_Stats)]
     L.scs_set_collectives.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.scs_set_collectives_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.scs_kernel_time.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_uint64), C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     L.scs_predict_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
@@ -186,10 +187,14 @@ class GenReads:
     def read_length(self):
         return self._L.scs_read_length(self._ctx)
 
-    def set_collectives(self, coll):
-        """Sharded single job (shard_count > 1): `coll` = scssim_amd.dist.Collectives (torch.distributed hooks)."""
+    def set_collectives(self, coll, device_hooks=False):
+        """Sharded single job (shard_count > 1): `coll` = scssim_amd.dist.Collectives (torch.distributed hooks).
+        device_hooks=True: collectives act on the library's HBM buffers directly (create the GenReads on torch's
+        current stream: stream=torch.cuda.current_stream().cuda_stream)."""
         self._coll = coll                      # keep the ctypes callbacks alive
         self._ck(self._L.scs_set_collectives(self._ctx, C.cast(coll.allreduce_cb, C.c_void_p), C.cast(coll.allgatherv_cb, C.c_void_p), None))
+        if device_hooks:
+            self._ck(self._L.scs_set_collectives_device(self._ctx, C.cast(coll.allreduce_dev_cb, C.c_void_p), C.cast(coll.allgather_dev_cb, C.c_void_p), None))
 
     def set_seed(self, seed):
         self._ck(self._L.scs_set_seed(self._ctx, seed))

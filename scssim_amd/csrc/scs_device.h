@@ -61,7 +61,8 @@ struct AmplifyParams {
 
 struct PoissonParams {
     RngKey key; uint32_t call; double gamma;
-    uint64_t total_primers, total_len, template_num;   // Malbac::setPrimers inputs (Malbac.cpp:236-262)
+    uint64_t total_primers;                            // Malbac::setPrimers inputs (Malbac.cpp:236-262)
+    const uint64_t* totals;                            // device: {template_num, total_len} over ALL shards
 };
 struct AllocState { double total; unsigned long long sum_rn, sum_quota; };
 

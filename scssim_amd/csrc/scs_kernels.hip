@@ -607,8 +607,9 @@ __device__ __forceinline__ void block_add_u64(unsigned long long v, unsigned lon
 //     sums[0] += sum of k over fragments, sums[1] += sum of UNTRUNCATED k over semis (Malbac.cpp:282).
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ double poisson_lambda(const PoissonParams& p, uint32_t len) {
-    const unsigned long long expected = (unsigned long long)((double)p.total_primers * p.gamma * (double)p.template_num);
-    return (double)expected * (1.0 * (double)len / (double)p.total_len);
+    const uint64_t template_num = p.totals[0], total_len = p.totals[1];
+    const unsigned long long expected = (unsigned long long)((double)p.total_primers * p.gamma * (double)template_num);
+    return (double)expected * (1.0 * (double)len / (double)total_len);
 }
 // semis: lambda ~ 6 -> one thread per semi amplicon
 __global__ void __launch_bounds__(256) k_poisson_semis(DevAmps semis, uint32_t n_semis, PoissonParams p, uint32_t* __restrict__ budget_s,

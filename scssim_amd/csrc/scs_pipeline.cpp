@@ -112,6 +112,8 @@ struct scs_ctx {
     DevBuf slot_b, slot_q, lens, sizes1, sizes2, off1, off2, out1, out2; std::vector<char> h_out1, h_out2;
     // sharded single job: collectives supplied by the caller + segment bookkeeping of the local amplicon lists
     scs_allreduce_fn allreduce = nullptr; scs_allgatherv_fn allgatherv = nullptr; void* coll_user = nullptr;
+    scs_allreduce_dev_fn allreduce_dev = nullptr; scs_allgather_dev_fn allgather_dev = nullptr; void* coll_dev_user = nullptr;
+    DevBuf d_tot, d_stage, d_all;
     std::vector<uint32_t> semi_block_end;                  // local semi count after each fragment pass
     struct Seg { int c, p; uint32_t count; }; std::vector<Seg> full_segs;   // local fulls list = these, in order
     DevBuf d_gidx, d_gw, d_grn; bool have_gidx = false;
@@ -120,6 +122,18 @@ struct scs_ctx {
     void reduce(uint64_t* v, uint64_t n) {
         if (!sharded()) return;
         if (!allreduce || allreduce(coll_user, v, n)) throw ScsError(SCS_EINVAL, "sharded job: all-reduce hook missing or failed (scs_set_collectives)");
+    }
+    // sum a device array over all shards, in place, ordered on the ctx stream when the device hook is set
+    void reduce_dev(void* d, uint64_t n, int elem_bytes) {
+        if (!sharded()) return;
+        if (allreduce_dev) { if (allreduce_dev(coll_dev_user, d, n, elem_bytes)) throw ScsError(SCS_EINVAL, "sharded job: device all-reduce hook failed"); return; }
+        std::vector<uint64_t> v(n);                                                // fallback: stage through the host hook
+        if (elem_bytes == 8) { HIP_OK(hipMemcpyAsync(v.data(), d, n * 8, hipMemcpyDeviceToHost, stream)); HIP_OK(hipStreamSynchronize(stream)); }
+        else { std::vector<uint32_t> w(n); HIP_OK(hipMemcpyAsync(w.data(), d, n * 4, hipMemcpyDeviceToHost, stream)); HIP_OK(hipStreamSynchronize(stream)); for (uint64_t i = 0; i < n; ++i) v[i] = w[i]; }
+        reduce(v.data(), n);
+        if (elem_bytes == 8) { HIP_OK(hipMemcpyAsync(d, v.data(), n * 8, hipMemcpyHostToDevice, stream)); HIP_OK(hipStreamSynchronize(stream)); }
+        else { std::vector<uint32_t> w(n); for (uint64_t i = 0; i < n; ++i) w[i] = (uint32_t)std::min<uint64_t>(v[i], 0xFFFFFFFFull);
+               HIP_OK(hipMemcpyAsync(d, w.data(), n * 4, hipMemcpyHostToDevice, stream)); HIP_OK(hipStreamSynchronize(stream)); }
     }
     scs_stats st{};
     KernelTimer tm_errscan{"k_errs<semi->full>"}, tm_errscan_f{"k_errs<frag->semi>"}, tm_reads{"k_reads"}, tm_attach{"k_attach"}, tm_format{"k_format"};
@@ -238,9 +252,10 @@ void set_primers(scs_ctx* c, bool only_frags, uint32_t call) {
     hipStream_t s = c->stream;
     const uint32_t nf = (uint32_t)c->f_len.size(), ns = only_frags ? 0u : c->semis.n;
     PoissonParams p; p.key = c->key; p.call = call; p.gamma = c->cfg.gamma; p.total_primers = c->total_primers;
-    uint64_t tot[2] = {(uint64_t)nf + ns, c->frag_total_len + (only_frags ? 0 : c->semi_total_len)};   // {templateNum, totalLen}
-    c->reduce(tot, 2);                                                             // sharded: totals over all shards
-    p.template_num = tot[0]; p.total_len = tot[1];
+    c->h_rb[12] = (uint64_t)nf + ns; c->h_rb[13] = c->frag_total_len + (only_frags ? 0 : c->semi_total_len);   // {templateNum, totalLen}, local
+    HIP_OK(hipMemcpyAsync(c->d_tot.p, &c->h_rb[12], 16, hipMemcpyHostToDevice, s));
+    c->reduce_dev(c->d_tot.p, 2, 8);                                               // sharded: totals over all shards
+    p.totals = c->d_tot.as<uint64_t>();
     c->budget_f.reserve(((size_t)nf + 1) * 4, s); c->budget_s.reserve(((size_t)ns + 1) * 4, s);
     c->slot_off_f.reserve(((size_t)nf + 1) * 4, s); c->slot_off_s.reserve(((size_t)ns + 1) * 4, s);
     c->scan_tmp.reserve(scan_temp_bytes(std::max(nf, ns)), s);
@@ -248,15 +263,14 @@ void set_primers(scs_ctx* c, bool only_frags, uint32_t call) {
     launch_poisson(s, c->frags_view(), c->semis.view(), ns, p, c->budget_f.as<uint32_t>(), c->budget_s.as<uint32_t>(), c->dsums.as<unsigned long long>());
     exclusive_scan_u32(s, c->budget_f.as<uint32_t>(), c->slot_off_f.as<uint32_t>(), nf, c->scan_tmp.p, c->scan_tmp.cap);
     if (ns) exclusive_scan_u32(s, c->budget_s.as<uint32_t>(), c->slot_off_s.as<uint32_t>(), ns, c->scan_tmp.p, c->scan_tmp.cap);
+    c->reduce_dev(c->dsums.p, 2, 8);                                               // sharded: budgets of all shards leave the pool
     uint64_t* rb = c->h_rb;
     HIP_OK(hipMemcpyAsync(rb, c->dsums.p, 16, hipMemcpyDeviceToHost, s));
     rb[2] = rb[3] = 0;
     HIP_OK(hipMemcpyAsync(&rb[2], c->slot_off_f.as<uint32_t>() + nf, 4, hipMemcpyDeviceToHost, s));
     if (ns) HIP_OK(hipMemcpyAsync(&rb[3], c->slot_off_s.as<uint32_t>() + ns, 4, hipMemcpyDeviceToHost, s));
     HIP_OK(hipStreamSynchronize(s));
-    uint64_t ksum = rb[0] + rb[1];
-    c->reduce(&ksum, 1);
-    c->total_primers -= ksum;
+    c->total_primers -= rb[0] + rb[1];
     c->slots_f = (uint32_t)rb[2]; c->slots_s = (uint32_t)rb[3]; c->budget_ns = ns;
 }
 
@@ -267,7 +281,11 @@ void launch_pass(scs_ctx* c, bool from_frag, uint32_t pass, int rb_slot) {
     const uint32_t nt = from_frag ? (uint32_t)c->f_len.size() : c->budget_ns;
     const uint32_t n_slots = from_frag ? c->slots_f : c->slots_s;
     c->h_rb[rb_slot] = 0;
-    if (nt == 0 || n_slots == 0) return;
+    if (nt == 0 || n_slots == 0) {                                                 // nothing local; a shard still joins the pass's collective
+        if (c->sharded()) { c->reduce_dev(c->primer_delta.p, 65536, 4); launch_primer_update(s, c->primer_cnt.as<int64_t>(), c->primer_delta.as<uint32_t>()); }
+        if (!from_frag) { for (size_t b = 0; b < 8; ++b) c->h_rb[16 + b] = 0; c->pending_seg_cycle = (int)pass; }
+        return;
+    }
     const uint32_t* slot_off = (from_frag ? c->slot_off_f : c->slot_off_s).as<uint32_t>();
     c->valid.reserve(((size_t)nt + 1) * 4, s); c->valid_off.reserve(((size_t)nt + 1) * 4, s);
     c->slots.reserve((size_t)n_slots * 4, s); c->slot_tmpl.reserve((size_t)n_slots * 4, s);
@@ -295,14 +313,7 @@ void launch_pass(scs_ctx* c, bool from_frag, uint32_t pass, int rb_slot) {
     else launch_errs_semis(s, g, gx, fr, c->semis.view(), nt, c->semis.pool_view(), n_slots, slot_off, c->slots.as<uint32_t>(), c->slot_tmpl.as<uint32_t>(),
                            c->valid_off.as<uint32_t>(), out.view(), out.n, out.pool_view(), c->flags.as<uint32_t>(), c->d_binom.as<unsigned long long>(), p);
     tm.end(s);
-    if (c->sharded()) {                                                           // stock decrements of all shards (host-staged, 65536 counters)
-        std::vector<uint32_t> d32(65536); std::vector<uint64_t> d64(65536);
-        HIP_OK(hipMemcpyAsync(d32.data(), c->primer_delta.p, 65536 * 4, hipMemcpyDeviceToHost, s)); HIP_OK(hipStreamSynchronize(s));
-        for (int i = 0; i < 65536; ++i) d64[i] = d32[i];
-        c->reduce(d64.data(), 65536);
-        for (int i = 0; i < 65536; ++i) d32[i] = (uint32_t)std::min<uint64_t>(d64[i], 0xFFFFFFFFull);
-        HIP_OK(hipMemcpyAsync(c->primer_delta.p, d32.data(), 65536 * 4, hipMemcpyHostToDevice, s)); HIP_OK(hipStreamSynchronize(s));
-    }
+    c->reduce_dev(c->primer_delta.p, 65536, 4);                                    // sharded: stock decrements of all shards
     launch_primer_update(s, c->primer_cnt.as<int64_t>(), c->primer_delta.as<uint32_t>());
     HIP_OK(hipMemcpyAsync(&c->h_rb[rb_slot], c->valid_off.as<uint32_t>() + nt, 4, hipMemcpyDeviceToHost, s));
     if (!from_frag) {                                                             // fulls made from the semis of each fragment pass (segments)
@@ -400,23 +411,37 @@ void do_allocate(scs_ctx* c, uint64_t reads) {
         for (int r = 0; r < R; ++r) { for (int k = 0; k < NSEG; ++k) nloc[r] += segc[(size_t)r * NSEG + k]; maxn = std::max(maxn, nloc[r]); total += nloc[r]; }
         if (nloc[c->cfg.shard_rank] != ac) throw ScsError(SCS_EINVAL, "sharded allocation: segment bookkeeping mismatch");
         if (total > 0xFFFFFFF0ull) throw ScsError(SCS_EOVERFLOW, "more than 2^32 amplicons in the whole job");
-        std::vector<double> w(ac), all((size_t)R * maxn), gw; std::vector<uint64_t> sizes(R, 0), loff(R, 0);
-        if (ac) HIP_OK(hipMemcpyAsync(w.data(), d_w, (size_t)ac * 8, hipMemcpyDeviceToHost, s));
-        HIP_OK(hipStreamSynchronize(s));
-        if (!c->allgatherv || c->allgatherv(c->coll_user, w.data(), (uint64_t)ac * 8, all.data(), maxn * 8, sizes.data()))
-            throw ScsError(SCS_EINVAL, "sharded job: all-gather hook missing or failed (scs_set_collectives)");
-        gw.reserve(total);
-        for (int cy = 0; cy < 5; ++cy) for (int pb = 7; pb >= 0; --pb) for (int r = 0; r < R; ++r) {
-            const uint64_t n = segc[(size_t)r * NSEG + cy * 8 + pb];
-            if (!n) continue;
-            if (r == c->cfg.shard_rank) mine.push_back({gw.size(), (uint32_t)n});
-            gw.insert(gw.end(), all.begin() + (size_t)r * maxn + loff[r], all.begin() + (size_t)r * maxn + loff[r] + n);
-            loff[r] += n;
-        }
         n_alloc = (uint32_t)total;
         c->d_gw.reserve(std::max<size_t>((size_t)n_alloc * 8, 16), s); c->d_grn.reserve(((size_t)n_alloc + 1) * 4, s);
-        if (n_alloc) HIP_OK(hipMemcpyAsync(c->d_gw.p, gw.data(), (size_t)n_alloc * 8, hipMemcpyHostToDevice, s));
-        HIP_OK(hipStreamSynchronize(s));
+        std::vector<uint64_t> loff(R, 0); uint64_t goff = 0;
+        if (c->allgather_dev) {                                                    // weights gathered device to device (RCCL), segments placed by D2D copies
+            c->weights.reserve(maxn * 8, s, (size_t)ac * 8); d_w = c->weights.as<double>();
+            c->d_all.reserve((size_t)R * maxn * 8, s);
+            if (c->allgather_dev(c->coll_dev_user, d_w, c->d_all.p, maxn * 8)) throw ScsError(SCS_EINVAL, "sharded job: device all-gather hook failed");
+            for (int cy = 0; cy < 5; ++cy) for (int pb = 7; pb >= 0; --pb) for (int r = 0; r < R; ++r) {
+                const uint64_t n = segc[(size_t)r * NSEG + cy * 8 + pb];
+                if (!n) continue;
+                if (r == c->cfg.shard_rank) mine.push_back({goff, (uint32_t)n});
+                HIP_OK(hipMemcpyAsync(c->d_gw.as<double>() + goff, c->d_all.as<double>() + (size_t)r * maxn + loff[r], n * 8, hipMemcpyDeviceToDevice, s));
+                loff[r] += n; goff += n;
+            }
+        } else {
+            std::vector<double> w(ac), all((size_t)R * maxn), gw; std::vector<uint64_t> sizes(R, 0);
+            if (ac) HIP_OK(hipMemcpyAsync(w.data(), d_w, (size_t)ac * 8, hipMemcpyDeviceToHost, s));
+            HIP_OK(hipStreamSynchronize(s));
+            if (!c->allgatherv || c->allgatherv(c->coll_user, w.data(), (uint64_t)ac * 8, all.data(), maxn * 8, sizes.data()))
+                throw ScsError(SCS_EINVAL, "sharded job: all-gather hook missing or failed (scs_set_collectives)");
+            gw.reserve(total);
+            for (int cy = 0; cy < 5; ++cy) for (int pb = 7; pb >= 0; --pb) for (int r = 0; r < R; ++r) {
+                const uint64_t n = segc[(size_t)r * NSEG + cy * 8 + pb];
+                if (!n) continue;
+                if (r == c->cfg.shard_rank) mine.push_back({gw.size(), (uint32_t)n});
+                gw.insert(gw.end(), all.begin() + (size_t)r * maxn + loff[r], all.begin() + (size_t)r * maxn + loff[r] + n);
+                loff[r] += n;
+            }
+            if (n_alloc) HIP_OK(hipMemcpyAsync(c->d_gw.p, gw.data(), (size_t)n_alloc * 8, hipMemcpyHostToDevice, s));
+            HIP_OK(hipStreamSynchronize(s));
+        }
         d_w = c->d_gw.as<double>(); d_rn = c->d_grn.as<uint32_t>();
     }
     const uint32_t nch = (n_alloc + 999) / 1000;
@@ -559,6 +584,7 @@ int scs_create(const scs_config* cfg, scs_ctx** out) {
         c->key = RngKey{(uint32_t)cfg->seed, (uint32_t)(cfg->seed >> 32)};
         c->flags.reserve(256, c->stream); HIP_OK(hipMemsetAsync(c->flags.p, 0, 256, c->stream));
         c->dsums.reserve(256, c->stream); HIP_OK(hipMemsetAsync(c->dsums.p, 0, 256, c->stream));
+        c->d_tot.reserve(256, c->stream);
         HIP_OK(hipHostMalloc((void**)&c->h_rb, 256, hipHostMallocDefault)); memset(c->h_rb, 0, 256);
         HIP_OK(hipStreamSynchronize(c->stream));
     } catch (const std::exception& e) { g_create_error = e.what(); delete c; return SCS_EDEVICE; }
@@ -572,7 +598,7 @@ void scs_destroy(scs_ctx* c) {
     for (DevBuf* b : {&c->t_guide, &c->t_subs1, &c->t_subs2, &c->t_qual, &c->t_ins, &c->t_del, &c->t_isize, &c->d_subs1, &c->d_subs2, &c->d_qual, &c->d_ins, &c->d_del,
                       &c->d_isize, &c->d_gcmeans, &c->genome, &c->gx_gc_bits, &c->gx_n_bits, &c->gx_gc_cnt, &c->gx_n_cnt, &c->gx_gc_pref, &c->gx_n_pref, &c->d_binom, &c->df_goff, &c->df_len, &c->df_strand, &c->df_primers, &c->primer_cnt, &c->primer_delta,
                       &c->slots, &c->slot_tmpl, &c->valid, &c->valid_off, &c->scan_tmp, &c->flags, &c->weights, &c->read_numbers,
-                      &c->pair_off, &c->pairs, &c->odd_before, &c->a_part, &c->a_tp, &c->a_probs, &c->a_quota, &c->a_poff, &c->d_gidx, &c->d_gw, &c->d_grn, &c->budget_f, &c->budget_s, &c->slot_off_f,
+                      &c->pair_off, &c->pairs, &c->odd_before, &c->a_part, &c->a_tp, &c->a_probs, &c->a_quota, &c->a_poff, &c->d_gidx, &c->d_gw, &c->d_grn, &c->d_tot, &c->d_stage, &c->d_all, &c->budget_f, &c->budget_s, &c->slot_off_f,
                       &c->slot_off_s, &c->dsums, &c->slot_b, &c->slot_q, &c->lens, &c->sizes1, &c->sizes2, &c->off1, &c->off2, &c->out1, &c->out2}) b->release();
     c->semis.release(); c->fulls.release();
     for (KernelTimer* t : {&c->tm_errscan, &c->tm_errscan_f, &c->tm_reads, &c->tm_attach, &c->tm_format}) t->release();
@@ -629,6 +655,10 @@ int scs_run_genreads(scs_ctx* c, scs_sink_fn sink, void* user) {
 int scs_set_collectives(scs_ctx* c, scs_allreduce_fn ar, scs_allgatherv_fn ag, void* user) {
     if (!c) return SCS_EINVAL;
     c->allreduce = ar; c->allgatherv = ag; c->coll_user = user; return SCS_OK;
+}
+int scs_set_collectives_device(scs_ctx* c, scs_allreduce_dev_fn ar, scs_allgather_dev_fn ag, void* user) {
+    if (!c) return SCS_EINVAL;
+    c->allreduce_dev = ar; c->allgather_dev = ag; c->coll_dev_user = user; return SCS_OK;
 }
 int scs_get_stats(const scs_ctx* c, scs_stats* out) { if (!c || !out) return SCS_EINVAL; *out = c->st; return SCS_OK; }
 

@@ -17,6 +17,15 @@ import numpy as np
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint64), C.c_uint64)
 ALLGATHERV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64))
+ALLREDUCE_DEV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int)
+ALLGATHER_DEV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64)
+
+
+class _DevArray:
+    """Zero-copy view of raw device memory for torch (CUDA array interface; works on ROCm builds too)."""
+
+    def __init__(self, ptr, n, typestr):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": typestr, "data": (int(ptr), False), "version": 3}
 
 
 class Collectives:
@@ -31,7 +40,50 @@ class Collectives:
         self.rank = dist.get_rank()
         self.allreduce_cb = ALLREDUCE_FN(self._allreduce)
         self.allgatherv_cb = ALLGATHERV_FN(self._allgatherv)
-        self.calls = dict(allreduce=0, allgatherv=0, bytes=0)
+        self.allreduce_dev_cb = ALLREDUCE_DEV_FN(self._allreduce_dev)
+        self.allgather_dev_cb = ALLGATHER_DEV_FN(self._allgather_dev)
+        self.calls = dict(allreduce=0, allgatherv=0, allreduce_dev=0, allgather_dev=0, bytes=0)
+
+    # ---- device-memory hooks: the tensors alias the library's HBM buffers; with the NCCL (= RCCL) backend the
+    # collective runs on torch's current stream (give GenReads that stream), with gloo it is staged through the CPU.
+    def _dev_tensor(self, ptr, n, elem_bytes):
+        return self.torch.as_tensor(_DevArray(ptr, n, "<i8" if elem_bytes == 8 else ("<i4" if elem_bytes == 4 else "|u1")), device="cuda")
+
+    def _allreduce_dev(self, _user, d_vals, n, elem_bytes):
+        try:
+            t = self._dev_tensor(d_vals, n, elem_bytes)          # uint sums as two's-complement ints: same bits
+            if self.dist.get_backend() == "nccl":
+                self.dist.all_reduce(t)
+            else:
+                h = t.cpu()
+                self.dist.all_reduce(h)
+                t.copy_(h)
+                self.torch.cuda.current_stream().synchronize()
+            self.calls["allreduce_dev"] += 1
+            self.calls["bytes"] += int(n) * int(elem_bytes)
+            return 0
+        except Exception as e:
+            print("device allreduce hook failed:", repr(e))
+            return 1
+
+    def _allgather_dev(self, _user, d_send, d_recv, nbytes):
+        try:
+            src = self._dev_tensor(d_send, nbytes, 1)
+            dst = self._dev_tensor(d_recv, int(nbytes) * self.world, 1)
+            if self.dist.get_backend() == "nccl":
+                self.dist.all_gather_into_tensor(dst, src)
+            else:
+                h = src.cpu()
+                outs = [self.torch.empty_like(h) for _ in range(self.world)]
+                self.dist.all_gather(outs, h)
+                dst.copy_(self.torch.cat(outs))
+                self.torch.cuda.current_stream().synchronize()
+            self.calls["allgather_dev"] += 1
+            self.calls["bytes"] += int(nbytes) * self.world
+            return 0
+        except Exception as e:
+            print("device allgather hook failed:", repr(e))
+            return 1
 
     def _allreduce(self, _user, vals, n):
         try:

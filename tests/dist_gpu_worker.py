@@ -7,15 +7,17 @@ sys.path.insert(0, ROOT)
 
 
 def main():
-    fasta, profile, prefix, coverage, layout, seed = sys.argv[1:7]
+    fasta, profile, prefix, coverage, layout, seed, hooks = sys.argv[1:8]
     import torch.distributed as dist
     import scssim_amd
     from scssim_amd.dist import Collectives
     dist.init_process_group("gloo")
+    import torch
+    torch.cuda.set_device(0)
     coll = Collectives(device="cpu")
     g = scssim_amd.GenReads(profile=profile, input_fasta=fasta, coverage=float(coverage), layout=layout, seed=int(seed), device=0,
-                            shard_rank=dist.get_rank(), shard_count=dist.get_world_size())
-    g.set_collectives(coll)
+                            stream=torch.cuda.current_stream().cuda_stream, shard_rank=dist.get_rank(), shard_count=dist.get_world_size())
+    g.set_collectives(coll, device_hooks=(hooks == "device"))
     fq1, fq2 = g.run()
     st = g.stats()
     pre = "%s.r%d" % (prefix, dist.get_rank())

@@ -194,9 +194,10 @@ def test_full_size_properties(models, tmp_path):
     assert g2.run()[0] != fq1
 
 
-@pytest.mark.parametrize("world,case,model,cov,layout", [(2, "g1_hiseq2500_pe", "Illumina_HiSeq2500", "3", "PE"),
-                                                         (3, "g2_xten_pe_nblock", "Illumina_HiSeqXTen", "2", "PE")])
-def test_sharded_gpu_job_equals_whole_job(world, case, model, cov, layout, oracle_bin, models, golden_inputs, tmp_path):
+@pytest.mark.parametrize("world,case,model,cov,layout,hooks", [(2, "g1_hiseq2500_pe", "Illumina_HiSeq2500", "3", "PE", "host"),
+                                                               (2, "g1_hiseq2500_pe", "Illumina_HiSeq2500", "3", "PE", "device"),
+                                                               (3, "g2_xten_pe_nblock", "Illumina_HiSeqXTen", "2", "PE", "device")])
+def test_sharded_gpu_job_equals_whole_job(world, case, model, cov, layout, hooks, oracle_bin, models, golden_inputs, tmp_path):
     """ONE job sharded by fragment lineage over `world` processes (sharing this box's single GPU, collectives over gloo)
     must merge to exactly the unsharded job's FASTQ -- which in turn is the oracle's."""
     import socket
@@ -210,10 +211,37 @@ def test_sharded_gpu_job_equals_whole_job(world, case, model, cov, layout, oracl
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=port, LOCAL_RANK="0")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_gpu_worker.py"), golden_inputs[case], models[model],
-                                       str(tmp_path / "shard"), cov, layout, seed], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+                                       str(tmp_path / "shard"), cov, layout, seed, hooks], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = [p.communicate(timeout=600)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
     for suffix in ("_1.fq", "_2.fq"):
         pools = [open(str(tmp_path / "shard") + ".r%d%s" % (r, suffix), "rb").read() for r in range(world)]
         assert all(len(p) > 0 for p in pools)
         assert merge_fastq(pools) == open(whole + suffix, "rb").read(), "sharded GPU job differs from the whole job (%s)" % suffix
+
+
+def test_device_hooks_over_rccl_single_rank(models, golden_inputs, oracle_bin, tmp_path):
+    """The RCCL code path of the device hooks (torch tensors aliasing the library's HBM buffers, collectives on the
+    shared stream) with a 1-rank NCCL group: a 1-shard "sharded" job must equal the plain job."""
+    import sys
+    code = '''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+import scssim_amd
+from scssim_amd.dist import Collectives
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+coll = Collectives()
+t = torch.arange(8, dtype=torch.int64, device="cuda")
+assert coll._allreduce_dev(None, t.data_ptr(), 8, 8) == 0 and t.tolist() == list(range(8))
+g = scssim_amd.GenReads(profile=%r, input_fasta=%r, coverage=2.0, seed=5, stream=torch.cuda.current_stream().cuda_stream)
+a = g.run()
+dist.destroy_process_group()
+open(%r, "wb").write(a[0])
+''' % (ROOT, models["Illumina_HiSeq2500"], golden_inputs["g1_hiseq2500_pe"], str(tmp_path / "nccl_1.fq"))
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29777", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    prefix = str(tmp_path / "orc")
+    _oracle_run(oracle_bin, golden_inputs["g1_hiseq2500_pe"], models["Illumina_HiSeq2500"], prefix, ["-c", "2"], 5)
+    assert open(str(tmp_path / "nccl_1.fq"), "rb").read() == open(prefix + "_1.fq", "rb").read()
