@@ -31,10 +31,13 @@ class _DevArray:
 class Collectives:
     """ctypes callbacks implementing the scso_* / scs_* collective hooks with torch.distributed."""
 
-    def __init__(self, device=None):
+    def __init__(self, device=None, stream=None):
+        """stream: the torch.cuda.Stream the GenReads ctx runs on (GenReads(stream=stream.cuda_stream)); the device
+        hooks issue their collectives on it so they are ordered with the library's kernels."""
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
+        self.stream = stream
         self.device = device if device is not None else ("cuda" if dist.get_backend() == "nccl" else "cpu")
         self.world = dist.get_world_size()
         self.rank = dist.get_rank()
@@ -49,16 +52,21 @@ class Collectives:
     def _dev_tensor(self, ptr, n, elem_bytes):
         return self.torch.as_tensor(_DevArray(ptr, n, "<i8" if elem_bytes == 8 else ("<i4" if elem_bytes == 4 else "|u1")), device="cuda")
 
+    def _on_stream(self):
+        import contextlib
+        return self.torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()
+
     def _allreduce_dev(self, _user, d_vals, n, elem_bytes):
         try:
-            t = self._dev_tensor(d_vals, n, elem_bytes)          # uint sums as two's-complement ints: same bits
-            if self.dist.get_backend() == "nccl":
-                self.dist.all_reduce(t)
-            else:
-                h = t.cpu()
-                self.dist.all_reduce(h)
-                t.copy_(h)
-                self.torch.cuda.current_stream().synchronize()
+            with self._on_stream():
+                t = self._dev_tensor(d_vals, n, elem_bytes)      # uint sums as two's-complement ints: same bits
+                if self.dist.get_backend() == "nccl":
+                    self.dist.all_reduce(t)
+                else:
+                    h = t.cpu()
+                    self.dist.all_reduce(h)
+                    t.copy_(h)
+                    self.torch.cuda.current_stream().synchronize()
             self.calls["allreduce_dev"] += 1
             self.calls["bytes"] += int(n) * int(elem_bytes)
             return 0
@@ -68,16 +76,17 @@ class Collectives:
 
     def _allgather_dev(self, _user, d_send, d_recv, nbytes):
         try:
-            src = self._dev_tensor(d_send, nbytes, 1)
-            dst = self._dev_tensor(d_recv, int(nbytes) * self.world, 1)
-            if self.dist.get_backend() == "nccl":
-                self.dist.all_gather_into_tensor(dst, src)
-            else:
-                h = src.cpu()
-                outs = [self.torch.empty_like(h) for _ in range(self.world)]
-                self.dist.all_gather(outs, h)
-                dst.copy_(self.torch.cat(outs))
-                self.torch.cuda.current_stream().synchronize()
+            with self._on_stream():
+                src = self._dev_tensor(d_send, nbytes, 1)
+                dst = self._dev_tensor(d_recv, int(nbytes) * self.world, 1)
+                if self.dist.get_backend() == "nccl":
+                    self.dist.all_gather_into_tensor(dst, src)
+                else:
+                    h = src.cpu()
+                    outs = [self.torch.empty_like(h) for _ in range(self.world)]
+                    self.dist.all_gather(outs, h)
+                    dst.copy_(self.torch.cat(outs))
+                    self.torch.cuda.current_stream().synchronize()
             self.calls["allgather_dev"] += 1
             self.calls["bytes"] += int(nbytes) * self.world
             return 0

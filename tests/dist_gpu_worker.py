@@ -14,9 +14,10 @@ def main():
     dist.init_process_group("gloo")
     import torch
     torch.cuda.set_device(0)
-    coll = Collectives(device="cpu")
+    stream = torch.cuda.Stream()
+    coll = Collectives(device="cpu", stream=stream)
     g = scssim_amd.GenReads(profile=profile, input_fasta=fasta, coverage=float(coverage), layout=layout, seed=int(seed), device=0,
-                            stream=torch.cuda.current_stream().cuda_stream, shard_rank=dist.get_rank(), shard_count=dist.get_world_size())
+                            stream=stream.cuda_stream, shard_rank=dist.get_rank(), shard_count=dist.get_world_size())
     g.set_collectives(coll, device_hooks=(hooks == "device"))
     fq1, fq2 = g.run()
     st = g.stats()

@@ -231,10 +231,15 @@ import scssim_amd
 from scssim_amd.dist import Collectives
 torch.cuda.set_device(0)
 dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
-coll = Collectives()
+stream = torch.cuda.Stream()
+coll = Collectives(stream=stream)
 t = torch.arange(8, dtype=torch.int64, device="cuda")
-assert coll._allreduce_dev(None, t.data_ptr(), 8, 8) == 0 and t.tolist() == list(range(8))
-g = scssim_amd.GenReads(profile=%r, input_fasta=%r, coverage=2.0, seed=5, stream=torch.cuda.current_stream().cuda_stream)
+torch.cuda.synchronize()
+assert coll._allreduce_dev(None, t.data_ptr(), 8, 8) == 0
+torch.cuda.synchronize()
+assert t.tolist() == list(range(8))
+g = scssim_amd.GenReads(profile=%r, input_fasta=%r, coverage=2.0, seed=5, stream=stream.cuda_stream, shard_rank=0, shard_count=1)
+g.set_collectives(coll, device_hooks=True)
 a = g.run()
 dist.destroy_process_group()
 open(%r, "wb").write(a[0])
