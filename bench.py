@@ -29,10 +29,11 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def make_inputs(td, rank):
+def make_inputs(td, rank, n_records=1):
+    """n_records x 1 Mb records (weak scaling: one record's worth of fragments per rank); every rank builds the same file."""
     fa = os.path.join(td, "simu_%d.fa" % rank)
-    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "make_genome.py"), "--lengths", "1000000",
-                           "--seed", str(1 + rank), "--first-chr", str(20 + rank), "--simu-out", fa])
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "make_genome.py"), "--lengths", ",".join(["1000000"] * n_records),
+                           "--seed", "1", "--first-chr", "20", "--simu-out", fa])
     src = os.path.join(td, "hiseq2500_%d.profile" % rank)
     open(src, "wb").write(gzip.open(os.path.join(ROOT, "tests", "golden", "models", "Illumina_HiSeq2500.profile.gz")).read())
     prof = os.path.join(td, "pe150_%d.profile" % rank)
@@ -94,6 +95,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-hooks", action="store_true", help="install the collective hooks even at N=1 (measures their cost)")
     a = ap.parse_args()
 
     import torch
@@ -113,8 +115,21 @@ def main():
     dev = torch.device("cuda", local)
 
     td = tempfile.mkdtemp(prefix="scsbench_")
-    fa, prof = make_inputs(td, rank)
-    g = scssim_amd.GenReads(profile=prof, input_fasta=fa, coverage=30.0, isize=260, layout="PE", seed=1, device=local)
+    fa, prof = make_inputs(td, rank, world)
+    # N > 1: ONE job (world x 1 Mb genome) sharded by fragment lineage; the setPrimers totals, the primer stock and the
+    # weight normalisation are exchanged through RCCL (scssim_amd/dist.py hooks on the ctx stream); FASTQ is identical to
+    # the 1-GPU run of the same genome.
+    stream = torch.cuda.Stream()
+    g = scssim_amd.GenReads(profile=prof, input_fasta=fa, coverage=30.0, isize=260, layout="PE", seed=1, device=local,
+                            stream=stream.cuda_stream, shard_rank=rank, shard_count=world)
+    if world > 1 or a.force_hooks:
+        from scssim_amd.dist import Collectives
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        coll = Collectives(stream=stream)
+        g.set_collectives(coll, device_hooks=True)
     cap = 96 << 20
     pool1 = torch.empty(cap, dtype=torch.uint8, device=dev)
     pool2 = torch.empty(cap, dtype=torch.uint8, device=dev)
@@ -199,7 +214,8 @@ def main():
             "dtype": "u8/u32 (integer draws, byte sequences; fp64 only in the GC-weight draw)", "data": "synthetic",
             "config": {"workload": "configs[1]: 1 Mb synthetic reference (diploid simuvars FASTA), PE150 30x, HiSeq2500 model resampled to 150 bins, -p 100000 -r 1e-9 -s 260",
                        "pairs_per_step_per_gpu": last["pairs_written"], "full_amplicons_per_step": last["full_amplicons"],
-                       "semi_amplicons_per_step": last["semi_amplicons"], "sharding": "one 1 Mb record per rank; read pool gathered on rank 0 over RCCL" if world > 1 else "single GPU"},
+                       "semi_amplicons_per_step": last["semi_amplicons"], "sharding": ("one job over %d GPUs: %d x 1 Mb records sharded by fragment lineage, RCCL all-reduce of primer stock / setPrimers totals, "
+                                    "all-gather of GC weights, read pool gathered on rank 0" % (world, world)) if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes": note,
                          "algorithmic_bytes_per_launch": alg / max(1, kd["launches"]), "avg_launch_ms": kd["ms"] / max(1, kd["launches"])},

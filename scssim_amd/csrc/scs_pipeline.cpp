@@ -118,7 +118,8 @@ struct scs_ctx {
     struct Seg { int c, p; uint32_t count; }; std::vector<Seg> full_segs;   // local fulls list = these, in order
     DevBuf d_gidx, d_gw, d_grn; bool have_gidx = false;
     int pending_seg_cycle = -1;
-    bool sharded() const { return cfg.shard_count > 1; }
+    // collectives run when the job is sharded -- or whenever hooks are installed (1-shard jobs then exercise them too)
+    bool sharded() const { return cfg.shard_count > 1 || allreduce || allreduce_dev; }
     void reduce(uint64_t* v, uint64_t n) {
         if (!sharded()) return;
         if (!allreduce || allreduce(coll_user, v, n)) throw ScsError(SCS_EINVAL, "sharded job: all-reduce hook missing or failed (scs_set_collectives)");
