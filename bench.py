@@ -131,36 +131,44 @@ def main():
         coll = Collectives(stream=stream)
         g.set_collectives(coll, device_hooks=True)
     cap = 96 << 20
-    pool1 = torch.empty(cap, dtype=torch.uint8, device=dev)
-    pool2 = torch.empty(cap, dtype=torch.uint8, device=dev)
+    # FASTQ pools are double-buffered so the gather of step i (RCCL point-to-point on its own stream) overlaps the
+    # compute of step i+1; every transfer completes inside the timed region (final synchronize + barrier).
+    pools = [[torch.empty(cap, dtype=torch.uint8, device=dev) for _ in range(2)] for _ in range(2)]
     gathered = [torch.empty(cap, dtype=torch.uint8, device=dev) for _ in range(2 * (world - 1))] if (world > 1 and rank == 0) else []
+    inflight = [[], []]
     ktimes = {}
 
     def step(i, record):
+        b = i & 1
+        with torch.cuda.stream(stream):
+            for w in inflight[b]:                       # the ctx stream waits until this buffer's previous gather is done
+                w.wait()
+        inflight[b] = []
         g.set_seed(1000 + i)
         g.create_frags()
         g.amplify()
         if record:
             acc(g.kernel_times(), ("k_errs<semi->full>", "k_errs<frag->semi>", "k_attach"))
         g.allocate_reads(0)
+        pool1, pool2 = pools[b]
         n1, n2, pairs = g.yield_reads_device(pool1.data_ptr(), cap, pool2.data_ptr(), cap)
         if record:
             acc(g.kernel_times(), ("k_reads", "k_format"))
         if world > 1:                                   # read pool -> writer rank (RCCL point-to-point over xGMI)
-            sizes = torch.tensor([n1, n2], dtype=torch.int64, device=dev)
-            allsz = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in range(world)]
-            dist.all_gather(allsz, sizes)
-            ops = []
-            if rank == 0:
-                for r in range(1, world):
-                    s1, s2 = int(allsz[r][0]), int(allsz[r][1])
-                    ops.append(dist.P2POp(dist.irecv, gathered[2 * (r - 1)][:s1], r))
-                    ops.append(dist.P2POp(dist.irecv, gathered[2 * (r - 1) + 1][:s2], r))
-            else:
-                ops.append(dist.P2POp(dist.isend, pool1[:n1], 0))
-                ops.append(dist.P2POp(dist.isend, pool2[:n2], 0))
-            for w in dist.batch_isend_irecv(ops):
-                w.wait()
+            with torch.cuda.stream(stream):
+                sizes = torch.tensor([n1, n2], dtype=torch.int64, device=dev)
+                allsz = torch.zeros(2 * world, dtype=torch.int64, device=dev)
+                dist.all_gather_into_tensor(allsz, sizes)
+                ops = []
+                if rank == 0:
+                    hs = allsz.cpu().tolist()
+                    for r in range(1, world):
+                        ops.append(dist.P2POp(dist.irecv, gathered[2 * (r - 1)][:hs[2 * r]], r))
+                        ops.append(dist.P2POp(dist.irecv, gathered[2 * (r - 1) + 1][:hs[2 * r + 1]], r))
+                else:
+                    ops.append(dist.P2POp(dist.isend, pool1[:n1], 0))
+                    ops.append(dist.P2POp(dist.isend, pool2[:n2], 0))
+                inflight[b] = dist.batch_isend_irecv(ops)
         return pairs, g.stats()
 
     def acc(kt, names):
@@ -181,6 +189,9 @@ def main():
         pairs_total += p
         fq_bytes += sum(last["fastq_bytes"])
         alg_bytes += last["algorithmic_bytes"]
+    for q in inflight:
+        for w in q:
+            w.wait()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

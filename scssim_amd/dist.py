@@ -46,11 +46,19 @@ class Collectives:
         self.allreduce_dev_cb = ALLREDUCE_DEV_FN(self._allreduce_dev)
         self.allgather_dev_cb = ALLGATHER_DEV_FN(self._allgather_dev)
         self.calls = dict(allreduce=0, allgatherv=0, allreduce_dev=0, allgather_dev=0, bytes=0)
+        self._views = {}
 
     # ---- device-memory hooks: the tensors alias the library's HBM buffers; with the NCCL (= RCCL) backend the
     # collective runs on torch's current stream (give GenReads that stream), with gloo it is staged through the CPU.
     def _dev_tensor(self, ptr, n, elem_bytes):
-        return self.torch.as_tensor(_DevArray(ptr, n, "<i8" if elem_bytes == 8 else ("<i4" if elem_bytes == 4 else "|u1")), device="cuda")
+        key = (int(ptr), int(n), int(elem_bytes))
+        t = self._views.get(key)
+        if t is None:                                            # the library reuses its buffers: cache the aliasing views
+            t = self.torch.as_tensor(_DevArray(ptr, n, "<i8" if elem_bytes == 8 else ("<i4" if elem_bytes == 4 else "|u1")), device="cuda")
+            if len(self._views) > 64:
+                self._views.clear()
+            self._views[key] = t
+        return t
 
     def _on_stream(self):
         import contextlib
