@@ -250,3 +250,20 @@ open(%r, "wb").write(a[0])
     prefix = str(tmp_path / "orc")
     _oracle_run(oracle_bin, golden_inputs["g1_hiseq2500_pe"], models["Illumina_HiSeq2500"], prefix, ["-c", "2"], 5)
     assert open(str(tmp_path / "nccl_1.fq"), "rb").read() == open(prefix + "_1.fq", "rb").read()
+
+
+def test_medium_genome_bit_exact(oracle_bin, models, tmp_path):
+    """12 Mb, two records, 4x: thousands of allocation chunks, hundreds of fragments, the >4-errors overflow pool,
+    multi-digit record names -- FASTQ still byte-identical to the oracle."""
+    fa = str(tmp_path / "simu.fa")
+    subprocess.check_call(["python3", os.path.join(ROOT, "tools", "make_genome.py"), "--lengths", "7000000,5000000", "--seed", "31", "--n-block", "20000", "--simu-out", fa])
+    prefix = str(tmp_path / "orc")
+    _oracle_run(oracle_bin, fa, models["Illumina_HiSeqXTen"], prefix, ["-c", "4"], 8, threads=min(32, os.cpu_count() or 1))
+    g = scssim_amd.GenReads(profile=models["Illumina_HiSeqXTen"], input_fasta=fa, coverage=4.0, seed=8)
+    fq1, fq2 = g.run()
+    st = g.stats()
+    assert st["full_amplicons"] > 4000000
+    a = g.download_amplicons(1)
+    assert (a["nerr"] > 4).sum() > 100, "overflow pool not exercised"
+    assert fq1 == open(prefix + "_1.fq", "rb").read()
+    assert fq2 == open(prefix + "_2.fq", "rb").read()
