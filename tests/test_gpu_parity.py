@@ -267,3 +267,27 @@ def test_medium_genome_bit_exact(oracle_bin, models, tmp_path):
     assert (a["nerr"] > 4).sum() > 100, "overflow pool not exercised"
     assert fq1 == open(prefix + "_1.fq", "rb").read()
     assert fq2 == open(prefix + "_2.fq", "rb").read()
+
+
+def test_pe250_and_unequal_haplotypes(oracle_bin, models, tmp_path):
+    """BASELINE config 5 shape in miniature: a synthesised 250 bp profile (4 lane chunks per read, -s 500) on a
+    'CNV-edited' input whose two haplotype records have different lengths (simuvars output after copy-number changes:
+    names keep the reference length, Genome.cpp:368; the read budget uses that name field, Malbac.cpp:413-420)."""
+    rng = np.random.default_rng(9)
+    hap1 = "".join(rng.choice(list("ACGT"), size=150000, p=[0.3, 0.2, 0.2, 0.3]))
+    hap2 = hap1[:40000] + hap1[40000:70000] * 3 + hap1[90000:]            # a 3-copy gain and a loss
+    fa = str(tmp_path / "cnv.fa")
+    with open(fa, "w") as f:
+        for name, s in (("7_1_150000", hap1), ("7_2_150000", hap2)):
+            f.write(">%s\n" % name)
+            f.write("\n".join(s[i:i + 100] for i in range(0, len(s), 100)) + "\n")
+    prof = str(tmp_path / "pe250.profile")
+    subprocess.check_call(["python3", os.path.join(ROOT, "tools", "make_profile.py"), models["Illumina_HiSeqXTen"], prof, "--read-length", "250"])
+    prefix = str(tmp_path / "orc")
+    _oracle_run(oracle_bin, fa, prof, prefix, ["-c", "6", "-s", "500"], 21)
+    g = scssim_amd.GenReads(profile=prof, input_fasta=fa, coverage=6.0, isize=500, seed=21)
+    assert g.read_length == 250
+    fq1, fq2 = g.run()
+    assert g.stats()["reads_requested"] == 150000 * 6 // 250
+    assert fq1 == open(prefix + "_1.fq", "rb").read()
+    assert fq2 == open(prefix + "_2.fq", "rb").read()
