@@ -642,9 +642,13 @@ __global__ void __launch_bounds__(64) k_poisson_frags(DevFrags fr, PoissonParams
         const uint32_t n = c * WAVE + lane;
         const U4 d = draw4(p.key, ST_POISSON, aux, tuid, n >> 2);
         const double lg = det_log((double)d.w[n & 3] / 4294967296.0);
+        const int lo = __double2loint(lg), hi = __double2hiint(lg);
+#pragma unroll
         for (int l = 0; l < WAVE; ++l) {                       // log1 += log(u) in draw order: same rounding as the serial loop
-            log1 += __shfl(lg, l); ++x;
-            if (!(log1 >= log2)) { more = false; break; }
+            if (more) {                                        // wave-uniform
+                log1 += __hiloint2double(__builtin_amdgcn_readlane(hi, l), __builtin_amdgcn_readlane(lo, l)); ++x;
+                if (!(log1 >= log2)) more = false;
+            }
         }
     }
     if (lane == 0) { budget_f[t] = (uint32_t)(int)x; atomicAdd(&sums[0], (unsigned long long)x); }
@@ -765,10 +769,19 @@ __global__ void __launch_bounds__(64) k_alloc_chunk_sum(const double* __restrict
     __builtin_amdgcn_wave_barrier();
     if (threadIdx.x == 0) { double s = 0; for (uint32_t i = 0; i < n; ++i) s += s_w[i]; part[c] = s; }
 }
-__global__ void k_alloc_total(const double* __restrict__ part, uint32_t nch, AllocState* __restrict__ st) {
-    if (blockIdx.x || threadIdx.x) return;
-    double t = 0; for (uint32_t c = 0; c < nch; ++c) t += part[c];                       // [REMAP] partials in order
-    st->total = t; st->sum_rn = 0; st->sum_quota = 0;
+// serial sums over the chunk partials (order matters for the rounding): tiles staged coalesced into LDS, lane 0 adds
+#define SERIAL_TILE 2048
+__global__ void __launch_bounds__(256) k_alloc_total(const double* __restrict__ part, uint32_t nch, AllocState* __restrict__ st) {
+    __shared__ double s_v[SERIAL_TILE];
+    double t = 0;
+    for (uint32_t b = 0; b < nch; b += SERIAL_TILE) {
+        const uint32_t n = min(nch - b, (uint32_t)SERIAL_TILE);
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) s_v[i] = part[b + i];
+        __syncthreads();
+        if (threadIdx.x == 0) for (uint32_t i = 0; i < n; ++i) t += s_v[i];                // [REMAP] partials in order
+    }
+    if (threadIdx.x == 0) { st->total = t; st->sum_rn = 0; st->sum_quota = 0; }
 }
 __global__ void __launch_bounds__(256) k_alloc_floor(double* __restrict__ w, uint32_t ac, unsigned long long reads, AllocState* __restrict__ st,
                                                      uint32_t* __restrict__ rn) {
@@ -804,9 +817,18 @@ __global__ void __launch_bounds__(64) k_alloc_quota(double* __restrict__ w, uint
     __builtin_amdgcn_wave_barrier();
     for (uint32_t i = threadIdx.x; i < n; i += WAVE) w[b + i] = s_w[i];
 }
-__global__ void k_alloc_top_prefix(const double* __restrict__ tp, uint32_t nch, double* __restrict__ probs) {
-    if (blockIdx.x || threadIdx.x) return;
-    double run = 0; for (uint32_t c = 0; c < nch; ++c) { run = c ? run + tp[c] : tp[0]; probs[c] = run; }
+__global__ void __launch_bounds__(256) k_alloc_top_prefix(const double* __restrict__ tp, uint32_t nch, double* __restrict__ probs) {
+    __shared__ double s_v[SERIAL_TILE];
+    double run = 0;
+    for (uint32_t b = 0; b < nch; b += SERIAL_TILE) {
+        const uint32_t n = min(nch - b, (uint32_t)SERIAL_TILE);
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) s_v[i] = tp[b + i];
+        __syncthreads();
+        if (threadIdx.x == 0) for (uint32_t i = 0; i < n; ++i) { run = (b + i) ? run + s_v[i] : s_v[0]; s_v[i] = run; }
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) probs[b + i] = s_v[i];
+    }
 }
 __device__ __forceinline__ uint32_t first_le(const double* __restrict__ cdf, uint32_t n, double r) {
     uint32_t lo = 0, hi = n;
@@ -841,6 +863,17 @@ __global__ void k_alloc_parity(uint32_t* __restrict__ rn, const uint32_t* __rest
 }
 
 struct Widen { __host__ __device__ uint64_t operator()(uint32_t v) const { return (uint64_t)v; } };
+// mailbox: collects scattered device scalars into one contiguous block so the host reads them with ONE copy
+struct MailSrc { const void* p[12]; int w[12]; int dst[12]; int n; };
+__global__ void k_mail(MailSrc m, unsigned long long* __restrict__ mail) {
+    const int i = threadIdx.x;
+    if (i < m.n) mail[m.dst[i]] = m.w[i] == 8 ? *reinterpret_cast<const unsigned long long*>(m.p[i]) : (unsigned long long)*reinterpret_cast<const uint32_t*>(m.p[i]);
+}
+void launch_mail(hipStream_t s, const void* const* srcs, const int* widths, const int* dsts, int n, unsigned long long* mail) {
+    MailSrc m; m.n = n;
+    for (int i = 0; i < 12; ++i) { m.p[i] = i < n ? srcs[i] : nullptr; m.w[i] = i < n ? widths[i] : 4; m.dst[i] = i < n ? dsts[i] : 0; }
+    hipLaunchKernelGGL(k_mail, dim3(1), dim3(64), 0, s, m, mail);
+}
 struct OddBit { __host__ __device__ uint32_t operator()(uint32_t v) const { return v & 1u; } };
 struct HalfUp { __host__ __device__ uint32_t operator()(uint32_t v) const { return (v + 1u) >> 1; } };
 
@@ -867,10 +900,10 @@ void launch_alloc(hipStream_t s, double* w, uint32_t ac, unsigned long long read
     if (ac == 0) return;
     const uint32_t nch = (ac + ALLOC_CHUNK - 1) / ALLOC_CHUNK;
     hipLaunchKernelGGL(k_alloc_chunk_sum, dim3(nch), dim3(64), 0, s, w, ac, part);
-    hipLaunchKernelGGL(k_alloc_total, dim3(1), dim3(64), 0, s, part, nch, st);
+    hipLaunchKernelGGL(k_alloc_total, dim3(1), dim3(256), 0, s, part, nch, st);
     hipLaunchKernelGGL(k_alloc_floor, dim3(cdiv(ac, 256)), dim3(256), 0, s, w, ac, reads, st, rn);
     hipLaunchKernelGGL(k_alloc_quota, dim3(nch), dim3(64), 0, s, w, ac, reads, st, tp, quota);
-    hipLaunchKernelGGL(k_alloc_top_prefix, dim3(1), dim3(64), 0, s, tp, nch, probs);
+    hipLaunchKernelGGL(k_alloc_top_prefix, dim3(1), dim3(256), 0, s, tp, nch, probs);
     hipLaunchKernelGGL(k_alloc_top_draws, dim3(cdiv((uint64_t)nch + 1024, 256)), dim3(256), 0, s, probs, nch, reads, st, key, quota);
     hipLaunchKernelGGL(k_alloc_sample, dim3(nch), dim3(256), 0, s, w, ac, quota, key, rn);
     if (paired) {

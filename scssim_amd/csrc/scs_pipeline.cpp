@@ -113,7 +113,7 @@ struct scs_ctx {
     // sharded single job: collectives supplied by the caller + segment bookkeeping of the local amplicon lists
     scs_allreduce_fn allreduce = nullptr; scs_allgatherv_fn allgatherv = nullptr; void* coll_user = nullptr;
     scs_allreduce_dev_fn allreduce_dev = nullptr; scs_allgather_dev_fn allgather_dev = nullptr; void* coll_dev_user = nullptr;
-    DevBuf d_tot, d_stage, d_all;
+    DevBuf d_tot, d_stage, d_all, d_mail;
     std::vector<uint32_t> semi_block_end;                  // local semi count after each fragment pass
     struct Seg { int c, p; uint32_t count; }; std::vector<Seg> full_segs;   // local fulls list = these, in order
     DevBuf d_gidx, d_gw, d_grn; bool have_gidx = false;
@@ -266,10 +266,12 @@ void set_primers(scs_ctx* c, bool only_frags, uint32_t call) {
     if (ns) exclusive_scan_u32(s, c->budget_s.as<uint32_t>(), c->slot_off_s.as<uint32_t>(), ns, c->scan_tmp.p, c->scan_tmp.cap);
     c->reduce_dev(c->dsums.p, 2, 8);                                               // sharded: budgets of all shards leave the pool
     uint64_t* rb = c->h_rb;
-    HIP_OK(hipMemcpyAsync(rb, c->dsums.p, 16, hipMemcpyDeviceToHost, s));
-    rb[2] = rb[3] = 0;
-    HIP_OK(hipMemcpyAsync(&rb[2], c->slot_off_f.as<uint32_t>() + nf, 4, hipMemcpyDeviceToHost, s));
-    if (ns) HIP_OK(hipMemcpyAsync(&rb[3], c->slot_off_s.as<uint32_t>() + ns, 4, hipMemcpyDeviceToHost, s));
+    {
+        const void* src[4] = {c->dsums.p, c->dsums.as<unsigned long long>() + 1, c->slot_off_f.as<uint32_t>() + nf, ns ? (const void*)(c->slot_off_s.as<uint32_t>() + ns) : c->dsums.as<unsigned long long>() + 7};
+        const int wd[4] = {8, 8, 4, ns ? 4 : 8}, dst[4] = {0, 1, 2, 3};
+        launch_mail(s, src, wd, dst, 4, c->d_mail.as<unsigned long long>());
+        HIP_OK(hipMemcpyAsync(rb, c->d_mail.p, 32, hipMemcpyDeviceToHost, s));
+    }
     HIP_OK(hipStreamSynchronize(s));
     c->total_primers -= rb[0] + rb[1];
     c->slots_f = (uint32_t)rb[2]; c->slots_s = (uint32_t)rb[3]; c->budget_ns = ns;
@@ -281,10 +283,10 @@ void launch_pass(scs_ctx* c, bool from_frag, uint32_t pass, int rb_slot) {
     hipStream_t s = c->stream;
     const uint32_t nt = from_frag ? (uint32_t)c->f_len.size() : c->budget_ns;
     const uint32_t n_slots = from_frag ? c->slots_f : c->slots_s;
-    c->h_rb[rb_slot] = 0;
     if (nt == 0 || n_slots == 0) {                                                 // nothing local; a shard still joins the pass's collective
         if (c->sharded()) { c->reduce_dev(c->primer_delta.p, 65536, 4); launch_primer_update(s, c->primer_cnt.as<int64_t>(), c->primer_delta.as<uint32_t>()); }
-        if (!from_frag) { for (size_t b = 0; b < 8; ++b) c->h_rb[16 + b] = 0; c->pending_seg_cycle = (int)pass; }
+        HIP_OK(hipMemsetAsync(c->d_mail.as<unsigned long long>() + rb_slot, 0, 8, s));
+        if (!from_frag) { HIP_OK(hipMemsetAsync(c->d_mail.as<unsigned long long>() + 16, 0, 64, s)); c->pending_seg_cycle = (int)pass; }
         return;
     }
     const uint32_t* slot_off = (from_frag ? c->slot_off_f : c->slot_off_s).as<uint32_t>();
@@ -316,19 +318,25 @@ void launch_pass(scs_ctx* c, bool from_frag, uint32_t pass, int rb_slot) {
     tm.end(s);
     c->reduce_dev(c->primer_delta.p, 65536, 4);                                    // sharded: stock decrements of all shards
     launch_primer_update(s, c->primer_cnt.as<int64_t>(), c->primer_delta.as<uint32_t>());
-    HIP_OK(hipMemcpyAsync(&c->h_rb[rb_slot], c->valid_off.as<uint32_t>() + nt, 4, hipMemcpyDeviceToHost, s));
-    if (!from_frag) {                                                             // fulls made from the semis of each fragment pass (segments)
-        for (size_t b = 0; b < c->semi_block_end.size() && b < 8; ++b) {
-            c->h_rb[16 + b] = 0;
-            HIP_OK(hipMemcpyAsync(&c->h_rb[16 + b], c->valid_off.as<uint32_t>() + std::min(c->semi_block_end[b], nt), 4, hipMemcpyDeviceToHost, s));
+    {   // counts of this pass -> mailbox (read by the host at the group's sync): new amplicons, and for a semi pass the
+        // fulls made from the semis of each fragment pass (segments)
+        const void* src[12]; int wd[12], dst[12]; int n = 0;
+        src[n] = c->valid_off.as<uint32_t>() + nt; wd[n] = 4; dst[n] = rb_slot; ++n;
+        if (!from_frag) {
+            for (size_t b = 0; b < c->semi_block_end.size() && b < 8; ++b) { src[n] = c->valid_off.as<uint32_t>() + std::min(c->semi_block_end[b], nt); wd[n] = 4; dst[n] = 16 + (int)b; ++n; }
+            c->pending_seg_cycle = (int)pass;
         }
-        c->pending_seg_cycle = (int)pass;
+        launch_mail(s, src, wd, dst, n, c->d_mail.as<unsigned long long>());
     }
 }
 // host sync closing a group of passes: counts of new amplicons, total length of the semis
 void collect_passes(scs_ctx* c, int rb_fulls, int rb_semis) {
     hipStream_t s = c->stream;
-    HIP_OK(hipMemcpyAsync(&c->h_rb[8], c->dsums.as<unsigned long long>() + 4, 8, hipMemcpyDeviceToHost, s));
+    {
+        const void* src[1] = {c->dsums.as<unsigned long long>() + 4}; const int wd[1] = {8}, dst[1] = {8};
+        launch_mail(s, src, wd, dst, 1, c->d_mail.as<unsigned long long>());
+    }
+    HIP_OK(hipMemcpyAsync(c->h_rb, c->d_mail.p, 256, hipMemcpyDeviceToHost, s));
     HIP_OK(hipStreamSynchronize(s));
     if (rb_fulls >= 0) {
         c->fulls.n += (uint32_t)c->h_rb[rb_fulls]; c->tm_errscan.units += c->h_rb[rb_fulls];
@@ -585,7 +593,7 @@ int scs_create(const scs_config* cfg, scs_ctx** out) {
         c->key = RngKey{(uint32_t)cfg->seed, (uint32_t)(cfg->seed >> 32)};
         c->flags.reserve(256, c->stream); HIP_OK(hipMemsetAsync(c->flags.p, 0, 256, c->stream));
         c->dsums.reserve(256, c->stream); HIP_OK(hipMemsetAsync(c->dsums.p, 0, 256, c->stream));
-        c->d_tot.reserve(256, c->stream);
+        c->d_tot.reserve(256, c->stream); c->d_mail.reserve(256, c->stream); HIP_OK(hipMemsetAsync(c->d_mail.p, 0, 256, c->stream));
         HIP_OK(hipHostMalloc((void**)&c->h_rb, 256, hipHostMallocDefault)); memset(c->h_rb, 0, 256);
         HIP_OK(hipStreamSynchronize(c->stream));
     } catch (const std::exception& e) { g_create_error = e.what(); delete c; return SCS_EDEVICE; }
@@ -599,7 +607,7 @@ void scs_destroy(scs_ctx* c) {
     for (DevBuf* b : {&c->t_guide, &c->t_subs1, &c->t_subs2, &c->t_qual, &c->t_ins, &c->t_del, &c->t_isize, &c->d_subs1, &c->d_subs2, &c->d_qual, &c->d_ins, &c->d_del,
                       &c->d_isize, &c->d_gcmeans, &c->genome, &c->gx_gc_bits, &c->gx_n_bits, &c->gx_gc_cnt, &c->gx_n_cnt, &c->gx_gc_pref, &c->gx_n_pref, &c->d_binom, &c->df_goff, &c->df_len, &c->df_strand, &c->df_primers, &c->primer_cnt, &c->primer_delta,
                       &c->slots, &c->slot_tmpl, &c->valid, &c->valid_off, &c->scan_tmp, &c->flags, &c->weights, &c->read_numbers,
-                      &c->pair_off, &c->pairs, &c->odd_before, &c->a_part, &c->a_tp, &c->a_probs, &c->a_quota, &c->a_poff, &c->d_gidx, &c->d_gw, &c->d_grn, &c->d_tot, &c->d_stage, &c->d_all, &c->budget_f, &c->budget_s, &c->slot_off_f,
+                      &c->pair_off, &c->pairs, &c->odd_before, &c->a_part, &c->a_tp, &c->a_probs, &c->a_quota, &c->a_poff, &c->d_gidx, &c->d_gw, &c->d_grn, &c->d_tot, &c->d_stage, &c->d_all, &c->d_mail, &c->budget_f, &c->budget_s, &c->slot_off_f,
                       &c->slot_off_s, &c->dsums, &c->slot_b, &c->slot_q, &c->lens, &c->sizes1, &c->sizes2, &c->off1, &c->off2, &c->out1, &c->out2}) b->release();
     c->semis.release(); c->fulls.release();
     for (KernelTimer* t : {&c->tm_errscan, &c->tm_errscan_f, &c->tm_reads, &c->tm_attach, &c->tm_format}) t->release();
