@@ -216,7 +216,7 @@ class GenReads:
                 parts1.append(C.string_at(p1, n1) if n1 else b"")
                 parts2.append(C.string_at(p2, n2) if n2 else b"")
             return 0
-        cb = _SINK(sink) if collect else None      # None = NULL sink: generate on the device and count only
+        cb = _SINK(sink) if collect else _SINK()   # NULL sink: generate on the device and count only
         self._ck(self._L.scs_yield_reads(self._ctx, cb, None))
         return b"".join(parts1), b"".join(parts2)
 
