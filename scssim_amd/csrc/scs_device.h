@@ -107,10 +107,10 @@ void launch_plan_pairs(hipStream_t s, DevFrags fr, DevAmps semis, DevAmps fulls,
 void launch_pair_offsets(hipStream_t s, const uint32_t* rn, uint32_t ac, int paired, uint32_t* pair_cnt_off, void* temp, size_t temp_bytes);
 // reads of pairs [p0, p0+np): slot layout [2*np][slot] bases / quals (SE: [np][slot])
 void launch_reads(hipStream_t s, const uint8_t* g, DevErrPool spool, DevErrPool fpool,
-                  const PairRec* pairs, uint32_t np, uint32_t amp_index_base, DevTables tb, RngKey key, int paired, uint32_t slot,
+                  const PairRec* pairs, uint32_t np, uint32_t amp_index_base, DevTables tb, const DevTables* d_tb, RngKey key, int paired, uint32_t slot,
                   char* slot_b, char* slot_q, uint32_t* lens, uint32_t* sizes1, uint32_t* sizes2, uint32_t* flags);
 void launch_predict_windows(hipStream_t s, const uint8_t* windows, uint32_t n_reads, const uint64_t* uids, const uint32_t* atts,
-                            const uint8_t* is_read1, DevTables tb, RngKey key, uint32_t slot, char* slot_b, char* slot_q,
+                            const uint8_t* is_read1, DevTables tb, const DevTables* d_tb, RngKey key, uint32_t slot, char* slot_b, char* slot_q,
                             uint32_t* lens, uint32_t* flags);
 void launch_format(hipStream_t s, const PairRec* pairs, uint32_t np, uint32_t amp_index_base, int paired, uint32_t slot,
                    const char* slot_b, const char* slot_q, const uint32_t* lens, const uint64_t* off1, const uint64_t* off2,

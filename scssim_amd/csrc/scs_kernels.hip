@@ -316,11 +316,11 @@ __global__ void k_plan_pairs(DevFrags fr, DevAmps semis, DevAmps fulls, uint32_t
 //     prefix sum gives the output offsets, then k-mer-conditioned substitution + quality per
 //     output base.  MAXCH chunks of 64 lanes cover reads up to 256 bases.
 // ------------------------------------------------------------------------------------------------
-#define MAXCH 4
 #define SRC_CAP 512
 
 struct ReadJob { uint64_t uid; uint32_t att; uint32_t rd; };   // rd: 0 = read 1, 1 = read 2
 
+template <int MAXCH>
 __device__ __forceinline__ void predict_wave(const uint8_t* s_win, uint8_t* s_src, const uint8_t* s_guide, int lane, ReadJob job, const DevTables& tb, RngKey key,
                                              uint32_t slot, char* __restrict__ out_b, char* __restrict__ out_q,
                                              uint32_t* __restrict__ out_len, uint32_t* __restrict__ flags) {
@@ -466,12 +466,14 @@ __device__ __forceinline__ uint32_t dec_digits(uint32_t v) {
 // materialised) + predict.  512-thread workgroups: the quality guide table is staged into LDS once per
 // workgroup, each wave then walks reads with a grid stride.
 #define READS_WAVES 8
+template <int MAXCH>
 __global__ void __launch_bounds__(64 * READS_WAVES) k_reads(const uint8_t* __restrict__ g, DevErrPool spool, DevErrPool fpool,
                                                const PairRec* __restrict__ pairs, uint32_t np, uint32_t amp_index_base,
-                                               DevTables tb, RngKey key, int paired, uint32_t slot, char* __restrict__ slot_b,
+                                               const DevTables* __restrict__ tbp, RngKey key, int paired, uint32_t slot, char* __restrict__ slot_b,
                                                char* __restrict__ slot_q, uint32_t* __restrict__ lens, uint32_t* __restrict__ sizes1,
                                                uint32_t* __restrict__ sizes2, uint32_t* __restrict__ flags) {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
+    const DevTables& tb = *tbp;                                            // tables live in device memory: fields are fetched when used
     uint8_t* s_guide = s_dyn;                                              // [16*bins][17]
     const uint32_t guide_bytes = (uint32_t)(16 * tb.bins * 17), guide_pad = (guide_bytes + 15u) & ~15u;
     uint8_t* s_win_all = s_dyn + guide_pad;                                // [READS_WAVES][256]
@@ -501,7 +503,7 @@ __global__ void __launch_bounds__(64 * READS_WAVES) k_reads(const uint8_t* __res
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         ReadJob job; job.uid = pr.uid; job.att = pr.att; job.rd = rd;
-        predict_wave(s_win, s_src, s_guide, lane, job, tb, key, slot, slot_b + (size_t)r * slot, slot_q + (size_t)r * slot, &lens[r], flags);
+        predict_wave<MAXCH>(s_win, s_src, s_guide, lane, job, tb, key, slot, slot_b + (size_t)r * slot, slot_q + (size_t)r * slot, &lens[r], flags);
         __builtin_amdgcn_wave_barrier();
         if (lane == 0) {
             const uint32_t nl = lens[r];
@@ -512,11 +514,13 @@ __global__ void __launch_bounds__(64 * READS_WAVES) k_reads(const uint8_t* __res
 }
 
 // kernel-level entry for parity tests: windows given explicitly
+template <int MAXCH>
 __global__ void __launch_bounds__(64 * READS_WAVES) k_predict_windows(const uint8_t* __restrict__ windows, uint32_t n_reads, const uint64_t* __restrict__ uids,
-                                                         const uint32_t* __restrict__ atts, const uint8_t* __restrict__ is_read1, DevTables tb,
+                                                         const uint32_t* __restrict__ atts, const uint8_t* __restrict__ is_read1, const DevTables* __restrict__ tbp,
                                                          RngKey key, uint32_t slot, char* __restrict__ slot_b, char* __restrict__ slot_q,
                                                          uint32_t* __restrict__ lens, uint32_t* __restrict__ flags) {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
+    const DevTables& tb = *tbp;
     uint8_t* s_guide = s_dyn;
     const uint32_t guide_bytes = (uint32_t)(16 * tb.bins * 17), guide_pad = (guide_bytes + 15u) & ~15u;
     uint8_t* s_win_all = s_dyn + guide_pad; uint8_t* s_src_all = s_win_all + READS_WAVES * 256;
@@ -531,7 +535,7 @@ __global__ void __launch_bounds__(64 * READS_WAVES) k_predict_windows(const uint
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         ReadJob job; job.uid = uids[r]; job.att = atts[r]; job.rd = is_read1[r] ? 0u : 1u;
-        predict_wave(s_win, s_src, s_guide, lane, job, tb, key, slot, slot_b + (size_t)r * slot, slot_q + (size_t)r * slot, &lens[r], flags);
+        predict_wave<MAXCH>(s_win, s_src, s_guide, lane, job, tb, key, slot, slot_b + (size_t)r * slot, slot_q + (size_t)r * slot, &lens[r], flags);
         __builtin_amdgcn_wave_barrier();
     }
 }
@@ -963,17 +967,24 @@ static inline uint32_t reads_grid(uint64_t nreads) {
     return grid < 1 ? 1 : (grid > cap ? cap : grid);
 }
 void launch_reads(hipStream_t s, const uint8_t* g, DevErrPool spool, DevErrPool fpool,
-                  const PairRec* pairs, uint32_t np, uint32_t amp_index_base, DevTables tb, RngKey key, int paired, uint32_t slot,
+                  const PairRec* pairs, uint32_t np, uint32_t amp_index_base, DevTables tb, const DevTables* d_tb, RngKey key, int paired, uint32_t slot,
                   char* slot_b, char* slot_q, uint32_t* lens, uint32_t* sizes1, uint32_t* sizes2, uint32_t* flags) {
     if (np == 0) return;
     const uint64_t nreads = paired ? 2ull * np : np;
-    hipLaunchKernelGGL(k_reads, dim3(reads_grid(nreads)), dim3(64 * READS_WAVES), reads_lds_bytes(tb), s, g, spool, fpool, pairs, np, amp_index_base, tb, key, paired, slot,
-                       slot_b, slot_q, lens, sizes1, sizes2, flags);
+    const int nch = (tb.L + 63) / 64;
+#define SCS_LAUNCH_READS(N) hipLaunchKernelGGL(k_reads<N>, dim3(reads_grid(nreads)), dim3(64 * READS_WAVES), reads_lds_bytes(tb), s, g, spool, fpool, pairs, np, \
+                                                amp_index_base, d_tb, key, paired, slot, slot_b, slot_q, lens, sizes1, sizes2, flags)
+    if (nch <= 2) SCS_LAUNCH_READS(2); else if (nch == 3) SCS_LAUNCH_READS(3); else SCS_LAUNCH_READS(4);
+#undef SCS_LAUNCH_READS
 }
 void launch_predict_windows(hipStream_t s, const uint8_t* windows, uint32_t n_reads, const uint64_t* uids, const uint32_t* atts,
-                            const uint8_t* is_read1, DevTables tb, RngKey key, uint32_t slot, char* slot_b, char* slot_q, uint32_t* lens, uint32_t* flags) {
+                            const uint8_t* is_read1, DevTables tb, const DevTables* d_tb, RngKey key, uint32_t slot, char* slot_b, char* slot_q, uint32_t* lens, uint32_t* flags) {
     if (n_reads == 0) return;
-    hipLaunchKernelGGL(k_predict_windows, dim3(reads_grid(n_reads)), dim3(64 * READS_WAVES), reads_lds_bytes(tb), s, windows, n_reads, uids, atts, is_read1, tb, key, slot, slot_b, slot_q, lens, flags);
+    const int nch = (tb.L + 63) / 64;
+#define SCS_LAUNCH_PW(N) hipLaunchKernelGGL(k_predict_windows<N>, dim3(reads_grid(n_reads)), dim3(64 * READS_WAVES), reads_lds_bytes(tb), s, windows, n_reads, uids, atts, \
+                                             is_read1, d_tb, key, slot, slot_b, slot_q, lens, flags)
+    if (nch <= 2) SCS_LAUNCH_PW(2); else if (nch == 3) SCS_LAUNCH_PW(3); else SCS_LAUNCH_PW(4);
+#undef SCS_LAUNCH_PW
 }
 void launch_format(hipStream_t s, const PairRec* pairs, uint32_t np, uint32_t amp_index_base, int paired, uint32_t slot, const char* slot_b,
                    const char* slot_q, const uint32_t* lens, const uint64_t* off1, const uint64_t* off2, char* out1, char* out2) {

@@ -94,7 +94,7 @@ struct scs_ctx {
     RngKey key{0, 0};
     // model
     ProfileTables prof; bool have_profile = false; DevTables dtb{};
-    DevBuf t_guide, t_subs1, t_subs2, t_qual, t_ins, t_del, t_isize, d_subs1, d_subs2, d_qual, d_ins, d_del, d_isize, d_gcmeans;
+    DevBuf d_tables, t_guide, t_subs1, t_subs2, t_qual, t_ins, t_del, t_isize, d_subs1, d_subs2, d_qual, d_ins, d_del, d_isize, d_gcmeans;
     // genome + fragments
     DevBuf gx_gc_bits, gx_n_bits, gx_gc_cnt, gx_n_cnt, gx_gc_pref, gx_n_pref, d_binom;
     std::vector<FastaRecord> recs; bool have_genome = false; DevBuf genome; std::vector<uint64_t> rec_off; uint64_t genome_bases = 0;
@@ -186,6 +186,8 @@ void do_load_profile(scs_ctx* c, const char* path) {
     t.ins_d = c->d_ins.as<double>(); t.del_d = c->d_del.as<double>(); t.isize_d = c->d_isize.as<double>();
     t.gc_means = c->d_gcmeans.as<double>(); t.gc_std = P.gc_std;
     if (P.read_length > 256) throw ScsError(SCS_EINVAL, "read length > 256 not supported by the inject_errors kernel");
+    c->d_tables.reserve(sizeof(DevTables), s);                                    // the table descriptor itself also lives in HBM (kernels fetch fields on use)
+    HIP_OK(hipMemcpyAsync(c->d_tables.p, &c->dtb, sizeof(DevTables), hipMemcpyHostToDevice, s)); HIP_OK(hipStreamSynchronize(s));
     c->have_profile = true;
     if (c->cfg.verbose) fprintf(stderr, "profile was loaded from file %s\n", path);
 }
@@ -501,7 +503,7 @@ void do_yield(scs_ctx* c, const OutTarget& tg, uint64_t* n1_out, uint64_t* n2_ou
         const PairRec* pr = c->pairs.as<PairRec>() + p0;
         c->tm_reads.begin(s);
         launch_reads(s, c->genome.as<uint8_t>(), c->semis.pool_view(), c->fulls.pool_view(), pr, np, 0,
-                     c->dtb, c->key, paired, slot, c->slot_b.as<char>(), c->slot_q.as<char>(), c->lens.as<uint32_t>(), c->sizes1.as<uint32_t>(),
+                     c->dtb, c->d_tables.as<DevTables>(), c->key, paired, slot, c->slot_b.as<char>(), c->slot_q.as<char>(), c->lens.as<uint32_t>(), c->sizes1.as<uint32_t>(),
                      c->sizes2.as<uint32_t>(), c->flags.as<uint32_t>());
         c->tm_reads.end(s);
         c->tm_reads.units += np;
@@ -604,7 +606,7 @@ void scs_destroy(scs_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->cfg.device);
     (void)hipStreamSynchronize(c->stream);
-    for (DevBuf* b : {&c->t_guide, &c->t_subs1, &c->t_subs2, &c->t_qual, &c->t_ins, &c->t_del, &c->t_isize, &c->d_subs1, &c->d_subs2, &c->d_qual, &c->d_ins, &c->d_del,
+    for (DevBuf* b : {&c->d_tables, &c->t_guide, &c->t_subs1, &c->t_subs2, &c->t_qual, &c->t_ins, &c->t_del, &c->t_isize, &c->d_subs1, &c->d_subs2, &c->d_qual, &c->d_ins, &c->d_del,
                       &c->d_isize, &c->d_gcmeans, &c->genome, &c->gx_gc_bits, &c->gx_n_bits, &c->gx_gc_cnt, &c->gx_n_cnt, &c->gx_gc_pref, &c->gx_n_pref, &c->d_binom, &c->df_goff, &c->df_len, &c->df_strand, &c->df_primers, &c->primer_cnt, &c->primer_delta,
                       &c->slots, &c->slot_tmpl, &c->valid, &c->valid_off, &c->scan_tmp, &c->flags, &c->weights, &c->read_numbers,
                       &c->pair_off, &c->pairs, &c->odd_before, &c->a_part, &c->a_tp, &c->a_probs, &c->a_quota, &c->a_poff, &c->d_gidx, &c->d_gw, &c->d_grn, &c->d_tot, &c->d_stage, &c->d_all, &c->d_mail, &c->budget_f, &c->budget_s, &c->slot_off_f,
@@ -691,7 +693,7 @@ int scs_predict_batch(scs_ctx* c, const uint8_t* windows, size_t n_reads, const 
         HIP_OK(hipMemcpyAsync(dw.p, windows, (size_t)n * L, hipMemcpyHostToDevice, s)); HIP_OK(hipMemcpyAsync(du.p, uids, (size_t)n * 8, hipMemcpyHostToDevice, s));
         HIP_OK(hipMemcpyAsync(da.p, attempts, (size_t)n * 4, hipMemcpyHostToDevice, s)); HIP_OK(hipMemcpyAsync(dr.p, is_read1, n, hipMemcpyHostToDevice, s));
         c->slot_b.reserve((size_t)n * slot, s); c->slot_q.reserve((size_t)n * slot, s); c->lens.reserve(std::max<size_t>((size_t)n * 4, 16), s);
-        launch_predict_windows(s, dw.as<uint8_t>(), n, du.as<uint64_t>(), da.as<uint32_t>(), dr.as<uint8_t>(), c->dtb, c->key, slot, c->slot_b.as<char>(),
+        launch_predict_windows(s, dw.as<uint8_t>(), n, du.as<uint64_t>(), da.as<uint32_t>(), dr.as<uint8_t>(), c->dtb, c->d_tables.as<DevTables>(), c->key, slot, c->slot_b.as<char>(),
                                c->slot_q.as<char>(), c->lens.as<uint32_t>(), c->flags.as<uint32_t>());
         std::vector<char> hb((size_t)n * slot), hq((size_t)n * slot); std::vector<uint32_t> hl(n);
         HIP_OK(hipMemcpyAsync(hb.data(), c->slot_b.p, hb.size(), hipMemcpyDeviceToHost, s)); HIP_OK(hipMemcpyAsync(hq.data(), c->slot_q.p, hq.size(), hipMemcpyDeviceToHost, s));
