@@ -465,9 +465,11 @@ __device__ __forceinline__ uint32_t dec_digits(uint32_t v) {
 // K4b+K5: window extraction through the index map of the pair record (no amplicon is ever
 // materialised) + predict.  512-thread workgroups: the quality guide table is staged into LDS once per
 // workgroup, each wave then walks reads with a grid stride.
-#define READS_WAVES 8
+// waves per workgroup by chunk count: two workgroups per CU fill the VGPR-limited occupancy (NCH 2: 6, 3: 5, 4: 4 waves/SIMD)
+#define READS_MAX_WAVES 12
+template <int NCH> struct ReadsGeom { static constexpr int waves = NCH <= 2 ? 12 : (NCH == 3 ? 10 : 8); static constexpr int per_simd = NCH <= 2 ? 6 : (NCH == 3 ? 5 : 4); };
 template <int MAXCH>
-__global__ void __launch_bounds__(64 * READS_WAVES) k_reads(const uint8_t* __restrict__ g, DevErrPool spool, DevErrPool fpool,
+__global__ void __launch_bounds__(64 * ReadsGeom<MAXCH>::waves, ReadsGeom<MAXCH>::per_simd) k_reads(const uint8_t* __restrict__ g, DevErrPool spool, DevErrPool fpool,
                                                const PairRec* __restrict__ pairs, uint32_t np, uint32_t amp_index_base,
                                                const DevTables* __restrict__ tbp, RngKey key, int paired, uint32_t slot, char* __restrict__ slot_b,
                                                char* __restrict__ slot_q, uint32_t* __restrict__ lens, uint32_t* __restrict__ sizes1,
@@ -476,6 +478,7 @@ __global__ void __launch_bounds__(64 * READS_WAVES) k_reads(const uint8_t* __res
     const DevTables& tb = *tbp;                                            // tables live in device memory: fields are fetched when used
     uint8_t* s_guide = s_dyn;                                              // [16*bins][17]
     const uint32_t guide_bytes = (uint32_t)(16 * tb.bins * 17), guide_pad = (guide_bytes + 15u) & ~15u;
+    constexpr int READS_WAVES = ReadsGeom<MAXCH>::waves;
     uint8_t* s_win_all = s_dyn + guide_pad;                                // [READS_WAVES][256]
     uint8_t* s_src_all = s_win_all + READS_WAVES * 256;                    // [READS_WAVES][SRC_CAP]
     for (uint32_t k = threadIdx.x * 4; k < guide_pad; k += blockDim.x * 4)
@@ -515,7 +518,7 @@ __global__ void __launch_bounds__(64 * READS_WAVES) k_reads(const uint8_t* __res
 
 // kernel-level entry for parity tests: windows given explicitly
 template <int MAXCH>
-__global__ void __launch_bounds__(64 * READS_WAVES) k_predict_windows(const uint8_t* __restrict__ windows, uint32_t n_reads, const uint64_t* __restrict__ uids,
+__global__ void __launch_bounds__(64 * ReadsGeom<MAXCH>::waves, ReadsGeom<MAXCH>::per_simd) k_predict_windows(const uint8_t* __restrict__ windows, uint32_t n_reads, const uint64_t* __restrict__ uids,
                                                          const uint32_t* __restrict__ atts, const uint8_t* __restrict__ is_read1, const DevTables* __restrict__ tbp,
                                                          RngKey key, uint32_t slot, char* __restrict__ slot_b, char* __restrict__ slot_q,
                                                          uint32_t* __restrict__ lens, uint32_t* __restrict__ flags) {
@@ -523,6 +526,7 @@ __global__ void __launch_bounds__(64 * READS_WAVES) k_predict_windows(const uint
     const DevTables& tb = *tbp;
     uint8_t* s_guide = s_dyn;
     const uint32_t guide_bytes = (uint32_t)(16 * tb.bins * 17), guide_pad = (guide_bytes + 15u) & ~15u;
+    constexpr int READS_WAVES = ReadsGeom<MAXCH>::waves;
     uint8_t* s_win_all = s_dyn + guide_pad; uint8_t* s_src_all = s_win_all + READS_WAVES * 256;
     for (uint32_t k = threadIdx.x * 4; k < guide_pad; k += blockDim.x * 4)
         *reinterpret_cast<uint32_t*>(s_guide + k) = *reinterpret_cast<const uint32_t*>(tb.qual_guide + k);
@@ -960,10 +964,10 @@ void launch_pair_offsets(hipStream_t s, const uint32_t* rn, uint32_t ac, int pai
     if (paired) (void)rocprim::exclusive_scan(temp, temp_bytes, rocprim::make_transform_iterator(rn, HalfUp()), pair_cnt_off, 0u, (size_t)ac + 1, rocprim::plus<uint32_t>(), s);
     else (void)rocprim::exclusive_scan(temp, temp_bytes, rn, pair_cnt_off, 0u, (size_t)ac + 1, rocprim::plus<uint32_t>(), s);
 }
-static inline size_t reads_lds_bytes(const DevTables& tb) { return (((size_t)16 * tb.bins * 17 + 15) & ~(size_t)15) + READS_WAVES * (256 + SRC_CAP); }
-static inline uint32_t reads_grid(uint64_t nreads) {
-    uint32_t grid = cdiv(nreads, READS_WAVES * 2);                  // >= 2 reads per wave before more workgroups are added
-    const uint32_t cap = 256 * 3;                                   // 3 workgroups of 8 waves per CU hold the guide table in LDS
+static inline size_t reads_lds_bytes(const DevTables& tb, int waves) { return (((size_t)16 * tb.bins * 17 + 15) & ~(size_t)15) + (size_t)waves * (256 + SRC_CAP); }
+static inline uint32_t reads_grid(uint64_t nreads, int waves) {
+    uint32_t grid = cdiv(nreads, (uint32_t)waves * 2);               // >= 2 reads per wave before more workgroups are added
+    const uint32_t cap = 256 * 2;                                   // two resident workgroups per CU (VGPR-limited), each stages the guide table once
     return grid < 1 ? 1 : (grid > cap ? cap : grid);
 }
 void launch_reads(hipStream_t s, const uint8_t* g, DevErrPool spool, DevErrPool fpool,
@@ -972,7 +976,7 @@ void launch_reads(hipStream_t s, const uint8_t* g, DevErrPool spool, DevErrPool 
     if (np == 0) return;
     const uint64_t nreads = paired ? 2ull * np : np;
     const int nch = (tb.L + 63) / 64;
-#define SCS_LAUNCH_READS(N) hipLaunchKernelGGL(k_reads<N>, dim3(reads_grid(nreads)), dim3(64 * READS_WAVES), reads_lds_bytes(tb), s, g, spool, fpool, pairs, np, \
+#define SCS_LAUNCH_READS(N) hipLaunchKernelGGL(k_reads<N>, dim3(reads_grid(nreads, ReadsGeom<N>::waves)), dim3(64 * ReadsGeom<N>::waves), reads_lds_bytes(tb, ReadsGeom<N>::waves), s, g, spool, fpool, pairs, np, \
                                                 amp_index_base, d_tb, key, paired, slot, slot_b, slot_q, lens, sizes1, sizes2, flags)
     if (nch <= 2) SCS_LAUNCH_READS(2); else if (nch == 3) SCS_LAUNCH_READS(3); else SCS_LAUNCH_READS(4);
 #undef SCS_LAUNCH_READS
@@ -981,7 +985,7 @@ void launch_predict_windows(hipStream_t s, const uint8_t* windows, uint32_t n_re
                             const uint8_t* is_read1, DevTables tb, const DevTables* d_tb, RngKey key, uint32_t slot, char* slot_b, char* slot_q, uint32_t* lens, uint32_t* flags) {
     if (n_reads == 0) return;
     const int nch = (tb.L + 63) / 64;
-#define SCS_LAUNCH_PW(N) hipLaunchKernelGGL(k_predict_windows<N>, dim3(reads_grid(n_reads)), dim3(64 * READS_WAVES), reads_lds_bytes(tb), s, windows, n_reads, uids, atts, \
+#define SCS_LAUNCH_PW(N) hipLaunchKernelGGL(k_predict_windows<N>, dim3(reads_grid(n_reads, ReadsGeom<N>::waves)), dim3(64 * ReadsGeom<N>::waves), reads_lds_bytes(tb, ReadsGeom<N>::waves), s, windows, n_reads, uids, atts, \
                                              is_read1, d_tb, key, slot, slot_b, slot_q, lens, flags)
     if (nch <= 2) SCS_LAUNCH_PW(2); else if (nch == 3) SCS_LAUNCH_PW(3); else SCS_LAUNCH_PW(4);
 #undef SCS_LAUNCH_PW
