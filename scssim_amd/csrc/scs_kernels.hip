@@ -467,7 +467,8 @@ __device__ __forceinline__ uint32_t dec_digits(uint32_t v) {
 // workgroup, each wave then walks reads with a grid stride.
 // waves per workgroup by chunk count: two workgroups per CU fill the VGPR-limited occupancy (NCH 2: 6, 3: 5, 4: 4 waves/SIMD)
 #define READS_MAX_WAVES 12
-template <int NCH> struct ReadsGeom { static constexpr int waves = NCH <= 2 ? 12 : (NCH == 3 ? 10 : 8); static constexpr int per_simd = NCH <= 2 ? 6 : (NCH == 3 ? 5 : 4); };
+// (measured at 300 Mb / 5.96e7 reads: 8 waves x 768 workgroups 169 ms; 10 waves x 512 workgroups 204 ms)
+template <int NCH> struct ReadsGeom { static constexpr int waves = 8; static constexpr int per_simd = NCH <= 2 ? 6 : (NCH == 3 ? 5 : 4); };
 template <int MAXCH>
 __global__ void __launch_bounds__(64 * ReadsGeom<MAXCH>::waves, ReadsGeom<MAXCH>::per_simd) k_reads(const uint8_t* __restrict__ g, DevErrPool spool, DevErrPool fpool,
                                                const PairRec* __restrict__ pairs, uint32_t np, uint32_t amp_index_base,
@@ -967,7 +968,7 @@ void launch_pair_offsets(hipStream_t s, const uint32_t* rn, uint32_t ac, int pai
 static inline size_t reads_lds_bytes(const DevTables& tb, int waves) { return (((size_t)16 * tb.bins * 17 + 15) & ~(size_t)15) + (size_t)waves * (256 + SRC_CAP); }
 static inline uint32_t reads_grid(uint64_t nreads, int waves) {
     uint32_t grid = cdiv(nreads, (uint32_t)waves * 2);               // >= 2 reads per wave before more workgroups are added
-    const uint32_t cap = 256 * 2;                                   // two resident workgroups per CU (VGPR-limited), each stages the guide table once
+    const uint32_t cap = 256 * 3;                                   // up to three 8-wave workgroups per CU, each stages the guide table once
     return grid < 1 ? 1 : (grid > cap ? cap : grid);
 }
 void launch_reads(hipStream_t s, const uint8_t* g, DevErrPool spool, DevErrPool fpool,
