@@ -164,6 +164,11 @@ int         scs_profile_table(void* handle, int which, const uint32_t** thr, con
 int         scs_profile_scalars(void* handle, double* out);
 void        scs_profile_close(void* handle);
 
+/* Host-only: parse a FASTA exactly as scs_load_genome_fasta stages it (no GPU).  names_buf receives the index
+ * names joined by '\n'; checksum = FNV-1a over the upper-cased sequence bytes of all records in order. */
+int         scs_fasta_probe(const char* fasta_path, int* n_records, uint64_t* total_bases, uint64_t* checksum,
+                            char* names_buf, size_t names_len, char* errbuf, size_t errlen);
+
 /* Per-kernel timing (HIP events recorded on the ctx stream around every launch, accumulated over the
  * last scs_amplify / scs_yield_reads call): name, launches, total milliseconds, and the units the
  * launches processed (amplicons created for the errscan kernels, read pairs for k_reads/k_format,

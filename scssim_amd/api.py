@@ -78,8 +78,20 @@ def load_library():
     L.scs_profile_table.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.POINTER(C.c_double)), C.POINTER(C.c_size_t)]
     L.scs_profile_scalars.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
     L.scs_profile_close.argtypes = [C.c_void_p]
+    L.scs_fasta_probe.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]
     _lib = L
     return L
+
+
+def fasta_probe(path):
+    """Host-only: (names, total bases, FNV-1a checksum of the upper-cased sequence) as the library stages the file."""
+    L = load_library()
+    n, tot, h = C.c_int(), C.c_uint64(), C.c_uint64()
+    names, err = C.create_string_buffer(1 << 16), C.create_string_buffer(512)
+    rc = L.scs_fasta_probe(os.fsencode(path), C.byref(n), C.byref(tot), C.byref(h), names, 1 << 16, err, 512)
+    if rc:
+        raise ScsError(rc, err.value.decode())
+    return names.value.decode().split("\n")[:n.value], tot.value, h.value
 
 
 class Profile:

@@ -104,6 +104,23 @@ __device__ __forceinline__ uint32_t qual_lookup(const uint32_t* __restrict__ T, 
     return lo < (uint32_t)NQ ? lo : (uint32_t)NQ - 1;
 }
 
+// ASCII -> base code, in place (0..3 = ACGT either case, 4 = anything else): Genome::getSubSequence's toupper
+// (lib/genome/Genome.cpp:272-278) + getIndexOfBase (lib/mydefine/MyDefine.cpp:326-334).  16 bytes per thread.
+__global__ void k_encode_bases(uint8_t* __restrict__ g, uint64_t n) {
+    const uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
+    if (i >= n) return;
+    auto code = [](uint32_t c) -> uint32_t { c &= 0xDFu; return c == 'A' ? 0u : c == 'C' ? 1u : c == 'G' ? 2u : c == 'T' ? 3u : 4u; };
+    if (i + 16 <= n && ((uintptr_t)(g + i) & 15) == 0) {
+        uint4 v = *reinterpret_cast<uint4*>(g + i); uint32_t* w = &v.x;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const uint32_t x = w[k]; w[k] = code(x & 255u) | (code((x >> 8) & 255u) << 8) | (code((x >> 16) & 255u) << 16) | (code(x >> 24) << 24); }
+        *reinterpret_cast<uint4*>(g + i) = v;
+    } else for (uint64_t k = i; k < n && k < i + 16; ++k) g[k] = (uint8_t)code(g[k]);
+}
+void launch_encode_bases(hipStream_t s, uint8_t* g, uint64_t n) {
+    if (n) hipLaunchKernelGGL(k_encode_bases, dim3((unsigned)((n + 16 * 256 - 1) / (16 * 256))), dim3(256), 0, s, g, n);
+}
+
 // ------------------------------------------------------------------------------------------------
 // genome bit index: per 64-base word a G/C mask and an N mask plus running counts, so the GC count
 // and the any-N test of ANY window are O(1) (countGC, lib/mydefine/MyDefine.cpp:434-452, without

@@ -11,8 +11,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <mutex>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace scs;
@@ -88,6 +91,8 @@ struct KernelTimer {         // HIP events on the ctx stream around the launches
 
 }  // namespace
 
+namespace { struct SinkPipe; }
+
 struct scs_ctx {
     scs_config cfg; std::string err;
     hipStream_t stream = nullptr; bool own_stream = false;
@@ -109,7 +114,7 @@ struct scs_ctx {
     DevBuf slots, slot_tmpl, valid, valid_off, scan_tmp, flags;
     // allocation + reads
     DevBuf weights, read_numbers, pair_off, pairs, odd_before, a_part, a_tp, a_probs, a_quota, a_poff; std::vector<uint32_t> h_read_numbers; uint64_t reads_requested = 0, n_pairs_planned = 0; bool allocated = false;
-    DevBuf slot_b, slot_q, lens, sizes1, sizes2, off1, off2, out1, out2; std::vector<char> h_out1, h_out2;
+    DevBuf slot_b, slot_q, lens, sizes1, sizes2, off1, off2, out1, out2; SinkPipe* pipe = nullptr;
     // sharded single job: collectives supplied by the caller + segment bookkeeping of the local amplicon lists
     scs_allreduce_fn allreduce = nullptr; scs_allgatherv_fn allgatherv = nullptr; void* coll_user = nullptr;
     scs_allreduce_dev_fn allreduce_dev = nullptr; scs_allgather_dev_fn allgather_dev = nullptr; void* coll_dev_user = nullptr;
@@ -201,6 +206,7 @@ void stage_genome(scs_ctx* c) {
     for (size_t i = 0; i < c->recs.size(); ++i)
         if (!c->recs[i].code.empty())
             HIP_OK(hipMemcpyAsync((uint8_t*)c->genome.p + c->rec_off[i], c->recs[i].code.data(), c->recs[i].code.size(), hipMemcpyHostToDevice, c->stream));
+    launch_encode_bases(c->stream, c->genome.as<uint8_t>(), tot);                 // raw ASCII -> base codes on the device
     {   // bit index: GC count / any-N of any window in O(1)
         hipStream_t s = c->stream; const uint64_t nw = (tot + 63) / 64;
         c->gx_gc_bits.reserve((nw + 1) * 8, s); c->gx_n_bits.reserve((nw + 1) * 8, s); c->gx_gc_cnt.reserve((nw + 2) * 4, s); c->gx_n_cnt.reserve((nw + 2) * 4, s);
@@ -481,6 +487,34 @@ void do_allocate(scs_ctx* c, uint64_t reads) {
 }
 
 // ---------------------------------------------------------------- a10/a11/a13/a16: yieldReads
+// FASTQ sink pipeline (replaces the mutexed ofstream of lib/seqwriter/SeqWriter.cpp:41-54): batches are
+// copied D2H into two pinned buffer pairs asynchronously; a writer thread waits for each copy's event and hands the
+// batch to the caller's sink IN ORDER while the GPU already produces the next batch.
+struct SinkPipe {
+    struct Job { int slot; size_t n1, n2; };
+    char* h1[2] = {nullptr, nullptr}; char* h2[2] = {nullptr, nullptr}; size_t cap1 = 0, cap2 = 0;
+    hipEvent_t ev[2]; bool busy[2] = {false, false};
+    std::mutex mu; std::condition_variable cv; std::vector<Job> q; bool done = false, failed = false;
+    std::thread th; scs_sink_fn sink; void* user; bool paired; int device;
+    void start(scs_sink_fn f, void* u, bool pe, int dev) {
+        sink = f; user = u; paired = pe; device = dev; done = failed = false; busy[0] = busy[1] = false; q.clear();
+        th = std::thread([this] {
+            (void)hipSetDevice(device);
+            for (;;) {
+                Job j;
+                { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [this] { return !q.empty() || done; }); if (q.empty()) return; j = q.front(); q.erase(q.begin()); }
+                bool bad = hipEventSynchronize(ev[j.slot]) != hipSuccess;
+                if (!bad && !failed) bad = sink(user, h1[j.slot], j.n1, paired ? h2[j.slot] : nullptr, j.n2) != 0;
+                { std::lock_guard<std::mutex> lk(mu); busy[j.slot] = false; if (bad) failed = true; }
+                cv.notify_all();
+            }
+        });
+    }
+    int acquire(int slot) { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return !busy[slot]; }); busy[slot] = true; return failed ? 1 : 0; }
+    void submit(int slot, size_t n1, size_t n2) { { std::lock_guard<std::mutex> lk(mu); q.push_back(Job{slot, n1, n2}); } cv.notify_all(); }
+    bool finish() { { std::lock_guard<std::mutex> lk(mu); done = true; } cv.notify_all(); if (th.joinable()) th.join(); return !failed; }
+};
+
 struct OutTarget { bool device; char* d1; char* d2; size_t cap1, cap2; scs_sink_fn sink; void* user; };
 
 void do_yield(scs_ctx* c, const OutTarget& tg, uint64_t* n1_out, uint64_t* n2_out, uint64_t* pairs_out) {
@@ -492,7 +526,14 @@ void do_yield(scs_ctx* c, const OutTarget& tg, uint64_t* n1_out, uint64_t* n2_ou
     const uint32_t L = (uint32_t)c->prof.read_length, slot = ((L + 64 + 63) / 64) * 64;
     c->pairs.reserve(std::max<size_t>(P * sizeof(PairRec), 16), s);
     launch_plan_pairs(s, c->frags_view(), c->semis.view(), c->fulls.view(), c->fulls.n, c->read_numbers.as<uint32_t>(), c->pair_off.as<uint32_t>(), c->have_gidx ? c->d_gidx.as<uint32_t>() : nullptr, c->dtb, c->key, paired, c->pairs.as<PairRec>());
-    const uint64_t batch = std::min<uint64_t>(std::max<uint64_t>(P, 1), 1ull << 21);
+    const bool to_sink = !tg.device && tg.sink;
+    const uint64_t batch = std::min<uint64_t>(std::max<uint64_t>(P, 1), to_sink ? (1ull << 19) : (1ull << 21));   // sink: smaller batches, pinned double buffers
+    struct PipeGuard { SinkPipe* p; ~PipeGuard() { if (p) (void)p->finish(); } } guard{nullptr};
+    if (to_sink) {
+        if (!c->pipe) { c->pipe = new SinkPipe; HIP_OK(hipEventCreateWithFlags(&c->pipe->ev[0], hipEventDisableTiming)); HIP_OK(hipEventCreateWithFlags(&c->pipe->ev[1], hipEventDisableTiming)); }
+        c->pipe->start(tg.sink, tg.user, paired != 0, c->cfg.device); guard.p = c->pipe;
+    }
+    uint64_t bi = 0;
     const uint64_t nreads_b = paired ? 2 * batch : batch;
     c->slot_b.reserve(nreads_b * slot, s); c->slot_q.reserve(nreads_b * slot, s); c->lens.reserve(nreads_b * 4, s);
     c->sizes1.reserve((batch + 1) * 4, s); c->sizes2.reserve((batch + 1) * 4, s); c->off1.reserve((batch + 1) * 8, s); c->off2.reserve((batch + 1) * 8, s);
@@ -525,12 +566,23 @@ void do_yield(scs_ctx* c, const OutTarget& tg, uint64_t* n1_out, uint64_t* n2_ou
         launch_format(s, pr, np, 0, paired, slot, c->slot_b.as<char>(), c->slot_q.as<char>(), c->lens.as<uint32_t>(), c->off1.as<uint64_t>(), c->off2.as<uint64_t>(), o1, o2);
         c->tm_format.end(s);
         c->tm_format.units += np;
-        if (!tg.device && tg.sink) {
-            c->h_out1.resize(b1); c->h_out2.resize(b2);
-            if (b1) HIP_OK(hipMemcpyAsync(c->h_out1.data(), o1, b1, hipMemcpyDeviceToHost, s));
-            if (b2) HIP_OK(hipMemcpyAsync(c->h_out2.data(), o2, b2, hipMemcpyDeviceToHost, s));
-            HIP_OK(hipStreamSynchronize(s));
-            if (tg.sink(tg.user, c->h_out1.data(), b1, paired ? c->h_out2.data() : nullptr, b2)) throw ScsError(SCS_EIO, "sink aborted");
+        if (to_sink) {
+            SinkPipe* pp = c->pipe; const int sl = (int)(bi++ & 1);
+            if (pp->acquire(sl)) throw ScsError(SCS_EIO, "sink aborted");
+            for (int f = 0; f < 2; ++f) {                                           // per-slot pinned buffers, grown on demand (capacity kept in a 16-byte header)
+                char*& h = f == 0 ? pp->h1[sl] : pp->h2[sl]; const size_t need = f == 0 ? b1 : b2;
+                size_t have = 0; if (h) { have = ((size_t*)h)[-1]; }
+                if (need > have) {
+                    if (h) HIP_OK(hipHostFree((size_t*)h - 2));
+                    const size_t nc = std::max<size_t>(need + need / 8, 1 << 20); void* raw = nullptr;
+                    HIP_OK(hipHostMalloc(&raw, nc + 16, hipHostMallocDefault));
+                    ((size_t*)raw)[1] = nc; h = (char*)((size_t*)raw + 2);
+                }
+            }
+            if (b1) HIP_OK(hipMemcpyAsync(pp->h1[sl], o1, b1, hipMemcpyDeviceToHost, s));
+            if (b2) HIP_OK(hipMemcpyAsync(pp->h2[sl], o2, b2, hipMemcpyDeviceToHost, s));
+            HIP_OK(hipEventRecord(pp->ev[sl], s));
+            pp->submit(sl, b1, b2);
         }
         tot1 += b1; tot2 += b2;
     }
@@ -544,6 +596,7 @@ void do_yield(scs_ctx* c, const OutTarget& tg, uint64_t* n1_out, uint64_t* n2_ou
         else pairs_written = P;
     }
     HIP_OK(hipStreamSynchronize(s));
+    if (to_sink) { guard.p = nullptr; if (!c->pipe->finish()) throw ScsError(SCS_EIO, "sink aborted"); }
     check_flags(c);
     c->tm_reads.collect(); c->tm_format.collect();
     c->st.pairs_written = pairs_written; c->st.reads_written = paired ? 2 * pairs_written : pairs_written;
@@ -614,6 +667,10 @@ void scs_destroy(scs_ctx* c) {
     c->semis.release(); c->fulls.release();
     for (KernelTimer* t : {&c->tm_errscan, &c->tm_errscan_f, &c->tm_reads, &c->tm_attach, &c->tm_format}) t->release();
     if (c->h_rb) (void)hipHostFree(c->h_rb);
+    if (c->pipe) {
+        for (int k = 0; k < 2; ++k) { if (c->pipe->h1[k]) (void)hipHostFree((size_t*)c->pipe->h1[k] - 2); if (c->pipe->h2[k]) (void)hipHostFree((size_t*)c->pipe->h2[k] - 2); (void)hipEventDestroy(c->pipe->ev[k]); }
+        delete c->pipe;
+    }
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -754,6 +811,20 @@ int scs_download_read_numbers(scs_ctx* c, uint32_t* rn) {
     });
 }
 
+int scs_fasta_probe(const char* path, int* n_records, uint64_t* total_bases, uint64_t* checksum, char* names_buf, size_t names_len, char* errbuf, size_t errlen) {
+    if (!path) return SCS_EINVAL;
+    std::vector<FastaRecord> recs;
+    try { load_fasta(path, recs); }
+    catch (const std::exception& e) { if (errbuf && errlen) { strncpy(errbuf, e.what(), errlen - 1); errbuf[errlen - 1] = 0; } return SCS_EIO; }
+    uint64_t tot = 0, h = 1469598103934665603ull; std::string names;
+    for (auto& r : recs) {
+        tot += r.code.size(); names += r.name; names += '\n';
+        for (uint8_t b : r.code) { h ^= (uint64_t)(b >= 'a' && b <= 'z' ? b - 32 : b); h *= 1099511628211ull; }
+    }
+    if (n_records) *n_records = (int)recs.size(); if (total_bases) *total_bases = tot; if (checksum) *checksum = h;
+    if (names_buf && names_len) { strncpy(names_buf, names.c_str(), names_len - 1); names_buf[names_len - 1] = 0; }
+    return SCS_OK;
+}
 int scs_profile_open(const char* path, int paired, int isize, void** handle, char* errbuf, size_t errlen) {
     if (!path || !handle) return SCS_EINVAL;
     ProfileTables* T = new ProfileTables;

@@ -224,9 +224,8 @@ void load_profile(const std::string& path, bool paired, int isize, ProfileTables
 }
 
 // ---------------------------------------------------------------- FASTA
-static inline uint8_t base_code(char c) {
-    switch (c) { case 'A': case 'a': return 0; case 'C': case 'c': return 1; case 'G': case 'g': return 2; case 'T': case 't': return 3; default: return 4; }
-}
+// Staging for whole-genome inputs: the file is mmap'ed and cut at line ends with memchr; sequence
+// lines are appended as raw ASCII (bulk memcpy), the base-code conversion happens on the GPU after the upload.
 static std::string index_name(const std::string& header) {      // Fasta.cpp:56-68: first token, "chrom"/"chr" prefix dropped
     std::string nm = header;
     size_t e = nm.find_first_of(" \t");
@@ -239,9 +238,14 @@ static std::string index_name(const std::string& header) {      // Fasta.cpp:56-
 }
 void encode_record(const char* name, const char* seq, uint64_t len, FastaRecord& out) {
     out.name = index_name(name);
-    out.code.resize(len);
-    for (uint64_t i = 0; i < len; ++i) out.code[i] = base_code(seq[i]);
+    out.code.assign((const uint8_t*)seq, (const uint8_t*)seq + len);
 }
+}  // namespace scs
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+namespace scs {
 void load_fasta(const std::string& path_in, std::vector<FastaRecord>& out) {
     std::string path = path_in;
     if (path.empty()) throw std::runtime_error("reference sequence file not specified!");
@@ -251,32 +255,52 @@ void load_fasta(const std::string& path_in, std::vector<FastaRecord>& out) {
         if (system(cmd.c_str()) != 0) throw std::runtime_error("could not inflate " + path);
         path = plain;
     }
-    FILE* f = fopen(path.c_str(), "rb");
-    if (!f) throw std::runtime_error("could not open " + path);
+    const int fd = open(path.c_str(), O_RDONLY);
+    if (fd < 0) throw std::runtime_error("could not open " + path);
+    struct stat st;
+    if (fstat(fd, &st) != 0) { close(fd); throw std::runtime_error("could not stat " + path); }
+    const size_t size = (size_t)st.st_size;
     out.clear();
-    std::vector<char> buf(1 << 22);
-    std::string header; bool in_header = false, line_start = true, skip_line = false;
-    size_t n;
-    while ((n = fread(buf.data(), 1, buf.size(), f)) > 0) {
-        for (size_t i = 0; i < n; ++i) {
-            const char c = buf[i];
-            if (c == '\n') {
-                if (in_header) { out.push_back(FastaRecord{index_name(header), {}}); header.clear(); in_header = false; }
-                line_start = true; skip_line = false; continue;
-            }
-            if (line_start) {
-                line_start = false;
-                if (c == '>') { in_header = true; continue; }
-                if (c == ';') { skip_line = true; continue; }
-            }
-            if (in_header) { header.push_back(c); continue; }
-            if (skip_line || c == '\r') continue;
-            if (out.empty()) { fclose(f); throw std::runtime_error("malformed FASTA (sequence before header): " + path); }
-            out.back().code.push_back(base_code(c));
+    if (size == 0) { close(fd); throw std::runtime_error("ERROR: reference sequence cannot be empty!"); }
+    const char* base = (const char*)mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+    if (base == MAP_FAILED) { close(fd); throw std::runtime_error("could not map " + path); }
+    (void)madvise((void*)base, size, MADV_SEQUENTIAL);
+    // pass 1: record boundaries (headers) so each record's buffer is reserved once
+    struct Span { size_t hdr, body, end; };
+    std::vector<Span> spans;
+    for (size_t pos = 0; pos < size;) {
+        const char* nl = (const char*)memchr(base + pos, '\n', size - pos);
+        const size_t eol = nl ? (size_t)(nl - base) : size;
+        if (base[pos] == '>') { if (!spans.empty()) spans.back().end = pos; spans.push_back(Span{pos, eol + 1 < size ? eol + 1 : size, size}); }
+        else if (spans.empty() && base[pos] != ';' && eol > pos && base[pos] != '\r') { munmap((void*)base, size); close(fd); throw std::runtime_error("malformed FASTA (sequence before header): " + path); }
+        if (base[pos] == '>') {
+            // jump: headers are rare; look for the next one directly
+            const char* nx = (const char*)memmem(base + eol, size - eol, "\n>", 2);
+            pos = nx ? (size_t)(nx - base) + 1 : size;
+            continue;
         }
+        pos = eol + 1;
     }
-    fclose(f);
-    if (in_header) out.push_back(FastaRecord{index_name(header), {}});
+    out.resize(spans.size());
+    for (size_t r = 0; r < spans.size(); ++r) {
+        const Span& sp = spans[r];
+        const char* nl = (const char*)memchr(base + sp.hdr, '\n', sp.end - sp.hdr);
+        size_t heol = nl ? (size_t)(nl - base) : sp.end;
+        size_t hend = heol; if (hend > sp.hdr && base[hend - 1] == '\r') --hend;
+        out[r].name = index_name(std::string(base + sp.hdr + 1, base + hend));
+        std::vector<uint8_t>& dst = out[r].code;
+        dst.resize(sp.end > sp.body ? sp.end - sp.body : 0);
+        size_t w = 0;
+        for (size_t pos = sp.body; pos < sp.end;) {
+            const char* e = (const char*)memchr(base + pos, '\n', sp.end - pos);
+            size_t eol = e ? (size_t)(e - base) : sp.end, le = eol;
+            if (le > pos && base[le - 1] == '\r') --le;
+            if (base[pos] != ';' && le > pos) { memcpy(dst.data() + w, base + pos, le - pos); w += le - pos; }
+            pos = eol + 1;
+        }
+        dst.resize(w);
+    }
+    munmap((void*)base, size); close(fd);
     if (out.empty()) throw std::runtime_error("ERROR: reference sequence cannot be empty!");
 }
 

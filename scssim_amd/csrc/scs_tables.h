@@ -44,7 +44,10 @@ std::vector<uint64_t> binom_table(double ber, int n_min, int n_max);
 // Throws std::runtime_error with the reference's message where it has one.
 void load_profile(const std::string& path, bool paired, int isize, ProfileTables& out);
 
-struct FastaRecord { std::string name; std::vector<uint8_t> code; };   // codes 0..3 ACGT, 4 other
+// One FASTA record as staged on the host: `code` holds the sequence as RAW ASCII (line breaks removed); the
+// ASCII -> base-code conversion (0..3 ACGT, 4 other; upper-casing of Genome::getSubSequence, Genome.cpp:272-278)
+// runs on the device after the upload (k_encode_bases).
+struct FastaRecord { std::string name; std::vector<uint8_t> code; };
 void load_fasta(const std::string& path, std::vector<FastaRecord>& out);
 void encode_record(const char* name, const char* seq, uint64_t len, FastaRecord& out);
 

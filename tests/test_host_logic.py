@@ -108,3 +108,32 @@ def test_det_log_is_accurate(oracle_lib):
     for x in xs:
         got, want = oracle_lib.scso_det_log(float(x)), math.log(float(x))
         assert abs(got - want) <= 4.5e-16 * max(1.0, abs(want)), x
+
+
+def _fnv(seq):
+    h = 1469598103934665603
+    for b in seq.upper().encode():
+        h = ((h ^ b) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+def test_fasta_staging_edge_cases(tmp_path):
+    """mmap/memchr FASTA staging (lib/fastahack/Fasta.cpp:45-215 semantics): names lose a chr/chrom prefix and anything
+    after the first blank; CRLF, comments, blank lines, lower case, a missing final newline and empty records are handled."""
+    cases = {
+        "plain": (">chr20_1_12\nACGTAC\nGTACGT\n>chr20_2_12 extra words\nacgtnn\nNNACGT\n", ["20_1_12", "20_2_12"], "ACGTACGTACGT" + "ACGTNNNNACGT"),
+        "crlf_nonl": (">chrom7_1_8\r\nACGT\r\nTTGA\r\n>x\r\nAC", ["7_1_8", "x"], "ACGTTTGA" + "AC"),
+        "comments": (";file comment\n>a b\n;in-record comment\nAAAA\n\nCCCC\n>empty\n>b\nG\n", ["a", "empty", "b"], "AAAACCCC" + "" + "G"),
+    }
+    for name, (text, want_names, want_seq) in cases.items():
+        p = tmp_path / (name + ".fa")
+        p.write_bytes(text.encode())
+        names, tot, h = scssim_amd.fasta_probe(str(p))
+        assert names == want_names, name
+        assert tot == len(want_seq) and h == _fnv(want_seq), name
+    bad = tmp_path / "bad.fa"
+    bad.write_bytes(b"ACGT\n>late\nAC\n")
+    with pytest.raises(scssim_amd.ScsError):
+        scssim_amd.fasta_probe(str(bad))
+    with pytest.raises(scssim_amd.ScsError):
+        scssim_amd.fasta_probe(str(tmp_path / "missing.fa"))
