@@ -291,3 +291,53 @@ def test_pe250_and_unequal_haplotypes(oracle_bin, models, tmp_path):
     assert g.stats()["reads_requested"] == 150000 * 6 // 250
     assert fq1 == open(prefix + "_1.fq", "rb").read()
     assert fq2 == open(prefix + "_2.fq", "rb").read()
+
+
+def _write_fa(path, recs):
+    with open(path, "w") as f:
+        for name, s in recs:
+            f.write(">%s\n" % name)
+            for i in range(0, len(s), 100):
+                f.write(s[i:i + 100] + "\n")
+
+
+@pytest.mark.parametrize("name", ["short_record", "too_short_to_amplify", "all_N", "zero_reads", "empty_record_mixed"])
+def test_degenerate_inputs_match_oracle(name, oracle_bin, models, tmp_path):
+    """Ragged / empty inputs: records shorter than the fragment or amplicon minimum, all-N sequence, zero requested reads,
+    an empty record next to a normal one.  No faults, and the (possibly empty) FASTQ equals the oracle's."""
+    rng = np.random.default_rng(3)
+    rnd = lambda n: "".join(rng.choice(list("ACGT"), size=n))
+    recs, cov = {
+        "short_record": ([("1_1_6000", rnd(6000)), ("1_2_6000", rnd(6000))], "40"),
+        "too_short_to_amplify": ([("1_1_900", rnd(900)), ("1_2_900", rnd(900))], "30"),
+        "all_N": ([("1_1_30000", "N" * 30000), ("1_2_30000", "N" * 30000)], "5"),
+        "zero_reads": ([("1_1_20000", rnd(20000)), ("1_2_20000", rnd(20000))], "0.001"),
+        "empty_record_mixed": ([("1_1_0", ""), ("2_1_15000", rnd(15000)), ("2_2_15000", rnd(15000))], "20"),
+    }[name]
+    fa = str(tmp_path / "in.fa")
+    _write_fa(fa, recs)
+    prefix = str(tmp_path / "orc")
+    _oracle_run(oracle_bin, fa, models["Illumina_HiSeq2500"], prefix, ["-c", cov], 77, threads=2)
+    g = scssim_amd.GenReads(profile=models["Illumina_HiSeq2500"], input_fasta=fa, coverage=float(cov), seed=77)
+    fq1, fq2 = g.run()
+    assert fq1 == open(prefix + "_1.fq", "rb").read()
+    assert fq2 == open(prefix + "_2.fq", "rb").read()
+    st = g.stats()
+    assert st["pairs_written"] == fq1.count(b"\n") // 4
+    if name in ("too_short_to_amplify", "all_N"):
+        assert st["full_amplicons"] == 0 and fq1 == b""
+
+
+def test_error_reporting_through_the_abi(models, tmp_path):
+    g = scssim_amd.GenReads(profile=models["Illumina_HiSeq2500"])
+    with pytest.raises(scssim_amd.ScsError) as e:
+        g.create_frags()
+    assert e.value.code == 1 and "no genome" in str(e.value)
+    with pytest.raises(scssim_amd.ScsError):
+        g.load_genome(str(tmp_path / "nope.fa"))
+    with pytest.raises(scssim_amd.ScsError) as e:
+        scssim_amd.GenReads(primers=10)
+    assert "at least 1000" in str(e.value)
+    with pytest.raises(scssim_amd.ScsError) as e:
+        scssim_amd.GenReads(gamma=1.0)
+    assert "0~1e-8" in str(e.value)
