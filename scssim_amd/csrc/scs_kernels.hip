@@ -3,6 +3,7 @@
 // Built with -ffp-contract=off: the few fp64 expressions must round exactly like the CPU oracle.
 #include "scs_device.h"
 
+#include <cstdlib>
 #include <cstring>
 #include <rocprim/rocprim.hpp>
 
@@ -102,6 +103,17 @@ __device__ __forceinline__ uint32_t qual_lookup(const uint32_t* __restrict__ T, 
     uint32_t lo = guide_row[v], hi = guide_row[v + 1];          // answer in [lo, hi]
     while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (x < T[mid]) hi = mid; else lo = mid + 1; }
     return lo < (uint32_t)NQ ? lo : (uint32_t)NQ - 1;
+}
+
+// quality lookup on the compact row: one 64-byte line per draw, search in registers.  Returns 255 when the row does
+// not fit the compact form (caller falls back to qual_lookup on the full row).
+__device__ __forceinline__ uint32_t qual_lookup_compact(const uint4* __restrict__ row, uint32_t x) {
+    const uint4 a = row[0], b = row[1], c = row[2], d = row[3];
+    if (d.w == 255u) return 255u;
+    const uint32_t cnt = (x >= a.x) + (x >= a.y) + (x >= a.z) + (x >= a.w) + (x >= b.x) + (x >= b.y) + (x >= b.z) + (x >= b.w) +
+                         (x >= c.x) + (x >= c.y) + (x >= c.z) + (x >= c.w);                 // thresholds ascend, 0xFFFFFFFF padded
+    const uint32_t word = cnt < 4 ? d.x : (cnt < 8 ? d.y : d.z);                              // cnt == n -> padded symbol 93 = fallback ac-1
+    return cnt >= 12 ? 93u : (word >> (8 * (cnt & 3u))) & 255u;
 }
 
 // ASCII -> base code, in place (0..3 = ACGT either case, 4 = anything else): Genome::getSubSequence's toupper
@@ -339,7 +351,7 @@ struct ReadJob { uint64_t uid; uint32_t att; uint32_t rd; };   // rd: 0 = read 1
 
 template <int MAXCH>
 __device__ __forceinline__ void predict_wave(const uint8_t* s_win, uint8_t* s_src, const uint8_t* s_guide, int lane, ReadJob job, const DevTables& tb, RngKey key,
-                                             uint32_t slot, char* __restrict__ out_b, char* __restrict__ out_q,
+                                             uint32_t ablate, uint32_t slot, char* __restrict__ out_b, char* __restrict__ out_q,
                                              uint32_t* __restrict__ out_len, uint32_t* __restrict__ flags) {
     const int n = tb.L;
     const uint32_t aux = job.rd | (job.att << 1);
@@ -353,7 +365,9 @@ __device__ __forceinline__ void predict_wave(const uint8_t* s_win, uint8_t* s_sr
         ev[c] = 0; evk[c] = 0; wsub[c] = 0; wql[c] = 0;
         const int j = c * WAVE + lane;
         if (c < nch && j < n) {
-            const U4 d = draw4(key, ST_READ, aux, job.uid, (uint32_t)j);
+            U4 d;
+            if (ablate & 4u) { d.w[0] = d.w[1] = 0x80000000u; d.w[2] = (uint32_t)j * 2654435761u + (uint32_t)job.uid; d.w[3] = d.w[2] * 40503u; }   // timing experiment only
+            else d = draw4(key, ST_READ, aux, job.uid, (uint32_t)j);
             wsub[c] = d.w[2]; wql[c] = d.w[3];
             if (d.w[0] < tb.t_insert) {                                            // p <= insertRate
                 const uint32_t k = rand_indx_thr(tb.ins_t, tb.ins_d, (uint32_t)tb.n_ins, draw4(key, ST_INDEL_LEN, aux, job.uid, (uint32_t)j).w[0]);
@@ -435,10 +449,8 @@ __device__ __forceinline__ void predict_wave(const uint8_t* s_win, uint8_t* s_sr
                 }
             }
         }
-    } else {
-#pragma unroll
-        for (int c = 0; c < MAXCH; ++c) { const int j = c * WAVE + lane; if (c < nch && j < n) s_src[j] = s_win[j]; }
     }
+    const uint8_t* src = anyw ? s_src : s_win;                                      // no indels anywhere: the window is the source
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     // ---- per output base: substitution conditioned on the 3-mer ending here, then quality (Profile.cpp:1666-1694)
@@ -449,7 +461,7 @@ __device__ __forceinline__ void predict_wave(const uint8_t* s_win, uint8_t* s_sr
     for (int c = 0; c <= MAXCH; ++c) {
         const int j = c * WAVE + lane;
         if (j >= n_out) continue;
-        const uint32_t c2 = s_src[j], c1 = j >= 1 ? s_src[j - 1] : 5u, c0 = j >= 2 ? s_src[j - 2] : 5u;
+        const uint32_t c2 = src[j], c1 = j >= 1 ? src[j - 1] : 5u, c0 = j >= 2 ? src[j - 2] : 5u;
         const int bin = n_out == B ? j : j * B / n_out;                             // binIndx = j*binCount/n
         const int ki = kmer_index(c0, c1, c2);
         uint32_t xs, xq;
@@ -459,7 +471,8 @@ __device__ __forceinline__ void predict_wave(const uint8_t* s_win, uint8_t* s_sr
         if (ki < 0) k = c2 < 4 ? (int)c2 : -1;
         else {
             const uint32_t row = ((uint32_t)ki * (uint32_t)B + (uint32_t)bin) * 4u;
-            if (xs == 0xFFFFFFFFu) k = (int)rand_indx_slow(subs_d + row, 4, xs);
+            if (ablate & 1u) k = (int)c2;
+            else if (xs == 0xFFFFFFFFu) k = (int)rand_indx_slow(subs_d + row, 4, xs);
             else { const uint4 T = *reinterpret_cast<const uint4*>(subs + row); k = (xs >= T.x) + (xs >= T.y) + (xs >= T.z); }
         }
         char bc, qc;
@@ -467,7 +480,14 @@ __device__ __forceinline__ void predict_wave(const uint8_t* s_win, uint8_t* s_sr
         else {
             bc = "ACGT"[k];
             const uint32_t qrow = (c2 * 4u + (uint32_t)k) * (uint32_t)B + (uint32_t)bin;
-            qc = (char)(33 + qual_lookup(tb.qual + qrow * (uint32_t)NQ, tb.qual_d + qrow * (uint32_t)NQ, s_guide + qrow * 17u, xq));
+            uint32_t qv;
+            if (ablate & 2u) qv = xq >> 27;
+            else if (xq == 0xFFFFFFFFu) qv = rand_indx_slow(tb.qual_d + qrow * (uint32_t)NQ, NQ, xq);
+            else {
+                qv = qual_lookup_compact(tb.qual_compact + qrow * 4u, xq);
+                if (qv == 255u) qv = qual_lookup(tb.qual + qrow * (uint32_t)NQ, tb.qual_d + qrow * (uint32_t)NQ, s_guide + qrow * 17u, xq);
+            }
+            qc = (char)(33 + qv);
         }
         out_b[j] = bc; out_q[j] = qc;
     }
@@ -489,7 +509,7 @@ template <int NCH> struct ReadsGeom { static constexpr int waves = 8; static con
 template <int MAXCH>
 __global__ void __launch_bounds__(64 * ReadsGeom<MAXCH>::waves, ReadsGeom<MAXCH>::per_simd) k_reads(const uint8_t* __restrict__ g, DevErrPool spool, DevErrPool fpool,
                                                const PairRec* __restrict__ pairs, uint32_t np, uint32_t amp_index_base,
-                                               const DevTables* __restrict__ tbp, RngKey key, int paired, uint32_t slot, char* __restrict__ slot_b,
+                                               const DevTables* __restrict__ tbp, RngKey key, int paired, uint32_t ablate, uint32_t slot, char* __restrict__ slot_b,
                                                char* __restrict__ slot_q, uint32_t* __restrict__ lens, uint32_t* __restrict__ sizes1,
                                                uint32_t* __restrict__ sizes2, uint32_t* __restrict__ flags) {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
@@ -515,7 +535,7 @@ __global__ void __launch_bounds__(64 * ReadsGeom<MAXCH>::waves, ReadsGeom<MAXCH>
         const int L = tb.L;
         for (int k = lane; k < L; k += WAVE) {
             const uint32_t t = rd ? pr.pos + pr.isz - 1 - (uint32_t)k : pr.pos + (uint32_t)k;   // read 2 = revcomp of the far end
-            uint32_t c = g[pr.base + dir * (int64_t)t];
+            uint32_t c = (ablate & 8u) ? (t & 3u) : g[pr.base + dir * (int64_t)t];
             if (comp) c = comp_code((uint8_t)c);
             for_each_err(pr.e1, spool.data, [&](uint32_t e) { if (pr.k1 - (int32_t)err_pos(e) == (int32_t)t) c = 3u - err_alt(e); });
             for_each_err(pr.e2, fpool.data, [&](uint32_t e) { if (err_pos(e) == t) c = err_alt(e); });
@@ -524,7 +544,7 @@ __global__ void __launch_bounds__(64 * ReadsGeom<MAXCH>::waves, ReadsGeom<MAXCH>
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         ReadJob job; job.uid = pr.uid; job.att = pr.att; job.rd = rd;
-        predict_wave<MAXCH>(s_win, s_src, s_guide, lane, job, tb, key, slot, slot_b + (size_t)r * slot, slot_q + (size_t)r * slot, &lens[r], flags);
+        predict_wave<MAXCH>(s_win, s_src, s_guide, lane, job, tb, key, ablate, slot, slot_b + (size_t)r * slot, slot_q + (size_t)r * slot, &lens[r], flags);
         __builtin_amdgcn_wave_barrier();
         if (lane == 0) {
             const uint32_t nl = lens[r];
@@ -557,7 +577,7 @@ __global__ void __launch_bounds__(64 * ReadsGeom<MAXCH>::waves, ReadsGeom<MAXCH>
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         ReadJob job; job.uid = uids[r]; job.att = atts[r]; job.rd = is_read1[r] ? 0u : 1u;
-        predict_wave<MAXCH>(s_win, s_src, s_guide, lane, job, tb, key, slot, slot_b + (size_t)r * slot, slot_q + (size_t)r * slot, &lens[r], flags);
+        predict_wave<MAXCH>(s_win, s_src, s_guide, lane, job, tb, key, 0u, slot, slot_b + (size_t)r * slot, slot_q + (size_t)r * slot, &lens[r], flags);
         __builtin_amdgcn_wave_barrier();
     }
 }
@@ -994,8 +1014,9 @@ void launch_reads(hipStream_t s, const uint8_t* g, DevErrPool spool, DevErrPool 
     if (np == 0) return;
     const uint64_t nreads = paired ? 2ull * np : np;
     const int nch = (tb.L + 63) / 64;
+    static const uint32_t ablate = getenv("SCS_ABLATE") ? (uint32_t)atoi(getenv("SCS_ABLATE")) : 0u;   // timing experiments only (wrong output): 1 subs, 2 quality, 4 Philox, 8 genome gather
 #define SCS_LAUNCH_READS(N) hipLaunchKernelGGL(k_reads<N>, dim3(reads_grid(nreads, ReadsGeom<N>::waves)), dim3(64 * ReadsGeom<N>::waves), reads_lds_bytes(tb, ReadsGeom<N>::waves), s, g, spool, fpool, pairs, np, \
-                                                amp_index_base, d_tb, key, paired, slot, slot_b, slot_q, lens, sizes1, sizes2, flags)
+                                                amp_index_base, d_tb, key, paired, ablate, slot, slot_b, slot_q, lens, sizes1, sizes2, flags)
     if (nch <= 2) SCS_LAUNCH_READS(2); else if (nch == 3) SCS_LAUNCH_READS(3); else SCS_LAUNCH_READS(4);
 #undef SCS_LAUNCH_READS
 }

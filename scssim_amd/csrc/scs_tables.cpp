@@ -219,6 +219,17 @@ void load_profile(const std::string& path, bool paired, int isize, ProfileTables
         const uint32_t* t = &T.qual_t[row * 94];
         for (uint64_t v = 0; v <= 16; ++v) { uint32_t n = 0; while (n < 94 && (uint64_t)t[n] <= (v << 28)) ++n; T.qual_guide[row * 17 + v] = (uint8_t)n; }
     }
+    T.qual_compact.assign((size_t)16 * B * 16, 0xFFFFFFFFu);
+    for (size_t row = 0; row < 16 * B; ++row) {
+        const uint32_t* t = &T.qual_t[row * 94]; uint32_t* w = &T.qual_compact[row * 16];
+        uint8_t sym[16]; uint32_t thr[16]; int n = 0; uint32_t prev = 0; bool fits = true;
+        for (int k = 0; k < 94; ++k) if (t[k] > prev) { if (n == 12) { fits = false; break; } thr[n] = t[k]; sym[n] = (uint8_t)k; ++n; prev = t[k]; }
+        if (!fits) { w[15] = 255u; continue; }
+        for (int i = 0; i < 12; ++i) w[i] = i < n ? thr[i] : 0xFFFFFFFFu;
+        uint8_t bytes[16]; for (int i = 0; i < 12; ++i) bytes[i] = i < n ? sym[i] : (uint8_t)93; bytes[12] = bytes[13] = bytes[14] = 93; bytes[15] = 0;
+        memcpy(&w[12], bytes, 12);
+        w[15] = (uint32_t)n;
+    }
     T.t_insert = threshold_le(T.insert_rate);
     T.t_delete = threshold_lt(T.del_rate / (1 - T.insert_rate));
 }

@@ -26,6 +26,10 @@ struct ProfileTables {
     // per quality row (16*bins of them) 17 counts: guide[v] = #{k : qual_t[row][k] <= v << 28}, v = 0..16
     // (a draw x with x >> 28 == v resolves to a symbol in [guide[v], guide[v+1]]).
     std::vector<uint8_t> qual_guide;
+    // compact quality rows, one 64-byte cache line each: the <= 12 symbols of the row that can be drawn at all
+    // (threshold strictly above the previous one), as 12 ascending thresholds (0xFFFFFFFF padded) + 12 symbol bytes +
+    // count byte (255 = more than 12 symbols: use the full row + guide).  words[16] per row.
+    std::vector<uint32_t> qual_compact;
     uint32_t t_insert = 0;               // p <= insertRate            (Profile.cpp:1557)
     uint32_t t_delete = 0;               // p <  delRate/(1-insertRate) (Profile.cpp:1565-1566)
 };
