@@ -100,11 +100,11 @@ double det_log(double x) {
 // ---------------------------------------------------------------------------
 enum Stage : uint32_t {
     ST_FRAGSPLIT = 1, ST_POISSON = 2, ST_ATTACH = 3, ST_ERR = 4, ST_ERRALT = 5, ST_WEIGHT = 6,
-    ST_ALLOC_TOP = 7, ST_ALLOC_CHUNK = 8, ST_PAIR = 9, ST_READ = 10, ST_INDEL_INS = 11, ST_INDEL_LEN = 12
+    ST_ALLOC_TOP = 7, ST_ALLOC_CHUNK = 8, ST_PAIR = 9, ST_READ = 10, ST_INDEL_INS = 11, ST_INDEL_LEN = 12, ST_INDEL = 13
 };
-// ST_READ block j of a read: word0 = insertion test of input base j, word1 = deletion test of input
-// base j, word2 = substitution draw of OUTPUT base j, word3 = quality draw of OUTPUT base j (or the
-// random quality when that base is N).  One Philox block per base index serves both passes.
+// One Philox block serves TWO positions: ST_INDEL block j>>1, words 2(j&1) / 2(j&1)+1 = insertion / deletion test of
+// input base j; ST_READ block j>>1, words 2(j&1) / 2(j&1)+1 = substitution draw / quality draw (or the random quality
+// of an N) of OUTPUT base j.
 
 struct Key { uint32_t idx; uint64_t uid; uint32_t stage_word; int word; };
 inline Key mk(uint32_t stage, uint32_t aux, uint64_t uid, uint32_t idx, int word) {
@@ -386,7 +386,7 @@ int predict(const Profile& P, Rng& rng, const uint8_t* win, int n, bool isRead1,
     int indelLength = 0;
     for (int j = 0; j < n;) {                                                  // 1606-1622
         int k = 0; bool isIns = false;
-        double p = rng.real(mk(ST_READ, aux, uid, j, 0));                       // getIndelSeq 1552-1570
+        double p = rng.real(mk(ST_INDEL, aux, uid, j >> 1, 2 * (j & 1)));       // getIndelSeq 1552-1570
         if (p <= P.insertRate) {
             k = rand_indx(P.insCdf.data(), P.insCdf.size(), rng.real(mk(ST_INDEL_LEN, aux, uid, j, 0)));
             for (int t = 0; t < k; ++t) {
@@ -395,7 +395,7 @@ int predict(const Profile& P, Rng& rng, const uint8_t* win, int n, bool isRead1,
             }
             isIns = !ins[j].empty();
         } else {
-            p = rng.real(mk(ST_READ, aux, uid, j, 1));
+            p = rng.real(mk(ST_INDEL, aux, uid, j >> 1, 2 * (j & 1) + 1));
             if (p < P.delRate / (1 - P.insertRate))
                 k = rand_indx(P.delCdf.data(), P.delCdf.size(), rng.real(mk(ST_INDEL_LEN, aux, uid, j, 0)));
         }
@@ -432,14 +432,14 @@ int predict(const Profile& P, Rng& rng, const uint8_t* win, int n, bool isRead1,
         int ki = kmer_index(c0, c1, c2);
         int k;
         if (ki < 0) k = refIndx;
-        else k = rand_indx(&subs[((size_t)ki * B + bin) * 4], 4, rng.real(mk(ST_READ, aux, uid, j, 2)));
+        else k = rand_indx(&subs[((size_t)ki * B + bin) * 4], 4, rng.real(mk(ST_READ, aux, uid, j >> 1, 2 * (j & 1))));
         if (k < 0) {
             out_b[j] = 'N';
-            out_q[j] = (char)(long)(33 + (53 - 33) * rng.integer(mk(ST_READ, aux, uid, j, 3)));   // getRandBaseQuality 1578-1580
+            out_q[j] = (char)(long)(33 + (53 - 33) * rng.integer(mk(ST_READ, aux, uid, j >> 1, 2 * (j & 1) + 1)));   // getRandBaseQuality 1578-1580
         } else {
             out_b[j] = BASES[k];
             int bp = refIndx * 4 + k;
-            out_q[j] = (char)(33 + rand_indx(&P.qual[((size_t)bp * B + bin) * 94], 94, rng.real(mk(ST_READ, aux, uid, j, 3))));
+            out_q[j] = (char)(33 + rand_indx(&P.qual[((size_t)bp * B + bin) * 94], 94, rng.real(mk(ST_READ, aux, uid, j >> 1, 2 * (j & 1) + 1))));
         }
     }
     return m;

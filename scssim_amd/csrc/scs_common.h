@@ -29,10 +29,11 @@ enum Stage : uint32_t {
     ST_ALLOC_TOP   = 7,   // uid = 0, idx = t, word 0                                           (MyDefine.cpp:242-245)
     ST_ALLOC_CHUNK = 8,   // uid = chunk, idx = t, word 0                                       (MyDefine.cpp:191-201)
     ST_PAIR        = 9,   // uid = full uid, idx = attempt, word0 insert size, word1 position   (Amplicon.cpp:483-491)
-    ST_READ        = 10,  // uid = full uid, aux = rd | attempt<<1, idx = j: word0 insertion test and word1 deletion test of
-                          //   INPUT base j; word2 substitution and word3 quality (or random quality of an N) of OUTPUT base j
+    ST_READ        = 10,  // uid = full uid, aux = rd | attempt<<1, idx = j>>1: words 2(j&1) substitution, 2(j&1)+1 quality
+                          //   (or random quality of an N) of OUTPUT base j                       (Profile.cpp:1666-1692)
     ST_INDEL_INS   = 11,  // same aux, idx = j | (t/4)<<16, word t%4 : t-th inserted base       (Profile.cpp:1560)
-    ST_INDEL_LEN   = 12   // same aux, idx = j, word0 : insertion / deletion length             (Profile.cpp:1515-1521)
+    ST_INDEL_LEN   = 12,  // same aux, idx = j, word0 : insertion / deletion length             (Profile.cpp:1515-1521)
+    ST_INDEL       = 13   // same aux, idx = j>>1: words 2(j&1) insertion test, 2(j&1)+1 deletion test of INPUT base j (Profile.cpp:1556-1566)
 };
 
 SCS_HD uint32_t stage_word(uint32_t stage, uint32_t aux) { return stage | (aux << 8); }

@@ -340,245 +340,215 @@ __global__ void k_plan_pairs(DevFrags fr, DevAmps semis, DevAmps fulls, uint32_t
 }
 
 // ------------------------------------------------------------------------------------------------
-// K5  inject_errors = Profile::predict (lib/profile/Profile.cpp:1582-1697), one wave per read.
-//     lanes = bases; indel events drawn per input base, deletion spans resolved in order, wave
-//     prefix sum gives the output offsets, then k-mer-conditioned substitution + quality per
-//     output base.  MAXCH chunks of 64 lanes cover reads up to 256 bases.
+// K5  inject_errors = Profile::predict (lib/profile/Profile.cpp:1582-1697) + window extraction
+//     (Amplicon::yieldReads, Amplicon.cpp:492-528).  One THREAD per read, one workgroup per 256 reads of
+//     the same mate, stepping synchronously over the output positions:
+//       * the read windows are gathered through the pair records' index maps with coalesced loads
+//         (a wave per read, 64 consecutive bases per instruction) into an LDS tile;
+//       * phase 1 (per thread, registers only): the indel tests of every input base -> event list, n';
+//       * phase 2 (workgroup-synchronous over the output position j): because all 256 reads are at the
+//         same position, only the table rows of a few bins around j are live -- a ring of 16 bins
+//         (64 k-mer substitution rows + the 4 diagonal quality rows each, 1.25 KB per bin) sits in LDS and
+//         is refilled 8 bins at a time, so the per-base table lookups are LDS reads instead of divergent
+//         global gathers (measured: the gathers were 2/3 of the wave-per-read kernel).  Rows outside the
+//         ring (reads whose length changed by > 3, first two bases, substituted bases) come from global.
 // ------------------------------------------------------------------------------------------------
-#define SRC_CAP 512
-
-struct ReadJob { uint64_t uid; uint32_t att; uint32_t rd; };   // rd: 0 = read 1, 1 = read 2
-
-template <int MAXCH>
-__device__ __forceinline__ void predict_wave(const uint8_t* s_win, uint8_t* s_src, const uint8_t* s_guide, int lane, ReadJob job, const DevTables& tb, RngKey key,
-                                             uint32_t ablate, uint32_t slot, char* __restrict__ out_b, char* __restrict__ out_q,
-                                             uint32_t* __restrict__ out_len, uint32_t* __restrict__ flags) {
-    const int n = tb.L;
-    const uint32_t aux = job.rd | (job.att << 1);
-    const int nch = (n + WAVE - 1) / WAVE;
-    // ---- indel events per input base (getIndelSeq, Profile.cpp:1552-1570).  One ST_READ block per base index:
-    //      words 0,1 feed the indel tests of input base j, words 2,3 the substitution/quality of output base j.
-    uint32_t ev[MAXCH], evk[MAXCH], wsub[MAXCH], wql[MAXCH];     // 0 none, 1 insertion, 2 deletion ; length
-    bool any = false;
-#pragma unroll
-    for (int c = 0; c < MAXCH; ++c) {
-        ev[c] = 0; evk[c] = 0; wsub[c] = 0; wql[c] = 0;
-        const int j = c * WAVE + lane;
-        if (c < nch && j < n) {
-            U4 d;
-            if (ablate & 4u) { d.w[0] = d.w[1] = 0x80000000u; d.w[2] = (uint32_t)j * 2654435761u + (uint32_t)job.uid; d.w[3] = d.w[2] * 40503u; }   // timing experiment only
-            else d = draw4(key, ST_READ, aux, job.uid, (uint32_t)j);
-            wsub[c] = d.w[2]; wql[c] = d.w[3];
-            if (d.w[0] < tb.t_insert) {                                            // p <= insertRate
-                const uint32_t k = rand_indx_thr(tb.ins_t, tb.ins_d, (uint32_t)tb.n_ins, draw4(key, ST_INDEL_LEN, aux, job.uid, (uint32_t)j).w[0]);
-                if (k > 0) { ev[c] = 1; evk[c] = k; }
-            } else if (d.w[1] < tb.t_delete) {                                     // p < delRate/(1-insertRate)
-                const uint32_t k = rand_indx_thr(tb.del_t, tb.del_d, (uint32_t)tb.n_del, draw4(key, ST_INDEL_LEN, aux, job.uid, (uint32_t)j).w[0]);
-                if (k > 0) { ev[c] = 2; evk[c] = k; }
-            }
-            any |= ev[c] != 0;
-        }
-    }
-    int n_out = n;
-    uint32_t off[MAXCH];
-    const bool anyw = __ballot(any) != 0;
-    if (anyw) {
-        // ---- visit order: a deletion of length k at j skips j+1..j+k-1 (Profile.cpp:1606-1622)
-        int until = 0;
-#pragma unroll
-        for (int c = 0; c < MAXCH; ++c) {
-            if (c >= nch) break;
-            unsigned long long m = __ballot(ev[c] != 0);
-            bool dead = false;
-            while (m) {
-                const int l = __ffsll((long long)m) - 1; m &= m - 1;
-                const int j = c * WAVE + l;
-                const uint32_t e = __shfl(ev[c], l), k = __shfl(evk[c], l);
-                if (j < until) { if (lane == l) dead = true; continue; }             // inside an earlier deletion: never visited
-                if (e == 2) { int kk = (int)k < n - j ? (int)k : n - j; until = j + kk; if (lane == l) evk[c] = (uint32_t)kk; }
-            }
-            if (dead) { ev[c] = 0; evk[c] = 0; }
-        }
-        // a lane is deleted if it lies in a live deletion span; recompute by a second ordered sweep
-        uint32_t olen[MAXCH];
-#pragma unroll
-        for (int c = 0; c < MAXCH; ++c) olen[c] = (c < nch && c * WAVE + lane < n) ? 1u : 0u;
-#pragma unroll
-        for (int c = 0; c < MAXCH; ++c) {
-            if (c >= nch) break;
-            unsigned long long m = __ballot(ev[c] == 2);
-            while (m) {
-                const int l = __ffsll((long long)m) - 1; m &= m - 1;
-                const int js = c * WAVE + l, je = js + (int)__shfl(evk[c], l);
-#pragma unroll
-                for (int c2 = 0; c2 < MAXCH; ++c2) { const int j2 = c2 * WAVE + lane; if (j2 >= js && j2 < je) olen[c2] = 0; }
-            }
-        }
-        int delta = 0;
-#pragma unroll
-        for (int c = 0; c < MAXCH; ++c) {
-            if (ev[c] == 1) { olen[c] += evk[c]; delta += (int)evk[c]; }
-            if (ev[c] == 2) delta -= (int)evk[c];
-        }
-        delta = wave_sum_i(delta);
-        if (n + delta < 50) {                                                       // Profile.cpp:1623-1630: drop all indels
-#pragma unroll
-            for (int c = 0; c < MAXCH; ++c) { ev[c] = 0; evk[c] = 0; olen[c] = (c < nch && c * WAVE + lane < n) ? 1u : 0u; }
-            delta = 0;
-        }
-        n_out = n + delta;
-        // ---- wavefront prefix sum of the per-base output lengths -> offsets in the source sequence
-        uint32_t carry = 0;
-#pragma unroll
-        for (int c = 0; c < MAXCH; ++c) {
-            const uint32_t inc = wave_incl_scan(olen[c], lane);
-            off[c] = carry + inc - olen[c];
-            carry += __shfl(inc, WAVE - 1);
-        }
-        if (n_out > (int)slot || n_out > SRC_CAP) { if (lane == 0) atomicOr(flags, (uint32_t)FLAG_READSLOT); n_out = 0; }
-        else {
-#pragma unroll
-            for (int c = 0; c < MAXCH; ++c) {
-                const int j = c * WAVE + lane;
-                if (c < nch && j < n && olen[c] > 0) {
-                    s_src[off[c]] = s_win[j];
-                    if (ev[c] == 1) for (uint32_t t = 0; t < evk[c]; ++t) {           // inserted bases: randomInteger(0, N-1) -> never 'T'
-                        const U4 d = draw4(key, ST_INDEL_INS, aux, job.uid, (uint32_t)j | ((t >> 2) << 16));
-                        s_src[off[c] + 1 + t] = (uint8_t)scale_draw(d.w[t & 3], 0, 3);
-                    }
-                }
-            }
-        }
-    }
-    const uint8_t* src = anyw ? s_src : s_win;                                      // no indels anywhere: the window is the source
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    // ---- per output base: substitution conditioned on the 3-mer ending here, then quality (Profile.cpp:1666-1694)
-    const uint32_t* __restrict__ subs = (job.rd == 0 || tb.subs2 == nullptr) ? tb.subs1 : tb.subs2;
-    const double* __restrict__ subs_d = (job.rd == 0 || tb.subs2 == nullptr) ? tb.subs1_d : tb.subs2_d;
-    const int B = tb.bins;
-#pragma unroll
-    for (int c = 0; c <= MAXCH; ++c) {
-        const int j = c * WAVE + lane;
-        if (j >= n_out) continue;
-        const uint32_t c2 = src[j], c1 = j >= 1 ? src[j - 1] : 5u, c0 = j >= 2 ? src[j - 2] : 5u;
-        const int bin = n_out == B ? j : j * B / n_out;                             // binIndx = j*binCount/n
-        const int ki = kmer_index(c0, c1, c2);
-        uint32_t xs, xq;
-        if (c < MAXCH && c < nch && j < n) { xs = wsub[c < MAXCH ? c : 0]; xq = wql[c < MAXCH ? c : 0]; }
-        else { const U4 d = draw4(key, ST_READ, aux, job.uid, (uint32_t)j); xs = d.w[2]; xq = d.w[3]; }     // output longer than the input
-        int k;
-        if (ki < 0) k = c2 < 4 ? (int)c2 : -1;
-        else {
-            const uint32_t row = ((uint32_t)ki * (uint32_t)B + (uint32_t)bin) * 4u;
-            if (ablate & 1u) k = (int)c2;
-            else if (xs == 0xFFFFFFFFu) k = (int)rand_indx_slow(subs_d + row, 4, xs);
-            else { const uint4 T = *reinterpret_cast<const uint4*>(subs + row); k = (xs >= T.x) + (xs >= T.y) + (xs >= T.z); }
-        }
-        char bc, qc;
-        if (k < 0) { bc = 'N'; qc = (char)(33 + scale_draw(xq, 0, 20)); }           // getRandBaseQuality
-        else {
-            bc = "ACGT"[k];
-            const uint32_t qrow = (c2 * 4u + (uint32_t)k) * (uint32_t)B + (uint32_t)bin;
-            uint32_t qv;
-            if (ablate & 2u) qv = xq >> 27;
-            else if (xq == 0xFFFFFFFFu) qv = rand_indx_slow(tb.qual_d + qrow * (uint32_t)NQ, NQ, xq);
-            else {
-                qv = qual_lookup_compact(tb.qual_compact + qrow * 4u, xq);
-                if (qv == 255u) qv = qual_lookup(tb.qual + qrow * (uint32_t)NQ, tb.qual_d + qrow * (uint32_t)NQ, s_guide + qrow * 17u, xq);
-            }
-            qc = (char)(33 + qv);
-        }
-        out_b[j] = bc; out_q[j] = qc;
-    }
-    if (lane == 0) *out_len = (uint32_t)n_out;
-}
+#define RB 256
+#define EV_MAX 8
+#define RING 16
+struct RingBin { uint4 subs[64]; uint4 qd[4][4]; };            // 1024 + 256 bytes per bin
 
 __device__ __forceinline__ uint32_t dec_digits(uint32_t v) {
     return v < 10u ? 1u : v < 100u ? 2u : v < 1000u ? 3u : v < 10000u ? 4u : v < 100000u ? 5u : v < 1000000u ? 6u :
            v < 10000000u ? 7u : v < 100000000u ? 8u : v < 1000000000u ? 9u : 10u;
 }
-
-// K4b+K5: window extraction through the index map of the pair record (no amplicon is ever
-// materialised) + predict.  512-thread workgroups: the quality guide table is staged into LDS once per
-// workgroup, each wave then walks reads with a grid stride.
-// waves per workgroup by chunk count: two workgroups per CU fill the VGPR-limited occupancy (NCH 2: 6, 3: 5, 4: 4 waves/SIMD)
-#define READS_MAX_WAVES 12
-// (measured at 300 Mb / 5.96e7 reads: 8 waves x 768 workgroups 169 ms; 10 waves x 512 workgroups 204 ms)
-template <int NCH> struct ReadsGeom { static constexpr int waves = 8; static constexpr int per_simd = NCH <= 2 ? 6 : (NCH == 3 ? 5 : 4); };
-template <int MAXCH>
-__global__ void __launch_bounds__(64 * ReadsGeom<MAXCH>::waves, ReadsGeom<MAXCH>::per_simd) k_reads(const uint8_t* __restrict__ g, DevErrPool spool, DevErrPool fpool,
-                                               const PairRec* __restrict__ pairs, uint32_t np, uint32_t amp_index_base,
-                                               const DevTables* __restrict__ tbp, RngKey key, int paired, uint32_t ablate, uint32_t slot, char* __restrict__ slot_b,
-                                               char* __restrict__ slot_q, uint32_t* __restrict__ lens, uint32_t* __restrict__ sizes1,
-                                               uint32_t* __restrict__ sizes2, uint32_t* __restrict__ flags) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
-    const DevTables& tb = *tbp;                                            // tables live in device memory: fields are fetched when used
-    uint8_t* s_guide = s_dyn;                                              // [16*bins][17]
-    const uint32_t guide_bytes = (uint32_t)(16 * tb.bins * 17), guide_pad = (guide_bytes + 15u) & ~15u;
-    constexpr int READS_WAVES = ReadsGeom<MAXCH>::waves;
-    uint8_t* s_win_all = s_dyn + guide_pad;                                // [READS_WAVES][256]
-    uint8_t* s_src_all = s_win_all + READS_WAVES * 256;                    // [READS_WAVES][SRC_CAP]
-    for (uint32_t k = threadIdx.x * 4; k < guide_pad; k += blockDim.x * 4)
-        *reinterpret_cast<uint32_t*>(s_guide + k) = *reinterpret_cast<const uint32_t*>(tb.qual_guide + k);
-    __syncthreads();
-    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
-    uint8_t* s_win = s_win_all + wib * 256; uint8_t* s_src = s_src_all + wib * SRC_CAP;
-    const uint32_t nreads = paired ? 2 * np : np;
-    const uint32_t nwaves = gridDim.x * READS_WAVES;
-    for (uint32_t r = blockIdx.x * READS_WAVES + wib; r < nreads; r += nwaves) {
-        const uint32_t pi = paired ? r >> 1 : r, rd = paired ? (r & 1u) : 0u;
-        const PairRec pr = pairs[pi];
-        uint32_t* sz = rd ? sizes2 : sizes1;
-        if (pr.isz == 0) { if (lane == 0) { lens[r] = 0; sz[pi] = 0; } continue; }
-        const int64_t dir = (pr.flags & 2u) ? -1 : 1; const bool comp = pr.flags & 1u;
-        const int L = tb.L;
-        for (int k = lane; k < L; k += WAVE) {
-            const uint32_t t = rd ? pr.pos + pr.isz - 1 - (uint32_t)k : pr.pos + (uint32_t)k;   // read 2 = revcomp of the far end
-            uint32_t c = (ablate & 8u) ? (t & 3u) : g[pr.base + dir * (int64_t)t];
-            if (comp) c = comp_code((uint8_t)c);
-            for_each_err(pr.e1, spool.data, [&](uint32_t e) { if (pr.k1 - (int32_t)err_pos(e) == (int32_t)t) c = 3u - err_alt(e); });
-            for_each_err(pr.e2, fpool.data, [&](uint32_t e) { if (err_pos(e) == t) c = err_alt(e); });
-            s_win[k] = (uint8_t)(rd ? comp_code((uint8_t)c) : c);
-        }
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        ReadJob job; job.uid = pr.uid; job.att = pr.att; job.rd = rd;
-        predict_wave<MAXCH>(s_win, s_src, s_guide, lane, job, tb, key, ablate, slot, slot_b + (size_t)r * slot, slot_q + (size_t)r * slot, &lens[r], flags);
-        __builtin_amdgcn_wave_barrier();
-        if (lane == 0) {
-            const uint32_t nl = lens[r];
-            // "@<ampIdx>#<fragCount>[/1|/2]\n" + seq + "\n+\n" + qual + "\n"   (Amplicon.cpp:459-466,497-504)
-            sz[pi] = nl == 0 ? 0u : 1u + dec_digits(amp_index_base + pr.amp) + 1u + dec_digits(pr.att + 1) + (paired ? 2u : 0u) + 1u + 2u * nl + 4u;
-        }
-    }
+__device__ __forceinline__ uint32_t compact_search(const uint4 a, const uint4 b, const uint4 c, const uint4 d, uint32_t x) {
+    if (d.w == 255u) return 255u;
+    const uint32_t cnt = (x >= a.x) + (x >= a.y) + (x >= a.z) + (x >= a.w) + (x >= b.x) + (x >= b.y) + (x >= b.z) + (x >= b.w) +
+                         (x >= c.x) + (x >= c.y) + (x >= c.z) + (x >= c.w);
+    const uint32_t word = cnt < 4 ? d.x : (cnt < 8 ? d.y : d.z);
+    return cnt >= 12 ? 93u : (word >> (8 * (cnt & 3u))) & 255u;
 }
 
-// kernel-level entry for parity tests: windows given explicitly
-template <int MAXCH>
-__global__ void __launch_bounds__(64 * ReadsGeom<MAXCH>::waves, ReadsGeom<MAXCH>::per_simd) k_predict_windows(const uint8_t* __restrict__ windows, uint32_t n_reads, const uint64_t* __restrict__ uids,
-                                                         const uint32_t* __restrict__ atts, const uint8_t* __restrict__ is_read1, const DevTables* __restrict__ tbp,
-                                                         RngKey key, uint32_t slot, char* __restrict__ slot_b, char* __restrict__ slot_q,
-                                                         uint32_t* __restrict__ lens, uint32_t* __restrict__ flags) {
+template <bool FROM_PAIRS>
+__global__ void __launch_bounds__(RB) k_reads(const uint8_t* __restrict__ g, DevErrPool spool, DevErrPool fpool, const PairRec* __restrict__ pairs,
+                                              uint32_t np, int paired, const uint8_t* __restrict__ windows, const uint64_t* __restrict__ uids,
+                                              const uint32_t* __restrict__ atts, const uint8_t* __restrict__ is_read1, uint32_t n_explicit,
+                                              const DevTables* __restrict__ tbp, RngKey key, uint32_t slot, char* __restrict__ slot_b,
+                                              char* __restrict__ slot_q, uint32_t* __restrict__ lens, uint32_t* __restrict__ sizes1,
+                                              uint32_t* __restrict__ sizes2, uint32_t* __restrict__ flags) {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
     const DevTables& tb = *tbp;
-    uint8_t* s_guide = s_dyn;
-    const uint32_t guide_bytes = (uint32_t)(16 * tb.bins * 17), guide_pad = (guide_bytes + 15u) & ~15u;
-    constexpr int READS_WAVES = ReadsGeom<MAXCH>::waves;
-    uint8_t* s_win_all = s_dyn + guide_pad; uint8_t* s_src_all = s_win_all + READS_WAVES * 256;
-    for (uint32_t k = threadIdx.x * 4; k < guide_pad; k += blockDim.x * 4)
-        *reinterpret_cast<uint32_t*>(s_guide + k) = *reinterpret_cast<const uint32_t*>(tb.qual_guide + k);
+    const int n = tb.L, B = tb.bins;
+    const uint32_t WS = ((uint32_t)n + 7u) & ~3u;                          // window row stride
+    RingBin* s_ring = reinterpret_cast<RingBin*>(s_dyn);                   // [RING]
+    int64_t* s_gbase = reinterpret_cast<int64_t*>(s_dyn + RING * sizeof(RingBin));   // [RB]
+    uint32_t* s_gflag = reinterpret_cast<uint32_t*>(s_gbase + RB);         // [RB]  bit0 complement, bit1 direction -1, bit2 valid
+    uint32_t* s_ev = s_gflag + RB;                                         // [RB][EV_MAX]  pos | kind<<16 | len<<20
+    uint8_t* s_win = reinterpret_cast<uint8_t*>(s_ev + RB * EV_MAX);       // [RB][WS]
+    __shared__ int s_nmax;
+    const int tid = threadIdx.x, lane = tid & 63, wib = tid >> 6;
+    if (tid == 0) s_nmax = 0;
+
+    // ---- which read is mine
+    uint32_t r, pi = 0, rd; bool valid; PairRec pr{}; uint64_t uid = 0; uint32_t att = 0;
+    if (FROM_PAIRS) {
+        const uint32_t q = paired ? blockIdx.x >> 1 : blockIdx.x;
+        rd = paired ? (blockIdx.x & 1u) : 0u;
+        pi = q * RB + tid; valid = pi < np;
+        r = paired ? 2 * pi + rd : pi;
+        if (valid) { pr = pairs[pi]; uid = pr.uid; att = pr.att; }
+    } else {
+        r = blockIdx.x * RB + tid; valid = r < n_explicit; rd = 0;
+        if (valid) { uid = uids[r]; att = atts[r]; rd = is_read1[r] ? 0u : 1u; }
+    }
+    uint32_t* sz = FROM_PAIRS ? (rd ? sizes2 : sizes1) : nullptr;
+    bool live = valid && (!FROM_PAIRS || pr.isz != 0);
+    if (FROM_PAIRS && valid && !live) { lens[r] = 0; sz[pi] = 0; }
+
+    // ---- stage the windows (coalesced), then patch the amplification errors
+    uint8_t* my_win = s_win + (size_t)tid * WS;
+    if (FROM_PAIRS) {
+        int64_t gb = 0; uint32_t gf = 0;
+        if (live) {
+            const int64_t dir = (pr.flags & 2u) ? -1 : 1; const uint32_t comp = pr.flags & 1u;
+            if (rd == 0) { gb = pr.base + dir * (int64_t)pr.pos; gf = comp | ((dir < 0) ? 2u : 0u) | 4u; }
+            else { gb = pr.base + dir * (int64_t)(pr.pos + pr.isz - 1); gf = (comp ^ 1u) | ((dir < 0) ? 0u : 2u) | 4u; }   // read 2 = revcomp of the far end
+        }
+        s_gbase[tid] = gb; s_gflag[tid] = gf;
+        __syncthreads();
+        for (int q = 0; q < 64; ++q) {
+            const int rr = wib * 64 + q; const uint32_t f = s_gflag[rr];
+            if (!(f & 4u)) continue;
+            const int64_t b0 = s_gbase[rr], d = (f & 2u) ? -1 : 1;
+            for (int k = lane; k < n; k += WAVE) { uint32_t c = g[b0 + d * (int64_t)k]; if (f & 1u) c = comp_code((uint8_t)c); s_win[(size_t)rr * WS + k] = (uint8_t)c; }
+        }
+        __syncthreads();
+        if (live) {
+            // U[t] patched at t = k1 - pos(e) with comp(alt) (semi) and at t = pos(e) with alt (full); window index of t:
+            // read 1: t - pos ; read 2: pos + isz - 1 - t, complemented
+            for_each_err(pr.e1, spool.data, [&](uint32_t e) {
+                const int t = pr.k1 - (int)err_pos(e); const int k = rd ? (int)(pr.pos + pr.isz - 1) - t : t - (int)pr.pos;
+                if (k >= 0 && k < n) my_win[k] = (uint8_t)(rd ? err_alt(e) : 3u - err_alt(e));
+            });
+            for_each_err(pr.e2, fpool.data, [&](uint32_t e) {
+                const int t = (int)err_pos(e); const int k = rd ? (int)(pr.pos + pr.isz - 1) - t : t - (int)pr.pos;
+                if (k >= 0 && k < n) my_win[k] = (uint8_t)(rd ? 3u - err_alt(e) : err_alt(e));
+            });
+        }
+    } else {
+        const size_t base_off = (size_t)blockIdx.x * RB * (size_t)n;
+        const uint32_t nblk = min((uint32_t)RB, n_explicit - blockIdx.x * RB);
+        for (uint32_t idx = tid; idx < nblk * (uint32_t)n; idx += RB) s_win[(size_t)(idx / n) * WS + idx % n] = windows[base_off + idx];
+        __syncthreads();
+    }
+
+    // ---- phase 1: indel events per input base (getIndelSeq, Profile.cpp:1552-1570 / loop 1606-1630)
+    const uint32_t aux = rd | (att << 1);
+    uint32_t* my_ev = s_ev + tid * EV_MAX;
+    int nev = 0, delta = 0, n_out = 0;
+    if (live) {
+        uint32_t cur = 0xFFFFFFFFu; U4 d{};
+        for (int ji = 0; ji < n;) {
+            if ((uint32_t)(ji >> 1) != cur) { cur = (uint32_t)(ji >> 1); d = draw4(key, ST_INDEL, aux, uid, cur); }
+            const uint32_t w0 = d.w[2 * (ji & 1)], w1 = d.w[2 * (ji & 1) + 1];
+            if (w0 < tb.t_insert) {                                                // p <= insertRate
+                const uint32_t k = rand_indx_thr(tb.ins_t, tb.ins_d, (uint32_t)tb.n_ins, draw4(key, ST_INDEL_LEN, aux, uid, (uint32_t)ji).w[0]);
+                if (k > 0) { if (nev < EV_MAX) my_ev[nev] = (uint32_t)ji | (1u << 16) | (k << 20); ++nev; delta += (int)k; }
+                ++ji;
+            } else if (w1 < tb.t_delete) {                                         // p < delRate/(1-insertRate)
+                const uint32_t k = rand_indx_thr(tb.del_t, tb.del_d, (uint32_t)tb.n_del, draw4(key, ST_INDEL_LEN, aux, uid, (uint32_t)ji).w[0]);
+                if (k > 0) { const int kk = (int)k < n - ji ? (int)k : n - ji; if (nev < EV_MAX) my_ev[nev] = (uint32_t)ji | (2u << 16) | ((uint32_t)kk << 20); ++nev; delta -= kk; ji += kk; }
+                else ++ji;
+            } else ++ji;
+        }
+        if (n + delta < 50) { nev = 0; delta = 0; }                                // Profile.cpp:1623-1630: drop all indels
+        n_out = n + delta;
+        if (nev > EV_MAX || n_out > (int)slot) { atomicOr(flags, (uint32_t)FLAG_READSLOT); n_out = 0; nev = 0; }
+        atomicMax(&s_nmax, n_out);
+    }
     __syncthreads();
-    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
-    uint8_t* s_win = s_win_all + wib * 256; uint8_t* s_src = s_src_all + wib * SRC_CAP;
-    const uint32_t nwaves = gridDim.x * READS_WAVES;
-    for (uint32_t r = blockIdx.x * READS_WAVES + wib; r < n_reads; r += nwaves) {
-        for (int k = lane; k < tb.L; k += WAVE) s_win[k] = windows[(size_t)r * tb.L + k];
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        ReadJob job; job.uid = uids[r]; job.att = atts[r]; job.rd = is_read1[r] ? 0u : 1u;
-        predict_wave<MAXCH>(s_win, s_src, s_guide, lane, job, tb, key, 0u, slot, slot_b + (size_t)r * slot, slot_q + (size_t)r * slot, &lens[r], flags);
-        __builtin_amdgcn_wave_barrier();
+    const int nmax = s_nmax;
+
+    // ---- phase 2: per output base, workgroup-synchronous (Profile.cpp:1632-1694)
+    const bool second = rd != 0 && tb.subs2 != nullptr;
+    const uint32_t* __restrict__ subs = second ? tb.subs2 : tb.subs1;
+    const double* __restrict__ subs_d = second ? tb.subs2_d : tb.subs1_d;
+    // the ring holds the substitution rows of the workgroup's mate (explicit-window mode: of read 1)
+    const bool ring_subs_ok = FROM_PAIRS ? true : !second;
+    const uint32_t* __restrict__ ring_src = FROM_PAIRS ? subs : tb.subs1;
+    int ji = 0, ins_left = 0, ins_pos = 0, ins_t = 0, evi = 0;
+    uint32_t c0 = 5u, c1 = 5u;
+    uint32_t ob[4] = {0, 0, 0, 0}, oq[4] = {0, 0, 0, 0}; U4 db{};
+    char* my_b = slot_b + (size_t)r * slot; char* my_q = slot_q + (size_t)r * slot;
+    for (int jo = 0; jo < nmax; ++jo) {
+        if ((jo & 7) == 0) {                                                       // refill: ring covers bins [jo-4, jo+12)
+            const int first = jo == 0 ? 0 : jo + 4, last = min(B, jo + 12);
+            __syncthreads();
+            for (int idx = tid; idx < (last - first) * 80; idx += RB) {            // 80 uint4 per bin
+                const int bin = first + idx / 80, w = idx % 80;
+                uint4 v;
+                if (w < 64) v = *reinterpret_cast<const uint4*>(ring_src + ((size_t)(20 + w) * B + bin) * 4);
+                else { const int cc = (w - 64) >> 2; v = tb.qual_compact[((size_t)(cc * 5) * B + bin) * 4 + ((w - 64) & 3)]; }
+                reinterpret_cast<uint4*>(&s_ring[bin & (RING - 1)])[w] = v;
+            }
+            __syncthreads();
+        }
+        if (jo < n_out) {
+            uint32_t c2;
+            if (ins_left > 0) {                                                    // inserted base: randomInteger(0, N-1) -> never 'T'
+                const U4 di = draw4(key, ST_INDEL_INS, aux, uid, (uint32_t)ins_pos | ((uint32_t)(ins_t >> 2) << 16));
+                c2 = scale_draw(di.w[ins_t & 3], 0, 3); ++ins_t; --ins_left;
+            } else {
+                while (evi < nev && (my_ev[evi] & 0xFFFFu) == (uint32_t)ji && ((my_ev[evi] >> 16) & 3u) == 2u) { ji += (int)(my_ev[evi] >> 20); ++evi; }
+                c2 = my_win[ji];
+                if (evi < nev && (my_ev[evi] & 0xFFFFu) == (uint32_t)ji) { ins_left = (int)(my_ev[evi] >> 20); ins_pos = ji; ins_t = 0; ++evi; }
+                ++ji;
+            }
+            const int bin = n_out == B ? jo : jo * B / n_out;                       // binIndx = j*binCount/n
+            const bool in_ring = bin >= (jo & ~7) - 4 && bin < min(B, (jo & ~7) + 12) && bin >= 0;
+            if ((jo & 1) == 0) db = draw4(key, ST_READ, aux, uid, (uint32_t)jo >> 1);
+            const uint32_t xs = db.w[2 * (jo & 1)], xq = db.w[2 * (jo & 1) + 1];
+            const int ki = kmer_index(c0, c1, c2);
+            int k;
+            if (ki < 0) k = c2 < 4 ? (int)c2 : -1;
+            else {
+                const uint32_t row = ((uint32_t)ki * (uint32_t)B + (uint32_t)bin) * 4u;
+                if (xs == 0xFFFFFFFFu) k = (int)rand_indx_slow(subs_d + row, 4, xs);
+                else {
+                    const uint4 T = (ki >= 20 && in_ring && ring_subs_ok) ? s_ring[bin & (RING - 1)].subs[ki - 20] : *reinterpret_cast<const uint4*>(subs + row);
+                    k = (xs >= T.x) + (xs >= T.y) + (xs >= T.z);
+                }
+            }
+            uint32_t bc, qc;
+            if (k < 0) { bc = 'N'; qc = 33 + scale_draw(xq, 0, 20); }               // getRandBaseQuality
+            else {
+                bc = (uint32_t)"ACGT"[k];
+                const uint32_t qrow = (c2 * 4u + (uint32_t)k) * (uint32_t)B + (uint32_t)bin;
+                uint32_t qv;
+                if (xq == 0xFFFFFFFFu) qv = rand_indx_slow(tb.qual_d + qrow * (uint32_t)NQ, NQ, xq);
+                else {
+                    if ((uint32_t)k == c2 && in_ring) { const uint4* rw = s_ring[bin & (RING - 1)].qd[c2]; qv = compact_search(rw[0], rw[1], rw[2], rw[3], xq); }
+                    else { const uint4* rw = tb.qual_compact + (size_t)qrow * 4; qv = compact_search(rw[0], rw[1], rw[2], rw[3], xq); }
+                    if (qv == 255u) qv = qual_lookup(tb.qual + qrow * (uint32_t)NQ, tb.qual_d + qrow * (uint32_t)NQ, tb.qual_guide + (size_t)qrow * 17u, xq);
+                }
+                qc = 33 + qv;
+            }
+            const int w = (jo >> 2) & 3, sh = 8 * (jo & 3);
+            ob[w] |= bc << sh; oq[w] |= qc << sh;
+            if ((jo & 15) == 15 || jo == n_out - 1) {                              // 16 output characters per store
+                const int o = jo & ~15;
+                *reinterpret_cast<uint4*>(my_b + o) = make_uint4(ob[0], ob[1], ob[2], ob[3]);
+                *reinterpret_cast<uint4*>(my_q + o) = make_uint4(oq[0], oq[1], oq[2], oq[3]);
+                ob[0] = ob[1] = ob[2] = ob[3] = 0; oq[0] = oq[1] = oq[2] = oq[3] = 0;
+            }
+            c0 = c1; c1 = c2;
+        }
+    }
+    if (live) {
+        lens[r] = (uint32_t)n_out;
+        // "@<ampIdx>#<fragCount>[/1|/2]\n" + seq + "\n+\n" + qual + "\n"   (Amplicon.cpp:459-466,497-504)
+        if (FROM_PAIRS) sz[pi] = n_out == 0 ? 0u : 1u + dec_digits(pr.amp) + 1u + dec_digits(pr.att + 1) + (paired ? 2u : 0u) + 1u + 2u * (uint32_t)n_out + 4u;
     }
 }
 
@@ -1002,32 +972,30 @@ void launch_pair_offsets(hipStream_t s, const uint32_t* rn, uint32_t ac, int pai
     if (paired) (void)rocprim::exclusive_scan(temp, temp_bytes, rocprim::make_transform_iterator(rn, HalfUp()), pair_cnt_off, 0u, (size_t)ac + 1, rocprim::plus<uint32_t>(), s);
     else (void)rocprim::exclusive_scan(temp, temp_bytes, rn, pair_cnt_off, 0u, (size_t)ac + 1, rocprim::plus<uint32_t>(), s);
 }
-static inline size_t reads_lds_bytes(const DevTables& tb, int waves) { return (((size_t)16 * tb.bins * 17 + 15) & ~(size_t)15) + (size_t)waves * (256 + SRC_CAP); }
-static inline uint32_t reads_grid(uint64_t nreads, int waves) {
-    uint32_t grid = cdiv(nreads, (uint32_t)waves * 2);               // >= 2 reads per wave before more workgroups are added
-    const uint32_t cap = 256 * 3;                                   // up to three 8-wave workgroups per CU, each stages the guide table once
-    return grid < 1 ? 1 : (grid > cap ? cap : grid);
+static inline size_t reads_lds_bytes(const DevTables& tb) {
+    const size_t WS = ((size_t)tb.L + 7) & ~(size_t)3;
+    return RING * sizeof(RingBin) + RB * 8 + RB * 4 + RB * EV_MAX * 4 + RB * WS + 16;
 }
 void launch_reads(hipStream_t s, const uint8_t* g, DevErrPool spool, DevErrPool fpool,
                   const PairRec* pairs, uint32_t np, uint32_t amp_index_base, DevTables tb, const DevTables* d_tb, RngKey key, int paired, uint32_t slot,
                   char* slot_b, char* slot_q, uint32_t* lens, uint32_t* sizes1, uint32_t* sizes2, uint32_t* flags) {
     if (np == 0) return;
-    const uint64_t nreads = paired ? 2ull * np : np;
-    const int nch = (tb.L + 63) / 64;
-    static const uint32_t ablate = getenv("SCS_ABLATE") ? (uint32_t)atoi(getenv("SCS_ABLATE")) : 0u;   // timing experiments only (wrong output): 1 subs, 2 quality, 4 Philox, 8 genome gather
-#define SCS_LAUNCH_READS(N) hipLaunchKernelGGL(k_reads<N>, dim3(reads_grid(nreads, ReadsGeom<N>::waves)), dim3(64 * ReadsGeom<N>::waves), reads_lds_bytes(tb, ReadsGeom<N>::waves), s, g, spool, fpool, pairs, np, \
-                                                amp_index_base, d_tb, key, paired, ablate, slot, slot_b, slot_q, lens, sizes1, sizes2, flags)
-    if (nch <= 2) SCS_LAUNCH_READS(2); else if (nch == 3) SCS_LAUNCH_READS(3); else SCS_LAUNCH_READS(4);
-#undef SCS_LAUNCH_READS
+    (void)amp_index_base;
+    static bool attr_set = false;                                  // > 64 KB of dynamic LDS needs the opt-in
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_reads<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+    const uint32_t groups = cdiv(np, RB);
+    hipLaunchKernelGGL(k_reads<true>, dim3(paired ? 2 * groups : groups), dim3(RB), reads_lds_bytes(tb), s, g, spool, fpool, pairs, np, paired,
+                       (const uint8_t*)nullptr, (const uint64_t*)nullptr, (const uint32_t*)nullptr, (const uint8_t*)nullptr, 0u, d_tb, key, slot, slot_b, slot_q,
+                       lens, sizes1, sizes2, flags);
 }
 void launch_predict_windows(hipStream_t s, const uint8_t* windows, uint32_t n_reads, const uint64_t* uids, const uint32_t* atts,
                             const uint8_t* is_read1, DevTables tb, const DevTables* d_tb, RngKey key, uint32_t slot, char* slot_b, char* slot_q, uint32_t* lens, uint32_t* flags) {
     if (n_reads == 0) return;
-    const int nch = (tb.L + 63) / 64;
-#define SCS_LAUNCH_PW(N) hipLaunchKernelGGL(k_predict_windows<N>, dim3(reads_grid(n_reads, ReadsGeom<N>::waves)), dim3(64 * ReadsGeom<N>::waves), reads_lds_bytes(tb, ReadsGeom<N>::waves), s, windows, n_reads, uids, atts, \
-                                             is_read1, d_tb, key, slot, slot_b, slot_q, lens, flags)
-    if (nch <= 2) SCS_LAUNCH_PW(2); else if (nch == 3) SCS_LAUNCH_PW(3); else SCS_LAUNCH_PW(4);
-#undef SCS_LAUNCH_PW
+    static bool attr_set = false;
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_reads<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+    DevErrPool none{};
+    hipLaunchKernelGGL(k_reads<false>, dim3(cdiv(n_reads, RB)), dim3(RB), reads_lds_bytes(tb), s, (const uint8_t*)nullptr, none, none, (const PairRec*)nullptr, 0u, 0,
+                       windows, uids, atts, is_read1, n_reads, d_tb, key, slot, slot_b, slot_q, lens, (uint32_t*)nullptr, (uint32_t*)nullptr, flags);
 }
 void launch_format(hipStream_t s, const PairRec* pairs, uint32_t np, uint32_t amp_index_base, int paired, uint32_t slot, const char* slot_b,
                    const char* slot_q, const uint32_t* lens, const uint64_t* off1, const uint64_t* off2, char* out1, char* out2) {
