@@ -374,7 +374,7 @@ template <bool FROM_PAIRS>
 __global__ void __launch_bounds__(RB) k_reads(const uint8_t* __restrict__ g, DevErrPool spool, DevErrPool fpool, const PairRec* __restrict__ pairs,
                                               uint32_t np, int paired, const uint8_t* __restrict__ windows, const uint64_t* __restrict__ uids,
                                               const uint32_t* __restrict__ atts, const uint8_t* __restrict__ is_read1, uint32_t n_explicit,
-                                              const DevTables* __restrict__ tbp, RngKey key, uint32_t slot, char* __restrict__ slot_b,
+                                              const DevTables* __restrict__ tbp, RngKey key, uint32_t slot, uint32_t n_slots_cap, char* __restrict__ slot_b,
                                               char* __restrict__ slot_q, uint32_t* __restrict__ lens, uint32_t* __restrict__ sizes1,
                                               uint32_t* __restrict__ sizes2, uint32_t* __restrict__ flags) {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
@@ -403,6 +403,7 @@ __global__ void __launch_bounds__(RB) k_reads(const uint8_t* __restrict__ g, Dev
         if (valid) { uid = uids[r]; att = atts[r]; rd = is_read1[r] ? 0u : 1u; }
     }
     uint32_t* sz = FROM_PAIRS ? (rd ? sizes2 : sizes1) : nullptr;
+    if (valid && r >= n_slots_cap) { atomicOr(flags, (uint32_t)FLAG_INTERNAL); valid = false; }   // never write outside the slot buffers
     bool live = valid && (!FROM_PAIRS || pr.isz != 0);
     if (FROM_PAIRS && valid && !live) { lens[r] = 0; sz[pi] = 0; }
 
@@ -451,7 +452,7 @@ __global__ void __launch_bounds__(RB) k_reads(const uint8_t* __restrict__ g, Dev
         uint32_t cur = 0xFFFFFFFFu; U4 d{};
         for (int ji = 0; ji < n;) {
             if ((uint32_t)(ji >> 1) != cur) { cur = (uint32_t)(ji >> 1); d = draw4(key, ST_INDEL, aux, uid, cur); }
-            const uint32_t w0 = d.w[2 * (ji & 1)], w1 = d.w[2 * (ji & 1) + 1];
+            const uint32_t w0 = (ji & 1) ? d.w[2] : d.w[0], w1 = (ji & 1) ? d.w[3] : d.w[1];
             if (w0 < tb.t_insert) {                                                // p <= insertRate
                 const uint32_t k = rand_indx_thr(tb.ins_t, tb.ins_d, (uint32_t)tb.n_ins, draw4(key, ST_INDEL_LEN, aux, uid, (uint32_t)ji).w[0]);
                 if (k > 0) { if (nev < EV_MAX) my_ev[nev] = (uint32_t)ji | (1u << 16) | (k << 20); ++nev; delta += (int)k; }
@@ -498,7 +499,8 @@ __global__ void __launch_bounds__(RB) k_reads(const uint8_t* __restrict__ g, Dev
             uint32_t c2;
             if (ins_left > 0) {                                                    // inserted base: randomInteger(0, N-1) -> never 'T'
                 const U4 di = draw4(key, ST_INDEL_INS, aux, uid, (uint32_t)ins_pos | ((uint32_t)(ins_t >> 2) << 16));
-                c2 = scale_draw(di.w[ins_t & 3], 0, 3); ++ins_t; --ins_left;
+                const int wi = ins_t & 3;
+                c2 = scale_draw(wi == 0 ? di.w[0] : wi == 1 ? di.w[1] : wi == 2 ? di.w[2] : di.w[3], 0, 3); ++ins_t; --ins_left;
             } else {
                 while (evi < nev && (my_ev[evi] & 0xFFFFu) == (uint32_t)ji && ((my_ev[evi] >> 16) & 3u) == 2u) { ji += (int)(my_ev[evi] >> 20); ++evi; }
                 c2 = my_win[ji];
@@ -508,7 +510,7 @@ __global__ void __launch_bounds__(RB) k_reads(const uint8_t* __restrict__ g, Dev
             const int bin = n_out == B ? jo : jo * B / n_out;                       // binIndx = j*binCount/n
             const bool in_ring = bin >= (jo & ~7) - 4 && bin < min(B, (jo & ~7) + 12) && bin >= 0;
             if ((jo & 1) == 0) db = draw4(key, ST_READ, aux, uid, (uint32_t)jo >> 1);
-            const uint32_t xs = db.w[2 * (jo & 1)], xq = db.w[2 * (jo & 1) + 1];
+            const uint32_t xs = (jo & 1) ? db.w[2] : db.w[0], xq = (jo & 1) ? db.w[3] : db.w[1];
             const int ki = kmer_index(c0, c1, c2);
             int k;
             if (ki < 0) k = c2 < 4 ? (int)c2 : -1;
@@ -535,7 +537,9 @@ __global__ void __launch_bounds__(RB) k_reads(const uint8_t* __restrict__ g, Dev
                 qc = 33 + qv;
             }
             const int w = (jo >> 2) & 3, sh = 8 * (jo & 3);
-            ob[w] |= bc << sh; oq[w] |= qc << sh;
+            const uint32_t bsh = bc << sh, qsh = qc << sh;
+#pragma unroll
+            for (int z = 0; z < 4; ++z) { ob[z] |= (z == w) ? bsh : 0u; oq[z] |= (z == w) ? qsh : 0u; }
             if ((jo & 15) == 15 || jo == n_out - 1) {                              // 16 output characters per store
                 const int o = jo & ~15;
                 *reinterpret_cast<uint4*>(my_b + o) = make_uint4(ob[0], ob[1], ob[2], ob[3]);
@@ -571,7 +575,7 @@ __global__ void __launch_bounds__(256) k_format(const PairRec* __restrict__ pair
     for (uint32_t r = blockIdx.x * 4 + wib; r < nreads; r += nwaves) {
         const uint32_t pi = paired ? r >> 1 : r, rd = paired ? (r & 1u) : 0u;
         const uint32_t nl = lens[r];
-        if (nl == 0) continue;
+        if (nl == 0 || nl > slot) continue;
         const PairRec pr = pairs[pi];
         char* dst = (rd ? out2 : out1) + (rd ? off2[pi] : off1[pi]);
         uint32_t h = 0;
@@ -985,8 +989,8 @@ void launch_reads(hipStream_t s, const uint8_t* g, DevErrPool spool, DevErrPool 
     if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_reads<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
     const uint32_t groups = cdiv(np, RB);
     hipLaunchKernelGGL(k_reads<true>, dim3(paired ? 2 * groups : groups), dim3(RB), reads_lds_bytes(tb), s, g, spool, fpool, pairs, np, paired,
-                       (const uint8_t*)nullptr, (const uint64_t*)nullptr, (const uint32_t*)nullptr, (const uint8_t*)nullptr, 0u, d_tb, key, slot, slot_b, slot_q,
-                       lens, sizes1, sizes2, flags);
+                       (const uint8_t*)nullptr, (const uint64_t*)nullptr, (const uint32_t*)nullptr, (const uint8_t*)nullptr, 0u, d_tb, key, slot,
+                       (uint32_t)(paired ? 2ull * np : np), slot_b, slot_q, lens, sizes1, sizes2, flags);
 }
 void launch_predict_windows(hipStream_t s, const uint8_t* windows, uint32_t n_reads, const uint64_t* uids, const uint32_t* atts,
                             const uint8_t* is_read1, DevTables tb, const DevTables* d_tb, RngKey key, uint32_t slot, char* slot_b, char* slot_q, uint32_t* lens, uint32_t* flags) {
@@ -995,7 +999,7 @@ void launch_predict_windows(hipStream_t s, const uint8_t* windows, uint32_t n_re
     if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_reads<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
     DevErrPool none{};
     hipLaunchKernelGGL(k_reads<false>, dim3(cdiv(n_reads, RB)), dim3(RB), reads_lds_bytes(tb), s, (const uint8_t*)nullptr, none, none, (const PairRec*)nullptr, 0u, 0,
-                       windows, uids, atts, is_read1, n_reads, d_tb, key, slot, slot_b, slot_q, lens, (uint32_t*)nullptr, (uint32_t*)nullptr, flags);
+                       windows, uids, atts, is_read1, n_reads, d_tb, key, slot, n_reads, slot_b, slot_q, lens, (uint32_t*)nullptr, (uint32_t*)nullptr, flags);
 }
 void launch_format(hipStream_t s, const PairRec* pairs, uint32_t np, uint32_t amp_index_base, int paired, uint32_t slot, const char* slot_b,
                    const char* slot_q, const uint32_t* lens, const uint64_t* off1, const uint64_t* off2, char* out1, char* out2) {
