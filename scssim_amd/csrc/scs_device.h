@@ -123,6 +123,9 @@ void launch_detlog(hipStream_t s, const double* x, uint32_t n, double* out);
 // gathers up to 12 device scalars (4 or 8 bytes wide) into mail[dsts[i]] (u64 each)
 void launch_mail(hipStream_t s, const void* const* srcs, const int* widths, const int* dsts, int n, unsigned long long* mail);
 
+// first error of any kernel launch / attribute call since the last call (hipSuccess if none)
+hipError_t take_launch_error();
+
 // device-wide exclusive scans (n inputs -> n+1 outputs, last = total)
 size_t scan_temp_bytes(size_t n);
 void exclusive_scan_u32(hipStream_t s, const uint32_t* in, uint32_t* out, size_t n, void* temp, size_t temp_bytes);

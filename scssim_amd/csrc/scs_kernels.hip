@@ -902,6 +902,10 @@ struct HalfUp { __host__ __device__ uint32_t operator()(uint32_t v) const { retu
 // are capped at 256 CUs x 8 workgroups.
 // ------------------------------------------------------------------------------------------------
 static inline uint32_t cdiv(uint64_t a, uint32_t b) { return (uint32_t)((a + b - 1) / b); }
+// launch errors are latched here and surfaced by the pipeline at its next check (take_launch_error)
+static thread_local hipError_t g_launch_err = hipSuccess;
+static inline void note_launch(hipError_t e) { if (e != hipSuccess && g_launch_err == hipSuccess) g_launch_err = e; }
+hipError_t take_launch_error() { note_launch(hipGetLastError()); const hipError_t e = g_launch_err; g_launch_err = hipSuccess; return e; }
 static const uint32_t kMaxStrideGrid = 256 * 8;
 
 void launch_attach_frags(hipStream_t s, const uint8_t* g, DevFrags fr, const uint32_t* slot_off, uint32_t* slots, uint32_t* slot_tmpl,
@@ -985,8 +989,8 @@ void launch_reads(hipStream_t s, const uint8_t* g, DevErrPool spool, DevErrPool 
                   char* slot_b, char* slot_q, uint32_t* lens, uint32_t* sizes1, uint32_t* sizes2, uint32_t* flags) {
     if (np == 0) return;
     (void)amp_index_base;
-    static bool attr_set = false;                                  // > 64 KB of dynamic LDS needs the opt-in
-    if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_reads<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+    // > 64 KB of dynamic LDS needs the opt-in; the limit is raised to what this profile needs
+    note_launch(hipFuncSetAttribute((const void*)k_reads<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)reads_lds_bytes(tb)));
     const uint32_t groups = cdiv(np, RB);
     hipLaunchKernelGGL(k_reads<true>, dim3(paired ? 2 * groups : groups), dim3(RB), reads_lds_bytes(tb), s, g, spool, fpool, pairs, np, paired,
                        (const uint8_t*)nullptr, (const uint64_t*)nullptr, (const uint32_t*)nullptr, (const uint8_t*)nullptr, 0u, d_tb, key, slot,
@@ -995,8 +999,7 @@ void launch_reads(hipStream_t s, const uint8_t* g, DevErrPool spool, DevErrPool 
 void launch_predict_windows(hipStream_t s, const uint8_t* windows, uint32_t n_reads, const uint64_t* uids, const uint32_t* atts,
                             const uint8_t* is_read1, DevTables tb, const DevTables* d_tb, RngKey key, uint32_t slot, char* slot_b, char* slot_q, uint32_t* lens, uint32_t* flags) {
     if (n_reads == 0) return;
-    static bool attr_set = false;
-    if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_reads<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+    note_launch(hipFuncSetAttribute((const void*)k_reads<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)reads_lds_bytes(tb)));
     DevErrPool none{};
     hipLaunchKernelGGL(k_reads<false>, dim3(cdiv(n_reads, RB)), dim3(RB), reads_lds_bytes(tb), s, (const uint8_t*)nullptr, none, none, (const PairRec*)nullptr, 0u, 0,
                        windows, uids, atts, is_read1, n_reads, d_tb, key, slot, n_reads, slot_b, slot_q, lens, (uint32_t*)nullptr, (uint32_t*)nullptr, flags);

@@ -152,6 +152,7 @@ struct scs_ctx {
 namespace {
 
 void check_flags(scs_ctx* c) {
+    { const hipError_t le = take_launch_error(); if (le != hipSuccess) throw ScsError(SCS_EDEVICE, std::string("kernel launch failed: ") + hipGetErrorString(le)); }
     uint32_t f = 0;
     HIP_OK(hipMemcpyAsync(&f, c->flags.p, 4, hipMemcpyDeviceToHost, c->stream));
     HIP_OK(hipStreamSynchronize(c->stream));
@@ -548,6 +549,7 @@ void do_yield(scs_ctx* c, const OutTarget& tg, uint64_t* n1_out, uint64_t* n2_ou
                      c->sizes2.as<uint32_t>(), c->flags.as<uint32_t>());
         c->tm_reads.end(s);
         c->tm_reads.units += np;
+        { const hipError_t le = take_launch_error(); if (le != hipSuccess) throw ScsError(SCS_EDEVICE, std::string("k_reads launch failed: ") + hipGetErrorString(le)); }
         exclusive_scan_u32_to_u64(s, c->sizes1.as<uint32_t>(), c->off1.as<uint64_t>(), np, c->scan_tmp.p, c->scan_tmp.cap);
         if (paired) exclusive_scan_u32_to_u64(s, c->sizes2.as<uint32_t>(), c->off2.as<uint64_t>(), np, c->scan_tmp.p, c->scan_tmp.cap);
         uint64_t b1 = 0, b2 = 0;
