@@ -418,11 +418,24 @@ __global__ void __launch_bounds__(RB) k_reads(const uint8_t* __restrict__ g, Dev
         }
         s_gbase[tid] = gb; s_gflag[tid] = gf;
         __syncthreads();
-        for (int q = 0; q < 64; ++q) {
-            const int rr = wib * 64 + q; const uint32_t f = s_gflag[rr];
-            if (!(f & 4u)) continue;
-            const int64_t b0 = s_gbase[rr], d = (f & 2u) ? -1 : 1;
-            for (int k = lane; k < n; k += WAVE) { uint32_t c = g[b0 + d * (int64_t)k]; if (f & 1u) c = comp_code((uint8_t)c); s_win[(size_t)rr * WS + k] = (uint8_t)c; }
+        for (int q0 = 0; q0 < 64; q0 += 8) {                                        // 8 reads x up to 4 chunks of loads in flight per lane
+            uint32_t cv[8][4];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int rr = wib * 64 + q0 + u; const uint32_t f = s_gflag[rr];
+                const int64_t b0 = s_gbase[rr], d = (f & 2u) ? -1 : 1;
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) { const int k = cc * WAVE + lane; cv[u][cc] = ((f & 4u) && k < n) ? (uint32_t)g[b0 + d * (int64_t)k] : 4u; }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int rr = wib * 64 + q0 + u; const uint32_t f = s_gflag[rr];
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) {
+                    const int k = cc * WAVE + lane;
+                    if ((f & 4u) && k < n) s_win[(size_t)rr * WS + k] = (uint8_t)((f & 1u) ? (uint32_t)comp_code((uint8_t)cv[u][cc]) : cv[u][cc]);
+                }
+            }
         }
         __syncthreads();
         if (live) {
@@ -482,18 +495,31 @@ __global__ void __launch_bounds__(RB) k_reads(const uint8_t* __restrict__ g, Dev
     uint32_t c0 = 5u, c1 = 5u;
     uint32_t ob[4] = {0, 0, 0, 0}, oq[4] = {0, 0, 0, 0}; U4 db{};
     char* my_b = slot_b + (size_t)r * slot; char* my_q = slot_q + (size_t)r * slot;
+    // ring maintenance: group g = jo/8 needs bins [8g-4, 8g+12).  Bins [0,12) are loaded up front; the 8 bins a later
+    // group adds are prefetched into registers one group ahead and only written to LDS at the group boundary.
+    auto ring_entry = [&](int bin, int w) -> uint4 {                              // entry w (0..79) of a bin's ring image
+        if (w < 64) return *reinterpret_cast<const uint4*>(ring_src + ((size_t)(20 + w) * B + bin) * 4);
+        const int cc = (w - 64) >> 2;
+        return tb.qual_compact[((size_t)(cc * 5) * B + bin) * 4 + ((w - 64) & 3)];
+    };
+    uint4 pre[3];
+    auto prefetch = [&](int first) {                                              // bins [first, first+8) -> registers
+#pragma unroll
+        for (int u = 0; u < 3; ++u) { const int idx = tid + u * RB; const int bin = first + idx / 80; pre[u] = (idx < 640 && bin < B) ? ring_entry(bin, idx % 80) : make_uint4(0, 0, 0, 0); }
+    };
+    auto commit = [&](int first) {                                                // registers -> LDS slots of bins [first, first+8)
+#pragma unroll
+        for (int u = 0; u < 3; ++u) { const int idx = tid + u * RB; const int bin = first + idx / 80; if (idx < 640 && bin < B) reinterpret_cast<uint4*>(&s_ring[bin & (RING - 1)])[idx % 80] = pre[u]; }
+    };
+    for (int idx = tid; idx < min(B, 12) * 80; idx += RB) reinterpret_cast<uint4*>(&s_ring[(idx / 80) & (RING - 1)])[idx % 80] = ring_entry(idx / 80, idx % 80);
+    prefetch(12);
+    __syncthreads();
     for (int jo = 0; jo < nmax; ++jo) {
-        if ((jo & 7) == 0) {                                                       // refill: ring covers bins [jo-4, jo+12)
-            const int first = jo == 0 ? 0 : jo + 4, last = min(B, jo + 12);
+        if ((jo & 7) == 0 && jo > 0) {
+            __syncthreads();                                                       // everyone is past the bins being replaced
+            commit(jo + 4);
             __syncthreads();
-            for (int idx = tid; idx < (last - first) * 80; idx += RB) {            // 80 uint4 per bin
-                const int bin = first + idx / 80, w = idx % 80;
-                uint4 v;
-                if (w < 64) v = *reinterpret_cast<const uint4*>(ring_src + ((size_t)(20 + w) * B + bin) * 4);
-                else { const int cc = (w - 64) >> 2; v = tb.qual_compact[((size_t)(cc * 5) * B + bin) * 4 + ((w - 64) & 3)]; }
-                reinterpret_cast<uint4*>(&s_ring[bin & (RING - 1)])[w] = v;
-            }
-            __syncthreads();
+            prefetch(jo + 12);
         }
         if (jo < n_out) {
             uint32_t c2;
