@@ -374,12 +374,13 @@ template <bool FROM_PAIRS>
 __global__ void __launch_bounds__(RB) k_reads(const uint8_t* __restrict__ g, DevErrPool spool, DevErrPool fpool, const PairRec* __restrict__ pairs,
                                               uint32_t np, int paired, const uint8_t* __restrict__ windows, const uint64_t* __restrict__ uids,
                                               const uint32_t* __restrict__ atts, const uint8_t* __restrict__ is_read1, uint32_t n_explicit,
-                                              const DevTables* __restrict__ tbp, RngKey key, uint32_t slot, uint32_t n_slots_cap, char* __restrict__ slot_b,
+                                              const DevTables* __restrict__ tbp, RngKey key, uint32_t slot, uint32_t n_slots_cap, uint32_t ablate, char* __restrict__ slot_b,
                                               char* __restrict__ slot_q, uint32_t* __restrict__ lens, uint32_t* __restrict__ sizes1,
                                               uint32_t* __restrict__ sizes2, uint32_t* __restrict__ flags) {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
-    const DevTables& tb = *tbp;
+    const DevTables tb = *tbp;                                             // one uniform load of the descriptor; fields stay in SGPRs
     const int n = tb.L, B = tb.bins;
+    const uint32_t t_insert = tb.t_insert, t_delete = tb.t_delete;
     const uint32_t WS = ((uint32_t)n + 7u) & ~3u;                          // window row stride
     RingBin* s_ring = reinterpret_cast<RingBin*>(s_dyn);                   // [RING]
     int64_t* s_gbase = reinterpret_cast<int64_t*>(s_dyn + RING * sizeof(RingBin));   // [RB]
@@ -425,7 +426,7 @@ __global__ void __launch_bounds__(RB) k_reads(const uint8_t* __restrict__ g, Dev
                 const int rr = wib * 64 + q0 + u; const uint32_t f = s_gflag[rr];
                 const int64_t b0 = s_gbase[rr], d = (f & 2u) ? -1 : 1;
 #pragma unroll
-                for (int cc = 0; cc < 4; ++cc) { const int k = cc * WAVE + lane; cv[u][cc] = ((f & 4u) && k < n) ? (uint32_t)g[b0 + d * (int64_t)k] : 4u; }
+                for (int cc = 0; cc < 4; ++cc) { const int k = cc * WAVE + lane; cv[u][cc] = ((f & 4u) && k < n && !(ablate & 1u)) ? (uint32_t)g[b0 + d * (int64_t)k] : (uint32_t)(k & 3); }
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -461,16 +462,17 @@ __global__ void __launch_bounds__(RB) k_reads(const uint8_t* __restrict__ g, Dev
     const uint32_t aux = rd | (att << 1);
     uint32_t* my_ev = s_ev + tid * EV_MAX;
     int nev = 0, delta = 0, n_out = 0;
-    if (live) {
+    if (live && (ablate & 2u)) { n_out = n; atomicMax(&s_nmax, n_out); }
+    else if (live) {
         uint32_t cur = 0xFFFFFFFFu; U4 d{};
         for (int ji = 0; ji < n;) {
             if ((uint32_t)(ji >> 1) != cur) { cur = (uint32_t)(ji >> 1); d = draw4(key, ST_INDEL, aux, uid, cur); }
             const uint32_t w0 = (ji & 1) ? d.w[2] : d.w[0], w1 = (ji & 1) ? d.w[3] : d.w[1];
-            if (w0 < tb.t_insert) {                                                // p <= insertRate
+            if (w0 < t_insert) {                                                   // p <= insertRate
                 const uint32_t k = rand_indx_thr(tb.ins_t, tb.ins_d, (uint32_t)tb.n_ins, draw4(key, ST_INDEL_LEN, aux, uid, (uint32_t)ji).w[0]);
                 if (k > 0) { if (nev < EV_MAX) my_ev[nev] = (uint32_t)ji | (1u << 16) | (k << 20); ++nev; delta += (int)k; }
                 ++ji;
-            } else if (w1 < tb.t_delete) {                                         // p < delRate/(1-insertRate)
+            } else if (w1 < t_delete) {                                         // p < delRate/(1-insertRate)
                 const uint32_t k = rand_indx_thr(tb.del_t, tb.del_d, (uint32_t)tb.n_del, draw4(key, ST_INDEL_LEN, aux, uid, (uint32_t)ji).w[0]);
                 if (k > 0) { const int kk = (int)k < n - ji ? (int)k : n - ji; if (nev < EV_MAX) my_ev[nev] = (uint32_t)ji | (2u << 16) | ((uint32_t)kk << 20); ++nev; delta -= kk; ji += kk; }
                 else ++ji;
@@ -492,6 +494,7 @@ __global__ void __launch_bounds__(RB) k_reads(const uint8_t* __restrict__ g, Dev
     const bool ring_subs_ok = FROM_PAIRS ? true : !second;
     const uint32_t* __restrict__ ring_src = FROM_PAIRS ? subs : tb.subs1;
     int ji = 0, ins_left = 0, ins_pos = 0, ins_t = 0, evi = 0;
+    int bin = 0, bin_acc = 0;                                                      // bin = floor(jo * B / n_out), kept incrementally
     uint32_t c0 = 5u, c1 = 5u;
     uint32_t ob[4] = {0, 0, 0, 0}, oq[4] = {0, 0, 0, 0}; U4 db{};
     char* my_b = slot_b + (size_t)r * slot; char* my_q = slot_q + (size_t)r * slot;
@@ -533,11 +536,11 @@ __global__ void __launch_bounds__(RB) k_reads(const uint8_t* __restrict__ g, Dev
                 if (evi < nev && (my_ev[evi] & 0xFFFFu) == (uint32_t)ji) { ins_left = (int)(my_ev[evi] >> 20); ins_pos = ji; ins_t = 0; ++evi; }
                 ++ji;
             }
-            const int bin = n_out == B ? jo : jo * B / n_out;                       // binIndx = j*binCount/n
+            // binIndx = j*binCount/n (Profile.cpp:1668) without the division: bin_acc = jo*B - bin*n_out
             const bool in_ring = bin >= (jo & ~7) - 4 && bin < min(B, (jo & ~7) + 12) && bin >= 0;
-            if ((jo & 1) == 0) db = draw4(key, ST_READ, aux, uid, (uint32_t)jo >> 1);
+            if ((jo & 1) == 0) { if (ablate & 16u) { db.w[0] = (uint32_t)jo * 2654435761u + (uint32_t)uid; db.w[1] = db.w[0] * 40503u; db.w[2] = db.w[1] + 7u; db.w[3] = db.w[2] * 9u; } else db = draw4(key, ST_READ, aux, uid, (uint32_t)jo >> 1); }
             const uint32_t xs = (jo & 1) ? db.w[2] : db.w[0], xq = (jo & 1) ? db.w[3] : db.w[1];
-            const int ki = kmer_index(c0, c1, c2);
+            const int ki = (ablate & 4u) ? -1 : kmer_index(c0, c1, c2);
             int k;
             if (ki < 0) k = c2 < 4 ? (int)c2 : -1;
             else {
@@ -554,7 +557,8 @@ __global__ void __launch_bounds__(RB) k_reads(const uint8_t* __restrict__ g, Dev
                 bc = (uint32_t)"ACGT"[k];
                 const uint32_t qrow = (c2 * 4u + (uint32_t)k) * (uint32_t)B + (uint32_t)bin;
                 uint32_t qv;
-                if (xq == 0xFFFFFFFFu) qv = rand_indx_slow(tb.qual_d + qrow * (uint32_t)NQ, NQ, xq);
+                if (ablate & 4u) qv = xq >> 27;
+                else if (xq == 0xFFFFFFFFu) qv = rand_indx_slow(tb.qual_d + qrow * (uint32_t)NQ, NQ, xq);
                 else {
                     if ((uint32_t)k == c2 && in_ring) { const uint4* rw = s_ring[bin & (RING - 1)].qd[c2]; qv = compact_search(rw[0], rw[1], rw[2], rw[3], xq); }
                     else { const uint4* rw = tb.qual_compact + (size_t)qrow * 4; qv = compact_search(rw[0], rw[1], rw[2], rw[3], xq); }
@@ -566,13 +570,14 @@ __global__ void __launch_bounds__(RB) k_reads(const uint8_t* __restrict__ g, Dev
             const uint32_t bsh = bc << sh, qsh = qc << sh;
 #pragma unroll
             for (int z = 0; z < 4; ++z) { ob[z] |= (z == w) ? bsh : 0u; oq[z] |= (z == w) ? qsh : 0u; }
-            if ((jo & 15) == 15 || jo == n_out - 1) {                              // 16 output characters per store
+            if (((jo & 15) == 15 || jo == n_out - 1) && !(ablate & 8u)) {          // 16 output characters per store
                 const int o = jo & ~15;
                 *reinterpret_cast<uint4*>(my_b + o) = make_uint4(ob[0], ob[1], ob[2], ob[3]);
                 *reinterpret_cast<uint4*>(my_q + o) = make_uint4(oq[0], oq[1], oq[2], oq[3]);
                 ob[0] = ob[1] = ob[2] = ob[3] = 0; oq[0] = oq[1] = oq[2] = oq[3] = 0;
             }
             c0 = c1; c1 = c2;
+            bin_acc += B; while (bin_acc >= n_out) { bin_acc -= n_out; ++bin; }
         }
     }
     if (live) {
@@ -1018,9 +1023,10 @@ void launch_reads(hipStream_t s, const uint8_t* g, DevErrPool spool, DevErrPool 
     // > 64 KB of dynamic LDS needs the opt-in; the limit is raised to what this profile needs
     note_launch(hipFuncSetAttribute((const void*)k_reads<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)reads_lds_bytes(tb)));
     const uint32_t groups = cdiv(np, RB);
+    static const uint32_t ablate = getenv("SCS_ABLATE") ? (uint32_t)atoi(getenv("SCS_ABLATE")) : 0u;   // timing experiments only (wrong output): 1 gather, 2 indel pass, 4 tables, 8 stores, 16 Philox
     hipLaunchKernelGGL(k_reads<true>, dim3(paired ? 2 * groups : groups), dim3(RB), reads_lds_bytes(tb), s, g, spool, fpool, pairs, np, paired,
                        (const uint8_t*)nullptr, (const uint64_t*)nullptr, (const uint32_t*)nullptr, (const uint8_t*)nullptr, 0u, d_tb, key, slot,
-                       (uint32_t)(paired ? 2ull * np : np), slot_b, slot_q, lens, sizes1, sizes2, flags);
+                       (uint32_t)(paired ? 2ull * np : np), ablate, slot_b, slot_q, lens, sizes1, sizes2, flags);
 }
 void launch_predict_windows(hipStream_t s, const uint8_t* windows, uint32_t n_reads, const uint64_t* uids, const uint32_t* atts,
                             const uint8_t* is_read1, DevTables tb, const DevTables* d_tb, RngKey key, uint32_t slot, char* slot_b, char* slot_q, uint32_t* lens, uint32_t* flags) {
@@ -1028,7 +1034,7 @@ void launch_predict_windows(hipStream_t s, const uint8_t* windows, uint32_t n_re
     note_launch(hipFuncSetAttribute((const void*)k_reads<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)reads_lds_bytes(tb)));
     DevErrPool none{};
     hipLaunchKernelGGL(k_reads<false>, dim3(cdiv(n_reads, RB)), dim3(RB), reads_lds_bytes(tb), s, (const uint8_t*)nullptr, none, none, (const PairRec*)nullptr, 0u, 0,
-                       windows, uids, atts, is_read1, n_reads, d_tb, key, slot, n_reads, slot_b, slot_q, lens, (uint32_t*)nullptr, (uint32_t*)nullptr, flags);
+                       windows, uids, atts, is_read1, n_reads, d_tb, key, slot, n_reads, 0u, slot_b, slot_q, lens, (uint32_t*)nullptr, (uint32_t*)nullptr, flags);
 }
 void launch_format(hipStream_t s, const PairRec* pairs, uint32_t np, uint32_t amp_index_base, int paired, uint32_t slot, const char* slot_b,
                    const char* slot_q, const uint32_t* lens, const uint64_t* off1, const uint64_t* off2, char* out1, char* out2) {
