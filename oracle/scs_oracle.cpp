@@ -62,6 +62,22 @@ inline void philox(const uint32_t c_in[4], const uint32_t k_in[2], uint32_t out[
 }
 
 // ---------------------------------------------------------------------------
+// xoshiro128++ (Blackman & Vigna, public domain): the per-read sequential streams of the counter mode.
+// ---------------------------------------------------------------------------
+struct Xoshiro {
+    uint32_t s[4];
+    static inline uint32_t rotl(uint32_t x, int k) { return (x << k) | (x >> (32 - k)); }
+    void seed(const uint32_t w[4]) { for (int i = 0; i < 4; ++i) s[i] = w[i]; if (!(s[0] | s[1] | s[2] | s[3])) s[0] = 1; }
+    inline uint32_t next() {
+        const uint32_t result = rotl(s[0] + s[3], 7) + s[0];
+        const uint32_t t = s[1] << 9;
+        s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3];
+        s[2] ^= t; s[3] = rotl(s[3], 11);
+        return result;
+    }
+};
+
+// ---------------------------------------------------------------------------
 // Deterministic log: classic argument reduction x = 2^k (1+f), s = f/(2+f),
 // degree-14 minimax in s (the fdlibm e_log scheme and coefficients).  Uses only
 // IEEE +,-,*,/ so that x86 and gfx950 give the same bits (no contraction).
@@ -102,9 +118,7 @@ enum Stage : uint32_t {
     ST_FRAGSPLIT = 1, ST_POISSON = 2, ST_ATTACH = 3, ST_ERR = 4, ST_ERRALT = 5, ST_WEIGHT = 6,
     ST_ALLOC_TOP = 7, ST_ALLOC_CHUNK = 8, ST_PAIR = 9, ST_READ = 10, ST_INDEL_INS = 11, ST_INDEL_LEN = 12, ST_INDEL = 13
 };
-// One Philox block serves TWO positions: ST_INDEL block j>>1, words 2(j&1) / 2(j&1)+1 = insertion / deletion test of
-// input base j; ST_READ block j>>1, words 2(j&1) / 2(j&1)+1 = substitution draw / quality draw (or the random quality
-// of an N) of OUTPUT base j.
+// ST_READ blocks 0 and 1 of a read seed its two xoshiro128++ streams (indel tests / base-pass draws).
 
 struct Key { uint32_t idx; uint64_t uid; uint32_t stage_word; int word; };
 inline Key mk(uint32_t stage, uint32_t aux, uint64_t uid, uint32_t idx, int word) {
@@ -381,12 +395,24 @@ int predict(const Profile& P, Rng& rng, const uint8_t* win, int n, bool isRead1,
             uint64_t uid, uint32_t attempt, char* out_b, char* out_q) {
     const uint32_t rd = isRead1 ? 0u : 1u;
     const uint32_t aux = rd | (attempt << 1);
+    // [REMAP] counter mode: each read owns two xoshiro128++ streams seeded by Philox blocks 0 and 1 of ST_READ --
+    // A feeds the indel tests, B the substitution / quality draws -- consumed in the reference's own order (a draw
+    // is only taken where the reference takes one).  Lengths and inserted bases (rare) stay keyed Philox draws.
+    Xoshiro xa, xb;
+    if (rng.counter) {
+        uint32_t c[4] = {0, (uint32_t)uid, (uint32_t)(uid >> 32), ST_READ | (aux << 8)}, o[4];
+        philox(c, rng.key, o); xa.seed(o);
+        c[0] = 1; philox(c, rng.key, o); xb.seed(o);
+    }
+    auto drawA = [&]() { return rng.counter ? xa.next() / 4294967296.0 : rng.real(Key{}); };
+    auto drawB = [&]() { return rng.counter ? xb.next() / 4294967296.0 : rng.real(Key{}); };
+    auto drawBi = [&]() { return rng.counter ? xb.next() / 4294967296.0 : rng.integer(Key{}); };
     std::vector<int> indelLens; indelLens.reserve(n);
     std::vector<std::vector<uint8_t>> ins(n);
     int indelLength = 0;
     for (int j = 0; j < n;) {                                                  // 1606-1622
         int k = 0; bool isIns = false;
-        double p = rng.real(mk(ST_INDEL, aux, uid, j >> 1, 2 * (j & 1)));       // getIndelSeq 1552-1570
+        double p = drawA();                                                     // getIndelSeq 1552-1570
         if (p <= P.insertRate) {
             k = rand_indx(P.insCdf.data(), P.insCdf.size(), rng.real(mk(ST_INDEL_LEN, aux, uid, j, 0)));
             for (int t = 0; t < k; ++t) {
@@ -395,7 +421,7 @@ int predict(const Profile& P, Rng& rng, const uint8_t* win, int n, bool isRead1,
             }
             isIns = !ins[j].empty();
         } else {
-            p = rng.real(mk(ST_INDEL, aux, uid, j >> 1, 2 * (j & 1) + 1));
+            p = drawA();
             if (p < P.delRate / (1 - P.insertRate))
                 k = rand_indx(P.delCdf.data(), P.delCdf.size(), rng.real(mk(ST_INDEL_LEN, aux, uid, j, 0)));
         }
@@ -432,14 +458,14 @@ int predict(const Profile& P, Rng& rng, const uint8_t* win, int n, bool isRead1,
         int ki = kmer_index(c0, c1, c2);
         int k;
         if (ki < 0) k = refIndx;
-        else k = rand_indx(&subs[((size_t)ki * B + bin) * 4], 4, rng.real(mk(ST_READ, aux, uid, j >> 1, 2 * (j & 1))));
+        else k = rand_indx(&subs[((size_t)ki * B + bin) * 4], 4, drawB());
         if (k < 0) {
             out_b[j] = 'N';
-            out_q[j] = (char)(long)(33 + (53 - 33) * rng.integer(mk(ST_READ, aux, uid, j >> 1, 2 * (j & 1) + 1)));   // getRandBaseQuality 1578-1580
+            out_q[j] = (char)(long)(33 + (53 - 33) * drawBi());                 // getRandBaseQuality 1578-1580
         } else {
             out_b[j] = BASES[k];
             int bp = refIndx * 4 + k;
-            out_q[j] = (char)(33 + rand_indx(&P.qual[((size_t)bp * B + bin) * 94], 94, rng.real(mk(ST_READ, aux, uid, j >> 1, 2 * (j & 1) + 1))));
+            out_q[j] = (char)(33 + rand_indx(&P.qual[((size_t)bp * B + bin) * 94], 94, drawB()));
         }
     }
     return m;

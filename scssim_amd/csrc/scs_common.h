@@ -29,11 +29,11 @@ enum Stage : uint32_t {
     ST_ALLOC_TOP   = 7,   // uid = 0, idx = t, word 0                                           (MyDefine.cpp:242-245)
     ST_ALLOC_CHUNK = 8,   // uid = chunk, idx = t, word 0                                       (MyDefine.cpp:191-201)
     ST_PAIR        = 9,   // uid = full uid, idx = attempt, word0 insert size, word1 position   (Amplicon.cpp:483-491)
-    ST_READ        = 10,  // uid = full uid, aux = rd | attempt<<1, idx = j>>1: words 2(j&1) substitution, 2(j&1)+1 quality
-                          //   (or random quality of an N) of OUTPUT base j                       (Profile.cpp:1666-1692)
+    ST_READ        = 10,  // uid = full uid, aux = rd | attempt<<1: block 0 seeds the read's xoshiro128++ stream A (insertion /
+                          //   deletion tests, Profile.cpp:1556-1566), block 1 stream B (substitution, quality, random quality of
+                          //   an N, Profile.cpp:1666-1692); both are consumed in the reference's order
     ST_INDEL_INS   = 11,  // same aux, idx = j | (t/4)<<16, word t%4 : t-th inserted base       (Profile.cpp:1560)
-    ST_INDEL_LEN   = 12,  // same aux, idx = j, word0 : insertion / deletion length             (Profile.cpp:1515-1521)
-    ST_INDEL       = 13   // same aux, idx = j>>1: words 2(j&1) insertion test, 2(j&1)+1 deletion test of INPUT base j (Profile.cpp:1556-1566)
+    ST_INDEL_LEN   = 12   // same aux, idx = j, word0 : insertion / deletion length             (Profile.cpp:1515-1521)
 };
 
 SCS_HD uint32_t stage_word(uint32_t stage, uint32_t aux) { return stage | (aux << 8); }
@@ -67,6 +67,21 @@ SCS_HD U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint
 }
 
 struct RngKey { uint32_t k0, k1; };
+
+// xoshiro128++ (Blackman & Vigna, public domain): per-read sequential streams seeded from Philox blocks.  All
+// full-rate 32-bit ops (no multiplies), ~11 instructions per draw.
+struct Xoshiro {
+    uint32_t s0, s1, s2, s3;
+    SCS_HD void seed(U4 w) { s0 = w.w[0]; s1 = w.w[1]; s2 = w.w[2]; s3 = w.w[3]; if (!(s0 | s1 | s2 | s3)) s0 = 1; }
+    SCS_HD uint32_t next() {
+        const uint32_t a = s0 + s3;
+        const uint32_t result = ((a << 7) | (a >> 25)) + s0;
+        const uint32_t t = s1 << 9;
+        s2 ^= s0; s3 ^= s1; s1 ^= s2; s0 ^= s3;
+        s2 ^= t; s3 = (s3 << 11) | (s3 >> 21);
+        return result;
+    }
+};
 
 SCS_HD U4 draw4(RngKey key, uint32_t stage, uint32_t aux, uint64_t uid, uint32_t idx) {
     return philox4x32_10(idx, (uint32_t)uid, (uint32_t)(uid >> 32), stage_word(stage, aux), key.k0, key.k1);

@@ -464,15 +464,14 @@ __global__ void __launch_bounds__(RB) k_reads(const uint8_t* __restrict__ g, Dev
     int nev = 0, delta = 0, n_out = 0;
     if (live && (ablate & 2u)) { n_out = n; atomicMax(&s_nmax, n_out); }
     else if (live) {
-        uint32_t cur = 0xFFFFFFFFu; U4 d{};
+        Xoshiro xa; xa.seed(draw4(key, ST_READ, aux, uid, 0));                     // stream A: the indel tests, in visiting order
         for (int ji = 0; ji < n;) {
-            if ((uint32_t)(ji >> 1) != cur) { cur = (uint32_t)(ji >> 1); d = draw4(key, ST_INDEL, aux, uid, cur); }
-            const uint32_t w0 = (ji & 1) ? d.w[2] : d.w[0], w1 = (ji & 1) ? d.w[3] : d.w[1];
+            const uint32_t w0 = xa.next();
             if (w0 < t_insert) {                                                   // p <= insertRate
                 const uint32_t k = rand_indx_thr(tb.ins_t, tb.ins_d, (uint32_t)tb.n_ins, draw4(key, ST_INDEL_LEN, aux, uid, (uint32_t)ji).w[0]);
                 if (k > 0) { if (nev < EV_MAX) my_ev[nev] = (uint32_t)ji | (1u << 16) | (k << 20); ++nev; delta += (int)k; }
                 ++ji;
-            } else if (w1 < t_delete) {                                         // p < delRate/(1-insertRate)
+            } else if (xa.next() < t_delete) {                                     // second draw only when no insertion; p < delRate/(1-insertRate)
                 const uint32_t k = rand_indx_thr(tb.del_t, tb.del_d, (uint32_t)tb.n_del, draw4(key, ST_INDEL_LEN, aux, uid, (uint32_t)ji).w[0]);
                 if (k > 0) { const int kk = (int)k < n - ji ? (int)k : n - ji; if (nev < EV_MAX) my_ev[nev] = (uint32_t)ji | (2u << 16) | ((uint32_t)kk << 20); ++nev; delta -= kk; ji += kk; }
                 else ++ji;
@@ -496,7 +495,8 @@ __global__ void __launch_bounds__(RB) k_reads(const uint8_t* __restrict__ g, Dev
     int ji = 0, ins_left = 0, ins_pos = 0, ins_t = 0, evi = 0;
     int bin = 0, bin_acc = 0;                                                      // bin = floor(jo * B / n_out), kept incrementally
     uint32_t c0 = 5u, c1 = 5u;
-    uint32_t ob[4] = {0, 0, 0, 0}, oq[4] = {0, 0, 0, 0}; U4 db{};
+    uint32_t ob[4] = {0, 0, 0, 0}, oq[4] = {0, 0, 0, 0};
+    Xoshiro xb; xb.seed(draw4(key, ST_READ, aux, uid, 1));                         // stream B: substitution / quality draws, in output order
     char* my_b = slot_b + (size_t)r * slot; char* my_q = slot_q + (size_t)r * slot;
     // ring maintenance: group g = jo/8 needs bins [8g-4, 8g+12).  Bins [0,12) are loaded up front; the 8 bins a later
     // group adds are prefetched into registers one group ahead and only written to LDS at the group boundary.
@@ -538,13 +538,12 @@ __global__ void __launch_bounds__(RB) k_reads(const uint8_t* __restrict__ g, Dev
             }
             // binIndx = j*binCount/n (Profile.cpp:1668) without the division: bin_acc = jo*B - bin*n_out
             const bool in_ring = bin >= (jo & ~7) - 4 && bin < min(B, (jo & ~7) + 12) && bin >= 0;
-            if ((jo & 1) == 0) { if (ablate & 16u) { db.w[0] = (uint32_t)jo * 2654435761u + (uint32_t)uid; db.w[1] = db.w[0] * 40503u; db.w[2] = db.w[1] + 7u; db.w[3] = db.w[2] * 9u; } else db = draw4(key, ST_READ, aux, uid, (uint32_t)jo >> 1); }
-            const uint32_t xs = (jo & 1) ? db.w[2] : db.w[0], xq = (jo & 1) ? db.w[3] : db.w[1];
             const int ki = (ablate & 4u) ? -1 : kmer_index(c0, c1, c2);
             int k;
             if (ki < 0) k = c2 < 4 ? (int)c2 : -1;
             else {
                 const uint32_t row = ((uint32_t)ki * (uint32_t)B + (uint32_t)bin) * 4u;
+                const uint32_t xs = xb.next();                                     // drawn only when the k-mer is in the table
                 if (xs == 0xFFFFFFFFu) k = (int)rand_indx_slow(subs_d + row, 4, xs);
                 else {
                     const uint4 T = (ki >= 20 && in_ring && ring_subs_ok) ? s_ring[bin & (RING - 1)].subs[ki - 20] : *reinterpret_cast<const uint4*>(subs + row);
@@ -552,6 +551,7 @@ __global__ void __launch_bounds__(RB) k_reads(const uint8_t* __restrict__ g, Dev
                 }
             }
             uint32_t bc, qc;
+            const uint32_t xq = xb.next();
             if (k < 0) { bc = 'N'; qc = 33 + scale_draw(xq, 0, 20); }               // getRandBaseQuality
             else {
                 bc = (uint32_t)"ACGT"[k];
