@@ -357,6 +357,10 @@ __global__ void k_plan_pairs(DevFrags fr, DevAmps semis, DevAmps fulls, uint32_t
 #define EV_MAX 8
 #define RING 16
 struct RingBin { uint4 subs[64]; uint4 qd[4][4]; };            // 1024 + 256 bytes per bin
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) u32x4_t LdsU4;           // LDS-qualified: keeps the compiler from merging LDS and global loads into FLAT ones
+typedef __attribute__((address_space(3))) uint8_t LdsU8;
+typedef __attribute__((address_space(3))) uint32_t LdsU32;
 
 __device__ __forceinline__ uint32_t dec_digits(uint32_t v) {
     return v < 10u ? 1u : v < 100u ? 2u : v < 1000u ? 3u : v < 10000u ? 4u : v < 100000u ? 5u : v < 1000000u ? 6u :
@@ -374,11 +378,12 @@ template <bool FROM_PAIRS>
 __global__ void __launch_bounds__(RB) k_reads(const uint8_t* __restrict__ g, DevErrPool spool, DevErrPool fpool, const PairRec* __restrict__ pairs,
                                               uint32_t np, int paired, const uint8_t* __restrict__ windows, const uint64_t* __restrict__ uids,
                                               const uint32_t* __restrict__ atts, const uint8_t* __restrict__ is_read1, uint32_t n_explicit,
-                                              const DevTables* __restrict__ tbp, RngKey key, uint32_t slot, uint32_t n_slots_cap, uint32_t ablate, char* __restrict__ slot_b,
+                                              const DevTables tb, RngKey key, uint32_t slot, uint32_t n_slots_cap, uint32_t ablate, char* __restrict__ slot_b,
                                               char* __restrict__ slot_q, uint32_t* __restrict__ lens, uint32_t* __restrict__ sizes1,
                                               uint32_t* __restrict__ sizes2, uint32_t* __restrict__ flags) {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
-    const DevTables tb = *tbp;                                             // one uniform load of the descriptor; fields stay in SGPRs
+    // the table descriptor is a by-value kernel argument: pointers loaded from the kernarg segment are known to be
+    // global (a descriptor fetched through a pointer makes every table access a FLAT load)
     const int n = tb.L, B = tb.bins;
     const uint32_t t_insert = tb.t_insert, t_delete = tb.t_delete;
     const uint32_t WS = ((uint32_t)n + 7u) & ~3u;                          // window row stride
@@ -409,7 +414,7 @@ __global__ void __launch_bounds__(RB) k_reads(const uint8_t* __restrict__ g, Dev
     if (FROM_PAIRS && valid && !live) { lens[r] = 0; sz[pi] = 0; }
 
     // ---- stage the windows (coalesced), then patch the amplification errors
-    uint8_t* my_win = s_win + (size_t)tid * WS;
+    LdsU8* my_win = (LdsU8*)(s_win + (size_t)tid * WS);
     if (FROM_PAIRS) {
         int64_t gb = 0; uint32_t gf = 0;
         if (live) {
@@ -460,7 +465,7 @@ __global__ void __launch_bounds__(RB) k_reads(const uint8_t* __restrict__ g, Dev
 
     // ---- phase 1: indel events per input base (getIndelSeq, Profile.cpp:1552-1570 / loop 1606-1630)
     const uint32_t aux = rd | (att << 1);
-    uint32_t* my_ev = s_ev + tid * EV_MAX;
+    LdsU32* my_ev = (LdsU32*)(s_ev + tid * EV_MAX);
     int nev = 0, delta = 0, n_out = 0;
     if (live && (ablate & 2u)) { n_out = n; atomicMax(&s_nmax, n_out); }
     else if (live) {
@@ -546,7 +551,11 @@ __global__ void __launch_bounds__(RB) k_reads(const uint8_t* __restrict__ g, Dev
                 const uint32_t xs = xb.next();                                     // drawn only when the k-mer is in the table
                 if (xs == 0xFFFFFFFFu) k = (int)rand_indx_slow(subs_d + row, 4, xs);
                 else {
-                    const uint4 T = (ki >= 20 && in_ring && ring_subs_ok) ? s_ring[bin & (RING - 1)].subs[ki - 20] : *reinterpret_cast<const uint4*>(subs + row);
+                    // unconditional LDS read + rare global override: a select between an LDS and a global pointer would
+                    // compile to FLAT loads (TA path, ~10x the LDS latency)
+                    const u32x4_t Tl = *((const LdsU4*)&s_ring[bin & (RING - 1)].subs[ki >= 20 ? ki - 20 : 0]);
+                    uint4 T = make_uint4(Tl.x, Tl.y, Tl.z, Tl.w);
+                    if (!(ki >= 20 && in_ring && ring_subs_ok)) T = *reinterpret_cast<const uint4*>(subs + row);
                     k = (xs >= T.x) + (xs >= T.y) + (xs >= T.z);
                 }
             }
@@ -560,8 +569,15 @@ __global__ void __launch_bounds__(RB) k_reads(const uint8_t* __restrict__ g, Dev
                 if (ablate & 4u) qv = xq >> 27;
                 else if (xq == 0xFFFFFFFFu) qv = rand_indx_slow(tb.qual_d + qrow * (uint32_t)NQ, NQ, xq);
                 else {
-                    if ((uint32_t)k == c2 && in_ring) { const uint4* rw = s_ring[bin & (RING - 1)].qd[c2]; qv = compact_search(rw[0], rw[1], rw[2], rw[3], xq); }
-                    else { const uint4* rw = tb.qual_compact + (size_t)qrow * 4; qv = compact_search(rw[0], rw[1], rw[2], rw[3], xq); }
+                    const LdsU4* lrow = (const LdsU4*)s_ring[bin & (RING - 1)].qd[c2 & 3u];          // explicit LDS address space
+                    const u32x4_t l0 = lrow[0], l1 = lrow[1], l2 = lrow[2], l3 = lrow[3];            // ds_read_b128, always in bounds
+                    uint4 q0 = make_uint4(l0.x, l0.y, l0.z, l0.w), q1 = make_uint4(l1.x, l1.y, l1.z, l1.w);
+                    uint4 q2 = make_uint4(l2.x, l2.y, l2.z, l2.w), q3 = make_uint4(l3.x, l3.y, l3.z, l3.w);
+                    if (!((uint32_t)k == c2 && in_ring)) {                                          // substituted base / bin outside the ring: global row
+                        const uint4* grow = tb.qual_compact + (size_t)qrow * 4;
+                        q0 = grow[0]; q1 = grow[1]; q2 = grow[2]; q3 = grow[3];
+                    }
+                    qv = compact_search(q0, q1, q2, q3, xq);
                     if (qv == 255u) qv = qual_lookup(tb.qual + qrow * (uint32_t)NQ, tb.qual_d + qrow * (uint32_t)NQ, tb.qual_guide + (size_t)qrow * 17u, xq);
                 }
                 qc = 33 + qv;
@@ -1019,22 +1035,23 @@ void launch_reads(hipStream_t s, const uint8_t* g, DevErrPool spool, DevErrPool 
                   const PairRec* pairs, uint32_t np, uint32_t amp_index_base, DevTables tb, const DevTables* d_tb, RngKey key, int paired, uint32_t slot,
                   char* slot_b, char* slot_q, uint32_t* lens, uint32_t* sizes1, uint32_t* sizes2, uint32_t* flags) {
     if (np == 0) return;
-    (void)amp_index_base;
+    (void)amp_index_base; (void)d_tb;
     // > 64 KB of dynamic LDS needs the opt-in; the limit is raised to what this profile needs
     note_launch(hipFuncSetAttribute((const void*)k_reads<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)reads_lds_bytes(tb)));
     const uint32_t groups = cdiv(np, RB);
     static const uint32_t ablate = getenv("SCS_ABLATE") ? (uint32_t)atoi(getenv("SCS_ABLATE")) : 0u;   // timing experiments only (wrong output): 1 gather, 2 indel pass, 4 tables, 8 stores, 16 Philox
     hipLaunchKernelGGL(k_reads<true>, dim3(paired ? 2 * groups : groups), dim3(RB), reads_lds_bytes(tb), s, g, spool, fpool, pairs, np, paired,
-                       (const uint8_t*)nullptr, (const uint64_t*)nullptr, (const uint32_t*)nullptr, (const uint8_t*)nullptr, 0u, d_tb, key, slot,
+                       (const uint8_t*)nullptr, (const uint64_t*)nullptr, (const uint32_t*)nullptr, (const uint8_t*)nullptr, 0u, tb, key, slot,
                        (uint32_t)(paired ? 2ull * np : np), ablate, slot_b, slot_q, lens, sizes1, sizes2, flags);
 }
 void launch_predict_windows(hipStream_t s, const uint8_t* windows, uint32_t n_reads, const uint64_t* uids, const uint32_t* atts,
                             const uint8_t* is_read1, DevTables tb, const DevTables* d_tb, RngKey key, uint32_t slot, char* slot_b, char* slot_q, uint32_t* lens, uint32_t* flags) {
     if (n_reads == 0) return;
+    (void)d_tb;
     note_launch(hipFuncSetAttribute((const void*)k_reads<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)reads_lds_bytes(tb)));
     DevErrPool none{};
     hipLaunchKernelGGL(k_reads<false>, dim3(cdiv(n_reads, RB)), dim3(RB), reads_lds_bytes(tb), s, (const uint8_t*)nullptr, none, none, (const PairRec*)nullptr, 0u, 0,
-                       windows, uids, atts, is_read1, n_reads, d_tb, key, slot, n_reads, 0u, slot_b, slot_q, lens, (uint32_t*)nullptr, (uint32_t*)nullptr, flags);
+                       windows, uids, atts, is_read1, n_reads, tb, key, slot, n_reads, 0u, slot_b, slot_q, lens, (uint32_t*)nullptr, (uint32_t*)nullptr, flags);
 }
 void launch_format(hipStream_t s, const PairRec* pairs, uint32_t np, uint32_t amp_index_base, int paired, uint32_t slot, const char* slot_b,
                    const char* slot_q, const uint32_t* lens, const uint64_t* off1, const uint64_t* off2, char* out1, char* out2) {
