@@ -43,7 +43,7 @@ struct DevTables {
     uint32_t t_insert, t_delete, t_ber;
     const uint32_t* subs1; const uint32_t* subs2;   // [84][bins][4] thresholds (uint4 rows)
     const uint32_t* qual;                            // [16][bins][94]
-    const uint4* qual_compact;                       // [16*bins] x 64 B: 12 thresholds, 12 symbols, count (255 = use the full row)
+    const uint4* qual_compact;                       // [16*bins] x 64 B: head {t3,t7,t11,count|255=use the full row} + 3 x {3 thresholds, 4 symbols}
     const uint8_t* qual_guide;                       // [16*bins][17]: #thresholds <= v<<28, v = 0..16 (search range per draw bucket)
     const uint32_t* ins_t; int n_ins;
     const uint32_t* del_t; int n_del;
@@ -108,6 +108,7 @@ void launch_plan_pairs(hipStream_t s, DevFrags fr, DevAmps semis, DevAmps fulls,
                        const uint32_t* gidx, DevTables tb, RngKey key, int paired, PairRec* pairs);
 void launch_pair_offsets(hipStream_t s, const uint32_t* rn, uint32_t ac, int paired, uint32_t* pair_cnt_off, void* temp, size_t temp_bytes);
 // reads of pairs [p0, p0+np): slot layout [2*np][slot] bases / quals (SE: [np][slot])
+size_t reads_lds_bytes(const DevTables& tb);          // dynamic LDS of one inject_errors workgroup for this profile
 void launch_reads(hipStream_t s, const uint8_t* g, DevErrPool spool, DevErrPool fpool,
                   const PairRec* pairs, uint32_t np, uint32_t amp_index_base, DevTables tb, const DevTables* d_tb, RngKey key, int paired, uint32_t slot,
                   char* slot_b, char* slot_q, uint32_t* lens, uint32_t* sizes1, uint32_t* sizes2, uint32_t* flags);

@@ -105,15 +105,17 @@ __device__ __forceinline__ uint32_t qual_lookup(const uint32_t* __restrict__ T, 
     return lo < (uint32_t)NQ ? lo : (uint32_t)NQ - 1;
 }
 
-// quality lookup on the compact row: one 64-byte line per draw, search in registers.  Returns 255 when the row does
+// quality lookup on the compact row (one 64-byte line: head {t3, t7, t11, count|255}, then three groups
+// {t4g, t4g+1, t4g+2, 4 symbol bytes}): two dependent 16-byte reads, search in registers.  Returns 255 when the row does
 // not fit the compact form (caller falls back to qual_lookup on the full row).
 __device__ __forceinline__ uint32_t qual_lookup_compact(const uint4* __restrict__ row, uint32_t x) {
-    const uint4 a = row[0], b = row[1], c = row[2], d = row[3];
-    if (d.w == 255u) return 255u;
-    const uint32_t cnt = (x >= a.x) + (x >= a.y) + (x >= a.z) + (x >= a.w) + (x >= b.x) + (x >= b.y) + (x >= b.z) + (x >= b.w) +
-                         (x >= c.x) + (x >= c.y) + (x >= c.z) + (x >= c.w);                 // thresholds ascend, 0xFFFFFFFF padded
-    const uint32_t word = cnt < 4 ? d.x : (cnt < 8 ? d.y : d.z);                              // cnt == n -> padded symbol 93 = fallback ac-1
-    return cnt >= 12 ? 93u : (word >> (8 * (cnt & 3u))) & 255u;
+    const uint4 h = row[0];
+    if (h.w == 255u) return 255u;
+    const uint32_t gsel = (x >= h.x) + (x >= h.y) + (x >= h.z);                                 // thresholds ascend, 0xFFFFFFFF padded
+    if (gsel == 3u) return 93u;                                                                 // past 12 symbols: fallback ac-1
+    const uint4 G = row[1u + gsel];
+    const uint32_t ci = (x >= G.x) + (x >= G.y) + (x >= G.z);                                   // count == n -> padded symbol 93 = fallback ac-1
+    return (G.w >> (8u * ci)) & 255u;
 }
 
 // ASCII -> base code, in place (0..3 = ACGT either case, 4 = anything else): Genome::getSubSequence's toupper
@@ -344,53 +346,99 @@ __global__ void k_plan_pairs(DevFrags fr, DevAmps semis, DevAmps fulls, uint32_t
 //     (Amplicon::yieldReads, Amplicon.cpp:492-528).  One THREAD per read, one workgroup per 256 reads of
 //     the same mate, stepping synchronously over the output positions:
 //       * the read windows are gathered through the pair records' index maps with coalesced loads
-//         (a wave per read, 64 consecutive bases per instruction) into an LDS tile;
-//       * phase 1 (per thread, registers only): the indel tests of every input base -> event list, n';
+//         (a wave per read, 64 consecutive bases per instruction) into an LDS tile, two bases per byte;
+//       * phase 1 (per thread): the indel tests of every input base -> event list (LDS), n';
 //       * phase 2 (workgroup-synchronous over the output position j): because all 256 reads are at the
 //         same position, only the table rows of a few bins around j are live -- a ring of 16 bins
-//         (64 k-mer substitution rows + the 4 diagonal quality rows each, 1.25 KB per bin) sits in LDS and
+//         (64 k-mer substitution rows + the 4 diagonal quality rows each, 1 KB per bin) sits in LDS and
 //         is refilled 8 bins at a time, so the per-base table lookups are LDS reads instead of divergent
-//         global gathers (measured: the gathers were 2/3 of the wave-per-read kernel).  Rows outside the
-//         ring (reads whose length changed by > 3, first two bases, substituted bases) come from global.
+//         global gathers.  A wave whose 64 reads all sit on a plain base (no indel event, clean k-mer, bin
+//         inside the ring) takes a branch-free fast step; any exception sends the wave through the
+//         general step for that position.  Rows outside the ring and substituted bases come from global.
+//     LDS per workgroup at L = 150: 16 KB ring + 4 KB events + 19 KB windows -> 4 workgroups per CU.
 // ------------------------------------------------------------------------------------------------
 #define RB 256
 #define EV_MAX 8
 #define RING 16
-struct RingBin { uint4 subs[64]; uint4 qd[4][4]; };            // 1024 + 256 bytes per bin
+struct RingBin { uint4 qd[4][4]; uint32_t subs[64][3]; };      // 256 + 768 bytes per bin
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(3))) u32x4_t LdsU4;           // LDS-qualified: keeps the compiler from merging LDS and global loads into FLAT ones
+// LDS-qualified pointer types: keep the compiler from merging LDS and global accesses into FLAT ones
+typedef __attribute__((address_space(3))) u32x4_t LdsU4;
 typedef __attribute__((address_space(3))) uint8_t LdsU8;
+typedef __attribute__((address_space(3))) uint16_t LdsU16;
 typedef __attribute__((address_space(3))) uint32_t LdsU32;
+
+// window row stride in bytes (two bases per byte, one spare byte, an odd number of dwords: conflict-free columns)
+__host__ __device__ static inline uint32_t win_stride(uint32_t n) {
+    uint32_t ws = ((n >> 1) + 1u + 3u) & ~3u;
+    if (((ws >> 2) & 1u) == 0) ws += 4;
+    return ws;
+}
+// indel events: narrow = pos:10 | del:1 | len:5 (read length <= 1023, indel length <= 31), wide = pos:16 | del:1 | len:15
+template <bool WIDE> struct Ev;
+template <> struct Ev<false> {
+    typedef uint16_t T; typedef LdsU16 L;
+    __device__ static __forceinline__ uint32_t pack(uint32_t pos, uint32_t del, uint32_t len) { return pos | (del << 10) | (len << 11); }
+    __device__ static __forceinline__ uint32_t pos(uint32_t v) { return v & 1023u; }
+    __device__ static __forceinline__ uint32_t del(uint32_t v) { return (v >> 10) & 1u; }
+    __device__ static __forceinline__ uint32_t len(uint32_t v) { return v >> 11; }
+};
+template <> struct Ev<true> {
+    typedef uint32_t T; typedef LdsU32 L;
+    __device__ static __forceinline__ uint32_t pack(uint32_t pos, uint32_t del, uint32_t len) { return pos | (del << 16) | (len << 17); }
+    __device__ static __forceinline__ uint32_t pos(uint32_t v) { return v & 0xFFFFu; }
+    __device__ static __forceinline__ uint32_t del(uint32_t v) { return (v >> 16) & 1u; }
+    __device__ static __forceinline__ uint32_t len(uint32_t v) { return v >> 17; }
+};
 
 __device__ __forceinline__ uint32_t dec_digits(uint32_t v) {
     return v < 10u ? 1u : v < 100u ? 2u : v < 1000u ? 3u : v < 10000u ? 4u : v < 100000u ? 5u : v < 1000000u ? 6u :
            v < 10000000u ? 7u : v < 100000000u ? 8u : v < 1000000000u ? 9u : 10u;
 }
-__device__ __forceinline__ uint32_t compact_search(const uint4 a, const uint4 b, const uint4 c, const uint4 d, uint32_t x) {
-    if (d.w == 255u) return 255u;
-    const uint32_t cnt = (x >= a.x) + (x >= a.y) + (x >= a.z) + (x >= a.w) + (x >= b.x) + (x >= b.y) + (x >= b.z) + (x >= b.w) +
-                         (x >= c.x) + (x >= c.y) + (x >= c.z) + (x >= c.w);
-    const uint32_t word = cnt < 4 ? d.x : (cnt < 8 ? d.y : d.z);
-    return cnt >= 12 ? 93u : (word >> (8 * (cnt & 3u))) & 255u;
+__device__ __forceinline__ uint32_t win_get(const LdsU8* w, int i) { return ((uint32_t)w[i >> 1] >> ((i & 1) * 4)) & 15u; }
+__device__ __forceinline__ void win_put(LdsU8* w, int i, uint32_t v) {
+    const uint32_t sh = (uint32_t)(i & 1) * 4u, old = w[i >> 1];
+    w[i >> 1] = (uint8_t)((old & ~(15u << sh)) | (v << sh));
 }
 
-template <bool FROM_PAIRS>
-__global__ void __launch_bounds__(RB) k_reads(const uint8_t* __restrict__ g, DevErrPool spool, DevErrPool fpool, const PairRec* __restrict__ pairs,
+// base call + quality of one position entirely from the global tables (rows outside the LDS ring, substituted bases,
+// the x == 0xFFFFFFFF draws, rows that do not fit the compact form).  ki < 0: the base is not re-drawn, k comes in.
+__device__ __noinline__ uint32_t call_global(const uint32_t* __restrict__ subs, const double* __restrict__ subs_d, const uint4* __restrict__ qcomp,
+                                             const uint32_t* __restrict__ qual, const double* __restrict__ qual_d, const uint8_t* __restrict__ guide,
+                                             uint32_t B, int ki, uint32_t k, uint32_t c2, uint32_t bin, uint32_t xs, uint32_t xq) {
+    if (ki >= 0) {
+        const uint32_t row = ((uint32_t)ki * B + bin) * 4u;
+        if (xs == 0xFFFFFFFFu) k = rand_indx_slow(subs_d + row, 4, xs);
+        else { const uint4 T = *reinterpret_cast<const uint4*>(subs + row); k = (xs >= T.x) + (xs >= T.y) + (xs >= T.z); }
+    }
+    const uint32_t qrow = (c2 * 4u + k) * B + bin;
+    uint32_t qv;
+    if (xq == 0xFFFFFFFFu) qv = rand_indx_slow(qual_d + (size_t)qrow * NQ, NQ, xq);
+    else {
+        qv = qual_lookup_compact(qcomp + (size_t)qrow * 4, xq);
+        if (qv == 255u) qv = qual_lookup(qual + (size_t)qrow * NQ, qual_d + (size_t)qrow * NQ, guide + (size_t)qrow * 17u, xq);
+    }
+    return k | (qv << 8);
+}
+
+template <bool FROM_PAIRS, bool WIDE>
+__global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, DevErrPool spool, DevErrPool fpool, const PairRec* __restrict__ pairs,
                                               uint32_t np, int paired, const uint8_t* __restrict__ windows, const uint64_t* __restrict__ uids,
                                               const uint32_t* __restrict__ atts, const uint8_t* __restrict__ is_read1, uint32_t n_explicit,
-                                              const DevTables tb, RngKey key, uint32_t slot, uint32_t n_slots_cap, uint32_t ablate, char* __restrict__ slot_b,
+                                              const DevTables tb, RngKey key, uint32_t slot, uint32_t n_slots_cap, char* __restrict__ slot_b,
                                               char* __restrict__ slot_q, uint32_t* __restrict__ lens, uint32_t* __restrict__ sizes1,
                                               uint32_t* __restrict__ sizes2, uint32_t* __restrict__ flags) {
+    typedef Ev<WIDE> E;
     extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
     // the table descriptor is a by-value kernel argument: pointers loaded from the kernarg segment are known to be
     // global (a descriptor fetched through a pointer makes every table access a FLAT load)
     const int n = tb.L, B = tb.bins;
     const uint32_t t_insert = tb.t_insert, t_delete = tb.t_delete;
-    const uint32_t WS = ((uint32_t)n + 7u) & ~3u;                          // window row stride
+    const uint32_t WS = win_stride((uint32_t)n);
     RingBin* s_ring = reinterpret_cast<RingBin*>(s_dyn);                   // [RING]
-    int64_t* s_gbase = reinterpret_cast<int64_t*>(s_dyn + RING * sizeof(RingBin));   // [RB]
+    int64_t* s_gbase = reinterpret_cast<int64_t*>(s_dyn);                  // [RB]  staging only: aliases the ring, which is filled later
     uint32_t* s_gflag = reinterpret_cast<uint32_t*>(s_gbase + RB);         // [RB]  bit0 complement, bit1 direction -1, bit2 valid
-    uint32_t* s_ev = s_gflag + RB;                                         // [RB][EV_MAX]  pos | kind<<16 | len<<20
+    typename E::T* s_ev = reinterpret_cast<typename E::T*>(s_dyn + RING * sizeof(RingBin));   // [RB][EV_MAX]
     uint8_t* s_win = reinterpret_cast<uint8_t*>(s_ev + RB * EV_MAX);       // [RB][WS]
     __shared__ int s_nmax;
     const int tid = threadIdx.x, lane = tid & 63, wib = tid >> 6;
@@ -424,22 +472,26 @@ __global__ void __launch_bounds__(RB) k_reads(const uint8_t* __restrict__ g, Dev
         }
         s_gbase[tid] = gb; s_gflag[tid] = gf;
         __syncthreads();
-        for (int q0 = 0; q0 < 64; q0 += 8) {                                        // 8 reads x up to 4 chunks of loads in flight per lane
-            uint32_t cv[8][4];
+        for (int kb = 0; kb < n; kb += 4 * WAVE) {                                  // 256 bases of every read per round (one round for L <= 256)
+            for (int q0 = 0; q0 < 64; q0 += 8) {                                    // 8 reads x up to 4 chunks of loads in flight per lane
+                uint32_t cv[8][4];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int rr = wib * 64 + q0 + u; const uint32_t f = s_gflag[rr];
-                const int64_t b0 = s_gbase[rr], d = (f & 2u) ? -1 : 1;
+                for (int u = 0; u < 8; ++u) {
+                    const int rr = wib * 64 + q0 + u; const uint32_t f = s_gflag[rr];
+                    const int64_t b0 = s_gbase[rr], d = (f & 2u) ? -1 : 1;
 #pragma unroll
-                for (int cc = 0; cc < 4; ++cc) { const int k = cc * WAVE + lane; cv[u][cc] = ((f & 4u) && k < n && !(ablate & 1u)) ? (uint32_t)g[b0 + d * (int64_t)k] : (uint32_t)(k & 3); }
-            }
+                    for (int cc = 0; cc < 4; ++cc) { const int k = kb + cc * WAVE + lane; cv[u][cc] = ((f & 4u) && k < n) ? (uint32_t)g[b0 + d * (int64_t)k] : 0u; }
+                }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int rr = wib * 64 + q0 + u; const uint32_t f = s_gflag[rr];
+                for (int u = 0; u < 8; ++u) {
+                    const int rr = wib * 64 + q0 + u; const uint32_t f = s_gflag[rr];
 #pragma unroll
-                for (int cc = 0; cc < 4; ++cc) {
-                    const int k = cc * WAVE + lane;
-                    if ((f & 4u) && k < n) s_win[(size_t)rr * WS + k] = (uint8_t)((f & 1u) ? (uint32_t)comp_code((uint8_t)cv[u][cc]) : cv[u][cc]);
+                    for (int cc = 0; cc < 4; ++cc) {
+                        const int k = kb + cc * WAVE + lane;
+                        const uint32_t v = (f & 1u) ? (uint32_t)comp_code((uint8_t)cv[u][cc]) : cv[u][cc];
+                        const uint32_t hi = __shfl_down(v, 1);                          // the odd neighbour's base: two bases per byte
+                        if ((f & 4u) && k < n && !(lane & 1)) s_win[(size_t)rr * WS + (k >> 1)] = (uint8_t)(v | ((k + 1 < n ? hi : 0u) << 4));
+                    }
                 }
             }
         }
@@ -449,36 +501,40 @@ __global__ void __launch_bounds__(RB) k_reads(const uint8_t* __restrict__ g, Dev
             // read 1: t - pos ; read 2: pos + isz - 1 - t, complemented
             for_each_err(pr.e1, spool.data, [&](uint32_t e) {
                 const int t = pr.k1 - (int)err_pos(e); const int k = rd ? (int)(pr.pos + pr.isz - 1) - t : t - (int)pr.pos;
-                if (k >= 0 && k < n) my_win[k] = (uint8_t)(rd ? err_alt(e) : 3u - err_alt(e));
+                if (k >= 0 && k < n) win_put(my_win, k, rd ? err_alt(e) : 3u - err_alt(e));
             });
             for_each_err(pr.e2, fpool.data, [&](uint32_t e) {
                 const int t = (int)err_pos(e); const int k = rd ? (int)(pr.pos + pr.isz - 1) - t : t - (int)pr.pos;
-                if (k >= 0 && k < n) my_win[k] = (uint8_t)(rd ? 3u - err_alt(e) : err_alt(e));
+                if (k >= 0 && k < n) win_put(my_win, k, rd ? 3u - err_alt(e) : err_alt(e));
             });
         }
     } else {
         const size_t base_off = (size_t)blockIdx.x * RB * (size_t)n;
         const uint32_t nblk = min((uint32_t)RB, n_explicit - blockIdx.x * RB);
-        for (uint32_t idx = tid; idx < nblk * (uint32_t)n; idx += RB) s_win[(size_t)(idx / n) * WS + idx % n] = windows[base_off + idx];
-        __syncthreads();
+        const uint32_t hb = ((uint32_t)n + 1u) >> 1;
+        for (uint32_t idx = tid; idx < nblk * hb; idx += RB) {
+            const uint32_t row = idx / hb, b = idx % hb;
+            const uint32_t lo = windows[base_off + (size_t)row * n + 2 * b] & 15u;
+            const uint32_t hi = 2 * b + 1 < (uint32_t)n ? windows[base_off + (size_t)row * n + 2 * b + 1] & 15u : 0u;
+            s_win[(size_t)row * WS + b] = (uint8_t)(lo | (hi << 4));
+        }
     }
 
     // ---- phase 1: indel events per input base (getIndelSeq, Profile.cpp:1552-1570 / loop 1606-1630)
     const uint32_t aux = rd | (att << 1);
-    LdsU32* my_ev = (LdsU32*)(s_ev + tid * EV_MAX);
+    typename E::L* my_ev = (typename E::L*)(s_ev + tid * EV_MAX);
     int nev = 0, delta = 0, n_out = 0;
-    if (live && (ablate & 2u)) { n_out = n; atomicMax(&s_nmax, n_out); }
-    else if (live) {
+    if (live) {
         Xoshiro xa; xa.seed(draw4(key, ST_READ, aux, uid, 0));                     // stream A: the indel tests, in visiting order
         for (int ji = 0; ji < n;) {
             const uint32_t w0 = xa.next();
             if (w0 < t_insert) {                                                   // p <= insertRate
                 const uint32_t k = rand_indx_thr(tb.ins_t, tb.ins_d, (uint32_t)tb.n_ins, draw4(key, ST_INDEL_LEN, aux, uid, (uint32_t)ji).w[0]);
-                if (k > 0) { if (nev < EV_MAX) my_ev[nev] = (uint32_t)ji | (1u << 16) | (k << 20); ++nev; delta += (int)k; }
+                if (k > 0) { if (nev < EV_MAX) my_ev[nev] = (typename E::T)E::pack((uint32_t)ji, 0u, k); ++nev; delta += (int)k; }
                 ++ji;
             } else if (xa.next() < t_delete) {                                     // second draw only when no insertion; p < delRate/(1-insertRate)
                 const uint32_t k = rand_indx_thr(tb.del_t, tb.del_d, (uint32_t)tb.n_del, draw4(key, ST_INDEL_LEN, aux, uid, (uint32_t)ji).w[0]);
-                if (k > 0) { const int kk = (int)k < n - ji ? (int)k : n - ji; if (nev < EV_MAX) my_ev[nev] = (uint32_t)ji | (2u << 16) | ((uint32_t)kk << 20); ++nev; delta -= kk; ji += kk; }
+                if (k > 0) { const int kk = (int)k < n - ji ? (int)k : n - ji; if (nev < EV_MAX) my_ev[nev] = (typename E::T)E::pack((uint32_t)ji, 1u, (uint32_t)kk); ++nev; delta -= kk; ji += kk; }
                 else ++ji;
             } else ++ji;
         }
@@ -487,7 +543,7 @@ __global__ void __launch_bounds__(RB) k_reads(const uint8_t* __restrict__ g, Dev
         if (nev > EV_MAX || n_out > (int)slot) { atomicOr(flags, (uint32_t)FLAG_READSLOT); n_out = 0; nev = 0; }
         atomicMax(&s_nmax, n_out);
     }
-    __syncthreads();
+    __syncthreads();                                                               // also: everyone is done with s_gbase/s_gflag (ring alias)
     const int nmax = s_nmax;
 
     // ---- phase 2: per output base, workgroup-synchronous (Profile.cpp:1632-1694)
@@ -498,17 +554,23 @@ __global__ void __launch_bounds__(RB) k_reads(const uint8_t* __restrict__ g, Dev
     const bool ring_subs_ok = FROM_PAIRS ? true : !second;
     const uint32_t* __restrict__ ring_src = FROM_PAIRS ? subs : tb.subs1;
     int ji = 0, ins_left = 0, ins_pos = 0, ins_t = 0, evi = 0;
-    int bin = 0, bin_acc = 0;                                                      // bin = floor(jo * B / n_out), kept incrementally
+    uint32_t next_ev = nev > 0 ? E::pos(my_ev[0]) : 0xFFFFFFFFu;                    // input position of the next indel event
+    // binIndx = j*binCount/n' (Profile.cpp:1668) as a multiply-high: exact while j*binCount*n' < 2^32 (checked on the host)
+    const uint32_t mdiv = n_out > 0 ? 0xFFFFFFFFu / (uint32_t)n_out + 1u : 0u;     // ceil(2^32 / n')
     uint32_t c0 = 5u, c1 = 5u;
-    uint32_t ob[4] = {0, 0, 0, 0}, oq[4] = {0, 0, 0, 0};
+    uint32_t cur_b = 0, cur_q = 0, ob0 = 0, ob1 = 0, ob2 = 0, ob3 = 0, oq0 = 0, oq1 = 0, oq2 = 0, oq3 = 0;
     Xoshiro xb; xb.seed(draw4(key, ST_READ, aux, uid, 1));                         // stream B: substitution / quality draws, in output order
     char* my_b = slot_b + (size_t)r * slot; char* my_q = slot_q + (size_t)r * slot;
     // ring maintenance: group g = jo/8 needs bins [8g-4, 8g+12).  Bins [0,12) are loaded up front; the 8 bins a later
     // group adds are prefetched into registers one group ahead and only written to LDS at the group boundary.
     auto ring_entry = [&](int bin, int w) -> uint4 {                              // entry w (0..79) of a bin's ring image
-        if (w < 64) return *reinterpret_cast<const uint4*>(ring_src + ((size_t)(20 + w) * B + bin) * 4);
-        const int cc = (w - 64) >> 2;
-        return tb.qual_compact[((size_t)(cc * 5) * B + bin) * 4 + ((w - 64) & 3)];
+        if (w >= 16) return *reinterpret_cast<const uint4*>(ring_src + ((size_t)(20 + w - 16) * B + bin) * 4);
+        return tb.qual_compact[((size_t)((w >> 2) * 5) * B + bin) * 4 + (w & 3)];
+    };
+    auto ring_put = [&](int bin, int w, uint4 v) {
+        RingBin* rb = &s_ring[bin & (RING - 1)];
+        if (w < 16) reinterpret_cast<uint4*>(rb->qd)[w] = v;
+        else { uint32_t* d = rb->subs[w - 16]; d[0] = v.x; d[1] = v.y; d[2] = v.z; }
     };
     uint4 pre[3];
     auto prefetch = [&](int first) {                                              // bins [first, first+8) -> registers
@@ -517,11 +579,26 @@ __global__ void __launch_bounds__(RB) k_reads(const uint8_t* __restrict__ g, Dev
     };
     auto commit = [&](int first) {                                                // registers -> LDS slots of bins [first, first+8)
 #pragma unroll
-        for (int u = 0; u < 3; ++u) { const int idx = tid + u * RB; const int bin = first + idx / 80; if (idx < 640 && bin < B) reinterpret_cast<uint4*>(&s_ring[bin & (RING - 1)])[idx % 80] = pre[u]; }
+        for (int u = 0; u < 3; ++u) { const int idx = tid + u * RB; const int bin = first + idx / 80; if (idx < 640 && bin < B) ring_put(bin, idx % 80, pre[u]); }
     };
-    for (int idx = tid; idx < min(B, 12) * 80; idx += RB) reinterpret_cast<uint4*>(&s_ring[(idx / 80) & (RING - 1)])[idx % 80] = ring_entry(idx / 80, idx % 80);
+    for (int idx = tid; idx < min(B, 12) * 80; idx += RB) ring_put(idx / 80, idx % 80, ring_entry(idx / 80, idx % 80));
     prefetch(12);
     __syncthreads();
+
+    // base call + quality from the ring (plain clean k-mer kk, bin inside the ring); odd = the result needs the global tables
+    auto call_lds = [&](uint32_t kk, uint32_t c2, uint32_t bin, uint32_t xs, uint32_t xq, uint32_t& k, uint32_t& qv) -> bool {
+        const RingBin* rb = &s_ring[bin & (RING - 1)];
+        const LdsU32* st = (const LdsU32*)rb->subs[kk];
+        k = (xs >= st[0]) + (xs >= st[1]) + (xs >= st[2]);
+        const LdsU4* row = (const LdsU4*)rb->qd[c2 & 3u];
+        const u32x4_t h = row[0];                                                  // {t3, t7, t11, count | 255}
+        const uint32_t gsel = (xq >= h.x) + (xq >= h.y) + (xq >= h.z);
+        const u32x4_t G = row[1u + (gsel < 3u ? gsel : 2u)];                       // {t4g, t4g+1, t4g+2, 4 symbols}
+        const uint32_t ci = (xq >= G.x) + (xq >= G.y) + (xq >= G.z);
+        qv = gsel == 3u ? 93u : (G.w >> (8u * ci)) & 255u;
+        return (k != c2) | (xs == 0xFFFFFFFFu) | (xq == 0xFFFFFFFFu) | (h.w == 255u);
+    };
+
     for (int jo = 0; jo < nmax; ++jo) {
         if ((jo & 7) == 0 && jo > 0) {
             __syncthreads();                                                       // everyone is past the bins being replaced
@@ -529,71 +606,71 @@ __global__ void __launch_bounds__(RB) k_reads(const uint8_t* __restrict__ g, Dev
             __syncthreads();
             prefetch(jo + 12);
         }
-        if (jo < n_out) {
-            uint32_t c2;
-            if (ins_left > 0) {                                                    // inserted base: randomInteger(0, N-1) -> never 'T'
-                const U4 di = draw4(key, ST_INDEL_INS, aux, uid, (uint32_t)ins_pos | ((uint32_t)(ins_t >> 2) << 16));
-                const int wi = ins_t & 3;
-                c2 = scale_draw(wi == 0 ? di.w[0] : wi == 1 ? di.w[1] : wi == 2 ? di.w[2] : di.w[3], 0, 3); ++ins_t; --ins_left;
-            } else {
-                while (evi < nev && (my_ev[evi] & 0xFFFFu) == (uint32_t)ji && ((my_ev[evi] >> 16) & 3u) == 2u) { ji += (int)(my_ev[evi] >> 20); ++evi; }
-                c2 = my_win[ji];
-                if (evi < nev && (my_ev[evi] & 0xFFFFu) == (uint32_t)ji) { ins_left = (int)(my_ev[evi] >> 20); ins_pos = ji; ins_t = 0; ++evi; }
-                ++ji;
-            }
-            // binIndx = j*binCount/n (Profile.cpp:1668) without the division: bin_acc = jo*B - bin*n_out
-            const bool in_ring = bin >= (jo & ~7) - 4 && bin < min(B, (jo & ~7) + 12) && bin >= 0;
-            const int ki = (ablate & 4u) ? -1 : kmer_index(c0, c1, c2);
-            int k;
-            if (ki < 0) k = c2 < 4 ? (int)c2 : -1;
-            else {
-                const uint32_t row = ((uint32_t)ki * (uint32_t)B + (uint32_t)bin) * 4u;
-                const uint32_t xs = xb.next();                                     // drawn only when the k-mer is in the table
-                if (xs == 0xFFFFFFFFu) k = (int)rand_indx_slow(subs_d + row, 4, xs);
-                else {
-                    // unconditional LDS read + rare global override: a select between an LDS and a global pointer would
-                    // compile to FLAT loads (TA path, ~10x the LDS latency)
-                    const u32x4_t Tl = *((const LdsU4*)&s_ring[bin & (RING - 1)].subs[ki >= 20 ? ki - 20 : 0]);
-                    uint4 T = make_uint4(Tl.x, Tl.y, Tl.z, Tl.w);
-                    if (!(ki >= 20 && in_ring && ring_subs_ok)) T = *reinterpret_cast<const uint4*>(subs + row);
-                    k = (xs >= T.x) + (xs >= T.y) + (xs >= T.z);
-                }
-            }
-            uint32_t bc, qc;
-            const uint32_t xq = xb.next();
-            if (k < 0) { bc = 'N'; qc = 33 + scale_draw(xq, 0, 20); }               // getRandBaseQuality
-            else {
-                bc = (uint32_t)"ACGT"[k];
-                const uint32_t qrow = (c2 * 4u + (uint32_t)k) * (uint32_t)B + (uint32_t)bin;
-                uint32_t qv;
-                if (ablate & 4u) qv = xq >> 27;
-                else if (xq == 0xFFFFFFFFu) qv = rand_indx_slow(tb.qual_d + qrow * (uint32_t)NQ, NQ, xq);
-                else {
-                    const LdsU4* lrow = (const LdsU4*)s_ring[bin & (RING - 1)].qd[c2 & 3u];          // explicit LDS address space
-                    const u32x4_t l0 = lrow[0], l1 = lrow[1], l2 = lrow[2], l3 = lrow[3];            // ds_read_b128, always in bounds
-                    uint4 q0 = make_uint4(l0.x, l0.y, l0.z, l0.w), q1 = make_uint4(l1.x, l1.y, l1.z, l1.w);
-                    uint4 q2 = make_uint4(l2.x, l2.y, l2.z, l2.w), q3 = make_uint4(l3.x, l3.y, l3.z, l3.w);
-                    if (!((uint32_t)k == c2 && in_ring)) {                                          // substituted base / bin outside the ring: global row
-                        const uint4* grow = tb.qual_compact + (size_t)qrow * 4;
-                        q0 = grow[0]; q1 = grow[1]; q2 = grow[2]; q3 = grow[3];
+        const int ring_lo = (jo & ~7) - 4, ring_span = max(min(B, (jo & ~7) + 12) - ring_lo, 0);
+        const bool active = jo < n_out;
+        const uint32_t bin = __umulhi((uint32_t)jo * (uint32_t)B, mdiv);
+        const bool in_ring = (uint32_t)((int)bin - ring_lo) < (uint32_t)ring_span && ring_subs_ok;
+        const uint32_t peek = win_get(my_win, ji);
+        const bool special = active && (ins_left > 0 || (uint32_t)ji == next_ev || (c0 | c1 | peek) > 3u || !in_ring);
+        uint32_t c2 = 0, bc = 0, qc = 0;
+        if (__any(special)) {
+            if (active) {                                                          // ---- general step
+                if (ins_left > 0) {                                                // inserted base: randomInteger(0, N-1) -> never 'T'
+                    const U4 di = draw4(key, ST_INDEL_INS, aux, uid, (uint32_t)ins_pos | ((uint32_t)(ins_t >> 2) << 16));
+                    const int wi = ins_t & 3;
+                    c2 = scale_draw(wi == 0 ? di.w[0] : wi == 1 ? di.w[1] : wi == 2 ? di.w[2] : di.w[3], 0, 3); ++ins_t; --ins_left;
+                } else {
+                    while (evi < nev) {                                            // deletions starting here
+                        const uint32_t ev = my_ev[evi];
+                        if (E::pos(ev) != (uint32_t)ji || !E::del(ev)) break;
+                        ji += (int)E::len(ev); ++evi;
                     }
-                    qv = compact_search(q0, q1, q2, q3, xq);
-                    if (qv == 255u) qv = qual_lookup(tb.qual + qrow * (uint32_t)NQ, tb.qual_d + qrow * (uint32_t)NQ, tb.qual_guide + (size_t)qrow * 17u, xq);
+                    c2 = win_get(my_win, ji);
+                    if (evi < nev) { const uint32_t ev = my_ev[evi]; if (E::pos(ev) == (uint32_t)ji) { ins_left = (int)E::len(ev); ins_pos = ji; ins_t = 0; ++evi; } }
+                    ++ji;
+                    next_ev = evi < nev ? E::pos(my_ev[evi]) : 0xFFFFFFFFu;
                 }
-                qc = 33 + qv;
+                const int ki = kmer_index(c0, c1, c2);
+                const uint32_t xs = ki >= 0 ? xb.next() : 0u;                      // drawn only when the k-mer is in the table
+                const uint32_t xq = xb.next();
+                if (ki < 0 && c2 > 3u) { bc = 'N'; qc = 33 + scale_draw(xq, 0, 20); }   // getRandBaseQuality
+                else {
+                    uint32_t k = c2, qv = 0; bool odd = true;
+                    if (ki >= 20 && in_ring) odd = call_lds((uint32_t)ki - 20u, c2, bin, xs, xq, k, qv);
+                    if (odd) {
+                        const uint32_t kq = call_global(subs, subs_d, tb.qual_compact, tb.qual, tb.qual_d, tb.qual_guide, (uint32_t)B, ki, c2, c2, bin, xs, xq);
+                        k = kq & 255u; qv = kq >> 8;
+                    }
+                    bc = (0x54474341u >> (8u * k)) & 255u; qc = 33 + qv;           // "ACGT"[k]
+                }
             }
-            const int w = (jo >> 2) & 3, sh = 8 * (jo & 3);
-            const uint32_t bsh = bc << sh, qsh = qc << sh;
-#pragma unroll
-            for (int z = 0; z < 4; ++z) { ob[z] |= (z == w) ? bsh : 0u; oq[z] |= (z == w) ? qsh : 0u; }
-            if (((jo & 15) == 15 || jo == n_out - 1) && !(ablate & 8u)) {          // 16 output characters per store
+        } else if (active) {                                                       // ---- fast step: 64 plain bases
+            c2 = peek; ++ji;
+            const uint32_t xs = xb.next(), xq = xb.next();
+            const uint32_t kk = (c0 << 4) | (c1 << 2) | c2;
+            uint32_t k, qv;
+            if (call_lds(kk, c2, bin, xs, xq, k, qv)) {
+                const uint32_t kq = call_global(subs, subs_d, tb.qual_compact, tb.qual, tb.qual_d, tb.qual_guide, (uint32_t)B, (int)kk + 20, c2, c2, bin, xs, xq);
+                k = kq & 255u; qv = kq >> 8;
+            }
+            bc = (0x54474341u >> (8u * k)) & 255u; qc = 33 + qv;
+        }
+        const uint32_t sh = 8u * ((uint32_t)jo & 3u);
+        if (active) { cur_b |= bc << sh; cur_q |= qc << sh; c0 = c1; c1 = c2; }
+        const bool last = jo == nmax - 1;
+        if ((jo & 3) == 3 || last) {                                               // uniform: close the 4-character word
+            const int w = (jo >> 2) & 3;
+            if (w == 0) { ob0 = cur_b; oq0 = cur_q; } else if (w == 1) { ob1 = cur_b; oq1 = cur_q; }
+            else if (w == 2) { ob2 = cur_b; oq2 = cur_q; } else { ob3 = cur_b; oq3 = cur_q; }
+            cur_b = 0; cur_q = 0;
+            if ((jo & 15) == 15 || last) {                                         // 16 output characters per store
                 const int o = jo & ~15;
-                *reinterpret_cast<uint4*>(my_b + o) = make_uint4(ob[0], ob[1], ob[2], ob[3]);
-                *reinterpret_cast<uint4*>(my_q + o) = make_uint4(oq[0], oq[1], oq[2], oq[3]);
-                ob[0] = ob[1] = ob[2] = ob[3] = 0; oq[0] = oq[1] = oq[2] = oq[3] = 0;
+                if (o < n_out) {
+                    *reinterpret_cast<uint4*>(my_b + o) = make_uint4(ob0, ob1, ob2, ob3);
+                    *reinterpret_cast<uint4*>(my_q + o) = make_uint4(oq0, oq1, oq2, oq3);
+                }
+                ob0 = ob1 = ob2 = ob3 = 0; oq0 = oq1 = oq2 = oq3 = 0;
             }
-            c0 = c1; c1 = c2;
-            bin_acc += B; while (bin_acc >= n_out) { bin_acc -= n_out; ++bin; }
         }
     }
     if (live) {
@@ -1027,31 +1104,42 @@ void launch_pair_offsets(hipStream_t s, const uint32_t* rn, uint32_t ac, int pai
     if (paired) (void)rocprim::exclusive_scan(temp, temp_bytes, rocprim::make_transform_iterator(rn, HalfUp()), pair_cnt_off, 0u, (size_t)ac + 1, rocprim::plus<uint32_t>(), s);
     else (void)rocprim::exclusive_scan(temp, temp_bytes, rn, pair_cnt_off, 0u, (size_t)ac + 1, rocprim::plus<uint32_t>(), s);
 }
-static inline size_t reads_lds_bytes(const DevTables& tb) {
-    const size_t WS = ((size_t)tb.L + 7) & ~(size_t)3;
-    return RING * sizeof(RingBin) + RB * 8 + RB * 4 + RB * EV_MAX * 4 + RB * WS + 16;
+static inline bool reads_wide_events(const DevTables& tb) {
+    static const bool force = getenv("SCS_EV_WIDE") != nullptr;                    // tests run the parity suite through the wide-event build too
+    return force || tb.L > 1023 || tb.n_ins > 32 || tb.n_del > 32;
+}
+size_t reads_lds_bytes(const DevTables& tb) {
+    return RING * sizeof(RingBin) + (size_t)RB * EV_MAX * (reads_wide_events(tb) ? 4 : 2) + (size_t)RB * win_stride((uint32_t)tb.L);
+}
+template <bool FROM_PAIRS, class... Args>
+static void launch_reads_kernel(hipStream_t s, dim3 grid, const DevTables& tb, Args... args) {
+    const size_t lds = reads_lds_bytes(tb);
+    if (reads_wide_events(tb)) {
+        // > 64 KB of dynamic LDS needs the opt-in; the limit is raised to exactly what this profile needs
+        note_launch(hipFuncSetAttribute((const void*)k_reads<FROM_PAIRS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((k_reads<FROM_PAIRS, true>), grid, dim3(RB), lds, s, args...);
+    } else {
+        note_launch(hipFuncSetAttribute((const void*)k_reads<FROM_PAIRS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((k_reads<FROM_PAIRS, false>), grid, dim3(RB), lds, s, args...);
+    }
 }
 void launch_reads(hipStream_t s, const uint8_t* g, DevErrPool spool, DevErrPool fpool,
                   const PairRec* pairs, uint32_t np, uint32_t amp_index_base, DevTables tb, const DevTables* d_tb, RngKey key, int paired, uint32_t slot,
                   char* slot_b, char* slot_q, uint32_t* lens, uint32_t* sizes1, uint32_t* sizes2, uint32_t* flags) {
     if (np == 0) return;
     (void)amp_index_base; (void)d_tb;
-    // > 64 KB of dynamic LDS needs the opt-in; the limit is raised to what this profile needs
-    note_launch(hipFuncSetAttribute((const void*)k_reads<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)reads_lds_bytes(tb)));
     const uint32_t groups = cdiv(np, RB);
-    static const uint32_t ablate = getenv("SCS_ABLATE") ? (uint32_t)atoi(getenv("SCS_ABLATE")) : 0u;   // timing experiments only (wrong output): 1 gather, 2 indel pass, 4 tables, 8 stores, 16 Philox
-    hipLaunchKernelGGL(k_reads<true>, dim3(paired ? 2 * groups : groups), dim3(RB), reads_lds_bytes(tb), s, g, spool, fpool, pairs, np, paired,
-                       (const uint8_t*)nullptr, (const uint64_t*)nullptr, (const uint32_t*)nullptr, (const uint8_t*)nullptr, 0u, tb, key, slot,
-                       (uint32_t)(paired ? 2ull * np : np), ablate, slot_b, slot_q, lens, sizes1, sizes2, flags);
+    launch_reads_kernel<true>(s, dim3(paired ? 2 * groups : groups), tb, g, spool, fpool, pairs, np, paired,
+                              (const uint8_t*)nullptr, (const uint64_t*)nullptr, (const uint32_t*)nullptr, (const uint8_t*)nullptr, 0u, tb, key, slot,
+                              (uint32_t)(paired ? 2ull * np : np), slot_b, slot_q, lens, sizes1, sizes2, flags);
 }
 void launch_predict_windows(hipStream_t s, const uint8_t* windows, uint32_t n_reads, const uint64_t* uids, const uint32_t* atts,
                             const uint8_t* is_read1, DevTables tb, const DevTables* d_tb, RngKey key, uint32_t slot, char* slot_b, char* slot_q, uint32_t* lens, uint32_t* flags) {
     if (n_reads == 0) return;
     (void)d_tb;
-    note_launch(hipFuncSetAttribute((const void*)k_reads<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)reads_lds_bytes(tb)));
     DevErrPool none{};
-    hipLaunchKernelGGL(k_reads<false>, dim3(cdiv(n_reads, RB)), dim3(RB), reads_lds_bytes(tb), s, (const uint8_t*)nullptr, none, none, (const PairRec*)nullptr, 0u, 0,
-                       windows, uids, atts, is_read1, n_reads, tb, key, slot, n_reads, 0u, slot_b, slot_q, lens, (uint32_t*)nullptr, (uint32_t*)nullptr, flags);
+    launch_reads_kernel<false>(s, dim3(cdiv(n_reads, RB)), tb, (const uint8_t*)nullptr, none, none, (const PairRec*)nullptr, 0u, 0,
+                               windows, uids, atts, is_read1, n_reads, tb, key, slot, n_reads, slot_b, slot_q, lens, (uint32_t*)nullptr, (uint32_t*)nullptr, flags);
 }
 void launch_format(hipStream_t s, const PairRec* pairs, uint32_t np, uint32_t amp_index_base, int paired, uint32_t slot, const char* slot_b,
                    const char* slot_q, const uint32_t* lens, const uint64_t* off1, const uint64_t* off2, char* out1, char* out2) {

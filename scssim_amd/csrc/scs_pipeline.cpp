@@ -191,7 +191,11 @@ void do_load_profile(scs_ctx* c, const char* path) {
     t.subs1_d = c->d_subs1.as<double>(); t.subs2_d = P.have_cdf2 ? c->d_subs2.as<double>() : nullptr; t.qual_d = c->d_qual.as<double>();
     t.ins_d = c->d_ins.as<double>(); t.del_d = c->d_del.as<double>(); t.isize_d = c->d_isize.as<double>();
     t.gc_means = c->d_gcmeans.as<double>(); t.gc_std = P.gc_std;
-    if (P.read_length > 256) throw ScsError(SCS_EINVAL, "read length > 256 not supported by the inject_errors kernel");
+    // inject_errors keeps 256 read windows + indel events + a 16 KB table ring in one workgroup's LDS, and its bin index
+    // is a 32-bit multiply-high (exact while position * bins * length < 2^32)
+    if (reads_lds_bytes(t) > 160u * 1024u - 64u) throw ScsError(SCS_EINVAL, "read length too large for the inject_errors kernel (LDS tile)");
+    if ((uint64_t)(P.read_length + 128) * (uint64_t)(P.read_length + 128) * (uint64_t)P.bins >= (1ull << 32))
+        throw ScsError(SCS_EINVAL, "read length x bin count too large for the inject_errors kernel");
     c->d_tables.reserve(sizeof(DevTables), s);                                    // the table descriptor itself also lives in HBM (kernels fetch fields on use)
     HIP_OK(hipMemcpyAsync(c->d_tables.p, &c->dtb, sizeof(DevTables), hipMemcpyHostToDevice, s)); HIP_OK(hipStreamSynchronize(s));
     c->have_profile = true;

@@ -224,11 +224,15 @@ void load_profile(const std::string& path, bool paired, int isize, ProfileTables
         const uint32_t* t = &T.qual_t[row * 94]; uint32_t* w = &T.qual_compact[row * 16];
         uint8_t sym[16]; uint32_t thr[16]; int n = 0; uint32_t prev = 0; bool fits = true;
         for (int k = 0; k < 94; ++k) if (t[k] > prev) { if (n == 12) { fits = false; break; } thr[n] = t[k]; sym[n] = (uint8_t)k; ++n; prev = t[k]; }
-        if (!fits) { w[15] = 255u; continue; }
-        for (int i = 0; i < 12; ++i) w[i] = i < n ? thr[i] : 0xFFFFFFFFu;
-        uint8_t bytes[16]; for (int i = 0; i < 12; ++i) bytes[i] = i < n ? sym[i] : (uint8_t)93; bytes[12] = bytes[13] = bytes[14] = 93; bytes[15] = 0;
-        memcpy(&w[12], bytes, 12);
-        w[15] = (uint32_t)n;
+        if (!fits) { w[3] = 255u; continue; }
+        for (int i = n; i < 12; ++i) { thr[i] = 0xFFFFFFFFu; sym[i] = 93; }
+        // head {t3, t7, t11, count}; group g = {t[4g], t[4g+1], t[4g+2], symbols 4g..4g+3}: two 16-byte reads per lookup
+        w[0] = thr[3]; w[1] = thr[7]; w[2] = thr[11]; w[3] = (uint32_t)n;
+        for (int gq = 0; gq < 3; ++gq) {
+            uint32_t* d = w + 4 + 4 * gq;
+            d[0] = thr[4 * gq]; d[1] = thr[4 * gq + 1]; d[2] = thr[4 * gq + 2];
+            d[3] = (uint32_t)sym[4 * gq] | ((uint32_t)sym[4 * gq + 1] << 8) | ((uint32_t)sym[4 * gq + 2] << 16) | ((uint32_t)sym[4 * gq + 3] << 24);
+        }
     }
     T.t_insert = threshold_le(T.insert_rate);
     T.t_delete = threshold_lt(T.del_rate / (1 - T.insert_rate));

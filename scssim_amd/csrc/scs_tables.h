@@ -27,8 +27,9 @@ struct ProfileTables {
     // (a draw x with x >> 28 == v resolves to a symbol in [guide[v], guide[v+1]]).
     std::vector<uint8_t> qual_guide;
     // compact quality rows, one 64-byte cache line each: the <= 12 symbols of the row that can be drawn at all
-    // (threshold strictly above the previous one), as 12 ascending thresholds (0xFFFFFFFF padded) + 12 symbol bytes +
-    // count byte (255 = more than 12 symbols: use the full row + guide).  words[16] per row.
+    // (threshold strictly above the previous one), thresholds ascending and 0xFFFFFFFF padded, as words
+    // {t3, t7, t11, count} + 3 x {t[4g], t[4g+1], t[4g+2], symbols 4g..4g+3}; count 255 = more than 12 symbols:
+    // use the full row + guide.  words[16] per row.
     std::vector<uint32_t> qual_compact;
     uint32_t t_insert = 0;               // p <= insertRate            (Profile.cpp:1557)
     uint32_t t_delete = 0;               // p <  delRate/(1-insertRate) (Profile.cpp:1565-1566)
