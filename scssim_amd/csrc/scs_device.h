@@ -43,7 +43,7 @@ struct DevTables {
     uint32_t t_insert, t_delete, t_ber;
     const uint32_t* subs1; const uint32_t* subs2;   // [84][bins][4] thresholds (uint4 rows)
     const uint32_t* qual;                            // [16][bins][94]
-    const uint4* qual_compact;                       // [16*bins] x 64 B: head {t3,t7,t11,count|255=use the full row} + 3 x {3 thresholds, 4 symbols}
+    const uint4* qual_compact; int qual_big;         // [16*bins] compact rows, 64 B (small) or 224 B (big): layout in scs_tables.h
     const uint8_t* qual_guide;                       // [16*bins][17]: #thresholds <= v<<28, v = 0..16 (search range per draw bucket)
     const uint32_t* ins_t; int n_ins;
     const uint32_t* del_t; int n_del;

@@ -105,19 +105,6 @@ __device__ __forceinline__ uint32_t qual_lookup(const uint32_t* __restrict__ T, 
     return lo < (uint32_t)NQ ? lo : (uint32_t)NQ - 1;
 }
 
-// quality lookup on the compact row (one 64-byte line: head {t3, t7, t11, count|255}, then three groups
-// {t4g, t4g+1, t4g+2, 4 symbol bytes}): two dependent 16-byte reads, search in registers.  Returns 255 when the row does
-// not fit the compact form (caller falls back to qual_lookup on the full row).
-__device__ __forceinline__ uint32_t qual_lookup_compact(const uint4* __restrict__ row, uint32_t x) {
-    const uint4 h = row[0];
-    if (h.w == 255u) return 255u;
-    const uint32_t gsel = (x >= h.x) + (x >= h.y) + (x >= h.z);                                 // thresholds ascend, 0xFFFFFFFF padded
-    if (gsel == 3u) return 93u;                                                                 // past 12 symbols: fallback ac-1
-    const uint4 G = row[1u + gsel];
-    const uint32_t ci = (x >= G.x) + (x >= G.y) + (x >= G.z);                                   // count == n -> padded symbol 93 = fallback ac-1
-    return (G.w >> (8u * ci)) & 255u;
-}
-
 // ASCII -> base code, in place (0..3 = ACGT either case, 4 = anything else): Genome::getSubSequence's toupper
 // (lib/genome/Genome.cpp:272-278) + getIndexOfBase (lib/mydefine/MyDefine.cpp:326-334).  16 bytes per thread.
 __global__ void k_encode_bases(uint8_t* __restrict__ g, uint64_t n) {
@@ -350,20 +337,27 @@ __global__ void k_plan_pairs(DevFrags fr, DevAmps semis, DevAmps fulls, uint32_t
 //       * phase 1 (per thread): the indel tests of every input base -> event list (LDS), n';
 //       * phase 2 (workgroup-synchronous over the output position j): because all 256 reads are at the
 //         same position, only the table rows of a few bins around j are live -- a ring of 16 bins
-//         (64 k-mer substitution rows + the 4 diagonal quality rows each, 1 KB per bin) sits in LDS and
-//         is refilled 8 bins at a time, so the per-base table lookups are LDS reads instead of divergent
-//         global gathers.  A wave whose 64 reads all sit on a plain base (no indel event, clean k-mer, bin
+//         (64 k-mer substitution rows + the 4 diagonal quality rows each, 1 or 2 KB per bin) sits in LDS and
+//         is refilled a group of bins at a time, so the per-base table lookups are LDS reads instead of
+//         divergent global gathers.  A wave whose 64 reads all sit on a plain base (no indel event, clean k-mer, bin
 //         inside the ring) takes a branch-free fast step; any exception sends the wave through the
 //         general step for that position.  Rows outside the ring and substituted bases come from global.
-//     LDS per workgroup at L = 150: 16 KB ring + 4 KB events + 19 KB windows -> 4 workgroups per CU.
+//     LDS per workgroup at L = 150: 13-16 KB ring + 4 KB events + 19 KB windows -> 4 workgroups per CU.
 // ------------------------------------------------------------------------------------------------
 #define RB 256
 #define EV_MAX 8
-#define RING 16
-struct RingBin { uint4 qd[4][4]; uint32_t subs[64][3]; };      // 256 + 768 bytes per bin
+// ring geometry.  Small rows (every quality row has <= 12 drawable symbols, e.g. binned-quality HiSeq X profiles):
+// 1 KB bins, 16 slots, refilled 8 bins every 8 positions, reads whose bin runs within +-4 of the position stay inside.
+// Big rows (<= 40 symbols, the 8-bit-quality profiles): 2 KB bins, 8 slots, 4 bins every 4 positions, +-2.
+template <bool QBIG> struct RingGeo;
+template <> struct RingGeo<false> { enum { SLOTS = 16, GROUP = 8, TOL = 4, QROW = 4, NPRE = 3 }; };    // QROW: uint4 per quality row
+template <> struct RingGeo<true>  { enum { SLOTS = 8,  GROUP = 4, TOL = 2, QROW = 14, NPRE = 2 }; };
+template <bool QBIG> struct RingBin { uint4 qd[4][RingGeo<QBIG>::QROW]; uint32_t subs[64][3]; };       // small 256 + 768 B, big 896 + 768 B
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 // LDS-qualified pointer types: keep the compiler from merging LDS and global accesses into FLAT ones
 typedef __attribute__((address_space(3))) u32x4_t LdsU4;
+typedef __attribute__((address_space(3))) u32x2_t LdsU2;
 typedef __attribute__((address_space(3))) uint8_t LdsU8;
 typedef __attribute__((address_space(3))) uint16_t LdsU16;
 typedef __attribute__((address_space(3))) uint32_t LdsU32;
@@ -374,22 +368,12 @@ __host__ __device__ static inline uint32_t win_stride(uint32_t n) {
     if (((ws >> 2) & 1u) == 0) ws += 4;
     return ws;
 }
-// indel events: narrow = pos:10 | del:1 | len:5 (read length <= 1023, indel length <= 31), wide = pos:16 | del:1 | len:15
-template <bool WIDE> struct Ev;
-template <> struct Ev<false> {
-    typedef uint16_t T; typedef LdsU16 L;
-    __device__ static __forceinline__ uint32_t pack(uint32_t pos, uint32_t del, uint32_t len) { return pos | (del << 10) | (len << 11); }
-    __device__ static __forceinline__ uint32_t pos(uint32_t v) { return v & 1023u; }
-    __device__ static __forceinline__ uint32_t del(uint32_t v) { return (v >> 10) & 1u; }
-    __device__ static __forceinline__ uint32_t len(uint32_t v) { return v >> 11; }
-};
-template <> struct Ev<true> {
-    typedef uint32_t T; typedef LdsU32 L;
-    __device__ static __forceinline__ uint32_t pack(uint32_t pos, uint32_t del, uint32_t len) { return pos | (del << 16) | (len << 17); }
-    __device__ static __forceinline__ uint32_t pos(uint32_t v) { return v & 0xFFFFu; }
-    __device__ static __forceinline__ uint32_t del(uint32_t v) { return (v >> 16) & 1u; }
-    __device__ static __forceinline__ uint32_t len(uint32_t v) { return v >> 17; }
-};
+// indel events, 16 bits: pos:10 | del:1 | len:5.  A read with an event that does not fit (position >= 1024, length
+// >= 32, more than EV_MAX events) is "replayed": phase 2 re-draws its indel tests from stream A as it goes.
+__device__ __forceinline__ uint32_t ev_pack(uint32_t pos, uint32_t del, uint32_t len) { return pos | (del << 10) | (len << 11); }
+__device__ __forceinline__ uint32_t ev_pos(uint32_t v) { return v & 1023u; }
+__device__ __forceinline__ uint32_t ev_del(uint32_t v) { return (v >> 10) & 1u; }
+__device__ __forceinline__ uint32_t ev_len(uint32_t v) { return v >> 11; }
 
 __device__ __forceinline__ uint32_t dec_digits(uint32_t v) {
     return v < 10u ? 1u : v < 100u ? 2u : v < 1000u ? 3u : v < 10000u ? 4u : v < 100000u ? 5u : v < 1000000u ? 6u :
@@ -401,8 +385,34 @@ __device__ __forceinline__ void win_put(LdsU8* w, int i, uint32_t v) {
     w[i >> 1] = (uint8_t)((old & ~(15u << sh)) | (v << sh));
 }
 
+// quality lookup on a compact row in global memory; 255 = not resolved here (row does not fit, or the draw lies past the
+// last stored threshold): the caller searches the full row.
+//   small row, 16 words: {t3, t7, t11, -} + 3 x {t[4g], t[4g+1], t[4g+2], symbols 4g..4g+3}
+//   big row, 56 words:   pivots t[5g+4] (8) + 8 x {t[5g] .. t[5g+3]} + 8 x {symbols 5g..5g+4, 3 pad bytes}
+// thresholds ascend and are 0xFFFFFFFF padded; a row that does not fit has all-zero pivots.
+template <bool QBIG>
+__device__ __forceinline__ uint32_t qual_lookup_compact(const uint4* __restrict__ row, uint32_t x) {
+    if (!QBIG) {
+        const uint4 h = row[0];
+        const uint32_t gsel = (x >= h.x) + (x >= h.y) + (x >= h.z);
+        if (gsel == 3u) return 255u;
+        const uint4 G = row[1u + gsel];
+        const uint32_t ci = (x >= G.x) + (x >= G.y) + (x >= G.z);
+        return (G.w >> (8u * ci)) & 255u;
+    } else {
+        const uint4 p0 = row[0], p1 = row[1];
+        const uint32_t gsel = (x >= p0.x) + (x >= p0.y) + (x >= p0.z) + (x >= p0.w) + (x >= p1.x) + (x >= p1.y) + (x >= p1.z) + (x >= p1.w);
+        if (gsel == 8u) return 255u;
+        const uint4 G = row[2u + gsel];
+        const uint2 S = reinterpret_cast<const uint2*>(row + 10)[gsel];
+        const uint32_t ci = (x >= G.x) + (x >= G.y) + (x >= G.z) + (x >= G.w);
+        return ci < 4u ? (S.x >> (8u * ci)) & 255u : S.y & 255u;
+    }
+}
+
 // base call + quality of one position entirely from the global tables (rows outside the LDS ring, substituted bases,
 // the x == 0xFFFFFFFF draws, rows that do not fit the compact form).  ki < 0: the base is not re-drawn, k comes in.
+template <bool QBIG>
 __device__ __noinline__ uint32_t call_global(const uint32_t* __restrict__ subs, const double* __restrict__ subs_d, const uint4* __restrict__ qcomp,
                                              const uint32_t* __restrict__ qual, const double* __restrict__ qual_d, const uint8_t* __restrict__ guide,
                                              uint32_t B, int ki, uint32_t k, uint32_t c2, uint32_t bin, uint32_t xs, uint32_t xq) {
@@ -415,30 +425,32 @@ __device__ __noinline__ uint32_t call_global(const uint32_t* __restrict__ subs, 
     uint32_t qv;
     if (xq == 0xFFFFFFFFu) qv = rand_indx_slow(qual_d + (size_t)qrow * NQ, NQ, xq);
     else {
-        qv = qual_lookup_compact(qcomp + (size_t)qrow * 4, xq);
+        qv = qual_lookup_compact<QBIG>(qcomp + (size_t)qrow * RingGeo<QBIG>::QROW, xq);
         if (qv == 255u) qv = qual_lookup(qual + (size_t)qrow * NQ, qual_d + (size_t)qrow * NQ, guide + (size_t)qrow * 17u, xq);
     }
     return k | (qv << 8);
 }
 
-template <bool FROM_PAIRS, bool WIDE>
+template <bool FROM_PAIRS, bool QBIG>
 __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, DevErrPool spool, DevErrPool fpool, const PairRec* __restrict__ pairs,
                                               uint32_t np, int paired, const uint8_t* __restrict__ windows, const uint64_t* __restrict__ uids,
                                               const uint32_t* __restrict__ atts, const uint8_t* __restrict__ is_read1, uint32_t n_explicit,
-                                              const DevTables tb, RngKey key, uint32_t slot, uint32_t n_slots_cap, char* __restrict__ slot_b,
-                                              char* __restrict__ slot_q, uint32_t* __restrict__ lens, uint32_t* __restrict__ sizes1,
-                                              uint32_t* __restrict__ sizes2, uint32_t* __restrict__ flags) {
-    typedef Ev<WIDE> E;
+                                              const DevTables tb, RngKey key, uint32_t slot, uint32_t n_slots_cap, uint32_t force_replay,
+                                              char* __restrict__ slot_b, char* __restrict__ slot_q, uint32_t* __restrict__ lens,
+                                              uint32_t* __restrict__ sizes1, uint32_t* __restrict__ sizes2, uint32_t* __restrict__ flags) {
+    typedef RingGeo<QBIG> Geo;
+    typedef RingBin<QBIG> Bin;
+    constexpr int SLOTS = Geo::SLOTS, GROUP = Geo::GROUP, TOL = Geo::TOL, QROW = Geo::QROW, EPB = 64 + 4 * QROW;   // EPB: 16-byte entries per bin image
     extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
     // the table descriptor is a by-value kernel argument: pointers loaded from the kernarg segment are known to be
     // global (a descriptor fetched through a pointer makes every table access a FLAT load)
     const int n = tb.L, B = tb.bins;
     const uint32_t t_insert = tb.t_insert, t_delete = tb.t_delete;
     const uint32_t WS = win_stride((uint32_t)n);
-    RingBin* s_ring = reinterpret_cast<RingBin*>(s_dyn);                   // [RING]
+    Bin* s_ring = reinterpret_cast<Bin*>(s_dyn);                           // [SLOTS]
     int64_t* s_gbase = reinterpret_cast<int64_t*>(s_dyn);                  // [RB]  staging only: aliases the ring, which is filled later
     uint32_t* s_gflag = reinterpret_cast<uint32_t*>(s_gbase + RB);         // [RB]  bit0 complement, bit1 direction -1, bit2 valid
-    typename E::T* s_ev = reinterpret_cast<typename E::T*>(s_dyn + RING * sizeof(RingBin));   // [RB][EV_MAX]
+    uint16_t* s_ev = reinterpret_cast<uint16_t*>(s_dyn + SLOTS * sizeof(Bin));   // [RB][EV_MAX]; a replayed read keeps its stream-A state here
     uint8_t* s_win = reinterpret_cast<uint8_t*>(s_ev + RB * EV_MAX);       // [RB][WS]
     __shared__ int s_nmax;
     const int tid = threadIdx.x, lane = tid & 63, wib = tid >> 6;
@@ -522,25 +534,38 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
 
     // ---- phase 1: indel events per input base (getIndelSeq, Profile.cpp:1552-1570 / loop 1606-1630)
     const uint32_t aux = rd | (att << 1);
-    typename E::L* my_ev = (typename E::L*)(s_ev + tid * EV_MAX);
-    int nev = 0, delta = 0, n_out = 0;
+    LdsU16* my_ev = (LdsU16*)(s_ev + tid * EV_MAX);
+    LdsU32* my_xa = (LdsU32*)(s_ev + tid * EV_MAX);                                // the same 16 bytes, as a stream-A state (replayed reads)
+    int nev = 0, delta = 0, n_out = 0; bool replay = false;
     if (live) {
         Xoshiro xa; xa.seed(draw4(key, ST_READ, aux, uid, 0));                     // stream A: the indel tests, in visiting order
         for (int ji = 0; ji < n;) {
             const uint32_t w0 = xa.next();
             if (w0 < t_insert) {                                                   // p <= insertRate
                 const uint32_t k = rand_indx_thr(tb.ins_t, tb.ins_d, (uint32_t)tb.n_ins, draw4(key, ST_INDEL_LEN, aux, uid, (uint32_t)ji).w[0]);
-                if (k > 0) { if (nev < EV_MAX) my_ev[nev] = (typename E::T)E::pack((uint32_t)ji, 0u, k); ++nev; delta += (int)k; }
+                if (k > 0) {
+                    if (nev < EV_MAX && ji < 1024 && k < 32u) my_ev[nev] = (uint16_t)ev_pack((uint32_t)ji, 0u, k); else replay = true;
+                    ++nev; delta += (int)k;
+                }
                 ++ji;
             } else if (xa.next() < t_delete) {                                     // second draw only when no insertion; p < delRate/(1-insertRate)
                 const uint32_t k = rand_indx_thr(tb.del_t, tb.del_d, (uint32_t)tb.n_del, draw4(key, ST_INDEL_LEN, aux, uid, (uint32_t)ji).w[0]);
-                if (k > 0) { const int kk = (int)k < n - ji ? (int)k : n - ji; if (nev < EV_MAX) my_ev[nev] = (typename E::T)E::pack((uint32_t)ji, 1u, (uint32_t)kk); ++nev; delta -= kk; ji += kk; }
+                if (k > 0) {
+                    const int kk = (int)k < n - ji ? (int)k : n - ji;
+                    if (nev < EV_MAX && ji < 1024 && kk < 32) my_ev[nev] = (uint16_t)ev_pack((uint32_t)ji, 1u, (uint32_t)kk); else replay = true;
+                    ++nev; delta -= kk; ji += kk;
+                }
                 else ++ji;
             } else ++ji;
         }
-        if (n + delta < 50) { nev = 0; delta = 0; }                                // Profile.cpp:1623-1630: drop all indels
+        if (force_replay && nev > 0) replay = true;
+        if (n + delta < 50) { nev = 0; delta = 0; replay = false; }                // Profile.cpp:1623-1630: drop all indels
         n_out = n + delta;
-        if (nev > EV_MAX || n_out > (int)slot) { atomicOr(flags, (uint32_t)FLAG_READSLOT); n_out = 0; nev = 0; }
+        if (n_out > (int)slot) { atomicOr(flags, (uint32_t)FLAG_READSLOT); n_out = 0; nev = 0; replay = false; }
+        if (replay) {                                                              // phase 2 draws the tests again
+            nev = 0; xa.seed(draw4(key, ST_READ, aux, uid, 0));
+            my_xa[0] = xa.s0; my_xa[1] = xa.s1; my_xa[2] = xa.s2; my_xa[3] = xa.s3;
+        }
         atomicMax(&s_nmax, n_out);
     }
     __syncthreads();                                                               // also: everyone is done with s_gbase/s_gflag (ring alias)
@@ -554,64 +579,76 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
     const bool ring_subs_ok = FROM_PAIRS ? true : !second;
     const uint32_t* __restrict__ ring_src = FROM_PAIRS ? subs : tb.subs1;
     int ji = 0, ins_left = 0, ins_pos = 0, ins_t = 0, evi = 0;
-    uint32_t next_ev = nev > 0 ? E::pos(my_ev[0]) : 0xFFFFFFFFu;                    // input position of the next indel event
+    uint32_t next_ev = nev > 0 ? ev_pos(my_ev[0]) : 0xFFFFFFFFu;                    // input position of the next indel event
     // binIndx = j*binCount/n' (Profile.cpp:1668) as a multiply-high: exact while j*binCount*n' < 2^32 (checked on the host)
     const uint32_t mdiv = n_out > 0 ? 0xFFFFFFFFu / (uint32_t)n_out + 1u : 0u;     // ceil(2^32 / n')
     uint32_t c0 = 5u, c1 = 5u;
     uint32_t cur_b = 0, cur_q = 0, ob0 = 0, ob1 = 0, ob2 = 0, ob3 = 0, oq0 = 0, oq1 = 0, oq2 = 0, oq3 = 0;
     Xoshiro xb; xb.seed(draw4(key, ST_READ, aux, uid, 1));                         // stream B: substitution / quality draws, in output order
     char* my_b = slot_b + (size_t)r * slot; char* my_q = slot_q + (size_t)r * slot;
-    // ring maintenance: group g = jo/8 needs bins [8g-4, 8g+12).  Bins [0,12) are loaded up front; the 8 bins a later
-    // group adds are prefetched into registers one group ahead and only written to LDS at the group boundary.
-    auto ring_entry = [&](int bin, int w) -> uint4 {                              // entry w (0..79) of a bin's ring image
-        if (w >= 16) return *reinterpret_cast<const uint4*>(ring_src + ((size_t)(20 + w - 16) * B + bin) * 4);
-        return tb.qual_compact[((size_t)((w >> 2) * 5) * B + bin) * 4 + (w & 3)];
+    // ring maintenance: group gq = jo/GROUP needs bins [GROUP*gq - TOL, GROUP*gq + GROUP + TOL).  The first GROUP+TOL bins are
+    // loaded up front; the GROUP bins a later group adds are prefetched into registers one group ahead and only written
+    // to LDS at the group boundary.
+    auto ring_entry = [&](int bin, int w) -> uint4 {                              // entry w (0..EPB) of a bin's ring image
+        if (w >= 4 * QROW) return *reinterpret_cast<const uint4*>(ring_src + ((size_t)(20 + w - 4 * QROW) * B + bin) * 4);
+        return tb.qual_compact[((size_t)((w / QROW) * 5) * B + bin) * QROW + (w % QROW)];
     };
     auto ring_put = [&](int bin, int w, uint4 v) {
-        RingBin* rb = &s_ring[bin & (RING - 1)];
-        if (w < 16) reinterpret_cast<uint4*>(rb->qd)[w] = v;
-        else { uint32_t* d = rb->subs[w - 16]; d[0] = v.x; d[1] = v.y; d[2] = v.z; }
+        Bin* rb = &s_ring[bin & (SLOTS - 1)];
+        if (w < 4 * QROW) reinterpret_cast<uint4*>(rb->qd)[w] = v;
+        else { uint32_t* d = rb->subs[w - 4 * QROW]; d[0] = v.x; d[1] = v.y; d[2] = v.z; }
     };
-    uint4 pre[3];
-    auto prefetch = [&](int first) {                                              // bins [first, first+8) -> registers
+    uint4 pre[Geo::NPRE];
+    auto prefetch = [&](int first) {                                              // bins [first, first+GROUP) -> registers
 #pragma unroll
-        for (int u = 0; u < 3; ++u) { const int idx = tid + u * RB; const int bin = first + idx / 80; pre[u] = (idx < 640 && bin < B) ? ring_entry(bin, idx % 80) : make_uint4(0, 0, 0, 0); }
+        for (int u = 0; u < Geo::NPRE; ++u) { const int idx = tid + u * RB; const int bin = first + idx / EPB; pre[u] = (idx < GROUP * EPB && bin < B) ? ring_entry(bin, idx % EPB) : make_uint4(0, 0, 0, 0); }
     };
-    auto commit = [&](int first) {                                                // registers -> LDS slots of bins [first, first+8)
+    auto commit = [&](int first) {                                                // registers -> LDS slots of bins [first, first+GROUP)
 #pragma unroll
-        for (int u = 0; u < 3; ++u) { const int idx = tid + u * RB; const int bin = first + idx / 80; if (idx < 640 && bin < B) ring_put(bin, idx % 80, pre[u]); }
+        for (int u = 0; u < Geo::NPRE; ++u) { const int idx = tid + u * RB; const int bin = first + idx / EPB; if (idx < GROUP * EPB && bin < B) ring_put(bin, idx % EPB, pre[u]); }
     };
-    for (int idx = tid; idx < min(B, 12) * 80; idx += RB) ring_put(idx / 80, idx % 80, ring_entry(idx / 80, idx % 80));
-    prefetch(12);
+    for (int idx = tid; idx < min(B, GROUP + TOL) * EPB; idx += RB) ring_put(idx / EPB, idx % EPB, ring_entry(idx / EPB, idx % EPB));
+    prefetch(GROUP + TOL);
     __syncthreads();
 
-    // base call + quality from the ring (plain clean k-mer kk, bin inside the ring); odd = the result needs the global tables
+    // base call + quality from the ring (plain clean k-mer kk, bin inside the ring); true = the result needs the global tables
     auto call_lds = [&](uint32_t kk, uint32_t c2, uint32_t bin, uint32_t xs, uint32_t xq, uint32_t& k, uint32_t& qv) -> bool {
-        const RingBin* rb = &s_ring[bin & (RING - 1)];
+        const Bin* rb = &s_ring[bin & (SLOTS - 1)];
         const LdsU32* st = (const LdsU32*)rb->subs[kk];
         k = (xs >= st[0]) + (xs >= st[1]) + (xs >= st[2]);
         const LdsU4* row = (const LdsU4*)rb->qd[c2 & 3u];
-        const u32x4_t h = row[0];                                                  // {t3, t7, t11, count | 255}
-        const uint32_t gsel = (xq >= h.x) + (xq >= h.y) + (xq >= h.z);
-        const u32x4_t G = row[1u + (gsel < 3u ? gsel : 2u)];                       // {t4g, t4g+1, t4g+2, 4 symbols}
-        const uint32_t ci = (xq >= G.x) + (xq >= G.y) + (xq >= G.z);
-        qv = gsel == 3u ? 93u : (G.w >> (8u * ci)) & 255u;
-        return (k != c2) | (xs == 0xFFFFFFFFu) | (xq == 0xFFFFFFFFu) | (h.w == 255u);
+        bool unresolved;
+        if (!QBIG) {
+            const u32x4_t h = row[0];                                              // {t3, t7, t11, -}
+            const uint32_t gsel = (xq >= h.x) + (xq >= h.y) + (xq >= h.z);
+            const u32x4_t G = row[1u + (gsel < 3u ? gsel : 2u)];                   // {t4g, t4g+1, t4g+2, 4 symbols}
+            const uint32_t ci = (xq >= G.x) + (xq >= G.y) + (xq >= G.z);
+            qv = (G.w >> (8u * ci)) & 255u; unresolved = gsel == 3u;
+        } else {
+            const u32x4_t p0 = row[0], p1 = row[1];                                // pivots t[5g+4]
+            const uint32_t gsel = (xq >= p0.x) + (xq >= p0.y) + (xq >= p0.z) + (xq >= p0.w) + (xq >= p1.x) + (xq >= p1.y) + (xq >= p1.z) + (xq >= p1.w);
+            const uint32_t gs = gsel < 8u ? gsel : 7u;
+            const u32x4_t G = row[2u + gs];                                        // t[5g] .. t[5g+3]
+            const u32x2_t S = ((const LdsU2*)(row + 10))[gs];                      // symbols 5g .. 5g+4
+            const uint32_t ci = (xq >= G.x) + (xq >= G.y) + (xq >= G.z) + (xq >= G.w);
+            qv = ci < 4u ? (S.x >> (8u * ci)) & 255u : S.y & 255u; unresolved = gsel == 8u;
+        }
+        return (k != c2) | (xs == 0xFFFFFFFFu) | (xq == 0xFFFFFFFFu) | unresolved;
     };
 
     for (int jo = 0; jo < nmax; ++jo) {
-        if ((jo & 7) == 0 && jo > 0) {
+        if ((jo & (GROUP - 1)) == 0 && jo > 0) {
             __syncthreads();                                                       // everyone is past the bins being replaced
-            commit(jo + 4);
+            commit(jo + TOL);
             __syncthreads();
-            prefetch(jo + 12);
+            prefetch(jo + TOL + GROUP);
         }
-        const int ring_lo = (jo & ~7) - 4, ring_span = max(min(B, (jo & ~7) + 12) - ring_lo, 0);
+        const int ring_lo = (jo & ~(GROUP - 1)) - TOL, ring_span = max(min(B, (jo & ~(GROUP - 1)) + GROUP + TOL) - ring_lo, 0);
         const bool active = jo < n_out;
         const uint32_t bin = __umulhi((uint32_t)jo * (uint32_t)B, mdiv);
         const bool in_ring = (uint32_t)((int)bin - ring_lo) < (uint32_t)ring_span && ring_subs_ok;
         const uint32_t peek = win_get(my_win, ji);
-        const bool special = active && (ins_left > 0 || (uint32_t)ji == next_ev || (c0 | c1 | peek) > 3u || !in_ring);
+        const bool special = active && (ins_left > 0 || (uint32_t)ji == next_ev || (c0 | c1 | peek) > 3u || !in_ring || replay);
         uint32_t c2 = 0, bc = 0, qc = 0;
         if (__any(special)) {
             if (active) {                                                          // ---- general step
@@ -619,16 +656,32 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
                     const U4 di = draw4(key, ST_INDEL_INS, aux, uid, (uint32_t)ins_pos | ((uint32_t)(ins_t >> 2) << 16));
                     const int wi = ins_t & 3;
                     c2 = scale_draw(wi == 0 ? di.w[0] : wi == 1 ? di.w[1] : wi == 2 ? di.w[2] : di.w[3], 0, 3); ++ins_t; --ins_left;
+                } else if (replay) {                                               // the indel tests of phase 1, drawn again (same stream, same order)
+                    Xoshiro xa; xa.s0 = my_xa[0]; xa.s1 = my_xa[1]; xa.s2 = my_xa[2]; xa.s3 = my_xa[3];
+                    while (ji < n) {
+                        if (xa.next() < t_insert) {
+                            const uint32_t k = rand_indx_thr(tb.ins_t, tb.ins_d, (uint32_t)tb.n_ins, draw4(key, ST_INDEL_LEN, aux, uid, (uint32_t)ji).w[0]);
+                            if (k > 0) { ins_left = (int)k; ins_pos = ji; ins_t = 0; }
+                            break;
+                        }
+                        if (xa.next() < t_delete) {
+                            const uint32_t k = rand_indx_thr(tb.del_t, tb.del_d, (uint32_t)tb.n_del, draw4(key, ST_INDEL_LEN, aux, uid, (uint32_t)ji).w[0]);
+                            if (k > 0) { ji += (int)k < n - ji ? (int)k : n - ji; continue; }
+                        }
+                        break;
+                    }
+                    c2 = win_get(my_win, ji); ++ji;
+                    my_xa[0] = xa.s0; my_xa[1] = xa.s1; my_xa[2] = xa.s2; my_xa[3] = xa.s3;
                 } else {
                     while (evi < nev) {                                            // deletions starting here
                         const uint32_t ev = my_ev[evi];
-                        if (E::pos(ev) != (uint32_t)ji || !E::del(ev)) break;
-                        ji += (int)E::len(ev); ++evi;
+                        if (ev_pos(ev) != (uint32_t)ji || !ev_del(ev)) break;
+                        ji += (int)ev_len(ev); ++evi;
                     }
                     c2 = win_get(my_win, ji);
-                    if (evi < nev) { const uint32_t ev = my_ev[evi]; if (E::pos(ev) == (uint32_t)ji) { ins_left = (int)E::len(ev); ins_pos = ji; ins_t = 0; ++evi; } }
+                    if (evi < nev) { const uint32_t ev = my_ev[evi]; if (ev_pos(ev) == (uint32_t)ji) { ins_left = (int)ev_len(ev); ins_pos = ji; ins_t = 0; ++evi; } }
                     ++ji;
-                    next_ev = evi < nev ? E::pos(my_ev[evi]) : 0xFFFFFFFFu;
+                    next_ev = evi < nev ? ev_pos(my_ev[evi]) : 0xFFFFFFFFu;
                 }
                 const int ki = kmer_index(c0, c1, c2);
                 const uint32_t xs = ki >= 0 ? xb.next() : 0u;                      // drawn only when the k-mer is in the table
@@ -638,7 +691,7 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
                     uint32_t k = c2, qv = 0; bool odd = true;
                     if (ki >= 20 && in_ring) odd = call_lds((uint32_t)ki - 20u, c2, bin, xs, xq, k, qv);
                     if (odd) {
-                        const uint32_t kq = call_global(subs, subs_d, tb.qual_compact, tb.qual, tb.qual_d, tb.qual_guide, (uint32_t)B, ki, c2, c2, bin, xs, xq);
+                        const uint32_t kq = call_global<QBIG>(subs, subs_d, tb.qual_compact, tb.qual, tb.qual_d, tb.qual_guide, (uint32_t)B, ki, c2, c2, bin, xs, xq);
                         k = kq & 255u; qv = kq >> 8;
                     }
                     bc = (0x54474341u >> (8u * k)) & 255u; qc = 33 + qv;           // "ACGT"[k]
@@ -650,7 +703,7 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
             const uint32_t kk = (c0 << 4) | (c1 << 2) | c2;
             uint32_t k, qv;
             if (call_lds(kk, c2, bin, xs, xq, k, qv)) {
-                const uint32_t kq = call_global(subs, subs_d, tb.qual_compact, tb.qual, tb.qual_d, tb.qual_guide, (uint32_t)B, (int)kk + 20, c2, c2, bin, xs, xq);
+                const uint32_t kq = call_global<QBIG>(subs, subs_d, tb.qual_compact, tb.qual, tb.qual_d, tb.qual_guide, (uint32_t)B, (int)kk + 20, c2, c2, bin, xs, xq);
                 k = kq & 255u; qv = kq >> 8;
             }
             bc = (0x54474341u >> (8u * k)) & 255u; qc = 33 + qv;
@@ -1104,24 +1157,25 @@ void launch_pair_offsets(hipStream_t s, const uint32_t* rn, uint32_t ac, int pai
     if (paired) (void)rocprim::exclusive_scan(temp, temp_bytes, rocprim::make_transform_iterator(rn, HalfUp()), pair_cnt_off, 0u, (size_t)ac + 1, rocprim::plus<uint32_t>(), s);
     else (void)rocprim::exclusive_scan(temp, temp_bytes, rn, pair_cnt_off, 0u, (size_t)ac + 1, rocprim::plus<uint32_t>(), s);
 }
-static inline bool reads_wide_events(const DevTables& tb) {
-    static const bool force = getenv("SCS_EV_WIDE") != nullptr;                    // tests run the parity suite through the wide-event build too
-    return force || tb.L > 1023 || tb.n_ins > 32 || tb.n_del > 32;
-}
 size_t reads_lds_bytes(const DevTables& tb) {
-    return RING * sizeof(RingBin) + (size_t)RB * EV_MAX * (reads_wide_events(tb) ? 4 : 2) + (size_t)RB * win_stride((uint32_t)tb.L);
+    const size_t ring = tb.qual_big ? RingGeo<true>::SLOTS * sizeof(RingBin<true>) : RingGeo<false>::SLOTS * sizeof(RingBin<false>);
+    return ring + (size_t)RB * EV_MAX * 2 + (size_t)RB * win_stride((uint32_t)tb.L);
 }
 template <bool FROM_PAIRS, class... Args>
 static void launch_reads_kernel(hipStream_t s, dim3 grid, const DevTables& tb, Args... args) {
     const size_t lds = reads_lds_bytes(tb);
-    if (reads_wide_events(tb)) {
-        // > 64 KB of dynamic LDS needs the opt-in; the limit is raised to exactly what this profile needs
+    // > 64 KB of dynamic LDS needs the opt-in; the limit is raised to exactly what this profile needs
+    if (tb.qual_big) {
         note_launch(hipFuncSetAttribute((const void*)k_reads<FROM_PAIRS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL((k_reads<FROM_PAIRS, true>), grid, dim3(RB), lds, s, args...);
     } else {
         note_launch(hipFuncSetAttribute((const void*)k_reads<FROM_PAIRS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL((k_reads<FROM_PAIRS, false>), grid, dim3(RB), lds, s, args...);
     }
+}
+static uint32_t reads_force_replay() {                                             // tests: every read with an indel takes the replay path
+    static const uint32_t v = getenv("SCS_EV_REPLAY") ? 1u : 0u;
+    return v;
 }
 void launch_reads(hipStream_t s, const uint8_t* g, DevErrPool spool, DevErrPool fpool,
                   const PairRec* pairs, uint32_t np, uint32_t amp_index_base, DevTables tb, const DevTables* d_tb, RngKey key, int paired, uint32_t slot,
@@ -1131,7 +1185,7 @@ void launch_reads(hipStream_t s, const uint8_t* g, DevErrPool spool, DevErrPool 
     const uint32_t groups = cdiv(np, RB);
     launch_reads_kernel<true>(s, dim3(paired ? 2 * groups : groups), tb, g, spool, fpool, pairs, np, paired,
                               (const uint8_t*)nullptr, (const uint64_t*)nullptr, (const uint32_t*)nullptr, (const uint8_t*)nullptr, 0u, tb, key, slot,
-                              (uint32_t)(paired ? 2ull * np : np), slot_b, slot_q, lens, sizes1, sizes2, flags);
+                              (uint32_t)(paired ? 2ull * np : np), reads_force_replay(), slot_b, slot_q, lens, sizes1, sizes2, flags);
 }
 void launch_predict_windows(hipStream_t s, const uint8_t* windows, uint32_t n_reads, const uint64_t* uids, const uint32_t* atts,
                             const uint8_t* is_read1, DevTables tb, const DevTables* d_tb, RngKey key, uint32_t slot, char* slot_b, char* slot_q, uint32_t* lens, uint32_t* flags) {
@@ -1139,7 +1193,7 @@ void launch_predict_windows(hipStream_t s, const uint8_t* windows, uint32_t n_re
     (void)d_tb;
     DevErrPool none{};
     launch_reads_kernel<false>(s, dim3(cdiv(n_reads, RB)), tb, (const uint8_t*)nullptr, none, none, (const PairRec*)nullptr, 0u, 0,
-                               windows, uids, atts, is_read1, n_reads, tb, key, slot, n_reads, slot_b, slot_q, lens, (uint32_t*)nullptr, (uint32_t*)nullptr, flags);
+                               windows, uids, atts, is_read1, n_reads, tb, key, slot, n_reads, reads_force_replay(), slot_b, slot_q, lens, (uint32_t*)nullptr, (uint32_t*)nullptr, flags);
 }
 void launch_format(hipStream_t s, const PairRec* pairs, uint32_t np, uint32_t amp_index_base, int paired, uint32_t slot, const char* slot_b,
                    const char* slot_q, const uint32_t* lens, const uint64_t* off1, const uint64_t* off2, char* out1, char* out2) {

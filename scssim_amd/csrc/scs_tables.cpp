@@ -6,6 +6,7 @@
 #include "scs_tables.h"
 #include "scs_common.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -219,19 +220,33 @@ void load_profile(const std::string& path, bool paired, int isize, ProfileTables
         const uint32_t* t = &T.qual_t[row * 94];
         for (uint64_t v = 0; v <= 16; ++v) { uint32_t n = 0; while (n < 94 && (uint64_t)t[n] <= (v << 28)) ++n; T.qual_guide[row * 17 + v] = (uint8_t)n; }
     }
-    T.qual_compact.assign((size_t)16 * B * 16, 0xFFFFFFFFu);
+    // compact rows: the symbols of a row that can be drawn at all (threshold strictly above the previous one)
+    std::vector<std::vector<uint32_t>> thr_of(16 * B); std::vector<std::vector<uint8_t>> sym_of(16 * B); size_t max_syms = 0;
     for (size_t row = 0; row < 16 * B; ++row) {
-        const uint32_t* t = &T.qual_t[row * 94]; uint32_t* w = &T.qual_compact[row * 16];
-        uint8_t sym[16]; uint32_t thr[16]; int n = 0; uint32_t prev = 0; bool fits = true;
-        for (int k = 0; k < 94; ++k) if (t[k] > prev) { if (n == 12) { fits = false; break; } thr[n] = t[k]; sym[n] = (uint8_t)k; ++n; prev = t[k]; }
-        if (!fits) { w[3] = 255u; continue; }
-        for (int i = n; i < 12; ++i) { thr[i] = 0xFFFFFFFFu; sym[i] = 93; }
-        // head {t3, t7, t11, count}; group g = {t[4g], t[4g+1], t[4g+2], symbols 4g..4g+3}: two 16-byte reads per lookup
-        w[0] = thr[3]; w[1] = thr[7]; w[2] = thr[11]; w[3] = (uint32_t)n;
-        for (int gq = 0; gq < 3; ++gq) {
-            uint32_t* d = w + 4 + 4 * gq;
-            d[0] = thr[4 * gq]; d[1] = thr[4 * gq + 1]; d[2] = thr[4 * gq + 2];
-            d[3] = (uint32_t)sym[4 * gq] | ((uint32_t)sym[4 * gq + 1] << 8) | ((uint32_t)sym[4 * gq + 2] << 16) | ((uint32_t)sym[4 * gq + 3] << 24);
+        const uint32_t* t = &T.qual_t[row * 94]; uint32_t prev = 0;
+        for (int k = 0; k < 94; ++k) if (t[k] > prev) { thr_of[row].push_back(t[k]); sym_of[row].push_back((uint8_t)k); prev = t[k]; }
+        max_syms = std::max(max_syms, thr_of[row].size());
+    }
+    T.qual_big = max_syms > 12; T.qual_row_words = T.qual_big ? 56 : 16;
+    const size_t cap = T.qual_big ? 40 : 12, RW = (size_t)T.qual_row_words;
+    T.qual_compact.assign((size_t)16 * B * RW, 0u);                                // all-zero pivots = "row does not fit": search the full row
+    for (size_t row = 0; row < 16 * B; ++row) {
+        const size_t n = thr_of[row].size(); uint32_t* w = &T.qual_compact[row * RW];
+        if (n > cap) continue;
+        uint32_t thr[40]; uint8_t sym[48];
+        for (size_t i = 0; i < 40; ++i) { thr[i] = i < n ? thr_of[row][i] : 0xFFFFFFFFu; sym[i] = i < n ? sym_of[row][i] : (uint8_t)93; }
+        auto pack4 = [&](size_t i) { return (uint32_t)sym[i] | ((uint32_t)sym[i + 1] << 8) | ((uint32_t)sym[i + 2] << 16) | ((uint32_t)sym[i + 3] << 24); };
+        if (!T.qual_big) {
+            // head {t3, t7, t11, 0}; group g = {t[4g], t[4g+1], t[4g+2], symbols 4g..4g+3}: two 16-byte reads per lookup
+            w[0] = thr[3]; w[1] = thr[7]; w[2] = thr[11]; w[3] = 0;
+            for (size_t gq = 0; gq < 3; ++gq) { uint32_t* d = w + 4 + 4 * gq; d[0] = thr[4 * gq]; d[1] = thr[4 * gq + 1]; d[2] = thr[4 * gq + 2]; d[3] = pack4(4 * gq); }
+        } else {
+            // 8 pivots t[5g+4]; 8 groups {t[5g] .. t[5g+3]}; 8 x {symbols 5g..5g+4, 3 pad bytes}
+            for (size_t gq = 0; gq < 8; ++gq) {
+                w[gq] = thr[5 * gq + 4];
+                for (size_t i = 0; i < 4; ++i) w[8 + 4 * gq + i] = thr[5 * gq + i];
+                w[40 + 2 * gq] = pack4(5 * gq); w[41 + 2 * gq] = (uint32_t)sym[5 * gq + 4];
+            }
         }
     }
     T.t_insert = threshold_le(T.insert_rate);

@@ -26,10 +26,14 @@ struct ProfileTables {
     // per quality row (16*bins of them) 17 counts: guide[v] = #{k : qual_t[row][k] <= v << 28}, v = 0..16
     // (a draw x with x >> 28 == v resolves to a symbol in [guide[v], guide[v+1]]).
     std::vector<uint8_t> qual_guide;
-    // compact quality rows, one 64-byte cache line each: the <= 12 symbols of the row that can be drawn at all
-    // (threshold strictly above the previous one), thresholds ascending and 0xFFFFFFFF padded, as words
-    // {t3, t7, t11, count} + 3 x {t[4g], t[4g+1], t[4g+2], symbols 4g..4g+3}; count 255 = more than 12 symbols:
-    // use the full row + guide.  words[16] per row.
+    // compact quality rows: the symbols of a row that can be drawn at all (threshold strictly above the previous one),
+    // thresholds ascending and 0xFFFFFFFF padded, laid out for a two-level search with 16-byte reads.
+    //   small (every row has <= 12 such symbols; qual_row_words = 16):
+    //       {t3, t7, t11, 0} + 3 x {t[4g], t[4g+1], t[4g+2], symbols 4g..4g+3}
+    //   big (some row has more; rows up to 40 symbols; qual_row_words = 56):
+    //       8 pivots t[5g+4] + 8 x {t[5g] .. t[5g+3]} + 8 x {symbols 5g..5g+4, 3 pad bytes}
+    // a row that does not fit keeps all-zero pivots: every draw falls off the end and the full row + guide is searched.
+    bool qual_big = false; int qual_row_words = 16;
     std::vector<uint32_t> qual_compact;
     uint32_t t_insert = 0;               // p <= insertRate            (Profile.cpp:1557)
     uint32_t t_delete = 0;               // p <  delRate/(1-insertRate) (Profile.cpp:1565-1566)
