@@ -397,7 +397,8 @@ int predict(const Profile& P, Rng& rng, const uint8_t* win, int n, bool isRead1,
     const uint32_t aux = rd | (attempt << 1);
     // [REMAP] counter mode: each read owns two xoshiro128++ streams seeded by Philox blocks 0 and 1 of ST_READ --
     // A feeds the indel tests, B the substitution / quality draws -- consumed in the reference's own order (a draw
-    // is only taken where the reference takes one).  Lengths and inserted bases (rare) stay keyed Philox draws.
+    // is only taken where the reference takes one).  Indel lengths (rare) stay keyed Philox draws; an inserted base is
+    // drawn from B at the moment it is emitted, ahead of that position's substitution / quality draws.
     Xoshiro xa, xb;
     if (rng.counter) {
         uint32_t c[4] = {0, (uint32_t)uid, (uint32_t)(uid >> 32), ST_READ | (aux << 8)}, o[4];
@@ -416,7 +417,8 @@ int predict(const Profile& P, Rng& rng, const uint8_t* win, int n, bool isRead1,
         if (p <= P.insertRate) {
             k = rand_indx(P.insCdf.data(), P.insCdf.size(), rng.real(mk(ST_INDEL_LEN, aux, uid, j, 0)));
             for (int t = 0; t < k; ++t) {
-                double u = rng.integer(mk(ST_INDEL_INS, aux, uid, (uint32_t)j | ((uint32_t)(t / 4) << 16), t % 4));
+                // [REMAP] counter mode: the inserted base is drawn from stream B when it is emitted (base pass below)
+                double u = rng.counter ? 0.0 : rng.integer(Key{});
                 ins[j].push_back((uint8_t)(long)(0 + (P.N - 1 - 0) * u));       // randomInteger(0, N-1): never 'T'
             }
             isIns = !ins[j].empty();
@@ -440,11 +442,11 @@ int predict(const Profile& P, Rng& rng, const uint8_t* win, int n, bool isRead1,
         for (auto& v : ins) v.clear();
         indelLens.assign(n, 0);
     }
-    std::vector<uint8_t> src; src.reserve(n + indelLength + 2);
+    std::vector<uint8_t> src, inserted; src.reserve(n + indelLength + 2); inserted.reserve(n + indelLength + 2);
     for (int j = 0; j < n;) {                                                   // 1632-1654
         if (ins[j].empty() && indelLens[j] > 0) { j += indelLens[j]; continue; }
-        src.push_back(win[j]);
-        for (uint8_t b : ins[j]) src.push_back(b);
+        src.push_back(win[j]); inserted.push_back(0);
+        for (uint8_t b : ins[j]) { src.push_back(b); inserted.push_back(1); }
         j++;
     }
     const int m = n + indelLength;
@@ -452,6 +454,7 @@ int predict(const Profile& P, Rng& rng, const uint8_t* win, int n, bool isRead1,
     const int B = P.bins;
     const std::vector<double>& subs = (isRead1 || !P.haveCdf2) ? P.subs1 : P.subs2;   // 1523-1550
     for (int j = 0; j < m; ++j) {                                               // 1666-1694
+        if (rng.counter && inserted[j]) src[j] = (uint8_t)(long)(0 + (P.N - 1 - 0) * drawBi());   // [REMAP] before this position's other draws
         uint8_t c0 = j >= 2 ? src[j - 2] : 5, c1 = j >= 1 ? src[j - 1] : 5, c2 = src[j];
         int refIndx = c2 < 4 ? c2 : -1;
         int bin = j * B / m;

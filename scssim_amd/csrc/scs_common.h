@@ -32,7 +32,7 @@ enum Stage : uint32_t {
     ST_READ        = 10,  // uid = full uid, aux = rd | attempt<<1: block 0 seeds the read's xoshiro128++ stream A (insertion /
                           //   deletion tests, Profile.cpp:1556-1566), block 1 stream B (substitution, quality, random quality of
                           //   an N, Profile.cpp:1666-1692); both are consumed in the reference's order
-    ST_INDEL_INS   = 11,  // same aux, idx = j | (t/4)<<16, word t%4 : t-th inserted base       (Profile.cpp:1560)
+    ST_INDEL_INS   = 11,  // retired: inserted bases are drawn from the read's stream B when emitted  (Profile.cpp:1560)
     ST_INDEL_LEN   = 12   // same aux, idx = j, word0 : insertion / deletion length             (Profile.cpp:1515-1521)
 };
 

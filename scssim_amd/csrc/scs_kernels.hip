@@ -578,8 +578,8 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
     // the ring holds the substitution rows of the workgroup's mate (explicit-window mode: of read 1)
     const bool ring_subs_ok = FROM_PAIRS ? true : !second;
     const uint32_t* __restrict__ ring_src = FROM_PAIRS ? subs : tb.subs1;
-    int ji = 0, ins_left = 0, ins_pos = 0, ins_t = 0, evi = 0;
-    uint32_t next_ev = nev > 0 ? ev_pos(my_ev[0]) : 0xFFFFFFFFu;                    // input position of the next indel event
+    int ji = 0, ins_left = 0, evi = 0;
+    uint32_t next_ev = replay ? 0u : nev > 0 ? ev_pos(my_ev[0]) : 0xFFFFFFFFu;     // input position of the next indel event (replayed reads: every base)
     // binIndx = j*binCount/n' (Profile.cpp:1668) as a multiply-high: exact while j*binCount*n' < 2^32 (checked on the host)
     const uint32_t mdiv = n_out > 0 ? 0xFFFFFFFFu / (uint32_t)n_out + 1u : 0u;     // ceil(2^32 / n')
     uint32_t c0 = 5u, c1 = 5u;
@@ -611,8 +611,9 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
     prefetch(GROUP + TOL);
     __syncthreads();
 
-    // base call + quality from the ring (plain clean k-mer kk, bin inside the ring); true = the result needs the global tables
-    auto call_lds = [&](uint32_t kk, uint32_t c2, uint32_t bin, uint32_t xs, uint32_t xq, uint32_t& k, uint32_t& qv) -> bool {
+    // base call + quality from the ring (plain clean k-mer kk, bin inside the ring); 0 = done, 1 = base substituted (quality
+    // row not in the ring), 2 = needs the global tables altogether
+    auto call_lds = [&](uint32_t kk, uint32_t c2, uint32_t bin, uint32_t xs, uint32_t xq, uint32_t& k, uint32_t& qv) -> uint32_t {
         const Bin* rb = &s_ring[bin & (SLOTS - 1)];
         const LdsU32* st = (const LdsU32*)rb->subs[kk];
         k = (xs >= st[0]) + (xs >= st[1]) + (xs >= st[2]);
@@ -633,8 +634,15 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
             const uint32_t ci = (xq >= G.x) + (xq >= G.y) + (xq >= G.z) + (xq >= G.w);
             qv = ci < 4u ? (S.x >> (8u * ci)) & 255u : S.y & 255u; unresolved = gsel == 8u;
         }
-        return (k != c2) | (xs == 0xFFFFFFFFu) | (xq == 0xFFFFFFFFu) | unresolved;
+        return ((xs == 0xFFFFFFFFu) | (xq == 0xFFFFFFFFu) | unresolved) ? 2u : (k != c2 ? 1u : 0u);
     };
+    // a substituted base (k != c2) needs an off-diagonal quality row, which only global memory holds.  Its quality does
+    // not feed back into the walk, so the lookup is deferred: (position, k, c2, draw) goes to the free tail of the read's
+    // quality slot and is resolved after the loop, off the workgroup-synchronous path.  No room -> resolved in place.
+    constexpr uint32_t PEND_MAX = 4;
+    const bool can_defer = n_out + 15 + (int)(8 * PEND_MAX) <= (int)slot;
+    uint32_t npend = 0;
+    uint2* my_pend = reinterpret_cast<uint2*>(my_q + slot - 8 * PEND_MAX);
 
     for (int jo = 0; jo < nmax; ++jo) {
         if ((jo & (GROUP - 1)) == 0 && jo > 0) {
@@ -647,21 +655,16 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
         const bool active = jo < n_out;
         const uint32_t bin = __umulhi((uint32_t)jo * (uint32_t)B, mdiv);
         const bool in_ring = (uint32_t)((int)bin - ring_lo) < (uint32_t)ring_span && ring_subs_ok;
-        const uint32_t peek = win_get(my_win, ji);
-        const bool special = active && (ins_left > 0 || (uint32_t)ji == next_ev || (c0 | c1 | peek) > 3u || !in_ring || replay);
-        uint32_t c2 = 0, bc = 0, qc = 0;
-        if (__any(special)) {
-            if (active) {                                                          // ---- general step
-                if (ins_left > 0) {                                                // inserted base: randomInteger(0, N-1) -> never 'T'
-                    const U4 di = draw4(key, ST_INDEL_INS, aux, uid, (uint32_t)ins_pos | ((uint32_t)(ins_t >> 2) << 16));
-                    const int wi = ins_t & 3;
-                    c2 = scale_draw(wi == 0 ? di.w[0] : wi == 1 ? di.w[1] : wi == 2 ? di.w[2] : di.w[3], 0, 3); ++ins_t; --ins_left;
-                } else if (replay) {                                               // the indel tests of phase 1, drawn again (same stream, same order)
+        // ---- (A) the source base of this output position (Profile.cpp:1632-1654, walked lazily)
+        uint32_t c2 = win_get(my_win, ji);                                         // the common case: the next window base
+        if (active && (ins_left > 0 || (uint32_t)ji == next_ev)) {                 // rare lanes: inside an insertion / at an indel event
+            if (ins_left > 0) { c2 = scale_draw(xb.next(), 0, 3); --ins_left; }    // inserted base: randomInteger(0, N-1) -> never 'T'
+            else {
+                if (replay) {                                                      // the indel tests of phase 1, drawn again (same stream, same order)
                     Xoshiro xa; xa.s0 = my_xa[0]; xa.s1 = my_xa[1]; xa.s2 = my_xa[2]; xa.s3 = my_xa[3];
                     while (ji < n) {
                         if (xa.next() < t_insert) {
-                            const uint32_t k = rand_indx_thr(tb.ins_t, tb.ins_d, (uint32_t)tb.n_ins, draw4(key, ST_INDEL_LEN, aux, uid, (uint32_t)ji).w[0]);
-                            if (k > 0) { ins_left = (int)k; ins_pos = ji; ins_t = 0; }
+                            ins_left = (int)rand_indx_thr(tb.ins_t, tb.ins_d, (uint32_t)tb.n_ins, draw4(key, ST_INDEL_LEN, aux, uid, (uint32_t)ji).w[0]);
                             break;
                         }
                         if (xa.next() < t_delete) {
@@ -670,8 +673,8 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
                         }
                         break;
                     }
-                    c2 = win_get(my_win, ji); ++ji;
                     my_xa[0] = xa.s0; my_xa[1] = xa.s1; my_xa[2] = xa.s2; my_xa[3] = xa.s3;
+                    c2 = win_get(my_win, ji); ++ji; next_ev = (uint32_t)ji;        // a replayed read stops here at every base
                 } else {
                     while (evi < nev) {                                            // deletions starting here
                         const uint32_t ev = my_ev[evi];
@@ -679,17 +682,24 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
                         ji += (int)ev_len(ev); ++evi;
                     }
                     c2 = win_get(my_win, ji);
-                    if (evi < nev) { const uint32_t ev = my_ev[evi]; if (ev_pos(ev) == (uint32_t)ji) { ins_left = (int)ev_len(ev); ins_pos = ji; ins_t = 0; ++evi; } }
+                    if (evi < nev) { const uint32_t ev = my_ev[evi]; if (ev_pos(ev) == (uint32_t)ji) { ins_left = (int)ev_len(ev); ++evi; } }
                     ++ji;
                     next_ev = evi < nev ? ev_pos(my_ev[evi]) : 0xFFFFFFFFu;
                 }
+            }
+        } else if (active) ++ji;
+        // ---- (B) base call + quality (Profile.cpp:1666-1694)
+        uint32_t bc = 0, qc = 0;
+        if (__any(active && ((c0 | c1 | c2) > 3u || !in_ring))) {                  // some read of the wave: first two bases, an N in the k-mer, bin outside the ring
+            if (active) {
                 const int ki = kmer_index(c0, c1, c2);
                 const uint32_t xs = ki >= 0 ? xb.next() : 0u;                      // drawn only when the k-mer is in the table
                 const uint32_t xq = xb.next();
                 if (ki < 0 && c2 > 3u) { bc = 'N'; qc = 33 + scale_draw(xq, 0, 20); }   // getRandBaseQuality
                 else {
-                    uint32_t k = c2, qv = 0; bool odd = true;
+                    uint32_t k = c2, qv = 0, odd = 2u;
                     if (ki >= 20 && in_ring) odd = call_lds((uint32_t)ki - 20u, c2, bin, xs, xq, k, qv);
+                    if (odd == 1u && can_defer && npend < PEND_MAX) { my_pend[npend++] = make_uint2((uint32_t)jo | (k << 12) | (c2 << 14) | (bin << 16), xq); qv = 0; odd = 0u; }
                     if (odd) {
                         const uint32_t kq = call_global<QBIG>(subs, subs_d, tb.qual_compact, tb.qual, tb.qual_d, tb.qual_guide, (uint32_t)B, ki, c2, c2, bin, xs, xq);
                         k = kq & 255u; qv = kq >> 8;
@@ -697,12 +707,13 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
                     bc = (0x54474341u >> (8u * k)) & 255u; qc = 33 + qv;           // "ACGT"[k]
                 }
             }
-        } else if (active) {                                                       // ---- fast step: 64 plain bases
-            c2 = peek; ++ji;
+        } else if (active) {                                                       // the whole wave on clean k-mers inside the ring
             const uint32_t xs = xb.next(), xq = xb.next();
             const uint32_t kk = (c0 << 4) | (c1 << 2) | c2;
             uint32_t k, qv;
-            if (call_lds(kk, c2, bin, xs, xq, k, qv)) {
+            uint32_t odd = call_lds(kk, c2, bin, xs, xq, k, qv);
+            if (odd == 1u && can_defer && npend < PEND_MAX) { my_pend[npend++] = make_uint2((uint32_t)jo | (k << 12) | (c2 << 14) | (bin << 16), xq); qv = 0; odd = 0u; }
+            if (odd) {
                 const uint32_t kq = call_global<QBIG>(subs, subs_d, tb.qual_compact, tb.qual, tb.qual_d, tb.qual_guide, (uint32_t)B, (int)kk + 20, c2, c2, bin, xs, xq);
                 k = kq & 255u; qv = kq >> 8;
             }
@@ -725,6 +736,13 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
                 ob0 = ob1 = ob2 = ob3 = 0; oq0 = oq1 = oq2 = oq3 = 0;
             }
         }
+    }
+    for (uint32_t e = 0; e < npend; ++e) {                                         // deferred qualities of substituted bases
+        const uint2 pe = my_pend[e];
+        const uint32_t pk = (pe.x >> 12) & 3u, pc = (pe.x >> 14) & 3u, qrow = (pc * 4u + pk) * (uint32_t)B + (pe.x >> 16);
+        uint32_t qv = qual_lookup_compact<QBIG>(tb.qual_compact + (size_t)qrow * QROW, pe.y);
+        if (qv == 255u) qv = qual_lookup(tb.qual + (size_t)qrow * NQ, tb.qual_d + (size_t)qrow * NQ, tb.qual_guide + (size_t)qrow * 17u, pe.y);
+        my_q[pe.x & 4095u] = (char)(33u + qv);
     }
     if (live) {
         lens[r] = (uint32_t)n_out;
