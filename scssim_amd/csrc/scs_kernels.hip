@@ -346,12 +346,12 @@ __global__ void k_plan_pairs(DevFrags fr, DevAmps semis, DevAmps fulls, uint32_t
 // ------------------------------------------------------------------------------------------------
 #define RB 256
 #define EV_MAX 8
-// ring geometry.  Small rows (every quality row has <= 12 drawable symbols, e.g. binned-quality HiSeq X profiles):
-// 1 KB bins, 16 slots, refilled 8 bins every 8 positions, reads whose bin runs within +-4 of the position stay inside.
-// Big rows (<= 40 symbols, the 8-bit-quality profiles): 2 KB bins, 8 slots, 4 bins every 4 positions, +-2.
+// ring geometry: two groups of bins (one being served, one being filled).  Small rows (every quality row has <= 12
+// drawable symbols, e.g. the binned-quality HiSeq X profiles): 1 KB bins, groups of 8.  Big rows (<= 40 symbols, the
+// 8-bit-quality profiles): 1.6 KB bins, groups of 4.
 template <bool QBIG> struct RingGeo;
-template <> struct RingGeo<false> { enum { SLOTS = 16, GROUP = 8, TOL = 4, QROW = 4, NPRE = 3 }; };    // QROW: uint4 per quality row
-template <> struct RingGeo<true>  { enum { SLOTS = 8,  GROUP = 4, TOL = 2, QROW = 14, NPRE = 2 }; };
+template <> struct RingGeo<false> { enum { SLOTS = 16, GROUP = 8, QROW = 4, NPRE = 3 }; };    // QROW: uint4 per quality row
+template <> struct RingGeo<true>  { enum { SLOTS = 8,  GROUP = 4, QROW = 14, NPRE = 2 }; };
 template <bool QBIG> struct RingBin { uint4 qd[4][RingGeo<QBIG>::QROW]; uint32_t subs[64][3]; };       // small 256 + 768 B, big 896 + 768 B
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
@@ -440,7 +440,7 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
                                               uint32_t* __restrict__ sizes1, uint32_t* __restrict__ sizes2, uint32_t* __restrict__ flags) {
     typedef RingGeo<QBIG> Geo;
     typedef RingBin<QBIG> Bin;
-    constexpr int SLOTS = Geo::SLOTS, GROUP = Geo::GROUP, TOL = Geo::TOL, QROW = Geo::QROW, EPB = 64 + 4 * QROW;   // EPB: 16-byte entries per bin image
+    constexpr int SLOTS = Geo::SLOTS, GROUP = Geo::GROUP, QROW = Geo::QROW, EPB = 64 + 4 * QROW;   // EPB: 16-byte entries per bin image
     extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
     // the table descriptor is a by-value kernel argument: pointers loaded from the kernarg segment are known to be
     // global (a descriptor fetched through a pointer makes every table access a FLAT load)
@@ -452,9 +452,7 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
     uint32_t* s_gflag = reinterpret_cast<uint32_t*>(s_gbase + RB);         // [RB]  bit0 complement, bit1 direction -1, bit2 valid
     uint16_t* s_ev = reinterpret_cast<uint16_t*>(s_dyn + SLOTS * sizeof(Bin));   // [RB][EV_MAX]; a replayed read keeps its stream-A state here
     uint8_t* s_win = reinterpret_cast<uint8_t*>(s_ev + RB * EV_MAX);       // [RB][WS]
-    __shared__ int s_nmax;
     const int tid = threadIdx.x, lane = tid & 63, wib = tid >> 6;
-    if (tid == 0) s_nmax = 0;
 
     // ---- which read is mine
     uint32_t r, pi = 0, rd; bool valid; PairRec pr{}; uint64_t uid = 0; uint32_t att = 0;
@@ -566,29 +564,32 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
             nev = 0; xa.seed(draw4(key, ST_READ, aux, uid, 0));
             my_xa[0] = xa.s0; my_xa[1] = xa.s1; my_xa[2] = xa.s2; my_xa[3] = xa.s3;
         }
-        atomicMax(&s_nmax, n_out);
     }
     __syncthreads();                                                               // also: everyone is done with s_gbase/s_gflag (ring alias)
-    const int nmax = s_nmax;
 
-    // ---- phase 2: per output base, workgroup-synchronous (Profile.cpp:1632-1694)
+    // ---- phase 2: the base pass (Profile.cpp:1632-1694), workgroup-synchronous over the TABLE BINS.  Output position j of a
+    // read uses the rows of bin j*binCount/n'; the workgroup walks the bins together and every read emits the positions
+    // that fall into the current bin: one each for a read of unchanged length (binCount == L), none or two at the places
+    // where indels changed n'.  So every lookup of every read hits the one bin the ring is serving.
     const bool second = rd != 0 && tb.subs2 != nullptr;
     const uint32_t* __restrict__ subs = second ? tb.subs2 : tb.subs1;
     const double* __restrict__ subs_d = second ? tb.subs2_d : tb.subs1_d;
     // the ring holds the substitution rows of the workgroup's mate (explicit-window mode: of read 1)
     const bool ring_subs_ok = FROM_PAIRS ? true : !second;
     const uint32_t* __restrict__ ring_src = FROM_PAIRS ? subs : tb.subs1;
-    int ji = 0, ins_left = 0, evi = 0;
+    int ji = 0, jo = 0, ins_left = 0, evi = 0;
     uint32_t next_ev = replay ? 0u : nev > 0 ? ev_pos(my_ev[0]) : 0xFFFFFFFFu;     // input position of the next indel event (replayed reads: every base)
     // binIndx = j*binCount/n' (Profile.cpp:1668) as a multiply-high: exact while j*binCount*n' < 2^32 (checked on the host)
     const uint32_t mdiv = n_out > 0 ? 0xFFFFFFFFu / (uint32_t)n_out + 1u : 0u;     // ceil(2^32 / n')
+    uint32_t nb = 0;                                                               // bin of my position jo
     uint32_t c0 = 5u, c1 = 5u;
     uint32_t cur_b = 0, cur_q = 0, ob0 = 0, ob1 = 0, ob2 = 0, ob3 = 0, oq0 = 0, oq1 = 0, oq2 = 0, oq3 = 0;
     Xoshiro xb; xb.seed(draw4(key, ST_READ, aux, uid, 1));                         // stream B: substitution / quality draws, in output order
     char* my_b = slot_b + (size_t)r * slot; char* my_q = slot_q + (size_t)r * slot;
-    // ring maintenance: group gq = jo/GROUP needs bins [GROUP*gq - TOL, GROUP*gq + GROUP + TOL).  The first GROUP+TOL bins are
-    // loaded up front; the GROUP bins a later group adds are prefetched into registers one group ahead and only written
-    // to LDS at the group boundary.
+    // ring maintenance: the bins of group gq = t/GROUP live in half (gq & 1) of the ring.  Group 0 is loaded up front; the
+    // bins of the next group are prefetched into registers one group ahead and written to LDS at the group boundary,
+    // into the half that group gq-2 used -- every wave left that group before the previous boundary's barrier, so one
+    // barrier per group is enough.
     auto ring_entry = [&](int bin, int w) -> uint4 {                              // entry w (0..EPB) of a bin's ring image
         if (w >= 4 * QROW) return *reinterpret_cast<const uint4*>(ring_src + ((size_t)(20 + w - 4 * QROW) * B + bin) * 4);
         return tb.qual_compact[((size_t)((w / QROW) * 5) * B + bin) * QROW + (w % QROW)];
@@ -607,133 +608,134 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
 #pragma unroll
         for (int u = 0; u < Geo::NPRE; ++u) { const int idx = tid + u * RB; const int bin = first + idx / EPB; if (idx < GROUP * EPB && bin < B) ring_put(bin, idx % EPB, pre[u]); }
     };
-    for (int idx = tid; idx < min(B, GROUP + TOL) * EPB; idx += RB) ring_put(idx / EPB, idx % EPB, ring_entry(idx / EPB, idx % EPB));
-    prefetch(GROUP + TOL);
+    for (int idx = tid; idx < min(B, GROUP) * EPB; idx += RB) ring_put(idx / EPB, idx % EPB, ring_entry(idx / EPB, idx % EPB));
+    prefetch(GROUP);
     __syncthreads();
 
-    // base call + quality from the ring (plain clean k-mer kk, bin inside the ring); 0 = done, 1 = base substituted (quality
-    // row not in the ring), 2 = needs the global tables altogether
-    auto call_lds = [&](uint32_t kk, uint32_t c2, uint32_t bin, uint32_t xs, uint32_t xq, uint32_t& k, uint32_t& qv) -> uint32_t {
-        const Bin* rb = &s_ring[bin & (SLOTS - 1)];
-        const LdsU32* st = (const LdsU32*)rb->subs[kk];
-        k = (xs >= st[0]) + (xs >= st[1]) + (xs >= st[2]);
-        const LdsU4* row = (const LdsU4*)rb->qd[c2 & 3u];
-        bool unresolved;
-        if (!QBIG) {
-            const u32x4_t h = row[0];                                              // {t3, t7, t11, -}
-            const uint32_t gsel = (xq >= h.x) + (xq >= h.y) + (xq >= h.z);
-            const u32x4_t G = row[1u + (gsel < 3u ? gsel : 2u)];                   // {t4g, t4g+1, t4g+2, 4 symbols}
-            const uint32_t ci = (xq >= G.x) + (xq >= G.y) + (xq >= G.z);
-            qv = (G.w >> (8u * ci)) & 255u; unresolved = gsel == 3u;
-        } else {
-            const u32x4_t p0 = row[0], p1 = row[1];                                // pivots t[5g+4]
-            const uint32_t gsel = (xq >= p0.x) + (xq >= p0.y) + (xq >= p0.z) + (xq >= p0.w) + (xq >= p1.x) + (xq >= p1.y) + (xq >= p1.z) + (xq >= p1.w);
-            const uint32_t gs = gsel < 8u ? gsel : 7u;
-            const u32x4_t G = row[2u + gs];                                        // t[5g] .. t[5g+3]
-            const u32x2_t S = ((const LdsU2*)(row + 10))[gs];                      // symbols 5g .. 5g+4
-            const uint32_t ci = (xq >= G.x) + (xq >= G.y) + (xq >= G.z) + (xq >= G.w);
-            qv = ci < 4u ? (S.x >> (8u * ci)) & 255u : S.y & 255u; unresolved = gsel == 8u;
-        }
-        return ((xs == 0xFFFFFFFFu) | (xq == 0xFFFFFFFFu) | unresolved) ? 2u : (k != c2 ? 1u : 0u);
-    };
     // a substituted base (k != c2) needs an off-diagonal quality row, which only global memory holds.  Its quality does
-    // not feed back into the walk, so the lookup is deferred: (position, k, c2, draw) goes to the free tail of the read's
-    // quality slot and is resolved after the loop, off the workgroup-synchronous path.  No room -> resolved in place.
+    // not feed back into the walk, so the lookup is deferred: (position, k, c2, bin, draw) goes to the free tail of the
+    // read's quality slot and is resolved after the loop, off the workgroup-synchronous path.  No room -> resolved in place.
     constexpr uint32_t PEND_MAX = 4;
     const bool can_defer = n_out + 15 + (int)(8 * PEND_MAX) <= (int)slot;
     uint32_t npend = 0;
     uint2* my_pend = reinterpret_cast<uint2*>(my_q + slot - 8 * PEND_MAX);
 
-    for (int jo = 0; jo < nmax; ++jo) {
-        if ((jo & (GROUP - 1)) == 0 && jo > 0) {
-            __syncthreads();                                                       // everyone is past the bins being replaced
-            commit(jo + TOL);
+    for (int t = 0; t < B; ++t) {
+        if ((t & (GROUP - 1)) == 0 && t > 0) {
+            commit(t);
             __syncthreads();
-            prefetch(jo + TOL + GROUP);
+            prefetch(t + GROUP);
         }
-        const int ring_lo = (jo & ~(GROUP - 1)) - TOL, ring_span = max(min(B, (jo & ~(GROUP - 1)) + GROUP + TOL) - ring_lo, 0);
-        const bool active = jo < n_out;
-        const uint32_t bin = __umulhi((uint32_t)jo * (uint32_t)B, mdiv);
-        const bool in_ring = (uint32_t)((int)bin - ring_lo) < (uint32_t)ring_span && ring_subs_ok;
-        // ---- (A) the source base of this output position (Profile.cpp:1632-1654, walked lazily)
-        uint32_t c2 = win_get(my_win, ji);                                         // the common case: the next window base
-        if (active && (ins_left > 0 || (uint32_t)ji == next_ev)) {                 // rare lanes: inside an insertion / at an indel event
-            if (ins_left > 0) { c2 = scale_draw(xb.next(), 0, 3); --ins_left; }    // inserted base: randomInteger(0, N-1) -> never 'T'
-            else {
-                if (replay) {                                                      // the indel tests of phase 1, drawn again (same stream, same order)
-                    Xoshiro xa; xa.s0 = my_xa[0]; xa.s1 = my_xa[1]; xa.s2 = my_xa[2]; xa.s3 = my_xa[3];
-                    while (ji < n) {
-                        if (xa.next() < t_insert) {
-                            ins_left = (int)rand_indx_thr(tb.ins_t, tb.ins_d, (uint32_t)tb.n_ins, draw4(key, ST_INDEL_LEN, aux, uid, (uint32_t)ji).w[0]);
+        const Bin* rb = &s_ring[t & (SLOTS - 1)];
+        // base call + quality from the ring (clean k-mer kk): 0 = done, 1 = base substituted (its quality row is not in the
+        // ring), 2 = needs the global tables altogether
+        auto call_lds = [&](uint32_t kk, uint32_t c2, uint32_t xs, uint32_t xq, uint32_t& k, uint32_t& qv) -> uint32_t {
+            const LdsU32* st = (const LdsU32*)rb->subs[kk];
+            k = (xs >= st[0]) + (xs >= st[1]) + (xs >= st[2]);
+            const LdsU4* row = (const LdsU4*)rb->qd[c2 & 3u];
+            bool unresolved;
+            if (!QBIG) {
+                const u32x4_t h = row[0];                                          // {t3, t7, t11, -}
+                const uint32_t gsel = (xq >= h.x) + (xq >= h.y) + (xq >= h.z);
+                const u32x4_t G = row[1u + (gsel < 3u ? gsel : 2u)];               // {t4g, t4g+1, t4g+2, 4 symbols}
+                const uint32_t ci = (xq >= G.x) + (xq >= G.y) + (xq >= G.z);
+                qv = (G.w >> (8u * ci)) & 255u; unresolved = gsel == 3u;
+            } else {
+                const u32x4_t p0 = row[0], p1 = row[1];                            // pivots t[5g+4]
+                const uint32_t gsel = (xq >= p0.x) + (xq >= p0.y) + (xq >= p0.z) + (xq >= p0.w) + (xq >= p1.x) + (xq >= p1.y) + (xq >= p1.z) + (xq >= p1.w);
+                const uint32_t gs = gsel < 8u ? gsel : 7u;
+                const u32x4_t G = row[2u + gs];                                    // t[5g] .. t[5g+3]
+                const u32x2_t S = ((const LdsU2*)(row + 10))[gs];                  // symbols 5g .. 5g+4
+                const uint32_t ci = (xq >= G.x) + (xq >= G.y) + (xq >= G.z) + (xq >= G.w);
+                qv = ci < 4u ? (S.x >> (8u * ci)) & 255u : S.y & 255u; unresolved = gsel == 8u;
+            }
+            return ((xs == 0xFFFFFFFFu) | (xq == 0xFFFFFFFFu) | unresolved) ? 2u : (k != c2 ? 1u : 0u);
+        };
+        for (;;) {
+            const bool mine = jo < n_out && nb == (uint32_t)t;                     // my position jo falls into bin t
+            if (!__any(mine)) break;
+            // ---- (A) the source base of this output position (Profile.cpp:1632-1654, walked lazily)
+            uint32_t c2 = win_get(my_win, ji);                                     // the common case: the next window base
+            if (mine && (ins_left > 0 || (uint32_t)ji == next_ev)) {               // rare lanes: inside an insertion / at an indel event
+                if (ins_left > 0) { c2 = scale_draw(xb.next(), 0, 3); --ins_left; }   // inserted base: randomInteger(0, N-1) -> never 'T'
+                else {
+                    if (replay) {                                                  // the indel tests of phase 1, drawn again (same stream, same order)
+                        Xoshiro xa; xa.s0 = my_xa[0]; xa.s1 = my_xa[1]; xa.s2 = my_xa[2]; xa.s3 = my_xa[3];
+                        while (ji < n) {
+                            if (xa.next() < t_insert) {
+                                ins_left = (int)rand_indx_thr(tb.ins_t, tb.ins_d, (uint32_t)tb.n_ins, draw4(key, ST_INDEL_LEN, aux, uid, (uint32_t)ji).w[0]);
+                                break;
+                            }
+                            if (xa.next() < t_delete) {
+                                const uint32_t k = rand_indx_thr(tb.del_t, tb.del_d, (uint32_t)tb.n_del, draw4(key, ST_INDEL_LEN, aux, uid, (uint32_t)ji).w[0]);
+                                if (k > 0) { ji += (int)k < n - ji ? (int)k : n - ji; continue; }
+                            }
                             break;
                         }
-                        if (xa.next() < t_delete) {
-                            const uint32_t k = rand_indx_thr(tb.del_t, tb.del_d, (uint32_t)tb.n_del, draw4(key, ST_INDEL_LEN, aux, uid, (uint32_t)ji).w[0]);
-                            if (k > 0) { ji += (int)k < n - ji ? (int)k : n - ji; continue; }
+                        my_xa[0] = xa.s0; my_xa[1] = xa.s1; my_xa[2] = xa.s2; my_xa[3] = xa.s3;
+                        c2 = win_get(my_win, ji); ++ji; next_ev = (uint32_t)ji;    // a replayed read stops here at every base
+                    } else {
+                        while (evi < nev) {                                        // deletions starting here
+                            const uint32_t ev = my_ev[evi];
+                            if (ev_pos(ev) != (uint32_t)ji || !ev_del(ev)) break;
+                            ji += (int)ev_len(ev); ++evi;
                         }
-                        break;
+                        c2 = win_get(my_win, ji);
+                        if (evi < nev) { const uint32_t ev = my_ev[evi]; if (ev_pos(ev) == (uint32_t)ji) { ins_left = (int)ev_len(ev); ++evi; } }
+                        ++ji;
+                        next_ev = evi < nev ? ev_pos(my_ev[evi]) : 0xFFFFFFFFu;
                     }
-                    my_xa[0] = xa.s0; my_xa[1] = xa.s1; my_xa[2] = xa.s2; my_xa[3] = xa.s3;
-                    c2 = win_get(my_win, ji); ++ji; next_ev = (uint32_t)ji;        // a replayed read stops here at every base
-                } else {
-                    while (evi < nev) {                                            // deletions starting here
-                        const uint32_t ev = my_ev[evi];
-                        if (ev_pos(ev) != (uint32_t)ji || !ev_del(ev)) break;
-                        ji += (int)ev_len(ev); ++evi;
+                }
+            } else if (mine) ++ji;
+            // ---- (B) base call + quality (Profile.cpp:1666-1694)
+            uint32_t bc = 0, qc = 0;
+            if (__any(mine && ((c0 | c1 | c2) > 3u || !ring_subs_ok))) {           // some read of the wave: first two bases, an N in the k-mer
+                if (mine) {
+                    const int ki = kmer_index(c0, c1, c2);
+                    const uint32_t xs = ki >= 0 ? xb.next() : 0u;                  // drawn only when the k-mer is in the table
+                    const uint32_t xq = xb.next();
+                    if (ki < 0 && c2 > 3u) { bc = 'N'; qc = 33 + scale_draw(xq, 0, 20); }   // getRandBaseQuality
+                    else {
+                        uint32_t k = c2, qv = 0, odd = 2u;
+                        if (ki >= 20 && ring_subs_ok) odd = call_lds((uint32_t)ki - 20u, c2, xs, xq, k, qv);
+                        if (odd == 1u && can_defer && npend < PEND_MAX) { my_pend[npend++] = make_uint2((uint32_t)jo | (k << 12) | (c2 << 14) | ((uint32_t)t << 16), xq); qv = 0; odd = 0u; }
+                        if (odd) {
+                            const uint32_t kq = call_global<QBIG>(subs, subs_d, tb.qual_compact, tb.qual, tb.qual_d, tb.qual_guide, (uint32_t)B, ki, c2, c2, (uint32_t)t, xs, xq);
+                            k = kq & 255u; qv = kq >> 8;
+                        }
+                        bc = (0x54474341u >> (8u * k)) & 255u; qc = 33 + qv;       // "ACGT"[k]
                     }
-                    c2 = win_get(my_win, ji);
-                    if (evi < nev) { const uint32_t ev = my_ev[evi]; if (ev_pos(ev) == (uint32_t)ji) { ins_left = (int)ev_len(ev); ++evi; } }
-                    ++ji;
-                    next_ev = evi < nev ? ev_pos(my_ev[evi]) : 0xFFFFFFFFu;
                 }
+            } else if (mine) {                                                     // the whole wave on clean k-mers
+                const uint32_t xs = xb.next(), xq = xb.next();
+                const uint32_t kk = (c0 << 4) | (c1 << 2) | c2;
+                uint32_t k, qv;
+                uint32_t odd = call_lds(kk, c2, xs, xq, k, qv);
+                if (odd == 1u && can_defer && npend < PEND_MAX) { my_pend[npend++] = make_uint2((uint32_t)jo | (k << 12) | (c2 << 14) | ((uint32_t)t << 16), xq); qv = 0; odd = 0u; }
+                if (odd) {
+                    const uint32_t kq = call_global<QBIG>(subs, subs_d, tb.qual_compact, tb.qual, tb.qual_d, tb.qual_guide, (uint32_t)B, (int)kk + 20, c2, c2, (uint32_t)t, xs, xq);
+                    k = kq & 255u; qv = kq >> 8;
+                }
+                bc = (0x54474341u >> (8u * k)) & 255u; qc = 33 + qv;
             }
-        } else if (active) ++ji;
-        // ---- (B) base call + quality (Profile.cpp:1666-1694)
-        uint32_t bc = 0, qc = 0;
-        if (__any(active && ((c0 | c1 | c2) > 3u || !in_ring))) {                  // some read of the wave: first two bases, an N in the k-mer, bin outside the ring
-            if (active) {
-                const int ki = kmer_index(c0, c1, c2);
-                const uint32_t xs = ki >= 0 ? xb.next() : 0u;                      // drawn only when the k-mer is in the table
-                const uint32_t xq = xb.next();
-                if (ki < 0 && c2 > 3u) { bc = 'N'; qc = 33 + scale_draw(xq, 0, 20); }   // getRandBaseQuality
-                else {
-                    uint32_t k = c2, qv = 0, odd = 2u;
-                    if (ki >= 20 && in_ring) odd = call_lds((uint32_t)ki - 20u, c2, bin, xs, xq, k, qv);
-                    if (odd == 1u && can_defer && npend < PEND_MAX) { my_pend[npend++] = make_uint2((uint32_t)jo | (k << 12) | (c2 << 14) | (bin << 16), xq); qv = 0; odd = 0u; }
-                    if (odd) {
-                        const uint32_t kq = call_global<QBIG>(subs, subs_d, tb.qual_compact, tb.qual, tb.qual_d, tb.qual_guide, (uint32_t)B, ki, c2, c2, bin, xs, xq);
-                        k = kq & 255u; qv = kq >> 8;
+            // ---- output: 4 characters per word, 16 per store
+            if (mine) {
+                const uint32_t sh = 8u * ((uint32_t)jo & 3u);
+                cur_b |= bc << sh; cur_q |= qc << sh; c0 = c1; c1 = c2;
+                const bool lastp = jo == n_out - 1;
+                if (((uint32_t)jo & 3u) == 3u || lastp) {
+                    const uint32_t w = ((uint32_t)jo >> 2) & 3u;
+                    ob0 = w == 0u ? cur_b : ob0; ob1 = w == 1u ? cur_b : ob1; ob2 = w == 2u ? cur_b : ob2; ob3 = w == 3u ? cur_b : ob3;
+                    oq0 = w == 0u ? cur_q : oq0; oq1 = w == 1u ? cur_q : oq1; oq2 = w == 2u ? cur_q : oq2; oq3 = w == 3u ? cur_q : oq3;
+                    cur_b = 0; cur_q = 0;
+                    if (((uint32_t)jo & 15u) == 15u || lastp) {
+                        const int o = jo & ~15;
+                        *reinterpret_cast<uint4*>(my_b + o) = make_uint4(ob0, ob1, ob2, ob3);
+                        *reinterpret_cast<uint4*>(my_q + o) = make_uint4(oq0, oq1, oq2, oq3);
+                        ob0 = ob1 = ob2 = ob3 = 0; oq0 = oq1 = oq2 = oq3 = 0;
                     }
-                    bc = (0x54474341u >> (8u * k)) & 255u; qc = 33 + qv;           // "ACGT"[k]
                 }
-            }
-        } else if (active) {                                                       // the whole wave on clean k-mers inside the ring
-            const uint32_t xs = xb.next(), xq = xb.next();
-            const uint32_t kk = (c0 << 4) | (c1 << 2) | c2;
-            uint32_t k, qv;
-            uint32_t odd = call_lds(kk, c2, bin, xs, xq, k, qv);
-            if (odd == 1u && can_defer && npend < PEND_MAX) { my_pend[npend++] = make_uint2((uint32_t)jo | (k << 12) | (c2 << 14) | (bin << 16), xq); qv = 0; odd = 0u; }
-            if (odd) {
-                const uint32_t kq = call_global<QBIG>(subs, subs_d, tb.qual_compact, tb.qual, tb.qual_d, tb.qual_guide, (uint32_t)B, (int)kk + 20, c2, c2, bin, xs, xq);
-                k = kq & 255u; qv = kq >> 8;
-            }
-            bc = (0x54474341u >> (8u * k)) & 255u; qc = 33 + qv;
-        }
-        const uint32_t sh = 8u * ((uint32_t)jo & 3u);
-        if (active) { cur_b |= bc << sh; cur_q |= qc << sh; c0 = c1; c1 = c2; }
-        const bool last = jo == nmax - 1;
-        if ((jo & 3) == 3 || last) {                                               // uniform: close the 4-character word
-            const int w = (jo >> 2) & 3;
-            if (w == 0) { ob0 = cur_b; oq0 = cur_q; } else if (w == 1) { ob1 = cur_b; oq1 = cur_q; }
-            else if (w == 2) { ob2 = cur_b; oq2 = cur_q; } else { ob3 = cur_b; oq3 = cur_q; }
-            cur_b = 0; cur_q = 0;
-            if ((jo & 15) == 15 || last) {                                         // 16 output characters per store
-                const int o = jo & ~15;
-                if (o < n_out) {
-                    *reinterpret_cast<uint4*>(my_b + o) = make_uint4(ob0, ob1, ob2, ob3);
-                    *reinterpret_cast<uint4*>(my_q + o) = make_uint4(oq0, oq1, oq2, oq3);
-                }
-                ob0 = ob1 = ob2 = ob3 = 0; oq0 = oq1 = oq2 = oq3 = 0;
+                ++jo; nb = __umulhi(__umul24((uint32_t)jo, (uint32_t)B), mdiv);
             }
         }
     }
