@@ -122,7 +122,8 @@ void launch_philox(hipStream_t s, const uint32_t* ctr, uint32_t n, RngKey key, u
 void launch_detlog(hipStream_t s, const double* x, uint32_t n, double* out);
 
 // gathers up to 12 device scalars (4 or 8 bytes wide) into mail[dsts[i]] (u64 each)
-void launch_mail(hipStream_t s, const void* const* srcs, const int* widths, const int* dsts, int n, unsigned long long* mail);
+#define MAIL_SEQ_SLOT 31                                   // mailbox word the sequence number of a post lands in
+void launch_mail(hipStream_t s, const void* const* srcs, const int* widths, const int* dsts, int n, unsigned long long* mail, unsigned long long seq);
 
 // first error of any kernel launch / attribute call since the last call (hipSuccess if none)
 hipError_t take_launch_error();

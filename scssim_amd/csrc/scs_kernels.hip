@@ -1080,16 +1080,25 @@ __global__ void k_alloc_parity(uint32_t* __restrict__ rn, const uint32_t* __rest
 }
 
 struct Widen { __host__ __device__ uint64_t operator()(uint32_t v) const { return (uint64_t)v; } };
-// mailbox: collects scattered device scalars into one contiguous block so the host reads them with ONE copy
+// mailbox: collects scattered device scalars into one contiguous block of PINNED, DEVICE-MAPPED host memory, so the
+// host reads them without a copy or a stream synchronisation: it spins on the sequence word that the post writes last
+// (system-scope release).  A null source posts 0.
 struct MailSrc { const void* p[12]; int w[12]; int dst[12]; int n; };
-__global__ void k_mail(MailSrc m, unsigned long long* __restrict__ mail) {
+__global__ void k_mail(MailSrc m, unsigned long long* __restrict__ mail, unsigned long long seq) {
     const int i = threadIdx.x;
-    if (i < m.n) mail[m.dst[i]] = m.w[i] == 8 ? *reinterpret_cast<const unsigned long long*>(m.p[i]) : (unsigned long long)*reinterpret_cast<const uint32_t*>(m.p[i]);
+    if (i < m.n) {
+        unsigned long long v = 0;
+        if (m.p[i]) v = m.w[i] == 8 ? *reinterpret_cast<const unsigned long long*>(m.p[i]) : (unsigned long long)*reinterpret_cast<const uint32_t*>(m.p[i]);
+        __hip_atomic_store(&mail[m.dst[i]], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (i == 0 && seq) __hip_atomic_store(&mail[MAIL_SEQ_SLOT], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-void launch_mail(hipStream_t s, const void* const* srcs, const int* widths, const int* dsts, int n, unsigned long long* mail) {
+void launch_mail(hipStream_t s, const void* const* srcs, const int* widths, const int* dsts, int n, unsigned long long* mail, unsigned long long seq) {
     MailSrc m; m.n = n;
     for (int i = 0; i < 12; ++i) { m.p[i] = i < n ? srcs[i] : nullptr; m.w[i] = i < n ? widths[i] : 4; m.dst[i] = i < n ? dsts[i] : 0; }
-    hipLaunchKernelGGL(k_mail, dim3(1), dim3(64), 0, s, m, mail);
+    hipLaunchKernelGGL(k_mail, dim3(1), dim3(64), 0, s, m, mail, seq);
 }
 struct OddBit { __host__ __device__ uint32_t operator()(uint32_t v) const { return v & 1u; } };
 struct HalfUp { __host__ __device__ uint32_t operator()(uint32_t v) const { return (v + 1u) >> 1; } };

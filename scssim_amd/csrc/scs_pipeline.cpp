@@ -5,6 +5,7 @@
 #include "scs_device.h"
 #include "scs_tables.h"
 
+#include <atomic>
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -108,7 +109,8 @@ struct scs_ctx {
     DevBuf df_goff, df_len, df_strand, df_primers;
     // amplicons
     AmpStore semis, fulls;
-    DevBuf budget_f, budget_s, slot_off_f, slot_off_s, dsums; uint64_t* h_rb = nullptr;   // dsums: device scalars; h_rb: pinned read-back slots
+    DevBuf budget_f, budget_s, slot_off_f, slot_off_s, dsums; uint64_t* h_rb = nullptr;   // dsums: device scalars; h_rb: pinned, device-mapped mailbox (32 words)
+    unsigned long long* d_rb = nullptr; uint64_t mail_seq = 0;                      // device address of h_rb; sequence of the last post
     uint64_t frag_total_len = 0, semi_total_len = 0; uint32_t slots_f = 0, slots_s = 0, budget_ns = 0;
     DevBuf primer_cnt, primer_delta; uint64_t total_primers = 0; bool amplified = false;
     DevBuf slots, slot_tmpl, valid, valid_off, scan_tmp, flags;
@@ -151,11 +153,31 @@ struct scs_ctx {
 
 namespace {
 
+// ---- mailbox: device scalars -> pinned host words, no copy and no stream sync (k_mail)
+struct Mail {
+    const void* src[12]; int wd[12]; int dst[12]; int n = 0;
+    void add(const void* p, int width, int slot) { src[n] = p; wd[n] = width; dst[n] = slot; ++n; }
+};
+void mail_post(scs_ctx* c, const Mail& m, bool last) {                            // last: the post the host will wait for
+    launch_mail(c->stream, m.src, m.wd, m.dst, m.n, c->d_rb, last ? ++c->mail_seq : 0ull);
+}
+void mail_wait(scs_ctx* c) {                                                      // everything posted so far has landed in h_rb
+    volatile uint64_t* flag = c->h_rb + MAIL_SEQ_SLOT;
+    for (uint64_t spin = 1;; ++spin) {
+        if (*flag == c->mail_seq) break;
+        if ((spin & 0x3FFF) == 0) {                                               // a failed or drained stream must not leave the host spinning
+            const hipError_t q = hipStreamQuery(c->stream);
+            if (q == hipSuccess) { if (*flag == c->mail_seq) break; throw ScsError(SCS_EDEVICE, "mailbox: stream drained without the expected post"); }
+            if (q != hipErrorNotReady) throw ScsError(SCS_EDEVICE, std::string("mailbox: ") + hipGetErrorString(q));
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+}
+
 void check_flags(scs_ctx* c) {
     { const hipError_t le = take_launch_error(); if (le != hipSuccess) throw ScsError(SCS_EDEVICE, std::string("kernel launch failed: ") + hipGetErrorString(le)); }
-    uint32_t f = 0;
-    HIP_OK(hipMemcpyAsync(&f, c->flags.p, 4, hipMemcpyDeviceToHost, c->stream));
-    HIP_OK(hipStreamSynchronize(c->stream));
+    Mail m; m.add(c->flags.p, 4, 30); mail_post(c, m, true); mail_wait(c);
+    const uint32_t f = (uint32_t)c->h_rb[30];
     if (f) {
         HIP_OK(hipMemsetAsync(c->flags.p, 0, 4, c->stream));
         std::string m = "device work buffer overflow:";
@@ -280,12 +302,11 @@ void set_primers(scs_ctx* c, bool only_frags, uint32_t call) {
     c->reduce_dev(c->dsums.p, 2, 8);                                               // sharded: budgets of all shards leave the pool
     uint64_t* rb = c->h_rb;
     {
-        const void* src[4] = {c->dsums.p, c->dsums.as<unsigned long long>() + 1, c->slot_off_f.as<uint32_t>() + nf, ns ? (const void*)(c->slot_off_s.as<uint32_t>() + ns) : c->dsums.as<unsigned long long>() + 7};
-        const int wd[4] = {8, 8, 4, ns ? 4 : 8}, dst[4] = {0, 1, 2, 3};
-        launch_mail(s, src, wd, dst, 4, c->d_mail.as<unsigned long long>());
-        HIP_OK(hipMemcpyAsync(rb, c->d_mail.p, 32, hipMemcpyDeviceToHost, s));
+        Mail m; m.add(c->dsums.p, 8, 0); m.add(c->dsums.as<unsigned long long>() + 1, 8, 1); m.add(c->slot_off_f.as<uint32_t>() + nf, 4, 2);
+        m.add(ns ? (const void*)(c->slot_off_s.as<uint32_t>() + ns) : nullptr, 4, 3);
+        mail_post(c, m, true);
     }
-    HIP_OK(hipStreamSynchronize(s));
+    mail_wait(c);
     c->total_primers -= rb[0] + rb[1];
     c->slots_f = (uint32_t)rb[2]; c->slots_s = (uint32_t)rb[3]; c->budget_ns = ns;
 }
@@ -298,8 +319,9 @@ void launch_pass(scs_ctx* c, bool from_frag, uint32_t pass, int rb_slot) {
     const uint32_t n_slots = from_frag ? c->slots_f : c->slots_s;
     if (nt == 0 || n_slots == 0) {                                                 // nothing local; a shard still joins the pass's collective
         if (c->sharded()) { c->reduce_dev(c->primer_delta.p, 65536, 4); launch_primer_update(s, c->primer_cnt.as<int64_t>(), c->primer_delta.as<uint32_t>()); }
-        HIP_OK(hipMemsetAsync(c->d_mail.as<unsigned long long>() + rb_slot, 0, 8, s));
-        if (!from_frag) { HIP_OK(hipMemsetAsync(c->d_mail.as<unsigned long long>() + 16, 0, 64, s)); c->pending_seg_cycle = (int)pass; }
+        Mail m; m.add(nullptr, 8, rb_slot);
+        if (!from_frag) { for (int b = 0; b < 8; ++b) m.add(nullptr, 8, 16 + b); c->pending_seg_cycle = (int)pass; }
+        mail_post(c, m, false);
         return;
     }
     const uint32_t* slot_off = (from_frag ? c->slot_off_f : c->slot_off_s).as<uint32_t>();
@@ -333,24 +355,18 @@ void launch_pass(scs_ctx* c, bool from_frag, uint32_t pass, int rb_slot) {
     launch_primer_update(s, c->primer_cnt.as<int64_t>(), c->primer_delta.as<uint32_t>());
     {   // counts of this pass -> mailbox (read by the host at the group's sync): new amplicons, and for a semi pass the
         // fulls made from the semis of each fragment pass (segments)
-        const void* src[12]; int wd[12], dst[12]; int n = 0;
-        src[n] = c->valid_off.as<uint32_t>() + nt; wd[n] = 4; dst[n] = rb_slot; ++n;
+        Mail m; m.add(c->valid_off.as<uint32_t>() + nt, 4, rb_slot);
         if (!from_frag) {
-            for (size_t b = 0; b < c->semi_block_end.size() && b < 8; ++b) { src[n] = c->valid_off.as<uint32_t>() + std::min(c->semi_block_end[b], nt); wd[n] = 4; dst[n] = 16 + (int)b; ++n; }
+            for (size_t b = 0; b < c->semi_block_end.size() && b < 8; ++b) m.add(c->valid_off.as<uint32_t>() + std::min(c->semi_block_end[b], nt), 4, 16 + (int)b);
             c->pending_seg_cycle = (int)pass;
         }
-        launch_mail(s, src, wd, dst, n, c->d_mail.as<unsigned long long>());
+        mail_post(c, m, false);
     }
 }
 // host sync closing a group of passes: counts of new amplicons, total length of the semis
 void collect_passes(scs_ctx* c, int rb_fulls, int rb_semis) {
-    hipStream_t s = c->stream;
-    {
-        const void* src[1] = {c->dsums.as<unsigned long long>() + 4}; const int wd[1] = {8}, dst[1] = {8};
-        launch_mail(s, src, wd, dst, 1, c->d_mail.as<unsigned long long>());
-    }
-    HIP_OK(hipMemcpyAsync(c->h_rb, c->d_mail.p, 256, hipMemcpyDeviceToHost, s));
-    HIP_OK(hipStreamSynchronize(s));
+    { Mail m; m.add(c->dsums.as<unsigned long long>() + 4, 8, 8); mail_post(c, m, true); }
+    mail_wait(c);
     if (rb_fulls >= 0) {
         c->fulls.n += (uint32_t)c->h_rb[rb_fulls]; c->tm_errscan.units += c->h_rb[rb_fulls];
         if (c->pending_seg_cycle >= 0) {                                          // stored order within a cycle: fragment pass p descending
@@ -483,9 +499,8 @@ void do_allocate(scs_ctx* c, uint64_t reads) {
         upload(c->d_gidx, gidx, s); HIP_OK(hipStreamSynchronize(s)); c->have_gidx = true;
     }
     launch_pair_offsets(s, c->read_numbers.as<uint32_t>(), ac, c->cfg.paired != 0, c->pair_off.as<uint32_t>(), c->scan_tmp.p, c->scan_tmp.cap);
-    c->h_rb[0] = 0;
-    if (ac) HIP_OK(hipMemcpyAsync(&c->h_rb[0], c->pair_off.as<uint32_t>() + ac, 4, hipMemcpyDeviceToHost, s));
-    HIP_OK(hipStreamSynchronize(s));
+    { Mail m; m.add(ac ? (const void*)(c->pair_off.as<uint32_t>() + ac) : nullptr, 4, 0); mail_post(c, m, true); }
+    mail_wait(c);
     c->n_pairs_planned = (uint32_t)c->h_rb[0];
     c->st.t_stage[3] = 0; c->st.t_stage[4] = now_s() - t0;
     c->allocated = true;
@@ -556,10 +571,9 @@ void do_yield(scs_ctx* c, const OutTarget& tg, uint64_t* n1_out, uint64_t* n2_ou
         { const hipError_t le = take_launch_error(); if (le != hipSuccess) throw ScsError(SCS_EDEVICE, std::string("k_reads launch failed: ") + hipGetErrorString(le)); }
         exclusive_scan_u32_to_u64(s, c->sizes1.as<uint32_t>(), c->off1.as<uint64_t>(), np, c->scan_tmp.p, c->scan_tmp.cap);
         if (paired) exclusive_scan_u32_to_u64(s, c->sizes2.as<uint32_t>(), c->off2.as<uint64_t>(), np, c->scan_tmp.p, c->scan_tmp.cap);
-        uint64_t b1 = 0, b2 = 0;
-        HIP_OK(hipMemcpyAsync(&b1, c->off1.as<uint64_t>() + np, 8, hipMemcpyDeviceToHost, s));
-        if (paired) HIP_OK(hipMemcpyAsync(&b2, c->off2.as<uint64_t>() + np, 8, hipMemcpyDeviceToHost, s));
-        HIP_OK(hipStreamSynchronize(s));
+        { Mail m; m.add(c->off1.as<uint64_t>() + np, 8, 0); m.add(paired ? (const void*)(c->off2.as<uint64_t>() + np) : nullptr, 8, 1); mail_post(c, m, true); }
+        mail_wait(c);
+        const uint64_t b1 = c->h_rb[0], b2 = c->h_rb[1];
         char *o1, *o2;
         if (tg.device) {
             if (tot1 + b1 > tg.cap1 || tot2 + b2 > tg.cap2) throw ScsError(SCS_EOVERFLOW, "scs_yield_reads_device: output buffer too small");
@@ -654,8 +668,9 @@ int scs_create(const scs_config* cfg, scs_ctx** out) {
         c->key = RngKey{(uint32_t)cfg->seed, (uint32_t)(cfg->seed >> 32)};
         c->flags.reserve(256, c->stream); HIP_OK(hipMemsetAsync(c->flags.p, 0, 256, c->stream));
         c->dsums.reserve(256, c->stream); HIP_OK(hipMemsetAsync(c->dsums.p, 0, 256, c->stream));
-        c->d_tot.reserve(256, c->stream); c->d_mail.reserve(256, c->stream); HIP_OK(hipMemsetAsync(c->d_mail.p, 0, 256, c->stream));
-        HIP_OK(hipHostMalloc((void**)&c->h_rb, 256, hipHostMallocDefault)); memset(c->h_rb, 0, 256);
+        c->d_tot.reserve(256, c->stream);
+        HIP_OK(hipHostMalloc((void**)&c->h_rb, 256, hipHostMallocMapped | hipHostMallocCoherent)); memset(c->h_rb, 0, 256);
+        HIP_OK(hipHostGetDevicePointer((void**)&c->d_rb, c->h_rb, 0));
         HIP_OK(hipStreamSynchronize(c->stream));
     } catch (const std::exception& e) { g_create_error = e.what(); delete c; return SCS_EDEVICE; }
     *out = c; return SCS_OK;
