@@ -177,8 +177,14 @@ def main():
             for f in ("launches", "ms", "units"):
                 d[f] += kt[k][f]
 
+    # warm-up: every kernel timed -> per-kernel breakdown and the dominant kernel.  Timed region: HIP events only around
+    # that dominant kernel (each event record is a packet on the stream of this latency-bound job).
     for i in range(a.warmup):
-        step(i, False)
+        step(i, True)
+    warm_ktimes = {k: dict(v) for k, v in ktimes.items()}
+    dominant = max(warm_ktimes, key=lambda k: warm_ktimes[k]["ms"]) if warm_ktimes else "k_reads"
+    ktimes.clear()
+    g.set_kernel_timing([dominant])
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -205,7 +211,7 @@ def main():
         pairs_total = int(pt[0])
 
     if rank == 0:
-        dom = max(ktimes, key=lambda k: ktimes[k]["ms"])
+        dom = dominant
         kd = ktimes[dom]
         if dom.startswith("k_errs"):
             # 1526 algorithmic bytes per created amplicon (template window read once + descriptor
@@ -230,7 +236,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes": note,
                          "algorithmic_bytes_per_launch": alg / max(1, kd["launches"]), "avg_launch_ms": kd["ms"] / max(1, kd["launches"])},
-            "kernels_ms_per_step": {k: v["ms"] / a.steps for k, v in ktimes.items()},
+            "kernels_ms_per_step_warmup": {k: v["ms"] / max(1, a.warmup) for k, v in warm_ktimes.items()},
             "whole_job_algorithmic_GBps": alg_bytes / elapsed / 1e9,
         }
         if world == 1 and not a.no_cpu_baseline:

@@ -63,7 +63,8 @@ struct AmplifyParams {
 struct PoissonParams {
     RngKey key; uint32_t call; double gamma;
     uint64_t total_primers;                            // Malbac::setPrimers inputs (Malbac.cpp:236-262)
-    const uint64_t* totals;                            // device: {template_num, total_len} over ALL shards
+    const uint64_t* totals;                            // sharded job: device {template_num, total_len} over ALL shards; else null
+    uint64_t tot_n, tot_len;                           // unsharded job: the same two totals, by value
 };
 struct AllocState { double total; unsigned long long sum_rn, sum_quota; };
 
@@ -123,7 +124,7 @@ void launch_detlog(hipStream_t s, const double* x, uint32_t n, double* out);
 
 // gathers up to 12 device scalars (4 or 8 bytes wide) into mail[dsts[i]] (u64 each)
 #define MAIL_SEQ_SLOT 31                                   // mailbox word the sequence number of a post lands in
-void launch_mail(hipStream_t s, const void* const* srcs, const int* widths, const int* dsts, int n, unsigned long long* mail, unsigned long long seq);
+void launch_mail(hipStream_t s, const void* const* srcs, const int* widths, const int* dsts, int n, unsigned clear, unsigned long long* mail, unsigned long long seq);
 
 // first error of any kernel launch / attribute call since the last call (hipSuccess if none)
 hipError_t take_launch_error();
@@ -131,6 +132,7 @@ hipError_t take_launch_error();
 // device-wide exclusive scans (n inputs -> n+1 outputs, last = total)
 size_t scan_temp_bytes(size_t n);
 void exclusive_scan_u32(hipStream_t s, const uint32_t* in, uint32_t* out, size_t n, void* temp, size_t temp_bytes);
+void exclusive_scan_u32_pair(hipStream_t s, const uint32_t* in0, uint32_t* out0, size_t n0, const uint32_t* in1, uint32_t* out1, size_t n1, void* temp, size_t temp_bytes);
 void exclusive_scan_u32_to_u64(hipStream_t s, const uint32_t* in, uint64_t* out, size_t n, void* temp, size_t temp_bytes);
 
 }  // namespace scs

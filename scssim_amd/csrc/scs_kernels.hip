@@ -824,7 +824,7 @@ __device__ __forceinline__ void block_add_u64(unsigned long long v, unsigned lon
 //     sums[0] += sum of k over fragments, sums[1] += sum of UNTRUNCATED k over semis (Malbac.cpp:282).
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ double poisson_lambda(const PoissonParams& p, uint32_t len) {
-    const uint64_t template_num = p.totals[0], total_len = p.totals[1];
+    const uint64_t template_num = p.totals ? p.totals[0] : p.tot_n, total_len = p.totals ? p.totals[1] : p.tot_len;
     const unsigned long long expected = (unsigned long long)((double)p.total_primers * p.gamma * (double)template_num);
     return (double)expected * (1.0 * (double)len / (double)total_len);
 }
@@ -903,10 +903,12 @@ __global__ void __launch_bounds__(64) k_attach(const uint8_t* __restrict__ g, De
         }
     }
     uint32_t* bits = s_bits + gi * WORDS;
+    const uint32_t base_slot = t < nt ? slot_off[t] : 0, aux = (FROM_FRAG ? 0u : 1u) | (p.pass << 1);
+    for (uint32_t w = gl; w < budget; w += G) slot_tmpl[base_slot + w] = 0xFFFFFFFFu;   // my template's slots start out unused (k_errs skips those)
+    __threadfence_block();                                                         // ... before any commit below rewrites one of them
     bool group_done = !(t < nt && len >= p.amp_min + 27 && budget > 0);
     if (!group_done) for (uint32_t w = gl; w < (len + 31) / 32; w += G) bits[w] = 0;
     __builtin_amdgcn_wave_barrier();
-    const uint32_t base_slot = t < nt ? slot_off[t] : 0, aux = (FROM_FRAG ? 0u : 1u) | (p.pass << 1);
     uint32_t v = 0, c0 = 0, i = 0, tries = 0, spos = 0, alen = 0, pidx = 0;
     bool fresh = true, unresolved = false, need = false, dead = false;
     unsigned long long lsum = 0; U4 dblk{};
@@ -1083,20 +1085,23 @@ struct Widen { __host__ __device__ uint64_t operator()(uint32_t v) const { retur
 // mailbox: collects scattered device scalars into one contiguous block of PINNED, DEVICE-MAPPED host memory, so the
 // host reads them without a copy or a stream synchronisation: it spins on the sequence word that the post writes last
 // (system-scope release).  A null source posts 0.
-struct MailSrc { const void* p[12]; int w[12]; int dst[12]; int n; };
+struct MailSrc { const void* p[12]; int w[12]; int dst[12]; int n; unsigned clear; };   // clear: bit i = zero source i after reading it
 __global__ void k_mail(MailSrc m, unsigned long long* __restrict__ mail, unsigned long long seq) {
     const int i = threadIdx.x;
     if (i < m.n) {
         unsigned long long v = 0;
-        if (m.p[i]) v = m.w[i] == 8 ? *reinterpret_cast<const unsigned long long*>(m.p[i]) : (unsigned long long)*reinterpret_cast<const uint32_t*>(m.p[i]);
+        if (m.p[i]) {
+            if (m.w[i] == 8) { unsigned long long* q = reinterpret_cast<unsigned long long*>(const_cast<void*>(m.p[i])); v = *q; if ((m.clear >> i) & 1u) *q = 0; }
+            else { uint32_t* q = reinterpret_cast<uint32_t*>(const_cast<void*>(m.p[i])); v = *q; if ((m.clear >> i) & 1u) *q = 0; }
+        }
         __hip_atomic_store(&mail[m.dst[i]], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     __threadfence_system();
     __syncthreads();
     if (i == 0 && seq) __hip_atomic_store(&mail[MAIL_SEQ_SLOT], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-void launch_mail(hipStream_t s, const void* const* srcs, const int* widths, const int* dsts, int n, unsigned long long* mail, unsigned long long seq) {
-    MailSrc m; m.n = n;
+void launch_mail(hipStream_t s, const void* const* srcs, const int* widths, const int* dsts, int n, unsigned clear, unsigned long long* mail, unsigned long long seq) {
+    MailSrc m; m.n = n; m.clear = clear;
     for (int i = 0; i < 12; ++i) { m.p[i] = i < n ? srcs[i] : nullptr; m.w[i] = i < n ? widths[i] : 4; m.dst[i] = i < n ? dsts[i] : 0; }
     hipLaunchKernelGGL(k_mail, dim3(1), dim3(64), 0, s, m, mail, seq);
 }
@@ -1246,9 +1251,51 @@ size_t scan_temp_bytes(size_t n) {
                                   (uint64_t*)nullptr, (uint64_t)0, n + 1, rocprim::plus<uint64_t>());
     return (a > b ? a : b) + 256;
 }
+// exclusive scan of up to two small arrays in ONE launch (one 1024-thread workgroup each; out gets n+1 entries).  The
+// per-pass scans of a small job are launch-latency bound: rocPRIM's scan is two launches per array.
+#define SMALL_SCAN_MAX (256u * 1024u)
+__global__ void __launch_bounds__(1024) k_scan_small(const uint32_t* __restrict__ in0, uint32_t* __restrict__ out0, uint32_t n0,
+                                                     const uint32_t* __restrict__ in1, uint32_t* __restrict__ out1, uint32_t n1) {
+    const uint32_t* __restrict__ in = blockIdx.x ? in1 : in0; uint32_t* __restrict__ out = blockIdx.x ? out1 : out0; const uint32_t n = blockIdx.x ? n1 : n0;
+    __shared__ uint32_t s_tot[16];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+    // wave w owns a contiguous segment (a multiple of 256 elements); tiles of 256 = one uint4 per lane, coalesced
+    const uint32_t seg = (((n + 15u) / 16u) + 255u) & ~255u, lo = min(w * seg, n), hi = min(lo + seg, n);
+    auto load4 = [&](uint32_t idx, uint32_t v[4]) {
+        if (idx + 3u < n) { const uint4 q = *reinterpret_cast<const uint4*>(in + idx); v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w; }
+        else for (uint32_t k = 0; k < 4; ++k) v[k] = idx + k < n ? in[idx + k] : 0u;
+    };
+    uint32_t sum = 0;
+    for (uint32_t base = lo; base < hi; base += 256u) { uint32_t v[4]; load4(base + 4u * lane, v); sum += v[0] + v[1] + v[2] + v[3]; }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) sum += __shfl_xor(sum, d);
+    if (lane == 0) s_tot[w] = sum;
+    __syncthreads();
+    uint32_t carry = 0, total = 0;
+    for (uint32_t k = 0; k < 16; ++k) { const uint32_t t = s_tot[k]; if (k < w) carry += t; total += t; }
+    for (uint32_t base = lo; base < hi; base += 256u) {
+        const uint32_t idx = base + 4u * lane; uint32_t v[4]; load4(idx, v);
+        const uint32_t t = v[0] + v[1] + v[2] + v[3];
+        uint32_t inc = t;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(inc, d); if ((int)lane >= d) inc += o; }
+        uint32_t run = carry + inc - t;
+        if (idx + 3u < n) { *reinterpret_cast<uint4*>(out + idx) = make_uint4(run, run + v[0], run + v[0] + v[1], run + v[0] + v[1] + v[2]); }
+        else for (uint32_t k = 0; k < 4; ++k) { if (idx + k < n) out[idx + k] = run; run += v[k]; }
+        carry += __shfl(inc, 63);
+    }
+    if (tid == 0) out[n] = total;
+}
 // NOTE: `in` must have n+1 readable entries (the last one is ignored by an exclusive scan but read).
 void exclusive_scan_u32(hipStream_t s, const uint32_t* in, uint32_t* out, size_t n, void* temp, size_t temp_bytes) {
+    if (n <= SMALL_SCAN_MAX) { hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(1024), 0, s, in, out, (uint32_t)n, in, out, 0u); return; }
     (void)rocprim::exclusive_scan(temp, temp_bytes, in, out, 0u, n + 1, rocprim::plus<uint32_t>(), s);
+}
+// two independent scans (either may be empty: n == 0 still writes out[0] = 0)
+void exclusive_scan_u32_pair(hipStream_t s, const uint32_t* in0, uint32_t* out0, size_t n0, const uint32_t* in1, uint32_t* out1, size_t n1, void* temp, size_t temp_bytes) {
+    if (n0 <= SMALL_SCAN_MAX && n1 <= SMALL_SCAN_MAX && in1) { hipLaunchKernelGGL(k_scan_small, dim3(2), dim3(1024), 0, s, in0, out0, (uint32_t)n0, in1, out1, (uint32_t)n1); return; }
+    exclusive_scan_u32(s, in0, out0, n0, temp, temp_bytes);
+    if (in1) exclusive_scan_u32(s, in1, out1, n1, temp, temp_bytes);
 }
 void exclusive_scan_u32_to_u64(hipStream_t s, const uint32_t* in, uint64_t* out, size_t n, void* temp, size_t temp_bytes) {
     (void)rocprim::exclusive_scan(temp, temp_bytes, rocprim::make_transform_iterator(in, Widen()), out, (uint64_t)0, n + 1, rocprim::plus<uint64_t>(), s);

@@ -75,13 +75,14 @@ struct AmpStore {            // SoA amplicon arrays (DevAmps) with capacity mana
     void release() { parent.release(); sl.release(); gc.release(); primers.release(); uid.release(); errs.release(); pool.release(); pool_head.release(); n = cap = pool_cap = 0; }
 };
 
-struct KernelTimer {         // HIP events on the ctx stream around the launches of one kernel
-    const char* name; std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; size_t used = 0; double ms = 0; uint64_t launches = 0; uint64_t units = 0;
+struct KernelTimer {         // HIP events on the ctx stream around the launches of one kernel (scs_set_kernel_timing turns one off)
+    const char* name; std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; size_t used = 0; double ms = 0; uint64_t launches = 0; uint64_t units = 0; bool on = true;
     void begin(hipStream_t s) {
+        if (!on) return;
         if (used == ev.size()) { hipEvent_t a, b; HIP_OK(hipEventCreate(&a)); HIP_OK(hipEventCreate(&b)); ev.push_back({a, b}); }
         HIP_OK(hipEventRecord(ev[used].first, s));
     }
-    void end(hipStream_t s) { HIP_OK(hipEventRecord(ev[used].second, s)); ++used; }
+    void end(hipStream_t s) { if (!on) return; HIP_OK(hipEventRecord(ev[used].second, s)); ++used; }
     void collect() {         // call after a stream sync
         for (size_t i = 0; i < used; ++i) { float t = 0; HIP_OK(hipEventElapsedTime(&t, ev[i].first, ev[i].second)); ms += t; ++launches; }
         used = 0;
@@ -93,6 +94,10 @@ struct KernelTimer {         // HIP events on the ctx stream around the launches
 }  // namespace
 
 namespace { struct SinkPipe; }
+struct Mail {                // a batch of device scalars for one k_mail post (at most 12)
+    const void* src[12]; int wd[12]; int dst[12]; int n = 0; unsigned clear = 0;
+    void add(const void* p, int width, int slot, bool clear_after = false) { src[n] = p; wd[n] = width; dst[n] = slot; if (clear_after) clear |= 1u << n; ++n; }
+};
 
 struct scs_ctx {
     scs_config cfg; std::string err;
@@ -111,9 +116,10 @@ struct scs_ctx {
     AmpStore semis, fulls;
     DevBuf budget_f, budget_s, slot_off_f, slot_off_s, dsums; uint64_t* h_rb = nullptr;   // dsums: device scalars; h_rb: pinned, device-mapped mailbox (32 words)
     unsigned long long* d_rb = nullptr; uint64_t mail_seq = 0;                      // device address of h_rb; sequence of the last post
+    Mail pend;                                                                     // counts of the passes launched since the last collect
     uint64_t frag_total_len = 0, semi_total_len = 0; uint32_t slots_f = 0, slots_s = 0, budget_ns = 0;
     DevBuf primer_cnt, primer_delta; uint64_t total_primers = 0; bool amplified = false;
-    DevBuf slots, slot_tmpl, valid, valid_off, scan_tmp, flags;
+    DevBuf slots, slot_tmpl, valid, valid_off, valid_f, valid_off_f, scan_tmp, flags;
     // allocation + reads
     DevBuf weights, read_numbers, pair_off, pairs, odd_before, a_part, a_tp, a_probs, a_quota, a_poff; std::vector<uint32_t> h_read_numbers; uint64_t reads_requested = 0, n_pairs_planned = 0; bool allocated = false;
     DevBuf slot_b, slot_q, lens, sizes1, sizes2, off1, off2, out1, out2; SinkPipe* pipe = nullptr;
@@ -154,12 +160,8 @@ struct scs_ctx {
 namespace {
 
 // ---- mailbox: device scalars -> pinned host words, no copy and no stream sync (k_mail)
-struct Mail {
-    const void* src[12]; int wd[12]; int dst[12]; int n = 0;
-    void add(const void* p, int width, int slot) { src[n] = p; wd[n] = width; dst[n] = slot; ++n; }
-};
 void mail_post(scs_ctx* c, const Mail& m, bool last) {                            // last: the post the host will wait for
-    launch_mail(c->stream, m.src, m.wd, m.dst, m.n, c->d_rb, last ? ++c->mail_seq : 0ull);
+    launch_mail(c->stream, m.src, m.wd, m.dst, m.n, m.clear, c->d_rb, last ? ++c->mail_seq : 0ull);
 }
 void mail_wait(scs_ctx* c) {                                                      // everything posted so far has landed in h_rb
     volatile uint64_t* flag = c->h_rb + MAIL_SEQ_SLOT;
@@ -288,21 +290,24 @@ void set_primers(scs_ctx* c, bool only_frags, uint32_t call) {
     hipStream_t s = c->stream;
     const uint32_t nf = (uint32_t)c->f_len.size(), ns = only_frags ? 0u : c->semis.n;
     PoissonParams p; p.key = c->key; p.call = call; p.gamma = c->cfg.gamma; p.total_primers = c->total_primers;
-    c->h_rb[12] = (uint64_t)nf + ns; c->h_rb[13] = c->frag_total_len + (only_frags ? 0 : c->semi_total_len);   // {templateNum, totalLen}, local
-    HIP_OK(hipMemcpyAsync(c->d_tot.p, &c->h_rb[12], 16, hipMemcpyHostToDevice, s));
-    c->reduce_dev(c->d_tot.p, 2, 8);                                               // sharded: totals over all shards
-    p.totals = c->d_tot.as<uint64_t>();
+    p.tot_n = (uint64_t)nf + ns; p.tot_len = c->frag_total_len + (only_frags ? 0 : c->semi_total_len);   // {templateNum, totalLen}, local
+    p.totals = nullptr;
+    if (c->sharded()) {                                                            // totals over all shards, reduced on the device
+        c->h_rb[12] = p.tot_n; c->h_rb[13] = p.tot_len;
+        HIP_OK(hipMemcpyAsync(c->d_tot.p, &c->h_rb[12], 16, hipMemcpyHostToDevice, s));
+        c->reduce_dev(c->d_tot.p, 2, 8);
+        p.totals = c->d_tot.as<uint64_t>();
+    }
     c->budget_f.reserve(((size_t)nf + 1) * 4, s); c->budget_s.reserve(((size_t)ns + 1) * 4, s);
     c->slot_off_f.reserve(((size_t)nf + 1) * 4, s); c->slot_off_s.reserve(((size_t)ns + 1) * 4, s);
     c->scan_tmp.reserve(scan_temp_bytes(std::max(nf, ns)), s);
-    HIP_OK(hipMemsetAsync(c->dsums.p, 0, 16, s));                                   // sums[0..1]; [4] keeps the running semi length total
+    // sums[0..1] are zero here: the previous call's mail cleared them after reading (do_amplify zeroes them first)
     launch_poisson(s, c->frags_view(), c->semis.view(), ns, p, c->budget_f.as<uint32_t>(), c->budget_s.as<uint32_t>(), c->dsums.as<unsigned long long>());
-    exclusive_scan_u32(s, c->budget_f.as<uint32_t>(), c->slot_off_f.as<uint32_t>(), nf, c->scan_tmp.p, c->scan_tmp.cap);
-    if (ns) exclusive_scan_u32(s, c->budget_s.as<uint32_t>(), c->slot_off_s.as<uint32_t>(), ns, c->scan_tmp.p, c->scan_tmp.cap);
+    exclusive_scan_u32_pair(s, c->budget_f.as<uint32_t>(), c->slot_off_f.as<uint32_t>(), nf, ns ? c->budget_s.as<uint32_t>() : nullptr, c->slot_off_s.as<uint32_t>(), ns, c->scan_tmp.p, c->scan_tmp.cap);
     c->reduce_dev(c->dsums.p, 2, 8);                                               // sharded: budgets of all shards leave the pool
     uint64_t* rb = c->h_rb;
     {
-        Mail m; m.add(c->dsums.p, 8, 0); m.add(c->dsums.as<unsigned long long>() + 1, 8, 1); m.add(c->slot_off_f.as<uint32_t>() + nf, 4, 2);
+        Mail m; m.add(c->dsums.p, 8, 0, true); m.add(c->dsums.as<unsigned long long>() + 1, 8, 1, true); m.add(c->slot_off_f.as<uint32_t>() + nf, 4, 2);
         m.add(ns ? (const void*)(c->slot_off_s.as<uint32_t>() + ns) : nullptr, 4, 3);
         mail_post(c, m, true);
     }
@@ -319,16 +324,16 @@ void launch_pass(scs_ctx* c, bool from_frag, uint32_t pass, int rb_slot) {
     const uint32_t n_slots = from_frag ? c->slots_f : c->slots_s;
     if (nt == 0 || n_slots == 0) {                                                 // nothing local; a shard still joins the pass's collective
         if (c->sharded()) { c->reduce_dev(c->primer_delta.p, 65536, 4); launch_primer_update(s, c->primer_cnt.as<int64_t>(), c->primer_delta.as<uint32_t>()); }
-        Mail m; m.add(nullptr, 8, rb_slot);
-        if (!from_frag) { for (int b = 0; b < 8; ++b) m.add(nullptr, 8, 16 + b); c->pending_seg_cycle = (int)pass; }
-        mail_post(c, m, false);
+        c->pend.add(nullptr, 8, rb_slot);
+        if (!from_frag) { for (int b = 0; b < 8; ++b) c->pend.add(nullptr, 8, 16 + b); c->pending_seg_cycle = (int)pass; }
         return;
     }
     const uint32_t* slot_off = (from_frag ? c->slot_off_f : c->slot_off_s).as<uint32_t>();
-    c->valid.reserve(((size_t)nt + 1) * 4, s); c->valid_off.reserve(((size_t)nt + 1) * 4, s);
-    c->slots.reserve((size_t)n_slots * 4, s); c->slot_tmpl.reserve((size_t)n_slots * 4, s);
+    // the two passes of a group keep their own count arrays: their totals are mailed together at the group's collect
+    DevBuf& valid = from_frag ? c->valid_f : c->valid; DevBuf& valid_off = from_frag ? c->valid_off_f : c->valid_off;
+    valid.reserve(((size_t)nt + 1) * 4, s); valid_off.reserve(((size_t)nt + 1) * 4, s);
+    c->slots.reserve((size_t)n_slots * 4, s); c->slot_tmpl.reserve((size_t)n_slots * 4, s);   // k_attach marks its own slots unused first
     c->scan_tmp.reserve(scan_temp_bytes(nt), s);
-    HIP_OK(hipMemsetAsync(c->slot_tmpl.p, 0xFF, (size_t)n_slots * 4, s));
     AmpStore& out = from_frag ? c->semis : c->fulls;
     out.reserve((uint64_t)out.n + n_slots, s);
     out.reserve_pool(std::max<uint32_t>(1u << 16, (uint32_t)std::min<uint64_t>(((uint64_t)out.n + n_slots) / 256 + 4096, 0xFFFFFFF0ull)), s);
@@ -336,36 +341,36 @@ void launch_pass(scs_ctx* c, bool from_frag, uint32_t pass, int rb_slot) {
     DevFrags fr = c->frags_view(); fr.primers = c->budget_f.as<uint32_t>();
     const uint8_t* g = c->genome.as<uint8_t>();
     c->tm_attach.begin(s);
-    if (from_frag) launch_attach_frags(s, g, fr, slot_off, c->slots.as<uint32_t>(), c->slot_tmpl.as<uint32_t>(), c->valid.as<uint32_t>(),
+    if (from_frag) launch_attach_frags(s, g, fr, slot_off, c->slots.as<uint32_t>(), c->slot_tmpl.as<uint32_t>(), valid.as<uint32_t>(),
                                        c->primer_cnt.as<int64_t>(), c->primer_delta.as<uint32_t>(), c->dsums.as<unsigned long long>() + 4, p);
     else launch_attach_semis(s, g, fr, c->semis.view(), nt, c->semis.pool_view(), slot_off, c->slots.as<uint32_t>(), c->slot_tmpl.as<uint32_t>(),
-                             c->valid.as<uint32_t>(), c->primer_cnt.as<int64_t>(), c->primer_delta.as<uint32_t>(), p);
+                             valid.as<uint32_t>(), c->primer_cnt.as<int64_t>(), c->primer_delta.as<uint32_t>(), p);
     c->tm_attach.end(s);
     c->tm_attach.units += nt;
-    exclusive_scan_u32(s, c->valid.as<uint32_t>(), c->valid_off.as<uint32_t>(), nt, c->scan_tmp.p, c->scan_tmp.cap);
+    exclusive_scan_u32(s, valid.as<uint32_t>(), valid_off.as<uint32_t>(), nt, c->scan_tmp.p, c->scan_tmp.cap);
     KernelTimer& tm = from_frag ? c->tm_errscan_f : c->tm_errscan;
     tm.begin(s);
     const DevGenomeIdx gx{c->gx_gc_bits.as<unsigned long long>(), c->gx_n_bits.as<unsigned long long>(), c->gx_gc_pref.as<uint64_t>(), c->gx_n_pref.as<uint64_t>()};
-    if (from_frag) launch_errs_frags(s, g, gx, fr, n_slots, slot_off, c->slots.as<uint32_t>(), c->slot_tmpl.as<uint32_t>(), c->valid_off.as<uint32_t>(),
+    if (from_frag) launch_errs_frags(s, g, gx, fr, n_slots, slot_off, c->slots.as<uint32_t>(), c->slot_tmpl.as<uint32_t>(), valid_off.as<uint32_t>(),
                                      out.view(), out.n, out.pool_view(), c->flags.as<uint32_t>(), c->d_binom.as<unsigned long long>(), p);
     else launch_errs_semis(s, g, gx, fr, c->semis.view(), nt, c->semis.pool_view(), n_slots, slot_off, c->slots.as<uint32_t>(), c->slot_tmpl.as<uint32_t>(),
-                           c->valid_off.as<uint32_t>(), out.view(), out.n, out.pool_view(), c->flags.as<uint32_t>(), c->d_binom.as<unsigned long long>(), p);
+                           valid_off.as<uint32_t>(), out.view(), out.n, out.pool_view(), c->flags.as<uint32_t>(), c->d_binom.as<unsigned long long>(), p);
     tm.end(s);
     c->reduce_dev(c->primer_delta.p, 65536, 4);                                    // sharded: stock decrements of all shards
     launch_primer_update(s, c->primer_cnt.as<int64_t>(), c->primer_delta.as<uint32_t>());
     {   // counts of this pass -> mailbox (read by the host at the group's sync): new amplicons, and for a semi pass the
         // fulls made from the semis of each fragment pass (segments)
-        Mail m; m.add(c->valid_off.as<uint32_t>() + nt, 4, rb_slot);
+        c->pend.add(valid_off.as<uint32_t>() + nt, 4, rb_slot);
         if (!from_frag) {
-            for (size_t b = 0; b < c->semi_block_end.size() && b < 8; ++b) m.add(c->valid_off.as<uint32_t>() + std::min(c->semi_block_end[b], nt), 4, 16 + (int)b);
+            for (size_t b = 0; b < c->semi_block_end.size() && b < 8; ++b) c->pend.add(valid_off.as<uint32_t>() + std::min(c->semi_block_end[b], nt), 4, 16 + (int)b);
             c->pending_seg_cycle = (int)pass;
         }
-        mail_post(c, m, false);
     }
 }
 // host sync closing a group of passes: counts of new amplicons, total length of the semis
 void collect_passes(scs_ctx* c, int rb_fulls, int rb_semis) {
-    { Mail m; m.add(c->dsums.as<unsigned long long>() + 4, 8, 8); mail_post(c, m, true); }
+    c->pend.add(c->dsums.as<unsigned long long>() + 4, 8, 8);
+    mail_post(c, c->pend, true); c->pend = Mail();
     mail_wait(c);
     if (rb_fulls >= 0) {
         c->fulls.n += (uint32_t)c->h_rb[rb_fulls]; c->tm_errscan.units += c->h_rb[rb_fulls];
@@ -388,7 +393,7 @@ void do_amplify(scs_ctx* c) {
     if (!c->have_profile) throw ScsError(SCS_EINVAL, "scs_amplify: load a profile first");
     hipStream_t s = c->stream;
     if (c->cfg.verbose) fprintf(stderr, "\nMALBAC amplification...\n");
-    c->semis.reset(s); c->fulls.reset(s); c->semi_block_end.clear(); c->full_segs.clear(); c->pending_seg_cycle = -1; c->have_gidx = false;
+    c->semis.reset(s); c->fulls.reset(s); c->semi_block_end.clear(); c->full_segs.clear(); c->pending_seg_cycle = -1; c->have_gidx = false; c->pend = Mail();
     c->tm_errscan.reset(); c->tm_errscan_f.reset(); c->tm_attach.reset();
     std::vector<int64_t> stock(65536, (int64_t)c->cfg.primers);                    // createPrimers: 4^8 types x `primers` copies
     upload(c->primer_cnt, stock, s);
@@ -682,7 +687,7 @@ void scs_destroy(scs_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     for (DevBuf* b : {&c->d_tables, &c->t_qcompact, &c->t_guide, &c->t_subs1, &c->t_subs2, &c->t_qual, &c->t_ins, &c->t_del, &c->t_isize, &c->d_subs1, &c->d_subs2, &c->d_qual, &c->d_ins, &c->d_del,
                       &c->d_isize, &c->d_gcmeans, &c->genome, &c->gx_gc_bits, &c->gx_n_bits, &c->gx_gc_cnt, &c->gx_n_cnt, &c->gx_gc_pref, &c->gx_n_pref, &c->d_binom, &c->df_goff, &c->df_len, &c->df_strand, &c->df_primers, &c->primer_cnt, &c->primer_delta,
-                      &c->slots, &c->slot_tmpl, &c->valid, &c->valid_off, &c->scan_tmp, &c->flags, &c->weights, &c->read_numbers,
+                      &c->slots, &c->slot_tmpl, &c->valid, &c->valid_off, &c->valid_f, &c->valid_off_f, &c->scan_tmp, &c->flags, &c->weights, &c->read_numbers,
                       &c->pair_off, &c->pairs, &c->odd_before, &c->a_part, &c->a_tp, &c->a_probs, &c->a_quota, &c->a_poff, &c->d_gidx, &c->d_gw, &c->d_grn, &c->d_tot, &c->d_stage, &c->d_all, &c->d_mail, &c->budget_f, &c->budget_s, &c->slot_off_f,
                       &c->slot_off_s, &c->dsums, &c->slot_b, &c->slot_q, &c->lens, &c->sizes1, &c->sizes2, &c->off1, &c->off2, &c->out1, &c->out2}) b->release();
     c->semis.release(); c->fulls.release();
@@ -756,6 +761,13 @@ int scs_kernel_time(const scs_ctx* c, int which, const char** name, uint64_t* la
     const KernelTimer* t[] = {&c->tm_errscan, &c->tm_errscan_f, &c->tm_reads, &c->tm_attach, &c->tm_format};
     if (which < 0 || which >= 5) return SCS_EINVAL;
     if (name) *name = t[which]->name; if (launches) *launches = t[which]->launches; if (ms) *ms = t[which]->ms; if (units) *units = t[which]->units;
+    return SCS_OK;
+}
+
+int scs_set_kernel_timing(scs_ctx* c, unsigned mask) {
+    if (!c) return SCS_EINVAL;
+    KernelTimer* t[] = {&c->tm_errscan, &c->tm_errscan_f, &c->tm_reads, &c->tm_attach, &c->tm_format};
+    for (int i = 0; i < 5; ++i) t[i]->on = (mask >> i) & 1u;
     return SCS_OK;
 }
 
