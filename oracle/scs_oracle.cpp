@@ -656,11 +656,15 @@ void amplify_template(Sim& S, Rng& rng, PrimerPool& pool, bool fromFrag, uint64_
     const uint32_t kind = fromFrag ? 0u : 1u, aux = kind | (pass << 1);
     for (unsigned i = 0; i < primerNum; ++i) {
         int tryTimes = 0; unsigned spos = 0, alen = 0;
+        // [REMAP] counter mode: primer i of this template owns a xoshiro128++ stream seeded by Philox block i of ST_ATTACH;
+        // every try takes two draws from it (position, then length)
+        Xoshiro xt;
+        if (rng.counter) { uint32_t c[4] = {i, (uint32_t)tuid, (uint32_t)(tuid >> 32), ST_ATTACH | (aux << 8)}, o[4]; philox(c, rng.key, o); xt.seed(o); }
         do {
-            // counter key: one block serves two consecutive tries (words 0,1 and 2,3)
-            const uint32_t blk = (i << 5) | ((uint32_t)tryTimes >> 1); const int w0 = 2 * (tryTimes & 1);
-            spos = (unsigned)(long)(27 + ((long)length - 27) * rng.integer(mk(ST_ATTACH, aux, tuid, blk, w0)));
-            alen = (unsigned)(p.ampMin + (double)(p.ampMax + 1 - p.ampMin) * rng.real(mk(ST_ATTACH, aux, tuid, blk, w0 + 1)));
+            const double u1 = rng.counter ? xt.next() / 4294967296.0 : rng.integer(Key{});
+            const double u2 = rng.counter ? xt.next() / 4294967296.0 : rng.real(Key{});
+            spos = (unsigned)(long)(27 + ((long)length - 27) * u1);
+            alen = (unsigned)(p.ampMin + (double)(p.ampMax + 1 - p.ampMin) * u2);
             tryTimes++;
             if (tryTimes > 50) break;
             if (spos + alen > length || posAttached[spos] == 1) continue;

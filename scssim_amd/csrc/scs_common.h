@@ -21,7 +21,7 @@ namespace scs {
 enum Stage : uint32_t {
     ST_FRAGSPLIT   = 1,   // uid = record index, idx = k-th fragment of the record, word 0     (Genome.cpp:760)
     ST_POISSON     = 2,   // uid = template uid, aux = kind | call<<1, draw t -> idx t/4 word t%4 (MyDefine.cpp:69-80)
-    ST_ATTACH      = 3,   // uid = template uid, aux = kind | pass<<1, idx = primer<<5 | try>>1, words 2(try&1): spos, +1: length
+    ST_ATTACH      = 3,   // uid = template uid, aux = kind | pass<<1, idx = primer: seeds the primer's xoshiro128++ try stream (spos, length per try)
     ST_ERR         = 4,   // uid = NEW amplicon uid, aux = kind; block 0: words 0,1 = 64-bit draw for the error COUNT
                           //   (binomial thresholds); blocks 1.. : candidate error positions, one word each   [REMAP of Fragment.cpp:100-104]
     ST_ERRALT      = 5,   // uid = NEW amplicon uid, aux = kind, idx = j | (a/4)<<16, word a%4  (Fragment.cpp:107-110)

@@ -87,6 +87,14 @@ __device__ __forceinline__ uint32_t rand_indx_thr(const uint32_t* __restrict__ T
     return lo < ac ? lo : ac - 1;
 }
 
+// start of Malbac::amplify: createPrimers (4^8 primer types x `copies`, Malbac.cpp:204-234) + the run's device scalars
+__global__ void k_amplify_init(int64_t* __restrict__ cnt, int64_t copies, uint32_t* __restrict__ delta, uint32_t* __restrict__ flags,
+                               unsigned long long* __restrict__ sums) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 65536) { cnt[i] = copies; delta[i] = 0; }
+    if (i < 8) sums[i] = 0;
+    if (i == 0) flags[0] = 0;
+}
 __global__ void k_primer_update(int64_t* __restrict__ cnt, uint32_t* __restrict__ delta) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= 65536) return;
@@ -757,10 +765,22 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
 // K6  format: one wave per FASTQ record, coalesced copy from the slot buffer to its final offset
 //     (record layout of Amplicon::yieldReads, Amplicon.cpp:459-466 / 497-525; sink = SeqWriter)
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t put_dec(char* dst, uint32_t v) {
-    const uint32_t nd = dec_digits(v);
-    for (uint32_t k = 0; k < nd; ++k) { dst[nd - 1 - k] = (char)('0' + v % 10u); v /= 10u; }
-    return nd;
+// One wave per FASTQ record.  The header is produced by the lanes in parallel (lane j writes character j), the two
+// 150-byte fields move as one dword per lane: aligned loads from the slot, stores at the record's (arbitrary) byte offset.
+__device__ __forceinline__ uint32_t dec_digit(uint32_t v, uint32_t k) { for (uint32_t i = 0; i < k; ++i) v /= 10u; return v % 10u; }   // digit k from the right
+// dst is byte-addressed (a record starts anywhere); src is a 64-byte aligned, padded slot.  The body moves as ALIGNED
+// dwords on both sides: destination dword j takes source bytes a+4j.., assembled from two aligned source dwords.
+__device__ __forceinline__ void copy_field(char* __restrict__ dst, const char* __restrict__ src, uint32_t nl, uint32_t slot, int lane) {
+    const uint32_t a = (uint32_t)(0u - (uint32_t)reinterpret_cast<uintptr_t>(dst)) & 3u;     // bytes before dst's first aligned dword
+    const uint32_t head = a < nl ? a : nl, nd = (nl - head) >> 2, tail0 = head + 4u * nd;
+    const uint32_t* __restrict__ s32 = reinterpret_cast<const uint32_t*>(src);
+    uint32_t* __restrict__ d32 = reinterpret_cast<uint32_t*>(dst + head);
+    for (uint32_t j = (uint32_t)lane; j < nd; j += WAVE) {
+        const uint32_t lo = s32[j], hi = (a && 4u * (j + 1u) < slot) ? s32[j + 1u] : 0u;
+        d32[j] = a ? __builtin_amdgcn_alignbyte(hi, lo, a) : lo;
+    }
+    if ((uint32_t)lane < head) dst[lane] = src[lane];
+    if ((uint32_t)lane < nl - tail0) dst[tail0 + lane] = src[tail0 + lane];
 }
 __global__ void __launch_bounds__(256) k_format(const PairRec* __restrict__ pairs, uint32_t np, uint32_t amp_index_base, int paired, uint32_t slot,
                                                 const char* __restrict__ slot_b, const char* __restrict__ slot_q, const uint32_t* __restrict__ lens,
@@ -773,18 +793,25 @@ __global__ void __launch_bounds__(256) k_format(const PairRec* __restrict__ pair
         const uint32_t pi = paired ? r >> 1 : r, rd = paired ? (r & 1u) : 0u;
         const uint32_t nl = lens[r];
         if (nl == 0 || nl > slot) continue;
-        const PairRec pr = pairs[pi];
+        const uint32_t amp = amp_index_base + pairs[pi].amp, cnt = pairs[pi].att + 1u;
         char* dst = (rd ? out2 : out1) + (rd ? off2[pi] : off1[pi]);
-        uint32_t h = 0;
-        if (lane == 0) {
-            dst[h++] = '@'; h += put_dec(dst + h, amp_index_base + pr.amp); dst[h++] = '#'; h += put_dec(dst + h, pr.att + 1);
-            if (paired) { dst[h++] = '/'; dst[h++] = rd ? '2' : '1'; }
-            dst[h++] = '\n';
+        // "@<amp>#<cnt>[/1|/2]\n"
+        const uint32_t d1 = dec_digits(amp), d2 = dec_digits(cnt), h = 1u + d1 + 1u + d2 + (paired ? 2u : 0u) + 1u;
+        const uint32_t j = (uint32_t)lane;
+        if (j < h) {
+            char ch;
+            if (j == 0) ch = '@';
+            else if (j <= d1) ch = (char)('0' + dec_digit(amp, d1 - j));
+            else if (j == d1 + 1u) ch = '#';
+            else if (j <= d1 + 1u + d2) ch = (char)('0' + dec_digit(cnt, d1 + 1u + d2 - j));
+            else if (j == h - 1u) ch = '\n';
+            else ch = j == h - 3u ? '/' : (rd ? '2' : '1');
+            dst[j] = ch;
         }
-        h = __shfl(h, 0);
-        const char* sb = slot_b + (size_t)r * slot; const char* sq = slot_q + (size_t)r * slot;
-        for (uint32_t k = lane; k < nl; k += WAVE) { dst[h + k] = sb[k]; dst[h + nl + 3 + k] = sq[k]; }
-        if (lane == 0) { dst[h + nl] = '\n'; dst[h + nl + 1] = '+'; dst[h + nl + 2] = '\n'; dst[h + 2 * nl + 3] = '\n'; }
+        copy_field(dst + h, slot_b + (size_t)r * slot, nl, slot, lane);
+        copy_field(dst + h + nl + 3u, slot_q + (size_t)r * slot, nl, slot, lane);
+        if (lane < 3) dst[h + nl + lane] = lane == 1 ? '+' : '\n';
+        if (lane == 3) dst[h + 2u * nl + 3u] = '\n';
     }
 }
 
@@ -911,16 +938,15 @@ __global__ void __launch_bounds__(64) k_attach(const uint8_t* __restrict__ g, De
     __builtin_amdgcn_wave_barrier();
     uint32_t v = 0, c0 = 0, i = 0, tries = 0, spos = 0, alen = 0, pidx = 0;
     bool fresh = true, unresolved = false, need = false, dead = false;
-    unsigned long long lsum = 0; U4 dblk{};
+    unsigned long long lsum = 0; Xoshiro xt{};                                     // [REMAP] primer i's try stream, seeded by Philox block i
     while (__ballot(!group_done)) {
         if (!group_done) {
-            if (fresh) { i = c0 + gl; unresolved = i < budget; need = unresolved; dead = false; tries = 0; fresh = false; }
+            if (fresh) { i = c0 + gl; unresolved = i < budget; need = unresolved; dead = false; tries = 0; fresh = false; if (unresolved) xt.seed(draw4(p.key, ST_ATTACH, aux, tuid, i)); }
             if (unresolved && !dead) {
                 if (!need && ((bits[spos >> 5] >> (spos & 31)) & 1u)) need = true;       // a lower primer took this position meanwhile
                 while (need) {
-                    if ((tries & 1u) == 0) dblk = draw4(p.key, ST_ATTACH, aux, tuid, (i << 5) | (tries >> 1));   // one block = two tries
-                    spos = scale_draw(dblk.w[2 * (tries & 1u)], 27, len - 27);                       // randomInteger(27, length)
-                    alen = scale_draw(dblk.w[2 * (tries & 1u) + 1], p.amp_min, p.amp_max + 1 - p.amp_min);   // (uint) randomDouble(minLen, maxLen+1)
+                    spos = scale_draw(xt.next(), 27, len - 27);                                       // randomInteger(27, length)
+                    alen = scale_draw(xt.next(), p.amp_min, p.amp_max + 1 - p.amp_min);               // (uint) randomDouble(minLen, maxLen+1)
                     ++tries;
                     if (tries > 50) { dead = true; break; }
                     if (spos + alen > len) continue;
@@ -1174,6 +1200,9 @@ void launch_genome_bits(hipStream_t s, const uint8_t* g, uint64_t n, uint64_t nw
     hipLaunchKernelGGL(k_genome_bits, dim3(cdiv(nwords + 1, 256)), dim3(256), 0, s, g, n, nwords, gc_bits, n_bits, gc_cnt, n_cnt);
     (void)rocprim::exclusive_scan(temp, temp_bytes, rocprim::make_transform_iterator((const uint32_t*)gc_cnt, Widen()), gc_pref, (uint64_t)0, nwords + 1, rocprim::plus<uint64_t>(), s);
     (void)rocprim::exclusive_scan(temp, temp_bytes, rocprim::make_transform_iterator((const uint32_t*)n_cnt, Widen()), n_pref, (uint64_t)0, nwords + 1, rocprim::plus<uint64_t>(), s);
+}
+void launch_amplify_init(hipStream_t s, int64_t* primer_cnt, int64_t copies, uint32_t* primer_delta, uint32_t* flags, unsigned long long* sums) {
+    hipLaunchKernelGGL(k_amplify_init, dim3(256), dim3(256), 0, s, primer_cnt, copies, primer_delta, flags, sums);
 }
 void launch_primer_update(hipStream_t s, int64_t* primer_cnt, uint32_t* primer_delta) {
     hipLaunchKernelGGL(k_primer_update, dim3(256), dim3(256), 0, s, primer_cnt, primer_delta);

@@ -395,11 +395,8 @@ void do_amplify(scs_ctx* c) {
     if (c->cfg.verbose) fprintf(stderr, "\nMALBAC amplification...\n");
     c->semis.reset(s); c->fulls.reset(s); c->semi_block_end.clear(); c->full_segs.clear(); c->pending_seg_cycle = -1; c->have_gidx = false; c->pend = Mail();
     c->tm_errscan.reset(); c->tm_errscan_f.reset(); c->tm_attach.reset();
-    std::vector<int64_t> stock(65536, (int64_t)c->cfg.primers);                    // createPrimers: 4^8 types x `primers` copies
-    upload(c->primer_cnt, stock, s);
-    c->primer_delta.reserve(65536 * 4, s); HIP_OK(hipMemsetAsync(c->primer_delta.p, 0, 65536 * 4, s));
-    HIP_OK(hipMemsetAsync(c->flags.p, 0, 4, s));
-    HIP_OK(hipMemsetAsync(c->dsums.p, 0, 64, s));
+    c->primer_cnt.reserve(65536 * 8, s); c->primer_delta.reserve(65536 * 4, s);   // createPrimers: 4^8 types x `primers` copies
+    launch_amplify_init(s, c->primer_cnt.as<int64_t>(), (int64_t)c->cfg.primers, c->primer_delta.as<uint32_t>(), c->flags.as<uint32_t>(), c->dsums.as<unsigned long long>());
     if (!c->d_binom.p) {   // [REMAP] error-count thresholds for every window length (cfg is fixed for the ctx lifetime)
         std::vector<uint64_t> bt = binom_table(c->cfg.ber, c->cfg.amplicon_min_len - 8, c->cfg.amplicon_max_len - 8);
         upload(c->d_binom, bt, s); HIP_OK(hipStreamSynchronize(s));
