@@ -174,10 +174,11 @@ int         scs_fasta_probe(const char* fasta_path, int* n_records, uint64_t* to
  * launches processed (amplicons created for the errscan kernels, read pairs for k_reads/k_format,
  * templates for k_attach).  which = 0..4. */
 int         scs_kernel_time(const scs_ctx* ctx, int which, const char** name, uint64_t* launches, double* ms, uint64_t* units);
-/* Which of the five kernels get their HIP event pairs: bit `which` of mask (default: all).  Every event record is a
- * packet on the stream, so a latency-bound job (the 1 Mb configuration) runs measurably faster with only the kernel
- * of interest timed. */
-int         scs_set_kernel_timing(scs_ctx* ctx, unsigned mask);
+/* Which of the five kernels get their HIP event pairs: bit `which` of mask (default: all), and on which calls: every
+ * `every`-th scs_amplify / scs_yield_reads call counted from this call (default 1 = all).  Every event record is a
+ * packet on the stream (about 6 us each on the latency-bound 1 Mb configuration), so a measurement run times only the
+ * kernel of interest, on a sample of the steps.  scs_kernel_time reports an untimed call as 0 launches / 0 units. */
+int         scs_set_kernel_timing(scs_ctx* ctx, unsigned mask, unsigned every);
 
 #ifdef __cplusplus
 }

@@ -68,7 +68,7 @@ def load_library():
     L.scs_set_collectives.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.scs_set_collectives_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.scs_kernel_time.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_uint64), C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
-    L.scs_set_kernel_timing.argtypes = [C.c_void_p, C.c_uint]
+    L.scs_set_kernel_timing.argtypes = [C.c_void_p, C.c_uint, C.c_uint]
     L.scs_predict_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     L.scs_philox_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
@@ -272,11 +272,11 @@ class GenReads:
 
     KERNELS = ("k_errs<semi->full>", "k_errs<frag->semi>", "k_reads", "k_attach", "k_format")
 
-    def set_kernel_timing(self, names=None):
-        """Keep HIP event pairs only around the named kernels (None = all five).  Every event record is a packet on the
-        stream; the latency-bound 1 Mb job runs measurably faster with just the kernel of interest timed."""
+    def set_kernel_timing(self, names=None, every=1):
+        """Keep HIP event pairs only around the named kernels (None = all five), on every `every`-th amplify / yield call.
+        Every event record is a packet on the stream (about 6 us each on the latency-bound 1 Mb job)."""
         mask = 0x1F if names is None else sum(1 << self.KERNELS.index(n) for n in names)
-        self._ck(self._L.scs_set_kernel_timing(self._ctx, mask))
+        self._ck(self._L.scs_set_kernel_timing(self._ctx, mask, every))
 
     def download_amplicons(self, kind):
         np = self._np

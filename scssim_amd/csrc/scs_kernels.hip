@@ -490,26 +490,35 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
         }
         s_gbase[tid] = gb; s_gflag[tid] = gf;
         __syncthreads();
-        for (int kb = 0; kb < n; kb += 4 * WAVE) {                                  // 256 bases of every read per round (one round for L <= 256)
-            for (int q0 = 0; q0 < 64; q0 += 8) {                                    // 8 reads x up to 4 chunks of loads in flight per lane
-                uint32_t cv[8][4];
+        // a lane takes 4 consecutive window bases = one dword of the genome (byte-reversed when the view runs backwards),
+        // complements them in place and packs them into two LDS bytes: one load instruction covers 256 bases of a read
+        for (int kb = 0; kb < n; kb += 4 * WAVE) {                                  // one round for L <= 256
+            const int k4 = kb + 4 * lane;
+            for (int q0 = 0; q0 < 64; q0 += 8) {                                    // 8 reads' loads in flight per lane
+                uint32_t cv[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const int rr = wib * 64 + q0 + u; const uint32_t f = s_gflag[rr];
-                    const int64_t b0 = s_gbase[rr], d = (f & 2u) ? -1 : 1;
-#pragma unroll
-                    for (int cc = 0; cc < 4; ++cc) { const int k = kb + cc * WAVE + lane; cv[u][cc] = ((f & 4u) && k < n) ? (uint32_t)g[b0 + d * (int64_t)k] : 0u; }
+                    const int64_t b0 = s_gbase[rr];
+                    uint32_t v = 0;
+                    if ((f & 4u) && k4 < n) {
+                        if (k4 + 4 <= n) {
+                            if (f & 2u) { __builtin_memcpy(&v, g + (b0 - k4 - 3), 4); v = __builtin_bswap32(v); }
+                            else __builtin_memcpy(&v, g + (b0 + k4), 4);
+                        } else {                                                    // the window's last, partial group: stay inside it
+                            const int64_t d = (f & 2u) ? -1 : 1;
+                            for (int j = 0; k4 + j < n; ++j) v |= (uint32_t)g[b0 + d * (int64_t)(k4 + j)] << (8 * j);
+                        }
+                    }
+                    cv[u] = v;
                 }
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const int rr = wib * 64 + q0 + u; const uint32_t f = s_gflag[rr];
-#pragma unroll
-                    for (int cc = 0; cc < 4; ++cc) {
-                        const int k = kb + cc * WAVE + lane;
-                        const uint32_t v = (f & 1u) ? (uint32_t)comp_code((uint8_t)cv[u][cc]) : cv[u][cc];
-                        const uint32_t hi = __shfl_down(v, 1);                          // the odd neighbour's base: two bases per byte
-                        if ((f & 4u) && k < n && !(lane & 1)) s_win[(size_t)rr * WS + (k >> 1)] = (uint8_t)(v | ((k + 1 < n ? hi : 0u) << 4));
-                    }
+                    uint32_t v = cv[u];
+                    if (f & 1u) v ^= 0x03030303u & ~(((v >> 2) & 0x01010101u) * 3u);   // complement: 3 - c for ACGT codes, N (4) stays
+                    const uint32_t pk = (v & 0xFu) | ((v >> 4) & 0xF0u) | ((v >> 8) & 0xF00u) | ((v >> 12) & 0xF000u);
+                    if ((f & 4u) && k4 < n) *reinterpret_cast<uint16_t*>(s_win + (size_t)rr * WS + (k4 >> 1)) = (uint16_t)pk;
                 }
             }
         }
@@ -765,22 +774,10 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
 // K6  format: one wave per FASTQ record, coalesced copy from the slot buffer to its final offset
 //     (record layout of Amplicon::yieldReads, Amplicon.cpp:459-466 / 497-525; sink = SeqWriter)
 // ------------------------------------------------------------------------------------------------
-// One wave per FASTQ record.  The header is produced by the lanes in parallel (lane j writes character j), the two
-// 150-byte fields move as one dword per lane: aligned loads from the slot, stores at the record's (arbitrary) byte offset.
-__device__ __forceinline__ uint32_t dec_digit(uint32_t v, uint32_t k) { for (uint32_t i = 0; i < k; ++i) v /= 10u; return v % 10u; }   // digit k from the right
-// dst is byte-addressed (a record starts anywhere); src is a 64-byte aligned, padded slot.  The body moves as ALIGNED
-// dwords on both sides: destination dword j takes source bytes a+4j.., assembled from two aligned source dwords.
-__device__ __forceinline__ void copy_field(char* __restrict__ dst, const char* __restrict__ src, uint32_t nl, uint32_t slot, int lane) {
-    const uint32_t a = (uint32_t)(0u - (uint32_t)reinterpret_cast<uintptr_t>(dst)) & 3u;     // bytes before dst's first aligned dword
-    const uint32_t head = a < nl ? a : nl, nd = (nl - head) >> 2, tail0 = head + 4u * nd;
-    const uint32_t* __restrict__ s32 = reinterpret_cast<const uint32_t*>(src);
-    uint32_t* __restrict__ d32 = reinterpret_cast<uint32_t*>(dst + head);
-    for (uint32_t j = (uint32_t)lane; j < nd; j += WAVE) {
-        const uint32_t lo = s32[j], hi = (a && 4u * (j + 1u) < slot) ? s32[j + 1u] : 0u;
-        d32[j] = a ? __builtin_amdgcn_alignbyte(hi, lo, a) : lo;
-    }
-    if ((uint32_t)lane < head) dst[lane] = src[lane];
-    if ((uint32_t)lane < nl - tail0) dst[tail0 + lane] = src[tail0 + lane];
+__device__ __forceinline__ uint32_t put_dec(char* dst, uint32_t v) {
+    const uint32_t nd = dec_digits(v);
+    for (uint32_t k = 0; k < nd; ++k) { dst[nd - 1 - k] = (char)('0' + v % 10u); v /= 10u; }
+    return nd;
 }
 __global__ void __launch_bounds__(256) k_format(const PairRec* __restrict__ pairs, uint32_t np, uint32_t amp_index_base, int paired, uint32_t slot,
                                                 const char* __restrict__ slot_b, const char* __restrict__ slot_q, const uint32_t* __restrict__ lens,
@@ -793,25 +790,18 @@ __global__ void __launch_bounds__(256) k_format(const PairRec* __restrict__ pair
         const uint32_t pi = paired ? r >> 1 : r, rd = paired ? (r & 1u) : 0u;
         const uint32_t nl = lens[r];
         if (nl == 0 || nl > slot) continue;
-        const uint32_t amp = amp_index_base + pairs[pi].amp, cnt = pairs[pi].att + 1u;
+        const PairRec pr = pairs[pi];
         char* dst = (rd ? out2 : out1) + (rd ? off2[pi] : off1[pi]);
-        // "@<amp>#<cnt>[/1|/2]\n"
-        const uint32_t d1 = dec_digits(amp), d2 = dec_digits(cnt), h = 1u + d1 + 1u + d2 + (paired ? 2u : 0u) + 1u;
-        const uint32_t j = (uint32_t)lane;
-        if (j < h) {
-            char ch;
-            if (j == 0) ch = '@';
-            else if (j <= d1) ch = (char)('0' + dec_digit(amp, d1 - j));
-            else if (j == d1 + 1u) ch = '#';
-            else if (j <= d1 + 1u + d2) ch = (char)('0' + dec_digit(cnt, d1 + 1u + d2 - j));
-            else if (j == h - 1u) ch = '\n';
-            else ch = j == h - 3u ? '/' : (rd ? '2' : '1');
-            dst[j] = ch;
+        uint32_t h = 0;
+        if (lane == 0) {
+            dst[h++] = '@'; h += put_dec(dst + h, amp_index_base + pr.amp); dst[h++] = '#'; h += put_dec(dst + h, pr.att + 1);
+            if (paired) { dst[h++] = '/'; dst[h++] = rd ? '2' : '1'; }
+            dst[h++] = '\n';
         }
-        copy_field(dst + h, slot_b + (size_t)r * slot, nl, slot, lane);
-        copy_field(dst + h + nl + 3u, slot_q + (size_t)r * slot, nl, slot, lane);
-        if (lane < 3) dst[h + nl + lane] = lane == 1 ? '+' : '\n';
-        if (lane == 3) dst[h + 2u * nl + 3u] = '\n';
+        h = __shfl(h, 0);
+        const char* sb = slot_b + (size_t)r * slot; const char* sq = slot_q + (size_t)r * slot;
+        for (uint32_t k = lane; k < nl; k += WAVE) { dst[h + k] = sb[k]; dst[h + nl + 3 + k] = sq[k]; }
+        if (lane == 0) { dst[h + nl] = '\n'; dst[h + nl + 1] = '+'; dst[h + nl + 2] = '\n'; dst[h + 2 * nl + 3] = '\n'; }
     }
 }
 

@@ -75,14 +75,16 @@ struct AmpStore {            // SoA amplicon arrays (DevAmps) with capacity mana
     void release() { parent.release(); sl.release(); gc.release(); primers.release(); uid.release(); errs.release(); pool.release(); pool_head.release(); n = cap = pool_cap = 0; }
 };
 
+static const bool kAlwaysTimed = true;
 struct KernelTimer {         // HIP events on the ctx stream around the launches of one kernel (scs_set_kernel_timing turns one off)
-    const char* name; std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; size_t used = 0; double ms = 0; uint64_t launches = 0; uint64_t units = 0; bool on = true;
+    const char* name; std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; size_t used = 0; double ms = 0; uint64_t launches = 0; uint64_t units = 0; bool on = true; const bool* gate = &kAlwaysTimed;
+    void add_units(uint64_t n) { if (on && *gate) units += n; }
     void begin(hipStream_t s) {
-        if (!on) return;
+        if (!on || !*gate) return;
         if (used == ev.size()) { hipEvent_t a, b; HIP_OK(hipEventCreate(&a)); HIP_OK(hipEventCreate(&b)); ev.push_back({a, b}); }
         HIP_OK(hipEventRecord(ev[used].first, s));
     }
-    void end(hipStream_t s) { if (!on) return; HIP_OK(hipEventRecord(ev[used].second, s)); ++used; }
+    void end(hipStream_t s) { if (!on || !*gate) return; HIP_OK(hipEventRecord(ev[used].second, s)); ++used; }
     void collect() {         // call after a stream sync
         for (size_t i = 0; i < used; ++i) { float t = 0; HIP_OK(hipEventElapsedTime(&t, ev[i].first, ev[i].second)); ms += t; ++launches; }
         used = 0;
@@ -117,6 +119,7 @@ struct scs_ctx {
     DevBuf budget_f, budget_s, slot_off_f, slot_off_s, dsums; uint64_t* h_rb = nullptr;   // dsums: device scalars; h_rb: pinned, device-mapped mailbox (32 words)
     unsigned long long* d_rb = nullptr; uint64_t mail_seq = 0;                      // device address of h_rb; sequence of the last post
     Mail pend;                                                                     // counts of the passes launched since the last collect
+    bool timing_gate = true; uint32_t timing_every = 1; uint64_t amplify_calls = 0, yield_calls = 0;   // scs_set_kernel_timing: events on every n-th call
     uint64_t frag_total_len = 0, semi_total_len = 0; uint32_t slots_f = 0, slots_s = 0, budget_ns = 0;
     DevBuf primer_cnt, primer_delta; uint64_t total_primers = 0; bool amplified = false;
     DevBuf slots, slot_tmpl, valid, valid_off, valid_f, valid_off_f, scan_tmp, flags;
@@ -346,7 +349,7 @@ void launch_pass(scs_ctx* c, bool from_frag, uint32_t pass, int rb_slot) {
     else launch_attach_semis(s, g, fr, c->semis.view(), nt, c->semis.pool_view(), slot_off, c->slots.as<uint32_t>(), c->slot_tmpl.as<uint32_t>(),
                              valid.as<uint32_t>(), c->primer_cnt.as<int64_t>(), c->primer_delta.as<uint32_t>(), p);
     c->tm_attach.end(s);
-    c->tm_attach.units += nt;
+    c->tm_attach.add_units(nt);
     exclusive_scan_u32(s, valid.as<uint32_t>(), valid_off.as<uint32_t>(), nt, c->scan_tmp.p, c->scan_tmp.cap);
     KernelTimer& tm = from_frag ? c->tm_errscan_f : c->tm_errscan;
     tm.begin(s);
@@ -373,7 +376,7 @@ void collect_passes(scs_ctx* c, int rb_fulls, int rb_semis) {
     mail_post(c, c->pend, true); c->pend = Mail();
     mail_wait(c);
     if (rb_fulls >= 0) {
-        c->fulls.n += (uint32_t)c->h_rb[rb_fulls]; c->tm_errscan.units += c->h_rb[rb_fulls];
+        c->fulls.n += (uint32_t)c->h_rb[rb_fulls]; c->tm_errscan.add_units(c->h_rb[rb_fulls]);
         if (c->pending_seg_cycle >= 0) {                                          // stored order within a cycle: fragment pass p descending
             const size_t nb = std::min<size_t>(c->semi_block_end.size(), 8);
             for (int b = (int)nb - 1; b >= 0; --b) {
@@ -383,7 +386,7 @@ void collect_passes(scs_ctx* c, int rb_fulls, int rb_semis) {
             c->pending_seg_cycle = -1;
         }
     }
-    if (rb_semis >= 0) { c->semis.n += (uint32_t)c->h_rb[rb_semis]; c->tm_errscan_f.units += c->h_rb[rb_semis]; c->semi_block_end.push_back(c->semis.n); }
+    if (rb_semis >= 0) { c->semis.n += (uint32_t)c->h_rb[rb_semis]; c->tm_errscan_f.add_units(c->h_rb[rb_semis]); c->semi_block_end.push_back(c->semis.n); }
     c->semi_total_len = c->h_rb[8];
 }
 
@@ -394,6 +397,7 @@ void do_amplify(scs_ctx* c) {
     hipStream_t s = c->stream;
     if (c->cfg.verbose) fprintf(stderr, "\nMALBAC amplification...\n");
     c->semis.reset(s); c->fulls.reset(s); c->semi_block_end.clear(); c->full_segs.clear(); c->pending_seg_cycle = -1; c->have_gidx = false; c->pend = Mail();
+    c->timing_gate = (c->amplify_calls++ % c->timing_every) == 0;
     c->tm_errscan.reset(); c->tm_errscan_f.reset(); c->tm_attach.reset();
     c->primer_cnt.reserve(65536 * 8, s); c->primer_delta.reserve(65536 * 4, s);   // createPrimers: 4^8 types x `primers` copies
     launch_amplify_init(s, c->primer_cnt.as<int64_t>(), (int64_t)c->cfg.primers, c->primer_delta.as<uint32_t>(), c->flags.as<uint32_t>(), c->dsums.as<unsigned long long>());
@@ -543,6 +547,7 @@ void do_yield(scs_ctx* c, const OutTarget& tg, uint64_t* n1_out, uint64_t* n2_ou
     if (!c->allocated) throw ScsError(SCS_EINVAL, "scs_yield_reads: call scs_allocate_reads first");
     hipStream_t s = c->stream; const int paired = c->cfg.paired != 0;
     if (c->cfg.verbose) fprintf(stderr, "\n*****Producing reads*****\n");
+    c->timing_gate = (c->yield_calls++ % c->timing_every) == 0;
     c->tm_reads.reset(); c->tm_format.reset();
     const uint64_t P = c->n_pairs_planned;
     const uint32_t L = (uint32_t)c->prof.read_length, slot = ((L + 64 + 63) / 64) * 64;
@@ -569,7 +574,7 @@ void do_yield(scs_ctx* c, const OutTarget& tg, uint64_t* n1_out, uint64_t* n2_ou
                      c->dtb, c->d_tables.as<DevTables>(), c->key, paired, slot, c->slot_b.as<char>(), c->slot_q.as<char>(), c->lens.as<uint32_t>(), c->sizes1.as<uint32_t>(),
                      c->sizes2.as<uint32_t>(), c->flags.as<uint32_t>());
         c->tm_reads.end(s);
-        c->tm_reads.units += np;
+        c->tm_reads.add_units(np);
         { const hipError_t le = take_launch_error(); if (le != hipSuccess) throw ScsError(SCS_EDEVICE, std::string("k_reads launch failed: ") + hipGetErrorString(le)); }
         exclusive_scan_u32_to_u64(s, c->sizes1.as<uint32_t>(), c->off1.as<uint64_t>(), np, c->scan_tmp.p, c->scan_tmp.cap);
         if (paired) exclusive_scan_u32_to_u64(s, c->sizes2.as<uint32_t>(), c->off2.as<uint64_t>(), np, c->scan_tmp.p, c->scan_tmp.cap);
@@ -587,7 +592,7 @@ void do_yield(scs_ctx* c, const OutTarget& tg, uint64_t* n1_out, uint64_t* n2_ou
         c->tm_format.begin(s);
         launch_format(s, pr, np, 0, paired, slot, c->slot_b.as<char>(), c->slot_q.as<char>(), c->lens.as<uint32_t>(), c->off1.as<uint64_t>(), c->off2.as<uint64_t>(), o1, o2);
         c->tm_format.end(s);
-        c->tm_format.units += np;
+        c->tm_format.add_units(np);
         if (to_sink) {
             SinkPipe* pp = c->pipe; const int sl = (int)(bi++ & 1);
             if (pp->acquire(sl)) throw ScsError(SCS_EIO, "sink aborted");
@@ -668,6 +673,7 @@ int scs_create(const scs_config* cfg, scs_ctx** out) {
         HIP_OK(hipSetDevice(cfg->device));
         if (cfg->stream) c->stream = (hipStream_t)cfg->stream; else { HIP_OK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
         c->key = RngKey{(uint32_t)cfg->seed, (uint32_t)(cfg->seed >> 32)};
+        for (KernelTimer* t : {&c->tm_errscan, &c->tm_errscan_f, &c->tm_reads, &c->tm_attach, &c->tm_format}) t->gate = &c->timing_gate;
         c->flags.reserve(256, c->stream); HIP_OK(hipMemsetAsync(c->flags.p, 0, 256, c->stream));
         c->dsums.reserve(256, c->stream); HIP_OK(hipMemsetAsync(c->dsums.p, 0, 256, c->stream));
         c->d_tot.reserve(256, c->stream);
@@ -761,10 +767,11 @@ int scs_kernel_time(const scs_ctx* c, int which, const char** name, uint64_t* la
     return SCS_OK;
 }
 
-int scs_set_kernel_timing(scs_ctx* c, unsigned mask) {
-    if (!c) return SCS_EINVAL;
+int scs_set_kernel_timing(scs_ctx* c, unsigned mask, unsigned every) {
+    if (!c || every == 0) return SCS_EINVAL;
     KernelTimer* t[] = {&c->tm_errscan, &c->tm_errscan_f, &c->tm_reads, &c->tm_attach, &c->tm_format};
     for (int i = 0; i < 5; ++i) t[i]->on = (mask >> i) & 1u;
+    c->timing_every = every; c->amplify_calls = 0; c->yield_calls = 0;
     return SCS_OK;
 }
 
