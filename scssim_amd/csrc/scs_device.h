@@ -64,8 +64,13 @@ struct PoissonParams {
     RngKey key; uint32_t call; double gamma;
     uint64_t total_primers;                            // Malbac::setPrimers inputs (Malbac.cpp:236-262)
     const uint64_t* totals;                            // sharded job: device {template_num, total_len} over ALL shards; else null
-    uint64_t tot_n, tot_len;                           // unsharded job: the same two totals, by value
+    // unsharded job: templateNum = nf + dev[DS_SEMIS_N], totalLen = frag_len + dev[DS_SEMI_LEN].  The semi amplicon
+    // count and length live on the device: setPrimers of a cycle is launched before the host has read them back.
+    uint64_t nf, frag_len; const unsigned long long* dev;
 };
+// device scalars of an amplification run (scs_ctx::dsums): [0],[1] budget sums of the current setPrimers call,
+// [4] total length of the semi amplicons, [5] number of semi amplicons
+enum { DS_SEMI_LEN = 4, DS_SEMIS_N = 5 };
 struct AllocState { double total; unsigned long long sum_rn, sum_quota; };
 
 // error flags raised by kernels (never silent): bit 0 error-list cap, 1 error pool, 2 read slot, 3 other
@@ -125,7 +130,8 @@ void launch_detlog(hipStream_t s, const double* x, uint32_t n, double* out);
 
 // gathers up to 12 device scalars (4 or 8 bytes wide) into mail[dsts[i]] (u64 each)
 #define MAIL_SEQ_SLOT 31                                   // mailbox word the sequence number of a post lands in
-void launch_mail(hipStream_t s, const void* const* srcs, const int* widths, const int* dsts, int n, unsigned clear, unsigned long long* mail, unsigned long long seq);
+void launch_mail(hipStream_t s, const void* const* srcs, const int* widths, const int* dsts, unsigned long long* const* accs, int n, unsigned clear, unsigned long long* mail, unsigned long long seq);
+void launch_local_totals(hipStream_t s, unsigned long long nf, unsigned long long frag_len, const unsigned long long* dev, unsigned long long* totals);
 
 // first error of any kernel launch / attribute call since the last call (hipSuccess if none)
 hipError_t take_launch_error();

@@ -841,15 +841,18 @@ __device__ __forceinline__ void block_add_u64(unsigned long long v, unsigned lon
 //     sums[0] += sum of k over fragments, sums[1] += sum of UNTRUNCATED k over semis (Malbac.cpp:282).
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ double poisson_lambda(const PoissonParams& p, uint32_t len) {
-    const uint64_t template_num = p.totals ? p.totals[0] : p.tot_n, total_len = p.totals ? p.totals[1] : p.tot_len;
+    const uint64_t template_num = p.totals ? p.totals[0] : p.nf + p.dev[DS_SEMIS_N], total_len = p.totals ? p.totals[1] : p.frag_len + p.dev[DS_SEMI_LEN];
     const unsigned long long expected = (unsigned long long)((double)p.total_primers * p.gamma * (double)template_num);
     return (double)expected * (1.0 * (double)len / (double)total_len);
 }
 // semis: lambda ~ 6 -> one thread per semi amplicon
-__global__ void __launch_bounds__(256) k_poisson_semis(DevAmps semis, uint32_t n_semis, PoissonParams p, uint32_t* __restrict__ budget_s,
+// n_cap: the host's upper bound of the semi count (grid size); the count itself is read from the device scalars
+__global__ void __launch_bounds__(256) k_poisson_semis(DevAmps semis, uint32_t n_cap, PoissonParams p, uint32_t* __restrict__ budget_s,
                                                        unsigned long long* __restrict__ sums) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t n_semis = (uint32_t)p.dev[DS_SEMIS_N];
     unsigned long long ks = 0;
+    if (i >= n_semis && i <= n_cap) budget_s[i] = 0;                               // the scan runs over n_cap + 1 entries
     if (i < n_semis) {
         const double log2 = -poisson_lambda(p, sl_len(semis.sl[i]));
         const uint64_t tuid = semis.uid[i];
@@ -1101,7 +1104,7 @@ struct Widen { __host__ __device__ uint64_t operator()(uint32_t v) const { retur
 // mailbox: collects scattered device scalars into one contiguous block of PINNED, DEVICE-MAPPED host memory, so the
 // host reads them without a copy or a stream synchronisation: it spins on the sequence word that the post writes last
 // (system-scope release).  A null source posts 0.
-struct MailSrc { const void* p[12]; int w[12]; int dst[12]; int n; unsigned clear; };   // clear: bit i = zero source i after reading it
+struct MailSrc { const void* p[12]; unsigned long long* acc[12]; int w[12]; int dst[12]; int n; unsigned clear; };   // clear: bit i = zero source i after reading it; acc: also add the value to a device word
 __global__ void k_mail(MailSrc m, unsigned long long* __restrict__ mail, unsigned long long seq) {
     const int i = threadIdx.x;
     if (i < m.n) {
@@ -1110,15 +1113,16 @@ __global__ void k_mail(MailSrc m, unsigned long long* __restrict__ mail, unsigne
             if (m.w[i] == 8) { unsigned long long* q = reinterpret_cast<unsigned long long*>(const_cast<void*>(m.p[i])); v = *q; if ((m.clear >> i) & 1u) *q = 0; }
             else { uint32_t* q = reinterpret_cast<uint32_t*>(const_cast<void*>(m.p[i])); v = *q; if ((m.clear >> i) & 1u) *q = 0; }
         }
+        if (m.acc[i]) *m.acc[i] += v;                                                  // one thread per source: plain read-modify-write
         __hip_atomic_store(&mail[m.dst[i]], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     __threadfence_system();
     __syncthreads();
     if (i == 0 && seq) __hip_atomic_store(&mail[MAIL_SEQ_SLOT], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-void launch_mail(hipStream_t s, const void* const* srcs, const int* widths, const int* dsts, int n, unsigned clear, unsigned long long* mail, unsigned long long seq) {
+void launch_mail(hipStream_t s, const void* const* srcs, const int* widths, const int* dsts, unsigned long long* const* accs, int n, unsigned clear, unsigned long long* mail, unsigned long long seq) {
     MailSrc m; m.n = n; m.clear = clear;
-    for (int i = 0; i < 12; ++i) { m.p[i] = i < n ? srcs[i] : nullptr; m.w[i] = i < n ? widths[i] : 4; m.dst[i] = i < n ? dsts[i] : 0; }
+    for (int i = 0; i < 12; ++i) { m.p[i] = i < n ? srcs[i] : nullptr; m.acc[i] = i < n ? accs[i] : nullptr; m.w[i] = i < n ? widths[i] : 4; m.dst[i] = i < n ? dsts[i] : 0; }
     hipLaunchKernelGGL(k_mail, dim3(1), dim3(64), 0, s, m, mail, seq);
 }
 struct OddBit { __host__ __device__ uint32_t operator()(uint32_t v) const { return v & 1u; } };
@@ -1144,7 +1148,7 @@ void launch_attach_frags(hipStream_t s, const uint8_t* g, DevFrags fr, const uin
 void launch_poisson(hipStream_t s, DevFrags fr, DevAmps semis, uint32_t n_semis, PoissonParams p, uint32_t* budget_f, uint32_t* budget_s,
                     unsigned long long* sums) {
     if (fr.n) hipLaunchKernelGGL(k_poisson_frags, dim3(fr.n), dim3(64), 0, s, fr, p, budget_f, sums);
-    if (n_semis) hipLaunchKernelGGL(k_poisson_semis, dim3(cdiv(n_semis, 256)), dim3(256), 0, s, semis, n_semis, p, budget_s, sums);
+    if (n_semis) hipLaunchKernelGGL(k_poisson_semis, dim3(cdiv((uint64_t)n_semis + 1, 256)), dim3(256), 0, s, semis, n_semis, p, budget_s, sums);
 }
 void launch_alloc(hipStream_t s, double* w, uint32_t ac, unsigned long long reads, RngKey key, int paired, AllocState* st, double* part, double* tp,
                   double* probs, uint32_t* quota, uint32_t* rn, uint32_t* odd_before, uint32_t* pair_cnt_off, void* temp, size_t temp_bytes) {
@@ -1190,6 +1194,13 @@ void launch_genome_bits(hipStream_t s, const uint8_t* g, uint64_t n, uint64_t nw
     hipLaunchKernelGGL(k_genome_bits, dim3(cdiv(nwords + 1, 256)), dim3(256), 0, s, g, n, nwords, gc_bits, n_bits, gc_cnt, n_cnt);
     (void)rocprim::exclusive_scan(temp, temp_bytes, rocprim::make_transform_iterator((const uint32_t*)gc_cnt, Widen()), gc_pref, (uint64_t)0, nwords + 1, rocprim::plus<uint64_t>(), s);
     (void)rocprim::exclusive_scan(temp, temp_bytes, rocprim::make_transform_iterator((const uint32_t*)n_cnt, Widen()), n_pref, (uint64_t)0, nwords + 1, rocprim::plus<uint64_t>(), s);
+}
+// sharded job: this shard's {templateNum, totalLen} for the all-reduce
+__global__ void k_local_totals(unsigned long long nf, unsigned long long frag_len, const unsigned long long* __restrict__ dev, unsigned long long* __restrict__ totals) {
+    if (threadIdx.x == 0) { totals[0] = nf + dev[DS_SEMIS_N]; totals[1] = frag_len + dev[DS_SEMI_LEN]; }
+}
+void launch_local_totals(hipStream_t s, unsigned long long nf, unsigned long long frag_len, const unsigned long long* dev, unsigned long long* totals) {
+    hipLaunchKernelGGL(k_local_totals, dim3(1), dim3(64), 0, s, nf, frag_len, dev, totals);
 }
 void launch_amplify_init(hipStream_t s, int64_t* primer_cnt, int64_t copies, uint32_t* primer_delta, uint32_t* flags, unsigned long long* sums) {
     hipLaunchKernelGGL(k_amplify_init, dim3(256), dim3(256), 0, s, primer_cnt, copies, primer_delta, flags, sums);

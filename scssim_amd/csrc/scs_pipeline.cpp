@@ -97,8 +97,10 @@ struct KernelTimer {         // HIP events on the ctx stream around the launches
 
 namespace { struct SinkPipe; }
 struct Mail {                // a batch of device scalars for one k_mail post (at most 12)
-    const void* src[12]; int wd[12]; int dst[12]; int n = 0; unsigned clear = 0;
-    void add(const void* p, int width, int slot, bool clear_after = false) { src[n] = p; wd[n] = width; dst[n] = slot; if (clear_after) clear |= 1u << n; ++n; }
+    const void* src[12]; unsigned long long* acc[12]; int wd[12]; int dst[12]; int n = 0; unsigned clear = 0;
+    void add(const void* p, int width, int slot, bool clear_after = false, unsigned long long* also_add_to = nullptr) {
+        src[n] = p; wd[n] = width; dst[n] = slot; acc[n] = also_add_to; if (clear_after) clear |= 1u << n; ++n;
+    }
 };
 
 struct scs_ctx {
@@ -164,7 +166,7 @@ namespace {
 
 // ---- mailbox: device scalars -> pinned host words, no copy and no stream sync (k_mail)
 void mail_post(scs_ctx* c, const Mail& m, bool last) {                            // last: the post the host will wait for
-    launch_mail(c->stream, m.src, m.wd, m.dst, m.n, m.clear, c->d_rb, last ? ++c->mail_seq : 0ull);
+    launch_mail(c->stream, m.src, m.wd, m.dst, m.acc, m.n, m.clear, c->d_rb, last ? ++c->mail_seq : 0ull);
 }
 void mail_wait(scs_ctx* c) {                                                      // everything posted so far has landed in h_rb
     volatile uint64_t* flag = c->h_rb + MAIL_SEQ_SLOT;
@@ -289,34 +291,33 @@ void do_create_frags(scs_ctx* c) {
 // ---------------------------------------------------------------- a3: Malbac::setPrimers (Malbac.cpp:236-283) on the device
 // One launch gives every template (fragments, then all semis so far) its Poisson budget; the scans
 // turn budgets into slot offsets.  One host sync: the sums feed totalPrimers and the buffer sizes.
-void set_primers(scs_ctx* c, bool only_frags, uint32_t call) {
+// ns_cap: upper bound of the semi amplicon count (the count itself is on the device: the passes that made the newest
+// semis have not been read back yet -- their counts arrive with this call's mail, ONE wait per cycle).
+void set_primers_launch(scs_ctx* c, bool only_frags, uint32_t call, uint32_t ns_cap) {
     hipStream_t s = c->stream;
-    const uint32_t nf = (uint32_t)c->f_len.size(), ns = only_frags ? 0u : c->semis.n;
+    const uint32_t nf = (uint32_t)c->f_len.size(), ns = only_frags ? 0u : ns_cap;
     PoissonParams p; p.key = c->key; p.call = call; p.gamma = c->cfg.gamma; p.total_primers = c->total_primers;
-    p.tot_n = (uint64_t)nf + ns; p.tot_len = c->frag_total_len + (only_frags ? 0 : c->semi_total_len);   // {templateNum, totalLen}, local
-    p.totals = nullptr;
+    p.nf = nf; p.frag_len = c->frag_total_len; p.dev = c->dsums.as<unsigned long long>(); p.totals = nullptr;
     if (c->sharded()) {                                                            // totals over all shards, reduced on the device
-        c->h_rb[12] = p.tot_n; c->h_rb[13] = p.tot_len;
-        HIP_OK(hipMemcpyAsync(c->d_tot.p, &c->h_rb[12], 16, hipMemcpyHostToDevice, s));
+        launch_local_totals(s, nf, c->frag_total_len, c->dsums.as<unsigned long long>(), c->d_tot.as<unsigned long long>());
         c->reduce_dev(c->d_tot.p, 2, 8);
         p.totals = c->d_tot.as<uint64_t>();
     }
-    c->budget_f.reserve(((size_t)nf + 1) * 4, s); c->budget_s.reserve(((size_t)ns + 1) * 4, s);
-    c->slot_off_f.reserve(((size_t)nf + 1) * 4, s); c->slot_off_s.reserve(((size_t)ns + 1) * 4, s);
+    c->budget_f.reserve(((size_t)nf + 1) * 4, s); c->budget_s.reserve(((size_t)ns + 2) * 4, s);
+    c->slot_off_f.reserve(((size_t)nf + 1) * 4, s); c->slot_off_s.reserve(((size_t)ns + 2) * 4, s);
     c->scan_tmp.reserve(scan_temp_bytes(std::max(nf, ns)), s);
-    // sums[0..1] are zero here: the previous call's mail cleared them after reading (do_amplify zeroes them first)
+    // sums[0..1] are zero here: the previous call's mail cleared them after reading (k_amplify_init zeroes them first)
     launch_poisson(s, c->frags_view(), c->semis.view(), ns, p, c->budget_f.as<uint32_t>(), c->budget_s.as<uint32_t>(), c->dsums.as<unsigned long long>());
     exclusive_scan_u32_pair(s, c->budget_f.as<uint32_t>(), c->slot_off_f.as<uint32_t>(), nf, ns ? c->budget_s.as<uint32_t>() : nullptr, c->slot_off_s.as<uint32_t>(), ns, c->scan_tmp.p, c->scan_tmp.cap);
     c->reduce_dev(c->dsums.p, 2, 8);                                               // sharded: budgets of all shards leave the pool
-    uint64_t* rb = c->h_rb;
-    {
-        Mail m; m.add(c->dsums.p, 8, 0, true); m.add(c->dsums.as<unsigned long long>() + 1, 8, 1, true); m.add(c->slot_off_f.as<uint32_t>() + nf, 4, 2);
-        m.add(ns ? (const void*)(c->slot_off_s.as<uint32_t>() + ns) : nullptr, 4, 3);
-        mail_post(c, m, true);
-    }
-    mail_wait(c);
+    Mail m; m.add(c->dsums.p, 8, 0, true); m.add(c->dsums.as<unsigned long long>() + 1, 8, 1, true); m.add(c->slot_off_f.as<uint32_t>() + nf, 4, 2);
+    m.add(ns ? (const void*)(c->slot_off_s.as<uint32_t>() + ns) : nullptr, 4, 3);  // budgets beyond the real count are 0: the total sits at [ns_cap] too
+    mail_post(c, m, true);
+}
+void set_primers_finish(scs_ctx* c) {                                              // after mail_wait (and collect_read: semis.n is current)
+    const uint64_t* rb = c->h_rb;
     c->total_primers -= rb[0] + rb[1];
-    c->slots_f = (uint32_t)rb[2]; c->slots_s = (uint32_t)rb[3]; c->budget_ns = ns;
+    c->slots_f = (uint32_t)rb[2]; c->slots_s = (uint32_t)rb[3]; c->budget_ns = c->semis.n;
 }
 
 // ---------------------------------------------------------------- one amplification pass (a4 / a5): launches only, no host sync.
@@ -363,18 +364,20 @@ void launch_pass(scs_ctx* c, bool from_frag, uint32_t pass, int rb_slot) {
     launch_primer_update(s, c->primer_cnt.as<int64_t>(), c->primer_delta.as<uint32_t>());
     {   // counts of this pass -> mailbox (read by the host at the group's sync): new amplicons, and for a semi pass the
         // fulls made from the semis of each fragment pass (segments)
-        c->pend.add(valid_off.as<uint32_t>() + nt, 4, rb_slot);
+        c->pend.add(valid_off.as<uint32_t>() + nt, 4, rb_slot, false, from_frag ? c->dsums.as<unsigned long long>() + DS_SEMIS_N : nullptr);
         if (!from_frag) {
             for (size_t b = 0; b < c->semi_block_end.size() && b < 8; ++b) c->pend.add(valid_off.as<uint32_t>() + std::min(c->semi_block_end[b], nt), 4, 16 + (int)b);
             c->pending_seg_cycle = (int)pass;
         }
     }
 }
-// host sync closing a group of passes: counts of new amplicons, total length of the semis
-void collect_passes(scs_ctx* c, int rb_fulls, int rb_semis) {
-    c->pend.add(c->dsums.as<unsigned long long>() + 4, 8, 8);
-    mail_post(c, c->pend, true); c->pend = Mail();
-    mail_wait(c);
+// closing a group of passes: their counts go to the mailbox (and the new semi count into the device scalars) ...
+void collect_post(scs_ctx* c, bool last) {
+    c->pend.add(c->dsums.as<unsigned long long>() + DS_SEMI_LEN, 8, 8);
+    mail_post(c, c->pend, last); c->pend = Mail();
+}
+// ... and are taken over by the host after the next mail_wait: counts of new amplicons, total length of the semis
+void collect_read(scs_ctx* c, int rb_fulls, int rb_semis) {
     if (rb_fulls >= 0) {
         c->fulls.n += (uint32_t)c->h_rb[rb_fulls]; c->tm_errscan.add_units(c->h_rb[rb_fulls]);
         if (c->pending_seg_cycle >= 0) {                                          // stored order within a cycle: fragment pass p descending
@@ -408,18 +411,25 @@ void do_amplify(scs_ctx* c) {
     c->total_primers = 65536ull * (uint64_t)c->cfg.primers;
     c->frag_total_len = 0; for (uint32_t l : c->f_len) c->frag_total_len += l;
     c->semi_total_len = 0;
-    set_primers(c, true, 0);
+    set_primers_launch(c, true, 0, 0); mail_wait(c); set_primers_finish(c);
     launch_pass(c, true, 0, 5);
-    collect_passes(c, -1, 5);
+    int open_fulls = -1, open_semis = 5; uint32_t semis_in_flight = c->slots_f;     // the group of passes not read back yet
     for (uint32_t i = 0; i < 5; ++i) {
         if (c->total_primers == 0) break;
         if (c->cfg.verbose) fprintf(stderr, "cycle number: %u\n", i + 1);
-        set_primers(c, false, i + 1);
+        // ONE wait per cycle: the counts of the previous group and this cycle's budgets come back together.  setPrimers runs
+        // on the device's own semi count; the host only bounds it (count so far + slots of the fragment pass in flight).
+        collect_post(c, false);
+        set_primers_launch(c, false, i + 1, c->semis.n + semis_in_flight);
+        mail_wait(c);
+        collect_read(c, open_fulls, open_semis);
+        set_primers_finish(c);
         launch_pass(c, false, i, 4);
         if (i < 4) launch_pass(c, true, i + 1, 5);
-        collect_passes(c, 4, i < 4 ? 5 : -1);
+        open_fulls = 4; open_semis = i < 4 ? 5 : -1; semis_in_flight = i < 4 ? c->slots_f : 0;
         if (c->cfg.verbose) { fprintf(stderr, "semi amplicon amplification done!\n"); if (i < 4) fprintf(stderr, "fragment amplification done!\n"); }
     }
+    collect_post(c, true); mail_wait(c); collect_read(c, open_fulls, open_semis);
     check_flags(c);
     c->tm_errscan.collect(); c->tm_errscan_f.collect(); c->tm_attach.collect();
     c->amplified = true; c->allocated = false;
