@@ -63,30 +63,30 @@ def cpu_baseline(fa, prof, seed):
                        (pairs, secs, float(m.group(4)), float(m.group(5)), float(m.group(6))))
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary of this same command
-    (FETCH_SIZE and WRITE_SIZE collected in separate --pmc passes; KB -> bytes).  bench.py cannot collect
-    PMC counters itself, so the number is read from profiles/; None if the summary is absent."""
+def pmc_traffic(members):
+    """HBM bytes per launch of the dominant kernel (group) from the committed rocprofv3 PMC summary of this same command
+    (FETCH_SIZE and WRITE_SIZE collected in separate --pmc passes; KB -> bytes; tools/pmc_summary.py).  bench.py cannot
+    collect PMC counters itself, so the number is read from profiles/; None if the summary is absent.  For the
+    amplification group one launch = one pass: bytes of all member kernels / passes."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_n1_pmc_hbm.csv")))
     if not files:
         return None, None
-    base = kernel.split("<")[0]
-    want_false = "semi->" in kernel
-    tot = None
+    prefix = {"k_attach": "scs::k_attach<", "k_errs<semi->full>": "scs::k_errs<false>", "k_errs<frag->semi>": "scs::k_errs<true>",
+              "k_reads": "scs::k_reads", "k_format": "scs::k_format"}
+    tot, launches0 = 0.0, 0
     for line in open(files[-1]):
         if line.startswith("#") or line.startswith("kernel"):
             continue
-        name, rest = line.rsplit(",", 3)[0], line.rsplit(",", 3)[1:]
-        if ("scs::" + base) not in name:
-            continue
-        if "<" in kernel and base in ("k_errs",) and (("<false>" in name) != want_false):
-            continue
-        # gfx950: FETCH_SIZE under-reports wide coalesced reads by 2x (MI355X_MICROARCH.md, HBM); byte/dword gathers
-        # as here are uncalibrated, so the raw value is reported and the x2 bound is in DESIGN.md
-        tot = (float(rest[0]) + float(rest[1])) * 1024.0
-        break
-    return tot, os.path.relpath(files[-1], ROOT)
+        name, fetch, write, n = line.rstrip("\n").rsplit(",", 3)
+        for i, m in enumerate(members):
+            if name.startswith(prefix[m]):
+                # gfx950: FETCH_SIZE under-reports wide coalesced reads by 2x (MI355X_MICROARCH.md, HBM); byte/dword gathers
+                # as here are uncalibrated, so the raw value is reported and the x2 bound is in DESIGN.md
+                tot += (float(fetch) + float(write)) * 1024.0 * int(n)
+                if i == 0:
+                    launches0 += int(n)
+    return (tot / launches0 if launches0 else None), os.path.relpath(files[-1], ROOT)
 
 
 def main():
@@ -230,7 +230,7 @@ def main():
             alg = 261.0 * kd["units"] + fq_bytes
             note = "(261 B template + FASTQ bytes) x %d pairs over %d launches" % (kd["units"], kd["launches"])
         achieved = alg / (kd["ms"] * 1e-3) / 1e9 if kd["ms"] > 0 else 0.0
-        traffic, traffic_src = pmc_traffic(dom)
+        traffic, traffic_src = pmc_traffic(GROUPS[dom])
         out = {
             "metric": "paired-end read pairs/s (whole genreads job: MALBAC amplification + read allocation + read generation)",
             "value": pairs_total / elapsed, "unit": "pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,

@@ -339,17 +339,16 @@ __global__ void k_plan_pairs(DevFrags fr, DevAmps semis, DevAmps fulls, uint32_t
 // ------------------------------------------------------------------------------------------------
 // K5  inject_errors = Profile::predict (lib/profile/Profile.cpp:1582-1697) + window extraction
 //     (Amplicon::yieldReads, Amplicon.cpp:492-528).  One THREAD per read, one workgroup per 256 reads of
-//     the same mate, stepping synchronously over the output positions:
-//       * the read windows are gathered through the pair records' index maps with coalesced loads
-//         (a wave per read, 64 consecutive bases per instruction) into an LDS tile, two bases per byte;
+//     the same mate:
+//       * staging: the read windows are gathered through the pair records' index maps, a dword (4 bases) per lane,
+//         one load instruction per read, into an LDS tile with two bases per byte;
 //       * phase 1 (per thread): the indel tests of every input base -> event list (LDS), n';
-//       * phase 2 (workgroup-synchronous over the output position j): because all 256 reads are at the
-//         same position, only the table rows of a few bins around j are live -- a ring of 16 bins
-//         (64 k-mer substitution rows + the 4 diagonal quality rows each, 1 or 2 KB per bin) sits in LDS and
-//         is refilled a group of bins at a time, so the per-base table lookups are LDS reads instead of
-//         divergent global gathers.  A wave whose 64 reads all sit on a plain base (no indel event, clean k-mer, bin
-//         inside the ring) takes a branch-free fast step; any exception sends the wave through the
-//         general step for that position.  Rows outside the ring and substituted bases come from global.
+//       * phase 2, the base pass, is workgroup-synchronous over the TABLE BINS: position j of a read uses bin
+//         j*bins/n', so all 256 reads look up the same bin at the same time and a small ring of bins in LDS
+//         (64 k-mer substitution rows + the 4 diagonal quality rows per bin), refilled a group of bins ahead
+//         through registers, serves every lookup.  A wave whose reads all sit on clean k-mers takes a branch-free
+//         fast step; first-two-bases / N k-mers take the general step; substituted bases (off-diagonal quality
+//         row, global) are resolved after the loop.
 //     LDS per workgroup at L = 150: 13-16 KB ring + 4 KB events + 19 KB windows -> 4 workgroups per CU.
 // ------------------------------------------------------------------------------------------------
 #define RB 256
