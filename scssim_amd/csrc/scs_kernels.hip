@@ -770,8 +770,11 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
 }
 
 // ------------------------------------------------------------------------------------------------
-// K6  format: one wave per FASTQ record, coalesced copy from the slot buffer to its final offset
-//     (record layout of Amplicon::yieldReads, Amplicon.cpp:459-466 / 497-525; sink = SeqWriter)
+// K6  format: slot buffer -> FASTQ text at the prefix-summed record offsets (record layout of Amplicon::yieldReads,
+//     Amplicon.cpp:459-466 / 497-525; sink = SeqWriter).  THREE records per wave, 21 lanes each: lanes 0-9 move the
+//     bases and lanes 10-19 the qualities, 16 bytes per lane per round, as ALIGNED dwords on both sides (a record
+//     starts at any byte: destination dword j takes source bytes a+4j.., assembled with v_alignbyte from the aligned
+//     slot); lane 20 writes the name line, the separators and the <= 3 bytes before/after each aligned body.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t put_dec(char* dst, uint32_t v) {
     const uint32_t nd = dec_digits(v);
@@ -785,22 +788,48 @@ __global__ void __launch_bounds__(256) k_format(const PairRec* __restrict__ pair
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
     const uint32_t nreads = paired ? 2 * np : np;
     const uint32_t nwaves = gridDim.x * 4;
-    for (uint32_t r = blockIdx.x * 4 + wib; r < nreads; r += nwaves) {
+    const uint32_t rec = (uint32_t)lane / 21u, sub = (uint32_t)lane % 21u;         // lane 63: rec 3 = idle
+    for (uint32_t r0 = (blockIdx.x * 4 + wib) * 3u; r0 < nreads; r0 += 3u * nwaves) {
+        const uint32_t r = r0 + rec;
+        if (rec >= 3u || r >= nreads) continue;
         const uint32_t pi = paired ? r >> 1 : r, rd = paired ? (r & 1u) : 0u;
         const uint32_t nl = lens[r];
         if (nl == 0 || nl > slot) continue;
-        const PairRec pr = pairs[pi];
+        const uint32_t amp = amp_index_base + pairs[pi].amp, cnt = pairs[pi].att + 1u;
         char* dst = (rd ? out2 : out1) + (rd ? off2[pi] : off1[pi]);
-        uint32_t h = 0;
-        if (lane == 0) {
-            dst[h++] = '@'; h += put_dec(dst + h, amp_index_base + pr.amp); dst[h++] = '#'; h += put_dec(dst + h, pr.att + 1);
-            if (paired) { dst[h++] = '/'; dst[h++] = rd ? '2' : '1'; }
-            dst[h++] = '\n';
+        const uint32_t h = 1u + dec_digits(amp) + 1u + dec_digits(cnt) + (paired ? 2u : 0u) + 1u;   // "@<amp>#<cnt>[/1|/2]\n"
+        const uint32_t words = slot >> 2;
+        if (sub < 20u) {                                                           // ---- field bodies
+            const bool qual = sub >= 10u;
+            char* fdst = dst + h + (qual ? nl + 3u : 0u);
+            const char* src = (qual ? slot_q : slot_b) + (size_t)r * slot;
+            const uint32_t a = (uint32_t)(0u - (uint32_t)reinterpret_cast<uintptr_t>(fdst)) & 3u;   // bytes before the first aligned dword
+            const uint32_t head = a < nl ? a : nl, nd = (nl - head) >> 2;          // aligned dwords in the body
+            const uint4* __restrict__ s128 = reinterpret_cast<const uint4*>(src); const uint32_t* __restrict__ s32 = reinterpret_cast<const uint32_t*>(src);
+            uint32_t* __restrict__ d32 = reinterpret_cast<uint32_t*>(fdst + head);
+            for (uint32_t q = sub - (qual ? 10u : 0u); 4u * q < nd; q += 10u) {
+                const uint4 S = s128[q]; const uint32_t N = 4u * q + 4u < words ? s32[4u * q + 4u] : 0u;
+                uint4 o = S;
+                if (a) { o.x = __builtin_amdgcn_alignbyte(S.y, S.x, a); o.y = __builtin_amdgcn_alignbyte(S.z, S.y, a); o.z = __builtin_amdgcn_alignbyte(S.w, S.z, a); o.w = __builtin_amdgcn_alignbyte(N, S.w, a); }
+                const uint32_t j = 4u * q;
+                if (j + 4u <= nd) { d32[j] = o.x; d32[j + 1] = o.y; d32[j + 2] = o.z; d32[j + 3] = o.w; }   // one dwordx4 store (dword aligned)
+                else { d32[j] = o.x; if (j + 1u < nd) d32[j + 1] = o.y; if (j + 2u < nd) d32[j + 2] = o.z; }
+            }
+        } else {                                                                   // ---- name line, separators, field edges
+            uint32_t k = 0;
+            dst[k++] = '@'; k += put_dec(dst + k, amp); dst[k++] = '#'; k += put_dec(dst + k, cnt);
+            if (paired) { dst[k++] = '/'; dst[k++] = rd ? '2' : '1'; }
+            dst[k++] = '\n';
+            dst[h + nl] = '\n'; dst[h + nl + 1] = '+'; dst[h + nl + 2] = '\n'; dst[h + 2u * nl + 3u] = '\n';
+            for (int f = 0; f < 2; ++f) {
+                char* fdst = dst + h + (f ? nl + 3u : 0u);
+                const char* src = (f ? slot_q : slot_b) + (size_t)r * slot;
+                const uint32_t a = (uint32_t)(0u - (uint32_t)reinterpret_cast<uintptr_t>(fdst)) & 3u;
+                const uint32_t head = a < nl ? a : nl, nd = (nl - head) >> 2, tail0 = head + 4u * nd;
+                for (uint32_t i = 0; i < head; ++i) fdst[i] = src[i];
+                for (uint32_t i = tail0; i < nl; ++i) fdst[i] = src[i];
+            }
         }
-        h = __shfl(h, 0);
-        const char* sb = slot_b + (size_t)r * slot; const char* sq = slot_q + (size_t)r * slot;
-        for (uint32_t k = lane; k < nl; k += WAVE) { dst[h + k] = sb[k]; dst[h + nl + 3 + k] = sq[k]; }
-        if (lane == 0) { dst[h + nl] = '\n'; dst[h + nl + 1] = '+'; dst[h + nl + 2] = '\n'; dst[h + 2 * nl + 3] = '\n'; }
     }
 }
 
@@ -1262,7 +1291,7 @@ void launch_format(hipStream_t s, const PairRec* pairs, uint32_t np, uint32_t am
                    const char* slot_q, const uint32_t* lens, const uint64_t* off1, const uint64_t* off2, char* out1, char* out2) {
     if (np == 0) return;
     const uint64_t nreads = paired ? 2ull * np : np;
-    uint32_t grid = cdiv(nreads, 4); if (grid > kMaxStrideGrid * 4) grid = kMaxStrideGrid * 4;
+    uint32_t grid = cdiv(nreads, 12); if (grid > kMaxStrideGrid * 4) grid = kMaxStrideGrid * 4;   // 4 waves x 3 records per workgroup and round
     hipLaunchKernelGGL(k_format, dim3(grid), dim3(256), 0, s, pairs, np, amp_index_base, paired, slot, slot_b, slot_q, lens, off1, off2, out1, out2);
 }
 void launch_philox(hipStream_t s, const uint32_t* ctr, uint32_t n, RngKey key, uint32_t* out) {

@@ -341,3 +341,16 @@ def test_error_reporting_through_the_abi(models, tmp_path):
     with pytest.raises(scssim_amd.ScsError) as e:
         scssim_amd.GenReads(gamma=1.0)
     assert "0~1e-8" in str(e.value)
+
+
+def test_replayed_indel_reads_match_oracle(models, tmp_path):
+    """A read whose indel events do not fit the 16-bit LDS slots is 'replayed' (phase 2 re-draws stream A).  The fallback is
+    rare in production, so the same parity checks run once more in a child process with SCS_EV_REPLAY=1, which sends every
+    read with an indel through it."""
+    env = dict(os.environ, SCS_EV_REPLAY="1")
+    sel = ["tests/test_gpu_parity.py::test_predict_batch_matches_oracle", "tests/test_gpu_parity.py::test_full_pipeline_fastq_bit_exact"]
+    if os.environ.get("SCS_EV_REPLAY"):
+        pytest.skip("already inside the replay run")
+    r = subprocess.run(["python", "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider"] + sel, cwd=ROOT, env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:]
