@@ -797,38 +797,41 @@ __global__ void __launch_bounds__(256) k_format(const PairRec* __restrict__ pair
         if (nl == 0 || nl > slot) continue;
         const uint32_t amp = amp_index_base + pairs[pi].amp, cnt = pairs[pi].att + 1u;
         char* dst = (rd ? out2 : out1) + (rd ? off2[pi] : off1[pi]);
-        const uint32_t h = 1u + dec_digits(amp) + 1u + dec_digits(cnt) + (paired ? 2u : 0u) + 1u;   // "@<amp>#<cnt>[/1|/2]\n"
+        const uint32_t d1 = dec_digits(amp), d2 = dec_digits(cnt), h = 1u + d1 + 1u + d2 + (paired ? 2u : 0u) + 1u;   // "@<amp>#<cnt>[/1|/2]\n"
         const uint32_t words = slot >> 2;
-        if (sub < 20u) {                                                           // ---- field bodies
+        for (uint32_t j = sub; j < h; j += 21u) {                                  // ---- name line: lane j writes character j
+            uint32_t ch;
+            if (j == 0) ch = '@';
+            else if (j <= d1) { uint32_t v = amp; for (uint32_t k = d1 - j; k; --k) v /= 10u; ch = '0' + v % 10u; }
+            else if (j == d1 + 1u) ch = '#';
+            else if (j <= d1 + 1u + d2) { uint32_t v = cnt; for (uint32_t k = d1 + 1u + d2 - j; k; --k) v /= 10u; ch = '0' + v % 10u; }
+            else if (j == h - 1u) ch = '\n';
+            else ch = j == h - 3u ? '/' : (rd ? '2' : '1');
+            dst[j] = (char)ch;
+        }
+        if (sub < 20u) {                                                           // ---- field bodies and their edges
             const bool qual = sub >= 10u;
             char* fdst = dst + h + (qual ? nl + 3u : 0u);
             const char* src = (qual ? slot_q : slot_b) + (size_t)r * slot;
             const uint32_t a = (uint32_t)(0u - (uint32_t)reinterpret_cast<uintptr_t>(fdst)) & 3u;   // bytes before the first aligned dword
-            const uint32_t head = a < nl ? a : nl, nd = (nl - head) >> 2;          // aligned dwords in the body
+            const uint32_t head = a < nl ? a : nl, nd = (nl - head) >> 2, tail0 = head + 4u * nd;   // nd aligned dwords in the body
             const uint4* __restrict__ s128 = reinterpret_cast<const uint4*>(src); const uint32_t* __restrict__ s32 = reinterpret_cast<const uint32_t*>(src);
             uint32_t* __restrict__ d32 = reinterpret_cast<uint32_t*>(fdst + head);
-            for (uint32_t q = sub - (qual ? 10u : 0u); 4u * q < nd; q += 10u) {
+            for (uint32_t q = sub - (qual ? 10u : 0u); 4u * q <= nd && 4u * q < words; q += 10u) {   // "<=": the lane that owns dword nd writes the tail bytes
                 const uint4 S = s128[q]; const uint32_t N = 4u * q + 4u < words ? s32[4u * q + 4u] : 0u;
                 uint4 o = S;
                 if (a) { o.x = __builtin_amdgcn_alignbyte(S.y, S.x, a); o.y = __builtin_amdgcn_alignbyte(S.z, S.y, a); o.z = __builtin_amdgcn_alignbyte(S.w, S.z, a); o.w = __builtin_amdgcn_alignbyte(N, S.w, a); }
                 const uint32_t j = 4u * q;
                 if (j + 4u <= nd) { d32[j] = o.x; d32[j + 1] = o.y; d32[j + 2] = o.z; d32[j + 3] = o.w; }   // one dwordx4 store (dword aligned)
-                else { d32[j] = o.x; if (j + 1u < nd) d32[j + 1] = o.y; if (j + 2u < nd) d32[j + 2] = o.z; }
+                else {
+                    if (j < nd) d32[j] = o.x; if (j + 1u < nd) d32[j + 1] = o.y; if (j + 2u < nd) d32[j + 2] = o.z;
+                    const uint32_t e = nd - j, vt = e == 0 ? o.x : e == 1 ? o.y : e == 2 ? o.z : o.w;   // the dword that would come next: its low bytes are the tail
+                    for (uint32_t i = tail0; i < nl; ++i) fdst[i] = (char)(vt >> (8u * (i - tail0)));
+                }
+                if (q == 0) for (uint32_t i = 0; i < head; ++i) fdst[i] = (char)(S.x >> (8u * i));   // bytes before the first aligned dword
             }
-        } else {                                                                   // ---- name line, separators, field edges
-            uint32_t k = 0;
-            dst[k++] = '@'; k += put_dec(dst + k, amp); dst[k++] = '#'; k += put_dec(dst + k, cnt);
-            if (paired) { dst[k++] = '/'; dst[k++] = rd ? '2' : '1'; }
-            dst[k++] = '\n';
+        } else {                                                                   // ---- separators
             dst[h + nl] = '\n'; dst[h + nl + 1] = '+'; dst[h + nl + 2] = '\n'; dst[h + 2u * nl + 3u] = '\n';
-            for (int f = 0; f < 2; ++f) {
-                char* fdst = dst + h + (f ? nl + 3u : 0u);
-                const char* src = (f ? slot_q : slot_b) + (size_t)r * slot;
-                const uint32_t a = (uint32_t)(0u - (uint32_t)reinterpret_cast<uintptr_t>(fdst)) & 3u;
-                const uint32_t head = a < nl ? a : nl, nd = (nl - head) >> 2, tail0 = head + 4u * nd;
-                for (uint32_t i = 0; i < head; ++i) fdst[i] = src[i];
-                for (uint32_t i = tail0; i < nl; ++i) fdst[i] = src[i];
-            }
         }
     }
 }
