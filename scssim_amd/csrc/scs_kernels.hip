@@ -1204,7 +1204,7 @@ void launch_attach_semis(hipStream_t s, const uint8_t* g, DevFrags fr, DevAmps s
                          const uint32_t* slot_off, uint32_t* slots, uint32_t* slot_tmpl, uint32_t* valid,
                          const int64_t* primer_cnt, uint32_t* primer_delta, AmplifyParams p) {
     if (n_semis == 0) return;
-    hipLaunchKernelGGL((k_attach<false, 16>), dim3(cdiv(n_semis, 4)), dim3(64), 0, s, g, fr, semis, n_semis, spool, slot_off, slots, slot_tmpl, valid,
+    hipLaunchKernelGGL((k_attach<false, 8>), dim3(cdiv(n_semis, 8)), dim3(64), 0, s, g, fr, semis, n_semis, spool, slot_off, slots, slot_tmpl, valid,
                        primer_cnt, primer_delta, (unsigned long long*)nullptr, p);
 }
 void launch_errs_frags(hipStream_t s, const uint8_t* g, DevGenomeIdx gx, DevFrags fr, uint32_t n_slots, const uint32_t* slot_off, const uint32_t* slots,
