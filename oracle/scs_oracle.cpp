@@ -206,6 +206,10 @@ std::vector<Record> load_fasta(const std::string& path) {
 struct Profile {
     int L = 0, bins = 0, kmer = 3, N = 4, kmerCount = 84, nq = 94;
     double insertRate = 0, delRate = 0, stdISize = 0, gcStd = 0;
+    // [REMAP] counter mode decides insertion / deletion / neither at a base from ONE 32-bit draw x:
+    //   x < tIns (#{x : x/2^32 <= insertRate}) -> insertion; else x < tIndel -> deletion, where the deletion test's own
+    //   threshold tDel = #{x : x/2^32 < delRate/(1-insertRate)} is rescaled to the draws left: tIndel = tIns + ((2^32-tIns)*tDel >> 32)
+    uint32_t tIns = 0, tIndel = 0;
     std::vector<double> insCdf, delCdf;
     std::vector<double> subs1, subs2;     // [84][bins][4]  (dist, then cdf in place)
     bool haveCdf2 = false;
@@ -376,6 +380,14 @@ Profile* load_profile(const std::string& path, bool paired, int isize) {
     for (int i = 0; i < 84; ++i) row_cumsum(P->subs1.data() + (size_t)i * B * 4, B, 4);
     P->haveCdf2 = paired && P->stdISize > 0;                                   // Profile.cpp:1416-1428
     if (P->haveCdf2) for (int i = 0; i < 84; ++i) row_cumsum(P->subs2.data() + (size_t)i * B * 4, B, 4);
+    {   // integer thresholds of the two indel tests (monotone in the 32-bit draw: found by bisection on the reference's
+        // own double comparisons), combined for the one-draw counter mode
+        auto count_true = [](auto pred) { uint64_t lo = 0, hi = 1ull << 32; while (lo < hi) { uint64_t mid = (lo + hi) >> 1; if (pred((uint32_t)mid)) lo = mid + 1; else hi = mid; } return (uint32_t)std::min<uint64_t>(lo, 0xFFFFFFFFull); };
+        const double ir = P->insertRate, dr = P->delRate / (1 - P->insertRate);
+        const uint32_t tIns = count_true([ir](uint32_t x) { return (x / 4294967296.0) <= ir; });
+        const uint32_t tDel = count_true([dr](uint32_t x) { return (x / 4294967296.0) < dr; });
+        P->tIns = tIns; P->tIndel = tIns + (uint32_t)((((1ull << 32) - tIns) * (uint64_t)tDel) >> 32);
+    }
     return P.release();
 }
 
@@ -413,8 +425,9 @@ int predict(const Profile& P, Rng& rng, const uint8_t* win, int n, bool isRead1,
     int indelLength = 0;
     for (int j = 0; j < n;) {                                                  // 1606-1622
         int k = 0; bool isIns = false;
-        double p = drawA();                                                     // getIndelSeq 1552-1570
-        if (p <= P.insertRate) {
+        const uint32_t xi = rng.counter ? xa.next() : 0u;                       // [REMAP] one draw per base in counter mode
+        double p = rng.counter ? 0.0 : drawA();                                 // getIndelSeq 1552-1570
+        if (rng.counter ? xi < P.tIns : p <= P.insertRate) {
             k = rand_indx(P.insCdf.data(), P.insCdf.size(), rng.real(mk(ST_INDEL_LEN, aux, uid, j, 0)));
             for (int t = 0; t < k; ++t) {
                 // [REMAP] counter mode: the inserted base is drawn from stream B when it is emitted (base pass below)
@@ -423,8 +436,8 @@ int predict(const Profile& P, Rng& rng, const uint8_t* win, int n, bool isRead1,
             }
             isIns = !ins[j].empty();
         } else {
-            p = drawA();
-            if (p < P.delRate / (1 - P.insertRate))
+            if (!rng.counter) p = drawA();
+            if (rng.counter ? xi < P.tIndel : p < P.delRate / (1 - P.insertRate))
                 k = rand_indx(P.delCdf.data(), P.delCdf.size(), rng.real(mk(ST_INDEL_LEN, aux, uid, j, 0)));
         }
         if (!isIns && k > 0) {                                                  // deletion

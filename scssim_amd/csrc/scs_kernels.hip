@@ -452,7 +452,7 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
     // the table descriptor is a by-value kernel argument: pointers loaded from the kernarg segment are known to be
     // global (a descriptor fetched through a pointer makes every table access a FLAT load)
     const int n = tb.L, B = tb.bins;
-    const uint32_t t_insert = tb.t_insert, t_delete = tb.t_delete;
+    const uint32_t t_insert = tb.t_insert, t_indel = tb.t_indel;
     const uint32_t WS = win_stride((uint32_t)n);
     Bin* s_ring = reinterpret_cast<Bin*>(s_dyn);                           // [SLOTS]
     int64_t* s_gbase = reinterpret_cast<int64_t*>(s_dyn);                  // [RB]  staging only: aliases the ring, which is filled later
@@ -562,7 +562,7 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
                     ++nev; delta += (int)k;
                 }
                 ++ji;
-            } else if (xa.next() < t_delete) {                                     // second draw only when no insertion; p < delRate/(1-insertRate)
+            } else if (w0 < t_indel) {                                             // [REMAP] the same draw: p < delRate/(1-insertRate) rescaled to the draws left
                 const uint32_t k = rand_indx_thr(tb.del_t, tb.del_d, (uint32_t)tb.n_del, draw4(key, ST_INDEL_LEN, aux, uid, (uint32_t)ji).w[0]);
                 if (k > 0) {
                     const int kk = (int)k < n - ji ? (int)k : n - ji;
@@ -678,11 +678,12 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
                     if (replay) {                                                  // the indel tests of phase 1, drawn again (same stream, same order)
                         Xoshiro xa; xa.s0 = my_xa[0]; xa.s1 = my_xa[1]; xa.s2 = my_xa[2]; xa.s3 = my_xa[3];
                         while (ji < n) {
-                            if (xa.next() < t_insert) {
+                            const uint32_t w0 = xa.next();
+                            if (w0 < t_insert) {
                                 ins_left = (int)rand_indx_thr(tb.ins_t, tb.ins_d, (uint32_t)tb.n_ins, draw4(key, ST_INDEL_LEN, aux, uid, (uint32_t)ji).w[0]);
                                 break;
                             }
-                            if (xa.next() < t_delete) {
+                            if (w0 < t_indel) {
                                 const uint32_t k = rand_indx_thr(tb.del_t, tb.del_d, (uint32_t)tb.n_del, draw4(key, ST_INDEL_LEN, aux, uid, (uint32_t)ji).w[0]);
                                 if (k > 0) { ji += (int)k < n - ji ? (int)k : n - ji; continue; }
                             }

@@ -251,6 +251,7 @@ void load_profile(const std::string& path, bool paired, int isize, ProfileTables
     }
     T.t_insert = threshold_le(T.insert_rate);
     T.t_delete = threshold_lt(T.del_rate / (1 - T.insert_rate));
+    T.t_indel = T.t_insert + (uint32_t)((((1ull << 32) - T.t_insert) * (uint64_t)T.t_delete) >> 32);
 }
 
 // ---------------------------------------------------------------- FASTA

@@ -37,6 +37,9 @@ struct ProfileTables {
     std::vector<uint32_t> qual_compact;
     uint32_t t_insert = 0;               // p <= insertRate            (Profile.cpp:1557)
     uint32_t t_delete = 0;               // p <  delRate/(1-insertRate) (Profile.cpp:1565-1566)
+    // [REMAP] both tests from ONE draw x: x < t_insert -> insertion, else x < t_indel -> deletion, with the deletion
+    // threshold rescaled to the draws left: t_indel = t_insert + ((2^32 - t_insert) * t_delete >> 32)
+    uint32_t t_indel = 0;
 };
 
 // count of 32-bit draws x with (x / 2^32) < c  resp. <= c, clamped to 2^32-1
