@@ -493,10 +493,11 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
         // complements them in place and packs them into two LDS bytes: one load instruction covers 256 bases of a read
         for (int kb = 0; kb < n; kb += 4 * WAVE) {                                  // one round for L <= 256
             const int k4 = kb + 4 * lane;
-            for (int q0 = 0; q0 < 64; q0 += 8) {                                    // 8 reads' loads in flight per lane
-                uint32_t cv[8];
+            constexpr int FLY = 32;                                                 // reads whose loads are in flight per lane: the gather is HBM-latency bound
+            for (int q0 = 0; q0 < 64; q0 += FLY) {
+                uint32_t cv[FLY];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
+                for (int u = 0; u < FLY; ++u) {
                     const int rr = wib * 64 + q0 + u; const uint32_t f = s_gflag[rr];
                     const int64_t b0 = s_gbase[rr];
                     uint32_t v = 0;
@@ -512,7 +513,7 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
                     cv[u] = v;
                 }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
+                for (int u = 0; u < FLY; ++u) {
                     const int rr = wib * 64 + q0 + u; const uint32_t f = s_gflag[rr];
                     uint32_t v = cv[u];
                     if (f & 1u) v ^= 0x03030303u & ~(((v >> 2) & 0x01010101u) * 3u);   // complement: 3 - c for ACGT codes, N (4) stays
