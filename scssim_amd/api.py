@@ -99,7 +99,7 @@ class Profile:
     """Host-only view of a .profile model: the exact uint32 thresholds and the double CDFs they come from
     (mirrors Profile::train(file), reference lib/profile/Profile.cpp:1432-1436).  Needs no GPU."""
 
-    TABLES = {"subs1": 0, "subs2": 1, "qual": 2, "ins": 3, "del": 4, "isize": 5}
+    TABLES = {"subs1": 0, "subs2": 1, "qual": 2, "ins": 3, "del": 4, "isize": 5, "qual_compact": 6}
 
     def __init__(self, path, paired=True, isize=260):
         import numpy as np
@@ -110,10 +110,11 @@ class Profile:
         rc = L.scs_profile_open(os.fsencode(path), int(paired), int(isize), C.byref(self._h), err, 512)
         if rc:
             raise ScsError(rc, err.value.decode())
-        sc = (C.c_double * 8)()
+        sc = (C.c_double * 10)()
         L.scs_profile_scalars(self._h, sc)
         (self.read_length, self.bins, self.t_insert, self.t_delete, self.isize_min, self.have_cdf2) = [int(v) for v in sc[:6]]
         self.insert_rate, self.del_rate = sc[6], sc[7]
+        self.t_indel, self.qual_row_words = int(sc[8]), int(sc[9])
 
     def table(self, name):
         np = self._np
@@ -125,6 +126,8 @@ class Profile:
             raise ScsError(rc, "bad table")
         if n.value == 0:
             return np.zeros(0, np.uint32), np.zeros(0, np.float64)
+        if not cdf:                                   # tables without a double twin (compact quality rows)
+            return np.ctypeslib.as_array(thr, (n.value,)).copy(), None
         return (np.ctypeslib.as_array(thr, (n.value,)).copy(), np.ctypeslib.as_array(cdf, (n.value,)).copy())
 
     def close(self):

@@ -886,6 +886,7 @@ int scs_profile_table(void* handle, int which, const uint32_t** thr, const doubl
     switch (which) {
         case 0: t = &T->subs1_t; d = &T->subs1; break; case 1: t = &T->subs2_t; d = &T->subs2; break; case 2: t = &T->qual_t; d = &T->qual; break;
         case 3: t = &T->ins_t; d = &T->ins_cdf; break; case 4: t = &T->del_t; d = &T->del_cdf; break; case 5: t = &T->isize_t; d = &T->isize_cdf; break;
+        case 6: if (thr) *thr = T->qual_compact.data(); if (cdf) *cdf = nullptr; if (n) *n = T->qual_compact.size(); return SCS_OK;   // compact quality rows
         default: return SCS_EINVAL;
     }
     if (thr) *thr = t->data(); if (cdf) *cdf = d->data(); if (n) *n = t->size();
@@ -895,6 +896,7 @@ int scs_profile_scalars(void* handle, double* out) {
     if (!handle || !out) return SCS_EINVAL;
     ProfileTables* T = (ProfileTables*)handle;
     out[0] = T->read_length; out[1] = T->bins; out[2] = T->t_insert; out[3] = T->t_delete; out[4] = T->isize_min; out[5] = T->have_cdf2; out[6] = T->insert_rate; out[7] = T->del_rate;
+    out[8] = T->t_indel; out[9] = T->qual_row_words;
     return SCS_OK;
 }
 void scs_profile_close(void* handle) { delete (ProfileTables*)handle; }
