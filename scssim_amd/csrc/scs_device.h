@@ -101,10 +101,11 @@ void launch_attach_semis(hipStream_t s, const uint8_t* g, DevFrags fr, DevAmps s
                          const int64_t* primer_cnt, uint32_t* primer_delta, AmplifyParams p);
 void launch_errs_frags(hipStream_t s, const uint8_t* g, DevGenomeIdx gx, DevFrags fr, uint32_t n_slots, const uint32_t* slot_off, const uint32_t* slots,
                        const uint32_t* slot_tmpl, const uint32_t* valid_off, DevAmps out, uint32_t out_base, DevErrPool pool, uint32_t* flags,
-                       const unsigned long long* binom, AmplifyParams p);
+                       const unsigned long long* binom, AmplifyParams p, int64_t* primer_cnt, uint32_t* primer_delta, unsigned long long* semis_n);
 void launch_errs_semis(hipStream_t s, const uint8_t* g, DevGenomeIdx gx, DevFrags fr, DevAmps semis, uint32_t n_semis, DevErrPool spool, uint32_t n_slots,
                        const uint32_t* slot_off, const uint32_t* slots, const uint32_t* slot_tmpl, const uint32_t* valid_off,
-                       DevAmps out, uint32_t out_base, DevErrPool pool, uint32_t* flags, const unsigned long long* binom, AmplifyParams p);
+                       DevAmps out, uint32_t out_base, DevErrPool pool, uint32_t* flags, const unsigned long long* binom, AmplifyParams p,
+                       int64_t* primer_cnt, uint32_t* primer_delta);   // primer_cnt non-null: the pass's stock update rides along (unsharded job)
 void launch_encode_bases(hipStream_t s, uint8_t* g, uint64_t n);
 void launch_genome_bits(hipStream_t s, const uint8_t* g, uint64_t n, uint64_t nwords, unsigned long long* gc_bits, unsigned long long* n_bits,
                         uint32_t* gc_cnt, uint32_t* n_cnt, uint64_t* gc_pref, uint64_t* n_pref, void* temp, size_t temp_bytes);
@@ -130,7 +131,7 @@ void launch_detlog(hipStream_t s, const double* x, uint32_t n, double* out);
 
 // gathers up to 12 device scalars (4 or 8 bytes wide) into mail[dsts[i]] (u64 each)
 #define MAIL_SEQ_SLOT 31                                   // mailbox word the sequence number of a post lands in
-void launch_mail(hipStream_t s, const void* const* srcs, const int* widths, const int* dsts, unsigned long long* const* accs, int n, unsigned clear, unsigned long long* mail, unsigned long long seq);
+void launch_mail(hipStream_t s, const void* const* srcs, const int* widths, const int* dsts, int n, unsigned clear, unsigned long long* mail, unsigned long long seq);   // n <= 16
 void launch_local_totals(hipStream_t s, unsigned long long nf, unsigned long long frag_len, const unsigned long long* dev, unsigned long long* totals);
 
 // first error of any kernel launch / attribute call since the last call (hipSuccess if none)

@@ -163,8 +163,14 @@ __global__ void __launch_bounds__(256) k_errs(const uint8_t* __restrict__ g, Dev
                                               uint32_t n_slots, const uint32_t* __restrict__ slot_off, const uint32_t* __restrict__ slots,
                                               const uint32_t* __restrict__ slot_tmpl, const uint32_t* __restrict__ valid_off, uint32_t n_tmpl,
                                               DevAmps out, uint32_t out_base, DevErrPool pool, uint32_t* __restrict__ flags,
-                                              const unsigned long long* __restrict__ binom, AmplifyParams p) {
+                                              const unsigned long long* __restrict__ binom, AmplifyParams p,
+                                              int64_t* __restrict__ primer_cnt, uint32_t* __restrict__ primer_delta, unsigned long long* __restrict__ semis_n) {
     const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+    // the pass epilogue rides along (unsharded job; a sharded one all-reduces the decrements first and launches
+    // k_primer_update): primer stock -= this pass's decrements, clamped ([REMAP] snapshot per pass), and the device-side
+    // semi amplicon count that the next setPrimers reads
+    if (primer_cnt) for (uint32_t i = w; i < 65536u; i += gridDim.x * blockDim.x) { const int64_t c = primer_cnt[i] - (int64_t)primer_delta[i]; primer_cnt[i] = c < 0 ? 0 : c; primer_delta[i] = 0; }
+    if (FROM_FRAG && w == 0 && semis_n) *semis_n += valid_off[n_tmpl];
     if (w >= n_slots) return;
     const uint32_t t = slot_tmpl[w];
     if (t == 0xFFFFFFFFu) return;                      // reserved but unused slot (aborted template)
@@ -1137,7 +1143,7 @@ struct Widen { __host__ __device__ uint64_t operator()(uint32_t v) const { retur
 // mailbox: collects scattered device scalars into one contiguous block of PINNED, DEVICE-MAPPED host memory, so the
 // host reads them without a copy or a stream synchronisation: it spins on the sequence word that the post writes last
 // (system-scope release).  A null source posts 0.
-struct MailSrc { const void* p[12]; unsigned long long* acc[12]; int w[12]; int dst[12]; int n; unsigned clear; };   // clear: bit i = zero source i after reading it; acc: also add the value to a device word
+struct MailSrc { const void* p[16]; int w[16]; int dst[16]; int n; unsigned clear; };   // clear: bit i = zero source i after reading it
 __global__ void k_mail(MailSrc m, unsigned long long* __restrict__ mail, unsigned long long seq) {
     const int i = threadIdx.x;
     if (i < m.n) {
@@ -1146,16 +1152,15 @@ __global__ void k_mail(MailSrc m, unsigned long long* __restrict__ mail, unsigne
             if (m.w[i] == 8) { unsigned long long* q = reinterpret_cast<unsigned long long*>(const_cast<void*>(m.p[i])); v = *q; if ((m.clear >> i) & 1u) *q = 0; }
             else { uint32_t* q = reinterpret_cast<uint32_t*>(const_cast<void*>(m.p[i])); v = *q; if ((m.clear >> i) & 1u) *q = 0; }
         }
-        if (m.acc[i]) *m.acc[i] += v;                                                  // one thread per source: plain read-modify-write
         __hip_atomic_store(&mail[m.dst[i]], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     __threadfence_system();
     __syncthreads();
     if (i == 0 && seq) __hip_atomic_store(&mail[MAIL_SEQ_SLOT], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-void launch_mail(hipStream_t s, const void* const* srcs, const int* widths, const int* dsts, unsigned long long* const* accs, int n, unsigned clear, unsigned long long* mail, unsigned long long seq) {
+void launch_mail(hipStream_t s, const void* const* srcs, const int* widths, const int* dsts, int n, unsigned clear, unsigned long long* mail, unsigned long long seq) {
     MailSrc m; m.n = n; m.clear = clear;
-    for (int i = 0; i < 12; ++i) { m.p[i] = i < n ? srcs[i] : nullptr; m.acc[i] = i < n ? accs[i] : nullptr; m.w[i] = i < n ? widths[i] : 4; m.dst[i] = i < n ? dsts[i] : 0; }
+    for (int i = 0; i < 16; ++i) { m.p[i] = i < n ? srcs[i] : nullptr; m.w[i] = i < n ? widths[i] : 4; m.dst[i] = i < n ? dsts[i] : 0; }
     hipLaunchKernelGGL(k_mail, dim3(1), dim3(64), 0, s, m, mail, seq);
 }
 struct OddBit { __host__ __device__ uint32_t operator()(uint32_t v) const { return v & 1u; } };
@@ -1218,16 +1223,19 @@ void launch_attach_semis(hipStream_t s, const uint8_t* g, DevFrags fr, DevAmps s
 }
 void launch_errs_frags(hipStream_t s, const uint8_t* g, DevGenomeIdx gx, DevFrags fr, uint32_t n_slots, const uint32_t* slot_off, const uint32_t* slots,
                        const uint32_t* slot_tmpl, const uint32_t* valid_off, DevAmps out, uint32_t out_base, DevErrPool pool, uint32_t* flags,
-                       const unsigned long long* binom, AmplifyParams p) {
+                       const unsigned long long* binom, AmplifyParams p, int64_t* primer_cnt, uint32_t* primer_delta, unsigned long long* semis_n) {
     if (n_slots == 0) return;
     DevAmps none{}; DevErrPool np{};
-    hipLaunchKernelGGL(k_errs<true>, dim3(cdiv(n_slots, 256)), dim3(256), 0, s, g, gx, fr, none, np, n_slots, slot_off, slots, slot_tmpl, valid_off, fr.n, out, out_base, pool, flags, binom, p);
+    hipLaunchKernelGGL(k_errs<true>, dim3(cdiv(n_slots, 256)), dim3(256), 0, s, g, gx, fr, none, np, n_slots, slot_off, slots, slot_tmpl, valid_off, fr.n, out, out_base, pool, flags, binom, p,
+                       primer_cnt, primer_delta, semis_n);
 }
 void launch_errs_semis(hipStream_t s, const uint8_t* g, DevGenomeIdx gx, DevFrags fr, DevAmps semis, uint32_t n_semis, DevErrPool spool, uint32_t n_slots,
                        const uint32_t* slot_off, const uint32_t* slots, const uint32_t* slot_tmpl, const uint32_t* valid_off,
-                       DevAmps out, uint32_t out_base, DevErrPool pool, uint32_t* flags, const unsigned long long* binom, AmplifyParams p) {
+                       DevAmps out, uint32_t out_base, DevErrPool pool, uint32_t* flags, const unsigned long long* binom, AmplifyParams p,
+                       int64_t* primer_cnt, uint32_t* primer_delta) {
     if (n_slots == 0) return;
-    hipLaunchKernelGGL(k_errs<false>, dim3(cdiv(n_slots, 256)), dim3(256), 0, s, g, gx, fr, semis, spool, n_slots, slot_off, slots, slot_tmpl, valid_off, n_semis, out, out_base, pool, flags, binom, p);
+    hipLaunchKernelGGL(k_errs<false>, dim3(cdiv(n_slots, 256)), dim3(256), 0, s, g, gx, fr, semis, spool, n_slots, slot_off, slots, slot_tmpl, valid_off, n_semis, out, out_base, pool, flags, binom, p,
+                       primer_cnt, primer_delta, (unsigned long long*)nullptr);
 }
 void launch_genome_bits(hipStream_t s, const uint8_t* g, uint64_t n, uint64_t nwords, unsigned long long* gc_bits, unsigned long long* n_bits,
                         uint32_t* gc_cnt, uint32_t* n_cnt, uint64_t* gc_pref, uint64_t* n_pref, void* temp, size_t temp_bytes) {

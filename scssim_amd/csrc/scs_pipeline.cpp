@@ -96,11 +96,9 @@ struct KernelTimer {         // HIP events on the ctx stream around the launches
 }  // namespace
 
 namespace { struct SinkPipe; }
-struct Mail {                // a batch of device scalars for one k_mail post (at most 12)
-    const void* src[12]; unsigned long long* acc[12]; int wd[12]; int dst[12]; int n = 0; unsigned clear = 0;
-    void add(const void* p, int width, int slot, bool clear_after = false, unsigned long long* also_add_to = nullptr) {
-        src[n] = p; wd[n] = width; dst[n] = slot; acc[n] = also_add_to; if (clear_after) clear |= 1u << n; ++n;
-    }
+struct Mail {                // a batch of device scalars for one k_mail post (at most 16)
+    const void* src[16]; int wd[16]; int dst[16]; int n = 0; unsigned clear = 0;
+    void add(const void* p, int width, int slot, bool clear_after = false) { src[n] = p; wd[n] = width; dst[n] = slot; if (clear_after) clear |= 1u << n; ++n; }
 };
 
 struct scs_ctx {
@@ -166,7 +164,7 @@ namespace {
 
 // ---- mailbox: device scalars -> pinned host words, no copy and no stream sync (k_mail)
 void mail_post(scs_ctx* c, const Mail& m, bool last) {                            // last: the post the host will wait for
-    launch_mail(c->stream, m.src, m.wd, m.dst, m.acc, m.n, m.clear, c->d_rb, last ? ++c->mail_seq : 0ull);
+    launch_mail(c->stream, m.src, m.wd, m.dst, m.n, m.clear, c->d_rb, last ? ++c->mail_seq : 0ull);
 }
 void mail_wait(scs_ctx* c) {                                                      // everything posted so far has landed in h_rb
     volatile uint64_t* flag = c->h_rb + MAIL_SEQ_SLOT;
@@ -310,9 +308,10 @@ void set_primers_launch(scs_ctx* c, bool only_frags, uint32_t call, uint32_t ns_
     launch_poisson(s, c->frags_view(), c->semis.view(), ns, p, c->budget_f.as<uint32_t>(), c->budget_s.as<uint32_t>(), c->dsums.as<unsigned long long>());
     exclusive_scan_u32_pair(s, c->budget_f.as<uint32_t>(), c->slot_off_f.as<uint32_t>(), nf, ns ? c->budget_s.as<uint32_t>() : nullptr, c->slot_off_s.as<uint32_t>(), ns, c->scan_tmp.p, c->scan_tmp.cap);
     c->reduce_dev(c->dsums.p, 2, 8);                                               // sharded: budgets of all shards leave the pool
-    Mail m; m.add(c->dsums.p, 8, 0, true); m.add(c->dsums.as<unsigned long long>() + 1, 8, 1, true); m.add(c->slot_off_f.as<uint32_t>() + nf, 4, 2);
+    Mail& m = c->pend;                                                             // together with the counts of the passes before (collect_post)
+    m.add(c->dsums.p, 8, 0, true); m.add(c->dsums.as<unsigned long long>() + 1, 8, 1, true); m.add(c->slot_off_f.as<uint32_t>() + nf, 4, 2);
     m.add(ns ? (const void*)(c->slot_off_s.as<uint32_t>() + ns) : nullptr, 4, 3);  // budgets beyond the real count are 0: the total sits at [ns_cap] too
-    mail_post(c, m, true);
+    mail_post(c, m, true); c->pend = Mail();
 }
 void set_primers_finish(scs_ctx* c) {                                              // after mail_wait (and collect_read: semis.n is current)
     const uint64_t* rb = c->h_rb;
@@ -353,18 +352,25 @@ void launch_pass(scs_ctx* c, bool from_frag, uint32_t pass, int rb_slot) {
     c->tm_attach.add_units(nt);
     exclusive_scan_u32(s, valid.as<uint32_t>(), valid_off.as<uint32_t>(), nt, c->scan_tmp.p, c->scan_tmp.cap);
     KernelTimer& tm = from_frag ? c->tm_errscan_f : c->tm_errscan;
+    // the stock update rides on k_errs when its grid covers the 65536 primer types with one entry per thread (a small
+    // grid would walk them serially); a sharded job all-reduces the decrements first
+    const bool ride = !c->sharded() && n_slots >= 65536u;
     tm.begin(s);
     const DevGenomeIdx gx{c->gx_gc_bits.as<unsigned long long>(), c->gx_n_bits.as<unsigned long long>(), c->gx_gc_pref.as<uint64_t>(), c->gx_n_pref.as<uint64_t>()};
     if (from_frag) launch_errs_frags(s, g, gx, fr, n_slots, slot_off, c->slots.as<uint32_t>(), c->slot_tmpl.as<uint32_t>(), valid_off.as<uint32_t>(),
-                                     out.view(), out.n, out.pool_view(), c->flags.as<uint32_t>(), c->d_binom.as<unsigned long long>(), p);
+                                     out.view(), out.n, out.pool_view(), c->flags.as<uint32_t>(), c->d_binom.as<unsigned long long>(), p,
+                                     ride ? c->primer_cnt.as<int64_t>() : nullptr, c->primer_delta.as<uint32_t>(), c->dsums.as<unsigned long long>() + DS_SEMIS_N);
     else launch_errs_semis(s, g, gx, fr, c->semis.view(), nt, c->semis.pool_view(), n_slots, slot_off, c->slots.as<uint32_t>(), c->slot_tmpl.as<uint32_t>(),
-                           valid_off.as<uint32_t>(), out.view(), out.n, out.pool_view(), c->flags.as<uint32_t>(), c->d_binom.as<unsigned long long>(), p);
+                           valid_off.as<uint32_t>(), out.view(), out.n, out.pool_view(), c->flags.as<uint32_t>(), c->d_binom.as<unsigned long long>(), p,
+                           ride ? c->primer_cnt.as<int64_t>() : nullptr, c->primer_delta.as<uint32_t>());
     tm.end(s);
-    c->reduce_dev(c->primer_delta.p, 65536, 4);                                    // sharded: stock decrements of all shards
-    launch_primer_update(s, c->primer_cnt.as<int64_t>(), c->primer_delta.as<uint32_t>());
+    if (!ride) {
+        c->reduce_dev(c->primer_delta.p, 65536, 4);                                // sharded: stock decrements of all shards
+        launch_primer_update(s, c->primer_cnt.as<int64_t>(), c->primer_delta.as<uint32_t>());
+    }
     {   // counts of this pass -> mailbox (read by the host at the group's sync): new amplicons, and for a semi pass the
         // fulls made from the semis of each fragment pass (segments)
-        c->pend.add(valid_off.as<uint32_t>() + nt, 4, rb_slot, false, from_frag ? c->dsums.as<unsigned long long>() + DS_SEMIS_N : nullptr);
+        c->pend.add(valid_off.as<uint32_t>() + nt, 4, rb_slot);
         if (!from_frag) {
             for (size_t b = 0; b < c->semi_block_end.size() && b < 8; ++b) c->pend.add(valid_off.as<uint32_t>() + std::min(c->semi_block_end[b], nt), 4, 16 + (int)b);
             c->pending_seg_cycle = (int)pass;
@@ -372,9 +378,9 @@ void launch_pass(scs_ctx* c, bool from_frag, uint32_t pass, int rb_slot) {
     }
 }
 // closing a group of passes: their counts go to the mailbox (and the new semi count into the device scalars) ...
-void collect_post(scs_ctx* c, bool last) {
+void collect_post(scs_ctx* c, bool post_now) {
     c->pend.add(c->dsums.as<unsigned long long>() + DS_SEMI_LEN, 8, 8);
-    mail_post(c, c->pend, last); c->pend = Mail();
+    if (post_now) { mail_post(c, c->pend, true); c->pend = Mail(); }               // else: rides on the next setPrimers mail
 }
 // ... and are taken over by the host after the next mail_wait: counts of new amplicons, total length of the semis
 void collect_read(scs_ctx* c, int rb_fulls, int rb_semis) {
