@@ -907,27 +907,39 @@ __global__ void __launch_bounds__(256) k_poisson_semis(DevAmps semis, uint32_t n
     }
     block_add_u64(ks, &sums[1]);
 }
-// fragments: lambda in the hundreds -> one wave per fragment; 64 logs at a time, accumulated in draw order
-__global__ void __launch_bounds__(64) k_poisson_frags(DevFrags fr, PoissonParams p, uint32_t* __restrict__ budget_f, unsigned long long* __restrict__ sums) {
-    const uint32_t t = blockIdx.x; const int lane = threadIdx.x;
+// fragments: lambda in the hundreds to thousands -> one 256-thread workgroup per fragment.  A round = 1024 draws: every
+// thread turns one Philox block into four logs (LDS, draw order); then the first wave adds them to log1 IN DRAW ORDER
+// (the rounding of the serial loop), eight at a time with one exit test per eight.
+__global__ void __launch_bounds__(256) k_poisson_frags(DevFrags fr, PoissonParams p, uint32_t* __restrict__ budget_f, unsigned long long* __restrict__ sums) {
+    __shared__ double s_lg[1024];
+    __shared__ int s_more;
+    const uint32_t t = blockIdx.x; const int tid = threadIdx.x;
     const double log2 = -poisson_lambda(p, fr.len[t]);
     const uint64_t tuid = fr.gidx_base + t;
     const uint32_t aux = 0u | (p.call << 1);
-    long x = -1; double log1 = 0; bool more = true;
-    for (uint32_t c = 0; more; ++c) {
-        const uint32_t n = c * WAVE + lane;
-        const U4 d = draw4(p.key, ST_POISSON, aux, tuid, n >> 2);
-        const double lg = det_log((double)d.w[n & 3] / 4294967296.0);
-        const int lo = __double2loint(lg), hi = __double2hiint(lg);
+    long x = -1; double log1 = 0;
+    for (uint32_t c = 0;; ++c) {
+        const U4 d = draw4(p.key, ST_POISSON, aux, tuid, c * 256u + (uint32_t)tid);   // draws 1024c + 4 tid .. + 3
 #pragma unroll
-        for (int l = 0; l < WAVE; ++l) {                       // log1 += log(u) in draw order: same rounding as the serial loop
-            if (more) {                                        // wave-uniform
-                log1 += __hiloint2double(__builtin_amdgcn_readlane(hi, l), __builtin_amdgcn_readlane(lo, l)); ++x;
-                if (!(log1 >= log2)) more = false;
+        for (int j = 0; j < 4; ++j) s_lg[4 * tid + j] = det_log((double)d.w[j] / 4294967296.0);
+        __syncthreads();
+        if (tid < 64) {                                                            // uniform over the wave: every lane runs the same serial sum
+            bool more = true;
+            for (int i = 0; i < 1024 && more; i += 8) {
+                double pre[8]; double acc = log1;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { acc += s_lg[i + k]; pre[k] = acc; }
+                int stop = 8;
+#pragma unroll
+                for (int k = 7; k >= 0; --k) if (!(pre[k] >= log2)) stop = k;     // first draw that ends the loop
+                if (stop < 8) { x += stop + 1; more = false; } else { x += 8; log1 = acc; }
             }
+            if (tid == 0) s_more = more ? 1 : 0;
         }
+        __syncthreads();
+        if (!s_more) break;
     }
-    if (lane == 0) { budget_f[t] = (uint32_t)(int)x; atomicAdd(&sums[0], (unsigned long long)x); }
+    if (tid == 0) { budget_f[t] = (uint32_t)(int)x; atomicAdd(&sums[0], (unsigned long long)x); }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1185,7 +1197,7 @@ void launch_attach_frags(hipStream_t s, const uint8_t* g, DevFrags fr, const uin
 }
 void launch_poisson(hipStream_t s, DevFrags fr, DevAmps semis, uint32_t n_semis, PoissonParams p, uint32_t* budget_f, uint32_t* budget_s,
                     unsigned long long* sums) {
-    if (fr.n) hipLaunchKernelGGL(k_poisson_frags, dim3(fr.n), dim3(64), 0, s, fr, p, budget_f, sums);
+    if (fr.n) hipLaunchKernelGGL(k_poisson_frags, dim3(fr.n), dim3(256), 0, s, fr, p, budget_f, sums);
     if (n_semis) hipLaunchKernelGGL(k_poisson_semis, dim3(cdiv((uint64_t)n_semis + 1, 256)), dim3(256), 0, s, semis, n_semis, p, budget_s, sums);
 }
 void launch_alloc(hipStream_t s, double* w, uint32_t ac, unsigned long long reads, RngKey key, int paired, AllocState* st, double* part, double* tp,
