@@ -32,19 +32,59 @@ struct ScsError : std::runtime_error { int code; ScsError(int c, const std::stri
 
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
-// growable device buffer
+// growable device buffer.  Small buffers are plain hipMalloc blocks.  A buffer that grows past 32 MB moves (once) into
+// a reserved virtual address range and from then on grows IN PLACE by mapping more physical memory behind it
+// (hipMemAddressReserve / hipMemCreate / hipMemMap): no reallocate-copy-free cycles while the amplicon arrays of a
+// whole-genome job grow cycle by cycle, no transient 2.5x footprint -- and fresh hipMalloc memory costs about 20 ms per
+// GB on its first touch on this platform (measured), mapped chunks do not.
 struct DevBuf {
-    void* p = nullptr; size_t cap = 0;
+    void* p = nullptr; size_t cap = 0;       // cap: usable (mapped) bytes
+    size_t va = 0;                           // reserved address range in bytes (0: plain hipMalloc block)
+    // equal-sized chunks: on ROCm 7.2 hipMemSetAccess rejects a chunk mapped right behind one of a different size (probed)
+    static constexpr size_t kVirtualFrom = 64ull << 20, kRange = 384ull << 30, kGran = 128ull << 20;
+    static bool& virtual_ok() { static bool ok = getenv("SCS_NO_VMM") == nullptr; return ok; }
+    void map_more(size_t ncap) {             // map [cap, ncap) of the reserved range, kGran at a time
+        int dev = 0; HIP_OK(hipGetDevice(&dev));
+        hipMemAllocationProp prop = {}; prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = dev;
+        hipMemAccessDesc acc = {}; acc.location.type = hipMemLocationTypeDevice; acc.location.id = dev; acc.flags = hipMemAccessFlagsProtReadWrite;
+        while (cap < ncap) {
+            hipMemGenericAllocationHandle_t h;
+            HIP_OK(hipMemCreate(&h, kGran, &prop, 0));
+            hipError_t e = hipMemMap((char*)p + cap, kGran, 0, h, 0);
+            if (e == hipSuccess) { e = hipMemSetAccess((char*)p + cap, kGran, &acc, 1); if (e != hipSuccess) (void)hipMemUnmap((char*)p + cap, kGran); }
+            (void)hipMemRelease(h);          // the mapping keeps the memory alive
+            if (e != hipSuccess) throw ScsError(SCS_EDEVICE, std::string("device memory map: ") + hipGetErrorString(e));
+            cap += kGran;
+        }
+    }
     void reserve(size_t bytes, hipStream_t s, size_t keep_bytes = 0) {
         if (bytes <= cap) return;
         size_t ncap = std::max(bytes, cap + cap / 2);
+        if (va) { map_more(std::min((ncap + kGran - 1) / kGran * kGran, va)); if (bytes > cap) throw ScsError(SCS_EOVERFLOW, "device buffer larger than its address range"); return; }
+        if (ncap > kVirtualFrom && virtual_ok()) {
+            void* base = nullptr;
+            if (hipMemAddressReserve(&base, kRange, kGran, nullptr, 0) == hipSuccess) {
+                void* old = p; const size_t old_cap = cap;
+                p = base; cap = 0; va = kRange;
+                try { map_more((ncap + kGran - 1) / kGran * kGran); }
+                catch (...) { (void)hipMemAddressFree(base, kRange); p = old; cap = old_cap; va = 0; throw; }
+                if (old && keep_bytes) { HIP_OK(hipMemcpyAsync(p, old, keep_bytes, hipMemcpyDeviceToDevice, s)); HIP_OK(hipStreamSynchronize(s)); }
+                if (old) HIP_OK(hipFree(old));
+                return;
+            }
+            (void)hipGetLastError(); virtual_ok() = false;                        // no virtual memory management here: classic path from now on
+        }
         void* np = nullptr;
         HIP_OK(hipMalloc(&np, ncap));
         if (p && keep_bytes) { HIP_OK(hipMemcpyAsync(np, p, keep_bytes, hipMemcpyDeviceToDevice, s)); HIP_OK(hipStreamSynchronize(s)); }
         if (p) HIP_OK(hipFree(p));
         p = np; cap = ncap;
     }
-    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    void release() {
+        if (p && va) { for (size_t o = 0; o < cap; o += kGran) (void)hipMemUnmap((char*)p + o, kGran); (void)hipMemAddressFree(p, va); }
+        else if (p) (void)hipFree(p);
+        p = nullptr; cap = 0; va = 0;
+    }
     template <class T> T* as() const { return (T*)p; }
 };
 
