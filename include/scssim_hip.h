@@ -170,6 +170,10 @@ void        scs_profile_close(void* handle);
  * names joined by '\n'; checksum = FNV-1a over the upper-cased sequence bytes of all records in order. */
 int         scs_fasta_probe(const char* fasta_path, int* n_records, uint64_t* total_bases, uint64_t* checksum,
                             char* names_buf, size_t names_len, char* errbuf, size_t errlen);
+/* Host-only: leave <fasta_path>.fai beside the file if there is none, exactly as scs_load_genome_fasta does (the
+ * reference indexes its input through fastahack, lib/fastahack/Fasta.cpp:241-249: name, length, offset, bases per
+ * line, bytes per line). */
+int         scs_fasta_write_index(const char* fasta_path, char* errbuf, size_t errlen);
 
 /* Per-kernel timing (HIP events recorded on the ctx stream around every launch, accumulated over the
  * last scs_amplify / scs_yield_reads call): name, launches, total milliseconds, and the units the

@@ -80,8 +80,18 @@ def load_library():
     L.scs_profile_scalars.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
     L.scs_profile_close.argtypes = [C.c_void_p]
     L.scs_fasta_probe.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]
+    L.scs_fasta_write_index.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t]
     _lib = L
     return L
+
+
+def fasta_write_index(path):
+    """Host-only: leave <path>.fai beside the FASTA if there is none, as loading the genome does (fastahack index)."""
+    L = load_library()
+    err = C.create_string_buffer(512)
+    rc = L.scs_fasta_write_index(os.fsencode(path), err, 512)
+    if rc:
+        raise ScsError(rc, err.value.decode())
 
 
 def fasta_probe(path):

@@ -773,7 +773,7 @@ int scs_read_length(const scs_ctx* c) { return c && c->have_profile ? c->prof.re
 int scs_load_genome_fasta(scs_ctx* c, const char* path) {
     return guarded(c, [&] {
         if (!path) throw ScsError(SCS_EINVAL, "null path");
-        load_fasta(path, c->recs); stage_genome(c);
+        load_fasta(path, c->recs, true); stage_genome(c);
         if (c->cfg.verbose) fprintf(stderr, "\nReference sequence was loaded from file %s\n", path);
     });
 }
@@ -916,6 +916,13 @@ int scs_fasta_probe(const char* path, int* n_records, uint64_t* total_bases, uin
     }
     if (n_records) *n_records = (int)recs.size(); if (total_bases) *total_bases = tot; if (checksum) *checksum = h;
     if (names_buf && names_len) { strncpy(names_buf, names.c_str(), names_len - 1); names_buf[names_len - 1] = 0; }
+    return SCS_OK;
+}
+int scs_fasta_write_index(const char* path, char* errbuf, size_t errlen) {
+    if (!path) return SCS_EINVAL;
+    std::vector<FastaRecord> recs;
+    try { load_fasta(path, recs, true); }
+    catch (const std::exception& e) { if (errbuf && errlen) { strncpy(errbuf, e.what(), errlen - 1); errbuf[errlen - 1] = 0; } return SCS_EIO; }
     return SCS_OK;
 }
 int scs_profile_open(const char* path, int paired, int isize, void** handle, char* errbuf, size_t errlen) {

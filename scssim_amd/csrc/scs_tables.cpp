@@ -277,7 +277,7 @@ void encode_record(const char* name, const char* seq, uint64_t len, FastaRecord&
 #include <sys/stat.h>
 #include <unistd.h>
 namespace scs {
-void load_fasta(const std::string& path_in, std::vector<FastaRecord>& out) {
+void load_fasta(const std::string& path_in, std::vector<FastaRecord>& out, bool make_index) {
     std::string path = path_in;
     if (path.empty()) throw std::runtime_error("reference sequence file not specified!");
     if (path.size() > 3 && path.compare(path.size() - 3, 3, ".gz") == 0) {      // Genome.cpp:183-187
@@ -313,6 +313,16 @@ void load_fasta(const std::string& path_in, std::vector<FastaRecord>& out) {
         pos = eol + 1;
     }
     out.resize(spans.size());
+    // the reference indexes the FASTA through fastahack and leaves <file>.fai beside it when there is none
+    // (lib/fastahack/Fasta.cpp:241-249; entry = first word of the name, length, offset, bases per line, bytes per line)
+    FILE* fai = nullptr;
+    if (make_index) {
+        const std::string fname = path + ".fai"; struct stat fst;
+        if (stat(fname.c_str(), &fst) != 0) {
+            fprintf(stderr, "index file %s not found, generating...\n", fname.c_str());
+            if (!(fai = fopen(fname.c_str(), "w"))) fprintf(stderr, "could not open index file %s for writing! (continuing without it)\n", fname.c_str());
+        }
+    }
     for (size_t r = 0; r < spans.size(); ++r) {
         const Span& sp = spans[r];
         const char* nl = (const char*)memchr(base + sp.hdr, '\n', sp.end - sp.hdr);
@@ -330,7 +340,17 @@ void load_fasta(const std::string& path_in, std::vector<FastaRecord>& out) {
             pos = eol + 1;
         }
         dst.resize(w);
+        if (fai) {
+            size_t fl = sp.body; while (fl < sp.end && base[fl] == ';') { const char* e = (const char*)memchr(base + fl, '\n', sp.end - fl); fl = e ? (size_t)(e - base) + 1 : sp.end; }
+            const char* e = fl < sp.end ? (const char*)memchr(base + fl, '\n', sp.end - fl) : nullptr;
+            const size_t line_len = fl < sp.end ? (e ? (size_t)(e - base) + 1 - fl : sp.end - fl) : 0;
+            size_t line_blen = e ? line_len - 1 : line_len; if (line_blen && base[fl + line_blen - 1] == '\r') --line_blen;
+            const std::string full(base + sp.hdr + 1, base + hend);
+            const std::string first = full.substr(0, full.find(' '));
+            fprintf(fai, "%s\t%zu\t%zu\t%zu\t%zu\n", first.c_str(), w, fl, line_blen, line_len);
+        }
     }
+    if (fai) fclose(fai);
     munmap((void*)base, size); close(fd);
     if (out.empty()) throw std::runtime_error("ERROR: reference sequence cannot be empty!");
 }

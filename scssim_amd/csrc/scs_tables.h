@@ -60,7 +60,8 @@ void load_profile(const std::string& path, bool paired, int isize, ProfileTables
 // ASCII -> base-code conversion (0..3 ACGT, 4 other; upper-casing of Genome::getSubSequence, Genome.cpp:272-278)
 // runs on the device after the upload (k_encode_bases).
 struct FastaRecord { std::string name; std::vector<uint8_t> code; };
-void load_fasta(const std::string& path, std::vector<FastaRecord>& out);
+// make_index: also leave <path>.fai beside the file when there is none, as the reference does (fastahack, Fasta.cpp:241-249)
+void load_fasta(const std::string& path, std::vector<FastaRecord>& out, bool make_index = false);
 void encode_record(const char* name, const char* seq, uint64_t len, FastaRecord& out);
 
 }  // namespace scs

@@ -4,6 +4,7 @@
 Runs only in the build container (needs /root/reference and `make -C oracle ref`).
 For each case it writes
     <case>.simu.fa.gz       input FASTA (simuvars format)  -- data
+    <case>.simu.fa.fai      the index the reference writes beside its input -- data
     <case>.ref_1.fq.gz ...  FASTQ written by oracle/_ref/scssim_ref at -t 1 under
                             oracle/_ref/libseedshim.so (SCS_FIXED_TIME pinned) -- data
 and copies the profile *data files* the reference ships (testData/models) as
@@ -70,6 +71,8 @@ def main():
                    "-t", "1", "-o", os.path.join(td, "ref")] + c["args"]
             subprocess.check_call(cmd, env=env, stderr=subprocess.DEVNULL)
             gz_write(os.path.join(HERE, c["name"] + ".simu.fa.gz"), open(fa, "rb").read())
+            # the FASTA index the reference leaves beside its input (fastahack, lib/fastahack/Fasta.cpp:241-249) -- data
+            shutil.copyfile(fa + ".fai", os.path.join(HERE, c["name"] + ".simu.fa.fai"))
             entry = dict(profile=c["profile"], args=c["args"], fixed_time=c["time"], files={})
             for suffix in ("_1.fq", "_2.fq", ".fq"):
                 src = os.path.join(td, "ref" + suffix)

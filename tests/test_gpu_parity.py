@@ -149,12 +149,17 @@ def test_full_pipeline_fastq_bit_exact(case, model, oargs, layout, cov, isize, e
 
 def test_cli_drop_in(oracle_bin, models, golden_inputs, tmp_path):
     """`scssim genreads` (the reference's CLI surface) writes the same files as the oracle CLI."""
+    import shutil
     exe = os.path.join(ROOT, "scssim_amd", "bin", "scssim")
     out = str(tmp_path / "cli")
-    r = subprocess.run([exe, "genreads", "-i", golden_inputs["g1_hiseq2500_pe"], "-m", models["Illumina_HiSeq2500"], "-c", "2",
+    fa = str(tmp_path / "input.fa")
+    shutil.copyfile(golden_inputs["g1_hiseq2500_pe"], fa)
+    r = subprocess.run([exe, "genreads", "-i", fa, "-m", models["Illumina_HiSeq2500"], "-c", "2",
                         "-o", out, "--seed", "99"], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert "MALBAC amplification..." in r.stderr and "Reads generation done!" in r.stderr
+    # the reference leaves a fastahack index beside its input (golden: written by the compiled reference)
+    assert open(fa + ".fai").read() == open(os.path.join(ROOT, "tests", "golden", "g1_hiseq2500_pe.simu.fa.fai")).read()
     prefix = str(tmp_path / "orc")
     _oracle_run(oracle_bin, golden_inputs["g1_hiseq2500_pe"], models["Illumina_HiSeq2500"], prefix, ["-c", "2"], 99)
     assert open(out + "_1.fq", "rb").read() == open(prefix + "_1.fq", "rb").read()

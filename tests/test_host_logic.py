@@ -186,3 +186,19 @@ def test_compact_quality_rows_equal_the_full_row_search(model, models):
     assert np.array_equal(got[resolved], want[resolved])
     # the one-draw indel test: x < t_insert -> insertion, else x < t_indel -> deletion, deletion threshold rescaled
     assert P.t_indel == P.t_insert + (((1 << 32) - P.t_insert) * P.t_delete >> 32)
+
+
+@pytest.mark.parametrize("case", ["g1_hiseq2500_pe", "g2_xten_pe_nblock", "g3_hiseq2000_se", "g4_gaiix_pe_lowprimers"])
+def test_fasta_index_matches_the_reference(case, golden_inputs, tmp_path):
+    """Loading a genome leaves <fasta>.fai beside it when there is none, like the reference (fastahack).  Golden = the index
+    the compiled reference wrote for the same file (tests/golden/<case>.simu.fa.fai)."""
+    import shutil
+    fa = tmp_path / "simu.fa"
+    shutil.copyfile(golden_inputs[case], fa)
+    scssim_amd.fasta_write_index(str(fa))
+    want = open(os.path.join(ROOT, "tests", "golden", case + ".simu.fa.fai")).read()
+    assert open(str(fa) + ".fai").read() == want
+    # an existing index is left alone
+    open(str(fa) + ".fai", "w").write("kept\n")
+    scssim_amd.fasta_write_index(str(fa))
+    assert open(str(fa) + ".fai").read() == "kept\n"
