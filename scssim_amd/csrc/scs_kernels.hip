@@ -886,9 +886,9 @@ __device__ __forceinline__ double poisson_lambda(const PoissonParams& p, uint32_
 }
 // semis: lambda ~ 6 -> one thread per semi amplicon
 // n_cap: the host's upper bound of the semi count (grid size); the count itself is read from the device scalars
-__global__ void __launch_bounds__(256) k_poisson_semis(DevAmps semis, uint32_t n_cap, PoissonParams p, uint32_t* __restrict__ budget_s,
-                                                       unsigned long long* __restrict__ sums) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void poisson_semis_block(uint32_t block, DevAmps semis, uint32_t n_cap, const PoissonParams& p, uint32_t* __restrict__ budget_s,
+                                                    unsigned long long* __restrict__ sums) {
+    const uint32_t i = block * blockDim.x + threadIdx.x;
     const uint32_t n_semis = (uint32_t)p.dev[DS_SEMIS_N];
     unsigned long long ks = 0;
     if (i >= n_semis && i <= n_cap) budget_s[i] = 0;                               // the scan runs over n_cap + 1 entries
@@ -910,10 +910,10 @@ __global__ void __launch_bounds__(256) k_poisson_semis(DevAmps semis, uint32_t n
 // fragments: lambda in the hundreds to thousands -> one 256-thread workgroup per fragment.  A round = 1024 draws: every
 // thread turns one Philox block into four logs (LDS, draw order); then the first wave adds them to log1 IN DRAW ORDER
 // (the rounding of the serial loop), eight at a time with one exit test per eight.
-__global__ void __launch_bounds__(256) k_poisson_frags(DevFrags fr, PoissonParams p, uint32_t* __restrict__ budget_f, unsigned long long* __restrict__ sums) {
+__device__ __forceinline__ void poisson_frag_block(uint32_t t, DevFrags fr, const PoissonParams& p, uint32_t* __restrict__ budget_f, unsigned long long* __restrict__ sums) {
     __shared__ double s_lg[1024];
     __shared__ int s_more;
-    const uint32_t t = blockIdx.x; const int tid = threadIdx.x;
+    const int tid = threadIdx.x;
     const double log2 = -poisson_lambda(p, fr.len[t]);
     const uint64_t tuid = fr.gidx_base + t;
     const uint32_t aux = 0u | (p.call << 1);
@@ -940,6 +940,13 @@ __global__ void __launch_bounds__(256) k_poisson_frags(DevFrags fr, PoissonParam
         if (!s_more) break;
     }
     if (tid == 0) { budget_f[t] = (uint32_t)(int)x; atomicAdd(&sums[0], (unsigned long long)x); }
+}
+
+// one launch for both template kinds: workgroups [0, nf) take a fragment each, the rest 256 semi amplicons each
+__global__ void __launch_bounds__(256) k_poisson(DevFrags fr, DevAmps semis, uint32_t n_cap, PoissonParams p, uint32_t* __restrict__ budget_f,
+                                                 uint32_t* __restrict__ budget_s, unsigned long long* __restrict__ sums) {
+    if (blockIdx.x < fr.n) poisson_frag_block(blockIdx.x, fr, p, budget_f, sums);
+    else poisson_semis_block(blockIdx.x - fr.n, semis, n_cap, p, budget_s, sums);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1197,8 +1204,8 @@ void launch_attach_frags(hipStream_t s, const uint8_t* g, DevFrags fr, const uin
 }
 void launch_poisson(hipStream_t s, DevFrags fr, DevAmps semis, uint32_t n_semis, PoissonParams p, uint32_t* budget_f, uint32_t* budget_s,
                     unsigned long long* sums) {
-    if (fr.n) hipLaunchKernelGGL(k_poisson_frags, dim3(fr.n), dim3(256), 0, s, fr, p, budget_f, sums);
-    if (n_semis) hipLaunchKernelGGL(k_poisson_semis, dim3(cdiv((uint64_t)n_semis + 1, 256)), dim3(256), 0, s, semis, n_semis, p, budget_s, sums);
+    const uint32_t semi_blocks = n_semis ? cdiv((uint64_t)n_semis + 1, 256) : 0u;
+    if (fr.n + semi_blocks) hipLaunchKernelGGL(k_poisson, dim3(fr.n + semi_blocks), dim3(256), 0, s, fr, semis, n_semis, p, budget_f, budget_s, sums);
 }
 void launch_alloc(hipStream_t s, double* w, uint32_t ac, unsigned long long reads, RngKey key, int paired, AllocState* st, double* part, double* tp,
                   double* probs, uint32_t* quota, uint32_t* rn, uint32_t* odd_before, uint32_t* pair_cnt_off, void* temp, size_t temp_bytes) {
