@@ -32,7 +32,7 @@ struct ScsError : std::runtime_error { int code; ScsError(int c, const std::stri
 
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
-// growable device buffer.  Small buffers are plain hipMalloc blocks.  A buffer that grows past 32 MB moves (once) into
+// growable device buffer.  Small buffers are plain hipMalloc blocks.  A buffer that grows past 64 MB moves (once) into
 // a reserved virtual address range and from then on grows IN PLACE by mapping more physical memory behind it
 // (hipMemAddressReserve / hipMemCreate / hipMemMap): no reallocate-copy-free cycles while the amplicon arrays of a
 // whole-genome job grow cycle by cycle, no transient 2.5x footprint -- and fresh hipMalloc memory costs about 20 ms per
@@ -41,7 +41,11 @@ struct DevBuf {
     void* p = nullptr; size_t cap = 0;       // cap: usable (mapped) bytes
     size_t va = 0;                           // reserved address range in bytes (0: plain hipMalloc block)
     // equal-sized chunks: on ROCm 7.2 hipMemSetAccess rejects a chunk mapped right behind one of a different size (probed)
-    static constexpr size_t kVirtualFrom = 64ull << 20, kRange = 384ull << 30, kGran = 128ull << 20;
+    static constexpr size_t kRange = 384ull << 30, kGran = 128ull << 20;
+    static size_t virtual_from() {           // SCS_VMM_FROM_MB: tests lower it so that small jobs run on mapped buffers too
+        static const size_t v = getenv("SCS_VMM_FROM_MB") ? (size_t)atol(getenv("SCS_VMM_FROM_MB")) << 20 : 64ull << 20;
+        return v;
+    }
     static bool& virtual_ok() { static bool ok = getenv("SCS_NO_VMM") == nullptr; return ok; }
     void map_more(size_t ncap) {             // map [cap, ncap) of the reserved range, kGran at a time
         int dev = 0; HIP_OK(hipGetDevice(&dev));
@@ -61,7 +65,7 @@ struct DevBuf {
         if (bytes <= cap) return;
         size_t ncap = std::max(bytes, cap + cap / 2);
         if (va) { map_more(std::min((ncap + kGran - 1) / kGran * kGran, va)); if (bytes > cap) throw ScsError(SCS_EOVERFLOW, "device buffer larger than its address range"); return; }
-        if (ncap > kVirtualFrom && virtual_ok()) {
+        if (ncap > virtual_from() && virtual_ok()) {
             void* base = nullptr;
             if (hipMemAddressReserve(&base, kRange, kGran, nullptr, 0) == hipSuccess) {
                 void* old = p; const size_t old_cap = cap;

@@ -359,3 +359,17 @@ def test_replayed_indel_reads_match_oracle(models, tmp_path):
     r = subprocess.run(["python", "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider"] + sel, cwd=ROOT, env=env,
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:]
+
+
+def test_mapped_buffers_parity(models, tmp_path):
+    """Device buffers above 64 MB live in a reserved address range and grow by mapping more memory behind them (HIP virtual
+    memory management).  The parity cases are far smaller, so they run once more in a child process with the threshold at
+    0 MB: every growable buffer is a mapped one."""
+    if os.environ.get("SCS_VMM_FROM_MB"):
+        pytest.skip("already inside the mapped-buffer run")
+    env = dict(os.environ, SCS_VMM_FROM_MB="0")
+    sel = ["tests/test_gpu_parity.py::test_full_pipeline_fastq_bit_exact", "tests/test_gpu_parity.py::test_medium_genome_bit_exact",
+           "tests/test_gpu_parity.py::test_degenerate_inputs_match_oracle"]
+    r = subprocess.run(["python", "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider"] + sel, cwd=ROOT, env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:]
