@@ -444,13 +444,72 @@ __device__ __noinline__ uint32_t call_global(const uint32_t* __restrict__ subs, 
     return k | (qv << 8);
 }
 
+// phase 1 of Profile::predict: the indel tests of every input base (getIndelSeq, Profile.cpp:1552-1570 / loop 1606-1630).
+// put(i, v) stores event i (16 bits).  Returns n' (0 = the read does not fit its slot), the event count and the replay flag.
+struct IndelPass { int n_out; int nev; bool replay; };
+template <class Put>
+__device__ __forceinline__ IndelPass indel_pass(const DevTables& tb, RngKey key, uint32_t aux, uint64_t uid, uint32_t force_replay, uint32_t slot,
+                                                uint32_t* __restrict__ flags, Put put) {
+    const int n = tb.L; const uint32_t t_insert = tb.t_insert, t_indel = tb.t_indel;
+    int nev = 0, delta = 0; bool replay = false;
+    Xoshiro xa; xa.seed(draw4(key, ST_READ, aux, uid, 0));                         // stream A: the indel tests, in visiting order
+    for (int ji = 0; ji < n;) {
+        const uint32_t w0 = xa.next();
+        if (w0 < t_insert) {                                                       // p <= insertRate
+            const uint32_t k = rand_indx_thr(tb.ins_t, tb.ins_d, (uint32_t)tb.n_ins, draw4(key, ST_INDEL_LEN, aux, uid, (uint32_t)ji).w[0]);
+            if (k > 0) {
+                if (nev < EV_MAX && ji < 1024 && k < 32u) put(nev, ev_pack((uint32_t)ji, 0u, k)); else replay = true;
+                ++nev; delta += (int)k;
+            }
+            ++ji;
+        } else if (w0 < t_indel) {                                                 // [REMAP] the same draw: p < delRate/(1-insertRate) rescaled to the draws left
+            const uint32_t k = rand_indx_thr(tb.del_t, tb.del_d, (uint32_t)tb.n_del, draw4(key, ST_INDEL_LEN, aux, uid, (uint32_t)ji).w[0]);
+            if (k > 0) {
+                const int kk = (int)k < n - ji ? (int)k : n - ji;
+                if (nev < EV_MAX && ji < 1024 && kk < 32) put(nev, ev_pack((uint32_t)ji, 1u, (uint32_t)kk)); else replay = true;
+                ++nev; delta -= kk; ji += kk;
+            }
+            else ++ji;
+        } else ++ji;
+    }
+    if (force_replay && nev > 0) replay = true;
+    if (n + delta < 50) { nev = 0; delta = 0; replay = false; }                    // Profile.cpp:1623-1630: drop all indels
+    int n_out = n + delta;
+    if (n_out > (int)slot) { atomicOr(flags, (uint32_t)FLAG_READSLOT); n_out = 0; nev = 0; replay = false; }
+    if (replay) nev = 0;                                                           // phase 2 draws the tests again
+    return IndelPass{n_out, nev, replay};
+}
+
+// K5a  the indel pass of every read of a batch, ahead of the base pass: n' fixes the size of the FASTQ record, so the
+//      record offsets (prefix sums) are known before k_reads runs.  Thread per read; events (8 x 16 bits) and
+//      header {n' | events << 16 | replay << 24 | live << 25} go to global memory.
+__global__ void __launch_bounds__(256) k_indels(const PairRec* __restrict__ pairs, uint32_t np, int paired, const DevTables tb, RngKey key, uint32_t slot,
+                                                uint32_t force_replay, uint32_t* __restrict__ ev_hdr, uint4* __restrict__ ev_dat,
+                                                uint32_t* __restrict__ sizes1, uint32_t* __restrict__ sizes2, uint32_t* __restrict__ flags) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t nreads = paired ? 2 * np : np;
+    if (r >= nreads) return;
+    const uint32_t pi = paired ? r >> 1 : r, rd = paired ? (r & 1u) : 0u;
+    const uint64_t uid = pairs[pi].uid; const uint32_t att = pairs[pi].att, isz = pairs[pi].isz, amp = pairs[pi].amp;
+    uint32_t* sz = rd ? sizes2 : sizes1;
+    if (isz == 0) { ev_hdr[r] = 0; sz[pi] = 0; return; }                            // hole: the insert-size loop gave up (Amplicon.cpp:484-489)
+    unsigned long long e_lo = 0, e_hi = 0;
+    const IndelPass ip = indel_pass(tb, key, rd | (att << 1), uid, force_replay, slot, flags, [&](int i, uint32_t v) {
+        if (i < 4) e_lo |= (unsigned long long)v << (16 * i); else e_hi |= (unsigned long long)v << (16 * (i - 4));
+    });
+    ev_hdr[r] = (uint32_t)ip.n_out | ((uint32_t)ip.nev << 16) | (ip.replay ? 1u << 24 : 0u) | (1u << 25);
+    ev_dat[r] = make_uint4((uint32_t)e_lo, (uint32_t)(e_lo >> 32), (uint32_t)e_hi, (uint32_t)(e_hi >> 32));
+    // "@<ampIdx>#<fragCount>[/1|/2]\n" + seq + "\n+\n" + qual + "\n"   (Amplicon.cpp:459-466,497-504)
+    sz[pi] = ip.n_out == 0 ? 0u : 1u + dec_digits(amp) + 1u + dec_digits(att + 1) + (paired ? 2u : 0u) + 1u + 2u * (uint32_t)ip.n_out + 4u;
+}
+
 template <bool FROM_PAIRS, bool QBIG>
 __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, DevErrPool spool, DevErrPool fpool, const PairRec* __restrict__ pairs,
                                               uint32_t np, int paired, const uint8_t* __restrict__ windows, const uint64_t* __restrict__ uids,
                                               const uint32_t* __restrict__ atts, const uint8_t* __restrict__ is_read1, uint32_t n_explicit,
                                               const DevTables tb, RngKey key, uint32_t slot, uint32_t n_slots_cap, uint32_t force_replay,
-                                              char* __restrict__ slot_b, char* __restrict__ slot_q, uint32_t* __restrict__ lens,
-                                              uint32_t* __restrict__ sizes1, uint32_t* __restrict__ sizes2, uint32_t* __restrict__ flags) {
+                                              const uint32_t* __restrict__ ev_hdr, const uint4* __restrict__ ev_dat,
+                                              char* __restrict__ slot_b, char* __restrict__ slot_q, uint32_t* __restrict__ lens, uint32_t* __restrict__ flags) {
     typedef RingGeo<QBIG> Geo;
     typedef RingBin<QBIG> Bin;
     constexpr int SLOTS = Geo::SLOTS, GROUP = Geo::GROUP, QROW = Geo::QROW, EPB = 64 + 4 * QROW;   // EPB: 16-byte entries per bin image
@@ -479,10 +538,9 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
         r = blockIdx.x * RB + tid; valid = r < n_explicit; rd = 0;
         if (valid) { uid = uids[r]; att = atts[r]; rd = is_read1[r] ? 0u : 1u; }
     }
-    uint32_t* sz = FROM_PAIRS ? (rd ? sizes2 : sizes1) : nullptr;
     if (valid && r >= n_slots_cap) { atomicOr(flags, (uint32_t)FLAG_INTERNAL); valid = false; }   // never write outside the slot buffers
     bool live = valid && (!FROM_PAIRS || pr.isz != 0);
-    if (FROM_PAIRS && valid && !live) { lens[r] = 0; sz[pi] = 0; }
+    if (FROM_PAIRS && valid && !live) lens[r] = 0;
 
     // ---- stage the windows (coalesced), then patch the amplification errors
     LdsU8* my_win = (LdsU8*)(s_win + (size_t)tid * WS);
@@ -553,38 +611,22 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
         }
     }
 
-    // ---- phase 1: indel events per input base (getIndelSeq, Profile.cpp:1552-1570 / loop 1606-1630)
+    // ---- phase 1: the indel events of my read: computed by k_indels ahead of this launch (pair mode), or here
     const uint32_t aux = rd | (att << 1);
     LdsU16* my_ev = (LdsU16*)(s_ev + tid * EV_MAX);
     LdsU32* my_xa = (LdsU32*)(s_ev + tid * EV_MAX);                                // the same 16 bytes, as a stream-A state (replayed reads)
-    int nev = 0, delta = 0, n_out = 0; bool replay = false;
+    int nev = 0, n_out = 0; bool replay = false;
     if (live) {
-        Xoshiro xa; xa.seed(draw4(key, ST_READ, aux, uid, 0));                     // stream A: the indel tests, in visiting order
-        for (int ji = 0; ji < n;) {
-            const uint32_t w0 = xa.next();
-            if (w0 < t_insert) {                                                   // p <= insertRate
-                const uint32_t k = rand_indx_thr(tb.ins_t, tb.ins_d, (uint32_t)tb.n_ins, draw4(key, ST_INDEL_LEN, aux, uid, (uint32_t)ji).w[0]);
-                if (k > 0) {
-                    if (nev < EV_MAX && ji < 1024 && k < 32u) my_ev[nev] = (uint16_t)ev_pack((uint32_t)ji, 0u, k); else replay = true;
-                    ++nev; delta += (int)k;
-                }
-                ++ji;
-            } else if (w0 < t_indel) {                                             // [REMAP] the same draw: p < delRate/(1-insertRate) rescaled to the draws left
-                const uint32_t k = rand_indx_thr(tb.del_t, tb.del_d, (uint32_t)tb.n_del, draw4(key, ST_INDEL_LEN, aux, uid, (uint32_t)ji).w[0]);
-                if (k > 0) {
-                    const int kk = (int)k < n - ji ? (int)k : n - ji;
-                    if (nev < EV_MAX && ji < 1024 && kk < 32) my_ev[nev] = (uint16_t)ev_pack((uint32_t)ji, 1u, (uint32_t)kk); else replay = true;
-                    ++nev; delta -= kk; ji += kk;
-                }
-                else ++ji;
-            } else ++ji;
+        if (FROM_PAIRS) {
+            const uint32_t h = ev_hdr[r]; const uint4 e = ev_dat[r];
+            n_out = (int)(h & 0xFFFFu); nev = (int)((h >> 16) & 0xFFu); replay = (h >> 24) & 1u;
+            my_xa[0] = e.x; my_xa[1] = e.y; my_xa[2] = e.z; my_xa[3] = e.w;          // 8 x 16-bit events
+        } else {
+            const IndelPass ip = indel_pass(tb, key, aux, uid, force_replay, slot, flags, [&](int i, uint32_t v) { my_ev[i] = (uint16_t)v; });
+            n_out = ip.n_out; nev = ip.nev; replay = ip.replay;
         }
-        if (force_replay && nev > 0) replay = true;
-        if (n + delta < 50) { nev = 0; delta = 0; replay = false; }                // Profile.cpp:1623-1630: drop all indels
-        n_out = n + delta;
-        if (n_out > (int)slot) { atomicOr(flags, (uint32_t)FLAG_READSLOT); n_out = 0; nev = 0; replay = false; }
-        if (replay) {                                                              // phase 2 draws the tests again
-            nev = 0; xa.seed(draw4(key, ST_READ, aux, uid, 0));
+        if (replay) {                                                              // phase 2 draws the tests again: stream A from its start
+            Xoshiro xa; xa.seed(draw4(key, ST_READ, aux, uid, 0));
             my_xa[0] = xa.s0; my_xa[1] = xa.s1; my_xa[2] = xa.s2; my_xa[3] = xa.s3;
         }
     }
@@ -772,8 +814,6 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
     }
     if (live) {
         lens[r] = (uint32_t)n_out;
-        // "@<ampIdx>#<fragCount>[/1|/2]\n" + seq + "\n+\n" + qual + "\n"   (Amplicon.cpp:459-466,497-504)
-        if (FROM_PAIRS) sz[pi] = n_out == 0 ? 0u : 1u + dec_digits(pr.amp) + 1u + dec_digits(pr.att + 1) + (paired ? 2u : 0u) + 1u + 2u * (uint32_t)n_out + 4u;
     }
 }
 
@@ -1308,15 +1348,21 @@ static uint32_t reads_force_replay() {                                          
     static const uint32_t v = getenv("SCS_EV_REPLAY") ? 1u : 0u;
     return v;
 }
+void launch_indels(hipStream_t s, const PairRec* pairs, uint32_t np, int paired, DevTables tb, RngKey key, uint32_t slot, uint32_t* ev_hdr, uint4* ev_dat,
+                   uint32_t* sizes1, uint32_t* sizes2, uint32_t* flags) {
+    if (np == 0) return;
+    const uint32_t nreads = paired ? 2 * np : np;
+    hipLaunchKernelGGL(k_indels, dim3(cdiv(nreads, 256)), dim3(256), 0, s, pairs, np, paired, tb, key, slot, reads_force_replay(), ev_hdr, ev_dat, sizes1, sizes2, flags);
+}
 void launch_reads(hipStream_t s, const uint8_t* g, DevErrPool spool, DevErrPool fpool,
                   const PairRec* pairs, uint32_t np, uint32_t amp_index_base, DevTables tb, const DevTables* d_tb, RngKey key, int paired, uint32_t slot,
-                  char* slot_b, char* slot_q, uint32_t* lens, uint32_t* sizes1, uint32_t* sizes2, uint32_t* flags) {
+                  const uint32_t* ev_hdr, const uint4* ev_dat, char* slot_b, char* slot_q, uint32_t* lens, uint32_t* flags) {
     if (np == 0) return;
     (void)amp_index_base; (void)d_tb;
     const uint32_t groups = cdiv(np, RB);
     launch_reads_kernel<true>(s, dim3(paired ? 2 * groups : groups), tb, g, spool, fpool, pairs, np, paired,
                               (const uint8_t*)nullptr, (const uint64_t*)nullptr, (const uint32_t*)nullptr, (const uint8_t*)nullptr, 0u, tb, key, slot,
-                              (uint32_t)(paired ? 2ull * np : np), reads_force_replay(), slot_b, slot_q, lens, sizes1, sizes2, flags);
+                              (uint32_t)(paired ? 2ull * np : np), reads_force_replay(), ev_hdr, ev_dat, slot_b, slot_q, lens, flags);
 }
 void launch_predict_windows(hipStream_t s, const uint8_t* windows, uint32_t n_reads, const uint64_t* uids, const uint32_t* atts,
                             const uint8_t* is_read1, DevTables tb, const DevTables* d_tb, RngKey key, uint32_t slot, char* slot_b, char* slot_q, uint32_t* lens, uint32_t* flags) {
@@ -1324,7 +1370,8 @@ void launch_predict_windows(hipStream_t s, const uint8_t* windows, uint32_t n_re
     (void)d_tb;
     DevErrPool none{};
     launch_reads_kernel<false>(s, dim3(cdiv(n_reads, RB)), tb, (const uint8_t*)nullptr, none, none, (const PairRec*)nullptr, 0u, 0,
-                               windows, uids, atts, is_read1, n_reads, tb, key, slot, n_reads, reads_force_replay(), slot_b, slot_q, lens, (uint32_t*)nullptr, (uint32_t*)nullptr, flags);
+                               windows, uids, atts, is_read1, n_reads, tb, key, slot, n_reads, reads_force_replay(), (const uint32_t*)nullptr, (const uint4*)nullptr,
+                               slot_b, slot_q, lens, flags);
 }
 void launch_format(hipStream_t s, const PairRec* pairs, uint32_t np, uint32_t amp_index_base, int paired, uint32_t slot, const char* slot_b,
                    const char* slot_q, const uint32_t* lens, const uint64_t* off1, const uint64_t* off2, char* out1, char* out2) {

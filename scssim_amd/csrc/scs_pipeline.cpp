@@ -169,7 +169,7 @@ struct scs_ctx {
     DevBuf slots, slot_tmpl, valid, valid_off, valid_f, valid_off_f, scan_tmp, flags;
     // allocation + reads
     DevBuf weights, read_numbers, pair_off, pairs, odd_before, a_part, a_tp, a_probs, a_quota, a_poff; std::vector<uint32_t> h_read_numbers; uint64_t reads_requested = 0, n_pairs_planned = 0; bool allocated = false;
-    DevBuf slot_b, slot_q, lens, sizes1, sizes2, off1, off2, out1, out2; SinkPipe* pipe = nullptr;
+    DevBuf slot_b, slot_q, lens, ev_hdr, ev_dat, sizes1, sizes2, off1, off2, out1, out2; SinkPipe* pipe = nullptr;
     // sharded single job: collectives supplied by the caller + segment bookkeeping of the local amplicon lists
     scs_allreduce_fn allreduce = nullptr; scs_allgatherv_fn allgatherv = nullptr; void* coll_user = nullptr;
     scs_allreduce_dev_fn allreduce_dev = nullptr; scs_allgather_dev_fn allgather_dev = nullptr; void* coll_dev_user = nullptr;
@@ -623,22 +623,25 @@ void do_yield(scs_ctx* c, const OutTarget& tg, uint64_t* n1_out, uint64_t* n2_ou
     uint64_t bi = 0;
     const uint64_t nreads_b = paired ? 2 * batch : batch;
     c->slot_b.reserve(nreads_b * slot, s); c->slot_q.reserve(nreads_b * slot, s); c->lens.reserve(nreads_b * 4, s);
+    c->ev_hdr.reserve(nreads_b * 4, s); c->ev_dat.reserve(nreads_b * 16, s);
     c->sizes1.reserve((batch + 1) * 4, s); c->sizes2.reserve((batch + 1) * 4, s); c->off1.reserve((batch + 1) * 8, s); c->off2.reserve((batch + 1) * 8, s);
     c->scan_tmp.reserve(scan_temp_bytes(batch), s);
     uint64_t tot1 = 0, tot2 = 0, pairs_written = 0;
     for (uint64_t p0 = 0; p0 < P; p0 += batch) {
         const uint32_t np = (uint32_t)std::min<uint64_t>(batch, P - p0);
         const PairRec* pr = c->pairs.as<PairRec>() + p0;
-        c->tm_reads.begin(s);
-        launch_reads(s, c->genome.as<uint8_t>(), c->semis.pool_view(), c->fulls.pool_view(), pr, np, 0,
-                     c->dtb, c->d_tables.as<DevTables>(), c->key, paired, slot, c->slot_b.as<char>(), c->slot_q.as<char>(), c->lens.as<uint32_t>(), c->sizes1.as<uint32_t>(),
-                     c->sizes2.as<uint32_t>(), c->flags.as<uint32_t>());
-        c->tm_reads.end(s);
-        c->tm_reads.add_units(np);
-        { const hipError_t le = take_launch_error(); if (le != hipSuccess) throw ScsError(SCS_EDEVICE, std::string("k_reads launch failed: ") + hipGetErrorString(le)); }
+        // the indel pass fixes every read's length, hence the record sizes and (prefix sums) the record offsets
+        launch_indels(s, pr, np, paired, c->dtb, c->key, slot, c->ev_hdr.as<uint32_t>(), c->ev_dat.as<uint4>(), c->sizes1.as<uint32_t>(), c->sizes2.as<uint32_t>(), c->flags.as<uint32_t>());
         exclusive_scan_u32_to_u64(s, c->sizes1.as<uint32_t>(), c->off1.as<uint64_t>(), np, c->scan_tmp.p, c->scan_tmp.cap);
         if (paired) exclusive_scan_u32_to_u64(s, c->sizes2.as<uint32_t>(), c->off2.as<uint64_t>(), np, c->scan_tmp.p, c->scan_tmp.cap);
         { Mail m; m.add(c->off1.as<uint64_t>() + np, 8, 0); m.add(paired ? (const void*)(c->off2.as<uint64_t>() + np) : nullptr, 8, 1); mail_post(c, m, true); }
+        c->tm_reads.begin(s);                                                      // the base pass does not wait for the host
+        launch_reads(s, c->genome.as<uint8_t>(), c->semis.pool_view(), c->fulls.pool_view(), pr, np, 0,
+                     c->dtb, c->d_tables.as<DevTables>(), c->key, paired, slot, c->ev_hdr.as<uint32_t>(), c->ev_dat.as<uint4>(), c->slot_b.as<char>(), c->slot_q.as<char>(),
+                     c->lens.as<uint32_t>(), c->flags.as<uint32_t>());
+        c->tm_reads.end(s);
+        c->tm_reads.add_units(np);
+        { const hipError_t le = take_launch_error(); if (le != hipSuccess) throw ScsError(SCS_EDEVICE, std::string("k_reads launch failed: ") + hipGetErrorString(le)); }
         mail_wait(c);
         const uint64_t b1 = c->h_rb[0], b2 = c->h_rb[1];
         char *o1, *o2;
@@ -752,7 +755,7 @@ void scs_destroy(scs_ctx* c) {
                       &c->d_isize, &c->d_gcmeans, &c->genome, &c->gx_gc_bits, &c->gx_n_bits, &c->gx_gc_cnt, &c->gx_n_cnt, &c->gx_gc_pref, &c->gx_n_pref, &c->d_binom, &c->df_goff, &c->df_len, &c->df_strand, &c->df_primers, &c->primer_cnt, &c->primer_delta,
                       &c->slots, &c->slot_tmpl, &c->valid, &c->valid_off, &c->valid_f, &c->valid_off_f, &c->scan_tmp, &c->flags, &c->weights, &c->read_numbers,
                       &c->pair_off, &c->pairs, &c->odd_before, &c->a_part, &c->a_tp, &c->a_probs, &c->a_quota, &c->a_poff, &c->d_gidx, &c->d_gw, &c->d_grn, &c->d_tot, &c->d_stage, &c->d_all, &c->d_mail, &c->budget_f, &c->budget_s, &c->slot_off_f,
-                      &c->slot_off_s, &c->dsums, &c->slot_b, &c->slot_q, &c->lens, &c->sizes1, &c->sizes2, &c->off1, &c->off2, &c->out1, &c->out2}) b->release();
+                      &c->slot_off_s, &c->dsums, &c->slot_b, &c->slot_q, &c->lens, &c->ev_hdr, &c->ev_dat, &c->sizes1, &c->sizes2, &c->off1, &c->off2, &c->out1, &c->out2}) b->release();
     c->semis.release(); c->fulls.release();
     for (KernelTimer* t : {&c->tm_errscan, &c->tm_errscan_f, &c->tm_reads, &c->tm_attach, &c->tm_format}) t->release();
     if (c->h_rb) (void)hipHostFree(c->h_rb);
