@@ -73,7 +73,7 @@ def pmc_traffic(members):
     if not files:
         return None, None
     prefix = {"k_attach": "scs::k_attach<", "k_errs<semi->full>": "scs::k_errs<false>", "k_errs<frag->semi>": "scs::k_errs<true>",
-              "k_reads": "scs::k_reads", "k_format": "scs::k_format"}
+              "k_reads": "scs::k_reads", "k_indels": "scs::k_indels"}
     tot, launches0 = 0.0, 0
     for line in open(files[-1]):
         if line.startswith("#") or line.startswith("kernel"):
@@ -153,7 +153,7 @@ def main():
         pool1, pool2 = pools[b]
         n1, n2, pairs = g.yield_reads_device(pool1.data_ptr(), cap, pool2.data_ptr(), cap)
         if record:
-            acc(g.kernel_times(), ("k_reads", "k_format"))
+            acc(g.kernel_times(), ("k_reads", "k_indels"))
         if world > 1:                                   # read pool -> writer rank (RCCL point-to-point over xGMI)
             with torch.cuda.stream(stream):
                 sizes = torch.tensor([n1, n2], dtype=torch.int64, device=dev)
@@ -183,7 +183,7 @@ def main():
         step(i, True)
     warm_ktimes = {k: dict(v) for k, v in ktimes.items()}
     # the amplification pass is one unit of SURVEY 8(d) (1526 B per created amplicon = attach + error scan together)
-    GROUPS = {"k_attach+k_errs": ("k_attach", "k_errs<semi->full>", "k_errs<frag->semi>"), "k_reads": ("k_reads",), "k_format": ("k_format",)}
+    GROUPS = {"k_attach+k_errs": ("k_attach", "k_errs<semi->full>", "k_errs<frag->semi>"), "k_reads": ("k_reads",), "k_indels": ("k_indels",)}
     # dominant = the kernel with the largest total time (rocprof's ranking); an amplification kernel stands for its pass
     top = max(warm_ktimes, key=lambda k: warm_ktimes[k]["ms"]) if warm_ktimes else "k_reads"
     dominant = top if top in GROUPS else "k_attach+k_errs"

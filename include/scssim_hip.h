@@ -177,7 +177,7 @@ int         scs_fasta_write_index(const char* fasta_path, char* errbuf, size_t e
 
 /* Per-kernel timing (HIP events recorded on the ctx stream around every launch, accumulated over the
  * last scs_amplify / scs_yield_reads call): name, launches, total milliseconds, and the units the
- * launches processed (amplicons created for the errscan kernels, read pairs for k_reads/k_format,
+ * launches processed (amplicons created for the errscan kernels, read pairs for k_reads/k_indels,
  * templates for k_attach).  which = 0..4. */
 int         scs_kernel_time(const scs_ctx* ctx, int which, const char** name, uint64_t* launches, double* ms, uint64_t* units);
 /* Which of the five kernels get their HIP event pairs: bit `which` of mask (default: all), and on which calls: every

@@ -283,7 +283,7 @@ class GenReads:
             out[name.value.decode()] = dict(launches=n.value, ms=ms.value, units=units.value)
         return out
 
-    KERNELS = ("k_errs<semi->full>", "k_errs<frag->semi>", "k_reads", "k_attach", "k_format")
+    KERNELS = ("k_errs<semi->full>", "k_errs<frag->semi>", "k_reads", "k_attach", "k_indels")
 
     def set_kernel_timing(self, names=None, every=1):
         """Keep HIP event pairs only around the named kernels (None = all five), on every `every`-th amplify / yield call.

@@ -503,13 +503,47 @@ __global__ void __launch_bounds__(256) k_indels(const PairRec* __restrict__ pair
     sz[pi] = ip.n_out == 0 ? 0u : 1u + dec_digits(amp) + 1u + dec_digits(att + 1) + (paired ? 2u : 0u) + 1u + 2u * (uint32_t)ip.n_out + 4u;
 }
 
+// ---- FASTQ text straight from the base pass (pair mode).  A record is two byte streams per read: the name line + bases +
+// "\n+\n", and the qualities + "\n".  A lane produces its characters four to a register word and sixteen to a block; a
+// stream starts at an arbitrary byte address T, so blocks are realigned in registers (v_alignbyte against the previous
+// word) and stored as ALIGNED dwords from Ta = T & ~3.  The bytes of a stream's first aligned dword that lie before T
+// are the end of what precedes it in the record, and are known: the tail of the name line for the bases, the tail of
+// "\n+\n" for the qualities -- so every dword except the record's very last one is written whole, exactly once.
+__device__ __forceinline__ uint32_t shifted_word(uint32_t cur, uint32_t prev, uint32_t s) {   // stream bytes 4k-s .. 4k-s+3; s = T & 3
+    return s ? __builtin_amdgcn_alignbyte(cur, prev, 4u - s) : cur;
+}
+__device__ __forceinline__ void emit_block(char* __restrict__ dst, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t& carry, uint32_t s) {
+    *reinterpret_cast<uint4*>(dst) = make_uint4(shifted_word(w0, carry, s), shifted_word(w1, w0, s), shifted_word(w2, w1, s), shifted_word(w3, w2, s));   // dword aligned
+    carry = w3;
+}
+// the last (partial) block of a stream: nbv valid bytes in w0..w3, then `sep` (seplen bytes), written up to `end`
+// (exclusive).  Whole dwords as far as they go; the <= 3 bytes left (only a record's very end) as bytes.
+__device__ __forceinline__ void emit_tail(char* __restrict__ dst, char* __restrict__ end, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t nbv,
+                                          uint32_t sep, uint32_t carry, uint32_t s) {
+    const unsigned long long sv = (unsigned long long)sep << (8u * (nbv & 3u));
+    const uint32_t wi = nbv >> 2, lo = (uint32_t)sv, hi = (uint32_t)(sv >> 32);
+    uint32_t w4 = 0, w5 = 0;
+    w0 |= wi == 0u ? lo : 0u; w1 |= wi == 1u ? lo : (wi == 0u ? hi : 0u); w2 |= wi == 2u ? lo : (wi == 1u ? hi : 0u);
+    w3 |= wi == 3u ? lo : (wi == 2u ? hi : 0u); w4 |= wi == 4u ? lo : (wi == 3u ? hi : 0u); w5 |= wi == 4u ? hi : 0u;
+    const uint32_t d[6] = {shifted_word(w0, carry, s), shifted_word(w1, w0, s), shifted_word(w2, w1, s), shifted_word(w3, w2, s),
+                           shifted_word(w4, w3, s), shifted_word(w5, w4, s)};
+    const uint32_t nbytes = (uint32_t)(end - dst), nd = nbytes >> 2, rem = nbytes & 3u;
+#pragma unroll
+    for (uint32_t k = 0; k < 6; ++k) {
+        if (k < nd) reinterpret_cast<uint32_t*>(dst)[k] = d[k];
+        else if (k == nd) for (uint32_t i = 0; i < rem; ++i) dst[4u * k + i] = (char)(d[k] >> (8u * i));
+    }
+}
+
 template <bool FROM_PAIRS, bool QBIG>
 __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, DevErrPool spool, DevErrPool fpool, const PairRec* __restrict__ pairs,
                                               uint32_t np, int paired, const uint8_t* __restrict__ windows, const uint64_t* __restrict__ uids,
                                               const uint32_t* __restrict__ atts, const uint8_t* __restrict__ is_read1, uint32_t n_explicit,
                                               const DevTables tb, RngKey key, uint32_t slot, uint32_t n_slots_cap, uint32_t force_replay,
                                               const uint32_t* __restrict__ ev_hdr, const uint4* __restrict__ ev_dat,
-                                              char* __restrict__ slot_b, char* __restrict__ slot_q, uint32_t* __restrict__ lens, uint32_t* __restrict__ flags) {
+                                              const uint64_t* __restrict__ off1, const uint64_t* __restrict__ off2, char* __restrict__ out1, char* __restrict__ out2,
+                                              uint32_t amp_index_base, char* __restrict__ slot_b, char* __restrict__ slot_q, uint32_t* __restrict__ lens,
+                                              uint32_t* __restrict__ flags) {
     typedef RingGeo<QBIG> Geo;
     typedef RingBin<QBIG> Bin;
     constexpr int SLOTS = Geo::SLOTS, GROUP = Geo::GROUP, QROW = Geo::QROW, EPB = 64 + 4 * QROW;   // EPB: 16-byte entries per bin image
@@ -538,9 +572,8 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
         r = blockIdx.x * RB + tid; valid = r < n_explicit; rd = 0;
         if (valid) { uid = uids[r]; att = atts[r]; rd = is_read1[r] ? 0u : 1u; }
     }
-    if (valid && r >= n_slots_cap) { atomicOr(flags, (uint32_t)FLAG_INTERNAL); valid = false; }   // never write outside the slot buffers
+    if (!FROM_PAIRS && valid && r >= n_slots_cap) { atomicOr(flags, (uint32_t)FLAG_INTERNAL); valid = false; }   // never write outside the slot buffers
     bool live = valid && (!FROM_PAIRS || pr.isz != 0);
-    if (FROM_PAIRS && valid && !live) lens[r] = 0;
 
     // ---- stage the windows (coalesced), then patch the amplification errors
     LdsU8* my_win = (LdsU8*)(s_win + (size_t)tid * WS);
@@ -650,7 +683,38 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
     uint32_t c0 = 5u, c1 = 5u;
     uint32_t cur_b = 0, cur_q = 0, ob0 = 0, ob1 = 0, ob2 = 0, ob3 = 0, oq0 = 0, oq1 = 0, oq2 = 0, oq3 = 0;
     Xoshiro xb; xb.seed(draw4(key, ST_READ, aux, uid, 1));                         // stream B: substitution / quality draws, in output order
-    char* my_b = slot_b + (size_t)r * slot; char* my_q = slot_q + (size_t)r * slot;
+    char* my_b = FROM_PAIRS ? nullptr : slot_b + (size_t)r * slot; char* my_q = FROM_PAIRS ? nullptr : slot_q + (size_t)r * slot;
+    // pair mode: the two byte streams of my FASTQ record (see emit_block above)
+    char *ta1 = nullptr, *ta2 = nullptr, *rec_end = nullptr; uint32_t s1 = 0, s2 = 0, carry_b = 0, carry_q = 0x0A2B0A00u;   // carry_q: "\n+\n" ahead of the qualities
+    if (FROM_PAIRS && live && n_out > 0) {
+        char* rec = (rd ? out2 : out1) + (rd ? off2[pi] : off1[pi]);
+        const uint32_t amp = amp_index_base + pr.amp, cnt = pr.att + 1u;
+        const uint32_t d1 = dec_digits(amp), d2 = dec_digits(cnt), h = 1u + d1 + 1u + d2 + (paired ? 2u : 0u) + 1u;   // "@<amp>#<cnt>[/1|/2]\n"
+        char* t1 = rec + h; s1 = (uint32_t)reinterpret_cast<uintptr_t>(t1) & 3u; ta1 = t1 - s1;
+        char* t2 = t1 + n_out + 3; s2 = (uint32_t)reinterpret_cast<uintptr_t>(t2) & 3u; ta2 = t2 - s2;
+        rec_end = t2 + n_out + 1;
+        // the name line is produced backwards from its end: its last s1 characters ride in the first dword of the bases,
+        // the rest ends on the aligned address ta1 and goes out as whole dwords, then the <= 3 leading bytes
+        uint32_t q = 0, vc = cnt, va = amp; const uint32_t dbase = paired ? 3u : 1u;
+        auto next_char = [&]() -> uint32_t {
+            uint32_t ch;
+            if (q == 0) ch = '\n';
+            else if (q < dbase) ch = q == 1 ? (rd ? '2' : '1') : '/';
+            else if (q < dbase + d2) { ch = '0' + vc % 10u; vc /= 10u; }
+            else if (q == dbase + d2) ch = '#';
+            else if (q < h - 1u) { ch = '0' + va % 10u; va /= 10u; }
+            else ch = '@';
+            ++q; return ch;
+        };
+        for (uint32_t i = 0; i < 3; ++i) if (i < s1) carry_b |= next_char() << (8u * (3u - i));
+        char* wp = ta1;
+        for (uint32_t m = 0; m < 7; ++m) {
+            uint32_t w = 0, nb4 = 0;
+            for (uint32_t b = 0; b < 4; ++b) if (q < h) { w = (w << 8) | next_char(); ++nb4; }
+            if (nb4 == 4u) { wp -= 4; *reinterpret_cast<uint32_t*>(wp) = w; }
+            else if (nb4) { wp -= nb4; for (uint32_t i = 0; i < nb4; ++i) wp[i] = (char)(w >> (8u * i)); }
+        }
+    }
     // ring maintenance: the bins of group gq = t/GROUP live in half (gq & 1) of the ring.  Group 0 is loaded up front; the
     // bins of the next group are prefetched into registers one group ahead and written to LDS at the group boundary,
     // into the half that group gq-2 used -- every wave left that group before the previous boundary's barrier, so one
@@ -681,9 +745,9 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
     // not feed back into the walk, so the lookup is deferred: (position, k, c2, bin, draw) goes to the free tail of the
     // read's quality slot and is resolved after the loop, off the workgroup-synchronous path.  No room -> resolved in place.
     constexpr uint32_t PEND_MAX = 4;
-    const bool can_defer = n_out + 15 + (int)(8 * PEND_MAX) <= (int)slot;
+    const bool can_defer = !FROM_PAIRS && n_out + 15 + (int)(8 * PEND_MAX) <= (int)slot;   // (slot mode only: pair mode writes FASTQ text directly)
     uint32_t npend = 0;
-    uint2* my_pend = reinterpret_cast<uint2*>(my_q + slot - 8 * PEND_MAX);
+    uint2* my_pend = FROM_PAIRS ? nullptr : reinterpret_cast<uint2*>(my_q + slot - 8 * PEND_MAX);
 
     for (int t = 0; t < B; ++t) {
         if ((t & (GROUP - 1)) == 0 && t > 0) {
@@ -796,8 +860,17 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
                     cur_b = 0; cur_q = 0;
                     if (((uint32_t)jo & 15u) == 15u || lastp) {
                         const int o = jo & ~15;
-                        *reinterpret_cast<uint4*>(my_b + o) = make_uint4(ob0, ob1, ob2, ob3);
-                        *reinterpret_cast<uint4*>(my_q + o) = make_uint4(oq0, oq1, oq2, oq3);
+                        if (!FROM_PAIRS) {                                         // slot mode (explicit windows)
+                            *reinterpret_cast<uint4*>(my_b + o) = make_uint4(ob0, ob1, ob2, ob3);
+                            *reinterpret_cast<uint4*>(my_q + o) = make_uint4(oq0, oq1, oq2, oq3);
+                        } else if (!lastp) {                                       // FASTQ text: a full block of each stream
+                            emit_block(ta1 + o, ob0, ob1, ob2, ob3, carry_b, s1);
+                            emit_block(ta2 + o, oq0, oq1, oq2, oq3, carry_q, s2);
+                        } else {                                                   // the read's last block: + "\n+\n" up to the qualities' first dword / + "\n" to the record's end
+                            const uint32_t nbv = ((uint32_t)jo & 15u) + 1u;
+                            emit_tail(ta1 + o, ta2, ob0, ob1, ob2, ob3, nbv, 0x0A2B0Au, carry_b, s1);
+                            emit_tail(ta2 + o, rec_end, oq0, oq1, oq2, oq3, nbv, 0x0Au, carry_q, s2);
+                        }
                         ob0 = ob1 = ob2 = ob3 = 0; oq0 = oq1 = oq2 = oq3 = 0;
                     }
                 }
@@ -812,75 +885,8 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
         if (qv == 255u) qv = qual_lookup(tb.qual + (size_t)qrow * NQ, tb.qual_d + (size_t)qrow * NQ, tb.qual_guide + (size_t)qrow * 17u, pe.y);
         my_q[pe.x & 4095u] = (char)(33u + qv);
     }
-    if (live) {
+    if (live && !FROM_PAIRS) {
         lens[r] = (uint32_t)n_out;
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// K6  format: slot buffer -> FASTQ text at the prefix-summed record offsets (record layout of Amplicon::yieldReads,
-//     Amplicon.cpp:459-466 / 497-525; sink = SeqWriter).  THREE records per wave, 21 lanes each: lanes 0-9 move the
-//     bases and lanes 10-19 the qualities, 16 bytes per lane per round, as ALIGNED dwords on both sides (a record
-//     starts at any byte: destination dword j takes source bytes a+4j.., assembled with v_alignbyte from the aligned
-//     slot); lane 20 writes the name line, the separators and the <= 3 bytes before/after each aligned body.
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t put_dec(char* dst, uint32_t v) {
-    const uint32_t nd = dec_digits(v);
-    for (uint32_t k = 0; k < nd; ++k) { dst[nd - 1 - k] = (char)('0' + v % 10u); v /= 10u; }
-    return nd;
-}
-__global__ void __launch_bounds__(256) k_format(const PairRec* __restrict__ pairs, uint32_t np, uint32_t amp_index_base, int paired, uint32_t slot,
-                                                const char* __restrict__ slot_b, const char* __restrict__ slot_q, const uint32_t* __restrict__ lens,
-                                                const uint64_t* __restrict__ off1, const uint64_t* __restrict__ off2,
-                                                char* __restrict__ out1, char* __restrict__ out2) {
-    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
-    const uint32_t nreads = paired ? 2 * np : np;
-    const uint32_t nwaves = gridDim.x * 4;
-    const uint32_t rec = (uint32_t)lane / 21u, sub = (uint32_t)lane % 21u;         // lane 63: rec 3 = idle
-    for (uint32_t r0 = (blockIdx.x * 4 + wib) * 3u; r0 < nreads; r0 += 3u * nwaves) {
-        const uint32_t r = r0 + rec;
-        if (rec >= 3u || r >= nreads) continue;
-        const uint32_t pi = paired ? r >> 1 : r, rd = paired ? (r & 1u) : 0u;
-        const uint32_t nl = lens[r];
-        if (nl == 0 || nl > slot) continue;
-        const uint32_t amp = amp_index_base + pairs[pi].amp, cnt = pairs[pi].att + 1u;
-        char* dst = (rd ? out2 : out1) + (rd ? off2[pi] : off1[pi]);
-        const uint32_t d1 = dec_digits(amp), d2 = dec_digits(cnt), h = 1u + d1 + 1u + d2 + (paired ? 2u : 0u) + 1u;   // "@<amp>#<cnt>[/1|/2]\n"
-        const uint32_t words = slot >> 2;
-        for (uint32_t j = sub; j < h; j += 21u) {                                  // ---- name line: lane j writes character j
-            uint32_t ch;
-            if (j == 0) ch = '@';
-            else if (j <= d1) { uint32_t v = amp; for (uint32_t k = d1 - j; k; --k) v /= 10u; ch = '0' + v % 10u; }
-            else if (j == d1 + 1u) ch = '#';
-            else if (j <= d1 + 1u + d2) { uint32_t v = cnt; for (uint32_t k = d1 + 1u + d2 - j; k; --k) v /= 10u; ch = '0' + v % 10u; }
-            else if (j == h - 1u) ch = '\n';
-            else ch = j == h - 3u ? '/' : (rd ? '2' : '1');
-            dst[j] = (char)ch;
-        }
-        if (sub < 20u) {                                                           // ---- field bodies and their edges
-            const bool qual = sub >= 10u;
-            char* fdst = dst + h + (qual ? nl + 3u : 0u);
-            const char* src = (qual ? slot_q : slot_b) + (size_t)r * slot;
-            const uint32_t a = (uint32_t)(0u - (uint32_t)reinterpret_cast<uintptr_t>(fdst)) & 3u;   // bytes before the first aligned dword
-            const uint32_t head = a < nl ? a : nl, nd = (nl - head) >> 2, tail0 = head + 4u * nd;   // nd aligned dwords in the body
-            const uint4* __restrict__ s128 = reinterpret_cast<const uint4*>(src); const uint32_t* __restrict__ s32 = reinterpret_cast<const uint32_t*>(src);
-            uint32_t* __restrict__ d32 = reinterpret_cast<uint32_t*>(fdst + head);
-            for (uint32_t q = sub - (qual ? 10u : 0u); 4u * q <= nd && 4u * q < words; q += 10u) {   // "<=": the lane that owns dword nd writes the tail bytes
-                const uint4 S = s128[q]; const uint32_t N = 4u * q + 4u < words ? s32[4u * q + 4u] : 0u;
-                uint4 o = S;
-                if (a) { o.x = __builtin_amdgcn_alignbyte(S.y, S.x, a); o.y = __builtin_amdgcn_alignbyte(S.z, S.y, a); o.z = __builtin_amdgcn_alignbyte(S.w, S.z, a); o.w = __builtin_amdgcn_alignbyte(N, S.w, a); }
-                const uint32_t j = 4u * q;
-                if (j + 4u <= nd) { d32[j] = o.x; d32[j + 1] = o.y; d32[j + 2] = o.z; d32[j + 3] = o.w; }   // one dwordx4 store (dword aligned)
-                else {
-                    if (j < nd) d32[j] = o.x; if (j + 1u < nd) d32[j + 1] = o.y; if (j + 2u < nd) d32[j + 2] = o.z;
-                    const uint32_t e = nd - j, vt = e == 0 ? o.x : e == 1 ? o.y : e == 2 ? o.z : o.w;   // the dword that would come next: its low bytes are the tail
-                    for (uint32_t i = tail0; i < nl; ++i) fdst[i] = (char)(vt >> (8u * (i - tail0)));
-                }
-                if (q == 0) for (uint32_t i = 0; i < head; ++i) fdst[i] = (char)(S.x >> (8u * i));   // bytes before the first aligned dword
-            }
-        } else {                                                                   // ---- separators
-            dst[h + nl] = '\n'; dst[h + nl + 1] = '+'; dst[h + nl + 2] = '\n'; dst[h + 2u * nl + 3u] = '\n';
-        }
     }
 }
 
@@ -1234,7 +1240,6 @@ static inline uint32_t cdiv(uint64_t a, uint32_t b) { return (uint32_t)((a + b -
 static thread_local hipError_t g_launch_err = hipSuccess;
 static inline void note_launch(hipError_t e) { if (e != hipSuccess && g_launch_err == hipSuccess) g_launch_err = e; }
 hipError_t take_launch_error() { note_launch(hipGetLastError()); const hipError_t e = g_launch_err; g_launch_err = hipSuccess; return e; }
-static const uint32_t kMaxStrideGrid = 256 * 8;
 
 void launch_attach_frags(hipStream_t s, const uint8_t* g, DevFrags fr, const uint32_t* slot_off, uint32_t* slots, uint32_t* slot_tmpl,
                          uint32_t* valid, const int64_t* primer_cnt, uint32_t* primer_delta, unsigned long long* len_sum, AmplifyParams p) {
@@ -1352,17 +1357,19 @@ void launch_indels(hipStream_t s, const PairRec* pairs, uint32_t np, int paired,
                    uint32_t* sizes1, uint32_t* sizes2, uint32_t* flags) {
     if (np == 0) return;
     const uint32_t nreads = paired ? 2 * np : np;
-    hipLaunchKernelGGL(k_indels, dim3(cdiv(nreads, 256)), dim3(256), 0, s, pairs, np, paired, tb, key, slot, reads_force_replay(), ev_hdr, ev_dat, sizes1, sizes2, flags);
+    (void)slot;                                                                    // the FASTQ record takes whatever length the read has (header field: 16 bits)
+    hipLaunchKernelGGL(k_indels, dim3(cdiv(nreads, 256)), dim3(256), 0, s, pairs, np, paired, tb, key, 65535u, reads_force_replay(), ev_hdr, ev_dat, sizes1, sizes2, flags);
 }
 void launch_reads(hipStream_t s, const uint8_t* g, DevErrPool spool, DevErrPool fpool,
                   const PairRec* pairs, uint32_t np, uint32_t amp_index_base, DevTables tb, const DevTables* d_tb, RngKey key, int paired, uint32_t slot,
-                  const uint32_t* ev_hdr, const uint4* ev_dat, char* slot_b, char* slot_q, uint32_t* lens, uint32_t* flags) {
+                  const uint32_t* ev_hdr, const uint4* ev_dat, const uint64_t* off1, const uint64_t* off2, char* out1, char* out2, uint32_t* flags) {
     if (np == 0) return;
-    (void)amp_index_base; (void)d_tb;
+    (void)d_tb;
     const uint32_t groups = cdiv(np, RB);
     launch_reads_kernel<true>(s, dim3(paired ? 2 * groups : groups), tb, g, spool, fpool, pairs, np, paired,
                               (const uint8_t*)nullptr, (const uint64_t*)nullptr, (const uint32_t*)nullptr, (const uint8_t*)nullptr, 0u, tb, key, slot,
-                              (uint32_t)(paired ? 2ull * np : np), reads_force_replay(), ev_hdr, ev_dat, slot_b, slot_q, lens, flags);
+                              (uint32_t)(paired ? 2ull * np : np), reads_force_replay(), ev_hdr, ev_dat, off1, off2, out1, out2, amp_index_base,
+                              (char*)nullptr, (char*)nullptr, (uint32_t*)nullptr, flags);
 }
 void launch_predict_windows(hipStream_t s, const uint8_t* windows, uint32_t n_reads, const uint64_t* uids, const uint32_t* atts,
                             const uint8_t* is_read1, DevTables tb, const DevTables* d_tb, RngKey key, uint32_t slot, char* slot_b, char* slot_q, uint32_t* lens, uint32_t* flags) {
@@ -1371,14 +1378,7 @@ void launch_predict_windows(hipStream_t s, const uint8_t* windows, uint32_t n_re
     DevErrPool none{};
     launch_reads_kernel<false>(s, dim3(cdiv(n_reads, RB)), tb, (const uint8_t*)nullptr, none, none, (const PairRec*)nullptr, 0u, 0,
                                windows, uids, atts, is_read1, n_reads, tb, key, slot, n_reads, reads_force_replay(), (const uint32_t*)nullptr, (const uint4*)nullptr,
-                               slot_b, slot_q, lens, flags);
-}
-void launch_format(hipStream_t s, const PairRec* pairs, uint32_t np, uint32_t amp_index_base, int paired, uint32_t slot, const char* slot_b,
-                   const char* slot_q, const uint32_t* lens, const uint64_t* off1, const uint64_t* off2, char* out1, char* out2) {
-    if (np == 0) return;
-    const uint64_t nreads = paired ? 2ull * np : np;
-    uint32_t grid = cdiv(nreads, 12); if (grid > kMaxStrideGrid * 4) grid = kMaxStrideGrid * 4;   // 4 waves x 3 records per workgroup and round
-    hipLaunchKernelGGL(k_format, dim3(grid), dim3(256), 0, s, pairs, np, amp_index_base, paired, slot, slot_b, slot_q, lens, off1, off2, out1, out2);
+                               (const uint64_t*)nullptr, (const uint64_t*)nullptr, (char*)nullptr, (char*)nullptr, 0u, slot_b, slot_q, lens, flags);
 }
 void launch_philox(hipStream_t s, const uint32_t* ctr, uint32_t n, RngKey key, uint32_t* out) {
     if (n) hipLaunchKernelGGL(k_philox, dim3(cdiv(n, 256)), dim3(256), 0, s, ctr, n, key, out);

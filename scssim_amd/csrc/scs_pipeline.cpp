@@ -197,7 +197,7 @@ struct scs_ctx {
                HIP_OK(hipMemcpyAsync(d, w.data(), n * 4, hipMemcpyHostToDevice, stream)); HIP_OK(hipStreamSynchronize(stream)); }
     }
     scs_stats st{};
-    KernelTimer tm_errscan{"k_errs<semi->full>"}, tm_errscan_f{"k_errs<frag->semi>"}, tm_reads{"k_reads"}, tm_attach{"k_attach"}, tm_format{"k_format"};
+    KernelTimer tm_errscan{"k_errs<semi->full>"}, tm_errscan_f{"k_errs<frag->semi>"}, tm_reads{"k_reads"}, tm_attach{"k_attach"}, tm_indels{"k_indels"};
 
     DevFrags frags_view() const {
         return DevFrags{df_goff.as<uint64_t>(), df_len.as<uint32_t>(), df_strand.as<int8_t>(), df_primers.as<uint32_t>(), (uint32_t)f_len.size(), f_gidx_base};
@@ -608,7 +608,7 @@ void do_yield(scs_ctx* c, const OutTarget& tg, uint64_t* n1_out, uint64_t* n2_ou
     hipStream_t s = c->stream; const int paired = c->cfg.paired != 0;
     if (c->cfg.verbose) fprintf(stderr, "\n*****Producing reads*****\n");
     c->timing_gate = (c->yield_calls++ % c->timing_every) == 0;
-    c->tm_reads.reset(); c->tm_format.reset();
+    c->tm_reads.reset(); c->tm_indels.reset();
     const uint64_t P = c->n_pairs_planned;
     const uint32_t L = (uint32_t)c->prof.read_length, slot = ((L + 64 + 63) / 64) * 64;
     c->pairs.reserve(std::max<size_t>(P * sizeof(PairRec), 16), s);
@@ -622,7 +622,6 @@ void do_yield(scs_ctx* c, const OutTarget& tg, uint64_t* n1_out, uint64_t* n2_ou
     }
     uint64_t bi = 0;
     const uint64_t nreads_b = paired ? 2 * batch : batch;
-    c->slot_b.reserve(nreads_b * slot, s); c->slot_q.reserve(nreads_b * slot, s); c->lens.reserve(nreads_b * 4, s);
     c->ev_hdr.reserve(nreads_b * 4, s); c->ev_dat.reserve(nreads_b * 16, s);
     c->sizes1.reserve((batch + 1) * 4, s); c->sizes2.reserve((batch + 1) * 4, s); c->off1.reserve((batch + 1) * 8, s); c->off2.reserve((batch + 1) * 8, s);
     c->scan_tmp.reserve(scan_temp_bytes(batch), s);
@@ -631,17 +630,13 @@ void do_yield(scs_ctx* c, const OutTarget& tg, uint64_t* n1_out, uint64_t* n2_ou
         const uint32_t np = (uint32_t)std::min<uint64_t>(batch, P - p0);
         const PairRec* pr = c->pairs.as<PairRec>() + p0;
         // the indel pass fixes every read's length, hence the record sizes and (prefix sums) the record offsets
+        c->tm_indels.begin(s);
         launch_indels(s, pr, np, paired, c->dtb, c->key, slot, c->ev_hdr.as<uint32_t>(), c->ev_dat.as<uint4>(), c->sizes1.as<uint32_t>(), c->sizes2.as<uint32_t>(), c->flags.as<uint32_t>());
+        c->tm_indels.end(s);
+        c->tm_indels.add_units(np);
         exclusive_scan_u32_to_u64(s, c->sizes1.as<uint32_t>(), c->off1.as<uint64_t>(), np, c->scan_tmp.p, c->scan_tmp.cap);
         if (paired) exclusive_scan_u32_to_u64(s, c->sizes2.as<uint32_t>(), c->off2.as<uint64_t>(), np, c->scan_tmp.p, c->scan_tmp.cap);
         { Mail m; m.add(c->off1.as<uint64_t>() + np, 8, 0); m.add(paired ? (const void*)(c->off2.as<uint64_t>() + np) : nullptr, 8, 1); mail_post(c, m, true); }
-        c->tm_reads.begin(s);                                                      // the base pass does not wait for the host
-        launch_reads(s, c->genome.as<uint8_t>(), c->semis.pool_view(), c->fulls.pool_view(), pr, np, 0,
-                     c->dtb, c->d_tables.as<DevTables>(), c->key, paired, slot, c->ev_hdr.as<uint32_t>(), c->ev_dat.as<uint4>(), c->slot_b.as<char>(), c->slot_q.as<char>(),
-                     c->lens.as<uint32_t>(), c->flags.as<uint32_t>());
-        c->tm_reads.end(s);
-        c->tm_reads.add_units(np);
-        { const hipError_t le = take_launch_error(); if (le != hipSuccess) throw ScsError(SCS_EDEVICE, std::string("k_reads launch failed: ") + hipGetErrorString(le)); }
         mail_wait(c);
         const uint64_t b1 = c->h_rb[0], b2 = c->h_rb[1];
         char *o1, *o2;
@@ -652,10 +647,13 @@ void do_yield(scs_ctx* c, const OutTarget& tg, uint64_t* n1_out, uint64_t* n2_ou
             c->out1.reserve(std::max<uint64_t>(b1, 16), s); c->out2.reserve(std::max<uint64_t>(b2, 16), s);
             o1 = c->out1.as<char>(); o2 = c->out2.as<char>();
         }
-        c->tm_format.begin(s);
-        launch_format(s, pr, np, 0, paired, slot, c->slot_b.as<char>(), c->slot_q.as<char>(), c->lens.as<uint32_t>(), c->off1.as<uint64_t>(), c->off2.as<uint64_t>(), o1, o2);
-        c->tm_format.end(s);
-        c->tm_format.add_units(np);
+        c->tm_reads.begin(s);                                                      // the base pass writes the FASTQ text at the record offsets
+        launch_reads(s, c->genome.as<uint8_t>(), c->semis.pool_view(), c->fulls.pool_view(), pr, np, 0,
+                     c->dtb, c->d_tables.as<DevTables>(), c->key, paired, slot, c->ev_hdr.as<uint32_t>(), c->ev_dat.as<uint4>(),
+                     c->off1.as<uint64_t>(), c->off2.as<uint64_t>(), o1, o2, c->flags.as<uint32_t>());
+        c->tm_reads.end(s);
+        c->tm_reads.add_units(np);
+        { const hipError_t le = take_launch_error(); if (le != hipSuccess) throw ScsError(SCS_EDEVICE, std::string("k_reads launch failed: ") + hipGetErrorString(le)); }
         if (to_sink) {
             SinkPipe* pp = c->pipe; const int sl = (int)(bi++ & 1);
             if (pp->acquire(sl)) throw ScsError(SCS_EIO, "sink aborted");
@@ -688,7 +686,7 @@ void do_yield(scs_ctx* c, const OutTarget& tg, uint64_t* n1_out, uint64_t* n2_ou
     HIP_OK(hipStreamSynchronize(s));
     if (to_sink) { guard.p = nullptr; if (!c->pipe->finish()) throw ScsError(SCS_EIO, "sink aborted"); }
     check_flags(c);
-    c->tm_reads.collect(); c->tm_format.collect();
+    c->tm_reads.collect(); c->tm_indels.collect();
     c->st.pairs_written = pairs_written; c->st.reads_written = paired ? 2 * pairs_written : pairs_written;
     c->st.fastq_bytes[0] = tot1; c->st.fastq_bytes[1] = tot2;
     // 1526 B per created amplicon + per pair (insert size + FASTQ bytes of both records)
@@ -736,7 +734,7 @@ int scs_create(const scs_config* cfg, scs_ctx** out) {
         HIP_OK(hipSetDevice(cfg->device));
         if (cfg->stream) c->stream = (hipStream_t)cfg->stream; else { HIP_OK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
         c->key = RngKey{(uint32_t)cfg->seed, (uint32_t)(cfg->seed >> 32)};
-        for (KernelTimer* t : {&c->tm_errscan, &c->tm_errscan_f, &c->tm_reads, &c->tm_attach, &c->tm_format}) t->gate = &c->timing_gate;
+        for (KernelTimer* t : {&c->tm_errscan, &c->tm_errscan_f, &c->tm_reads, &c->tm_attach, &c->tm_indels}) t->gate = &c->timing_gate;
         c->flags.reserve(256, c->stream); HIP_OK(hipMemsetAsync(c->flags.p, 0, 256, c->stream));
         c->dsums.reserve(256, c->stream); HIP_OK(hipMemsetAsync(c->dsums.p, 0, 256, c->stream));
         c->d_tot.reserve(256, c->stream);
@@ -757,7 +755,7 @@ void scs_destroy(scs_ctx* c) {
                       &c->pair_off, &c->pairs, &c->odd_before, &c->a_part, &c->a_tp, &c->a_probs, &c->a_quota, &c->a_poff, &c->d_gidx, &c->d_gw, &c->d_grn, &c->d_tot, &c->d_stage, &c->d_all, &c->d_mail, &c->budget_f, &c->budget_s, &c->slot_off_f,
                       &c->slot_off_s, &c->dsums, &c->slot_b, &c->slot_q, &c->lens, &c->ev_hdr, &c->ev_dat, &c->sizes1, &c->sizes2, &c->off1, &c->off2, &c->out1, &c->out2}) b->release();
     c->semis.release(); c->fulls.release();
-    for (KernelTimer* t : {&c->tm_errscan, &c->tm_errscan_f, &c->tm_reads, &c->tm_attach, &c->tm_format}) t->release();
+    for (KernelTimer* t : {&c->tm_errscan, &c->tm_errscan_f, &c->tm_reads, &c->tm_attach, &c->tm_indels}) t->release();
     if (c->h_rb) (void)hipHostFree(c->h_rb);
     if (c->pipe) {
         for (int k = 0; k < 2; ++k) { if (c->pipe->h1[k]) (void)hipHostFree((size_t*)c->pipe->h1[k] - 2); if (c->pipe->h2[k]) (void)hipHostFree((size_t*)c->pipe->h2[k] - 2); (void)hipEventDestroy(c->pipe->ev[k]); }
@@ -824,7 +822,7 @@ int scs_get_stats(const scs_ctx* c, scs_stats* out) { if (!c || !out) return SCS
 
 int scs_kernel_time(const scs_ctx* c, int which, const char** name, uint64_t* launches, double* ms, uint64_t* units) {
     if (!c) return SCS_EINVAL;
-    const KernelTimer* t[] = {&c->tm_errscan, &c->tm_errscan_f, &c->tm_reads, &c->tm_attach, &c->tm_format};
+    const KernelTimer* t[] = {&c->tm_errscan, &c->tm_errscan_f, &c->tm_reads, &c->tm_attach, &c->tm_indels};
     if (which < 0 || which >= 5) return SCS_EINVAL;
     if (name) *name = t[which]->name; if (launches) *launches = t[which]->launches; if (ms) *ms = t[which]->ms; if (units) *units = t[which]->units;
     return SCS_OK;
@@ -832,7 +830,7 @@ int scs_kernel_time(const scs_ctx* c, int which, const char** name, uint64_t* la
 
 int scs_set_kernel_timing(scs_ctx* c, unsigned mask, unsigned every) {
     if (!c || every == 0) return SCS_EINVAL;
-    KernelTimer* t[] = {&c->tm_errscan, &c->tm_errscan_f, &c->tm_reads, &c->tm_attach, &c->tm_format};
+    KernelTimer* t[] = {&c->tm_errscan, &c->tm_errscan_f, &c->tm_reads, &c->tm_attach, &c->tm_indels};
     for (int i = 0; i < 5; ++i) t[i]->on = (mask >> i) & 1u;
     c->timing_every = every; c->amplify_calls = 0; c->yield_calls = 0;
     return SCS_OK;
