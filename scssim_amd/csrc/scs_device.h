@@ -67,10 +67,15 @@ struct PoissonParams {
     // unsharded job: templateNum = nf + dev[DS_SEMIS_N], totalLen = frag_len + dev[DS_SEMI_LEN].  The semi amplicon
     // count and length live on the device: setPrimers of a cycle is launched before the host has read them back.
     uint64_t nf, frag_len; const unsigned long long* dev;
+    const unsigned long long* total_primers_dev;       // sharded job: the pool size lives on the device too (else null)
 };
 // device scalars of an amplification run (scs_ctx::dsums): [0],[1] budget sums of the current setPrimers call,
-// [4] total length of the semi amplicons, [5] number of semi amplicons
-enum { DS_SEMI_LEN = 4, DS_SEMIS_N = 5 };
+// [4] total length of this shard's semi amplicons, [5] their number.  Sharded job, whole-job values kept current by the
+// tail of the per-pass primer all-reduce (k_shard_tail / k_primer_update_sharded): [6] semi length already reported,
+// [8] semis, [9] their length, [10] primers left in the pool, [11],[12] {templateNum, totalLen} for setPrimers,
+// [13],[14] fragments and their length over all shards (constants)
+enum { DS_SEMI_LEN = 4, DS_SEMIS_N = 5, DS_REPORTED_LEN = 6, DS_G_SEMIS_N = 8, DS_G_SEMI_LEN = 9, DS_G_PRIMERS = 10, DS_G_TOTALS = 11, DS_G_NF = 13, DS_G_FRAG_LEN = 14 };
+enum { SHARD_TAIL_WORDS = 16 };                       // u32 words behind the 65536 primer decrements that ride on the same all-reduce
 struct AllocState { double total; unsigned long long sum_rn, sum_quota; };
 
 // error flags raised by kernels (never silent): bit 0 error-list cap, 1 error pool, 2 read slot, 3 other
@@ -109,7 +114,8 @@ void launch_errs_semis(hipStream_t s, const uint8_t* g, DevGenomeIdx gx, DevFrag
 void launch_encode_bases(hipStream_t s, uint8_t* g, uint64_t n);
 void launch_genome_bits(hipStream_t s, const uint8_t* g, uint64_t n, uint64_t nwords, unsigned long long* gc_bits, unsigned long long* n_bits,
                         uint32_t* gc_cnt, uint32_t* n_cnt, uint64_t* gc_pref, uint64_t* n_pref, void* temp, size_t temp_bytes);
-void launch_amplify_init(hipStream_t s, int64_t* primer_cnt, int64_t copies, uint32_t* primer_delta, uint32_t* flags, unsigned long long* sums);
+void launch_amplify_init(hipStream_t s, int64_t* primer_cnt, int64_t copies, uint32_t* primer_delta, uint32_t* flags, unsigned long long* sums,
+                         unsigned long long nf_all, unsigned long long frag_len_all, unsigned long long total_primers);
 void launch_primer_update(hipStream_t s, int64_t* primer_cnt, uint32_t* primer_delta);
 void launch_weights(hipStream_t s, DevAmps fulls, uint32_t n, DevTables tb, RngKey key, uint32_t frag_size, double* w);
 void launch_plan_pairs(hipStream_t s, DevFrags fr, DevAmps semis, DevAmps fulls, uint32_t n_fulls, const uint32_t* read_numbers, const uint32_t* pair_off,
@@ -132,7 +138,8 @@ void launch_detlog(hipStream_t s, const double* x, uint32_t n, double* out);
 // gathers up to 12 device scalars (4 or 8 bytes wide) into mail[dsts[i]] (u64 each)
 #define MAIL_SEQ_SLOT 31                                   // mailbox word the sequence number of a post lands in
 void launch_mail(hipStream_t s, const void* const* srcs, const int* widths, const int* dsts, int n, unsigned clear, unsigned long long* mail, unsigned long long seq);   // n <= 16
-void launch_local_totals(hipStream_t s, unsigned long long nf, unsigned long long frag_len, const unsigned long long* dev, unsigned long long* totals);
+void launch_shard_tail(hipStream_t s, uint32_t* primer_delta, unsigned long long* dsums, const uint32_t* new_semis, int with_budgets);
+void launch_primer_update_sharded(hipStream_t s, int64_t* primer_cnt, uint32_t* primer_delta, unsigned long long* dsums);
 
 // first error of any kernel launch / attribute call since the last call (hipSuccess if none)
 hipError_t take_launch_error();

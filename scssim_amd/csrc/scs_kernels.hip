@@ -89,11 +89,40 @@ __device__ __forceinline__ uint32_t rand_indx_thr(const uint32_t* __restrict__ T
 
 // start of Malbac::amplify: createPrimers (4^8 primer types x `copies`, Malbac.cpp:204-234) + the run's device scalars
 __global__ void k_amplify_init(int64_t* __restrict__ cnt, int64_t copies, uint32_t* __restrict__ delta, uint32_t* __restrict__ flags,
-                               unsigned long long* __restrict__ sums) {
+                               unsigned long long* __restrict__ sums, unsigned long long nf_all, unsigned long long frag_len_all, unsigned long long total_primers) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < 65536) { cnt[i] = copies; delta[i] = 0; }
-    if (i < 8) sums[i] = 0;
+    if (i < SHARD_TAIL_WORDS) delta[65536 + i] = 0;
+    if (i < 16) sums[i] = i == DS_G_PRIMERS ? total_primers : i == DS_G_TOTALS || i == DS_G_NF ? nf_all : i == DS_G_TOTALS + 1 || i == DS_G_FRAG_LEN ? frag_len_all : 0ull;
     if (i == 0) flags[0] = 0;
+}
+// sharded job.  What the shards owe each other besides the primer decrements -- the semi amplicons a fragment pass made
+// (count, total length) and the budgets the last setPrimers handed out -- rides on the SAME all-reduce, as 24-bit limbs in
+// 32-bit words behind the 65536 counters: k_shard_tail writes this shard's share before the collective ...
+__global__ void k_shard_tail(uint32_t* __restrict__ delta, unsigned long long* __restrict__ sums, const uint32_t* __restrict__ new_semis, int with_budgets) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    uint32_t* t = delta + 65536;
+    const unsigned long long len = sums[DS_SEMI_LEN] - sums[DS_REPORTED_LEN]; sums[DS_REPORTED_LEN] = sums[DS_SEMI_LEN];
+    t[0] = new_semis ? *new_semis : 0u;
+    t[1] = (uint32_t)(len & 0xFFFFFFull); t[2] = (uint32_t)((len >> 24) & 0xFFFFFFull); t[3] = (uint32_t)(len >> 48);
+    for (int k = 0; k < 2; ++k) {
+        const unsigned long long b = with_budgets ? sums[k] : 0ull;
+        t[4 + 3 * k] = (uint32_t)(b & 0xFFFFFFull); t[5 + 3 * k] = (uint32_t)((b >> 24) & 0xFFFFFFull); t[6 + 3 * k] = (uint32_t)(b >> 48);
+        if (with_budgets) sums[k] = 0;
+    }
+}
+// ... and the stock update after it folds the summed tail into the whole-job scalars that setPrimers reads
+__global__ void k_primer_update_sharded(int64_t* __restrict__ cnt, uint32_t* __restrict__ delta, unsigned long long* __restrict__ sums) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 65536) { const int64_t c = cnt[i] - (int64_t)delta[i]; cnt[i] = c < 0 ? 0 : c; delta[i] = 0; }
+    if (i == 0) {
+        uint32_t* t = delta + 65536;
+        auto limbs = [&](int o) { return (unsigned long long)t[o] + ((unsigned long long)t[o + 1] << 24) + ((unsigned long long)t[o + 2] << 48); };
+        sums[DS_G_SEMIS_N] += t[0]; sums[DS_G_SEMI_LEN] += limbs(1);
+        sums[DS_G_PRIMERS] -= limbs(4) + limbs(7);
+        sums[DS_G_TOTALS] = sums[DS_G_NF] + sums[DS_G_SEMIS_N]; sums[DS_G_TOTALS + 1] = sums[DS_G_FRAG_LEN] + sums[DS_G_SEMI_LEN];
+        for (int k = 0; k < SHARD_TAIL_WORDS; ++k) t[k] = 0;
+    }
 }
 __global__ void k_primer_update(int64_t* __restrict__ cnt, uint32_t* __restrict__ delta) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -927,7 +956,8 @@ __device__ __forceinline__ void block_add_u64(unsigned long long v, unsigned lon
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ double poisson_lambda(const PoissonParams& p, uint32_t len) {
     const uint64_t template_num = p.totals ? p.totals[0] : p.nf + p.dev[DS_SEMIS_N], total_len = p.totals ? p.totals[1] : p.frag_len + p.dev[DS_SEMI_LEN];
-    const unsigned long long expected = (unsigned long long)((double)p.total_primers * p.gamma * (double)template_num);
+    const uint64_t pool = p.total_primers_dev ? *p.total_primers_dev : p.total_primers;
+    const unsigned long long expected = (unsigned long long)((double)pool * p.gamma * (double)template_num);
     return (double)expected * (1.0 * (double)len / (double)total_len);
 }
 // semis: lambda ~ 6 -> one thread per semi amplicon
@@ -1307,15 +1337,15 @@ void launch_genome_bits(hipStream_t s, const uint8_t* g, uint64_t n, uint64_t nw
     (void)rocprim::exclusive_scan(temp, temp_bytes, rocprim::make_transform_iterator((const uint32_t*)gc_cnt, Widen()), gc_pref, (uint64_t)0, nwords + 1, rocprim::plus<uint64_t>(), s);
     (void)rocprim::exclusive_scan(temp, temp_bytes, rocprim::make_transform_iterator((const uint32_t*)n_cnt, Widen()), n_pref, (uint64_t)0, nwords + 1, rocprim::plus<uint64_t>(), s);
 }
-// sharded job: this shard's {templateNum, totalLen} for the all-reduce
-__global__ void k_local_totals(unsigned long long nf, unsigned long long frag_len, const unsigned long long* __restrict__ dev, unsigned long long* __restrict__ totals) {
-    if (threadIdx.x == 0) { totals[0] = nf + dev[DS_SEMIS_N]; totals[1] = frag_len + dev[DS_SEMI_LEN]; }
+void launch_amplify_init(hipStream_t s, int64_t* primer_cnt, int64_t copies, uint32_t* primer_delta, uint32_t* flags, unsigned long long* sums,
+                         unsigned long long nf_all, unsigned long long frag_len_all, unsigned long long total_primers) {
+    hipLaunchKernelGGL(k_amplify_init, dim3(256), dim3(256), 0, s, primer_cnt, copies, primer_delta, flags, sums, nf_all, frag_len_all, total_primers);
 }
-void launch_local_totals(hipStream_t s, unsigned long long nf, unsigned long long frag_len, const unsigned long long* dev, unsigned long long* totals) {
-    hipLaunchKernelGGL(k_local_totals, dim3(1), dim3(64), 0, s, nf, frag_len, dev, totals);
+void launch_shard_tail(hipStream_t s, uint32_t* primer_delta, unsigned long long* dsums, const uint32_t* new_semis, int with_budgets) {
+    hipLaunchKernelGGL(k_shard_tail, dim3(1), dim3(64), 0, s, primer_delta, dsums, new_semis, with_budgets);
 }
-void launch_amplify_init(hipStream_t s, int64_t* primer_cnt, int64_t copies, uint32_t* primer_delta, uint32_t* flags, unsigned long long* sums) {
-    hipLaunchKernelGGL(k_amplify_init, dim3(256), dim3(256), 0, s, primer_cnt, copies, primer_delta, flags, sums);
+void launch_primer_update_sharded(hipStream_t s, int64_t* primer_cnt, uint32_t* primer_delta, unsigned long long* dsums) {
+    hipLaunchKernelGGL(k_primer_update_sharded, dim3(256), dim3(256), 0, s, primer_cnt, primer_delta, dsums);
 }
 void launch_primer_update(hipStream_t s, int64_t* primer_cnt, uint32_t* primer_delta) {
     hipLaunchKernelGGL(k_primer_update, dim3(256), dim3(256), 0, s, primer_cnt, primer_delta);

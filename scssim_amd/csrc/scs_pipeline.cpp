@@ -165,6 +165,7 @@ struct scs_ctx {
     Mail pend;                                                                     // counts of the passes launched since the last collect
     bool timing_gate = true; uint32_t timing_every = 1; uint64_t amplify_calls = 0, yield_calls = 0;   // scs_set_kernel_timing: events on every n-th call
     uint64_t frag_total_len = 0, semi_total_len = 0; uint32_t slots_f = 0, slots_s = 0, budget_ns = 0;
+    uint64_t nf_all = 0, frag_len_all = 0; bool budgets_pending = false;            // sharded job: fragments of ALL shards; budgets not yet exchanged
     DevBuf primer_cnt, primer_delta; uint64_t total_primers = 0; bool amplified = false;
     DevBuf slots, slot_tmpl, valid, valid_off, valid_f, valid_off_f, scan_tmp, flags;
     // allocation + reads
@@ -321,6 +322,7 @@ void do_create_frags(scs_ctx* c) {
         for (size_t i = 0; i < len.size() && sh < cf.shard_count; ++i) { acc += len[i]; while (sh < cf.shard_count && acc * cf.shard_count >= tot * (uint64_t)sh) cut[sh++] = i + 1; }
         lo = cut[cf.shard_rank]; hi = cut[cf.shard_rank + 1];
     }
+    c->nf_all = len.size(); c->frag_len_all = 0; for (auto l : len) c->frag_len_all += l;
     c->f_goff.assign(goff.begin() + lo, goff.begin() + hi); c->f_len.assign(len.begin() + lo, len.begin() + hi);
     c->f_strand.assign(strand.begin() + lo, strand.begin() + hi); c->f_primers.assign(hi - lo, 0); c->f_gidx_base = lo;
     upload(c->df_goff, c->f_goff, c->stream); upload(c->df_len, c->f_len, c->stream); upload(c->df_strand, c->f_strand, c->stream);
@@ -339,11 +341,11 @@ void set_primers_launch(scs_ctx* c, bool only_frags, uint32_t call, uint32_t ns_
     hipStream_t s = c->stream;
     const uint32_t nf = (uint32_t)c->f_len.size(), ns = only_frags ? 0u : ns_cap;
     PoissonParams p; p.key = c->key; p.call = call; p.gamma = c->cfg.gamma; p.total_primers = c->total_primers;
-    p.nf = nf; p.frag_len = c->frag_total_len; p.dev = c->dsums.as<unsigned long long>(); p.totals = nullptr;
-    if (c->sharded()) {                                                            // totals over all shards, reduced on the device
-        launch_local_totals(s, nf, c->frag_total_len, c->dsums.as<unsigned long long>(), c->d_tot.as<unsigned long long>());
-        c->reduce_dev(c->d_tot.p, 2, 8);
-        p.totals = c->d_tot.as<uint64_t>();
+    p.nf = nf; p.frag_len = c->frag_total_len; p.dev = c->dsums.as<unsigned long long>(); p.totals = nullptr; p.total_primers_dev = nullptr;
+    if (c->sharded()) {
+        // whole-job {templateNum, totalLen} and the pool size are device scalars, kept current by the tail of the per-pass
+        // primer all-reduce (launch_pass): no collective of its own here
+        p.totals = c->dsums.as<uint64_t>() + DS_G_TOTALS; p.total_primers_dev = c->dsums.as<unsigned long long>() + DS_G_PRIMERS;
     }
     c->budget_f.reserve(((size_t)nf + 1) * 4, s); c->budget_s.reserve(((size_t)ns + 2) * 4, s);
     c->slot_off_f.reserve(((size_t)nf + 1) * 4, s); c->slot_off_s.reserve(((size_t)ns + 2) * 4, s);
@@ -351,16 +353,28 @@ void set_primers_launch(scs_ctx* c, bool only_frags, uint32_t call, uint32_t ns_
     // sums[0..1] are zero here: the previous call's mail cleared them after reading (k_amplify_init zeroes them first)
     launch_poisson(s, c->frags_view(), c->semis.view(), ns, p, c->budget_f.as<uint32_t>(), c->budget_s.as<uint32_t>(), c->dsums.as<unsigned long long>());
     exclusive_scan_u32_pair(s, c->budget_f.as<uint32_t>(), c->slot_off_f.as<uint32_t>(), nf, ns ? c->budget_s.as<uint32_t>() : nullptr, c->slot_off_s.as<uint32_t>(), ns, c->scan_tmp.p, c->scan_tmp.cap);
-    c->reduce_dev(c->dsums.p, 2, 8);                                               // sharded: budgets of all shards leave the pool
+    const bool sh = c->sharded();                                                  // sharded: the budget sums ride on the next pass's all-reduce (and are cleared there)
+    c->budgets_pending = sh;
     Mail& m = c->pend;                                                             // together with the counts of the passes before (collect_post)
-    m.add(c->dsums.p, 8, 0, true); m.add(c->dsums.as<unsigned long long>() + 1, 8, 1, true); m.add(c->slot_off_f.as<uint32_t>() + nf, 4, 2);
+    m.add(c->dsums.p, 8, 0, !sh); m.add(c->dsums.as<unsigned long long>() + 1, 8, 1, !sh); m.add(c->slot_off_f.as<uint32_t>() + nf, 4, 2);
     m.add(ns ? (const void*)(c->slot_off_s.as<uint32_t>() + ns) : nullptr, 4, 3);  // budgets beyond the real count are 0: the total sits at [ns_cap] too
     mail_post(c, m, true); c->pend = Mail();
 }
 void set_primers_finish(scs_ctx* c) {                                              // after mail_wait (and collect_read: semis.n is current)
     const uint64_t* rb = c->h_rb;
-    c->total_primers -= rb[0] + rb[1];
+    if (!c->sharded()) c->total_primers -= rb[0] + rb[1];                          // sharded: the whole-job pool size comes back with collect_read
     c->slots_f = (uint32_t)rb[2]; c->slots_s = (uint32_t)rb[3]; c->budget_ns = c->semis.n;
+}
+
+// sharded job, end of a pass: ONE all-reduce carries the primer decrements and, behind them, what else the shards owe each
+// other (new semi amplicons of a fragment pass, the budgets of the last setPrimers); the update folds it into the device
+// scalars the next setPrimers reads.
+void shard_exchange(scs_ctx* c, const uint32_t* new_semis) {
+    hipStream_t s = c->stream;
+    launch_shard_tail(s, c->primer_delta.as<uint32_t>(), c->dsums.as<unsigned long long>(), new_semis, c->budgets_pending ? 1 : 0);
+    c->budgets_pending = false;
+    c->reduce_dev(c->primer_delta.p, 65536 + SHARD_TAIL_WORDS, 4);
+    launch_primer_update_sharded(s, c->primer_cnt.as<int64_t>(), c->primer_delta.as<uint32_t>(), c->dsums.as<unsigned long long>());
 }
 
 // ---------------------------------------------------------------- one amplification pass (a4 / a5): launches only, no host sync.
@@ -370,7 +384,7 @@ void launch_pass(scs_ctx* c, bool from_frag, uint32_t pass, int rb_slot) {
     const uint32_t nt = from_frag ? (uint32_t)c->f_len.size() : c->budget_ns;
     const uint32_t n_slots = from_frag ? c->slots_f : c->slots_s;
     if (nt == 0 || n_slots == 0) {                                                 // nothing local; a shard still joins the pass's collective
-        if (c->sharded()) { c->reduce_dev(c->primer_delta.p, 65536, 4); launch_primer_update(s, c->primer_cnt.as<int64_t>(), c->primer_delta.as<uint32_t>()); }
+        if (c->sharded()) shard_exchange(c, nullptr);
         c->pend.add(nullptr, 8, rb_slot);
         if (!from_frag) { for (int b = 0; b < 8; ++b) c->pend.add(nullptr, 8, 16 + b); c->pending_seg_cycle = (int)pass; }
         return;
@@ -408,10 +422,8 @@ void launch_pass(scs_ctx* c, bool from_frag, uint32_t pass, int rb_slot) {
                            valid_off.as<uint32_t>(), out.view(), out.n, out.pool_view(), c->flags.as<uint32_t>(), c->d_binom.as<unsigned long long>(), p,
                            ride ? c->primer_cnt.as<int64_t>() : nullptr, c->primer_delta.as<uint32_t>());
     tm.end(s);
-    if (!ride) {
-        c->reduce_dev(c->primer_delta.p, 65536, 4);                                // sharded: stock decrements of all shards
-        launch_primer_update(s, c->primer_cnt.as<int64_t>(), c->primer_delta.as<uint32_t>());
-    }
+    if (c->sharded()) shard_exchange(c, from_frag ? valid_off.as<uint32_t>() + nt : nullptr);
+    else if (!ride) launch_primer_update(s, c->primer_cnt.as<int64_t>(), c->primer_delta.as<uint32_t>());
     {   // counts of this pass -> mailbox (read by the host at the group's sync): new amplicons, and for a semi pass the
         // fulls made from the semis of each fragment pass (segments)
         c->pend.add(valid_off.as<uint32_t>() + nt, 4, rb_slot);
@@ -424,6 +436,7 @@ void launch_pass(scs_ctx* c, bool from_frag, uint32_t pass, int rb_slot) {
 // closing a group of passes: their counts go to the mailbox (and the new semi count into the device scalars) ...
 void collect_post(scs_ctx* c, bool post_now) {
     c->pend.add(c->dsums.as<unsigned long long>() + DS_SEMI_LEN, 8, 8);
+    if (c->sharded()) c->pend.add(c->dsums.as<unsigned long long>() + DS_G_PRIMERS, 8, 9);
     if (post_now) { mail_post(c, c->pend, true); c->pend = Mail(); }               // else: rides on the next setPrimers mail
 }
 // ... and are taken over by the host after the next mail_wait: counts of new amplicons, total length of the semis
@@ -441,6 +454,7 @@ void collect_read(scs_ctx* c, int rb_fulls, int rb_semis) {
     }
     if (rb_semis >= 0) { c->semis.n += (uint32_t)c->h_rb[rb_semis]; c->tm_errscan_f.add_units(c->h_rb[rb_semis]); c->semi_block_end.push_back(c->semis.n); }
     c->semi_total_len = c->h_rb[8];
+    if (c->sharded()) c->total_primers = c->h_rb[9];                               // whole-job pool size after the budgets exchanged so far
 }
 
 // ---------------------------------------------------------------- Malbac::amplify (Malbac.cpp:173-201)
@@ -452,8 +466,9 @@ void do_amplify(scs_ctx* c) {
     c->semis.reset(s); c->fulls.reset(s); c->semi_block_end.clear(); c->full_segs.clear(); c->pending_seg_cycle = -1; c->have_gidx = false; c->pend = Mail();
     c->timing_gate = (c->amplify_calls++ % c->timing_every) == 0;
     c->tm_errscan.reset(); c->tm_errscan_f.reset(); c->tm_attach.reset();
-    c->primer_cnt.reserve(65536 * 8, s); c->primer_delta.reserve(65536 * 4, s);   // createPrimers: 4^8 types x `primers` copies
-    launch_amplify_init(s, c->primer_cnt.as<int64_t>(), (int64_t)c->cfg.primers, c->primer_delta.as<uint32_t>(), c->flags.as<uint32_t>(), c->dsums.as<unsigned long long>());
+    c->primer_cnt.reserve(65536 * 8, s); c->primer_delta.reserve((65536 + SHARD_TAIL_WORDS) * 4, s);   // createPrimers: 4^8 types x `primers` copies
+    launch_amplify_init(s, c->primer_cnt.as<int64_t>(), (int64_t)c->cfg.primers, c->primer_delta.as<uint32_t>(), c->flags.as<uint32_t>(), c->dsums.as<unsigned long long>(),
+                        c->nf_all, c->frag_len_all, 65536ull * (uint64_t)c->cfg.primers);
     if (!c->d_binom.p) {   // [REMAP] error-count thresholds for every window length (cfg is fixed for the ctx lifetime)
         std::vector<uint64_t> bt = binom_table(c->cfg.ber, c->cfg.amplicon_min_len - 8, c->cfg.amplicon_max_len - 8);
         upload(c->d_binom, bt, s); HIP_OK(hipStreamSynchronize(s));
