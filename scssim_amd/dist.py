@@ -2,8 +2,8 @@
 merge of per-shard FASTQ pools into the single-job order.
 
 A job is sharded by fragment lineage.  What crosses shards:
-  * setPrimers: all-reduce of {template count, total template length} and of the budgets' sum  (3 scalars / cycle)
-  * each pass: all-reduce of the 65536 primer-stock decrements                                   (256-512 KB)
+  * each pass: ONE all-reduce of the 65536 primer-stock decrements + a 16-word tail that carries what setPrimers needs
+    from the other shards (new semi amplicons: count and length; the budgets handed out)          (256 KB, 11 per job)
   * read allocation: all-reduce of the 5x6 segment sizes + all-gather of the GC weights
   * output: every record name carries the amplicon's index in the whole job's list, and each shard's pool is
     already sorted by it, so the writer k-way merges the pools (`merge_fastq`).
