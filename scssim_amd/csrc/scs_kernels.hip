@@ -372,18 +372,19 @@ __global__ void k_plan_pairs(DevFrags fr, DevAmps semis, DevAmps fulls, uint32_t
 }
 
 // ------------------------------------------------------------------------------------------------
-// K5  inject_errors = Profile::predict (lib/profile/Profile.cpp:1582-1697) + window extraction
-//     (Amplicon::yieldReads, Amplicon.cpp:492-528).  One THREAD per read, one workgroup per 256 reads of
-//     the same mate:
+// K5  inject_errors = Profile::predict (lib/profile/Profile.cpp:1582-1697) + window extraction and record formatting
+//     (Amplicon::yieldReads, Amplicon.cpp:459-541).  One THREAD per read, one workgroup per 256 reads of the same mate:
 //       * staging: the read windows are gathered through the pair records' index maps, a dword (4 bases) per lane,
 //         one load instruction per read, into an LDS tile with two bases per byte;
-//       * phase 1 (per thread): the indel tests of every input base -> event list (LDS), n';
+//       * phase 1, the indel tests of every input base (event list, n'), ran in k_indels over the whole batch first
+//         (pair mode; explicit-window mode does it here): n' fixes the FASTQ record sizes, hence the record offsets;
 //       * phase 2, the base pass, is workgroup-synchronous over the TABLE BINS: position j of a read uses bin
 //         j*bins/n', so all 256 reads look up the same bin at the same time and a small ring of bins in LDS
 //         (64 k-mer substitution rows + the 4 diagonal quality rows per bin), refilled a group of bins ahead
 //         through registers, serves every lookup.  A wave whose reads all sit on clean k-mers takes a branch-free
-//         fast step; first-two-bases / N k-mers take the general step; substituted bases (off-diagonal quality
-//         row, global) are resolved after the loop.
+//         fast step; first-two-bases / N k-mers take the general step;
+//       * output (pair mode): the FASTQ text itself, 16 characters per store, realigned in registers to the record's
+//         byte offset (emit_block / emit_tail); explicit-window mode writes sequence/quality slots.
 //     LDS per workgroup at L = 150: 13-16 KB ring + 4 KB events + 19 KB windows -> 4 workgroups per CU.
 // ------------------------------------------------------------------------------------------------
 #define RB 256
