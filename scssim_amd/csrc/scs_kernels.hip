@@ -627,16 +627,14 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
                 for (int u = 0; u < FLY; ++u) {
                     const int rr = wib * 64 + q0 + u; const uint32_t f = s_gflag[rr];
                     const int64_t b0 = s_gbase[rr];
-                    uint32_t v = 0;
-                    if ((f & 4u) && k4 < n) {
-                        if (k4 + 4 <= n) {
-                            if (f & 2u) { __builtin_memcpy(&v, g + (b0 - k4 - 3), 4); v = __builtin_bswap32(v); }
-                            else __builtin_memcpy(&v, g + (b0 + k4), 4);
-                        } else {                                                    // the window's last, partial group: stay inside it
-                            const int64_t d = (f & 2u) ? -1 : 1;
-                            for (int j = 0; k4 + j < n; ++j) v |= (uint32_t)g[b0 + d * (int64_t)(k4 + j)] << (8 * j);
-                        }
-                    }
+                    // branch-free: one unconditional dword load per lane and read, so that all FLY loads are in flight together
+                    // (a load under a divergent branch is waited for at the join).  The window's last, partial group loads
+                    // the last whole dword of the window and shifts; lanes past the window load it too and drop it.
+                    const int kk = k4 < n - 4 ? k4 : n - 4, drop = k4 - kk;            // n >= 4
+                    uint32_t v;
+                    __builtin_memcpy(&v, g + ((f & 2u) ? b0 - kk - 3 : b0 + kk), 4);
+                    if (f & 2u) v = __builtin_bswap32(v);
+                    v = drop < 4 ? v >> (8 * drop) : 0u;
                     cv[u] = v;
                 }
 #pragma unroll

@@ -265,6 +265,7 @@ void do_load_profile(scs_ctx* c, const char* path) {
     t.gc_means = c->d_gcmeans.as<double>(); t.gc_std = P.gc_std;
     // inject_errors keeps 256 read windows + indel events + a 16 KB table ring in one workgroup's LDS, and its bin index
     // is a 32-bit multiply-high (exact while position * bins * length < 2^32)
+    if (P.read_length < 4) throw ScsError(SCS_EINVAL, "read length < 4 not supported by the inject_errors kernel");
     if (reads_lds_bytes(t) > 160u * 1024u - 64u) throw ScsError(SCS_EINVAL, "read length too large for the inject_errors kernel (LDS tile)");
     if ((uint64_t)(P.read_length + 128) * (uint64_t)(P.read_length + 128) * (uint64_t)P.bins >= (1ull << 32))
         throw ScsError(SCS_EINVAL, "read length x bin count too large for the inject_errors kernel");
