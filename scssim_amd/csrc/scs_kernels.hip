@@ -49,6 +49,16 @@ __device__ __forceinline__ uint32_t view_base(const uint8_t* __restrict__ g, Vie
     return v.comp ? (uint32_t)comp_code((uint8_t)c) : c;
 }
 
+// bases i .. i+7 of a view in one 8-byte load: byte k = base i+k (codes 0-3 ACGT, 4 = N)
+__device__ __forceinline__ unsigned long long view_bases8(const uint8_t* __restrict__ g, View v, uint32_t i) {
+    const int64_t a = v.base + (int64_t)v.dir * (int64_t)i;
+    unsigned long long x;
+    __builtin_memcpy(&x, g + (v.dir > 0 ? a : a - 7), 8);
+    if (v.dir < 0) x = __builtin_bswap64(x);
+    if (v.comp) x ^= 0x0303030303030303ull & ~(((x >> 2) & 0x0101010101010101ull) * 3ull);   // 3 - c for ACGT, N stays
+    return x;
+}
+
 // iterate the error entries of an amplicon (inline u16 x4, or overflow list)
 template <class F>
 __device__ __forceinline__ void for_each_err(uint64_t e, const uint32_t* __restrict__ pool, F f) {
@@ -1077,11 +1087,17 @@ __global__ void __launch_bounds__(64) k_attach(const uint8_t* __restrict__ g, De
                     if (tries > 50) { dead = true; break; }
                     if (spos + alen > len) continue;
                     if ((bits[spos >> 5] >> (spos & 31)) & 1u) continue;                  // posAttached[spos]
-                    uint32_t idx = 0; bool hasN = false;                                 // primer 8-mer of the template strand
-                    for (uint32_t k = 0; k < 8; ++k) {
-                        const uint32_t c = FROM_FRAG ? view_base(g, tv, spos + k) : semi_tmpl_base(g, tv, len, errs, spool.data, spos + k);
-                        hasN |= c > 3; idx = (idx << 2) | (c & 3u);
-                    }
+                    // primer 8-mer of the template strand: the 8 bases are contiguous in the genome -> ONE 8-byte load (reversed /
+                    // complemented in registers), then the semi's own substitutions are patched in (no load sits under a branch)
+                    unsigned long long v8 = view_bases8(g, tv, spos);
+                    if (!FROM_FRAG) for_each_err(errs, spool.data, [&](uint32_t e) {
+                        const uint32_t k = len - 1u - err_pos(e) - spos;                 // template position of the error, relative to spos
+                        if (k < 8u) v8 = (v8 & ~(0xFFull << (8u * k))) | ((unsigned long long)(3u - err_alt(e)) << (8u * k));
+                    });
+                    const bool hasN = (v8 & 0xFCFCFCFCFCFCFCFCull) != 0;
+                    uint32_t idx = 0;
+#pragma unroll
+                    for (uint32_t k = 0; k < 8; ++k) idx = (idx << 2) | ((uint32_t)(v8 >> (8u * k)) & 3u);
                     if (hasN || primer_cnt[idx] <= 0) continue;                          // no stock for N 8-mers; [REMAP] stock as of pass start
                     pidx = idx; need = false;
                 }
