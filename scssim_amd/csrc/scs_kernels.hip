@@ -3,6 +3,7 @@
 // Built with -ffp-contract=off: the few fp64 expressions must round exactly like the CPU oracle.
 #include "scs_device.h"
 
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <rocprim/rocprim.hpp>
@@ -1335,7 +1336,8 @@ void launch_errs_frags(hipStream_t s, const uint8_t* g, DevGenomeIdx gx, DevFrag
                        const unsigned long long* binom, AmplifyParams p, int64_t* primer_cnt, uint32_t* primer_delta, unsigned long long* semis_n) {
     if (n_slots == 0) return;
     DevAmps none{}; DevErrPool np{};
-    hipLaunchKernelGGL(k_errs<true>, dim3(cdiv(n_slots, 256)), dim3(256), 0, s, g, gx, fr, none, np, n_slots, slot_off, slots, slot_tmpl, valid_off, fr.n, out, out_base, pool, flags, binom, p,
+    // a riding stock update wants every primer type covered with one entry per thread: never fewer than 256 workgroups
+    hipLaunchKernelGGL(k_errs<true>, dim3(primer_cnt ? std::max(cdiv(n_slots, 256), 256u) : cdiv(n_slots, 256)), dim3(256), 0, s, g, gx, fr, none, np, n_slots, slot_off, slots, slot_tmpl, valid_off, fr.n, out, out_base, pool, flags, binom, p,
                        primer_cnt, primer_delta, semis_n);
 }
 void launch_errs_semis(hipStream_t s, const uint8_t* g, DevGenomeIdx gx, DevFrags fr, DevAmps semis, uint32_t n_semis, DevErrPool spool, uint32_t n_slots,
@@ -1343,7 +1345,7 @@ void launch_errs_semis(hipStream_t s, const uint8_t* g, DevGenomeIdx gx, DevFrag
                        DevAmps out, uint32_t out_base, DevErrPool pool, uint32_t* flags, const unsigned long long* binom, AmplifyParams p,
                        int64_t* primer_cnt, uint32_t* primer_delta) {
     if (n_slots == 0) return;
-    hipLaunchKernelGGL(k_errs<false>, dim3(cdiv(n_slots, 256)), dim3(256), 0, s, g, gx, fr, semis, spool, n_slots, slot_off, slots, slot_tmpl, valid_off, n_semis, out, out_base, pool, flags, binom, p,
+    hipLaunchKernelGGL(k_errs<false>, dim3(primer_cnt ? std::max(cdiv(n_slots, 256), 256u) : cdiv(n_slots, 256)), dim3(256), 0, s, g, gx, fr, semis, spool, n_slots, slot_off, slots, slot_tmpl, valid_off, n_semis, out, out_base, pool, flags, binom, p,
                        primer_cnt, primer_delta, (unsigned long long*)nullptr);
 }
 void launch_genome_bits(hipStream_t s, const uint8_t* g, uint64_t n, uint64_t nwords, unsigned long long* gc_bits, unsigned long long* n_bits,

@@ -411,9 +411,9 @@ void launch_pass(scs_ctx* c, bool from_frag, uint32_t pass, int rb_slot) {
     c->tm_attach.add_units(nt);
     exclusive_scan_u32(s, valid.as<uint32_t>(), valid_off.as<uint32_t>(), nt, c->scan_tmp.p, c->scan_tmp.cap);
     KernelTimer& tm = from_frag ? c->tm_errscan_f : c->tm_errscan;
-    // the stock update rides on k_errs when its grid covers the 65536 primer types with one entry per thread (a small
-    // grid would walk them serially); a sharded job all-reduces the decrements first
-    const bool ride = !c->sharded() && n_slots >= 65536u;
+    // the stock update rides on k_errs (launched with at least 256 workgroups: one primer type per thread); a sharded job
+    // all-reduces the decrements first
+    const bool ride = !c->sharded();
     tm.begin(s);
     const DevGenomeIdx gx{c->gx_gc_bits.as<unsigned long long>(), c->gx_n_bits.as<unsigned long long>(), c->gx_gc_pref.as<uint64_t>(), c->gx_n_pref.as<uint64_t>()};
     if (from_frag) launch_errs_frags(s, g, gx, fr, n_slots, slot_off, c->slots.as<uint32_t>(), c->slot_tmpl.as<uint32_t>(), valid_off.as<uint32_t>(),
@@ -424,7 +424,6 @@ void launch_pass(scs_ctx* c, bool from_frag, uint32_t pass, int rb_slot) {
                            ride ? c->primer_cnt.as<int64_t>() : nullptr, c->primer_delta.as<uint32_t>());
     tm.end(s);
     if (c->sharded()) shard_exchange(c, from_frag ? valid_off.as<uint32_t>() + nt : nullptr);
-    else if (!ride) launch_primer_update(s, c->primer_cnt.as<int64_t>(), c->primer_delta.as<uint32_t>());
     {   // counts of this pass -> mailbox (read by the host at the group's sync): new amplicons, and for a semi pass the
         // fulls made from the semis of each fragment pass (segments)
         c->pend.add(valid_off.as<uint32_t>() + nt, 4, rb_slot);
