@@ -38,7 +38,14 @@ class Collectives:
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
         self.stream = stream
-        self.device = device if device is not None else ("cuda" if dist.get_backend() == "nccl" else "cpu")
+        self._nccl = dist.get_backend() == "nccl"
+        # the hooks are called from the thread that drives the job: make the ctx stream that thread's current stream once,
+        # instead of entering a stream context per collective (a Python context manager per call costs ~10 us)
+        self._stream_is_current = False
+        if stream is not None and self._nccl:
+            torch.cuda.set_stream(stream)
+            self._stream_is_current = True
+        self.device = device if device is not None else ("cuda" if self._nccl else "cpu")
         self.world = dist.get_world_size()
         self.rank = dist.get_rank()
         self.allreduce_cb = ALLREDUCE_FN(self._allreduce)
@@ -62,13 +69,15 @@ class Collectives:
 
     def _on_stream(self):
         import contextlib
-        return self.torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()
+        if self.stream is None or (self._stream_is_current and self.torch.cuda.current_stream() == self.stream):
+            return contextlib.nullcontext()
+        return self.torch.cuda.stream(self.stream)
 
     def _allreduce_dev(self, _user, d_vals, n, elem_bytes):
         try:
             with self._on_stream():
                 t = self._dev_tensor(d_vals, n, elem_bytes)      # uint sums as two's-complement ints: same bits
-                if self.dist.get_backend() == "nccl":
+                if self._nccl:
                     self.dist.all_reduce(t)
                 else:
                     h = t.cpu()
@@ -87,7 +96,7 @@ class Collectives:
             with self._on_stream():
                 src = self._dev_tensor(d_send, nbytes, 1)
                 dst = self._dev_tensor(d_recv, int(nbytes) * self.world, 1)
-                if self.dist.get_backend() == "nccl":
+                if self._nccl:
                     self.dist.all_gather_into_tensor(dst, src)
                 else:
                     h = src.cpu()
