@@ -1387,12 +1387,16 @@ size_t reads_lds_bytes(const DevTables& tb) {
 template <bool FROM_PAIRS, class... Args>
 static void launch_reads_kernel(hipStream_t s, dim3 grid, const DevTables& tb, Args... args) {
     const size_t lds = reads_lds_bytes(tb);
-    // > 64 KB of dynamic LDS needs the opt-in; the limit is raised to exactly what this profile needs
+    // > 64 KB of dynamic LDS needs the opt-in; the limit is raised to exactly what this profile needs (once per size:
+    // the call sits on the host's critical path of a small job)
+    static size_t opted_all[64][2] = {};                                           // per device (the attribute belongs to the device's code object)
+    int dev = 0; (void)hipGetDevice(&dev);
+    size_t* opted = opted_all[dev & 63];
     if (tb.qual_big) {
-        note_launch(hipFuncSetAttribute((const void*)k_reads<FROM_PAIRS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (opted[1] != lds) { note_launch(hipFuncSetAttribute((const void*)k_reads<FROM_PAIRS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); opted[1] = lds; }
         hipLaunchKernelGGL((k_reads<FROM_PAIRS, true>), grid, dim3(RB), lds, s, args...);
     } else {
-        note_launch(hipFuncSetAttribute((const void*)k_reads<FROM_PAIRS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (opted[0] != lds) { note_launch(hipFuncSetAttribute((const void*)k_reads<FROM_PAIRS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); opted[0] = lds; }
         hipLaunchKernelGGL((k_reads<FROM_PAIRS, false>), grid, dim3(RB), lds, s, args...);
     }
 }
