@@ -177,12 +177,19 @@ struct scs_ctx {
     DevBuf d_tot, d_stage, d_all, d_mail;
     std::vector<uint32_t> semi_block_end;                  // local semi count after each fragment pass
     struct Seg { int c, p; uint32_t count; }; std::vector<Seg> full_segs;   // local fulls list = these, in order
-    DevBuf d_gidx, d_gw, d_grn; bool have_gidx = false;
+    DevBuf d_gidx, d_gw, d_grn, d_hostred; bool have_gidx = false;
     int pending_seg_cycle = -1;
     // collectives run when the job is sharded -- or whenever hooks are installed (1-shard jobs then exercise them too)
     bool sharded() const { return cfg.shard_count > 1 || allreduce || allreduce_dev; }
     void reduce(uint64_t* v, uint64_t n) {
         if (!sharded()) return;
+        if (allreduce_dev) {                                                       // device hook installed: two small copies beat the host hook's round trip
+            d_hostred.reserve(n * 8, stream);
+            HIP_OK(hipMemcpyAsync(d_hostred.p, v, n * 8, hipMemcpyHostToDevice, stream));
+            if (allreduce_dev(coll_dev_user, d_hostred.p, n, 8)) throw ScsError(SCS_EINVAL, "sharded job: device all-reduce hook failed");
+            HIP_OK(hipMemcpyAsync(v, d_hostred.p, n * 8, hipMemcpyDeviceToHost, stream)); HIP_OK(hipStreamSynchronize(stream));
+            return;
+        }
         if (!allreduce || allreduce(coll_user, v, n)) throw ScsError(SCS_EINVAL, "sharded job: all-reduce hook missing or failed (scs_set_collectives)");
     }
     // sum a device array over all shards, in place, ordered on the ctx stream when the device hook is set
