@@ -47,7 +47,7 @@ def cpu_baseline(fa, prof, seed):
     oracle = os.path.join(ROOT, "oracle", "_build", "scs_oracle")
     if not os.path.exists(oracle):
         subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
-    cores = os.cpu_count() or 1
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     r = subprocess.run([oracle, "genreads", "-i", fa, "-m", prof, "-c", "30", "-t", str(cores), "-o", fa + ".cpu",
                         "--rng", "counter", "--seed", str(seed)], capture_output=True, text=True, check=True)
     m = re.search(r"pairs=(\d+) \| load ([\d.]+)s frag ([\d.]+)s amplify ([\d.]+)s alloc ([\d.]+)s readgen ([\d.]+)s", r.stderr)
