@@ -394,8 +394,10 @@ __global__ void k_plan_pairs(DevFrags fr, DevAmps semis, DevAmps fulls, uint32_t
 //         (64 k-mer substitution rows + the 4 diagonal quality rows per bin), refilled a group of bins ahead
 //         through registers, serves every lookup.  A wave whose reads all sit on clean k-mers takes a branch-free
 //         fast step; first-two-bases / N k-mers take the general step;
-//       * output (pair mode): the FASTQ text itself, 16 characters per store, realigned in registers to the record's
-//         byte offset (emit_block / emit_tail); explicit-window mode writes sequence/quality slots.
+//       * output (pair mode): the FASTQ text itself, realigned in registers to the record's byte offset and stored as
+//         whole 32-byte aligned sectors (SectorOut); the workgroup's reads are handed to its lanes ordered by the sector
+//         phase of their records, so that the lanes of a wave cross sector boundaries together.  Explicit-window mode
+//         writes sequence/quality slots.
 //     LDS per workgroup at L = 150: 13-16 KB ring + 4 KB events + 19 KB windows -> 4 workgroups per CU.
 // ------------------------------------------------------------------------------------------------
 #define RB 256
@@ -545,36 +547,68 @@ __global__ void __launch_bounds__(256) k_indels(const PairRec* __restrict__ pair
 }
 
 // ---- FASTQ text straight from the base pass (pair mode).  A record is two byte streams per read: the name line + bases +
-// "\n+\n", and the qualities + "\n".  A lane produces its characters four to a register word and sixteen to a block; a
-// stream starts at an arbitrary byte address T, so blocks are realigned in registers (v_alignbyte against the previous
-// word) and stored as ALIGNED dwords from Ta = T & ~3.  The bytes of a stream's first aligned dword that lie before T
-// are the end of what precedes it in the record, and are known: the tail of the name line for the bases, the tail of
-// "\n+\n" for the qualities -- so every dword except the record's very last one is written whole, exactly once.
-__device__ __forceinline__ uint32_t shifted_word(uint32_t cur, uint32_t prev, uint32_t s) {   // stream bytes 4k-s .. 4k-s+3; s = T & 3
-    return s ? __builtin_amdgcn_alignbyte(cur, prev, 4u - s) : cur;
-}
-__device__ __forceinline__ void emit_block(char* __restrict__ dst, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t& carry, uint32_t s) {
-    *reinterpret_cast<uint4*>(dst) = make_uint4(shifted_word(w0, carry, s), shifted_word(w1, w0, s), shifted_word(w2, w1, s), shifted_word(w3, w2, s));   // dword aligned
-    carry = w3;
-}
-// the last (partial) block of a stream: nbv valid bytes in w0..w3, then `sep` (seplen bytes), written up to `end`
-// (exclusive).  Whole dwords as far as they go; the <= 3 bytes left (only a record's very end) as bytes.
-__device__ __forceinline__ void emit_tail(char* __restrict__ dst, char* __restrict__ end, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t nbv,
-                                          uint32_t sep, uint32_t carry, uint32_t s) {
-    const unsigned long long sv = (unsigned long long)sep << (8u * (nbv & 3u));
-    const uint32_t wi = nbv >> 2, lo = (uint32_t)sv, hi = (uint32_t)(sv >> 32);
-    uint32_t w4 = 0, w5 = 0;
-    w0 |= wi == 0u ? lo : 0u; w1 |= wi == 1u ? lo : (wi == 0u ? hi : 0u); w2 |= wi == 2u ? lo : (wi == 1u ? hi : 0u);
-    w3 |= wi == 3u ? lo : (wi == 2u ? hi : 0u); w4 |= wi == 4u ? lo : (wi == 3u ? hi : 0u); w5 |= wi == 4u ? hi : 0u;
-    const uint32_t d[6] = {shifted_word(w0, carry, s), shifted_word(w1, w0, s), shifted_word(w2, w1, s), shifted_word(w3, w2, s),
-                           shifted_word(w4, w3, s), shifted_word(w5, w4, s)};
-    const uint32_t nbytes = (uint32_t)(end - dst), nd = nbytes >> 2, rem = nbytes & 3u;
+// "\n+\n", and the qualities + "\n".  A lane produces its characters four to a register word; a stream starts at an
+// arbitrary byte address T, so words are realigned in registers (v_alignbyte against the previous word) into the ALIGNED
+// dwords from Ta = T & ~3.  The bytes of a stream's first aligned dword that lie before T are the end of what precedes
+// it in the record, and are known: the tail of the name line for the bases, the tail of "\n+\n" for the qualities -- so
+// every dword except the record's very last one is written whole, exactly once.
+// The aligned dwords are collected eight at a time in a shift register (newest in r[7]) and leave as one whole, 32-byte
+// aligned sector (two dwordx4 stores back to back): a lane's partial lines do not survive in L2 until its next store
+// 16 positions later (the open lines of all lanes exceed the L2), so anything smaller than a sector is written to memory
+// as a masked sector each time.  Only a stream's first and last sector go out as single dwords.
+struct SectorOut {
+    uint32_t r[8]; uint32_t prev; uint32_t wo;                                     // wo: offset of the 32-byte aligned sector being filled from the workgroup's base
+    __device__ __forceinline__ void shift_in(uint32_t w) {
 #pragma unroll
-    for (uint32_t k = 0; k < 6; ++k) {
-        if (k < nd) reinterpret_cast<uint32_t*>(dst)[k] = d[k];
-        else if (k == nd) for (uint32_t i = 0; i < rem; ++i) dst[4u * k + i] = (char)(d[k] >> (8u * i));
+        for (int i = 0; i < 7; ++i) r[i] = r[i + 1];
+        r[7] = w;
     }
-}
+    __device__ __forceinline__ void store_full(char* __restrict__ base) {
+        reinterpret_cast<uint4*>(base + wo)[0] = make_uint4(r[0], r[1], r[2], r[3]);
+        reinterpret_cast<uint4*>(base + wo)[1] = make_uint4(r[4], r[5], r[6], r[7]);
+        wo += 32u;
+    }
+    __device__ __forceinline__ void store_range(char* __restrict__ base, uint32_t lo, uint32_t hi) {   // sector dwords lo..hi, held in r[lo..hi]
+#pragma unroll
+        for (uint32_t j = 0; j < 8; ++j) if (j >= lo && j <= hi) reinterpret_cast<uint32_t*>(base + wo)[j] = r[j];
+    }
+    // raw word number k of the stream (its characters 4k..4k+3) completes aligned dword k; pos = dw + k counts dwords
+    // from the first sector's base (dw = dword of Ta inside that sector)
+    __device__ __forceinline__ void push(char* __restrict__ base, uint32_t raw, uint32_t s, uint32_t dw, uint32_t pos) {
+        shift_in(s ? __builtin_amdgcn_alignbyte(raw, prev, 4u - s) : raw);
+        prev = raw;
+        if ((pos & 7u) == 7u) {
+            if (pos == 7u && dw) { store_range(base, dw, 7u); wo += 32u; }         // the stream's first sector starts inside it
+            else store_full(base);
+        }
+    }
+    // the read's last characters: raw word k0 (nv valid bytes, 4 if whole) followed by `sep`; the stream holds `nd` whole
+    // aligned dwords and `rem` (< 4) bytes after them (only a record's very end has rem != 0)
+    __device__ __forceinline__ void finish(char* __restrict__ base, uint32_t raw, uint32_t nv, uint32_t sep, uint32_t s, uint32_t dw, uint32_t k0, uint32_t nd, uint32_t rem) {
+        const unsigned long long sv = (unsigned long long)sep << (8u * (nv & 3u));
+        const uint32_t ext[3] = {nv < 4u ? raw | (uint32_t)sv : raw, nv < 4u ? (uint32_t)(sv >> 32) : sep, 0u};
+        uint32_t filled = k0 ? dw + k0 : 0u;                                       // 1 + position of the last dword shifted in (0: none yet)
+#pragma unroll
+        for (uint32_t i = 0; i < 3; ++i) {
+            const uint32_t k = k0 + i, pos = dw + k;
+            const uint32_t w = s ? __builtin_amdgcn_alignbyte(ext[i], prev, 4u - s) : ext[i];
+            if (k < nd) {
+                shift_in(w); prev = ext[i]; filled = pos + 1u;
+                if ((pos & 7u) == 7u) {
+                    if (pos == 7u && dw) { store_range(base, dw, 7u); wo += 32u; }
+                    else store_full(base);
+                }
+            } else if (k == nd) {
+                for (uint32_t b = 0; b < rem; ++b) base[wo + 4u * (pos & 7u) + b] = (char)(w >> (8u * b));
+            }
+        }
+        if (filled & 7u) {                                                         // the stream's last sector is not whole
+            const uint32_t idx = (filled - 1u) & 7u;
+            for (uint32_t m = idx; m < 7u; ++m) shift_in(0u);                      // bring sector dword j into r[j]
+            store_range(base, filled <= 8u ? dw : 0u, idx);
+        }
+    }
+};
 
 template <bool FROM_PAIRS, bool QBIG>
 __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, DevErrPool spool, DevErrPool fpool, const PairRec* __restrict__ pairs,
@@ -601,14 +635,49 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
     uint8_t* s_win = reinterpret_cast<uint8_t*>(s_ev + RB * EV_MAX);       // [RB][WS]
     const int tid = threadIdx.x, lane = tid & 63, wib = tid >> 6;
 
+    // the workgroup's records are contiguous: stores address them as a uniform base (aligned down to a sector) + a 32-bit offset
+    const bool second_file = FROM_PAIRS && paired && (blockIdx.x & 1u);
+    const uint64_t* __restrict__ offs = second_file ? off2 : off1;
+    char* __restrict__ outp = second_file ? out2 : out1;
+    const uint64_t off0 = FROM_PAIRS ? offs[(paired ? blockIdx.x >> 1 : blockIdx.x) * RB] : 0ull;
+    const uint32_t adj = (uint32_t)(reinterpret_cast<uintptr_t>(outp) + off0) & 31u;
+    char* __restrict__ wg_out = outp + off0 - adj;
+
     // ---- which read is mine
     uint32_t r, pi = 0, rd; bool valid; PairRec pr{}; uint64_t uid = 0; uint32_t att = 0;
+    uint32_t rec_rel = 0, rec_h = 0;                                               // pair mode: my record's offset from wg_out, length of its name line
     if (FROM_PAIRS) {
         const uint32_t q = paired ? blockIdx.x >> 1 : blockIdx.x;
         rd = paired ? (blockIdx.x & 1u) : 0u;
-        pi = q * RB + tid; valid = pi < np;
+        // The workgroup's 256 reads are handed to its lanes ORDERED BY THE SECTOR PHASE of their bases (byte address & 31):
+        // a lane stores a sector whenever its stream crosses a 32-byte boundary, and lanes of one wave that do so at the
+        // same positions share the store instructions.  (Which lane makes which read does not show in the output.)
+        uint32_t* s_cnt = reinterpret_cast<uint32_t*>(s_win); uint32_t* s_perm = s_cnt + 64;   // s_win is free until the staging
+        auto record_of = [&](uint32_t p, PairRec& o, uint32_t& rel, uint32_t& h) {
+            o = pairs[p];
+            const uint32_t amp = amp_index_base + o.amp, cnt = o.att + 1u;
+            h = 1u + dec_digits(amp) + 1u + dec_digits(cnt) + (paired ? 2u : 0u) + 1u;   // "@<amp>#<cnt>[/1|/2]\n"
+            rel = (uint32_t)(offs[p] - off0) + adj;
+        };
+        uint32_t keyp = 32u;
+        { const uint32_t p = q * RB + tid; if (p < np) { PairRec o; uint32_t rel, h; record_of(p, o, rel, h); keyp = (rel + h) & 31u; } }
+        if (tid < 64) s_cnt[tid] = 0;
+        __syncthreads();
+        const uint32_t rank = atomicAdd(&s_cnt[keyp], 1u);
+        __syncthreads();
+        if (tid < 64) {                                                            // exclusive prefix of the 33 bucket counts
+            const uint32_t c = s_cnt[tid]; uint32_t incl = c;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d); if (tid >= d) incl += o; }
+            s_cnt[tid] = incl - c;
+        }
+        __syncthreads();
+        s_perm[s_cnt[keyp] + rank] = (uint32_t)tid;
+        __syncthreads();
+        pi = q * RB + s_perm[tid]; valid = pi < np;
         r = paired ? 2 * pi + rd : pi;
-        if (valid) { pr = pairs[pi]; uid = pr.uid; att = pr.att; }
+        if (valid) { record_of(pi, pr, rec_rel, rec_h); uid = pr.uid; att = pr.att; }
+        __syncthreads();                                                           // s_perm is read before the staging overwrites it
     } else {
         r = blockIdx.x * RB + tid; valid = r < n_explicit; rd = 0;
         if (valid) { uid = uids[r]; att = atts[r]; rd = is_read1[r] ? 0u : 1u; }
@@ -720,18 +789,19 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
     const uint32_t mdiv = n_out > 0 ? 0xFFFFFFFFu / (uint32_t)n_out + 1u : 0u;     // ceil(2^32 / n')
     uint32_t nb = 0;                                                               // bin of my position jo
     uint32_t c0 = 5u, c1 = 5u;
-    uint32_t cur_b = 0, cur_q = 0, ob0 = 0, ob1 = 0, ob2 = 0, ob3 = 0, oq0 = 0, oq1 = 0, oq2 = 0, oq3 = 0;
+    uint32_t cur_b = 0, cur_q = 0, ob0 = 0, ob1 = 0, ob2 = 0, ob3 = 0, oq0 = 0, oq1 = 0, oq2 = 0, oq3 = 0;   // ob/oq: slot mode's 16-byte blocks
     Xoshiro xb; xb.seed(draw4(key, ST_READ, aux, uid, 1));                         // stream B: substitution / quality draws, in output order
     char* my_b = FROM_PAIRS ? nullptr : slot_b + (size_t)r * slot; char* my_q = FROM_PAIRS ? nullptr : slot_q + (size_t)r * slot;
-    // pair mode: the two byte streams of my FASTQ record (see emit_block above)
-    char *ta1 = nullptr, *ta2 = nullptr, *rec_end = nullptr; uint32_t s1 = 0, s2 = 0, carry_b = 0, carry_q = 0x0A2B0A00u;   // carry_q: "\n+\n" ahead of the qualities
+    // pair mode: the two byte streams of my FASTQ record (see SectorOut above)
+    SectorOut so_b, so_q; uint32_t a1 = 0, a2 = 0;                                // a = T & 31 of each stream: byte shift s = a & 3, dword dw = a >> 2
+    so_b.prev = 0; so_q.prev = 0x0A2B0A00u; so_b.wo = so_q.wo = 0;                // "\n+\n" rides ahead of the qualities
+#pragma unroll
+    for (int i = 0; i < 8; ++i) so_b.r[i] = so_q.r[i] = 0;
     if (FROM_PAIRS && live && n_out > 0) {
-        char* rec = (rd ? out2 : out1) + (rd ? off2[pi] : off1[pi]);
-        const uint32_t amp = amp_index_base + pr.amp, cnt = pr.att + 1u;
-        const uint32_t d1 = dec_digits(amp), d2 = dec_digits(cnt), h = 1u + d1 + 1u + d2 + (paired ? 2u : 0u) + 1u;   // "@<amp>#<cnt>[/1|/2]\n"
-        char* t1 = rec + h; s1 = (uint32_t)reinterpret_cast<uintptr_t>(t1) & 3u; ta1 = t1 - s1;
-        char* t2 = t1 + n_out + 3; s2 = (uint32_t)reinterpret_cast<uintptr_t>(t2) & 3u; ta2 = t2 - s2;
-        rec_end = t2 + n_out + 1;
+        const uint32_t amp = amp_index_base + pr.amp, cnt = pr.att + 1u, d2 = dec_digits(cnt), h = rec_h;
+        const uint32_t o1 = rec_rel + h, o2 = o1 + (uint32_t)n_out + 3u;          // where the bases / the qualities start
+        a1 = o1 & 31u; so_b.wo = o1 - a1; a2 = o2 & 31u; so_q.wo = o2 - a2;
+        const uint32_t s1 = a1 & 3u; char* ta1 = wg_out + (o1 - s1);
         // the name line is produced backwards from its end: its last s1 characters ride in the first dword of the bases,
         // the rest ends on the aligned address ta1 and goes out as whole dwords, then the <= 3 leading bytes
         uint32_t q = 0, vc = cnt, va = amp; const uint32_t dbase = paired ? 3u : 1u;
@@ -745,7 +815,7 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
             else ch = '@';
             ++q; return ch;
         };
-        for (uint32_t i = 0; i < 3; ++i) if (i < s1) carry_b |= next_char() << (8u * (3u - i));
+        for (uint32_t i = 0; i < 3; ++i) if (i < s1) so_b.prev |= next_char() << (8u * (3u - i));
         char* wp = ta1;
         for (uint32_t m = 0; m < 7; ++m) {
             uint32_t w = 0, nb4 = 0;
@@ -893,29 +963,36 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
                 cur_b |= bc << sh; cur_q |= qc << sh; c0 = c1; c1 = c2;
                 const bool lastp = jo == n_out - 1;
                 if (((uint32_t)jo & 3u) == 3u || lastp) {
-                    const uint32_t w = ((uint32_t)jo >> 2) & 3u;
-                    ob0 = w == 0u ? cur_b : ob0; ob1 = w == 1u ? cur_b : ob1; ob2 = w == 2u ? cur_b : ob2; ob3 = w == 3u ? cur_b : ob3;
-                    oq0 = w == 0u ? cur_q : oq0; oq1 = w == 1u ? cur_q : oq1; oq2 = w == 2u ? cur_q : oq2; oq3 = w == 3u ? cur_q : oq3;
-                    cur_b = 0; cur_q = 0;
-                    if (((uint32_t)jo & 15u) == 15u || lastp) {
-                        const int o = jo & ~15;
-                        if (!FROM_PAIRS) {                                         // slot mode (explicit windows)
+                    if (!FROM_PAIRS) {                                             // slot mode (explicit windows): 16-byte blocks
+                        const uint32_t w = ((uint32_t)jo >> 2) & 3u;
+                        ob0 = w == 0u ? cur_b : ob0; ob1 = w == 1u ? cur_b : ob1; ob2 = w == 2u ? cur_b : ob2; ob3 = w == 3u ? cur_b : ob3;
+                        oq0 = w == 0u ? cur_q : oq0; oq1 = w == 1u ? cur_q : oq1; oq2 = w == 2u ? cur_q : oq2; oq3 = w == 3u ? cur_q : oq3;
+                        if (((uint32_t)jo & 15u) == 15u || lastp) {
+                            const int o = jo & ~15;
                             *reinterpret_cast<uint4*>(my_b + o) = make_uint4(ob0, ob1, ob2, ob3);
                             *reinterpret_cast<uint4*>(my_q + o) = make_uint4(oq0, oq1, oq2, oq3);
-                        } else if (!lastp) {                                       // FASTQ text: a full block of each stream
-                            emit_block(ta1 + o, ob0, ob1, ob2, ob3, carry_b, s1);
-                            emit_block(ta2 + o, oq0, oq1, oq2, oq3, carry_q, s2);
-                        } else {                                                   // the read's last block: + "\n+\n" up to the qualities' first dword / + "\n" to the record's end
-                            const uint32_t nbv = ((uint32_t)jo & 15u) + 1u;
-                            emit_tail(ta1 + o, ta2, ob0, ob1, ob2, ob3, nbv, 0x0A2B0Au, carry_b, s1);
-                            emit_tail(ta2 + o, rec_end, oq0, oq1, oq2, oq3, nbv, 0x0Au, carry_q, s2);
+                            ob0 = ob1 = ob2 = ob3 = 0; oq0 = oq1 = oq2 = oq3 = 0;
                         }
-                        ob0 = ob1 = ob2 = ob3 = 0; oq0 = oq1 = oq2 = oq3 = 0;
+                    } else {                                                       // FASTQ text: whole sectors of each stream
+                        const uint32_t k = (uint32_t)jo >> 2;
+                        if (!lastp) {
+                            so_b.push(wg_out, cur_b, a1 & 3u, a1 >> 2, (a1 >> 2) + k);
+                            so_q.push(wg_out, cur_q, a2 & 3u, a2 >> 2, (a2 >> 2) + k);
+                        }
                     }
+                    if (!FROM_PAIRS || !lastp) { cur_b = 0; cur_q = 0; }           // pair mode keeps the read's last word for the finish below
                 }
                 ++jo; nb = __umulhi(__umul24((uint32_t)jo, (uint32_t)B), mdiv);
             }
         }
+    }
+    if (FROM_PAIRS && live && n_out > 0) {
+        // the streams' ends, once per wave after the pass (reads of different lengths end at different steps): the last
+        // characters + "\n+\n" up to the qualities' first dword / + "\n" to the record's end
+        const uint32_t k = ((uint32_t)n_out - 1u) >> 2, nv = (((uint32_t)n_out - 1u) & 3u) + 1u;
+        const uint32_t s1 = a1 & 3u, s2 = a2 & 3u, nq = s2 + (uint32_t)n_out + 1u;
+        so_b.finish(wg_out, cur_b, nv, 0x0A2B0Au, s1, a1 >> 2, k, (s1 + (uint32_t)n_out + 3u - s2) >> 2, 0u);   // the bases' dwords end where the qualities' first one starts
+        so_q.finish(wg_out, cur_q, nv, 0x0Au, s2, a2 >> 2, k, nq >> 2, nq & 3u);
     }
     for (uint32_t e = 0; e < npend; ++e) {                                         // deferred qualities of substituted bases
         const uint2 pe = my_pend[e];
