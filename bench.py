@@ -108,11 +108,21 @@ def main():
     if world != a.gpus:
         if world == 1 and a.gpus > 1:
             sys.exit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d bench.py --gpus %d ..." % (a.gpus, a.gpus))
+    # rehearsal of the N > 1 control flow on a box with ONE GPU: SCS_BENCH_BACKEND=gloo SCS_BENCH_ONE_DEVICE=1 (all ranks on
+    # cuda:0, collectives and the pool transfer staged through the CPU).  Never a measurement.
+    backend = os.environ.get("SCS_BENCH_BACKEND", "nccl")
+    cpu_coll = backend != "nccl"
+    if os.environ.get("SCS_BENCH_ONE_DEVICE") == "1":
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if cpu_coll:
+            dist.init_process_group(backend)
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     dev = torch.device("cuda", local)
+    cdev = torch.device("cpu") if cpu_coll else dev                     # where the bench's own collectives live
 
     td = tempfile.mkdtemp(prefix="scsbench_")
     fa, prof = make_inputs(td, rank, world)
@@ -134,7 +144,7 @@ def main():
     # FASTQ pools are double-buffered so the gather of step i (RCCL point-to-point on its own stream) overlaps the
     # compute of step i+1; every transfer completes inside the timed region (final synchronize + barrier).
     pools = [[torch.empty(cap, dtype=torch.uint8, device=dev) for _ in range(2)] for _ in range(2)]
-    gathered = [torch.empty(cap, dtype=torch.uint8, device=dev) for _ in range(2 * (world - 1))] if (world > 1 and rank == 0) else []
+    gathered = [torch.empty(cap, dtype=torch.uint8, device=cdev) for _ in range(2 * (world - 1))] if (world > 1 and rank == 0) else []
     inflight = [[], []]
     ktimes = {}
 
@@ -156,8 +166,8 @@ def main():
             acc(g.kernel_times(), ("k_reads", "k_indels"))
         if world > 1:                                   # read pool -> writer rank (RCCL point-to-point over xGMI)
             with torch.cuda.stream(stream):
-                sizes = torch.tensor([n1, n2], dtype=torch.int64, device=dev)
-                allsz = torch.zeros(2 * world, dtype=torch.int64, device=dev)
+                sizes = torch.tensor([n1, n2], dtype=torch.int64, device=cdev)
+                allsz = torch.zeros(2 * world, dtype=torch.int64, device=cdev)
                 dist.all_gather_into_tensor(allsz, sizes)
                 ops = []
                 if rank == 0:
@@ -166,8 +176,8 @@ def main():
                         ops.append(dist.P2POp(dist.irecv, gathered[2 * (r - 1)][:hs[2 * r]], r))
                         ops.append(dist.P2POp(dist.irecv, gathered[2 * (r - 1) + 1][:hs[2 * r + 1]], r))
                 else:
-                    ops.append(dist.P2POp(dist.isend, pool1[:n1], 0))
-                    ops.append(dist.P2POp(dist.isend, pool2[:n2], 0))
+                    ops.append(dist.P2POp(dist.isend, pool1[:n1].cpu() if cpu_coll else pool1[:n1], 0))
+                    ops.append(dist.P2POp(dist.isend, pool2[:n2].cpu() if cpu_coll else pool2[:n2], 0))
                 inflight[b] = dist.batch_isend_irecv(ops)
         return pairs, g.stats()
 
@@ -209,10 +219,10 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t[0])
-        pt = torch.tensor([pairs_total], dtype=torch.int64, device=dev)
+        pt = torch.tensor([pairs_total], dtype=torch.int64, device=cdev)
         dist.all_reduce(pt)
         pairs_total = int(pt[0])
 

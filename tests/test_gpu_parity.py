@@ -257,6 +257,28 @@ open(%r, "wb").write(a[0])
     assert open(str(tmp_path / "nccl_1.fq"), "rb").read() == open(prefix + "_1.fq", "rb").read()
 
 
+def test_bench_two_rank_control_flow(tmp_path):
+    """bench.py's N > 1 path (one sharded job, sizes all-gathered, read pools sent to rank 0, max-over-ranks timing)
+    rehearsed as 2 ranks on this box's one GPU: gloo collectives staged through the CPU instead of RCCL.  Checks the
+    control flow and the JSON contract, not a rate."""
+    import json
+    import sys
+    env = dict(os.environ, SCS_BENCH_BACKEND="gloo", SCS_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29791", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "rank 0 prints exactly one JSON line"
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 5 and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["value"] > 0 and abs(d["value"] - 2 * d["config"]["pairs_per_step_per_gpu"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 0.05
+    assert 150000 < 2 * d["config"]["pairs_per_step_per_gpu"] < 250000          # 2 x 1 Mb at 30x, PE150: ~200 k pairs per job
+    assert d["roofline"]["frac"] > 0 and "cpu_baseline" not in d
+
+
 def test_medium_genome_bit_exact(oracle_bin, models, tmp_path):
     """12 Mb, two records, 4x: thousands of allocation chunks, hundreds of fragments, the >4-errors overflow pool,
     multi-digit record names -- FASTQ still byte-identical to the oracle."""
