@@ -395,7 +395,7 @@ __global__ void k_plan_pairs(DevFrags fr, DevAmps semis, DevAmps fulls, uint32_t
 //         through registers, serves every lookup.  A wave whose reads all sit on clean k-mers takes a branch-free
 //         fast step; first-two-bases / N k-mers take the general step;
 //       * output (pair mode): the FASTQ text itself, realigned in registers to the record's byte offset and stored as
-//         whole 32-byte aligned sectors (SectorOut); the workgroup's reads are handed to its lanes ordered by the sector
+//         whole 32-byte aligned sectors (BlockOut); the workgroup's reads are handed to its lanes ordered by the sector
 //         phase of their records, so that the lanes of a wave cross sector boundaries together.  Explicit-window mode
 //         writes sequence/quality slots.
 //     LDS per workgroup at L = 150: 13-16 KB ring + 4 KB events + 19 KB windows -> 4 workgroups per CU.
@@ -552,61 +552,85 @@ __global__ void __launch_bounds__(256) k_indels(const PairRec* __restrict__ pair
 // dwords from Ta = T & ~3.  The bytes of a stream's first aligned dword that lie before T are the end of what precedes
 // it in the record, and are known: the tail of the name line for the bases, the tail of "\n+\n" for the qualities -- so
 // every dword except the record's very last one is written whole, exactly once.
-// The aligned dwords are collected eight at a time in a shift register (newest in r[7]) and leave as one whole, 32-byte
-// aligned sector (two dwordx4 stores back to back): a lane's partial lines do not survive in L2 until its next store
-// 16 positions later (the open lines of all lanes exceed the L2), so anything smaller than a sector is written to memory
-// as a masked sector each time.  Only a stream's first and last sector go out as single dwords.
-struct SectorOut {
-    uint32_t r[8]; uint32_t prev; uint32_t wo;                                     // wo: offset of the 32-byte aligned sector being filled from the workgroup's base
-    __device__ __forceinline__ void shift_in(uint32_t w) {
-#pragma unroll
-        for (int i = 0; i < 7; ++i) r[i] = r[i + 1];
-        r[7] = w;
+// A lane collects 16 characters (four raw words) of each stream, all lanes at the same steps.  At the block's end the four
+// words are byte-aligned (above) and then DWORD-aligned to the sector grid by a two-stage funnel over the previous and the
+// new aligned words (dq = dword of Ta inside its 16 bytes): that gives one 16-byte aligned half sector.  A lower half
+// waits in registers for its upper half, and the two leave as ONE WHOLE 32-BYTE ALIGNED SECTOR (two dwordx4 stores back
+// to back): a lane's partial lines do not survive in L2 until its next store 16 positions later (the open lines of all
+// lanes exceed the L2), so anything smaller than a sector is written to memory as a masked sector each time.  Only a
+// stream's first sector (masked dwords) and its end (single dwords, once per wave after the pass) are not whole.
+struct BlockOut {
+    uint32_t R[4];                                                                 // raw words of the block being filled (characters 16m .. 16m+15)
+    uint32_t P[3];                                                                 // byte-aligned dwords 1..3 of the previous block: its last dq are not placed yet
+    uint32_t H[4];                                                                 // a finished lower half sector waiting for its upper half
+    uint32_t carry;                                                                // the raw word before R[0]
+    static __device__ __forceinline__ uint32_t al(uint32_t x, uint32_t prev, uint32_t s) {   // stream bytes 4k-s .. 4k-s+3
+        return s ? __builtin_amdgcn_alignbyte(x, prev, 4u - s) : x;
     }
-    __device__ __forceinline__ void store_full(char* __restrict__ base) {
-        reinterpret_cast<uint4*>(base + wo)[0] = make_uint4(r[0], r[1], r[2], r[3]);
-        reinterpret_cast<uint4*>(base + wo)[1] = make_uint4(r[4], r[5], r[6], r[7]);
-        wo += 32u;
-    }
-    __device__ __forceinline__ void store_range(char* __restrict__ base, uint32_t lo, uint32_t hi) {   // sector dwords lo..hi, held in r[lo..hi]
-#pragma unroll
-        for (uint32_t j = 0; j < 8; ++j) if (j >= lo && j <= hi) reinterpret_cast<uint32_t*>(base + wo)[j] = r[j];
-    }
-    // raw word number k of the stream (its characters 4k..4k+3) completes aligned dword k; pos = dw + k counts dwords
-    // from the first sector's base (dw = dword of Ta inside that sector)
-    __device__ __forceinline__ void push(char* __restrict__ base, uint32_t raw, uint32_t s, uint32_t dw, uint32_t pos) {
-        shift_in(s ? __builtin_amdgcn_alignbyte(raw, prev, 4u - s) : raw);
-        prev = raw;
-        if ((pos & 7u) == 7u) {
-            if (pos == 7u && dw) { store_range(base, dw, 7u); wo += 32u; }         // the stream's first sector starts inside it
-            else store_full(base);
-        }
-    }
-    // the read's last characters: raw word k0 (nv valid bytes, 4 if whole) followed by `sep`; the stream holds `nd` whole
-    // aligned dwords and `rem` (< 4) bytes after them (only a record's very end has rem != 0)
-    __device__ __forceinline__ void finish(char* __restrict__ base, uint32_t raw, uint32_t nv, uint32_t sep, uint32_t s, uint32_t dw, uint32_t k0, uint32_t nd, uint32_t rem) {
-        const unsigned long long sv = (unsigned long long)sep << (8u * (nv & 3u));
-        const uint32_t ext[3] = {nv < 4u ? raw | (uint32_t)sv : raw, nv < 4u ? (uint32_t)(sv >> 32) : sep, 0u};
-        uint32_t filled = k0 ? dw + k0 : 0u;                                       // 1 + position of the last dword shifted in (0: none yet)
-#pragma unroll
-        for (uint32_t i = 0; i < 3; ++i) {
-            const uint32_t k = k0 + i, pos = dw + k;
-            const uint32_t w = s ? __builtin_amdgcn_alignbyte(ext[i], prev, 4u - s) : ext[i];
-            if (k < nd) {
-                shift_in(w); prev = ext[i]; filled = pos + 1u;
-                if ((pos & 7u) == 7u) {
-                    if (pos == 7u && dw) { store_range(base, dw, 7u); wo += 32u; }
-                    else store_full(base);
-                }
-            } else if (k == nd) {
-                for (uint32_t b = 0; b < rem; ++b) base[wo + 4u * (pos & 7u) + b] = (char)(w >> (8u * b));
+    // a = T & 31 of the stream (s = a & 3, dq = (a >> 2) & 3, first half = (a >> 4) & 1); sec0 = offset of its first sector
+    __device__ __forceinline__ void block(char* __restrict__ base, uint32_t sec0, uint32_t a, uint32_t m) {   // block m is complete
+        asm volatile("" : "+v"(a));                                                // the lane masks derived from a are made here, per block: kept in SGPRs through the whole pass they spill
+        const uint32_t s = a & 3u, dq = (a >> 2) & 3u, slot = ((a >> 4) & 1u) + m;  // slot: 16-byte slots from sec0
+        const uint32_t w0 = al(R[0], carry, s), w1 = al(R[1], R[0], s), w2 = al(R[2], R[1], s), w3 = al(R[3], R[2], s);
+        carry = R[3];
+        const bool t2 = dq & 2u, t1 = dq & 1u;                                     // A[j] = C[4 + j - dq], C = P[0..2] (1..3), w0..w3 (4..7)
+        const uint32_t e3 = t2 ? P[0] : P[2], e4 = t2 ? P[1] : w0, e5 = t2 ? P[2] : w1, e6 = t2 ? w0 : w2, e7 = t2 ? w1 : w3;
+        const uint32_t a0 = t1 ? e3 : e4, a1 = t1 ? e4 : e5, a2 = t1 ? e5 : e6, a3 = t1 ? e6 : e7;
+        P[0] = w1; P[1] = w2; P[2] = w3;
+        if (!(slot & 1u)) { H[0] = a0; H[1] = a1; H[2] = a2; H[3] = a3; }
+        else {
+            char* __restrict__ d = base + (sec0 + 16u * (slot - 1u));
+            uint32_t lo = a >> 2;                                                  // the stream's first dword inside its first sector
+            if (slot == 1u && lo) {                                                // first sector: only the dwords from Ta on are mine
+                uint32_t* q = reinterpret_cast<uint32_t*>(d);
+                asm volatile("" : "+v"(lo));                                       // compared here, once: not as six lane masks kept in SGPRs through the whole pass
+                if (lo <= 1u) q[1] = H[1];
+                if (lo <= 2u) q[2] = H[2];
+                if (lo <= 3u) q[3] = H[3];
+                if (lo <= 4u) q[4] = a0;
+                if (lo <= 5u) q[5] = a1;
+                if (lo <= 6u) q[6] = a2;
+                q[7] = a3;
+            } else {
+                reinterpret_cast<uint4*>(d)[0] = make_uint4(H[0], H[1], H[2], H[3]);
+                reinterpret_cast<uint4*>(d)[1] = make_uint4(a0, a1, a2, a3);
             }
         }
-        if (filled & 7u) {                                                         // the stream's last sector is not whole
-            const uint32_t idx = (filled - 1u) & 7u;
-            for (uint32_t m = idx; m < 7u; ++m) shift_in(0u);                      // bring sector dword j into r[j]
-            store_range(base, filled <= 8u ? dw : 0u, idx);
+    }
+    // the stream's end, after the pass: block m holds nw (1..4) raw words, the last with nv (1..4) characters; then `sep`.
+    // The stream has `nd` whole aligned dwords and `rem` (< 4) bytes after them (only a record's very end has rem != 0).
+    __device__ __forceinline__ void tail(char* __restrict__ base, uint32_t sec0, uint32_t a, uint32_t m, uint32_t nw, uint32_t nv, uint32_t sep,
+                                         uint32_t nd, uint32_t rem) {
+        const uint32_t s = a & 3u, dq = (a >> 2) & 3u, slot = ((a >> 4) & 1u) + m;
+        const int k0 = (int)(4u * m) - (int)dq;                                    // aligned dword of the stream that sits in slot `slot`, dword 0
+        if ((slot & 1u) && m) {                                                    // the lower half still waiting: dword j is aligned dword k0 - 4 + j
+            uint32_t* q = reinterpret_cast<uint32_t*>(base + (sec0 + 16u * (slot - 1u)));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (k0 - 4 + j >= 0) q[j] = H[j];
         }
+        const unsigned long long sv = (unsigned long long)sep << (8u * (nv & 3u));
+        const uint32_t last = nv < 4u ? (uint32_t)sv : 0u, after = nv < 4u ? (uint32_t)(sv >> 32) : sep;
+        // (named scalars, not arrays: a select between two array elements is turned into an indexed load and the array into scratch)
+        // the block's raw words with the separator behind them ...
+        const uint32_t e0 = 0u + 1u < nw ? R[0] : 0u + 1u == nw ? (R[0] | last) : 0u == nw ? after : 0u;
+        const uint32_t e1 = 1u + 1u < nw ? R[1] : 1u + 1u == nw ? (R[1] | last) : 1u == nw ? after : 0u;
+        const uint32_t e2 = 2u + 1u < nw ? R[2] : 2u + 1u == nw ? (R[2] | last) : 2u == nw ? after : 0u;
+        const uint32_t e3 = 3u + 1u < nw ? R[3] : 3u + 1u == nw ? (R[3] | last) : 3u == nw ? after : 0u;
+        const uint32_t e4 = 4u + 1u < nw ? 0u : 4u + 1u == nw ? (0u | last) : 4u == nw ? after : 0u;
+        const uint32_t e5 = 5u + 1u < nw ? 0u : 5u + 1u == nw ? (0u | last) : 5u == nw ? after : 0u;
+        // ... byte-aligned: c1..c3 = P, c4.. = the tail's aligned dwords; dword t of the slot = c[4 + t - dq] = aligned dword k0 + t
+        const uint32_t c1 = P[0], c2 = P[1], c3 = P[2], c4 = al(e0, carry, s), c5 = al(e1, e0, s), c6 = al(e2, e1, s), c7 = al(e3, e2, s),
+                       c8 = al(e4, e3, s), c9 = al(e5, e4, s), c10 = 0u, c11 = 0u, c12 = 0u;
+        const bool t2 = dq & 2u, t1 = dq & 1u;
+        const uint32_t f3 = t2 ? c1 : c3, f4 = t2 ? c2 : c4, f5 = t2 ? c3 : c5, f6 = t2 ? c4 : c6, f7 = t2 ? c5 : c7, f8 = t2 ? c6 : c8, f9 = t2 ? c7 : c9, f10 = t2 ? c8 : c10, f11 = t2 ? c9 : c11, f12 = t2 ? c10 : c12;
+        const uint32_t v0 = t1 ? f3 : f4, v1 = t1 ? f4 : f5, v2 = t1 ? f5 : f6, v3 = t1 ? f6 : f7, v4 = t1 ? f7 : f8, v5 = t1 ? f8 : f9, v6 = t1 ? f9 : f10, v7 = t1 ? f10 : f11, v8 = t1 ? f11 : f12;
+        uint32_t* q = reinterpret_cast<uint32_t*>(base + (sec0 + 16u * slot));
+        auto put = [&](int t, uint32_t v) {
+            const int k = k0 + t;
+            if (k >= 0 && k < (int)nd) q[t] = v;
+            else if (k == (int)nd) for (uint32_t b = 0; b < rem; ++b) reinterpret_cast<char*>(q + t)[b] = (char)(v >> (8u * b));
+        };
+        put(0, v0); put(1, v1); put(2, v2); put(3, v3); put(4, v4); put(5, v5); put(6, v6); put(7, v7); put(8, v8);
     }
 };
 
@@ -792,15 +816,15 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
     uint32_t cur_b = 0, cur_q = 0, ob0 = 0, ob1 = 0, ob2 = 0, ob3 = 0, oq0 = 0, oq1 = 0, oq2 = 0, oq3 = 0;   // ob/oq: slot mode's 16-byte blocks
     Xoshiro xb; xb.seed(draw4(key, ST_READ, aux, uid, 1));                         // stream B: substitution / quality draws, in output order
     char* my_b = FROM_PAIRS ? nullptr : slot_b + (size_t)r * slot; char* my_q = FROM_PAIRS ? nullptr : slot_q + (size_t)r * slot;
-    // pair mode: the two byte streams of my FASTQ record (see SectorOut above)
-    SectorOut so_b, so_q; uint32_t a1 = 0, a2 = 0;                                // a = T & 31 of each stream: byte shift s = a & 3, dword dw = a >> 2
-    so_b.prev = 0; so_q.prev = 0x0A2B0A00u; so_b.wo = so_q.wo = 0;                // "\n+\n" rides ahead of the qualities
+    // pair mode: the two byte streams of my FASTQ record (see BlockOut above)
+    BlockOut bo_b, bo_q; uint32_t a1 = 0, a2 = 0, sec1 = 0, sec2 = 0;             // a = T & 31 of each stream, sec = offset of its first sector from wg_out
+    bo_b.carry = 0; bo_q.carry = 0x0A2B0A00u;                                      // "\n+\n" rides ahead of the qualities
 #pragma unroll
-    for (int i = 0; i < 8; ++i) so_b.r[i] = so_q.r[i] = 0;
+    for (int i = 0; i < 4; ++i) { bo_b.R[i] = bo_q.R[i] = 0; bo_b.H[i] = bo_q.H[i] = 0; if (i < 3) bo_b.P[i] = bo_q.P[i] = 0; }
     if (FROM_PAIRS && live && n_out > 0) {
         const uint32_t amp = amp_index_base + pr.amp, cnt = pr.att + 1u, d2 = dec_digits(cnt), h = rec_h;
         const uint32_t o1 = rec_rel + h, o2 = o1 + (uint32_t)n_out + 3u;          // where the bases / the qualities start
-        a1 = o1 & 31u; so_b.wo = o1 - a1; a2 = o2 & 31u; so_q.wo = o2 - a2;
+        a1 = o1 & 31u; sec1 = o1 - a1; a2 = o2 & 31u; sec2 = o2 - a2;
         const uint32_t s1 = a1 & 3u; char* ta1 = wg_out + (o1 - s1);
         // the name line is produced backwards from its end: its last s1 characters ride in the first dword of the bases,
         // the rest ends on the aligned address ta1 and goes out as whole dwords, then the <= 3 leading bytes
@@ -815,7 +839,7 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
             else ch = '@';
             ++q; return ch;
         };
-        for (uint32_t i = 0; i < 3; ++i) if (i < s1) so_b.prev |= next_char() << (8u * (3u - i));
+        for (uint32_t i = 0; i < 3; ++i) if (i < s1) bo_b.carry |= next_char() << (8u * (3u - i));
         char* wp = ta1;
         for (uint32_t m = 0; m < 7; ++m) {
             uint32_t w = 0, nb4 = 0;
@@ -973,14 +997,16 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
                             *reinterpret_cast<uint4*>(my_q + o) = make_uint4(oq0, oq1, oq2, oq3);
                             ob0 = ob1 = ob2 = ob3 = 0; oq0 = oq1 = oq2 = oq3 = 0;
                         }
-                    } else {                                                       // FASTQ text: whole sectors of each stream
-                        const uint32_t k = (uint32_t)jo >> 2;
-                        if (!lastp) {
-                            so_b.push(wg_out, cur_b, a1 & 3u, a1 >> 2, (a1 >> 2) + k);
-                            so_q.push(wg_out, cur_q, a2 & 3u, a2 >> 2, (a2 >> 2) + k);
+                    } else {                                                       // FASTQ text: 16-character blocks of each stream -> whole sectors
+                        const uint32_t w = ((uint32_t)jo >> 2) & 3u;
+                        bo_b.R[0] = w == 0u ? cur_b : bo_b.R[0]; bo_b.R[1] = w == 1u ? cur_b : bo_b.R[1]; bo_b.R[2] = w == 2u ? cur_b : bo_b.R[2]; bo_b.R[3] = w == 3u ? cur_b : bo_b.R[3];
+                        bo_q.R[0] = w == 0u ? cur_q : bo_q.R[0]; bo_q.R[1] = w == 1u ? cur_q : bo_q.R[1]; bo_q.R[2] = w == 2u ? cur_q : bo_q.R[2]; bo_q.R[3] = w == 3u ? cur_q : bo_q.R[3];
+                        if (((uint32_t)jo & 15u) == 15u && !lastp) {
+                            bo_b.block(wg_out, sec1, a1, (uint32_t)jo >> 4);
+                            bo_q.block(wg_out, sec2, a2, (uint32_t)jo >> 4);
                         }
                     }
-                    if (!FROM_PAIRS || !lastp) { cur_b = 0; cur_q = 0; }           // pair mode keeps the read's last word for the finish below
+                    cur_b = 0; cur_q = 0;
                 }
                 ++jo; nb = __umulhi(__umul24((uint32_t)jo, (uint32_t)B), mdiv);
             }
@@ -989,10 +1015,10 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
     if (FROM_PAIRS && live && n_out > 0) {
         // the streams' ends, once per wave after the pass (reads of different lengths end at different steps): the last
         // characters + "\n+\n" up to the qualities' first dword / + "\n" to the record's end
-        const uint32_t k = ((uint32_t)n_out - 1u) >> 2, nv = (((uint32_t)n_out - 1u) & 3u) + 1u;
+        const uint32_t lastj = (uint32_t)n_out - 1u, m = lastj >> 4, nw = ((lastj & 15u) >> 2) + 1u, nv = (lastj & 3u) + 1u;
         const uint32_t s1 = a1 & 3u, s2 = a2 & 3u, nq = s2 + (uint32_t)n_out + 1u;
-        so_b.finish(wg_out, cur_b, nv, 0x0A2B0Au, s1, a1 >> 2, k, (s1 + (uint32_t)n_out + 3u - s2) >> 2, 0u);   // the bases' dwords end where the qualities' first one starts
-        so_q.finish(wg_out, cur_q, nv, 0x0Au, s2, a2 >> 2, k, nq >> 2, nq & 3u);
+        bo_b.tail(wg_out, sec1, a1, m, nw, nv, 0x0A2B0Au, (s1 + (uint32_t)n_out + 3u - s2) >> 2, 0u);   // the bases' dwords end where the qualities' first one starts
+        bo_q.tail(wg_out, sec2, a2, m, nw, nv, 0x0Au, nq >> 2, nq & 3u);
     }
     for (uint32_t e = 0; e < npend; ++e) {                                         // deferred qualities of substituted bases
         const uint2 pe = my_pend[e];
