@@ -875,12 +875,17 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
     __syncthreads();
 
     // a substituted base (k != c2) needs an off-diagonal quality row, which only global memory holds.  Its quality does
-    // not feed back into the walk, so the lookup is deferred: (position, k, c2, bin, draw) goes to the free tail of the
-    // read's quality slot and is resolved after the loop, off the workgroup-synchronous path.  No room -> resolved in place.
+    // not feed back into the walk, so the lookup is deferred: (position, k, c2, bin, draw) is set aside and resolved after
+    // the loop, off the workgroup-synchronous path (resolved in place, one lane of the wave fetches from global memory while
+    // the other 63 wait: with a substitution every few hundred bases that was 15 % of this kernel).  Pair mode keeps the
+    // entries in the START OF THE READ'S OWN WINDOW ROW in LDS -- entry e over the bases 16e .. 16e+15, dead once the walk
+    // has passed them -- and patches the quality character into the FASTQ text after the record is written; slot mode in
+    // the free tail of the read's quality slot.  No room (an early position, a fifth substitution) -> resolved in place.
     constexpr uint32_t PEND_MAX = 4;
-    const bool can_defer = !FROM_PAIRS && n_out + 15 + (int)(8 * PEND_MAX) <= (int)slot;   // (slot mode only: pair mode writes FASTQ text directly)
+    const bool can_defer = !FROM_PAIRS && n_out + 15 + (int)(8 * PEND_MAX) <= (int)slot;
     uint32_t npend = 0;
     uint2* my_pend = FROM_PAIRS ? nullptr : reinterpret_cast<uint2*>(my_q + slot - 8 * PEND_MAX);
+    LdsU32* my_pend_lds = (LdsU32*)(s_win + (size_t)tid * WS);                     // rows are dword aligned (win_stride)
 
     for (int t = 0; t < B; ++t) {
         if ((t & (GROUP - 1)) == 0 && t > 0) {
@@ -912,6 +917,17 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
                 qv = ci < 4u ? (S.x >> (8u * ci)) & 255u : S.y & 255u; unresolved = gsel == 8u;
             }
             return ((xs == 0xFFFFFFFFu) | (xq == 0xFFFFFFFFu) | unresolved) ? 2u : (k != c2 ? 1u : 0u);
+        };
+        auto defer = [&](uint32_t k, uint32_t c2, uint32_t xq) -> bool {
+            const uint32_t w0 = (uint32_t)jo | (k << 12) | (c2 << 14) | ((uint32_t)t << 16);
+            if (FROM_PAIRS) {
+                if (npend >= PEND_MAX || (uint32_t)ji < 16u * (npend + 1u)) return false;   // ji: the next base the walk reads
+                my_pend_lds[2u * npend] = w0; my_pend_lds[2u * npend + 1u] = xq; ++npend;
+            } else {
+                if (!can_defer || npend >= PEND_MAX) return false;
+                my_pend[npend++] = make_uint2(w0, xq);
+            }
+            return true;
         };
         for (;;) {
             const bool mine = jo < n_out && nb == (uint32_t)t;                     // my position jo falls into bin t
@@ -961,7 +977,7 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
                     else {
                         uint32_t k = c2, qv = 0, odd = 2u;
                         if (ki >= 20 && ring_subs_ok) odd = call_lds((uint32_t)ki - 20u, c2, xs, xq, k, qv);
-                        if (odd == 1u && can_defer && npend < PEND_MAX) { my_pend[npend++] = make_uint2((uint32_t)jo | (k << 12) | (c2 << 14) | ((uint32_t)t << 16), xq); qv = 0; odd = 0u; }
+                        if (odd == 1u && defer(k, c2, xq)) { qv = 0; odd = 0u; }
                         if (odd) {
                             const uint32_t kq = call_global<QBIG>(subs, subs_d, tb.qual_compact, tb.qual, tb.qual_d, tb.qual_guide, (uint32_t)B, ki, c2, c2, (uint32_t)t, xs, xq);
                             k = kq & 255u; qv = kq >> 8;
@@ -974,7 +990,7 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
                 const uint32_t kk = (c0 << 4) | (c1 << 2) | c2;
                 uint32_t k, qv;
                 uint32_t odd = call_lds(kk, c2, xs, xq, k, qv);
-                if (odd == 1u && can_defer && npend < PEND_MAX) { my_pend[npend++] = make_uint2((uint32_t)jo | (k << 12) | (c2 << 14) | ((uint32_t)t << 16), xq); qv = 0; odd = 0u; }
+                if (odd == 1u && defer(k, c2, xq)) { qv = 0; odd = 0u; }
                 if (odd) {
                     const uint32_t kq = call_global<QBIG>(subs, subs_d, tb.qual_compact, tb.qual, tb.qual_d, tb.qual_guide, (uint32_t)B, (int)kk + 20, c2, c2, (uint32_t)t, xs, xq);
                     k = kq & 255u; qv = kq >> 8;
@@ -1021,11 +1037,13 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
         bo_q.tail(wg_out, sec2, a2, m, nw, nv, 0x0Au, nq >> 2, nq & 3u);
     }
     for (uint32_t e = 0; e < npend; ++e) {                                         // deferred qualities of substituted bases
-        const uint2 pe = my_pend[e];
+        uint2 pe;
+        if (FROM_PAIRS) { pe.x = my_pend_lds[2u * e]; pe.y = my_pend_lds[2u * e + 1u]; } else pe = my_pend[e];
         const uint32_t pk = (pe.x >> 12) & 3u, pc = (pe.x >> 14) & 3u, qrow = (pc * 4u + pk) * (uint32_t)B + (pe.x >> 16);
         uint32_t qv = qual_lookup_compact<QBIG>(tb.qual_compact + (size_t)qrow * QROW, pe.y);
         if (qv == 255u) qv = qual_lookup(tb.qual + (size_t)qrow * NQ, tb.qual_d + (size_t)qrow * NQ, tb.qual_guide + (size_t)qrow * 17u, pe.y);
-        my_q[pe.x & 4095u] = (char)(33u + qv);
+        if (FROM_PAIRS) wg_out[sec2 + a2 + (pe.x & 4095u)] = (char)(33u + qv);    // after the record's own stores (same lane: program order)
+        else my_q[pe.x & 4095u] = (char)(33u + qv);
     }
     if (live && !FROM_PAIRS) {
         lens[r] = (uint32_t)n_out;
