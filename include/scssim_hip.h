@@ -178,9 +178,10 @@ int         scs_fasta_write_index(const char* fasta_path, char* errbuf, size_t e
 /* Per-kernel timing (HIP events recorded on the ctx stream around every launch, accumulated over the
  * last scs_amplify / scs_yield_reads call): name, launches, total milliseconds, and the units the
  * launches processed (amplicons created for the errscan kernels, read pairs for k_reads/k_indels,
- * templates for k_attach).  which = 0..4. */
+ * templates for the two k_attach instances).  which = 0..5: k_errs<semi->full>, k_errs<frag->semi>, k_reads,
+ * k_attach<semi>, k_indels, k_attach<frag>. */
 int         scs_kernel_time(const scs_ctx* ctx, int which, const char** name, uint64_t* launches, double* ms, uint64_t* units);
-/* Which of the five kernels get their HIP event pairs: bit `which` of mask (default: all), and on which calls: every
+/* Which of the six kernels get their HIP event pairs: bit `which` of mask (default: all), and on which calls: every
  * `every`-th scs_amplify / scs_yield_reads call counted from this call (default 1 = all).  Every event record is a
  * packet on the stream (about 6 us each on the latency-bound 1 Mb configuration), so a measurement run times only the
  * kernel of interest, on a sample of the steps.  scs_kernel_time reports an untimed call as 0 launches / 0 units. */

@@ -277,18 +277,18 @@ class GenReads:
 
     def kernel_times(self):
         out = {}
-        for i in range(5):
+        for i in range(len(self.KERNELS)):
             name, n, ms, units = C.c_char_p(), C.c_uint64(), C.c_double(), C.c_uint64()
             self._ck(self._L.scs_kernel_time(self._ctx, i, C.byref(name), C.byref(n), C.byref(ms), C.byref(units)))
             out[name.value.decode()] = dict(launches=n.value, ms=ms.value, units=units.value)
         return out
 
-    KERNELS = ("k_errs<semi->full>", "k_errs<frag->semi>", "k_reads", "k_attach", "k_indels")
+    KERNELS = ("k_errs<semi->full>", "k_errs<frag->semi>", "k_reads", "k_attach<semi>", "k_indels", "k_attach<frag>")
 
     def set_kernel_timing(self, names=None, every=1):
-        """Keep HIP event pairs only around the named kernels (None = all five), on every `every`-th amplify / yield call.
+        """Keep HIP event pairs only around the named kernels (None = all six), on every `every`-th amplify / yield call.
         Every event record is a packet on the stream (about 6 us each on the latency-bound 1 Mb job)."""
-        mask = 0x1F if names is None else sum(1 << self.KERNELS.index(n) for n in names)
+        mask = (1 << len(self.KERNELS)) - 1 if names is None else sum(1 << self.KERNELS.index(n) for n in names)
         self._ck(self._L.scs_set_kernel_timing(self._ctx, mask, every))
 
     def download_amplicons(self, kind):

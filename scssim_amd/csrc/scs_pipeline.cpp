@@ -205,7 +205,7 @@ struct scs_ctx {
                HIP_OK(hipMemcpyAsync(d, w.data(), n * 4, hipMemcpyHostToDevice, stream)); HIP_OK(hipStreamSynchronize(stream)); }
     }
     scs_stats st{};
-    KernelTimer tm_errscan{"k_errs<semi->full>"}, tm_errscan_f{"k_errs<frag->semi>"}, tm_reads{"k_reads"}, tm_attach{"k_attach"}, tm_indels{"k_indels"};
+    KernelTimer tm_errscan{"k_errs<semi->full>"}, tm_errscan_f{"k_errs<frag->semi>"}, tm_reads{"k_reads"}, tm_attach{"k_attach<semi>"}, tm_indels{"k_indels"}, tm_attach_f{"k_attach<frag>"};
 
     DevFrags frags_view() const {
         return DevFrags{df_goff.as<uint64_t>(), df_len.as<uint32_t>(), df_strand.as<int8_t>(), df_primers.as<uint32_t>(), (uint32_t)f_len.size(), f_gidx_base};
@@ -409,13 +409,14 @@ void launch_pass(scs_ctx* c, bool from_frag, uint32_t pass, int rb_slot) {
     AmplifyParams p; p.key = c->key; p.pass = pass; p.amp_min = (uint32_t)c->cfg.amplicon_min_len; p.amp_max = (uint32_t)c->cfg.amplicon_max_len; p.t_ber = c->dtb.t_ber;
     DevFrags fr = c->frags_view(); fr.primers = c->budget_f.as<uint32_t>();
     const uint8_t* g = c->genome.as<uint8_t>();
-    c->tm_attach.begin(s);
+    KernelTimer& tma = from_frag ? c->tm_attach_f : c->tm_attach;
+    tma.begin(s);
     if (from_frag) launch_attach_frags(s, g, fr, slot_off, c->slots.as<uint32_t>(), c->slot_tmpl.as<uint32_t>(), valid.as<uint32_t>(),
                                        c->primer_cnt.as<int64_t>(), c->primer_delta.as<uint32_t>(), c->dsums.as<unsigned long long>() + 4, p);
     else launch_attach_semis(s, g, fr, c->semis.view(), nt, c->semis.pool_view(), slot_off, c->slots.as<uint32_t>(), c->slot_tmpl.as<uint32_t>(),
                              valid.as<uint32_t>(), c->primer_cnt.as<int64_t>(), c->primer_delta.as<uint32_t>(), p);
-    c->tm_attach.end(s);
-    c->tm_attach.add_units(nt);
+    tma.end(s);
+    tma.add_units(nt);
     exclusive_scan_u32(s, valid.as<uint32_t>(), valid_off.as<uint32_t>(), nt, c->scan_tmp.p, c->scan_tmp.cap);
     KernelTimer& tm = from_frag ? c->tm_errscan_f : c->tm_errscan;
     // the stock update rides on k_errs (launched with at least 256 workgroups: one primer type per thread); a sharded job
@@ -472,7 +473,7 @@ void do_amplify(scs_ctx* c) {
     if (c->cfg.verbose) fprintf(stderr, "\nMALBAC amplification...\n");
     c->semis.reset(s); c->fulls.reset(s); c->semi_block_end.clear(); c->full_segs.clear(); c->pending_seg_cycle = -1; c->have_gidx = false; c->pend = Mail();
     c->timing_gate = (c->amplify_calls++ % c->timing_every) == 0;
-    c->tm_errscan.reset(); c->tm_errscan_f.reset(); c->tm_attach.reset();
+    c->tm_errscan.reset(); c->tm_errscan_f.reset(); c->tm_attach.reset(); c->tm_attach_f.reset();
     c->primer_cnt.reserve(65536 * 8, s); c->primer_delta.reserve((65536 + SHARD_TAIL_WORDS) * 4, s);   // createPrimers: 4^8 types x `primers` copies
     launch_amplify_init(s, c->primer_cnt.as<int64_t>(), (int64_t)c->cfg.primers, c->primer_delta.as<uint32_t>(), c->flags.as<uint32_t>(), c->dsums.as<unsigned long long>(),
                         c->nf_all, c->frag_len_all, 65536ull * (uint64_t)c->cfg.primers);
@@ -503,7 +504,7 @@ void do_amplify(scs_ctx* c) {
     }
     collect_post(c, true); mail_wait(c); collect_read(c, open_fulls, open_semis);
     check_flags(c);
-    c->tm_errscan.collect(); c->tm_errscan_f.collect(); c->tm_attach.collect();
+    c->tm_errscan.collect(); c->tm_errscan_f.collect(); c->tm_attach.collect(); c->tm_attach_f.collect();
     c->amplified = true; c->allocated = false;
     c->st.semi_amplicons = c->semis.n; c->st.full_amplicons = c->fulls.n; c->st.primers_left = c->total_primers;
 }
@@ -756,7 +757,7 @@ int scs_create(const scs_config* cfg, scs_ctx** out) {
         HIP_OK(hipSetDevice(cfg->device));
         if (cfg->stream) c->stream = (hipStream_t)cfg->stream; else { HIP_OK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
         c->key = RngKey{(uint32_t)cfg->seed, (uint32_t)(cfg->seed >> 32)};
-        for (KernelTimer* t : {&c->tm_errscan, &c->tm_errscan_f, &c->tm_reads, &c->tm_attach, &c->tm_indels}) t->gate = &c->timing_gate;
+        for (KernelTimer* t : {&c->tm_errscan, &c->tm_errscan_f, &c->tm_reads, &c->tm_attach, &c->tm_indels, &c->tm_attach_f}) t->gate = &c->timing_gate;
         c->flags.reserve(256, c->stream); HIP_OK(hipMemsetAsync(c->flags.p, 0, 256, c->stream));
         c->dsums.reserve(256, c->stream); HIP_OK(hipMemsetAsync(c->dsums.p, 0, 256, c->stream));
         c->d_tot.reserve(256, c->stream);
@@ -777,7 +778,7 @@ void scs_destroy(scs_ctx* c) {
                       &c->pair_off, &c->pairs, &c->odd_before, &c->a_part, &c->a_tp, &c->a_probs, &c->a_quota, &c->a_poff, &c->d_gidx, &c->d_gw, &c->d_grn, &c->d_tot, &c->d_stage, &c->d_all, &c->d_mail, &c->budget_f, &c->budget_s, &c->slot_off_f,
                       &c->slot_off_s, &c->dsums, &c->slot_b, &c->slot_q, &c->lens, &c->ev_hdr, &c->ev_dat, &c->sizes1, &c->sizes2, &c->off1, &c->off2, &c->out1, &c->out2}) b->release();
     c->semis.release(); c->fulls.release();
-    for (KernelTimer* t : {&c->tm_errscan, &c->tm_errscan_f, &c->tm_reads, &c->tm_attach, &c->tm_indels}) t->release();
+    for (KernelTimer* t : {&c->tm_errscan, &c->tm_errscan_f, &c->tm_reads, &c->tm_attach, &c->tm_indels, &c->tm_attach_f}) t->release();
     if (c->h_rb) (void)hipHostFree(c->h_rb);
     if (c->pipe) {
         for (int k = 0; k < 2; ++k) { if (c->pipe->h1[k]) (void)hipHostFree((size_t*)c->pipe->h1[k] - 2); if (c->pipe->h2[k]) (void)hipHostFree((size_t*)c->pipe->h2[k] - 2); (void)hipEventDestroy(c->pipe->ev[k]); }
@@ -844,16 +845,16 @@ int scs_get_stats(const scs_ctx* c, scs_stats* out) { if (!c || !out) return SCS
 
 int scs_kernel_time(const scs_ctx* c, int which, const char** name, uint64_t* launches, double* ms, uint64_t* units) {
     if (!c) return SCS_EINVAL;
-    const KernelTimer* t[] = {&c->tm_errscan, &c->tm_errscan_f, &c->tm_reads, &c->tm_attach, &c->tm_indels};
-    if (which < 0 || which >= 5) return SCS_EINVAL;
+    const KernelTimer* t[] = {&c->tm_errscan, &c->tm_errscan_f, &c->tm_reads, &c->tm_attach, &c->tm_indels, &c->tm_attach_f};
+    if (which < 0 || which >= 6) return SCS_EINVAL;
     if (name) *name = t[which]->name; if (launches) *launches = t[which]->launches; if (ms) *ms = t[which]->ms; if (units) *units = t[which]->units;
     return SCS_OK;
 }
 
 int scs_set_kernel_timing(scs_ctx* c, unsigned mask, unsigned every) {
     if (!c || every == 0) return SCS_EINVAL;
-    KernelTimer* t[] = {&c->tm_errscan, &c->tm_errscan_f, &c->tm_reads, &c->tm_attach, &c->tm_indels};
-    for (int i = 0; i < 5; ++i) t[i]->on = (mask >> i) & 1u;
+    KernelTimer* t[] = {&c->tm_errscan, &c->tm_errscan_f, &c->tm_reads, &c->tm_attach, &c->tm_indels, &c->tm_attach_f};
+    for (int i = 0; i < 6; ++i) t[i]->on = (mask >> i) & 1u;
     c->timing_every = every; c->amplify_calls = 0; c->yield_calls = 0;
     return SCS_OK;
 }

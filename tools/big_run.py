@@ -31,16 +31,21 @@ def main():
     t2 = time.time()
     print("FASTA parsed + uploaded + bit index in %.1f s" % (t2 - t1), flush=True)
     os.remove(fa)
-    g.create_frags(); t3 = time.time()
-    g.amplify(); t4 = time.time()
-    print("amplify %.2f s" % (t4 - t3), g.stats(), flush=True)
-    g.allocate_reads(0); t5 = time.time()
-    print("allocate %.2f s" % (t5 - t4), flush=True)
-    g.yield_reads(collect=False); t6 = time.time()
-    st = g.stats()
-    print("yield %.2f s" % (t6 - t5))
-    print("TOTAL hot path %.2f s for %d pairs -> %.2f M pairs/s ; fastq bytes %s ; kernels %s" %
-          (t6 - t3, st["pairs_written"], st["pairs_written"] / (t6 - t3) / 1e6, st["fastq_bytes"], g.kernel_times()))
+    # two passes over the hot path: the first maps the device buffers (cost depends on the state of the box's memory: a
+    # box handed over with freshly freed memory has been seen to spend 2 s there at 3 Gb), the second runs in them
+    for label, seed in (("first pass (maps device memory)", 1), ("second pass (buffers mapped)", 2)):
+        g.set_seed(seed)
+        t3 = time.time()
+        g.create_frags(); g.amplify(); t4 = time.time()
+        print("%s: amplify %.2f s" % (label, t4 - t3), g.stats(), flush=True)
+        g.allocate_reads(0); t5 = time.time()
+        print("allocate %.2f s" % (t5 - t4), flush=True)
+        g.yield_reads(collect=False); t6 = time.time()
+        st = g.stats()
+        kt = g.kernel_times()                                   # of this pass (the library restarts them per amplify / yield call)
+        print("yield %.2f s" % (t6 - t5))
+        print("TOTAL hot path %.2f s for %d pairs -> %.2f M pairs/s ; fastq bytes %s ; kernels %s" %
+              (t6 - t3, st["pairs_written"], st["pairs_written"] / (t6 - t3) / 1e6, st["fastq_bytes"], kt), flush=True)
 
 
 if __name__ == "__main__":
