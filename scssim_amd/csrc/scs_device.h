@@ -115,7 +115,7 @@ void launch_encode_bases(hipStream_t s, uint8_t* g, uint64_t n);
 void launch_genome_bits(hipStream_t s, const uint8_t* g, uint64_t n, uint64_t nwords, unsigned long long* gc_bits, unsigned long long* n_bits,
                         uint32_t* gc_cnt, uint32_t* n_cnt, uint64_t* gc_pref, uint64_t* n_pref, void* temp, size_t temp_bytes);
 void launch_amplify_init(hipStream_t s, int64_t* primer_cnt, int64_t copies, uint32_t* primer_delta, uint32_t* flags, unsigned long long* sums,
-                         unsigned long long nf_all, unsigned long long frag_len_all, unsigned long long total_primers);
+                         unsigned long long nf_all, unsigned long long frag_len_all, unsigned long long total_primers, uint32_t* pool_head_a, uint32_t* pool_head_b);
 void launch_primer_update(hipStream_t s, int64_t* primer_cnt, uint32_t* primer_delta);
 void launch_weights(hipStream_t s, DevAmps fulls, uint32_t n, DevTables tb, RngKey key, uint32_t frag_size, double* w);
 void launch_plan_pairs(hipStream_t s, DevFrags fr, DevAmps semis, DevAmps fulls, uint32_t n_fulls, const uint32_t* read_numbers, const uint32_t* pair_off,

@@ -100,12 +100,13 @@ __device__ __forceinline__ uint32_t rand_indx_thr(const uint32_t* __restrict__ T
 
 // start of Malbac::amplify: createPrimers (4^8 primer types x `copies`, Malbac.cpp:204-234) + the run's device scalars
 __global__ void k_amplify_init(int64_t* __restrict__ cnt, int64_t copies, uint32_t* __restrict__ delta, uint32_t* __restrict__ flags,
-                               unsigned long long* __restrict__ sums, unsigned long long nf_all, unsigned long long frag_len_all, unsigned long long total_primers) {
+                               unsigned long long* __restrict__ sums, unsigned long long nf_all, unsigned long long frag_len_all, unsigned long long total_primers,
+                               uint32_t* __restrict__ pool_head_a, uint32_t* __restrict__ pool_head_b) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < 65536) { cnt[i] = copies; delta[i] = 0; }
     if (i < SHARD_TAIL_WORDS) delta[65536 + i] = 0;
     if (i < 16) sums[i] = i == DS_G_PRIMERS ? total_primers : i == DS_G_TOTALS || i == DS_G_NF ? nf_all : i == DS_G_TOTALS + 1 || i == DS_G_FRAG_LEN ? frag_len_all : 0ull;
-    if (i == 0) flags[0] = 0;
+    if (i == 0) { flags[0] = 0; if (pool_head_a) *pool_head_a = 0; if (pool_head_b) *pool_head_b = 0; }   // error overflow pools of the two amplicon stores
 }
 // sharded job.  What the shards owe each other besides the primer decrements -- the semi amplicons a fragment pass made
 // (count, total length) and the budgets the last setPrimers handed out -- rides on the SAME all-reduce, as 24-bit limbs in
@@ -1476,8 +1477,8 @@ void launch_genome_bits(hipStream_t s, const uint8_t* g, uint64_t n, uint64_t nw
     (void)rocprim::exclusive_scan(temp, temp_bytes, rocprim::make_transform_iterator((const uint32_t*)n_cnt, Widen()), n_pref, (uint64_t)0, nwords + 1, rocprim::plus<uint64_t>(), s);
 }
 void launch_amplify_init(hipStream_t s, int64_t* primer_cnt, int64_t copies, uint32_t* primer_delta, uint32_t* flags, unsigned long long* sums,
-                         unsigned long long nf_all, unsigned long long frag_len_all, unsigned long long total_primers) {
-    hipLaunchKernelGGL(k_amplify_init, dim3(256), dim3(256), 0, s, primer_cnt, copies, primer_delta, flags, sums, nf_all, frag_len_all, total_primers);
+                         unsigned long long nf_all, unsigned long long frag_len_all, unsigned long long total_primers, uint32_t* pool_head_a, uint32_t* pool_head_b) {
+    hipLaunchKernelGGL(k_amplify_init, dim3(256), dim3(256), 0, s, primer_cnt, copies, primer_delta, flags, sums, nf_all, frag_len_all, total_primers, pool_head_a, pool_head_b);
 }
 void launch_shard_tail(hipStream_t s, uint32_t* primer_delta, unsigned long long* dsums, const uint32_t* new_semis, int with_budgets) {
     hipLaunchKernelGGL(k_shard_tail, dim3(1), dim3(64), 0, s, primer_delta, dsums, new_semis, with_budgets);

@@ -116,6 +116,7 @@ struct AmpStore {            // SoA amplicon arrays (DevAmps) with capacity mana
     DevAmps view() const { return DevAmps{parent.as<uint32_t>(), sl.as<uint32_t>(), gc.as<uint16_t>(), primers.as<uint16_t>(), uid.as<uint64_t>(), errs.as<uint64_t>()}; }
     DevErrPool pool_view() const { return DevErrPool{pool.as<uint32_t>(), pool_head.as<uint32_t>(), pool_cap}; }
     void reset(hipStream_t s) { n = 0; if (pool_head.p) HIP_OK(hipMemsetAsync(pool_head.p, 0, 4, s)); }
+    void reset_counts() { n = 0; }                                                // the pool head is zeroed by k_amplify_init
     void release() { parent.release(); sl.release(); gc.release(); primers.release(); uid.release(); errs.release(); pool.release(); pool_head.release(); n = cap = pool_cap = 0; }
 };
 
@@ -157,7 +158,8 @@ struct scs_ctx {
     std::vector<FastaRecord> recs; bool have_genome = false; DevBuf genome; std::vector<uint64_t> rec_off; uint64_t genome_bases = 0;
     std::vector<uint64_t> f_goff; std::vector<uint32_t> f_len; std::vector<int8_t> f_strand; std::vector<uint32_t> f_primers;
     uint64_t f_gidx_base = 0; bool have_frags = false;
-    DevBuf df_goff, df_len, df_strand, df_primers;
+    DevBuf df_blob, df_primers; size_t df_len_off = 0, df_strand_off = 0;           // fragments: offsets | lengths | strands in one block
+    uint8_t* h_frag = nullptr; size_t h_frag_cap = 0; bool frag_copy_pending = false;   // its pinned staging copy
     // amplicons
     AmpStore semis, fulls;
     DevBuf budget_f, budget_s, slot_off_f, slot_off_s, dsums; uint64_t* h_rb = nullptr;   // dsums: device scalars; h_rb: pinned, device-mapped mailbox (32 words)
@@ -208,7 +210,8 @@ struct scs_ctx {
     KernelTimer tm_errscan{"k_errs<semi->full>"}, tm_errscan_f{"k_errs<frag->semi>"}, tm_reads{"k_reads"}, tm_attach{"k_attach<semi>"}, tm_indels{"k_indels"}, tm_attach_f{"k_attach<frag>"};
 
     DevFrags frags_view() const {
-        return DevFrags{df_goff.as<uint64_t>(), df_len.as<uint32_t>(), df_strand.as<int8_t>(), df_primers.as<uint32_t>(), (uint32_t)f_len.size(), f_gidx_base};
+        uint8_t* b = df_blob.as<uint8_t>();
+        return DevFrags{(uint64_t*)b, (uint32_t*)(b + df_len_off), (int8_t*)(b + df_strand_off), df_primers.as<uint32_t>(), (uint32_t)f_len.size(), f_gidx_base};
     }
 };
 
@@ -231,9 +234,10 @@ void mail_wait(scs_ctx* c) {                                                    
     std::atomic_thread_fence(std::memory_order_acquire);
 }
 
-void check_flags(scs_ctx* c) {
+// device-side overflow flags: slot 30 of the mailbox.  flags_eval reads what a post already brought (the caller has
+// waited for that post, or synchronised the stream after it); check_flags posts and waits itself.
+void flags_eval(scs_ctx* c) {
     { const hipError_t le = take_launch_error(); if (le != hipSuccess) throw ScsError(SCS_EDEVICE, std::string("kernel launch failed: ") + hipGetErrorString(le)); }
-    Mail m; m.add(c->flags.p, 4, 30); mail_post(c, m, true); mail_wait(c);
     const uint32_t f = (uint32_t)c->h_rb[30];
     if (f) {
         HIP_OK(hipMemsetAsync(c->flags.p, 0, 4, c->stream));
@@ -244,6 +248,10 @@ void check_flags(scs_ctx* c) {
         if (f & FLAG_INTERNAL) m += " internal";
         throw ScsError(SCS_EOVERFLOW, m);
     }
+}
+void check_flags(scs_ctx* c) {
+    Mail m; m.add(c->flags.p, 4, 30); mail_post(c, m, true); mail_wait(c);
+    flags_eval(c);
 }
 
 template <class T>
@@ -333,9 +341,21 @@ void do_create_frags(scs_ctx* c) {
     c->nf_all = len.size(); c->frag_len_all = 0; for (auto l : len) c->frag_len_all += l;
     c->f_goff.assign(goff.begin() + lo, goff.begin() + hi); c->f_len.assign(len.begin() + lo, len.begin() + hi);
     c->f_strand.assign(strand.begin() + lo, strand.begin() + hi); c->f_primers.assign(hi - lo, 0); c->f_gidx_base = lo;
-    upload(c->df_goff, c->f_goff, c->stream); upload(c->df_len, c->f_len, c->stream); upload(c->df_strand, c->f_strand, c->stream);
+    // one asynchronous copy from a pinned staging block (offsets | lengths | strands); the stream orders it before the kernels
+    // that read it, and the block is not rewritten before that copy is done (frag_copy_pending, cleared by the next host wait)
+    {
+        const size_t nfr = c->f_len.size(), o_len = nfr * 8, o_str = o_len + nfr * 4, bytes = std::max<size_t>(o_str + nfr, 16);
+        if (c->frag_copy_pending) { HIP_OK(hipStreamSynchronize(c->stream)); c->frag_copy_pending = false; }
+        if (bytes > c->h_frag_cap) {
+            if (c->h_frag) HIP_OK(hipHostFree(c->h_frag));
+            c->h_frag_cap = bytes + bytes / 2; HIP_OK(hipHostMalloc((void**)&c->h_frag, c->h_frag_cap, hipHostMallocDefault));
+        }
+        if (nfr) { memcpy(c->h_frag, c->f_goff.data(), nfr * 8); memcpy(c->h_frag + o_len, c->f_len.data(), nfr * 4); memcpy(c->h_frag + o_str, c->f_strand.data(), nfr); }
+        c->df_blob.reserve(bytes, c->stream);
+        if (nfr) { HIP_OK(hipMemcpyAsync(c->df_blob.p, c->h_frag, o_str + nfr, hipMemcpyHostToDevice, c->stream)); c->frag_copy_pending = true; }
+        c->df_len_off = o_len; c->df_strand_off = o_str;
+    }
     c->df_primers.reserve(std::max<size_t>(c->f_len.size() * 4, 16), c->stream);
-    HIP_OK(hipStreamSynchronize(c->stream));
     c->have_frags = true; c->amplified = false; c->allocated = false;
     c->st.fragments = c->f_len.size();
 }
@@ -471,12 +491,12 @@ void do_amplify(scs_ctx* c) {
     if (!c->have_profile) throw ScsError(SCS_EINVAL, "scs_amplify: load a profile first");
     hipStream_t s = c->stream;
     if (c->cfg.verbose) fprintf(stderr, "\nMALBAC amplification...\n");
-    c->semis.reset(s); c->fulls.reset(s); c->semi_block_end.clear(); c->full_segs.clear(); c->pending_seg_cycle = -1; c->have_gidx = false; c->pend = Mail();
+    c->semis.reset_counts(); c->fulls.reset_counts(); c->semi_block_end.clear(); c->full_segs.clear(); c->pending_seg_cycle = -1; c->have_gidx = false; c->pend = Mail();
     c->timing_gate = (c->amplify_calls++ % c->timing_every) == 0;
     c->tm_errscan.reset(); c->tm_errscan_f.reset(); c->tm_attach.reset(); c->tm_attach_f.reset();
     c->primer_cnt.reserve(65536 * 8, s); c->primer_delta.reserve((65536 + SHARD_TAIL_WORDS) * 4, s);   // createPrimers: 4^8 types x `primers` copies
     launch_amplify_init(s, c->primer_cnt.as<int64_t>(), (int64_t)c->cfg.primers, c->primer_delta.as<uint32_t>(), c->flags.as<uint32_t>(), c->dsums.as<unsigned long long>(),
-                        c->nf_all, c->frag_len_all, 65536ull * (uint64_t)c->cfg.primers);
+                        c->nf_all, c->frag_len_all, 65536ull * (uint64_t)c->cfg.primers, c->semis.pool_head.as<uint32_t>(), c->fulls.pool_head.as<uint32_t>());
     if (!c->d_binom.p) {   // [REMAP] error-count thresholds for every window length (cfg is fixed for the ctx lifetime)
         std::vector<uint64_t> bt = binom_table(c->cfg.ber, c->cfg.amplicon_min_len - 8, c->cfg.amplicon_max_len - 8);
         upload(c->d_binom, bt, s); HIP_OK(hipStreamSynchronize(s));
@@ -484,7 +504,7 @@ void do_amplify(scs_ctx* c) {
     c->total_primers = 65536ull * (uint64_t)c->cfg.primers;
     c->frag_total_len = 0; for (uint32_t l : c->f_len) c->frag_total_len += l;
     c->semi_total_len = 0;
-    set_primers_launch(c, true, 0, 0); mail_wait(c); set_primers_finish(c);
+    set_primers_launch(c, true, 0, 0); mail_wait(c); c->frag_copy_pending = false; set_primers_finish(c);
     launch_pass(c, true, 0, 5);
     int open_fulls = -1, open_semis = 5; uint32_t semis_in_flight = c->slots_f;     // the group of passes not read back yet
     for (uint32_t i = 0; i < 5; ++i) {
@@ -502,8 +522,9 @@ void do_amplify(scs_ctx* c) {
         open_fulls = 4; open_semis = i < 4 ? 5 : -1; semis_in_flight = i < 4 ? c->slots_f : 0;
         if (c->cfg.verbose) { fprintf(stderr, "semi amplicon amplification done!\n"); if (i < 4) fprintf(stderr, "fragment amplification done!\n"); }
     }
+    c->pend.add(c->flags.p, 4, 30);                                              // the overflow flags ride on the last collect: one wait, not two
     collect_post(c, true); mail_wait(c); collect_read(c, open_fulls, open_semis);
-    check_flags(c);
+    flags_eval(c);
     c->tm_errscan.collect(); c->tm_errscan_f.collect(); c->tm_attach.collect(); c->tm_attach_f.collect();
     c->amplified = true; c->allocated = false;
     c->st.semi_amplicons = c->semis.n; c->st.full_amplicons = c->fulls.n; c->st.primers_left = c->total_primers;
@@ -706,9 +727,10 @@ void do_yield(scs_ctx* c, const OutTarget& tg, uint64_t* n1_out, uint64_t* n2_ou
                              for (auto& r : hp) pairs_written += r.isz != 0; }
         else pairs_written = P;
     }
+    { Mail m; m.add(c->flags.p, 4, 30); mail_post(c, m, true); }                  // the overflow flags land before the final synchronize: no second round trip
     HIP_OK(hipStreamSynchronize(s));
     if (to_sink) { guard.p = nullptr; if (!c->pipe->finish()) throw ScsError(SCS_EIO, "sink aborted"); }
-    check_flags(c);
+    mail_wait(c); flags_eval(c);
     c->tm_reads.collect(); c->tm_indels.collect();
     c->st.pairs_written = pairs_written; c->st.reads_written = paired ? 2 * pairs_written : pairs_written;
     c->st.fastq_bytes[0] = tot1; c->st.fastq_bytes[1] = tot2;
@@ -773,13 +795,14 @@ void scs_destroy(scs_ctx* c) {
     (void)hipSetDevice(c->cfg.device);
     (void)hipStreamSynchronize(c->stream);
     for (DevBuf* b : {&c->d_tables, &c->t_qcompact, &c->t_guide, &c->t_subs1, &c->t_subs2, &c->t_qual, &c->t_ins, &c->t_del, &c->t_isize, &c->d_subs1, &c->d_subs2, &c->d_qual, &c->d_ins, &c->d_del,
-                      &c->d_isize, &c->d_gcmeans, &c->genome, &c->gx_gc_bits, &c->gx_n_bits, &c->gx_gc_cnt, &c->gx_n_cnt, &c->gx_gc_pref, &c->gx_n_pref, &c->d_binom, &c->df_goff, &c->df_len, &c->df_strand, &c->df_primers, &c->primer_cnt, &c->primer_delta,
+                      &c->d_isize, &c->d_gcmeans, &c->genome, &c->gx_gc_bits, &c->gx_n_bits, &c->gx_gc_cnt, &c->gx_n_cnt, &c->gx_gc_pref, &c->gx_n_pref, &c->d_binom, &c->df_blob, &c->df_primers, &c->primer_cnt, &c->primer_delta,
                       &c->slots, &c->slot_tmpl, &c->valid, &c->valid_off, &c->valid_f, &c->valid_off_f, &c->scan_tmp, &c->flags, &c->weights, &c->read_numbers,
                       &c->pair_off, &c->pairs, &c->odd_before, &c->a_part, &c->a_tp, &c->a_probs, &c->a_quota, &c->a_poff, &c->d_gidx, &c->d_gw, &c->d_grn, &c->d_tot, &c->d_stage, &c->d_all, &c->d_mail, &c->budget_f, &c->budget_s, &c->slot_off_f,
                       &c->slot_off_s, &c->dsums, &c->slot_b, &c->slot_q, &c->lens, &c->ev_hdr, &c->ev_dat, &c->sizes1, &c->sizes2, &c->off1, &c->off2, &c->out1, &c->out2}) b->release();
     c->semis.release(); c->fulls.release();
     for (KernelTimer* t : {&c->tm_errscan, &c->tm_errscan_f, &c->tm_reads, &c->tm_attach, &c->tm_indels, &c->tm_attach_f}) t->release();
     if (c->h_rb) (void)hipHostFree(c->h_rb);
+    if (c->h_frag) (void)hipHostFree(c->h_frag);
     if (c->pipe) {
         for (int k = 0; k < 2; ++k) { if (c->pipe->h1[k]) (void)hipHostFree((size_t*)c->pipe->h1[k] - 2); if (c->pipe->h2[k]) (void)hipHostFree((size_t*)c->pipe->h2[k] - 2); (void)hipEventDestroy(c->pipe->ev[k]); }
         delete c->pipe;
