@@ -1204,14 +1204,22 @@ __global__ void __launch_bounds__(64) k_attach(const uint8_t* __restrict__ g, De
             if (unresolved && !dead) {
                 if (!need && ((bits[spos >> 5] >> (spos & 31)) & 1u)) need = true;       // a lower primer took this position meanwhile
                 while (need) {
-                    spos = scale_draw(xt.next(), 27, len - 27);                                       // randomInteger(27, length)
-                    alen = scale_draw(xt.next(), p.amp_min, p.amp_max + 1 - p.amp_min);               // (uint) randomDouble(minLen, maxLen+1)
-                    ++tries;
-                    if (tries > 50) { dead = true; break; }
-                    if (spos + alen > len) continue;
-                    if ((bits[spos >> 5] >> (spos & 31)) & 1u) continue;                  // posAttached[spos]
-                    // primer 8-mer of the template strand: the 8 bases are contiguous in the genome -> ONE 8-byte load (reversed /
-                    // complemented in registers), then the semi's own substitutions are patched in (no load sits under a branch)
+                    // (a) my stream's next try that fits the template and lands on a free position: draws and LDS only, so the
+                    // lanes of the wave run it together without a memory wait per try ...
+                    bool cand = false;
+                    while (!cand) {
+                        spos = scale_draw(xt.next(), 27, len - 27);                                   // randomInteger(27, length)
+                        alen = scale_draw(xt.next(), p.amp_min, p.amp_max + 1 - p.amp_min);           // (uint) randomDouble(minLen, maxLen+1)
+                        ++tries;
+                        if (tries > 50) { dead = true; break; }
+                        if (spos + alen > len) continue;
+                        if ((bits[spos >> 5] >> (spos & 31)) & 1u) continue;              // posAttached[spos]
+                        cand = true;
+                    }
+                    if (dead) break;
+                    // (b) ... and only then its primer 8-mer and the stock, all candidates of the wave in one round of loads.  The 8
+                    // bases are contiguous in the genome -> ONE 8-byte load (reversed / complemented in registers), then the semi's
+                    // own substitutions are patched in (no load sits under a branch)
                     unsigned long long v8 = view_bases8(g, tv, spos);
                     if (!FROM_FRAG) for_each_err(errs, spool.data, [&](uint32_t e) {
                         const uint32_t k = len - 1u - err_pos(e) - spos;                 // template position of the error, relative to spos
