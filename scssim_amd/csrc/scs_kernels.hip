@@ -1161,8 +1161,8 @@ __global__ void __launch_bounds__(256) k_poisson(DevFrags fr, DevAmps semis, uin
 // K1a  attach: the primer loop of Fragment::amplify (lib/fragment/Fragment.cpp:73-95) and
 //      Amplicon::amplify (lib/amplicon/Amplicon.cpp:176-198).  The reference's loop is sequential
 //      in the primer index (posAttached[] and the >50-tries abort).  Here a group of G lanes owns
-//      one template (G = 64: one wave per fragment, budgets of hundreds; G = 16: four semi
-//      amplicons per wave, budgets of ~6): the lanes evaluate G primers speculatively and commit
+//      one template (G = 64: one wave per fragment, budgets of hundreds; G = 8 or 4: eight or
+//      sixteen semi amplicons per wave, budgets of a few): the lanes evaluate G primers speculatively and commit
 //      them in index order -- a primer commits only when every lower primer has; one whose
 //      proposal hits a committed position moves on to its next try exactly as the sequential loop
 //      would.  The result is identical to running the sequential loop.
