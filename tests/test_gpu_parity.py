@@ -147,6 +147,24 @@ def test_full_pipeline_fastq_bit_exact(case, model, oargs, layout, cov, isize, e
     assert (again1, again2) == (fq1, fq2)
 
 
+@pytest.mark.parametrize("model", MODELS)
+def test_seed_sweep_fastq_bit_exact(model, oracle_bin, models, golden_inputs, tmp_path):
+    """The same small genome under every shipped model, both layouts and several seeds and insert sizes: every run moves
+    the records to other byte offsets (sector phases of the FASTQ writer), other indel patterns and other deferred
+    qualities.  FASTQ must equal the oracle's byte for byte each time."""
+    fa = golden_inputs["g1_hiseq2500_pe"]
+    for k, (layout, isize, seed) in enumerate((("PE", 260, 11), ("PE", 301, 12), ("SE", 260, 13), ("PE", 277, 14))):
+        prefix = str(tmp_path / ("o%d" % k))
+        _oracle_run(oracle_bin, fa, models[model], prefix, ["-c", "2", "-s", str(isize)] + (["-l", "SE"] if layout == "SE" else []), seed)
+        g = scssim_amd.GenReads(profile=models[model], input_fasta=fa, coverage=2.0, isize=isize, layout=layout, seed=seed)
+        fq1, fq2 = g.run()
+        if layout == "PE":
+            assert fq1 == open(prefix + "_1.fq", "rb").read(), (model, layout, isize, seed)
+            assert fq2 == open(prefix + "_2.fq", "rb").read(), (model, layout, isize, seed)
+        else:
+            assert fq1 == open(prefix + ".fq", "rb").read(), (model, layout, isize, seed)
+
+
 def test_cli_drop_in(oracle_bin, models, golden_inputs, tmp_path):
     """`scssim genreads` (the reference's CLI surface) writes the same files as the oracle CLI."""
     import shutil
