@@ -1,23 +1,36 @@
 #!/usr/bin/env python3
-"""bench.py -- genreads hot path on N MI355X (one process per GPU).
+"""bench.py -- the genreads hot path on N MI355X (one process per GPU), on the metric's configuration.
 
-Metric (BASELINE.json): paired-end read pairs/s, whole job, inputs resident in HBM, plus the HBM
-roofline fraction of the dominant kernel and the CPU path timed on this box's host cores.
+Metric (BASELINE.json): paired-end read pairs/s at PE150, 30x, quoted on the 3 Gb whole genome (configs[3]); plus the
+HBM roofline fraction of the dominant kernel and the reference's CPU path timed on this box's host cores.
 
-Workload at N=1 = BASELINE configs[1]: 1 Mb synthetic reference (i.i.d. 30/20/20/30 % A/C/G/T, seed 1,
-diploid simuvars-style FASTA), PE150 at 30x, HiSeq2500 model.  The reference ships no 150 bp model and
-takes the read length from the profile only, so "PE150" = the shipped HiSeq2500 profile with its bin
-axis resampled 125 -> 150 (tools/make_profile.py).  One step = one complete job
-(fragment split, 1+5 MALBAC cycles, read allocation, fragment sampling, error/quality injection,
-FASTQ formatting into an HBM pool) with a fresh seed.  N>1: weak scaling, each rank runs the same
-workload on its own 1 Mb record (fragment-lineage shard = one record per rank, no data-path
-collective), then the FASTQ pools are gathered on the writer rank over RCCL.
+Workload (fits one MI355X): synthetic diploid whole genome, 24 records with the hg19 chromosome lengths
+(3 095 677 412 bases per haplotype, two identical haplotype records per chromosome named <chr>_<hap>_<len> as
+`simuvars` writes them), i.i.d. bases P(A,C,G,T) = (0.3, 0.2, 0.2, 0.3) drawn on the GPU (torch, seeded) and handed to
+the library in HBM (scs_upload_genome_device) -- a 6 GB FASTA written and parsed per run would only time the disk.
+PE150 = the shipped HiSeq2500 profile with its bin axis resampled 125 -> 150 (tools/make_profile.py; the reference
+takes the read length from the profile only and ships no 150 bp model); 30x, -p 100000 -r 1e-9 -s 260.
+
+One step = one complete job with a fresh seed: fragment split, 1+5 MALBAC cycles, GC-biased read allocation, fragment
+sampling, indel / substitution / quality injection, FASTQ text -- generated batch by batch into HBM buffers
+(scs_yield_reads with a NULL sink: generate and count).  `value` = pairs / that time (inputs resident in HBM).
+Beside it, at N = 1 and outside the timed region:
+  sink_inclusive : one more step through scs_yield_reads with a real sink -- D2H into pinned buffers + write(2) into two
+                   tmpfs files (rewound every few GB so the page cache stays bounded) -- the window the reference times
+                   (src/scssim.cpp:59-73 includes SeqWriter);
+  cli_wall       : the `scssim genreads` binary end to end (FASTA parse, profile, job, files) at chr20 size (configs[2]);
+  cpu_baseline   : the reference itself (oracle/_ref/scssim_ref, compiled from /root/reference by oracle/Makefile) with
+                   -t <cores> on a bounded sample of the same genome; the oracle port beside it.
+N > 1 (driver: torch.distributed.run, one rank per GPU): the SAME job sharded N ways by fragment lineage (strong
+scaling); per-pass primer-stock all-reduce and the allocation partials over RCCL; every rank keeps its own FASTQ shard.
 """
 import argparse
+import glob
 import gzip
 import json
 import os
 import re
+import shutil
 import subprocess
 import sys
 import tempfile
@@ -27,75 +40,186 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HG19 = [249250621, 243199373, 198022430, 191154276, 180915260, 171115067, 159138663, 146364022, 141213431, 135534747,
+        135006516, 133851895, 115169878, 107349540, 102531392, 90354753, 81195210, 78077248, 59128983, 63025520,
+        48129895, 51304566, 155270560, 59373566]
 
 
-def make_inputs(td, rank, n_records=1):
-    """n_records x 1 Mb records (weak scaling: one record's worth of fragments per rank); every rank builds the same file."""
-    fa = os.path.join(td, "simu_%d.fa" % rank)
-    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "make_genome.py"), "--lengths", ",".join(["1000000"] * n_records),
-                           "--seed", "1", "--first-chr", "20", "--simu-out", fa])
-    src = os.path.join(td, "hiseq2500_%d.profile" % rank)
-    open(src, "wb").write(gzip.open(os.path.join(ROOT, "tests", "golden", "models", "Illumina_HiSeq2500.profile.gz")).read())
-    prof = os.path.join(td, "pe150_%d.profile" % rank)
+def record_lengths(genome_mb):
+    """24 hg19-like records; --genome-mb scales them (rehearsals and tests only: the default is the real lengths)."""
+    if not genome_mb:
+        return list(HG19)
+    f = genome_mb * 1e6 / sum(HG19)
+    return [max(50000, int(x * f)) for x in HG19]
+
+
+def make_profile(td):
+    src = os.path.join(td, "hiseq2500.profile")
+    with open(src, "wb") as f:
+        f.write(gzip.open(os.path.join(ROOT, "tests", "golden", "models", "Illumina_HiSeq2500.profile.gz")).read())
+    prof = os.path.join(td, "pe150.profile")
     subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "make_profile.py"), src, prof, "--read-length", "150"])
-    return fa, prof
+    return prof
 
 
-def cpu_baseline(fa, prof, seed):
-    """The oracle (CPU restatement, counter mode, thread pool) on this box's host cores: the same
-    workload, one step.  Checker code timed as a baseline -- never the thing shipped."""
+def synth_genome(torch, dev, lens, seed):
+    """Diploid genome in HBM as ASCII: per chromosome two identical haplotype records (what `simuvars` emits without a
+    variation file).  Returns (names, lens per record, uint8 tensor)."""
+    bases = torch.empty(2 * sum(lens), dtype=torch.uint8, device=dev)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed)
+    names, rl, off = [], [], 0
+    for i, n in enumerate(lens):
+        u = torch.rand(n, device=dev, generator=gen)
+        rec = (u >= 0.3).to(torch.uint8) * 2 + (u >= 0.5).to(torch.uint8) * 4 + (u >= 0.7).to(torch.uint8) * 13 + 65    # A C G T = 65 67 71 84
+        del u
+        for hap in (1, 2):
+            bases[off:off + n] = rec
+            off += n
+            names.append("%d_%d_%d" % (i + 1, hap, n))
+            rl.append(n)
+        del rec
+    return names, rl, bases
+
+
+def write_simu_fasta(path, names, seqs):
+    """simuvars-style FASTA (100 columns) from numpy uint8 arrays."""
+    import numpy as np
+    with open(path, "wb") as f:
+        for name, s in zip(names, seqs):
+            f.write(b">" + name.encode() + b"\n")
+            n = len(s)
+            full = (n // 100) * 100
+            if full:
+                body = np.concatenate([s[:full].reshape(-1, 100), np.full((full // 100, 1), 10, np.uint8)], axis=1)
+                f.write(body.tobytes())
+            if n > full:
+                f.write(s[full:].tobytes() + b"\n")
+
+
+def host_cores():
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:                                                # a cgroup CPU quota bounds what a thread pool really gets
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = max(1, min(n, int(float(q) / float(p) + 0.5)))
+    except Exception:
+        pass
+    return n
+
+
+def cpu_baseline(td, prof, names, seqs, sample_desc, coverage):
+    """The reference's own CPU path on this box's host cores, on a bounded sample of the bench genome (same profile,
+    coverage and options).  oracle/_ref/scssim_ref is the reference compiled from its sources (oracle/Makefile, target
+    ref); when it is absent the oracle port stands in.  Checker code timed as a baseline -- never the thing shipped."""
+    fa = os.path.join(td, "cpu_sample.fa")
+    write_simu_fasta(fa, names, seqs)
+    cores = host_cores()
+    out = {}
+    ref = os.path.join(ROOT, "oracle", "_ref", "scssim_ref")
     oracle = os.path.join(ROOT, "oracle", "_build", "scs_oracle")
-    if not os.path.exists(oracle):
-        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    r = subprocess.run([oracle, "genreads", "-i", fa, "-m", prof, "-c", "30", "-t", str(cores), "-o", fa + ".cpu",
-                        "--rng", "counter", "--seed", str(seed)], capture_output=True, text=True, check=True)
-    m = re.search(r"pairs=(\d+) \| load ([\d.]+)s frag ([\d.]+)s amplify ([\d.]+)s alloc ([\d.]+)s readgen ([\d.]+)s", r.stderr)
-    pairs = int(m.group(1))
-    secs = sum(float(m.group(i)) for i in (3, 4, 5, 6))
-    for suf in ("_1.fq", "_2.fq"):
-        try:
-            os.remove(fa + ".cpu" + suf)
-        except OSError:
-            pass
-    return dict(value=pairs / secs, unit="pairs/s", cores=cores, kind="port",
-                sample="the full N=1 workload, 1 step (%d pairs in %.2f s: amplify %.2f, allocate %.2f, readgen %.2f)" %
-                       (pairs, secs, float(m.group(4)), float(m.group(5)), float(m.group(6))))
+    if os.path.exists(ref):
+        t0 = time.perf_counter()
+        r = subprocess.run([ref, "genreads", "-i", fa, "-m", prof, "-c", "%g" % coverage, "-t", str(cores), "-o", fa + ".ref"], capture_output=True, text=True)
+        secs = time.perf_counter() - t0
+        if r.returncode == 0 and os.path.exists(fa + ".ref_1.fq"):
+            pairs = sum(1 for _ in open(fa + ".ref_1.fq", "rb")) // 4
+            out = dict(value=pairs / secs, unit="pairs/s", cores=cores, kind="reference",
+                       sample="%s: %d pairs in %.1f s wall of `scssim genreads -t %d` (whole process: load + amplify + reads + files)" % (sample_desc, pairs, secs, cores))
+        for suf in (".ref_1.fq", ".ref_2.fq"):
+            if os.path.exists(fa + suf):
+                os.remove(fa + suf)
+    if os.path.exists(oracle):
+        r = subprocess.run([oracle, "genreads", "-i", fa, "-m", prof, "-c", "%g" % coverage, "-t", str(cores), "-o", fa + ".cpu", "--rng", "counter", "--seed", "7"],
+                           capture_output=True, text=True)
+        m = re.search(r"pairs=(\d+) \| load ([\d.]+)s frag ([\d.]+)s amplify ([\d.]+)s alloc ([\d.]+)s readgen ([\d.]+)s", r.stderr)
+        if r.returncode == 0 and m:
+            pairs = int(m.group(1))
+            secs = sum(float(m.group(i)) for i in (3, 4, 5, 6))
+            port = dict(value=pairs / secs, unit="pairs/s", cores=cores, kind="port",
+                        sample="%s: %d pairs in %.1f s (amplify %.1f, allocate %.1f, readgen + files %.1f)" % (sample_desc, pairs, secs, float(m.group(4)), float(m.group(5)), float(m.group(6))))
+            if out:
+                out["port"] = port
+            else:
+                out = port
+        for suf in (".cpu_1.fq", ".cpu_2.fq"):
+            if os.path.exists(fa + suf):
+                os.remove(fa + suf)
+    os.remove(fa)
+    return out or None
 
 
-def pmc_traffic(members):
-    """HBM bytes per launch of the dominant kernel (group) from the committed rocprofv3 PMC summary of this same command
-    (FETCH_SIZE and WRITE_SIZE collected in separate --pmc passes; KB -> bytes; tools/pmc_summary.py).  bench.py cannot
-    collect PMC counters itself, so the number is read from profiles/; None if the summary is absent.  For the
-    amplification group one launch = one pass: bytes of all member kernels / passes."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_n1_pmc_hbm.csv")))
-    if not files:
-        return None, None
-    prefix = {"k_attach<semi>": "scs::k_attach<false", "k_attach<frag>": "scs::k_attach<true", "k_errs<semi->full>": "scs::k_errs<false>", "k_errs<frag->semi>": "scs::k_errs<true>",
-              "k_reads": "scs::k_reads", "k_indels": "scs::k_indels"}
-    tot, launches0 = 0.0, 0
-    for line in open(files[-1]):
-        if line.startswith("#") or line.startswith("kernel"):
-            continue
-        name, fetch, write, n = line.rstrip("\n").rsplit(",", 3)
-        for i, m in enumerate(members):
-            if name.startswith(prefix[m]):
-                # gfx950: FETCH_SIZE under-reports wide coalesced reads by 2x (MI355X_MICROARCH.md, HBM); byte/dword gathers
-                # as here are uncalibrated, so the raw value is reported and the x2 bound is in DESIGN.md
-                tot += (float(fetch) + float(write)) * 1024.0 * int(n)
-                if m.startswith("k_attach") or len(members) == 1:
-                    launches0 += int(n)
-    return (tot / launches0 if launches0 else None), os.path.relpath(files[-1], ROOT)
+def committed_counters(kernel_prefix):
+    """Counters bench.py cannot collect itself, read from the newest committed rocprofv3 summaries of this same command
+    (profiles/r*_bench_pmc_hbm.csv: FETCH_SIZE / WRITE_SIZE in separate --pmc passes, KB -> bytes, per launch;
+    profiles/r*_bench_sq.csv: SQ_INSTS_VALU, SQ_THREAD_CYCLES_VALU ... per launch).  None when absent."""
+    res = {}
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_pmc_hbm.csv")))
+    if files:
+        for line in open(files[-1]):
+            if line.startswith("#") or line.startswith("kernel"):
+                continue
+            name, fetch, write, n = line.rstrip("\n").rsplit(",", 3)
+            if name.startswith(kernel_prefix):
+                res["traffic"] = (float(fetch) + float(write)) * 1024.0
+                res["traffic_source"] = os.path.relpath(files[-1], ROOT)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_sq.csv")))
+    if files:
+        for line in open(files[-1]):
+            if line.startswith("#") or line.startswith("kernel"):
+                continue
+            f = line.rstrip("\n").rsplit(",", 3)                      # kernel names contain commas
+            if len(f) == 4 and f[0].startswith(kernel_prefix):
+                try:
+                    res["valu_insts_per_launch"] = float(f[1]); res["lanes_per_valu_inst"] = float(f[2]); res["salu_insts_per_launch"] = float(f[3])
+                    res["sq_source"] = os.path.relpath(files[-1], ROOT)
+                except ValueError:
+                    pass
+    return res
+
+
+class FileSink:
+    """scs_sink_fn for the sink-inclusive leg: write(2) into two tmpfs files, rewound every `recycle` bytes so that the
+    page cache stays bounded (a whole-genome job writes ~190 GB of FASTQ)."""
+
+    def __init__(self, d, recycle=4 << 30):
+        self.fd = [os.open(os.path.join(d, "bench_sink_%d.fq" % k), os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o600) for k in (1, 2)]
+        self.pos = [0, 0]
+        self.total = 0
+        self.recycle = recycle
+
+    def __call__(self, _u, p1, n1, p2, n2):
+        import ctypes as C
+        for k, (p, n) in enumerate(((p1, n1), (p2, n2))):
+            if not n:
+                continue
+            mv = memoryview((C.c_char * n).from_address(p))
+            done = 0
+            while done < n:
+                done += os.write(self.fd[k], mv[done:])
+            self.pos[k] += n
+            self.total += n
+            if self.pos[k] > self.recycle:
+                os.ftruncate(self.fd[k], 0)
+                os.lseek(self.fd[k], 0, os.SEEK_SET)
+                self.pos[k] = 0
+        return 0
+
+    def close(self):
+        for fd in self.fd:
+            os.close(fd)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--genome-mb", type=float, default=0.0, help="scale the 24 hg19-like records to this many Mb (default: the real 3096 Mb)")
+    ap.add_argument("--coverage", type=float, default=30.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--force-hooks", action="store_true", help="install the collective hooks even at N=1 (measures their cost)")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the sink-inclusive and CLI legs")
+    ap.add_argument("--cpu-sample-mb", type=float, default=4.0)
     a = ap.parse_args()
 
     import torch
@@ -105,115 +229,91 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            sys.exit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d bench.py --gpus %d ..." % (a.gpus, a.gpus))
+    if world != a.gpus and world == 1 and a.gpus > 1:
+        sys.exit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d bench.py --gpus %d ..." % (a.gpus, a.gpus))
     # rehearsal of the N > 1 control flow on a box with ONE GPU: SCS_BENCH_BACKEND=gloo SCS_BENCH_ONE_DEVICE=1 (all ranks on
-    # cuda:0, collectives and the pool transfer staged through the CPU).  Never a measurement.
+    # cuda:0, collectives staged through the CPU).  Never a measurement.
     backend = os.environ.get("SCS_BENCH_BACKEND", "nccl")
     cpu_coll = backend != "nccl"
     if os.environ.get("SCS_BENCH_ONE_DEVICE") == "1":
         local = 0
     torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if cpu_coll:
             dist.init_process_group(backend)
         else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    dev = torch.device("cuda", local)
-    cdev = torch.device("cpu") if cpu_coll else dev                     # where the bench's own collectives live
+            dist.init_process_group("nccl", device_id=dev)
+    cdev = torch.device("cpu") if cpu_coll else dev
 
     td = tempfile.mkdtemp(prefix="scsbench_")
-    fa, prof = make_inputs(td, rank, world)
-    # N > 1: ONE job (world x 1 Mb genome) sharded by fragment lineage; the setPrimers totals, the primer stock and the
-    # weight normalisation are exchanged through RCCL (scssim_amd/dist.py hooks on the ctx stream); FASTQ is identical to
-    # the 1-GPU run of the same genome.
+    prof = make_profile(td)
+    lens = record_lengths(a.genome_mb)
+    t_gen = time.perf_counter()
+    names, rl, bases = synth_genome(torch, dev, lens, 3000)
+    torch.cuda.synchronize()
+    t_gen = time.perf_counter() - t_gen
     stream = torch.cuda.Stream()
-    g = scssim_amd.GenReads(profile=prof, input_fasta=fa, coverage=30.0, isize=260, layout="PE", seed=1, device=local,
+    g = scssim_amd.GenReads(profile=prof, coverage=a.coverage, isize=260, layout="PE", seed=1, device=local,
                             stream=stream.cuda_stream, shard_rank=rank, shard_count=world)
-    if world > 1 or a.force_hooks:
+    t_up = time.perf_counter()
+    g.upload_genome_device(names, rl, bases.data_ptr())
+    t_up = time.perf_counter() - t_up
+    # samples for the CPU / CLI legs come from the same genome: taken before it is released
+    cpu_sample = cli_sample = None
+    if rank == 0 and world == 1:
+        n_cpu = min(rl[0], int(a.cpu_sample_mb * 1e6))
+        cpu_sample = bases[:n_cpu].cpu().numpy()
+        if not a.no_extra_legs:
+            i20 = 2 * 19 if len(rl) >= 40 else 0                     # chromosome 20 (configs[2]: chr20-size)
+            o20 = sum(rl[:i20])
+            cli_sample = bases[o20:o20 + rl[i20]].cpu().numpy()
+    del bases
+    torch.cuda.empty_cache()
+    if world > 1:
         from scssim_amd.dist import Collectives
-        if world == 1:
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
-            os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         coll = Collectives(stream=stream)
         g.set_collectives(coll, device_hooks=True)
-    cap = 96 << 20
-    # FASTQ pools are double-buffered so the gather of step i (RCCL point-to-point on its own stream) overlaps the
-    # compute of step i+1; every transfer completes inside the timed region (final synchronize + barrier).
-    pools = [[torch.empty(cap, dtype=torch.uint8, device=dev) for _ in range(2)] for _ in range(2)]
-    gathered = [torch.empty(cap, dtype=torch.uint8, device=cdev) for _ in range(2 * (world - 1))] if (world > 1 and rank == 0) else []
-    inflight = [[], []]
+
     ktimes = {}
 
-    def step(i, record):
-        b = i & 1
-        with torch.cuda.stream(stream):
-            for w in inflight[b]:                       # the ctx stream waits until this buffer's previous gather is done
-                w.wait()
-        inflight[b] = []
-        g.set_seed(1000 + i)
-        g.create_frags()
-        g.amplify()
-        if record:
-            acc(g.kernel_times(), ("k_errs<semi->full>", "k_errs<frag->semi>", "k_attach<semi>", "k_attach<frag>"))
-        g.allocate_reads(0)
-        pool1, pool2 = pools[b]
-        n1, n2, pairs = g.yield_reads_device(pool1.data_ptr(), cap, pool2.data_ptr(), cap)
-        if record:
-            acc(g.kernel_times(), ("k_reads", "k_indels"))
-        if world > 1:                                   # read pool -> writer rank (RCCL point-to-point over xGMI)
-            with torch.cuda.stream(stream):
-                sizes = torch.tensor([n1, n2], dtype=torch.int64, device=cdev)
-                allsz = torch.zeros(2 * world, dtype=torch.int64, device=cdev)
-                dist.all_gather_into_tensor(allsz, sizes)
-                ops = []
-                if rank == 0:
-                    hs = allsz.cpu().tolist()
-                    for r in range(1, world):
-                        ops.append(dist.P2POp(dist.irecv, gathered[2 * (r - 1)][:hs[2 * r]], r))
-                        ops.append(dist.P2POp(dist.irecv, gathered[2 * (r - 1) + 1][:hs[2 * r + 1]], r))
-                else:
-                    ops.append(dist.P2POp(dist.isend, pool1[:n1].cpu() if cpu_coll else pool1[:n1], 0))
-                    ops.append(dist.P2POp(dist.isend, pool2[:n2].cpu() if cpu_coll else pool2[:n2], 0))
-                inflight[b] = dist.batch_isend_irecv(ops)
-        return pairs, g.stats()
-
-    def acc(kt, names):
-        for k in names:
+    def acc(kt, names_):
+        for k in names_:
             d = ktimes.setdefault(k, dict(launches=0, ms=0.0, units=0))
             for f in ("launches", "ms", "units"):
                 d[f] += kt[k][f]
 
-    # warm-up: every kernel timed -> per-kernel breakdown and the dominant kernel.  Timed region: HIP events only around
-    # that dominant kernel (each event record is a packet on the stream of this latency-bound job).
-    for i in range(a.warmup):
-        step(i, True)
-    warm_ktimes = {k: dict(v) for k, v in ktimes.items()}
-    # the amplification pass is one unit of SURVEY 8(d) (1526 B per created amplicon = attach + error scan together)
-    GROUPS = {"k_attach+k_errs": ("k_attach<semi>", "k_attach<frag>", "k_errs<semi->full>", "k_errs<frag->semi>"), "k_reads": ("k_reads",), "k_indels": ("k_indels",)}
-    # dominant = the kernel with the largest total time (rocprof's ranking); an amplification kernel stands for its pass
-    top = max(warm_ktimes, key=lambda k: warm_ktimes[k]["ms"]) if warm_ktimes else "k_reads"
-    dominant = top if top in GROUPS else "k_attach+k_errs"
+    stage = dict(frags=0.0, amplify=0.0, allocate=0.0, reads=0.0)
+
+    def step(i, sink=None):
+        g.set_seed(1000 + i)
+        t0 = time.perf_counter(); g.create_frags()
+        t1 = time.perf_counter(); g.amplify()
+        acc(g.kernel_times(), ("k_errs<semi->full>", "k_errs<frag->semi>", "k_attach<semi>", "k_attach<frag>"))
+        t2 = time.perf_counter(); g.allocate_reads(0)
+        t3 = time.perf_counter(); g.yield_reads_sink(sink)
+        t4 = time.perf_counter()
+        acc(g.kernel_times(), ("k_reads", "k_indels"))
+        for k, v in (("frags", t1 - t0), ("amplify", t2 - t1), ("allocate", t3 - t2), ("reads", t4 - t3)):
+            stage[k] += v
+        return g.stats()
+
+    for i in range(a.warmup):                                        # the first step also maps the device buffers
+        step(i)
     ktimes.clear()
-    TIMING_EVERY = 4                                    # events around the dominant kernel on every 4th step of the timed region
-    g.set_kernel_timing(list(GROUPS[dominant]), every=TIMING_EVERY)
+    for k in stage:
+        stage[k] = 0.0
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    pairs_total, fq_bytes, alg_bytes, last = 0, 0, 0, None
+    pairs_total, fq_bytes, amps_total, last = 0, 0, 0, None
     for i in range(a.steps):
-        p, last = step(a.warmup + i, True)
-        pairs_total += p
-        if i % TIMING_EVERY == 0:                      # the steps whose launches carry events
-            fq_bytes += sum(last["fastq_bytes"])
-        alg_bytes += last["algorithmic_bytes"]
-    for q in inflight:
-        for w in q:
-            w.wait()
+        last = step(a.warmup + i)
+        pairs_total += last["pairs_written"]
+        fq_bytes += sum(last["fastq_bytes"])
+        amps_total += last["semi_amplicons"] + last["full_amplicons"]
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -222,46 +322,119 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t[0])
-        pt = torch.tensor([pairs_total], dtype=torch.int64, device=cdev)
+        pt = torch.tensor([pairs_total, fq_bytes, amps_total], dtype=torch.int64, device=cdev)
         dist.all_reduce(pt)
-        pairs_total = int(pt[0])
+        pairs_total, fq_bytes_all, amps_all = int(pt[0]), int(pt[1]), int(pt[2])
+    else:
+        fq_bytes_all, amps_all = fq_bytes, amps_total
 
     if rank == 0:
-        dom = dominant
-        passes = [k for k in GROUPS[dom] if k.startswith("k_attach")] or [GROUPS[dom][0]]     # one launch of the group = one pass
-        kd = dict(launches=sum(ktimes[k]["launches"] for k in passes), ms=sum(ktimes[k]["ms"] for k in GROUPS[dom]), units=0)
-        if dom == "k_attach+k_errs":
-            # 1526 algorithmic bytes per created amplicon (template window read once + descriptor
-            # write + primer-counter RMW + error entries) x amplicons created; one launch = one pass (attach + error scan)
-            kd["units"] = ktimes["k_errs<semi->full>"]["units"] + ktimes["k_errs<frag->semi>"]["units"]
-            alg = 1526.0 * kd["units"]
-            note = "1526 B x %d amplicons created over %d passes (k_attach + k_errs)" % (kd["units"], kd["launches"])
+        L = g.read_length
+        dom = max(ktimes, key=lambda k: ktimes[k]["ms"])
+        kd = ktimes[dom]
+        if dom in ("k_reads", "k_indels"):
+            # per pair: insert-size template bytes (mean 261 at -s 260) + the FASTQ bytes of both records; the
+            # indel pass alone: the pair record read + 20 B per read written
+            alg = (261.0 * kd["units"] + fq_bytes) if dom == "k_reads" else (64.0 + 2 * 20.0 + 8.0) * kd["units"]
+            note = ("(261 B template + FASTQ bytes of both records) x %d pairs over %d launches" if dom == "k_reads" else "(64 B pair record + 2 x 20 B events + 8 B sizes) x %d pairs over %d launches") % (kd["units"], kd["launches"])
+            draws = 4.0 * L * kd["units"] if dom == "k_reads" else 2.0 * L * kd["units"]
+            draws_note = "k_reads: 2 draws (substitution, quality) per output base x 2 mates" if dom == "k_reads" else "k_indels: 1 draw per input base x 2 mates"
+            survey_alg = None
         else:
-            # per pair: insert-size template bytes + FASTQ bytes of both records
-            kd["units"] = ktimes[dom]["units"]
-            alg = 261.0 * kd["units"] + fq_bytes
-            note = "(261 B template + FASTQ bytes) x %d pairs over %d launches" % (kd["units"], kd["launches"])
+            # amplification: the implementation's compulsory bytes per created amplicon (28 B record written, 8 B slot written and
+            # read back, 8 primer bases read, 4 B stock counter RMW, ~20 B of the parent's record read); SURVEY 8(d)'s 1526 B
+            # (the 1-2 kb template window read once) is not what this design moves -- GC comes from the bit index and the
+            # error count from one binomial draw -- so it is kept as a second figure only (it would put frac above 1)
+            made = ktimes["k_errs<semi->full>"]["units"] + ktimes["k_errs<frag->semi>"]["units"]
+            per = 68.0
+            alg = per * made * kd["ms"] / max(1e-9, sum(ktimes[k]["ms"] for k in ktimes if k.startswith("k_attach") or k.startswith("k_errs")))
+            note = "68 B compulsory per created amplicon x %d amplicons, share of %s in the amplification time" % (made, dom)
+            draws = None; draws_note = None
+            survey_alg = 1526.0 * made
         achieved = alg / (kd["ms"] * 1e-3) / 1e9 if kd["ms"] > 0 else 0.0
-        traffic, traffic_src = pmc_traffic(GROUPS[dom])
+        prefix = {"k_reads": "scs::k_reads", "k_indels": "scs::k_indels", "k_attach<semi>": "scs::k_attach<false", "k_attach<frag>": "scs::k_attach<true",
+                  "k_errs<semi->full>": "scs::k_errs<false>", "k_errs<frag->semi>": "scs::k_errs<true>"}[dom]
+        cc = committed_counters(prefix)
+        roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": cc.get("traffic"), "traffic_source": cc.get("traffic_source"), "algorithmic_bytes": note,
+                "algorithmic_bytes_per_launch": alg / max(1, kd["launches"]), "avg_launch_ms": kd["ms"] / max(1, kd["launches"]),
+                "timed_launches": kd["launches"], "timing": "HIP events on the ctx stream around every launch of the timed region"}
+        if draws:
+            roof["draws_per_s"] = draws / (kd["ms"] * 1e-3)
+            roof["draws"] = draws_note
+        if "valu_insts_per_launch" in cc:
+            # VALU issue: 256 CUs x 4 SIMDs, one wave64 VALU instruction per 4 cycles per SIMD at 2.4 GHz (measured integer-op
+            # issue rate: tools/valu_peak.hip) = 614 G wave-instructions/s
+            peak_valu = 256 * 4 * 2.4e9 / 4
+            roof["valu"] = {"insts_per_launch": cc["valu_insts_per_launch"], "lanes_per_inst": cc.get("lanes_per_valu_inst"),
+                            "salu_per_valu": cc.get("salu_insts_per_launch", 0) / max(1.0, cc["valu_insts_per_launch"]),
+                            "issue_frac": cc["valu_insts_per_launch"] / (kd["ms"] * 1e-3 / max(1, kd["launches"])) / peak_valu,
+                            "peak_wave_insts_per_s": peak_valu, "source": cc.get("sq_source")}
+        if survey_alg:
+            roof["survey_model_bytes"] = survey_alg
         out = {
-            "metric": "paired-end read pairs/s (whole genreads job: MALBAC amplification + read allocation + read generation)",
+            "metric": "paired-end read pairs/s (whole genreads job: MALBAC amplification + read allocation + read generation, PE150 30x)",
             "value": pairs_total / elapsed, "unit": "pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u8/u32 (integer draws, byte sequences; fp64 only in the GC-weight draw)", "data": "synthetic",
-            "config": {"workload": "configs[1]: 1 Mb synthetic reference (diploid simuvars FASTA), PE150 30x, HiSeq2500 model resampled to 150 bins, -p 100000 -r 1e-9 -s 260",
-                       "pairs_per_step_per_gpu": last["pairs_written"], "full_amplicons_per_step": last["full_amplicons"],
-                       "semi_amplicons_per_step": last["semi_amplicons"], "sharding": ("one job over %d GPUs: %d x 1 Mb records sharded by fragment lineage, RCCL all-reduce of primer stock / setPrimers totals, "
-                                    "all-gather of GC weights, read pool gathered on rank 0" % (world, world)) if world > 1 else "single GPU"},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes": note,
-                         "algorithmic_bytes_per_launch": alg / max(1, kd["launches"]), "avg_launch_ms": kd["ms"] / max(1, kd["launches"]),
-                         "timed_launches": kd["launches"], "timed_steps": "every %d-th step of the timed region (HIP event records cost ~6 us each)" % TIMING_EVERY},
-            "kernels_ms_per_step_warmup": {k: v["ms"] / max(1, a.warmup) for k, v in warm_ktimes.items()},
-            "whole_job_algorithmic_GBps": alg_bytes / elapsed / 1e9,
+            "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "strong" if world > 1 else "weak", "vs_baseline": None,
+            "dtype": "u8/u32 (integer draws, byte sequences; fp64 only in the GC-weight draw and the allocation sums)", "data": "synthetic",
+            "config": {"workload": ("configs[3] on %d GPU(s): %.0f Mb synthetic diploid genome (24 hg19-length records x 2 haplotypes, i.i.d. 30/20/20/30 %% ACGT, generated in HBM), "
+                                    "PE150 %gx, HiSeq2500 model resampled to 150 bins, -p 100000 -r 1e-9 -s 260" % (world, sum(lens) / 1e6, a.coverage)),
+                       "pairs_per_step": pairs_total // a.steps, "amplicons_per_step": amps_all // a.steps, "fastq_bytes_per_step": fq_bytes_all // a.steps,
+                       "sharding": ("one job over %d GPUs by fragment lineage; per-pass primer-stock all-reduce + allocation partials over RCCL; a FASTQ shard per rank" % world) if world > 1 else "single GPU",
+                       "output": "FASTQ text generated batch by batch into HBM buffers (NULL sink)"},
+            "roofline": roof,
+            "stages_s_per_step": {k: v / a.steps for k, v in stage.items()},
+            "kernels_ms_per_step": {k: v["ms"] / a.steps for k, v in ktimes.items()},
+            "setup_s": {"genome_generated_in_hbm": t_gen, "genome_staged_(encode+bit_index)": t_up},
+            # whole job against HBM: the implementation's compulsory bytes (68 B per amplicon, 64 B pair record written + read,
+            # 40 B events, 261 B template + FASTQ per pair); SURVEY 8(d)'s model (1526 B per amplicon) beside it
+            "whole_job_GBps": {"compulsory": (68.0 * amps_all + (261.0 + 168.0) * pairs_total + fq_bytes_all) / elapsed / 1e9,
+                               "survey_8d_model": (1526.0 * amps_all + 261.0 * pairs_total + fq_bytes_all) / elapsed / 1e9},
         }
-        if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(fa, prof, 1000 + a.warmup)
+        if world == 1 and not a.no_extra_legs:
+            # ---- sink-inclusive: the same job, FASTQ through D2H + write(2) to tmpfs
+            shm = "/dev/shm" if os.path.isdir("/dev/shm") else td
+            sd = tempfile.mkdtemp(prefix="scsbench_sink_", dir=shm)
+            try:
+                sink = FileSink(sd)
+                for k in stage:
+                    stage[k] = 0.0
+                t1 = time.perf_counter()
+                st = step(a.warmup + a.steps, sink)
+                dt = time.perf_counter() - t1
+                sink.close()
+                out["sink_inclusive"] = {"value": st["pairs_written"] / dt, "unit": "pairs/s", "seconds": dt, "fastq_bytes": sink.total,
+                                         "reads_stage_s": stage["reads"], "sink_GBps": sink.total / max(1e-9, stage["reads"]) / 1e9,
+                                         "what": "one more step; FASTQ D2H into pinned double buffers + write(2) into two tmpfs files (rewound every 4 GB)"}
+            finally:
+                shutil.rmtree(sd, ignore_errors=True)
+            # ---- CLI wall at chr20 size
+            cli = os.path.join(ROOT, "scssim_amd", "bin", "scssim")
+            if cli_sample is not None and os.path.exists(cli):
+                cd = tempfile.mkdtemp(prefix="scsbench_cli_", dir=shm)
+                try:
+                    fa = os.path.join(cd, "chr20.fa")
+                    n20 = len(cli_sample)
+                    write_simu_fasta(fa, ["20_1_%d" % n20, "20_2_%d" % n20], [cli_sample, cli_sample])
+                    t1 = time.perf_counter()
+                    r = subprocess.run([cli, "genreads", "-i", fa, "-m", prof, "-c", "%g" % a.coverage, "-o", os.path.join(cd, "reads"), "--seed", "5", "--device", str(local)],
+                                       capture_output=True, text=True)
+                    dt = time.perf_counter() - t1
+                    m = re.search(r"pairs (\d+);", r.stderr)
+                    if r.returncode == 0 and m:
+                        out["cli_wall"] = {"value": int(m.group(1)) / dt, "unit": "pairs/s", "seconds": dt, "pairs": int(m.group(1)),
+                                           "what": "`scssim genreads` end to end on a chr20-size record (%.1f Mb x 2 haplotypes; configs[2]): process start, FASTA parse + .fai, profile, job, both FASTQ files on tmpfs" % (n20 / 1e6)}
+                    else:
+                        out["cli_wall"] = {"error": r.stderr[-300:]}
+                finally:
+                    shutil.rmtree(cd, ignore_errors=True)
+        if world == 1 and not a.no_cpu_baseline and cpu_sample is not None:
+            n = len(cpu_sample)
+            out["cpu_baseline"] = cpu_baseline(td, prof, ["1_1_%d" % n, "1_2_%d" % n], [cpu_sample, cpu_sample],
+                                               "first %.1f Mb of chromosome 1 of the bench genome (x 2 haplotypes), PE150 %gx, same profile and options" % (n / 1e6, a.coverage), a.coverage)
         print(json.dumps(out))
+    g.close()
+    shutil.rmtree(td, ignore_errors=True)
     if dist.is_initialized():
         dist.destroy_process_group()
 

@@ -78,6 +78,12 @@ int         scs_load_genome_fasta(scs_ctx* ctx, const char* fasta_path);
 int         scs_upload_genome(scs_ctx* ctx, int n_records, const char* const* names,
                               const char* const* seqs, const uint64_t* lens);
 
+/* Same, with the bases already in device memory (HBM-resident producers: a genome edited on the GPU, a synthetic
+ * benchmark genome): d_bases = the records' ASCII bases concatenated without separators, sum(lens) bytes, readable
+ * on the ctx device; copied, the caller keeps ownership. */
+int         scs_upload_genome_device(scs_ctx* ctx, int n_records, const char* const* names, const uint64_t* lens,
+                                     const void* d_bases);
+
 /* Malbac::createFrags -> Genome::splitToFrags + Fragment::createSequence
  * (lib/malbac/Malbac.cpp:143-145, lib/genome/Genome.cpp:753-782, lib/fragment/Fragment.cpp:40-50) */
 int         scs_create_frags(scs_ctx* ctx);

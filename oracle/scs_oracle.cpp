@@ -862,14 +862,70 @@ void compute_weights(Sim& S, std::vector<double>& w) {
     }
 }
 
+// ---- [REMAP] fixed-shape sums of the counter mode's read allocation.  The reference adds 10^9 weights in one serial
+// loop (wls.normalize, Malbac.cpp:384) and builds its CDFs by serial prefix sums (MyDefine.cpp:203-253); a serial order
+// cannot be computed in parallel or by shards, so counter mode fixes a SHAPE instead (same terms, other association):
+//   tree1000(v, n <= 1000): 64 accumulators, a[l] = v[l] + v[l+64] + ... in index order, then the butterfly
+//       a[l] = a[l] + a[l ^ d], d = 32, 16, .. 1  (what 64 lanes with shuffle-xor compute); result a[0]
+//   tree_sum(v, n): tree1000 over consecutive groups of 1000, applied again to the group sums until one value is left
+//   scan1000(v, n <= 1000): rows of 64; inside a row the Hillis-Steele inclusive scan s[l] += s[l-d], d = 1, 2, .. 32
+//       (shuffle-up); out[64k + l] = carry + s[l], carry = out of the row's last lane (0 before row 0)
+//   scan_all(v, n): scan1000 inside groups of 1000; the groups' last entries are scanned the same way (recursively) and
+//       the entry before a group is added to every element of it
+// A scan of this shape may differ from a monotone sequence in the last bit, so the lookups are the BINARY search
+// first_le below (on a monotone CDF it returns what randIndx's linear scan returns, MyDefine.cpp:274-282).
+double tree1000(const double* v, size_t n) {
+    double a[64];
+    for (int l = 0; l < 64; ++l) { double acc = 0; for (size_t i = (size_t)l; i < n; i += 64) acc += v[i]; a[l] = acc; }
+    for (int d = 32; d >= 1; d >>= 1) { double b[64]; for (int l = 0; l < 64; ++l) b[l] = a[l] + a[l ^ d]; memcpy(a, b, sizeof a); }
+    return a[0];
+}
+double tree_sum(const double* v, size_t n) {
+    if (n == 0) return 0;
+    std::vector<double> cur, nxt;
+    for (size_t s = 0; s < n; s += 1000) cur.push_back(tree1000(v + s, std::min<size_t>(1000, n - s)));
+    while (cur.size() > 1) {
+        nxt.clear();
+        for (size_t s = 0; s < cur.size(); s += 1000) nxt.push_back(tree1000(cur.data() + s, std::min<size_t>(1000, cur.size() - s)));
+        cur.swap(nxt);
+    }
+    return cur[0];
+}
+void scan1000(const double* v, size_t n, double* out) {
+    double carry = 0;
+    for (size_t r = 0; r < n; r += 64) {
+        double s[64];
+        for (int l = 0; l < 64; ++l) s[l] = r + l < n ? v[r + l] : 0.0;
+        for (int d = 1; d < 64; d <<= 1) { double t[64]; for (int l = 0; l < 64; ++l) t[l] = l >= d ? s[l] + s[l - d] : s[l]; memcpy(s, t, sizeof s); }
+        for (int l = 0; l < 64 && r + l < n; ++l) out[r + l] = carry + s[l];
+        carry = carry + s[63];
+    }
+}
+void scan_all(const double* v, size_t n, double* out) {
+    if (n == 0) return;
+    const size_t ng = (n + 999) / 1000;
+    for (size_t g = 0; g < ng; ++g) scan1000(v + g * 1000, std::min<size_t>(1000, n - g * 1000), out + g * 1000);
+    if (ng == 1) return;
+    std::vector<double> last(ng), pre(ng);
+    for (size_t g = 0; g < ng; ++g) last[g] = out[std::min(n, (g + 1) * 1000) - 1];
+    scan_all(last.data(), ng, pre.data());
+    for (size_t g = 1; g < ng; ++g) for (size_t i = g * 1000; i < std::min(n, (g + 1) * 1000); ++i) out[i] = pre[g - 1] + out[i];
+}
+inline unsigned first_le(const double* cdf, unsigned n, double u) {                 // first k with r <= cdf[k] by bisection, else n-1
+    const double r = ZERO_FINAL + (1 - ZERO_FINAL) * u;
+    unsigned lo = 0, hi = n;
+    while (lo < hi) { const unsigned mid = (lo + hi) >> 1; if (r <= cdf[mid]) hi = mid; else lo = mid + 1; }
+    return lo < n ? lo : n - 1;
+}
+
 // allocation over a weight vector in (global) list order -> read numbers
 void allocate_reads(Sim& S, std::vector<double>& w, long reads, std::vector<unsigned>& readNumbers) {
     const size_t ac = w.size();
     const unsigned chunk = (unsigned)std::max<size_t>(1, std::min<size_t>(1000, ac / 1));   // loadPerThread at -t 1
+    const bool ctr = S.prm.counter;
     double total = 0;
-    if (S.prm.counter) {        // [REMAP] chunked sum: per-1000 partials, then partials in order
-        for (size_t s = 0; s < ac; s += chunk) { double part = 0; for (size_t i = s; i < std::min(ac, s + chunk); ++i) part += w[i]; total += part; }
-    } else for (size_t i = 0; i < ac; ++i) total += w[i];
+    if (ctr) total = tree_sum(w.data(), ac);                                      // [REMAP] fixed-shape sum
+    else for (size_t i = 0; i < ac; ++i) total += w[i];
     for (size_t i = 0; i < ac; ++i) w[i] /= (ZERO_FINAL + total);                 // wls.normalize(0)
     readNumbers.assign(ac, 0);
     unsigned long sum = 0;
@@ -882,23 +938,38 @@ void allocate_reads(Sim& S, std::vector<double>& w, long reads, std::vector<unsi
     for (size_t s = 0; s < ac; s += chunk) {
         size_t e = std::min(ac, s + chunk) - 1;
         Chunk c{s, e, 0, {}};
-        double tp = 0; for (size_t i = s; i <= e; ++i) tp += w[i];
-        c.cdf.resize(e - s + 1); double run = 0;
-        for (size_t i = s; i <= e; ++i) { run = run + w[i] / tp; c.cdf[i - s] = run; }
+        double tp = 0;
+        c.cdf.resize(e - s + 1);
+        if (ctr) {                                                                // [REMAP] fixed-shape sum and scan
+            tp = tree1000(&w[s], e - s + 1);
+            std::vector<double> q(e - s + 1);
+            for (size_t i = s; i <= e; ++i) q[i - s] = w[i] / tp;
+            scan1000(q.data(), q.size(), c.cdf.data());
+        } else {
+            for (size_t i = s; i <= e; ++i) tp += w[i];
+            double run = 0;
+            for (size_t i = s; i <= e; ++i) { run = run + w[i] / tp; c.cdf[i - s] = run; }
+        }
         c.quota = (unsigned)(tp * n); count += c.quota;
         totalProbs.push_back(tp); chunks.push_back(std::move(c));
     }
     n -= count;
     if (n > 0 && !chunks.empty()) {
-        std::vector<double> probs(totalProbs.size()); probs[0] = totalProbs[0];
-        for (size_t i = 1; i < probs.size(); ++i) probs[i] = probs[i - 1] + totalProbs[i];
+        std::vector<double> probs(totalProbs.size());
+        if (ctr) scan_all(totalProbs.data(), totalProbs.size(), probs.data());
+        else { probs[0] = totalProbs[0]; for (size_t i = 1; i < probs.size(); ++i) probs[i] = probs[i - 1] + totalProbs[i]; }
         uint32_t t = 0;
-        while (n-- > 0) { unsigned j = rand_indx(probs.data(), probs.size(), S.rng.main_real(mk(ST_ALLOC_TOP, 0, 0, t++, 0))); chunks[j].quota += 1; }
+        while (n-- > 0) {
+            const double u = S.rng.main_real(mk(ST_ALLOC_TOP, 0, 0, t++, 0));
+            unsigned j = ctr ? first_le(probs.data(), (unsigned)probs.size(), u) : rand_indx(probs.data(), probs.size(), u);
+            chunks[j].quota += 1;
+        }
     }
     for (size_t c = 0; c < chunks.size(); ++c) {                                  // batchSampling, one task per chunk, FIFO
         Chunk& ch = chunks[c];
         for (unsigned t = 0; t < ch.quota; ++t) {
-            unsigned j = rand_indx(ch.cdf.data(), ch.cdf.size(), S.rng.real(mk(ST_ALLOC_CHUNK, 0, c, t, 0)));
+            const double u = S.rng.real(mk(ST_ALLOC_CHUNK, 0, c, t, 0));
+            unsigned j = ctr ? first_le(ch.cdf.data(), (unsigned)ch.cdf.size(), u) : rand_indx(ch.cdf.data(), ch.cdf.size(), u);
             readNumbers[ch.s + j] += 1;
         }
     }

@@ -57,6 +57,7 @@ def load_library():
     L.scs_read_length.argtypes = [C.c_void_p]
     L.scs_load_genome_fasta.argtypes = [C.c_void_p, C.c_char_p]
     L.scs_upload_genome.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(C.c_uint64)]
+    L.scs_upload_genome_device.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_uint64), C.c_void_p]
     for f in ("scs_create_frags", "scs_amplify"):
         getattr(L, f).argtypes = [C.c_void_p]
     L.scs_allocate_reads.argtypes = [C.c_void_p, C.c_uint64]
@@ -206,6 +207,12 @@ class GenReads:
         self._ck(self._L.scs_upload_genome(self._ctx, n, (C.c_char_p * n)(*bn), (C.c_char_p * n)(*bs),
                                            (C.c_uint64 * n)(*[len(s) for s in bs])))
 
+    def upload_genome_device(self, names, lens, d_bases):
+        """Genome already in HBM: d_bases = device pointer to the records' ASCII bases, concatenated (sum(lens) bytes)."""
+        n = len(names)
+        bn = [s.encode() if isinstance(s, str) else s for s in names]
+        self._ck(self._L.scs_upload_genome_device(self._ctx, n, (C.c_char_p * n)(*bn), (C.c_uint64 * n)(*[int(x) for x in lens]), C.c_void_p(int(d_bases))))
+
     def load_profile(self, path):           # Profile::train(file)
         self._ck(self._L.scs_load_profile(self._ctx, os.fsencode(path)))
 
@@ -245,6 +252,12 @@ class GenReads:
         cb = _SINK(sink) if collect else _SINK()   # NULL sink: generate on the device and count only
         self._ck(self._L.scs_yield_reads(self._ctx, cb, None))
         return b"".join(parts1), b"".join(parts2)
+
+    def yield_reads_sink(self, sink=None):
+        """Malbac::yieldReads with a caller-supplied sink(user, p1, n1, p2, n2) -> int (host pointers valid during the call),
+        or None: the FASTQ text is generated batch by batch into HBM buffers and counted only."""
+        cb = _SINK(sink) if sink is not None else _SINK()
+        self._ck(self._L.scs_yield_reads(self._ctx, cb, None))
 
     def yield_reads_device(self, d_fq1, cap1, d_fq2, cap2):
         """FASTQ pool stays in HBM: d_fq1/d_fq2 are device pointers (e.g. torch uint8 tensors' data_ptr())."""

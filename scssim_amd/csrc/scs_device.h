@@ -74,6 +74,7 @@ struct PoissonParams {
 // tail of the per-pass primer all-reduce (k_shard_tail / k_primer_update_sharded): [6] semi length already reported,
 // [8] semis, [9] their length, [10] primers left in the pool, [11],[12] {templateNum, totalLen} for setPrimers,
 // [13],[14] fragments and their length over all shards (constants)
+enum { DS_HOLES = 20 };                                // pairs planned but not produced (k_plan_pairs; zeroed by scs_yield_reads)
 enum { DS_SEMI_LEN = 4, DS_SEMIS_N = 5, DS_REPORTED_LEN = 6, DS_G_SEMIS_N = 8, DS_G_SEMI_LEN = 9, DS_G_PRIMERS = 10, DS_G_TOTALS = 11, DS_G_NF = 13, DS_G_FRAG_LEN = 14 };
 enum { SHARD_TAIL_WORDS = 16 };                       // u32 words behind the 65536 primer decrements that ride on the same all-reduce
 struct AllocState { double total; unsigned long long sum_rn, sum_quota; };
@@ -119,7 +120,7 @@ void launch_amplify_init(hipStream_t s, int64_t* primer_cnt, int64_t copies, uin
 void launch_primer_update(hipStream_t s, int64_t* primer_cnt, uint32_t* primer_delta);
 void launch_weights(hipStream_t s, DevAmps fulls, uint32_t n, DevTables tb, RngKey key, uint32_t frag_size, double* w);
 void launch_plan_pairs(hipStream_t s, DevFrags fr, DevAmps semis, DevAmps fulls, uint32_t n_fulls, const uint32_t* read_numbers, const uint32_t* pair_off,
-                       const uint32_t* gidx, DevTables tb, RngKey key, int paired, PairRec* pairs);
+                       const uint32_t* gidx, DevTables tb, RngKey key, int paired, PairRec* pairs, unsigned long long* holes);
 void launch_pair_offsets(hipStream_t s, const uint32_t* rn, uint32_t ac, int paired, uint32_t* pair_cnt_off, void* temp, size_t temp_bytes);
 // reads of pairs [p0, p0+np): slot layout [2*np][slot] bases / quals (SE: [np][slot])
 size_t reads_lds_bytes(const DevTables& tb);          // dynamic LDS of one inject_errors workgroup for this profile

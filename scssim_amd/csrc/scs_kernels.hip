@@ -349,7 +349,7 @@ __global__ void k_weights(DevAmps fulls, uint32_t n, DevTables tb, RngKey key, u
 // ------------------------------------------------------------------------------------------------
 __global__ void k_plan_pairs(DevFrags fr, DevAmps semis, DevAmps fulls, uint32_t n_fulls, const uint32_t* __restrict__ read_numbers,
                              const uint32_t* __restrict__ pair_off, const uint32_t* __restrict__ gidx, DevTables tb, RngKey key, int paired,
-                             PairRec* __restrict__ pairs) {
+                             PairRec* __restrict__ pairs, unsigned long long* __restrict__ holes) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_fulls) return;
     int n = (int)read_numbers[i];
@@ -381,6 +381,7 @@ __global__ void k_plan_pairs(DevFrags fr, DevAmps semis, DevAmps fulls, uint32_t
     }
     r.att = 0; r.pos = 0; r.isz = 0;
     for (uint32_t q = made; q < want; ++q) dst[q] = r;                             // holes
+    if (made < want) atomicAdd(holes, (unsigned long long)(want - made));          // rare: the host reports pairs produced = planned - holes
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1275,78 +1276,168 @@ __global__ void __launch_bounds__(64) k_attach(const uint8_t* __restrict__ g, De
 
 // ------------------------------------------------------------------------------------------------
 // K3  read allocation: Malbac::setReadCounts (lib/malbac/Malbac.cpp:370-408) with randIndx_hp /
-//     batchSampling (lib/mydefine/MyDefine.cpp:191-272), chunk = 1000 amplicons (loadPerThread at -t 1).
-//     All sums run in the oracle's order (sequential inside a chunk, chunks in order).
+//     batchSampling (lib/mydefine/MyDefine.cpp:191-272), chunk = 1000 amplicons of the WHOLE JOB's list
+//     (loadPerThread at -t 1).  [REMAP] every sum has a fixed shape (oracle: tree1000 / tree_sum / scan1000 /
+//     scan_all) instead of the reference's serial order, so that it can be computed by 64 lanes and by shards:
+//       tree1000: lane l adds v[l], v[l+64], ... in index order, then the shuffle-xor butterfly d = 32 .. 1
+//       scan1000: rows of 64, Hillis-Steele inclusive scan inside a row (shuffle-up d = 1 .. 32), carry row to row
+//     A shard works on the chunks in which it has at least one amplicon.  A chunk that lies inside one of its own
+//     (locally contiguous) list segments is read in place; the few chunks that straddle a segment boundary -- at most two
+//     per segment -- are materialised as dense rows (k_alloc_bgather) from the shard's own weights and from the first /
+//     last 1000 weights of every segment of every shard (one small all-gather), so that every shard that shares a chunk
+//     computes the same sums for it.  Nothing O(amplicons) is replicated or exchanged: the shards all-reduce only the
+//     per-chunk partials (8 B per 1000 amplicons).
 // ------------------------------------------------------------------------------------------------
-#define ALLOC_CHUNK 1000u
-// one wave per chunk: coalesced load into LDS, then lane 0 adds in index order (the oracle's order)
-__global__ void __launch_bounds__(64) k_alloc_chunk_sum(const double* __restrict__ w, uint32_t ac, double* __restrict__ part) {
-    __shared__ double s_w[ALLOC_CHUNK];
-    const uint32_t c = blockIdx.x, b = c * ALLOC_CHUNK, e = min(ac, b + ALLOC_CHUNK), n = e - b;
-    for (uint32_t i = threadIdx.x; i < n; i += WAVE) s_w[i] = w[b + i];
-    __builtin_amdgcn_wave_barrier();
-    if (threadIdx.x == 0) { double s = 0; for (uint32_t i = 0; i < n; ++i) s += s_w[i]; part[c] = s; }
+__device__ __forceinline__ double shfl_xor_f64(double v, int d) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __shfl_xor((int)b, d), hi = __shfl_xor((int)(b >> 32), d);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
-// serial sums over the chunk partials (order matters for the rounding): tiles staged coalesced into LDS, lane 0 adds
-#define SERIAL_TILE 2048
-__global__ void __launch_bounds__(256) k_alloc_total(const double* __restrict__ part, uint32_t nch, AllocState* __restrict__ st) {
-    __shared__ double s_v[SERIAL_TILE];
-    double t = 0;
-    for (uint32_t b = 0; b < nch; b += SERIAL_TILE) {
-        const uint32_t n = min(nch - b, (uint32_t)SERIAL_TILE);
-        __syncthreads();
-        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) s_v[i] = part[b + i];
-        __syncthreads();
-        if (threadIdx.x == 0) for (uint32_t i = 0; i < n; ++i) t += s_v[i];                // [REMAP] partials in order
+__device__ __forceinline__ double shfl_up_f64(double v, int d) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __shfl_up((int)b, d), hi = __shfl_up((int)(b >> 32), d);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ double shfl_f64(double v, int src) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __shfl((int)b, src), hi = __shfl((int)(b >> 32), src);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ double wave_butterfly_f64(double acc) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) acc = acc + shfl_xor_f64(acc, d);
+    return acc;
+}
+// where work chunk q of this shard lives: its whole-job chunk id, its row (in place in the local list, or a
+// materialised boundary row), its length, and whether this shard owns it (holds its first amplicon)
+struct ChunkRef { uint32_t c, n, local0; int brow; bool owner; };
+__device__ __forceinline__ ChunkRef chunk_ref(const AllocPlan& pl, uint32_t q) {
+    ChunkRef r;
+    if (q < pl.n_interior) {
+        uint32_t k = 0;
+        while (k + 1 < pl.n_ranges && q >= pl.rng[k + 1].q0) ++k;                  // <= 40 ranges
+        const AllocRange& g = pl.rng[k];
+        r.c = g.c0 + (q - g.q0); r.local0 = g.local0 + (q - g.q0) * ALLOC_CHUNK; r.brow = -1; r.owner = true;
+        const unsigned long long b = (unsigned long long)r.c * ALLOC_CHUNK;
+        r.n = (uint32_t)min((unsigned long long)ALLOC_CHUNK, pl.total - b);
+    } else {
+        const uint32_t bi = q - pl.n_interior;
+        r.c = pl.bchunk[bi].c; r.n = pl.bchunk[bi].n; r.local0 = 0; r.brow = (int)bi; r.owner = pl.bchunk[bi].owner != 0;
     }
-    if (threadIdx.x == 0) { st->total = t; st->sum_rn = 0; st->sum_quota = 0; }
+    return r;
 }
-__global__ void __launch_bounds__(256) k_alloc_floor(double* __restrict__ w, uint32_t ac, unsigned long long reads, AllocState* __restrict__ st,
-                                                     uint32_t* __restrict__ rn) {
+// this shard's first / last 1000 weights of each of its list segments, for the other shards' boundary rows
+__global__ void __launch_bounds__(256) k_alloc_bpack(const double* __restrict__ w, AllocPlan pl, double* __restrict__ send) {
+    const uint32_t slot = blockIdx.x / 2, half = blockIdx.x & 1u;                   // one block per (segment slot, first | last)
+    const uint32_t n = pl.my_seg[slot].n, lo = pl.my_seg[slot].lo, m = min(n, ALLOC_CHUNK);
+    for (uint32_t i = threadIdx.x; i < ALLOC_CHUNK; i += blockDim.x)
+        send[((size_t)slot * 2 + half) * ALLOC_CHUNK + i] = i < m ? w[lo + (half ? n - m + i : i)] : 0.0;
+}
+// dense rows of the chunks that straddle a segment boundary: value and local index (-1: another shard's amplicon)
+__global__ void __launch_bounds__(256) k_alloc_bgather(const double* __restrict__ w, AllocPlan pl, const double* __restrict__ gathered,
+                                                       double* __restrict__ brow, int* __restrict__ bmap) {
+    const uint32_t bi = blockIdx.x;
+    const unsigned long long g0 = (unsigned long long)pl.bchunk[bi].c * ALLOC_CHUNK;
+    for (uint32_t e = threadIdx.x; e < ALLOC_CHUNK; e += blockDim.x) {
+        double v = 0; int mp = -1;
+        if (e < pl.bchunk[bi].n) {
+            const unsigned long long gi = g0 + e;
+            uint32_t lo = 0, hi = pl.n_gseg;                                          // last segment with go <= gi
+            while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (pl.gseg[mid].go <= gi) lo = mid; else hi = mid; }
+            const AllocGSeg sg = pl.gseg[lo];
+            const uint32_t j = (uint32_t)(gi - sg.go);
+            if (sg.owner == pl.rank) { mp = (int)(sg.lo + j); v = w[sg.lo + j]; }
+            else {
+                const double* src = gathered + ((size_t)sg.owner * ALLOC_SLOTS + sg.slot) * 2 * ALLOC_CHUNK;
+                v = j < ALLOC_CHUNK ? src[j] : src[ALLOC_CHUNK + (j - (sg.n - ALLOC_CHUNK))];   // a boundary chunk touches only the first / last 1000 of a foreign segment
+            }
+        }
+        brow[(size_t)bi * ALLOC_CHUNK + e] = v; bmap[(size_t)bi * ALLOC_CHUNK + e] = mp;
+    }
+}
+// tree1000 over every work chunk: one wave per chunk (four per workgroup).  The owner writes the chunk's sum.
+__global__ void __launch_bounds__(256) k_alloc_chunk_sum(const double* __restrict__ w, const double* __restrict__ brow, AllocPlan pl,
+                                                         double* __restrict__ part) {
+    const uint32_t q = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (q >= pl.n_interior + pl.n_boundary) return;
+    const ChunkRef r = chunk_ref(pl, q);
+    const double* __restrict__ v = r.brow < 0 ? w + r.local0 : brow + (size_t)r.brow * ALLOC_CHUNK;
+    double acc = 0;
+    for (uint32_t i = lane; i < r.n; i += WAVE) acc += v[i];
+    acc = wave_butterfly_f64(acc);
+    if (lane == 0 && r.owner) part[r.c] = acc;
+}
+// tree1000 over consecutive groups of 1000 of an array (the levels of tree_sum above the chunks)
+__global__ void __launch_bounds__(256) k_tree1000(const double* __restrict__ in, uint32_t n, double* __restrict__ out) {
+    const uint32_t gq = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const uint32_t b = gq * ALLOC_CHUNK;
+    if (b >= n) return;
+    const uint32_t m = min(ALLOC_CHUNK, n - b);
+    double acc = 0;
+    for (uint32_t i = lane; i < m; i += WAVE) acc += in[b + i];
+    acc = wave_butterfly_f64(acc);
+    if (lane == 0) out[gq] = acc;
+}
+// wls.normalize(0) + floor (Malbac.cpp:384-390) + the chunk's total probability (MyDefine.cpp:218-224), one pass:
+//   p = w / (2.2204e-16 + total) in place, readNumbers = trunc(p * reads) for this shard's amplicons,
+//   tp[c] = tree1000(p) (owner), crn[q] = sum of the read numbers set by this chunk
+__global__ void __launch_bounds__(256) k_alloc_norm(double* __restrict__ w, double* __restrict__ brow, const int* __restrict__ bmap, AllocPlan pl,
+                                                    const double* __restrict__ total, unsigned long long reads, uint32_t* __restrict__ rn,
+                                                    double* __restrict__ tp, uint32_t* __restrict__ crn) {
+    const uint32_t q = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (q >= pl.n_interior + pl.n_boundary) return;
+    const ChunkRef r = chunk_ref(pl, q);
+    double* __restrict__ v = r.brow < 0 ? w + r.local0 : brow + (size_t)r.brow * ALLOC_CHUNK;
+    const int* __restrict__ mp = r.brow < 0 ? nullptr : bmap + (size_t)r.brow * ALLOC_CHUNK;
+    const double den = 2.2204e-16 + *total;
+    double acc = 0; uint32_t cs = 0;
+    for (uint32_t i = lane; i < r.n; i += WAVE) {
+        const double p = v[i] / den;
+        v[i] = p; acc += p;
+        const uint32_t c = (uint32_t)(p * (double)(long long)reads);               // unsigned readCount = wls.get(0,i)*reads
+        if (mp) { const int li = mp[i]; if (li >= 0) { rn[li] = c; cs += c; } }
+        else { rn[r.local0 + i] = c; cs += c; }
+    }
+    acc = wave_butterfly_f64(acc);
+    cs = wave_sum(cs);
+    if (lane == 0) { if (r.owner) tp[r.c] = acc; crn[q] = cs; }
+}
+// sum of a u32 array into *dst (one workgroup; the arrays are per-chunk partials)
+__global__ void __launch_bounds__(1024) k_sum_u32(const uint32_t* __restrict__ v, uint32_t n, unsigned long long* __restrict__ dst, int add) {
+    __shared__ unsigned long long s_p[16];
+    unsigned long long acc = 0;
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) acc += v[i];
+    acc = wave_sum_u64(acc);
+    if ((threadIdx.x & 63) == 0) s_p[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) { unsigned long long t = 0; for (int k = 0; k < 16; ++k) t += s_p[k]; *dst = add ? *dst + t : t; }
+}
+// per-chunk quota of the residual reads: unsigned(tp * n) (MyDefine.cpp:225-227), for every chunk of the whole job
+__global__ void __launch_bounds__(256) k_alloc_quota(const double* __restrict__ tp, uint32_t nch, unsigned long long reads, const AllocState* __restrict__ st,
+                                                     uint32_t* __restrict__ quota) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nch) return;
+    const unsigned long long nres = reads - st->sum_rn;
+    quota[c] = (uint32_t)(tp[c] * (double)nres);
+}
+// scan_all, level 0: scan1000 inside every group of 1000 of `in`; last[g] = the group's last entry
+__global__ void __launch_bounds__(64) k_scan1000(const double* __restrict__ in, uint32_t n, double* __restrict__ out, double* __restrict__ last) {
+    const uint32_t g = blockIdx.x, b = g * ALLOC_CHUNK, m = min(ALLOC_CHUNK, n - b), lane = threadIdx.x;
+    double carry = 0;
+    for (uint32_t r = 0; r < m; r += WAVE) {
+        double s = r + lane < m ? in[b + r + lane] : 0.0;
+#pragma unroll
+        for (int d = 1; d < WAVE; d <<= 1) { const double t = shfl_up_f64(s, d); if ((int)lane >= d) s = s + t; }
+        if (r + lane < m) out[b + r + lane] = carry + s;
+        carry = carry + shfl_f64(s, 63);
+    }
+    if (lane == 0 && last) last[g] = carry;                                         // == out[b + m - 1]: zeros beyond m add nothing
+}
+// scan_all, fix-up: out[i] = pre[g-1] + out[i] for the groups g >= 1
+__global__ void __launch_bounds__(256) k_scan_fix(double* __restrict__ out, uint32_t n, const double* __restrict__ pre) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    unsigned long long r = 0;
-    if (i < ac) {
-        const double p = w[i] / (2.2204e-16 + st->total);                                // wls.normalize(0)
-        w[i] = p;
-        const uint32_t c = (uint32_t)(p * (double)(long long)reads);                     // unsigned readCount = wls.get(0,i)*reads
-        rn[i] = c; r = c;
-    }
-    block_add_u64(r, &st->sum_rn);
-}
-__global__ void __launch_bounds__(64) k_alloc_quota(double* __restrict__ w, uint32_t ac, unsigned long long reads, AllocState* __restrict__ st,
-                                                    double* __restrict__ tp, uint32_t* __restrict__ quota) {
-    __shared__ double s_w[ALLOC_CHUNK];
-    __shared__ double s_t;
-    const uint32_t c = blockIdx.x, b = c * ALLOC_CHUNK, e = min(ac, b + ALLOC_CHUNK), n = e - b;
-    for (uint32_t i = threadIdx.x; i < n; i += WAVE) s_w[i] = w[b + i];
-    __builtin_amdgcn_wave_barrier();
-    if (threadIdx.x == 0) { double t = 0; for (uint32_t i = 0; i < n; ++i) t += s_w[i]; s_t = t; }
-    __builtin_amdgcn_wave_barrier();
-    const double t = s_t;
-    for (uint32_t i = threadIdx.x; i < n; i += WAVE) s_w[i] = s_w[i] / t;                 // p[i]/totalProb (MyDefine.cpp:224)
-    __builtin_amdgcn_wave_barrier();
-    if (threadIdx.x == 0) {
-        double run = 0; for (uint32_t i = 0; i < n; ++i) { run = run + s_w[i]; s_w[i] = run; }   // chunk-local CDF, in index order
-        const unsigned long long nres = reads - st->sum_rn;
-        const uint32_t q = (uint32_t)(t * (double)nres);
-        tp[c] = t; quota[c] = q;
-        if (q) atomicAdd(&st->sum_quota, (unsigned long long)q);
-    }
-    __builtin_amdgcn_wave_barrier();
-    for (uint32_t i = threadIdx.x; i < n; i += WAVE) w[b + i] = s_w[i];
-}
-__global__ void __launch_bounds__(256) k_alloc_top_prefix(const double* __restrict__ tp, uint32_t nch, double* __restrict__ probs) {
-    __shared__ double s_v[SERIAL_TILE];
-    double run = 0;
-    for (uint32_t b = 0; b < nch; b += SERIAL_TILE) {
-        const uint32_t n = min(nch - b, (uint32_t)SERIAL_TILE);
-        __syncthreads();
-        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) s_v[i] = tp[b + i];
-        __syncthreads();
-        if (threadIdx.x == 0) for (uint32_t i = 0; i < n; ++i) { run = (b + i) ? run + s_v[i] : s_v[0]; s_v[i] = run; }
-        __syncthreads();
-        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) probs[b + i] = s_v[i];
-    }
+    if (i >= n || i < ALLOC_CHUNK) return;
+    out[i] = pre[i / ALLOC_CHUNK - 1] + out[i];
 }
 __device__ __forceinline__ uint32_t first_le(const double* __restrict__ cdf, uint32_t n, double r) {
     uint32_t lo = 0, hi = n;
@@ -1362,22 +1453,71 @@ __global__ void k_alloc_top_draws(const double* __restrict__ probs, uint32_t nch
     const double r = 2.2204e-16 + (1 - 2.2204e-16) * ((double)d.w[0] / 4294967296.0);
     atomicAdd(&quota[first_le(probs, nch, r)], 1u);
 }
-__global__ void __launch_bounds__(256) k_alloc_sample(const double* __restrict__ cdf, uint32_t ac, const uint32_t* __restrict__ quota, RngKey key,
-                                                      uint32_t* __restrict__ rn) {
-    const uint32_t c = blockIdx.x;                                                        // one workgroup per chunk
-    const uint32_t b = c * ALLOC_CHUNK, e = min(ac, b + ALLOC_CHUNK), q = quota[c];
-    for (uint32_t t = threadIdx.x; t < q; t += blockDim.x) {
-        const U4 d = draw4(key, ST_ALLOC_CHUNK, 0, c, t);
-        const double r = 2.2204e-16 + (1 - 2.2204e-16) * ((double)d.w[0] / 4294967296.0);
-        atomicAdd(&rn[b + first_le(cdf + b, e - b, r)], 1u);
+// batchSampling (MyDefine.cpp:191-201) of one chunk: the chunk-local CDF (scan1000 of p / tp) lives in LDS only; the
+// chunk's quota of draws is counted in LDS and added to this shard's read numbers in one coalesced pass
+__global__ void __launch_bounds__(64) k_alloc_sample(const double* __restrict__ w, const double* __restrict__ brow, const int* __restrict__ bmap, AllocPlan pl,
+                                                     const double* __restrict__ tp, const uint32_t* __restrict__ quota, RngKey key, uint32_t* __restrict__ rn) {
+    __shared__ double s_cdf[ALLOC_CHUNK];
+    __shared__ uint32_t s_cnt[ALLOC_CHUNK];
+    const uint32_t q = blockIdx.x, lane = threadIdx.x;
+    const ChunkRef r = chunk_ref(pl, q);
+    const uint32_t nq = quota[r.c];
+    if (nq == 0) return;
+    const double* __restrict__ v = r.brow < 0 ? w + r.local0 : brow + (size_t)r.brow * ALLOC_CHUNK;
+    const double t = tp[r.c];
+    double carry = 0;
+    for (uint32_t b = 0; b < r.n; b += WAVE) {
+        double s = b + lane < r.n ? v[b + lane] / t : 0.0;                             // p[i]/totalProb (MyDefine.cpp:224)
+#pragma unroll
+        for (int d = 1; d < WAVE; d <<= 1) { const double u = shfl_up_f64(s, d); if ((int)lane >= d) s = s + u; }
+        if (b + lane < r.n) { s_cdf[b + lane] = carry + s; s_cnt[b + lane] = 0; }
+        carry = carry + shfl_f64(s, 63);
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t k = lane; k < nq; k += WAVE) {
+        const U4 d = draw4(key, ST_ALLOC_CHUNK, 0, r.c, k);
+        const double x = 2.2204e-16 + (1 - 2.2204e-16) * ((double)d.w[0] / 4294967296.0);
+        atomicAdd(&s_cnt[first_le(s_cdf, r.n, x)], 1u);
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t i = lane; i < r.n; i += WAVE) {
+        const uint32_t c = s_cnt[i];
+        if (!c) continue;
+        if (r.brow < 0) rn[r.local0 + i] += c;
+        else { const int li = bmap[(size_t)r.brow * ALLOC_CHUNK + i]; if (li >= 0) rn[li] += c; }
     }
 }
-// PE parity fix (Malbac.cpp:399-407): the j-th odd entry gets +1 for even j, -1 for odd j.
-__global__ void k_alloc_parity(uint32_t* __restrict__ rn, const uint32_t* __restrict__ odd_before, uint32_t ac) {
+// odd entries of each of this shard's list segments (from the local exclusive scan of the odd bits) -> the shard's slots
+// of the whole-job table (laid out in list order: cycle, pass descending, shard)
+__global__ void k_alloc_odd_counts(const uint32_t* __restrict__ odd_before, AllocPlan pl, unsigned long long* __restrict__ table) {
+    const uint32_t slot = threadIdx.x;
+    if (slot >= ALLOC_SLOTS) return;
+    const uint32_t n = pl.my_seg[slot].n, lo = pl.my_seg[slot].lo;
+    table[(size_t)pl.my_seg[slot].order] = n ? odd_before[lo + n] - odd_before[lo] : 0u;
+}
+// PE parity fix (Malbac.cpp:399-407): the j-th odd entry OF THE WHOLE JOB's list gets +1 for even j, -1 for odd j.
+// table: odd counts of all segments in list order (summed over the shards); a thread finds its segment (<= 40), the odd
+// entries before the segment and adds the local ones.
+__global__ void __launch_bounds__(256) k_alloc_parity(uint32_t* __restrict__ rn, const uint32_t* __restrict__ odd_before, uint32_t ac, AllocPlan pl,
+                                                      const unsigned long long* __restrict__ table) {
+    __shared__ unsigned long long s_base[ALLOC_SLOTS];
+    if (threadIdx.x < ALLOC_SLOTS) {
+        unsigned long long b = 0;
+        if (table) { const uint32_t ord = pl.my_seg[threadIdx.x].order; for (uint32_t k = 0; k < ord; ++k) b += table[k]; }
+        s_base[threadIdx.x] = b;
+    }
+    __syncthreads();
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= ac) return;
     const uint32_t v = rn[i];
-    if (v & 1u) rn[i] = (odd_before[i] & 1u) ? v - 1u : v + 1u;
+    if (!(v & 1u)) return;
+    unsigned long long j = odd_before[i];
+    if (table) {
+        uint32_t k = 0;
+        while (k + 1 < ALLOC_SLOTS && (pl.my_seg[k].n == 0 || i >= pl.my_seg[k].lo + pl.my_seg[k].n)) ++k;   // local segments are stored in slot order
+        j = s_base[k] + (odd_before[i] - odd_before[pl.my_seg[k].lo]);
+    }
+    rn[i] = (j & 1ull) ? v - 1u : v + 1u;
 }
 
 struct Widen { __host__ __device__ uint64_t operator()(uint32_t v) const { return (uint64_t)v; } };
@@ -1502,9 +1642,9 @@ void launch_weights(hipStream_t s, DevAmps fulls, uint32_t n, DevTables tb, RngK
     hipLaunchKernelGGL(k_weights, dim3(cdiv(n, 256)), dim3(256), 0, s, fulls, n, tb, key, frag_size, w);
 }
 void launch_plan_pairs(hipStream_t s, DevFrags fr, DevAmps semis, DevAmps fulls, uint32_t n_fulls, const uint32_t* read_numbers, const uint32_t* pair_off,
-                       const uint32_t* gidx, DevTables tb, RngKey key, int paired, PairRec* pairs) {
+                       const uint32_t* gidx, DevTables tb, RngKey key, int paired, PairRec* pairs, unsigned long long* holes) {
     if (n_fulls == 0) return;
-    hipLaunchKernelGGL(k_plan_pairs, dim3(cdiv(n_fulls, 256)), dim3(256), 0, s, fr, semis, fulls, n_fulls, read_numbers, pair_off, gidx, tb, key, paired, pairs);
+    hipLaunchKernelGGL(k_plan_pairs, dim3(cdiv(n_fulls, 256)), dim3(256), 0, s, fr, semis, fulls, n_fulls, read_numbers, pair_off, gidx, tb, key, paired, pairs, holes);
 }
 void launch_pair_offsets(hipStream_t s, const uint32_t* rn, uint32_t ac, int paired, uint32_t* pair_cnt_off, void* temp, size_t temp_bytes) {
     if (paired) (void)rocprim::exclusive_scan(temp, temp_bytes, rocprim::make_transform_iterator(rn, HalfUp()), pair_cnt_off, 0u, (size_t)ac + 1, rocprim::plus<uint32_t>(), s);

@@ -155,7 +155,7 @@ struct scs_ctx {
     DevBuf d_tables, t_qcompact, t_guide, t_subs1, t_subs2, t_qual, t_ins, t_del, t_isize, d_subs1, d_subs2, d_qual, d_ins, d_del, d_isize, d_gcmeans;
     // genome + fragments
     DevBuf gx_gc_bits, gx_n_bits, gx_gc_cnt, gx_n_cnt, gx_gc_pref, gx_n_pref, d_binom;
-    std::vector<FastaRecord> recs; bool have_genome = false; DevBuf genome; std::vector<uint64_t> rec_off; uint64_t genome_bases = 0;
+    std::vector<FastaRecord> recs; bool have_genome = false; DevBuf genome; std::vector<uint64_t> rec_off, rec_len; uint64_t genome_bases = 0;   // recs: names only once staged
     std::vector<uint64_t> f_goff; std::vector<uint32_t> f_len; std::vector<int8_t> f_strand; std::vector<uint32_t> f_primers;
     uint64_t f_gidx_base = 0; bool have_frags = false;
     DevBuf df_blob, df_primers; size_t df_len_off = 0, df_strand_off = 0;           // fragments: offsets | lengths | strands in one block
@@ -223,13 +223,18 @@ void mail_post(scs_ctx* c, const Mail& m, bool last) {                          
 }
 void mail_wait(scs_ctx* c) {                                                      // everything posted so far has landed in h_rb
     volatile uint64_t* flag = c->h_rb + MAIL_SEQ_SLOT;
+    // a post usually lands within tens of microseconds: spin (with the CPU's pause hint) for about that long, then back
+    // off -- yield, then short sleeps -- so that a long device phase (a whole-genome pass, a collective waiting for another
+    // rank) does not burn a host core; a failed or drained stream must not leave the host waiting either
     for (uint64_t spin = 1;; ++spin) {
         if (*flag == c->mail_seq) break;
-        if ((spin & 0x3FFF) == 0) {                                               // a failed or drained stream must not leave the host spinning
+        if (spin < 20000) { __builtin_ia32_pause(); continue; }
+        if ((spin & 0x3F) == 0) {
             const hipError_t q = hipStreamQuery(c->stream);
             if (q == hipSuccess) { if (*flag == c->mail_seq) break; throw ScsError(SCS_EDEVICE, "mailbox: stream drained without the expected post"); }
             if (q != hipErrorNotReady) throw ScsError(SCS_EDEVICE, std::string("mailbox: ") + hipGetErrorString(q));
         }
+        if (spin < 20200) std::this_thread::yield(); else std::this_thread::sleep_for(std::chrono::microseconds(spin < 21000 ? 20 : 200));
     }
     std::atomic_thread_fence(std::memory_order_acquire);
 }
@@ -291,12 +296,15 @@ void do_load_profile(scs_ctx* c, const char* path) {
 }
 
 // ---------------------------------------------------------------- genome
-void stage_genome(scs_ctx* c) {
-    c->rec_off.clear(); uint64_t tot = 0;
-    for (auto& r : c->recs) { c->rec_off.push_back(tot); tot += r.code.size(); }
+// d_ascii: the records' ASCII bases already concatenated in device memory (scs_upload_genome_device), or null: host
+// records in c->recs[i].code.  The host copies are dropped once the genome is resident (6 GB at whole-genome size).
+void stage_genome(scs_ctx* c, const void* d_ascii = nullptr, const uint64_t* d_lens = nullptr) {
+    c->rec_off.clear(); c->rec_len.clear(); uint64_t tot = 0;
+    for (size_t i = 0; i < c->recs.size(); ++i) { const uint64_t l = d_ascii ? d_lens[i] : c->recs[i].code.size(); c->rec_off.push_back(tot); c->rec_len.push_back(l); tot += l; }
     c->genome_bases = tot;
     c->genome.reserve(std::max<uint64_t>(tot, 16), c->stream);
-    for (size_t i = 0; i < c->recs.size(); ++i)
+    if (d_ascii) { if (tot) HIP_OK(hipMemcpyAsync(c->genome.p, d_ascii, tot, hipMemcpyDeviceToDevice, c->stream)); }
+    else for (size_t i = 0; i < c->recs.size(); ++i)
         if (!c->recs[i].code.empty())
             HIP_OK(hipMemcpyAsync((uint8_t*)c->genome.p + c->rec_off[i], c->recs[i].code.data(), c->recs[i].code.size(), hipMemcpyHostToDevice, c->stream));
     launch_encode_bases(c->stream, c->genome.as<uint8_t>(), tot);                 // raw ASCII -> base codes on the device
@@ -308,6 +316,7 @@ void stage_genome(scs_ctx* c) {
                            c->gx_n_cnt.as<uint32_t>(), c->gx_gc_pref.as<uint64_t>(), c->gx_n_pref.as<uint64_t>(), c->scan_tmp.p, c->scan_tmp.cap);
     }
     HIP_OK(hipStreamSynchronize(c->stream));
+    for (auto& r : c->recs) std::vector<uint8_t>().swap(r.code);
     c->have_genome = true; c->have_frags = false; c->amplified = false; c->allocated = false;
     c->st.records = c->recs.size(); c->st.genome_bases = tot;
 }
@@ -318,7 +327,7 @@ void do_create_frags(scs_ctx* c) {
     const scs_config& cf = c->cfg;
     std::vector<uint64_t> goff; std::vector<uint32_t> len; std::vector<int8_t> strand;
     for (size_t r = 0; r < c->recs.size(); ++r) {
-        const int64_t chr_len = (int64_t)c->recs[r].code.size(); int64_t pos = 1; uint32_t k = 0;
+        const int64_t chr_len = (int64_t)c->rec_len[r]; int64_t pos = 1; uint32_t k = 0;
         while (pos <= chr_len) {
             const U4 d = draw4(c->key, ST_FRAGSPLIT, 0, r, k++);
             const int64_t fl = scale_draw(d.w[0], (uint32_t)cf.frag_min, (uint32_t)(cf.frag_max + 1 - cf.frag_min));   // randomInteger(minSize, maxSize+1)
@@ -656,7 +665,9 @@ void do_yield(scs_ctx* c, const OutTarget& tg, uint64_t* n1_out, uint64_t* n2_ou
     const uint64_t P = c->n_pairs_planned;
     const uint32_t L = (uint32_t)c->prof.read_length, slot = ((L + 64 + 63) / 64) * 64;
     c->pairs.reserve(std::max<size_t>(P * sizeof(PairRec), 16), s);
-    launch_plan_pairs(s, c->frags_view(), c->semis.view(), c->fulls.view(), c->fulls.n, c->read_numbers.as<uint32_t>(), c->pair_off.as<uint32_t>(), c->have_gidx ? c->d_gidx.as<uint32_t>() : nullptr, c->dtb, c->key, paired, c->pairs.as<PairRec>());
+    HIP_OK(hipMemsetAsync(c->dsums.as<unsigned long long>() + DS_HOLES, 0, 8, s));
+    launch_plan_pairs(s, c->frags_view(), c->semis.view(), c->fulls.view(), c->fulls.n, c->read_numbers.as<uint32_t>(), c->pair_off.as<uint32_t>(), c->have_gidx ? c->d_gidx.as<uint32_t>() : nullptr, c->dtb, c->key, paired, c->pairs.as<PairRec>(),
+                      c->dsums.as<unsigned long long>() + DS_HOLES);
     const bool to_sink = !tg.device && tg.sink;
     const uint64_t batch = std::min<uint64_t>(std::max<uint64_t>(P, 1), to_sink ? (1ull << 19) : (1ull << 21));   // sink: smaller batches, pinned double buffers
     struct PipeGuard { SinkPipe* p; ~PipeGuard() { if (p) (void)p->finish(); } } guard{nullptr};
@@ -718,19 +729,13 @@ void do_yield(scs_ctx* c, const OutTarget& tg, uint64_t* n1_out, uint64_t* n2_ou
         }
         tot1 += b1; tot2 += b2;
     }
-    // count produced pairs (holes have isz == 0); cheap host pass over the lengths is avoided: holes only
-    // arise when >1000 insert sizes in a row miss [readLength, ampliconLen] (Amplicon.cpp:484-489).
-    {
-        std::vector<PairRec> hp;   // only inspect when the insert range can miss
-        const bool can_miss = paired && (c->prof.isize_min + (int)c->prof.isize_t.size() - 1 > c->cfg.amplicon_min_len);
-        if (can_miss && P) { hp.resize(P); HIP_OK(hipMemcpyAsync(hp.data(), c->pairs.p, P * sizeof(PairRec), hipMemcpyDeviceToHost, s)); HIP_OK(hipStreamSynchronize(s));
-                             for (auto& r : hp) pairs_written += r.isz != 0; }
-        else pairs_written = P;
-    }
-    { Mail m; m.add(c->flags.p, 4, 30); mail_post(c, m, true); }                  // the overflow flags land before the final synchronize: no second round trip
+    // pairs produced = planned - holes; a hole arises only when > 1000 insert sizes in a row miss [readLength, ampliconLen]
+    // (Amplicon.cpp:484-489): k_plan_pairs counted them on the device
+    { Mail m; m.add(c->flags.p, 4, 30); m.add(c->dsums.as<unsigned long long>() + DS_HOLES, 8, 2); mail_post(c, m, true); }   // flags + hole count land before the final synchronize: no second round trip
     HIP_OK(hipStreamSynchronize(s));
     if (to_sink) { guard.p = nullptr; if (!c->pipe->finish()) throw ScsError(SCS_EIO, "sink aborted"); }
     mail_wait(c); flags_eval(c);
+    pairs_written = P - c->h_rb[2];
     c->tm_reads.collect(); c->tm_indels.collect();
     c->st.pairs_written = pairs_written; c->st.reads_written = paired ? 2 * pairs_written : pairs_written;
     c->st.fastq_bytes[0] = tot1; c->st.fastq_bytes[1] = tot2;
@@ -834,6 +839,14 @@ int scs_upload_genome(scs_ctx* c, int n, const char* const* names, const char* c
         c->recs.resize(n);
         for (int i = 0; i < n; ++i) encode_record(names[i], seqs[i], lens[i], c->recs[i]);
         stage_genome(c);
+    });
+}
+int scs_upload_genome_device(scs_ctx* c, int n, const char* const* names, const uint64_t* lens, const void* d_bases) {
+    return guarded(c, [&] {
+        if (n <= 0 || !names || !lens || !d_bases) throw ScsError(SCS_EINVAL, "scs_upload_genome_device: bad arguments");
+        c->recs.resize(n);
+        for (int i = 0; i < n; ++i) encode_record(names[i], nullptr, 0, c->recs[i]);
+        stage_genome(c, d_bases, lens);
     });
 }
 int scs_create_frags(scs_ctx* c) { return guarded(c, [&] { double t = now_s(); do_create_frags(c); c->st.t_stage[1] = now_s() - t; }); }

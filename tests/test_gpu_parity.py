@@ -276,25 +276,45 @@ open(%r, "wb").write(a[0])
 
 
 def test_bench_two_rank_control_flow(tmp_path):
-    """bench.py's N > 1 path (one sharded job, sizes all-gathered, read pools sent to rank 0, max-over-ranks timing)
-    rehearsed as 2 ranks on this box's one GPU: gloo collectives staged through the CPU instead of RCCL.  Checks the
-    control flow and the JSON contract, not a rate."""
+    """bench.py's N > 1 path (ONE job sharded 2 ways by fragment lineage -- strong scaling --, a FASTQ shard per rank,
+    max-over-ranks timing) rehearsed as 2 ranks on this box's one GPU on a scaled-down genome: gloo collectives staged
+    through the CPU instead of RCCL.  Checks the control flow and the JSON contract, not a rate."""
     import json
     import sys
     env = dict(os.environ, SCS_BENCH_BACKEND="gloo", SCS_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29791", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1"],
+                        "--master-port", "29791", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--genome-mb", "4"],
                        env=env, capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, "rank 0 prints exactly one JSON line"
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 5 and d["scaling"] == "weak" and d["vs_baseline"] is None
-    assert d["value"] > 0 and abs(d["value"] - 2 * d["config"]["pairs_per_step_per_gpu"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 0.05
-    assert 150000 < 2 * d["config"]["pairs_per_step_per_gpu"] < 250000          # 2 x 1 Mb at 30x, PE150: ~200 k pairs per job
-    assert d["roofline"]["frac"] > 0 and "cpu_baseline" not in d
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "strong" and d["vs_baseline"] is None
+    assert d["value"] > 0 and abs(d["value"] - d["config"]["pairs_per_step"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 0.05
+    assert 350000 < d["config"]["pairs_per_step"] < 450000                         # the whole 4 Mb job at 30x, PE150: ~400 k pairs
+    assert 0 < d["roofline"]["frac"] <= 1 and "cpu_baseline" not in d
+
+
+def test_bench_single_gpu_contract(tmp_path):
+    """bench.py at N = 1 on a scaled-down genome: every leg runs (timed steps, sink-inclusive step, CLI wall, CPU baseline)
+    and the JSON line carries the contract's fields."""
+    import json
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--genome-mb", "6", "--cpu-sample-mb", "0.2"],
+                       capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["unit"] == "pairs/s" and d["n_gpus"] == 1 and d["vs_baseline"] is None and "workload" in d["config"]
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and 0 < rf["frac"] <= 1 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and rf["draws_per_s"] > 0
+    assert d["cpu_baseline"]["kind"] in ("reference", "port") and d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] >= 1
+    assert d["sink_inclusive"]["value"] > 0 and d["sink_inclusive"]["fastq_bytes"] > 0
+    assert d["cli_wall"].get("value", 0) > 0, d["cli_wall"]
+    assert abs(d["value"] - d["config"]["pairs_per_step"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 0.05
 
 
 def test_medium_genome_bit_exact(oracle_bin, models, tmp_path):
