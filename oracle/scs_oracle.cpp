@@ -520,6 +520,7 @@ struct Sim {
     std::vector<Frag> frags; AmpList semis, fulls;
     std::vector<long> primerCount;          // 65536 counters (Malbac.cpp:36-81; flat instead of trie)
     std::vector<long> primerPending;        // [REMAP] counter mode: decrements applied at pass end
+    std::vector<long> primerUsed;           // attachments per primer type over the whole run (dump / statistics only)
     std::vector<uint64_t> binom;            // [REMAP] counter mode: error-count thresholds
     // sharded mode: this shard owns fragments [frag_gbase, frag_gbase + frags.size()) of the global list
     uint64_t frag_gbase = 0;
@@ -601,7 +602,7 @@ struct PrimerPool {
             (*pending)[idx]++; return true;
         }
         if (S.primerCount[idx] - 1 < 0) return false;
-        S.primerCount[idx] -= 1; return true;
+        S.primerCount[idx] -= 1; S.primerUsed[idx] += 1; return true;
     }
 };
 
@@ -756,7 +757,7 @@ void apply_pending(Sim& S, std::vector<std::vector<long>>& pend) {
     std::vector<uint64_t> sum(65536, 0);
     for (auto& v : pend) for (size_t i = 0; i < v.size(); ++i) sum[i] += (uint64_t)v[i];
     S.allreduce(sum.data(), sum.size());                                            // sharded: decrements of all shards
-    for (size_t i = 0; i < sum.size(); ++i) { S.primerCount[i] -= (long)sum[i]; if (S.primerCount[i] < 0) S.primerCount[i] = 0; }   // [REMAP] clamp at pass end
+    for (size_t i = 0; i < sum.size(); ++i) { S.primerUsed[i] += (long)sum[i]; S.primerCount[i] -= (long)sum[i]; if (S.primerCount[i] < 0) S.primerCount[i] = 0; }   // [REMAP] clamp at pass end
 }
 
 // Malbac::amplifyFrags (Malbac.cpp:318-343)
@@ -810,7 +811,7 @@ void amplify_semis(Sim& S, uint32_t cyc) {
 // Malbac::amplify (Malbac.cpp:173-201)
 void amplify(Sim& S) {
     if (S.prm.verbose) fprintf(stderr, "\nMALBAC amplification...\n");
-    S.primerCount.assign(65536, S.prm.primers);
+    S.primerCount.assign(65536, S.prm.primers); S.primerUsed.assign(65536, 0);
     if (S.prm.counter) S.binom = binom_table(S.prm.ber, S.prm.ampMin - 8, S.prm.ampMax - 8);
     S.totalPrimers = 65536UL * (unsigned long)S.prm.primers;
     set_primers(S, true, 0);
@@ -1125,6 +1126,9 @@ int genreads(const scso_params& q) {
         for (size_t i = 0; i < S.frags.size(); ++i) fprintf(f, "%zu\t%d\t%ld\t%d\t%d\n", i, S.frags[i].rec, S.frags[i].start, S.frags[i].len, S.frags[i].strand);
         fclose(f);
         dump_amps(d + ".semis.tsv", S.semis); dump_amps(d + ".fulls.tsv", S.fulls);
+        f = fopen((d + ".primers.tsv").c_str(), "w");                                       // primer type, attachments, stock left
+        for (size_t i = 0; i < S.primerCount.size(); ++i) if (S.primerUsed[i]) fprintf(f, "%zu\t%ld\t%ld\n", i, S.primerUsed[i], S.primerCount[i]);
+        fclose(f);
         f = fopen((d + ".readnum.tsv").c_str(), "w");
         for (size_t i = 0; i < S.readNumbers.size(); ++i) if (S.readNumbers[i]) fprintf(f, "%zu\t%u\n", i, S.readNumbers[i]);
         fclose(f);

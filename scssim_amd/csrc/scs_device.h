@@ -79,6 +79,25 @@ enum { DS_SEMI_LEN = 4, DS_SEMIS_N = 5, DS_REPORTED_LEN = 6, DS_G_SEMIS_N = 8, D
 enum { SHARD_TAIL_WORDS = 16 };                       // u32 words behind the 65536 primer decrements that ride on the same all-reduce
 struct AllocState { double total; unsigned long long sum_rn, sum_quota; };
 
+// ---- read allocation over the whole job's amplicon list, computed by the shards (scs_kernels.hip, K3) ---------------
+// The list is cut into chunks of 1000 (randIndx_hp's chunks, MyDefine.cpp:203-253).  A shard's local list is the
+// concatenation of its segments (cycle ascending, fragment pass descending: slot = cycle * 8 + (7 - pass)); the whole
+// job's list interleaves the shards' segments slot by slot (order = slot * shards + rank).
+#define ALLOC_CHUNK 1000u
+enum { ALLOC_SLOTS = 40 };
+struct AllocRange { uint32_t q0, c0, local0; };            // work chunks q0.. (up to the next range) = whole-job chunks c0.., in place at local0 + 1000 (q - q0)
+struct AllocBChunk { uint32_t c, n, owner; };              // a chunk that straddles a segment boundary: materialised row; owner: this shard holds its first amplicon
+struct AllocGSeg { unsigned long long go; uint32_t lo, n, owner, slot; };   // every non-empty segment of every shard, in list order
+struct AllocMySeg { unsigned long long go; uint32_t lo, n, order, pad; };  // this shard's segment of slot s
+struct AllocPlan {
+    unsigned long long total;                              // amplicons of the whole job
+    uint32_t rank, n_interior, n_boundary, n_ranges, n_gseg;
+    const AllocRange* rng; const AllocBChunk* bchunk; const AllocGSeg* gseg;    // device arrays
+    AllocMySeg my_seg[ALLOC_SLOTS];
+};
+// local amplicon index -> index in the whole job's list (the number printed in the record name); n == 0: identity
+struct SegMap { uint32_t n; uint32_t lo[ALLOC_SLOTS], cnt[ALLOC_SLOTS]; unsigned long long go[ALLOC_SLOTS]; };
+
 // error flags raised by kernels (never silent): bit 0 error-list cap, 1 error pool, 2 read slot, 3 other
 enum DevFlag : uint32_t { FLAG_ERRCAP = 1, FLAG_ERRPOOL = 2, FLAG_READSLOT = 4, FLAG_INTERNAL = 8 };
 
@@ -99,9 +118,19 @@ void launch_attach_frags(hipStream_t s, const uint8_t* g, DevFrags fr, const uin
                          unsigned long long* len_sum, AmplifyParams p);
 void launch_poisson(hipStream_t s, DevFrags fr, DevAmps semis, uint32_t n_semis, PoissonParams p, uint32_t* budget_f, uint32_t* budget_s,
                     unsigned long long* sums);
-// whole read allocation on the device; rn / pair_cnt_off need ac+1 entries, scan temp from scan_temp_bytes(ac)
-void launch_alloc(hipStream_t s, double* w, uint32_t ac, unsigned long long reads, RngKey key, int paired, AllocState* st, double* part, double* tp,
-                  double* probs, uint32_t* quota, uint32_t* rn, uint32_t* odd_before, uint32_t* pair_cnt_off, void* temp, size_t temp_bytes);
+// read allocation, stage by stage (the pipeline puts the shards' exchanges between them)
+void launch_alloc_bpack(hipStream_t s, const double* w, const AllocPlan& pl, double* send);
+void launch_alloc_bgather(hipStream_t s, const double* w, const AllocPlan& pl, const double* gathered, double* brow, int* bmap);
+void launch_alloc_chunk_sum(hipStream_t s, const double* w, const double* brow, const AllocPlan& pl, double* part);
+void launch_tree_sum(hipStream_t s, const double* part, uint32_t nch, double* scratch, double* total);     // scratch: nch/1000 + 1024 doubles
+void launch_alloc_norm(hipStream_t s, double* w, double* brow, const int* bmap, const AllocPlan& pl, const double* total, unsigned long long reads,
+                       uint32_t* rn, double* tp, uint32_t* crn, unsigned long long* sum_rn);
+void launch_alloc_quota(hipStream_t s, const double* tp, uint32_t nch, unsigned long long reads, const unsigned long long* sum_rn, unsigned long long* sum_quota,
+                        uint32_t* quota, double* probs, double* scratch, RngKey key);   // scratch: 3 * (nch / 1000) + 4096 doubles
+void launch_alloc_sample(hipStream_t s, const double* w, const double* brow, const int* bmap, const AllocPlan& pl, const double* tp, const uint32_t* quota, RngKey key, uint32_t* rn);
+void launch_alloc_odd_scan(hipStream_t s, const uint32_t* rn, uint32_t ac, uint32_t* odd_before, void* temp, size_t temp_bytes);
+void launch_alloc_odd_counts(hipStream_t s, const uint32_t* odd_before, const AllocPlan& pl, unsigned long long* table);
+void launch_alloc_parity(hipStream_t s, uint32_t* rn, const uint32_t* odd_before, uint32_t ac, const AllocPlan& pl, const unsigned long long* table);
 void launch_attach_semis(hipStream_t s, const uint8_t* g, DevFrags fr, DevAmps semis, uint32_t n_semis, DevErrPool spool,
                          const uint32_t* slot_off, uint32_t* slots, uint32_t* slot_tmpl, uint32_t* valid,
                          const int64_t* primer_cnt, uint32_t* primer_delta, AmplifyParams p);
@@ -120,7 +149,7 @@ void launch_amplify_init(hipStream_t s, int64_t* primer_cnt, int64_t copies, uin
 void launch_primer_update(hipStream_t s, int64_t* primer_cnt, uint32_t* primer_delta);
 void launch_weights(hipStream_t s, DevAmps fulls, uint32_t n, DevTables tb, RngKey key, uint32_t frag_size, double* w);
 void launch_plan_pairs(hipStream_t s, DevFrags fr, DevAmps semis, DevAmps fulls, uint32_t n_fulls, const uint32_t* read_numbers, const uint32_t* pair_off,
-                       const uint32_t* gidx, DevTables tb, RngKey key, int paired, PairRec* pairs, unsigned long long* holes);
+                       SegMap gmap, DevTables tb, RngKey key, int paired, PairRec* pairs, unsigned long long* holes);
 void launch_pair_offsets(hipStream_t s, const uint32_t* rn, uint32_t ac, int paired, uint32_t* pair_cnt_off, void* temp, size_t temp_bytes);
 // reads of pairs [p0, p0+np): slot layout [2*np][slot] bases / quals (SE: [np][slot])
 size_t reads_lds_bytes(const DevTables& tb);          // dynamic LDS of one inject_errors workgroup for this profile

@@ -348,7 +348,7 @@ __global__ void k_weights(DevAmps fulls, uint32_t n, DevTables tb, RngKey key, u
 //      (Amplicon.cpp:448-491): insert size, rejection, position.
 // ------------------------------------------------------------------------------------------------
 __global__ void k_plan_pairs(DevFrags fr, DevAmps semis, DevAmps fulls, uint32_t n_fulls, const uint32_t* __restrict__ read_numbers,
-                             const uint32_t* __restrict__ pair_off, const uint32_t* __restrict__ gidx, DevTables tb, RngKey key, int paired,
+                             const uint32_t* __restrict__ pair_off, const SegMap gmap, DevTables tb, RngKey key, int paired,
                              PairRec* __restrict__ pairs, unsigned long long* __restrict__ holes) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_fulls) return;
@@ -361,7 +361,8 @@ __global__ void k_plan_pairs(DevFrags fr, DevAmps semis, DevAmps fulls, uint32_t
     // resolve U = full amplicon sequence to an index map once (Amplicon::getSequence, Amplicon.cpp:266-340, without the copies)
     const uint32_t sm = fulls.parent[i], ssl = semis.sl[sm], l1 = sl_len(ssl), f = semis.parent[sm];
     const View uv = shift_view(semi_tmpl_view(frag_view(fr.goff[f], fr.len[f], fr.strand[f]), sl_spos(ssl), l1), s2);
-    PairRec r; r.amp = gidx ? gidx[i] : i;                                         // index in the whole job's list (record names)
+    PairRec r; r.amp = i;                                                          // index in the whole job's list (record names)
+    for (uint32_t k = 0; k < gmap.n; ++k) if (i - gmap.lo[k] < gmap.cnt[k]) { r.amp = (uint32_t)(gmap.go[k] + (i - gmap.lo[k])); break; }
     r.base = uv.base; r.flags = (uv.comp & 1u) | (uv.dir < 0 ? 2u : 0u); r.k1 = (int32_t)(l1 - 1 - s2);
     r.e1 = semis.errs[sm]; r.e2 = fulls.errs[i]; r.uid = fulls.uid[i]; r.pad = 0;
     uint32_t made = 0;
@@ -1413,11 +1414,11 @@ __global__ void __launch_bounds__(1024) k_sum_u32(const uint32_t* __restrict__ v
     if (threadIdx.x == 0) { unsigned long long t = 0; for (int k = 0; k < 16; ++k) t += s_p[k]; *dst = add ? *dst + t : t; }
 }
 // per-chunk quota of the residual reads: unsigned(tp * n) (MyDefine.cpp:225-227), for every chunk of the whole job
-__global__ void __launch_bounds__(256) k_alloc_quota(const double* __restrict__ tp, uint32_t nch, unsigned long long reads, const AllocState* __restrict__ st,
+__global__ void __launch_bounds__(256) k_alloc_quota(const double* __restrict__ tp, uint32_t nch, unsigned long long reads, const unsigned long long* __restrict__ sum_rn,
                                                      uint32_t* __restrict__ quota) {
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= nch) return;
-    const unsigned long long nres = reads - st->sum_rn;
+    const unsigned long long nres = reads - *sum_rn;
     quota[c] = (uint32_t)(tp[c] * (double)nres);
 }
 // scan_all, level 0: scan1000 inside every group of 1000 of `in`; last[g] = the group's last entry
@@ -1444,10 +1445,10 @@ __device__ __forceinline__ uint32_t first_le(const double* __restrict__ cdf, uin
     while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (r <= cdf[mid]) hi = mid; else lo = mid + 1; }
     return lo < n ? lo : n - 1;
 }
-__global__ void k_alloc_top_draws(const double* __restrict__ probs, uint32_t nch, unsigned long long reads, const AllocState* __restrict__ st,
-                                  RngKey key, uint32_t* __restrict__ quota) {
+__global__ void k_alloc_top_draws(const double* __restrict__ probs, uint32_t nch, unsigned long long reads, const unsigned long long* __restrict__ sum_rn,
+                                  const unsigned long long* __restrict__ sum_quota, RngKey key, uint32_t* __restrict__ quota) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    const unsigned long long n = reads - st->sum_rn - st->sum_quota;                     // leftover after the per-chunk quotas (< nch)
+    const unsigned long long n = reads - *sum_rn - *sum_quota;                           // leftover after the per-chunk quotas (< nch)
     if (t >= n) return;
     const U4 d = draw4(key, ST_ALLOC_TOP, 0, 0, t);
     const double r = 2.2204e-16 + (1 - 2.2204e-16) * ((double)d.w[0] / 4294967296.0);
@@ -1568,24 +1569,65 @@ void launch_poisson(hipStream_t s, DevFrags fr, DevAmps semis, uint32_t n_semis,
     const uint32_t semi_blocks = n_semis ? cdiv((uint64_t)n_semis + 1, 256) : 0u;
     if (fr.n + semi_blocks) hipLaunchKernelGGL(k_poisson, dim3(fr.n + semi_blocks), dim3(256), 0, s, fr, semis, n_semis, p, budget_f, budget_s, sums);
 }
-void launch_alloc(hipStream_t s, double* w, uint32_t ac, unsigned long long reads, RngKey key, int paired, AllocState* st, double* part, double* tp,
-                  double* probs, uint32_t* quota, uint32_t* rn, uint32_t* odd_before, uint32_t* pair_cnt_off, void* temp, size_t temp_bytes) {
-    if (ac == 0) return;
-    const uint32_t nch = (ac + ALLOC_CHUNK - 1) / ALLOC_CHUNK;
-    hipLaunchKernelGGL(k_alloc_chunk_sum, dim3(nch), dim3(64), 0, s, w, ac, part);
-    hipLaunchKernelGGL(k_alloc_total, dim3(1), dim3(256), 0, s, part, nch, st);
-    hipLaunchKernelGGL(k_alloc_floor, dim3(cdiv(ac, 256)), dim3(256), 0, s, w, ac, reads, st, rn);
-    hipLaunchKernelGGL(k_alloc_quota, dim3(nch), dim3(64), 0, s, w, ac, reads, st, tp, quota);
-    hipLaunchKernelGGL(k_alloc_top_prefix, dim3(1), dim3(256), 0, s, tp, nch, probs);
-    hipLaunchKernelGGL(k_alloc_top_draws, dim3(cdiv((uint64_t)nch + 1024, 256)), dim3(256), 0, s, probs, nch, reads, st, key, quota);
-    hipLaunchKernelGGL(k_alloc_sample, dim3(nch), dim3(256), 0, s, w, ac, quota, key, rn);
-    if (paired) {
-        (void)rocprim::exclusive_scan(temp, temp_bytes, rocprim::make_transform_iterator(rn, OddBit()), odd_before, 0u, (size_t)ac + 1, rocprim::plus<uint32_t>(), s);
-        hipLaunchKernelGGL(k_alloc_parity, dim3(cdiv(ac, 256)), dim3(256), 0, s, rn, odd_before, ac);
-        (void)rocprim::exclusive_scan(temp, temp_bytes, rocprim::make_transform_iterator(rn, HalfUp()), pair_cnt_off, 0u, (size_t)ac + 1, rocprim::plus<uint32_t>(), s);
-    } else {
-        (void)rocprim::exclusive_scan(temp, temp_bytes, rn, pair_cnt_off, 0u, (size_t)ac + 1, rocprim::plus<uint32_t>(), s);
+void launch_alloc_bpack(hipStream_t s, const double* w, const AllocPlan& pl, double* send) {
+    hipLaunchKernelGGL(k_alloc_bpack, dim3(2 * ALLOC_SLOTS), dim3(256), 0, s, w, pl, send);
+}
+void launch_alloc_bgather(hipStream_t s, const double* w, const AllocPlan& pl, const double* gathered, double* brow, int* bmap) {
+    if (pl.n_boundary) hipLaunchKernelGGL(k_alloc_bgather, dim3(pl.n_boundary), dim3(256), 0, s, w, pl, gathered, brow, bmap);
+}
+void launch_alloc_chunk_sum(hipStream_t s, const double* w, const double* brow, const AllocPlan& pl, double* part) {
+    const uint32_t nq = pl.n_interior + pl.n_boundary;
+    if (nq) hipLaunchKernelGGL(k_alloc_chunk_sum, dim3(cdiv(nq, 4)), dim3(256), 0, s, w, brow, pl, part);
+}
+// tree_sum above the chunk level: tree1000 over groups of 1000 until one value is left; *total receives it
+void launch_tree_sum(hipStream_t s, const double* part, uint32_t nch, double* scratch, double* total) {
+    if (nch == 0) { (void)hipMemsetAsync(total, 0, 8, s); return; }
+    if (nch == 1) { (void)hipMemcpyAsync(total, part, 8, hipMemcpyDeviceToDevice, s); return; }   // a single chunk: its sum is the total
+    const double* cur = part; uint32_t n = nch; double* nxt = scratch;
+    while (n > 1) {
+        const uint32_t ng = cdiv(n, ALLOC_CHUNK);
+        double* dst = ng == 1 ? total : nxt;
+        hipLaunchKernelGGL(k_tree1000, dim3(cdiv(ng, 4)), dim3(256), 0, s, cur, n, dst);
+        cur = dst; nxt += ng; n = ng;
     }
+}
+void launch_alloc_norm(hipStream_t s, double* w, double* brow, const int* bmap, const AllocPlan& pl, const double* total, unsigned long long reads,
+                       uint32_t* rn, double* tp, uint32_t* crn, unsigned long long* sum_rn) {
+    const uint32_t nq = pl.n_interior + pl.n_boundary;
+    if (nq) hipLaunchKernelGGL(k_alloc_norm, dim3(cdiv(nq, 4)), dim3(256), 0, s, w, brow, bmap, pl, total, reads, rn, tp, crn);
+    hipLaunchKernelGGL(k_sum_u32, dim3(1), dim3(1024), 0, s, crn, nq, sum_rn, 0);
+}
+// scan_all: scan1000 inside groups of 1000, recursively over the groups' last entries, then the fix-up
+static void scan_all_dev(hipStream_t s, const double* in, uint32_t n, double* out, double* scratch) {
+    const uint32_t ng = cdiv(n, ALLOC_CHUNK);
+    double* last = scratch; double* pre = scratch + ng;
+    hipLaunchKernelGGL(k_scan1000, dim3(ng), dim3(64), 0, s, in, n, out, ng > 1 ? last : (double*)nullptr);
+    if (ng == 1) return;
+    scan_all_dev(s, last, ng, pre, scratch + 2 * (size_t)ng);
+    hipLaunchKernelGGL(k_scan_fix, dim3(cdiv(n, 256)), dim3(256), 0, s, out, n, pre);
+}
+// per-chunk quotas of the residual reads, the CDF over the chunks and the leftover draws (MyDefine.cpp:225-245): every
+// shard computes them for ALL chunks of the job from the all-reduced tp[] (8 B per 1000 amplicons)
+void launch_alloc_quota(hipStream_t s, const double* tp, uint32_t nch, unsigned long long reads, const unsigned long long* sum_rn, unsigned long long* sum_quota,
+                        uint32_t* quota, double* probs, double* scratch, RngKey key) {
+    if (nch == 0) return;
+    hipLaunchKernelGGL(k_alloc_quota, dim3(cdiv(nch, 256)), dim3(256), 0, s, tp, nch, reads, sum_rn, quota);
+    hipLaunchKernelGGL(k_sum_u32, dim3(1), dim3(1024), 0, s, quota, nch, sum_quota, 0);
+    scan_all_dev(s, tp, nch, probs, scratch);
+    hipLaunchKernelGGL(k_alloc_top_draws, dim3(cdiv((uint64_t)nch + 1024, 256)), dim3(256), 0, s, probs, nch, reads, sum_rn, sum_quota, key, quota);
+}
+void launch_alloc_sample(hipStream_t s, const double* w, const double* brow, const int* bmap, const AllocPlan& pl, const double* tp, const uint32_t* quota, RngKey key, uint32_t* rn) {
+    const uint32_t nq = pl.n_interior + pl.n_boundary;
+    if (nq) hipLaunchKernelGGL(k_alloc_sample, dim3(nq), dim3(64), 0, s, w, brow, bmap, pl, tp, quota, key, rn);
+}
+void launch_alloc_odd_scan(hipStream_t s, const uint32_t* rn, uint32_t ac, uint32_t* odd_before, void* temp, size_t temp_bytes) {
+    (void)rocprim::exclusive_scan(temp, temp_bytes, rocprim::make_transform_iterator(rn, OddBit()), odd_before, 0u, (size_t)ac + 1, rocprim::plus<uint32_t>(), s);
+}
+void launch_alloc_odd_counts(hipStream_t s, const uint32_t* odd_before, const AllocPlan& pl, unsigned long long* table) {
+    hipLaunchKernelGGL(k_alloc_odd_counts, dim3(1), dim3(64), 0, s, odd_before, pl, table);
+}
+void launch_alloc_parity(hipStream_t s, uint32_t* rn, const uint32_t* odd_before, uint32_t ac, const AllocPlan& pl, const unsigned long long* table) {
+    if (ac) hipLaunchKernelGGL(k_alloc_parity, dim3(cdiv(ac, 256)), dim3(256), 0, s, rn, odd_before, ac, pl, table);
 }
 void launch_attach_semis(hipStream_t s, const uint8_t* g, DevFrags fr, DevAmps semis, uint32_t n_semis, DevErrPool spool,
                          const uint32_t* slot_off, uint32_t* slots, uint32_t* slot_tmpl, uint32_t* valid,
@@ -1642,9 +1684,9 @@ void launch_weights(hipStream_t s, DevAmps fulls, uint32_t n, DevTables tb, RngK
     hipLaunchKernelGGL(k_weights, dim3(cdiv(n, 256)), dim3(256), 0, s, fulls, n, tb, key, frag_size, w);
 }
 void launch_plan_pairs(hipStream_t s, DevFrags fr, DevAmps semis, DevAmps fulls, uint32_t n_fulls, const uint32_t* read_numbers, const uint32_t* pair_off,
-                       const uint32_t* gidx, DevTables tb, RngKey key, int paired, PairRec* pairs, unsigned long long* holes) {
+                       SegMap gmap, DevTables tb, RngKey key, int paired, PairRec* pairs, unsigned long long* holes) {
     if (n_fulls == 0) return;
-    hipLaunchKernelGGL(k_plan_pairs, dim3(cdiv(n_fulls, 256)), dim3(256), 0, s, fr, semis, fulls, n_fulls, read_numbers, pair_off, gidx, tb, key, paired, pairs, holes);
+    hipLaunchKernelGGL(k_plan_pairs, dim3(cdiv(n_fulls, 256)), dim3(256), 0, s, fr, semis, fulls, n_fulls, read_numbers, pair_off, gmap, tb, key, paired, pairs, holes);
 }
 void launch_pair_offsets(hipStream_t s, const uint32_t* rn, uint32_t ac, int paired, uint32_t* pair_cnt_off, void* temp, size_t temp_bytes) {
     if (paired) (void)rocprim::exclusive_scan(temp, temp_bytes, rocprim::make_transform_iterator(rn, HalfUp()), pair_cnt_off, 0u, (size_t)ac + 1, rocprim::plus<uint32_t>(), s);

@@ -171,15 +171,15 @@ struct scs_ctx {
     DevBuf primer_cnt, primer_delta; uint64_t total_primers = 0; bool amplified = false;
     DevBuf slots, slot_tmpl, valid, valid_off, valid_f, valid_off_f, scan_tmp, flags;
     // allocation + reads
-    DevBuf weights, read_numbers, pair_off, pairs, odd_before, a_part, a_tp, a_probs, a_quota, a_poff; std::vector<uint32_t> h_read_numbers; uint64_t reads_requested = 0, n_pairs_planned = 0; bool allocated = false;
+    DevBuf weights, read_numbers, pair_off, pairs, odd_before, a_part, a_tp, a_probs, a_quota, a_poff, a_plan, a_crn, a_scratch, a_brow, a_bmap, a_send, a_gath, a_odd; SegMap gmap{}; std::vector<uint32_t> h_read_numbers; uint64_t reads_requested = 0, n_pairs_planned = 0; bool allocated = false;
     DevBuf slot_b, slot_q, lens, ev_hdr, ev_dat, sizes1, sizes2, off1, off2, out1, out2; SinkPipe* pipe = nullptr;
     // sharded single job: collectives supplied by the caller + segment bookkeeping of the local amplicon lists
     scs_allreduce_fn allreduce = nullptr; scs_allgatherv_fn allgatherv = nullptr; void* coll_user = nullptr;
     scs_allreduce_dev_fn allreduce_dev = nullptr; scs_allgather_dev_fn allgather_dev = nullptr; void* coll_dev_user = nullptr;
-    DevBuf d_tot, d_stage, d_all, d_mail;
+    DevBuf d_tot, d_stage, d_mail;
     std::vector<uint32_t> semi_block_end;                  // local semi count after each fragment pass
     struct Seg { int c, p; uint32_t count; }; std::vector<Seg> full_segs;   // local fulls list = these, in order
-    DevBuf d_gidx, d_gw, d_grn, d_hostred; bool have_gidx = false;
+    DevBuf d_hostred;
     int pending_seg_cycle = -1;
     // collectives run when the job is sharded -- or whenever hooks are installed (1-shard jobs then exercise them too)
     bool sharded() const { return cfg.shard_count > 1 || allreduce || allreduce_dev; }
@@ -205,6 +205,14 @@ struct scs_ctx {
         if (elem_bytes == 8) { HIP_OK(hipMemcpyAsync(d, v.data(), n * 8, hipMemcpyHostToDevice, stream)); HIP_OK(hipStreamSynchronize(stream)); }
         else { std::vector<uint32_t> w(n); for (uint64_t i = 0; i < n; ++i) w[i] = (uint32_t)std::min<uint64_t>(v[i], 0xFFFFFFFFull);
                HIP_OK(hipMemcpyAsync(d, w.data(), n * 4, hipMemcpyHostToDevice, stream)); HIP_OK(hipStreamSynchronize(stream)); }
+    }
+    // every shard's `bytes` at d_send -> d_recv[r * bytes ..], ordered on the ctx stream when the device hook is set
+    void gather_dev(const void* d_send, void* d_recv, uint64_t bytes) {
+        if (allgather_dev) { if (allgather_dev(coll_dev_user, d_send, d_recv, bytes)) throw ScsError(SCS_EINVAL, "sharded job: device all-gather hook failed"); return; }
+        std::vector<uint8_t> h(bytes), all((size_t)bytes * cfg.shard_count); std::vector<uint64_t> sizes(cfg.shard_count, 0);
+        HIP_OK(hipMemcpyAsync(h.data(), d_send, bytes, hipMemcpyDeviceToHost, stream)); HIP_OK(hipStreamSynchronize(stream));
+        if (!allgatherv || allgatherv(coll_user, h.data(), bytes, all.data(), bytes, sizes.data())) throw ScsError(SCS_EINVAL, "sharded job: all-gather hook missing or failed (scs_set_collectives)");
+        HIP_OK(hipMemcpyAsync(d_recv, all.data(), all.size(), hipMemcpyHostToDevice, stream)); HIP_OK(hipStreamSynchronize(stream));
     }
     scs_stats st{};
     KernelTimer tm_errscan{"k_errs<semi->full>"}, tm_errscan_f{"k_errs<frag->semi>"}, tm_reads{"k_reads"}, tm_attach{"k_attach<semi>"}, tm_indels{"k_indels"}, tm_attach_f{"k_attach<frag>"};
@@ -500,7 +508,7 @@ void do_amplify(scs_ctx* c) {
     if (!c->have_profile) throw ScsError(SCS_EINVAL, "scs_amplify: load a profile first");
     hipStream_t s = c->stream;
     if (c->cfg.verbose) fprintf(stderr, "\nMALBAC amplification...\n");
-    c->semis.reset_counts(); c->fulls.reset_counts(); c->semi_block_end.clear(); c->full_segs.clear(); c->pending_seg_cycle = -1; c->have_gidx = false; c->pend = Mail();
+    c->semis.reset_counts(); c->fulls.reset_counts(); c->semi_block_end.clear(); c->full_segs.clear(); c->pending_seg_cycle = -1; c->pend = Mail();
     c->timing_gate = (c->amplify_calls++ % c->timing_every) == 0;
     c->tm_errscan.reset(); c->tm_errscan_f.reset(); c->tm_attach.reset(); c->tm_attach_f.reset();
     c->primer_cnt.reserve(65536 * 8, s); c->primer_delta.reserve((65536 + SHARD_TAIL_WORDS) * 4, s);   // createPrimers: 4^8 types x `primers` copies
@@ -556,68 +564,97 @@ void do_allocate(scs_ctx* c, uint64_t reads) {
     c->weights.reserve(std::max<size_t>((size_t)ac * 8, 16), s);
     c->read_numbers.reserve(((size_t)ac + 1) * 4, s); c->pair_off.reserve(((size_t)ac + 1) * 4, s);
     launch_weights(s, c->fulls.view(), ac, c->dtb, c->key, (uint32_t)c->cfg.frag_size, c->weights.as<double>());
-    double* d_w = c->weights.as<double>(); uint32_t* d_rn = c->read_numbers.as<uint32_t>(); uint32_t n_alloc = ac;
-    std::vector<std::pair<uint64_t, uint32_t>> mine;                              // (global offset, count) of my segments, local order
-    if (c->sharded()) {
-        // assemble the whole job's weight vector in list order: cycle c asc, fragment pass p desc, shard asc
-        const int R = c->cfg.shard_count, NSEG = 5 * 8;
-        std::vector<uint64_t> segc((size_t)R * NSEG, 0);
-        for (auto& sg : c->full_segs) segc[(size_t)c->cfg.shard_rank * NSEG + sg.c * 8 + sg.p] = sg.count;
-        c->reduce(segc.data(), segc.size());
-        uint64_t maxn = 1, total = 0; std::vector<uint64_t> nloc(R, 0);
-        for (int r = 0; r < R; ++r) { for (int k = 0; k < NSEG; ++k) nloc[r] += segc[(size_t)r * NSEG + k]; maxn = std::max(maxn, nloc[r]); total += nloc[r]; }
-        if (nloc[c->cfg.shard_rank] != ac) throw ScsError(SCS_EINVAL, "sharded allocation: segment bookkeeping mismatch");
-        if (total > 0xFFFFFFF0ull) throw ScsError(SCS_EOVERFLOW, "more than 2^32 amplicons in the whole job");
-        n_alloc = (uint32_t)total;
-        c->d_gw.reserve(std::max<size_t>((size_t)n_alloc * 8, 16), s); c->d_grn.reserve(((size_t)n_alloc + 1) * 4, s);
-        std::vector<uint64_t> loff(R, 0); uint64_t goff = 0;
-        if (c->allgather_dev) {                                                    // weights gathered device to device (RCCL), segments placed by D2D copies
-            c->weights.reserve(maxn * 8, s, (size_t)ac * 8); d_w = c->weights.as<double>();
-            c->d_all.reserve((size_t)R * maxn * 8, s);
-            if (c->allgather_dev(c->coll_dev_user, d_w, c->d_all.p, maxn * 8)) throw ScsError(SCS_EINVAL, "sharded job: device all-gather hook failed");
-            for (int cy = 0; cy < 5; ++cy) for (int pb = 7; pb >= 0; --pb) for (int r = 0; r < R; ++r) {
-                const uint64_t n = segc[(size_t)r * NSEG + cy * 8 + pb];
-                if (!n) continue;
-                if (r == c->cfg.shard_rank) mine.push_back({goff, (uint32_t)n});
-                HIP_OK(hipMemcpyAsync(c->d_gw.as<double>() + goff, c->d_all.as<double>() + (size_t)r * maxn + loff[r], n * 8, hipMemcpyDeviceToDevice, s));
-                loff[r] += n; goff += n;
-            }
-        } else {
-            std::vector<double> w(ac), all((size_t)R * maxn), gw; std::vector<uint64_t> sizes(R, 0);
-            if (ac) HIP_OK(hipMemcpyAsync(w.data(), d_w, (size_t)ac * 8, hipMemcpyDeviceToHost, s));
-            HIP_OK(hipStreamSynchronize(s));
-            if (!c->allgatherv || c->allgatherv(c->coll_user, w.data(), (uint64_t)ac * 8, all.data(), maxn * 8, sizes.data()))
-                throw ScsError(SCS_EINVAL, "sharded job: all-gather hook missing or failed (scs_set_collectives)");
-            gw.reserve(total);
-            for (int cy = 0; cy < 5; ++cy) for (int pb = 7; pb >= 0; --pb) for (int r = 0; r < R; ++r) {
-                const uint64_t n = segc[(size_t)r * NSEG + cy * 8 + pb];
-                if (!n) continue;
-                if (r == c->cfg.shard_rank) mine.push_back({gw.size(), (uint32_t)n});
-                gw.insert(gw.end(), all.begin() + (size_t)r * maxn + loff[r], all.begin() + (size_t)r * maxn + loff[r] + n);
-                loff[r] += n;
-            }
-            if (n_alloc) HIP_OK(hipMemcpyAsync(c->d_gw.p, gw.data(), (size_t)n_alloc * 8, hipMemcpyHostToDevice, s));
-            HIP_OK(hipStreamSynchronize(s));
-        }
-        d_w = c->d_gw.as<double>(); d_rn = c->d_grn.as<uint32_t>();
+    double* d_w = c->weights.as<double>(); uint32_t* d_rn = c->read_numbers.as<uint32_t>();
+
+    // ---- the plan: where the chunks of the whole job's list lie relative to this shard's list.
+    // slot = cycle * 8 + (7 - fragment pass): this shard's segments in local order; the whole job's list takes the
+    // shards' segments slot by slot, shard by shard
+    const int R = c->cfg.shard_count, me = c->cfg.shard_rank; const bool multi = c->sharded();
+    std::vector<uint64_t> segc((size_t)R * ALLOC_SLOTS, 0);
+    for (auto& sg : c->full_segs) { if (sg.c < 0 || sg.c >= 5 || sg.p < 0 || sg.p >= 8) throw ScsError(SCS_EINVAL, "allocation: segment out of range"); segc[(size_t)me * ALLOC_SLOTS + sg.c * 8 + (7 - sg.p)] += sg.count; }
+    if (multi) c->reduce(segc.data(), segc.size());
+    std::vector<AllocGSeg> gseg; std::vector<uint32_t> loff(R, 0); uint64_t total = 0;
+    AllocPlan pl{}; pl.rank = (uint32_t)me;
+    for (int sl = 0; sl < ALLOC_SLOTS; ++sl) for (int r = 0; r < R; ++r) {
+        const uint64_t n = segc[(size_t)r * ALLOC_SLOTS + sl];
+        if (r == me) pl.my_seg[sl] = AllocMySeg{total, loff[r], (uint32_t)n, (uint32_t)(sl * R + r), 0};
+        if (!n) continue;
+        gseg.push_back(AllocGSeg{total, loff[r], (uint32_t)n, (uint32_t)r, (uint32_t)sl});
+        loff[r] += (uint32_t)n; total += n;
     }
-    const uint32_t nch = (n_alloc + 999) / 1000;
-    c->odd_before.reserve(((size_t)n_alloc + 1) * 4, s); c->a_poff.reserve(((size_t)n_alloc + 1) * 4, s);
-    c->a_part.reserve(std::max<size_t>((size_t)nch * 8, 16), s); c->a_tp.reserve(std::max<size_t>((size_t)nch * 8, 16), s);
-    c->a_probs.reserve(std::max<size_t>((size_t)nch * 8, 16), s); c->a_quota.reserve(std::max<size_t>((size_t)nch * 4, 16), s);
-    c->scan_tmp.reserve(scan_temp_bytes(n_alloc), s);
-    launch_alloc(s, d_w, n_alloc, reads, c->key, c->cfg.paired != 0, (AllocState*)((char*)c->dsums.p + 128), c->a_part.as<double>(), c->a_tp.as<double>(),
-                 c->a_probs.as<double>(), c->a_quota.as<uint32_t>(), d_rn, c->odd_before.as<uint32_t>(), c->a_poff.as<uint32_t>(), c->scan_tmp.p, c->scan_tmp.cap);
-    if (c->sharded()) {                                                           // my amplicons' read numbers + their whole-job list index
-        std::vector<uint32_t> gidx; gidx.reserve(ac); uint32_t lo = 0;
-        for (auto& m : mine) {
-            HIP_OK(hipMemcpyAsync(c->read_numbers.as<uint32_t>() + lo, d_rn + m.first, (size_t)m.second * 4, hipMemcpyDeviceToDevice, s));
-            for (uint32_t k = 0; k < m.second; ++k) gidx.push_back((uint32_t)(m.first + k));
-            lo += m.second;
+    if (loff[me] != ac) throw ScsError(SCS_EINVAL, "sharded allocation: segment bookkeeping mismatch");
+    if (total > 0xFFFFFFF0ull) throw ScsError(SCS_EOVERFLOW, "more than 2^32 amplicons in the whole job");
+    const uint32_t nch = (uint32_t)((total + ALLOC_CHUNK - 1) / ALLOC_CHUNK);
+    std::vector<AllocRange> rng; std::vector<AllocBChunk> bch; uint32_t nq = 0;
+    {
+        auto owner_of = [&](uint64_t gi) { size_t lo = 0, hi = gseg.size(); while (hi - lo > 1) { const size_t mid = (lo + hi) / 2; if (gseg[mid].go <= gi) lo = mid; else hi = mid; } return gseg[lo].owner; };
+        auto add_boundary = [&](uint32_t ch) { for (auto& b : bch) if (b.c == ch) return; bch.push_back(AllocBChunk{ch, (uint32_t)std::min<uint64_t>(ALLOC_CHUNK, total - (uint64_t)ch * ALLOC_CHUNK), owner_of((uint64_t)ch * ALLOC_CHUNK) == (uint32_t)me ? 1u : 0u}); };
+        for (size_t k = 0; k < gseg.size();) {                                    // my segments, merged while they are contiguous in the whole list
+            if (gseg[k].owner != (uint32_t)me) { ++k; continue; }
+            uint64_t go = gseg[k].go, n = gseg[k].n; const uint32_t lo = gseg[k].lo; size_t j = k + 1;
+            while (j < gseg.size() && gseg[j].owner == (uint32_t)me && gseg[j].go == go + n) { n += gseg[j].n; ++j; }
+            k = j;
+            const uint64_t cA = (go + ALLOC_CHUNK - 1) / ALLOC_CHUNK, cB = go + n == total ? nch : (go + n) / ALLOC_CHUNK;   // whole chunks inside [go, go+n)
+            if (cA < cB) { rng.push_back(AllocRange{nq, (uint32_t)cA, (uint32_t)(lo + (cA * ALLOC_CHUNK - go))}); nq += (uint32_t)(cB - cA); }
+            if (cA >= cB) { for (uint64_t ch = go / ALLOC_CHUNK; ch <= (go + n - 1) / ALLOC_CHUNK; ++ch) add_boundary((uint32_t)ch); }   // shorter than a chunk (or two partial ones)
+            else {
+                if (go % ALLOC_CHUNK) add_boundary((uint32_t)(go / ALLOC_CHUNK));
+                if (cB * ALLOC_CHUNK < go + n) add_boundary((uint32_t)cB);
+            }
         }
-        upload(c->d_gidx, gidx, s); HIP_OK(hipStreamSynchronize(s)); c->have_gidx = true;
     }
-    launch_pair_offsets(s, c->read_numbers.as<uint32_t>(), ac, c->cfg.paired != 0, c->pair_off.as<uint32_t>(), c->scan_tmp.p, c->scan_tmp.cap);
+    pl.total = total; pl.n_interior = nq; pl.n_boundary = (uint32_t)bch.size(); pl.n_ranges = (uint32_t)rng.size(); pl.n_gseg = (uint32_t)gseg.size();
+    const uint32_t nwork = pl.n_interior + pl.n_boundary;
+    {   // the plan's arrays: one small upload
+        const size_t o_b = rng.size() * sizeof(AllocRange), o_g = o_b + bch.size() * sizeof(AllocBChunk), bytes = o_g + gseg.size() * sizeof(AllocGSeg);
+        std::vector<uint8_t> blob(std::max<size_t>(bytes, 16));
+        if (!rng.empty()) memcpy(blob.data(), rng.data(), o_b);
+        if (!bch.empty()) memcpy(blob.data() + o_b, bch.data(), o_g - o_b);
+        if (!gseg.empty()) memcpy(blob.data() + o_g, gseg.data(), bytes - o_g);
+        c->a_plan.reserve(blob.size(), s);
+        HIP_OK(hipMemcpyAsync(c->a_plan.p, blob.data(), blob.size(), hipMemcpyHostToDevice, s)); HIP_OK(hipStreamSynchronize(s));
+        pl.rng = (const AllocRange*)c->a_plan.p; pl.bchunk = (const AllocBChunk*)((char*)c->a_plan.p + o_b); pl.gseg = (const AllocGSeg*)((char*)c->a_plan.p + o_g);
+    }
+    c->gmap = SegMap{};
+    if (multi) { uint32_t k = 0; for (int sl = 0; sl < ALLOC_SLOTS; ++sl) if (pl.my_seg[sl].n) { c->gmap.lo[k] = pl.my_seg[sl].lo; c->gmap.cnt[k] = pl.my_seg[sl].n; c->gmap.go[k] = pl.my_seg[sl].go; ++k; } c->gmap.n = k; }
+
+    // ---- buffers: per-chunk partials of the WHOLE job (8 B per 1000 amplicons), per-work-chunk partials of this shard
+    const size_t tree_scratch = (size_t)nch / ALLOC_CHUNK * 3 + 4096;
+    c->a_part.reserve(((size_t)nch + 2) * 8, s); c->a_tp.reserve(((size_t)nch + 2) * 8, s); c->a_probs.reserve(((size_t)nch + 2) * 8, s);
+    c->a_quota.reserve(((size_t)nch + 2) * 4, s); c->a_crn.reserve(((size_t)nwork + 2) * 4, s); c->a_scratch.reserve(tree_scratch * 8, s);
+    c->a_brow.reserve(std::max<size_t>((size_t)pl.n_boundary * ALLOC_CHUNK * 8, 16), s); c->a_bmap.reserve(std::max<size_t>((size_t)pl.n_boundary * ALLOC_CHUNK * 4, 16), s);
+    c->odd_before.reserve(((size_t)ac + 1) * 4, s); c->scan_tmp.reserve(scan_temp_bytes(ac), s);
+    AllocState* st = (AllocState*)((char*)c->dsums.p + 128);
+    double* d_part = c->a_part.as<double>(); double* d_tp = c->a_tp.as<double>();
+    unsigned long long* d_sum_rn = (unsigned long long*)(d_tp + nch);               // rides behind tp[] on the same all-reduce
+    if (R > 1) {   // first / last 1000 weights of every segment of every shard: what the boundary rows of the others need
+        const size_t per = (size_t)ALLOC_SLOTS * 2 * ALLOC_CHUNK * 8;
+        c->a_send.reserve(per, s); c->a_gath.reserve(per * R, s);
+        launch_alloc_bpack(s, d_w, pl, c->a_send.as<double>());
+        c->gather_dev(c->a_send.p, c->a_gath.p, per);
+    }
+    launch_alloc_bgather(s, d_w, pl, c->a_gath.as<double>(), c->a_brow.as<double>(), c->a_bmap.as<int>());
+    if (multi) HIP_OK(hipMemsetAsync(d_part, 0, (size_t)nch * 8, s));               // owners fill their chunks; the all-reduce sums disjoint entries (x + 0 = x)
+    launch_alloc_chunk_sum(s, d_w, c->a_brow.as<double>(), pl, d_part);
+    if (multi) c->reduce_dev(d_part, nch, 8);
+    launch_tree_sum(s, d_part, nch, c->a_scratch.as<double>(), &st->total);
+    if (multi) HIP_OK(hipMemsetAsync(d_tp, 0, ((size_t)nch + 1) * 8, s));
+    launch_alloc_norm(s, d_w, c->a_brow.as<double>(), c->a_bmap.as<int>(), pl, &st->total, reads, d_rn, d_tp, c->a_crn.as<uint32_t>(), d_sum_rn);
+    if (multi) c->reduce_dev(d_tp, (uint64_t)nch + 1, 8);
+    launch_alloc_quota(s, d_tp, nch, reads, d_sum_rn, &st->sum_quota, c->a_quota.as<uint32_t>(), c->a_probs.as<double>(), c->a_scratch.as<double>(), c->key);
+    launch_alloc_sample(s, d_w, c->a_brow.as<double>(), c->a_bmap.as<int>(), pl, d_tp, c->a_quota.as<uint32_t>(), c->key, d_rn);
+    if (c->cfg.paired) {
+        launch_alloc_odd_scan(s, d_rn, ac, c->odd_before.as<uint32_t>(), c->scan_tmp.p, c->scan_tmp.cap);
+        unsigned long long* table = nullptr;
+        if (multi) {   // odd entries of every segment of every shard, in list order
+            c->a_odd.reserve((size_t)R * ALLOC_SLOTS * 8, s); table = c->a_odd.as<unsigned long long>();
+            HIP_OK(hipMemsetAsync(table, 0, (size_t)R * ALLOC_SLOTS * 8, s));
+            launch_alloc_odd_counts(s, c->odd_before.as<uint32_t>(), pl, table);
+            c->reduce_dev(table, (uint64_t)R * ALLOC_SLOTS, 8);
+        }
+        launch_alloc_parity(s, d_rn, c->odd_before.as<uint32_t>(), ac, pl, table);
+    }
+    launch_pair_offsets(s, d_rn, ac, c->cfg.paired != 0, c->pair_off.as<uint32_t>(), c->scan_tmp.p, c->scan_tmp.cap);
     { Mail m; m.add(ac ? (const void*)(c->pair_off.as<uint32_t>() + ac) : nullptr, 4, 0); mail_post(c, m, true); }
     mail_wait(c);
     c->n_pairs_planned = (uint32_t)c->h_rb[0];
@@ -666,7 +703,7 @@ void do_yield(scs_ctx* c, const OutTarget& tg, uint64_t* n1_out, uint64_t* n2_ou
     const uint32_t L = (uint32_t)c->prof.read_length, slot = ((L + 64 + 63) / 64) * 64;
     c->pairs.reserve(std::max<size_t>(P * sizeof(PairRec), 16), s);
     HIP_OK(hipMemsetAsync(c->dsums.as<unsigned long long>() + DS_HOLES, 0, 8, s));
-    launch_plan_pairs(s, c->frags_view(), c->semis.view(), c->fulls.view(), c->fulls.n, c->read_numbers.as<uint32_t>(), c->pair_off.as<uint32_t>(), c->have_gidx ? c->d_gidx.as<uint32_t>() : nullptr, c->dtb, c->key, paired, c->pairs.as<PairRec>(),
+    launch_plan_pairs(s, c->frags_view(), c->semis.view(), c->fulls.view(), c->fulls.n, c->read_numbers.as<uint32_t>(), c->pair_off.as<uint32_t>(), c->gmap, c->dtb, c->key, paired, c->pairs.as<PairRec>(),
                       c->dsums.as<unsigned long long>() + DS_HOLES);
     const bool to_sink = !tg.device && tg.sink;
     const uint64_t batch = std::min<uint64_t>(std::max<uint64_t>(P, 1), to_sink ? (1ull << 19) : (1ull << 21));   // sink: smaller batches, pinned double buffers
@@ -802,7 +839,7 @@ void scs_destroy(scs_ctx* c) {
     for (DevBuf* b : {&c->d_tables, &c->t_qcompact, &c->t_guide, &c->t_subs1, &c->t_subs2, &c->t_qual, &c->t_ins, &c->t_del, &c->t_isize, &c->d_subs1, &c->d_subs2, &c->d_qual, &c->d_ins, &c->d_del,
                       &c->d_isize, &c->d_gcmeans, &c->genome, &c->gx_gc_bits, &c->gx_n_bits, &c->gx_gc_cnt, &c->gx_n_cnt, &c->gx_gc_pref, &c->gx_n_pref, &c->d_binom, &c->df_blob, &c->df_primers, &c->primer_cnt, &c->primer_delta,
                       &c->slots, &c->slot_tmpl, &c->valid, &c->valid_off, &c->valid_f, &c->valid_off_f, &c->scan_tmp, &c->flags, &c->weights, &c->read_numbers,
-                      &c->pair_off, &c->pairs, &c->odd_before, &c->a_part, &c->a_tp, &c->a_probs, &c->a_quota, &c->a_poff, &c->d_gidx, &c->d_gw, &c->d_grn, &c->d_tot, &c->d_stage, &c->d_all, &c->d_mail, &c->budget_f, &c->budget_s, &c->slot_off_f,
+                      &c->pair_off, &c->pairs, &c->odd_before, &c->a_part, &c->a_tp, &c->a_probs, &c->a_quota, &c->a_poff, &c->a_plan, &c->a_crn, &c->a_scratch, &c->a_brow, &c->a_bmap, &c->a_send, &c->a_gath, &c->a_odd, &c->d_hostred, &c->d_tot, &c->d_stage, &c->d_mail, &c->budget_f, &c->budget_s, &c->slot_off_f,
                       &c->slot_off_s, &c->dsums, &c->slot_b, &c->slot_q, &c->lens, &c->ev_hdr, &c->ev_dat, &c->sizes1, &c->sizes2, &c->off1, &c->off2, &c->out1, &c->out2}) b->release();
     c->semis.release(); c->fulls.release();
     for (KernelTimer* t : {&c->tm_errscan, &c->tm_errscan_f, &c->tm_reads, &c->tm_attach, &c->tm_indels, &c->tm_attach_f}) t->release();

@@ -334,16 +334,32 @@ def test_medium_genome_bit_exact(oracle_bin, models, tmp_path):
     assert fq2 == open(prefix + "_2.fq", "rb").read()
 
 
+def _cnv_haplotype(base, rng, copies):
+    """A copy-number-edited haplotype in the shape `simuvars` writes it (Genome::generateSegment, Genome.cpp:386-691: the
+    segment of a `c` line is emitted CN times in tandem, or dropped for CN 0): 5 kb segments at random places, one per
+    requested copy number."""
+    n = len(base)
+    cuts = sorted(int(x) for x in rng.choice(np.arange(1, n // 5000 - 1), size=len(copies), replace=False) * 5000)
+    out, pos = [], 0
+    for start, cn in zip(cuts, copies):
+        out.append(base[pos:start]); out.append(base[start:start + 5000] * cn); pos = start + 5000
+    out.append(base[pos:])
+    return "".join(out)
+
+
 def test_pe250_and_unequal_haplotypes(oracle_bin, models, tmp_path):
     """BASELINE config 5 shape in miniature: a synthesised 250 bp profile (4 lane chunks per read, -s 500) on a
-    'CNV-edited' input whose two haplotype records have different lengths (simuvars output after copy-number changes:
-    names keep the reference length, Genome.cpp:368; the read budget uses that name field, Malbac.cpp:413-420)."""
+    CNV-heavy input: the two haplotype records carry tandem copy numbers 0..8 (copy number "up to 8") and so
+    differ in length from each other and from the reference length in their names (simuvars keeps the reference length
+    there, Genome.cpp:368; the read budget uses that name field, Malbac.cpp:413-420)."""
     rng = np.random.default_rng(9)
-    hap1 = "".join(rng.choice(list("ACGT"), size=150000, p=[0.3, 0.2, 0.2, 0.3]))
-    hap2 = hap1[:40000] + hap1[40000:70000] * 3 + hap1[90000:]            # a 3-copy gain and a loss
+    ref = "".join(rng.choice(list("ACGT"), size=300000, p=[0.3, 0.2, 0.2, 0.3]))
+    hap1 = _cnv_haplotype(ref, rng, [0, 3, 8, 1, 5])
+    hap2 = _cnv_haplotype(ref, rng, [2, 0, 4, 7, 6, 8])
+    assert len(hap1) != len(hap2) and len(hap1) > len(ref) < len(hap2)
     fa = str(tmp_path / "cnv.fa")
     with open(fa, "w") as f:
-        for name, s in (("7_1_150000", hap1), ("7_2_150000", hap2)):
+        for name, s in (("7_1_300000", hap1), ("7_2_300000", hap2)):
             f.write(">%s\n" % name)
             f.write("\n".join(s[i:i + 100] for i in range(0, len(s), 100)) + "\n")
     prof = str(tmp_path / "pe250.profile")
@@ -353,9 +369,82 @@ def test_pe250_and_unequal_haplotypes(oracle_bin, models, tmp_path):
     g = scssim_amd.GenReads(profile=prof, input_fasta=fa, coverage=6.0, isize=500, seed=21)
     assert g.read_length == 250
     fq1, fq2 = g.run()
-    assert g.stats()["reads_requested"] == 150000 * 6 // 250
+    assert g.stats()["reads_requested"] == 300000 * 6 // 250
     assert fq1 == open(prefix + "_1.fq", "rb").read()
     assert fq2 == open(prefix + "_2.fq", "rb").read()
+
+
+def test_bench_profile_pe150_bit_exact(oracle_bin, models, tmp_path):
+    """The bench's own model (HiSeq2500 resampled to 150 bins: 8-bit qualities, the big-row variant of k_reads) against
+    the oracle on a 1 Mb genome at low coverage, plus a low-coverage 30x-shaped slice of the bench options (-s 260)."""
+    fa = str(tmp_path / "simu.fa")
+    subprocess.check_call(["python3", os.path.join(ROOT, "tools", "make_genome.py"), "--lengths", "1000000", "--seed", "1", "--simu-out", fa])
+    prof = str(tmp_path / "pe150.profile")
+    subprocess.check_call(["python3", os.path.join(ROOT, "tools", "make_profile.py"), models["Illumina_HiSeq2500"], prof, "--read-length", "150"])
+    prefix = str(tmp_path / "orc")
+    _oracle_run(oracle_bin, fa, prof, prefix, ["-c", "3", "-s", "260"], 1003, threads=min(32, os.cpu_count() or 1))
+    g = scssim_amd.GenReads(profile=prof, input_fasta=fa, coverage=3.0, isize=260, seed=1003)
+    assert g.read_length == 150
+    fq1, fq2 = g.run()
+    assert g.stats()["pairs_written"] == 10000
+    assert fq1 == open(prefix + "_1.fq", "rb").read()
+    assert fq2 == open(prefix + "_2.fq", "rb").read()
+
+
+def _md5_file(path):
+    import hashlib
+    h = hashlib.md5()
+    with open(path, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 24), b""):
+            h.update(blk)
+    return h.hexdigest()
+
+
+class _HashSink:
+    """scs_sink_fn that hashes the two FASTQ streams batch by batch (a chr20-size job at 30x writes 4 GB)."""
+
+    def __init__(self):
+        import hashlib
+        self.h = [hashlib.md5(), hashlib.md5()]
+        self.bytes = [0, 0]
+
+    def __call__(self, _u, p1, n1, p2, n2):
+        for k, (p, n) in enumerate(((p1, n1), (p2, n2))):
+            if n:
+                self.h[k].update(memoryview((ctypes.c_char * n).from_address(p)))
+                self.bytes[k] += n
+        return 0
+
+
+@pytest.mark.parametrize("cfg", ["config0_pe100_1x", "config2_novaseq_pe150_30x"])
+def test_chr20_size_bit_exact(cfg, oracle_bin, models, tmp_path):
+    """BASELINE configs[0] and configs[2] at full size: a 63 025 520-base chr20 stand-in (the reference's testData ref.fa.gz
+    is absent from its mount; synthetic i.i.d. bases with a leading N block), two haplotype records.
+      config 0: HiSeq2500 model resampled to PE100, 1x  (the reference's own plumbing case)
+      config 2: "NovaSeq" = the HiSeq X Ten model (binned qualities, as NovaSeq reports them) resampled to 150 bins, 30x
+    Both are compared with the oracle bit for bit: 25 M amplicons, every allocation chunk, 6.3 M pairs / 4 GB of FASTQ at
+    30x (hashed stream against hashed files)."""
+    fa = str(tmp_path / "chr20.fa")
+    subprocess.check_call(["python3", os.path.join(ROOT, "tools", "make_genome.py"), "--lengths", "63025520", "--seed", "20", "--n-block", "60000", "--simu-out", fa])
+    prof = str(tmp_path / "m.profile")
+    if cfg == "config0_pe100_1x":
+        subprocess.check_call(["python3", os.path.join(ROOT, "tools", "make_profile.py"), models["Illumina_HiSeq2500"], prof, "--read-length", "100"])
+        cov, seed = 1.0, 100
+    else:
+        subprocess.check_call(["python3", os.path.join(ROOT, "tools", "make_profile.py"), models["Illumina_HiSeqXTen"], prof, "--read-length", "150"])
+        cov, seed = 30.0, 220
+    prefix = str(tmp_path / "orc")
+    _oracle_run(oracle_bin, fa, prof, prefix, ["-c", "%g" % cov], seed, threads=min(64, os.cpu_count() or 1))
+    g = scssim_amd.GenReads(profile=prof, input_fasta=fa, coverage=cov, seed=seed)
+    g.create_frags(); g.amplify(); g.allocate_reads(0)
+    sink = _HashSink()
+    g.yield_reads_sink(sink)
+    st = g.stats()
+    assert 24000000 < st["full_amplicons"] < 27000000                               # SURVEY 6: 25 359 057 measured on the reference
+    assert st["reads_requested"] == int(63025520 * cov / g.read_length) and abs(2 * st["pairs_written"] - st["reads_requested"]) <= 2
+    assert sink.bytes == [os.path.getsize(prefix + "_1.fq"), os.path.getsize(prefix + "_2.fq")]
+    assert sink.h[0].hexdigest() == _md5_file(prefix + "_1.fq")
+    assert sink.h[1].hexdigest() == _md5_file(prefix + "_2.fq")
 
 
 def _write_fa(path, recs):

@@ -70,3 +70,51 @@ def test_read_statistics_agree(runs):
         return np.array([int(l[1:l.index(b"#")]) for l in open(p + "_1.fq", "rb").read().split(b"\n")[0::4] if l])
     ia, ib = idx(runs["ref"]), idx(runs["counter"])
     assert abs(len(np.unique(ia)) - len(np.unique(ib))) < 0.05 * len(np.unique(ia))
+
+
+# ---- the exhaustion regime: the one remap that changes semantics ([REMAP] 1, primer stock = snapshot per pass) ------
+# With the default -p / -r a primer type runs dry only on whole-genome inputs; a repeat-rich genome at -p 10000 -r 1e-8
+# (same growth per cycle as the defaults: pool x gamma = 6.55 primers per template-length) exhausts the 8-mers of its
+# low-complexity blocks within 1.5 Mb.  ref mode = live decrement (Malbac.cpp:91-103): a type is used exactly `stock`
+# times.  counter mode: every attachment of the pass in which the stock runs out succeeds, then the stock is clamped to 0:
+# usage <= stock + (that pass's demand for the type).  The test pins how far that goes.
+@pytest.fixture(scope="module")
+def exhausted(oracle_bin, models, tmp_path_factory):
+    d = tmp_path_factory.mktemp("exhaust")
+    rng = np.random.default_rng(11)
+    n = 1500000
+    seq = np.frombuffer(b"ACGT", np.uint8)[rng.choice(4, size=n, p=[0.3, 0.2, 0.2, 0.3])].copy()
+    motifs = [b"A", b"AC", b"AG", b"T", b"GT"]
+    for pos in range(0, n - 8000, 8000):                                 # 25 % of the genome: 2 kb runs of (A)n, (AC)n, (AG)n, (T)n, (GT)n
+        m = motifs[rng.integers(len(motifs))]
+        seq[pos + 6000:pos + 8000] = np.frombuffer((m * 2000)[:2000], np.uint8)
+    fa = str(d / "rep.fa")
+    with open(fa, "wb") as f:
+        for hap in (1, 2):
+            f.write(b">9_%d_%d\n" % (hap, n))
+            f.write(np.concatenate([seq.reshape(-1, 100), np.full((n // 100, 1), 10, np.uint8)], axis=1).tobytes())
+    out = {}
+    for mode, extra in (("ref", ["--rng", "ref", "--fixed-time", "1555555555"]), ("counter", ["--rng", "counter", "--seed", "3", "-t", "4"])):
+        pre = str(d / mode)
+        subprocess.check_call([oracle_bin, "genreads", "-i", fa, "-m", models["Illumina_HiSeq2500"], "-c", "0.5", "-p", "10000", "-r", "1e-8",
+                               "-o", pre, "--dump", pre, "-q"] + extra)
+        out[mode] = np.loadtxt(pre + ".primers.tsv", dtype=np.int64)     # primer type, attachments, stock left
+    return out
+
+
+def test_primer_exhaustion_snapshot_vs_live(exhausted):
+    stock = 10000
+    ref, ctr = exhausted["ref"], exhausted["counter"]
+    ex_r, ex_c = ref[ref[:, 2] == 0], ctr[ctr[:, 2] == 0]
+    assert len(ex_r) >= 4, "the input must drive some primer types dry"
+    assert set(ex_r[:, 0]) == set(ex_c[:, 0]), "the same primer types run dry in both modes"
+    assert (ex_r[:, 1] == stock).all(), "live decrement: an exhausted type is used exactly `stock` times"
+    assert (ex_c[:, 1] >= stock).all()
+    # the snapshot's overshoot on the exhausted types: bounded by one pass's demand; measured +19 % on average, +55 % worst
+    assert ex_c[:, 1].mean() < 1.35 * stock and ex_c[:, 1].max() < 2.0 * stock
+    # what it does to the job as a whole: attachments (= amplicons made) and their spread over the other types
+    assert abs(int(ctr[:, 1].sum()) - int(ref[:, 1].sum())) < 0.05 * ref[:, 1].sum()
+    surplus = int(ex_c[:, 1].sum()) - stock * len(ex_c)
+    assert surplus < 0.03 * ctr[:, 1].sum(), "amplicons made beyond the stock of exhausted types: < 3 % of the job"
+    rest_r = ref[ref[:, 2] > 0][:, 1].astype(np.float64); rest_c = ctr[ctr[:, 2] > 0][:, 1].astype(np.float64)
+    assert abs(rest_r.mean() - rest_c.mean()) < 0.05 * rest_r.mean()
