@@ -178,38 +178,6 @@ def committed_counters(kernel_prefix):
     return res
 
 
-class FileSink:
-    """scs_sink_fn for the sink-inclusive leg: write(2) into two tmpfs files, rewound every `recycle` bytes so that the
-    page cache stays bounded (a whole-genome job writes ~190 GB of FASTQ)."""
-
-    def __init__(self, d, recycle=4 << 30):
-        self.fd = [os.open(os.path.join(d, "bench_sink_%d.fq" % k), os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o600) for k in (1, 2)]
-        self.pos = [0, 0]
-        self.total = 0
-        self.recycle = recycle
-
-    def __call__(self, _u, p1, n1, p2, n2):
-        import ctypes as C
-        for k, (p, n) in enumerate(((p1, n1), (p2, n2))):
-            if not n:
-                continue
-            mv = memoryview((C.c_char * n).from_address(p))
-            done = 0
-            while done < n:
-                done += os.write(self.fd[k], mv[done:])
-            self.pos[k] += n
-            self.total += n
-            if self.pos[k] > self.recycle:
-                os.ftruncate(self.fd[k], 0)
-                os.lseek(self.fd[k], 0, os.SEEK_SET)
-                self.pos[k] = 0
-        return 0
-
-    def close(self):
-        for fd in self.fd:
-            os.close(fd)
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -272,9 +240,14 @@ def main():
     del bases
     torch.cuda.empty_cache()
     if world > 1:
-        from scssim_amd.dist import Collectives
-        coll = Collectives(stream=stream)
-        g.set_collectives(coll, device_hooks=True)
+        if cpu_coll:                                                 # 1-GPU rehearsal: torch.distributed (gloo) hooks
+            from scssim_amd.dist import Collectives
+            coll = Collectives(stream=stream)
+            g.set_collectives(coll, device_hooks=True)
+        else:                                                        # RCCL inside the library: rank 0's id to every rank
+            ids = [scssim_amd.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
+            g.comm_init(ids[0], rank, world)
 
     ktimes = {}
 
@@ -286,13 +259,17 @@ def main():
 
     stage = dict(frags=0.0, amplify=0.0, allocate=0.0, reads=0.0)
 
-    def step(i, sink=None):
+    def step(i, files=None):
         g.set_seed(1000 + i)
         t0 = time.perf_counter(); g.create_frags()
         t1 = time.perf_counter(); g.amplify()
         acc(g.kernel_times(), ("k_errs<semi->full>", "k_errs<frag->semi>", "k_attach<semi>", "k_attach<frag>"))
         t2 = time.perf_counter(); g.allocate_reads(0)
-        t3 = time.perf_counter(); g.yield_reads_sink(sink)
+        t3 = time.perf_counter()
+        if files:
+            g.yield_reads_files(files, 8)                            # the library's file sink (SeqWriter): D2H + parallel pwrite()
+        else:
+            g.yield_reads_sink(None)                                 # generate into HBM batch buffers and count
         t4 = time.perf_counter()
         acc(g.kernel_times(), ("k_reads", "k_indels"))
         for k, v in (("frags", t1 - t0), ("amplify", t2 - t1), ("allocate", t3 - t2), ("reads", t4 - t3)):
@@ -396,16 +373,17 @@ def main():
             shm = "/dev/shm" if os.path.isdir("/dev/shm") else td
             sd = tempfile.mkdtemp(prefix="scsbench_sink_", dir=shm)
             try:
-                sink = FileSink(sd)
+                os.environ["SCS_SINK_RECYCLE_MB"] = "4096"            # rewind each file every 4 GB: bounded page cache
                 for k in stage:
                     stage[k] = 0.0
                 t1 = time.perf_counter()
-                st = step(a.warmup + a.steps, sink)
+                st = step(a.warmup + a.steps, os.path.join(sd, "bench_sink"))
                 dt = time.perf_counter() - t1
-                sink.close()
-                out["sink_inclusive"] = {"value": st["pairs_written"] / dt, "unit": "pairs/s", "seconds": dt, "fastq_bytes": sink.total,
-                                         "reads_stage_s": stage["reads"], "sink_GBps": sink.total / max(1e-9, stage["reads"]) / 1e9,
-                                         "what": "one more step; FASTQ D2H into pinned double buffers + write(2) into two tmpfs files (rewound every 4 GB)"}
+                del os.environ["SCS_SINK_RECYCLE_MB"]
+                nbytes = sum(st["fastq_bytes"])
+                out["sink_inclusive"] = {"value": st["pairs_written"] / dt, "unit": "pairs/s", "seconds": dt, "fastq_bytes": nbytes,
+                                         "reads_stage_s": stage["reads"], "sink_GBps": nbytes / max(1e-9, stage["reads"]) / 1e9,
+                                         "what": "one more step through scs_yield_reads_files: FASTQ D2H into pinned double buffers + pwrite() by 8 threads into two tmpfs files (rewound every 4 GB)"}
             finally:
                 shutil.rmtree(sd, ignore_errors=True)
             # ---- CLI wall at chr20 size

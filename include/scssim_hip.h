@@ -139,6 +139,23 @@ typedef int (*scs_allreduce_dev_fn)(void* user, void* d_vals, uint64_t n, int el
 typedef int (*scs_allgather_dev_fn)(void* user, const void* d_send, void* d_recv, uint64_t bytes_per_rank);
 int         scs_set_collectives_device(scs_ctx* ctx, scs_allreduce_dev_fn allreduce_dev, scs_allgather_dev_fn allgather_dev, void* user);
 
+/* RCCL inside the library (one process per GPU; no caller-side hooks needed).  Rank 0 obtains an id (ncclGetUniqueId) and
+ * hands its SCS_COMM_ID_BYTES to the other ranks by any means (a pipe, a file, MPI, torch.distributed); every rank then
+ * calls scs_comm_init on its ctx (ncclCommInitRank on the ctx device).  From then on the exchanges above run as RCCL
+ * all-reduce / all-gather on the ctx stream.  RCCL is bound at run time (dlopen), so the library loads without it. */
+#define SCS_COMM_ID_BYTES 128
+int         scs_comm_unique_id(void* id_out);
+int         scs_comm_init(scs_ctx* ctx, const void* id, int rank, int nranks);
+
+/* ---- FASTQ straight to files (SeqWriter, lib/seqwriter/SeqWriter.cpp:12-64; opened by Malbac::yieldReads, Malbac.cpp:426-435)
+ * Whole job (shard_count == 1): <prefix>_1.fq / <prefix>_2.fq, or <prefix>.fq for SE -- the reference's files.
+ * Sharded job: this shard's records go to <prefix>.r<rank>_1.fq / _2.fq (.fq) and <prefix>.r<rank>.idx lists the byte offset
+ * at which each of the shard's list segments starts.  The whole job's file is the shards' segments interleaved in list
+ * order, so scs_merge_fastq_shards rebuilds it by copying byte ranges (copy_file_range, a few threads) -- it parses no
+ * record -- and the result equals the unsharded job's files byte for byte.  writer_threads <= 0: default (6). */
+int         scs_yield_reads_files(scs_ctx* ctx, const char* prefix, int writer_threads);
+int         scs_merge_fastq_shards(const char* prefix, int nranks, int paired, int keep_shards, char* errbuf, size_t errlen);
+
 /* ---- kernel-level entry points (unit parity tests; same kernels as the pipeline) ------------ */
 
 /* char* Profile::predict(char* refSeq, int isRead1)  (lib/profile/Profile.cpp:1582-1697) for a batch:

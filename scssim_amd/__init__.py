@@ -6,4 +6,5 @@ method names follow the reference's call sequence (src/scssim.cpp:46-67: loadDat
 createFrags, amplify, yieldReads).  There is no CPU fallback: importing works anywhere, creating a
 `GenReads` needs the built library and a GPU, and fails loudly otherwise.
 """
-from .api import GenReads, ScsError, Profile, fasta_probe, fasta_write_index, lib_path, load_library, build  # noqa: F401
+from .api import (GenReads, ScsError, Profile, fasta_probe, fasta_write_index, lib_path, load_library, build,  # noqa: F401
+                  merge_fastq_shards, comm_unique_id)

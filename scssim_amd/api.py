@@ -65,6 +65,10 @@ def load_library():
     L.scs_run_genreads.argtypes = [C.c_void_p, _SINK, C.c_void_p]
     L.scs_yield_reads_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                          C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.scs_yield_reads_files.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+    L.scs_merge_fastq_shards.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_size_t]
+    L.scs_comm_unique_id.argtypes = [C.c_void_p]
+    L.scs_comm_init.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
     L.scs_get_stats.argtypes = [C.c_void_p, C.POINTER(_Stats)]
     L.scs_set_collectives.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.scs_set_collectives_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -84,6 +88,29 @@ def load_library():
     L.scs_fasta_write_index.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t]
     _lib = L
     return L
+
+
+def merge_fastq_shards(prefix, nranks, paired=True, keep_shards=False):
+    """Host-only: rebuild the single-job FASTQ files from the per-rank shards + indexes that a sharded job wrote with
+    GenReads.yield_reads_files (byte-range copies in list order; no record is parsed)."""
+    L = load_library()
+    err = C.create_string_buffer(512)
+    rc = L.scs_merge_fastq_shards(os.fsencode(prefix), int(nranks), int(paired), int(keep_shards), err, 512)
+    if rc:
+        raise ScsError(rc, err.value.decode())
+
+
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id():
+    """RCCL communicator id (ncclGetUniqueId) as bytes: rank 0 makes it, every rank passes it to GenReads.comm_init."""
+    L = load_library()
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    rc = L.scs_comm_unique_id(buf)
+    if rc:
+        raise ScsError(rc, L.scs_last_error(None).decode())
+    return buf.raw
 
 
 def fasta_write_index(path):
@@ -258,6 +285,15 @@ class GenReads:
         or None: the FASTQ text is generated batch by batch into HBM buffers and counted only."""
         cb = _SINK(sink) if sink is not None else _SINK()
         self._ck(self._L.scs_yield_reads(self._ctx, cb, None))
+
+    def yield_reads_files(self, prefix, writer_threads=0):
+        """Malbac::yieldReads + SeqWriter: <prefix>_1.fq/_2.fq (.fq), or this shard's <prefix>.r<rank>_*.fq + .idx."""
+        self._ck(self._L.scs_yield_reads_files(self._ctx, os.fsencode(prefix), int(writer_threads)))
+
+    def comm_init(self, comm_id, rank, nranks):
+        """RCCL inside the library: every rank of a sharded job calls this with rank 0's comm_unique_id()."""
+        self._id = C.create_string_buffer(bytes(comm_id), COMM_ID_BYTES)
+        self._ck(self._L.scs_comm_init(self._ctx, self._id, int(rank), int(nranks)))
 
     def yield_reads_device(self, d_fq1, cap1, d_fq2, cap2):
         """FASTQ pool stays in HBM: d_fq1/d_fq2 are device pointers (e.g. torch uint8 tensors' data_ptr())."""

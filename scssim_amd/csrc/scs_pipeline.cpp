@@ -4,6 +4,7 @@
 #include "../../include/scssim_hip.h"
 #include "scs_device.h"
 #include "scs_tables.h"
+#include "scs_comm.h"
 
 #include <atomic>
 #include <algorithm>
@@ -172,7 +173,8 @@ struct scs_ctx {
     DevBuf slots, slot_tmpl, valid, valid_off, valid_f, valid_off_f, scan_tmp, flags;
     // allocation + reads
     DevBuf weights, read_numbers, pair_off, pairs, odd_before, a_part, a_tp, a_probs, a_quota, a_poff, a_plan, a_crn, a_scratch, a_brow, a_bmap, a_send, a_gath, a_odd; SegMap gmap{}; std::vector<uint32_t> h_read_numbers; uint64_t reads_requested = 0, n_pairs_planned = 0; bool allocated = false;
-    DevBuf slot_b, slot_q, lens, ev_hdr, ev_dat, sizes1, sizes2, off1, off2, out1, out2; SinkPipe* pipe = nullptr;
+    DevBuf slot_b, slot_q, lens, ev_hdr, ev_dat, sizes1, sizes2, off1, off2, out1, out2, out1b, out2b; SinkPipe* pipe = nullptr;
+    hipStream_t copy_stream = nullptr; hipEvent_t ev_made[2] = {nullptr, nullptr};   // sink mode: D2H on its own stream, behind the batch's k_reads
     // sharded single job: collectives supplied by the caller + segment bookkeeping of the local amplicon lists
     scs_allreduce_fn allreduce = nullptr; scs_allgatherv_fn allgatherv = nullptr; void* coll_user = nullptr;
     scs_allreduce_dev_fn allreduce_dev = nullptr; scs_allgather_dev_fn allgather_dev = nullptr; void* coll_dev_user = nullptr;
@@ -180,6 +182,8 @@ struct scs_ctx {
     std::vector<uint32_t> semi_block_end;                  // local semi count after each fragment pass
     struct Seg { int c, p; uint32_t count; }; std::vector<Seg> full_segs;   // local fulls list = these, in order
     DevBuf d_hostred;
+    RcclComm* rccl = nullptr;                              // scs_comm_init: RCCL communicator of this shard (the device collectives then run on it)
+    uint32_t seg_lo[ALLOC_SLOTS + 1] = {0};                // first local amplicon of each list segment slot (do_allocate); [ALLOC_SLOTS] = amplicon count
     int pending_seg_cycle = -1;
     // collectives run when the job is sharded -- or whenever hooks are installed (1-shard jobs then exercise them too)
     bool sharded() const { return cfg.shard_count > 1 || allreduce || allreduce_dev; }
@@ -615,6 +619,8 @@ void do_allocate(scs_ctx* c, uint64_t reads) {
         HIP_OK(hipMemcpyAsync(c->a_plan.p, blob.data(), blob.size(), hipMemcpyHostToDevice, s)); HIP_OK(hipStreamSynchronize(s));
         pl.rng = (const AllocRange*)c->a_plan.p; pl.bchunk = (const AllocBChunk*)((char*)c->a_plan.p + o_b); pl.gseg = (const AllocGSeg*)((char*)c->a_plan.p + o_g);
     }
+    for (int sl = 0; sl < ALLOC_SLOTS; ++sl) c->seg_lo[sl] = pl.my_seg[sl].lo;
+    c->seg_lo[ALLOC_SLOTS] = ac;
     c->gmap = SegMap{};
     if (multi) { uint32_t k = 0; for (int sl = 0; sl < ALLOC_SLOTS; ++sl) if (pl.my_seg[sl].n) { c->gmap.lo[k] = pl.my_seg[sl].lo; c->gmap.cnt[k] = pl.my_seg[sl].n; c->gmap.go[k] = pl.my_seg[sl].go; ++k; } c->gmap.n = k; }
 
@@ -691,7 +697,8 @@ struct SinkPipe {
     bool finish() { { std::lock_guard<std::mutex> lk(mu); done = true; } cv.notify_all(); if (th.joinable()) th.join(); return !failed; }
 };
 
-struct OutTarget { bool device; char* d1; char* d2; size_t cap1, cap2; scs_sink_fn sink; void* user; };
+struct OutTarget { bool device; char* d1; char* d2; size_t cap1, cap2; scs_sink_fn sink; void* user;
+                   std::vector<uint64_t>* seg_off1 = nullptr; std::vector<uint64_t>* seg_off2 = nullptr; };   // seg_off: byte offset of each list segment's first record (shard index)
 
 void do_yield(scs_ctx* c, const OutTarget& tg, uint64_t* n1_out, uint64_t* n2_out, uint64_t* pairs_out) {
     if (!c->allocated) throw ScsError(SCS_EINVAL, "scs_yield_reads: call scs_allocate_reads first");
@@ -710,6 +717,7 @@ void do_yield(scs_ctx* c, const OutTarget& tg, uint64_t* n1_out, uint64_t* n2_ou
     struct PipeGuard { SinkPipe* p; ~PipeGuard() { if (p) (void)p->finish(); } } guard{nullptr};
     if (to_sink) {
         if (!c->pipe) { c->pipe = new SinkPipe; HIP_OK(hipEventCreateWithFlags(&c->pipe->ev[0], hipEventDisableTiming)); HIP_OK(hipEventCreateWithFlags(&c->pipe->ev[1], hipEventDisableTiming)); }
+        if (!c->copy_stream) { HIP_OK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking)); for (int k = 0; k < 2; ++k) HIP_OK(hipEventCreateWithFlags(&c->ev_made[k], hipEventDisableTiming)); }
         c->pipe->start(tg.sink, tg.user, paired != 0, c->cfg.device); guard.p = c->pipe;
     }
     uint64_t bi = 0;
@@ -718,6 +726,14 @@ void do_yield(scs_ctx* c, const OutTarget& tg, uint64_t* n1_out, uint64_t* n2_ou
     c->sizes1.reserve((batch + 1) * 4, s); c->sizes2.reserve((batch + 1) * 4, s); c->off1.reserve((batch + 1) * 8, s); c->off2.reserve((batch + 1) * 8, s);
     c->scan_tmp.reserve(scan_temp_bytes(batch), s);
     uint64_t tot1 = 0, tot2 = 0, pairs_written = 0;
+    // shard index: the pair index at which each list segment starts (pair_off at the segment's first amplicon)
+    std::vector<uint64_t> bpair; size_t bnext = 0;
+    if (tg.seg_off1) {
+        std::vector<uint32_t> v(ALLOC_SLOTS + 1, 0);
+        for (int k = 0; k <= ALLOC_SLOTS; ++k) HIP_OK(hipMemcpyAsync(&v[k], c->pair_off.as<uint32_t>() + c->seg_lo[k], 4, hipMemcpyDeviceToHost, s));
+        HIP_OK(hipStreamSynchronize(s));
+        bpair.assign(v.begin(), v.end()); tg.seg_off1->assign(ALLOC_SLOTS + 1, 0); if (tg.seg_off2) tg.seg_off2->assign(ALLOC_SLOTS + 1, 0);
+    }
     for (uint64_t p0 = 0; p0 < P; p0 += batch) {
         const uint32_t np = (uint32_t)std::min<uint64_t>(batch, P - p0);
         const PairRec* pr = c->pairs.as<PairRec>() + p0;
@@ -731,13 +747,27 @@ void do_yield(scs_ctx* c, const OutTarget& tg, uint64_t* n1_out, uint64_t* n2_ou
         { Mail m; m.add(c->off1.as<uint64_t>() + np, 8, 0); m.add(paired ? (const void*)(c->off2.as<uint64_t>() + np) : nullptr, 8, 1); mail_post(c, m, true); }
         mail_wait(c);
         const uint64_t b1 = c->h_rb[0], b2 = c->h_rb[1];
+        while (bnext < bpair.size() && bpair[bnext] < p0 + np) {                     // a segment starts inside this batch: its record's byte offset
+            uint64_t o1v = 0, o2v = 0; const uint64_t idx = bpair[bnext] - p0;
+            HIP_OK(hipMemcpyAsync(&o1v, c->off1.as<uint64_t>() + idx, 8, hipMemcpyDeviceToHost, s));
+            if (paired) HIP_OK(hipMemcpyAsync(&o2v, c->off2.as<uint64_t>() + idx, 8, hipMemcpyDeviceToHost, s));
+            HIP_OK(hipStreamSynchronize(s));
+            (*tg.seg_off1)[bnext] = tot1 + o1v; if (tg.seg_off2) (*tg.seg_off2)[bnext] = tot2 + o2v;
+            ++bnext;
+        }
         char *o1, *o2;
+        SinkPipe* pp = to_sink ? c->pipe : nullptr; const int sl = (int)(bi & 1);
         if (tg.device) {
             if (tot1 + b1 > tg.cap1 || tot2 + b2 > tg.cap2) throw ScsError(SCS_EOVERFLOW, "scs_yield_reads_device: output buffer too small");
             o1 = tg.d1 + tot1; o2 = tg.d2 ? tg.d2 + tot2 : nullptr;
         } else {
-            c->out1.reserve(std::max<uint64_t>(b1, 16), s); c->out2.reserve(std::max<uint64_t>(b2, 16), s);
-            o1 = c->out1.as<char>(); o2 = c->out2.as<char>();
+            // sink mode: two device buffers, like the two pinned ones.  The slot is free once the writer has handed its last
+            // batch to the sink (which implies that batch's D2H is done), so k_reads of this batch may overwrite it while
+            // the previous batch is still crossing PCIe on the copy stream.
+            if (pp && pp->acquire(sl)) throw ScsError(SCS_EIO, "sink aborted");
+            DevBuf& d1 = (pp && sl) ? c->out1b : c->out1; DevBuf& d2 = (pp && sl) ? c->out2b : c->out2;
+            d1.reserve(std::max<uint64_t>(b1 + b1 / 16, 16), s); d2.reserve(std::max<uint64_t>(b2 + b2 / 16, 16), s);
+            o1 = d1.as<char>(); o2 = d2.as<char>();
         }
         c->tm_reads.begin(s);                                                      // the base pass writes the FASTQ text at the record offsets
         launch_reads(s, c->genome.as<uint8_t>(), c->semis.pool_view(), c->fulls.pool_view(), pr, np, 0,
@@ -746,9 +776,7 @@ void do_yield(scs_ctx* c, const OutTarget& tg, uint64_t* n1_out, uint64_t* n2_ou
         c->tm_reads.end(s);
         c->tm_reads.add_units(np);
         { const hipError_t le = take_launch_error(); if (le != hipSuccess) throw ScsError(SCS_EDEVICE, std::string("k_reads launch failed: ") + hipGetErrorString(le)); }
-        if (to_sink) {
-            SinkPipe* pp = c->pipe; const int sl = (int)(bi++ & 1);
-            if (pp->acquire(sl)) throw ScsError(SCS_EIO, "sink aborted");
+        if (pp) {
             for (int f = 0; f < 2; ++f) {                                           // per-slot pinned buffers, grown on demand (capacity kept in a 16-byte header)
                 char*& h = f == 0 ? pp->h1[sl] : pp->h2[sl]; const size_t need = f == 0 ? b1 : b2;
                 size_t have = 0; if (h) { have = ((size_t*)h)[-1]; }
@@ -759,18 +787,22 @@ void do_yield(scs_ctx* c, const OutTarget& tg, uint64_t* n1_out, uint64_t* n2_ou
                     ((size_t*)raw)[1] = nc; h = (char*)((size_t*)raw + 2);
                 }
             }
-            if (b1) HIP_OK(hipMemcpyAsync(pp->h1[sl], o1, b1, hipMemcpyDeviceToHost, s));
-            if (b2) HIP_OK(hipMemcpyAsync(pp->h2[sl], o2, b2, hipMemcpyDeviceToHost, s));
-            HIP_OK(hipEventRecord(pp->ev[sl], s));
+            HIP_OK(hipEventRecord(c->ev_made[sl], s));                              // the batch's text is complete ...
+            HIP_OK(hipStreamWaitEvent(c->copy_stream, c->ev_made[sl], 0));          // ... and crosses PCIe on the copy stream, beside the next batch's kernels
+            if (b1) HIP_OK(hipMemcpyAsync(pp->h1[sl], o1, b1, hipMemcpyDeviceToHost, c->copy_stream));
+            if (b2) HIP_OK(hipMemcpyAsync(pp->h2[sl], o2, b2, hipMemcpyDeviceToHost, c->copy_stream));
+            HIP_OK(hipEventRecord(pp->ev[sl], c->copy_stream));
             pp->submit(sl, b1, b2);
+            ++bi;
         }
         tot1 += b1; tot2 += b2;
     }
+    for (; bnext < bpair.size(); ++bnext) { (*tg.seg_off1)[bnext] = tot1; if (tg.seg_off2) (*tg.seg_off2)[bnext] = tot2; }
     // pairs produced = planned - holes; a hole arises only when > 1000 insert sizes in a row miss [readLength, ampliconLen]
     // (Amplicon.cpp:484-489): k_plan_pairs counted them on the device
     { Mail m; m.add(c->flags.p, 4, 30); m.add(c->dsums.as<unsigned long long>() + DS_HOLES, 8, 2); mail_post(c, m, true); }   // flags + hole count land before the final synchronize: no second round trip
     HIP_OK(hipStreamSynchronize(s));
-    if (to_sink) { guard.p = nullptr; if (!c->pipe->finish()) throw ScsError(SCS_EIO, "sink aborted"); }
+    if (to_sink) { HIP_OK(hipStreamSynchronize(c->copy_stream)); guard.p = nullptr; if (!c->pipe->finish()) throw ScsError(SCS_EIO, "sink aborted"); }
     mail_wait(c); flags_eval(c);
     pairs_written = P - c->h_rb[2];
     c->tm_reads.collect(); c->tm_indels.collect();
@@ -840,7 +872,9 @@ void scs_destroy(scs_ctx* c) {
                       &c->d_isize, &c->d_gcmeans, &c->genome, &c->gx_gc_bits, &c->gx_n_bits, &c->gx_gc_cnt, &c->gx_n_cnt, &c->gx_gc_pref, &c->gx_n_pref, &c->d_binom, &c->df_blob, &c->df_primers, &c->primer_cnt, &c->primer_delta,
                       &c->slots, &c->slot_tmpl, &c->valid, &c->valid_off, &c->valid_f, &c->valid_off_f, &c->scan_tmp, &c->flags, &c->weights, &c->read_numbers,
                       &c->pair_off, &c->pairs, &c->odd_before, &c->a_part, &c->a_tp, &c->a_probs, &c->a_quota, &c->a_poff, &c->a_plan, &c->a_crn, &c->a_scratch, &c->a_brow, &c->a_bmap, &c->a_send, &c->a_gath, &c->a_odd, &c->d_hostred, &c->d_tot, &c->d_stage, &c->d_mail, &c->budget_f, &c->budget_s, &c->slot_off_f,
-                      &c->slot_off_s, &c->dsums, &c->slot_b, &c->slot_q, &c->lens, &c->ev_hdr, &c->ev_dat, &c->sizes1, &c->sizes2, &c->off1, &c->off2, &c->out1, &c->out2}) b->release();
+                      &c->slot_off_s, &c->dsums, &c->slot_b, &c->slot_q, &c->lens, &c->ev_hdr, &c->ev_dat, &c->sizes1, &c->sizes2, &c->off1, &c->off2, &c->out1, &c->out2, &c->out1b, &c->out2b}) b->release();
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    for (int k = 0; k < 2; ++k) if (c->ev_made[k]) (void)hipEventDestroy(c->ev_made[k]);
     c->semis.release(); c->fulls.release();
     for (KernelTimer* t : {&c->tm_errscan, &c->tm_errscan_f, &c->tm_reads, &c->tm_attach, &c->tm_indels, &c->tm_attach_f}) t->release();
     if (c->h_rb) (void)hipHostFree(c->h_rb);
@@ -849,6 +883,7 @@ void scs_destroy(scs_ctx* c) {
         for (int k = 0; k < 2; ++k) { if (c->pipe->h1[k]) (void)hipHostFree((size_t*)c->pipe->h1[k] - 2); if (c->pipe->h2[k]) (void)hipHostFree((size_t*)c->pipe->h2[k] - 2); (void)hipEventDestroy(c->pipe->ev[k]); }
         delete c->pipe;
     }
+    if (c->rccl) rccl_destroy(c->rccl);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -896,6 +931,58 @@ int scs_yield_reads_device(scs_ctx* c, void* d1, size_t cap1, void* d2, size_t c
     return guarded(c, [&] {
         if (!d1 || (c->cfg.paired && !d2)) throw ScsError(SCS_EINVAL, "scs_yield_reads_device: null output buffer");
         double t = now_s(); OutTarget tg{true, (char*)d1, (char*)d2, cap1, cap2, nullptr, nullptr}; do_yield(c, tg, n1, n2, pairs); c->st.t_stage[5] = now_s() - t;
+    });
+}
+static int files_sink(void* user, const char* a, size_t na, const char* b, size_t nb) { return ((FastqFiles*)user)->write(a, na, b, nb) ? 0 : 1; }
+int scs_yield_reads_files(scs_ctx* c, const char* prefix, int writer_threads) {
+    return guarded(c, [&] {
+        if (!prefix || !*prefix) throw ScsError(SCS_EINVAL, "scs_yield_reads_files: no output prefix");
+        const bool pe = c->cfg.paired != 0, shard = c->cfg.shard_count > 1; const std::string pre = prefix;
+        const std::string f1 = shard ? shard_path(pre, c->cfg.shard_rank, 0, pe) : pre + (pe ? "_1.fq" : ".fq");
+        const std::string f2 = pe ? (shard ? shard_path(pre, c->cfg.shard_rank, 1, pe) : pre + "_2.fq") : std::string();
+        FastqFiles files; std::string err;
+        if (!files.open(f1, f2, writer_threads > 0 ? writer_threads : 6, err)) throw ScsError(SCS_EIO, err);
+        if (const char* rc = getenv("SCS_SINK_RECYCLE_MB")) files.set_recycle((uint64_t)atoll(rc) << 20);   // measurement only: see FastqFiles::set_recycle
+        std::vector<uint64_t> so1, so2;
+        double t = now_s(); OutTarget tg{false, nullptr, nullptr, 0, 0, files_sink, &files}; if (shard) { tg.seg_off1 = &so1; tg.seg_off2 = &so2; }
+        do_yield(c, tg, nullptr, nullptr, nullptr);
+        if (!files.close()) throw ScsError(SCS_EIO, "writing " + f1 + " failed");
+        if (shard && !write_shard_index(shard_index_path(pre, c->cfg.shard_rank), so1, so2, err)) throw ScsError(SCS_EIO, err);
+        c->st.t_stage[5] = now_s() - t;
+    });
+}
+int scs_merge_fastq_shards(const char* prefix, int nranks, int paired, int keep_shards, char* errbuf, size_t errlen) {
+    if (!prefix) return SCS_EINVAL;
+    std::string err;
+    if (merge_shards(prefix, nranks, paired != 0, keep_shards != 0, err)) return SCS_OK;
+    if (errbuf && errlen) { strncpy(errbuf, err.c_str(), errlen - 1); errbuf[errlen - 1] = 0; }
+    return SCS_EIO;
+}
+int scs_comm_unique_id(void* id_out) {
+    std::string err;
+    if (!id_out) return SCS_EINVAL;
+    if (rccl_unique_id(id_out, err)) { g_create_error = err; return SCS_EDEVICE; }
+    return SCS_OK;
+}
+static int rccl_allreduce_hook(void* user, void* d_vals, uint64_t n, int elem_bytes) {
+    scs_ctx* c = (scs_ctx*)user; std::string err;
+    if (rccl_allreduce_sum(c->rccl, d_vals, n, elem_bytes, c->stream, err)) { c->err = err; return 1; }
+    return 0;
+}
+static int rccl_allgather_hook(void* user, const void* d_send, void* d_recv, uint64_t bytes) {
+    scs_ctx* c = (scs_ctx*)user; std::string err;
+    if (rccl_allgather(c->rccl, d_send, d_recv, bytes, c->stream, err)) { c->err = err; return 1; }
+    return 0;
+}
+int scs_comm_init(scs_ctx* c, const void* id, int rank, int nranks) {
+    return guarded(c, [&] {
+        if (!id || nranks < 1 || rank < 0 || rank >= nranks) throw ScsError(SCS_EINVAL, "scs_comm_init: bad arguments");
+        if (rank != c->cfg.shard_rank || nranks != c->cfg.shard_count) throw ScsError(SCS_EINVAL, "scs_comm_init: rank / size differ from the ctx's shard_rank / shard_count");
+        if (c->rccl) { rccl_destroy(c->rccl); c->rccl = nullptr; }
+        std::string err;
+        c->rccl = rccl_init(id, rank, nranks, err);
+        if (!c->rccl) throw ScsError(SCS_EDEVICE, err);
+        c->allreduce_dev = rccl_allreduce_hook; c->allgather_dev = rccl_allgather_hook; c->coll_dev_user = c;
     });
 }
 int scs_run_genreads(scs_ctx* c, scs_sink_fn sink, void* user) {

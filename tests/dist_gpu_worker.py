@@ -19,14 +19,9 @@ def main():
     g = scssim_amd.GenReads(profile=profile, input_fasta=fasta, coverage=float(coverage), layout=layout, seed=int(seed), device=0,
                             stream=stream.cuda_stream, shard_rank=dist.get_rank(), shard_count=dist.get_world_size())
     g.set_collectives(coll, device_hooks=(hooks == "device"))
-    fq1, fq2 = g.run()
+    g.create_frags(); g.amplify(); g.allocate_reads(0)
+    g.yield_reads_files(prefix)                     # this rank's shard + index: <prefix>.r<rank>_1.fq / _2.fq / .idx
     st = g.stats()
-    pre = "%s.r%d" % (prefix, dist.get_rank())
-    if layout == "PE":
-        open(pre + "_1.fq", "wb").write(fq1)
-        open(pre + "_2.fq", "wb").write(fq2)
-    else:
-        open(pre + ".fq", "wb").write(fq1)
     print("rank %d: %d fragments, %d fulls, %d pairs, collectives %s" % (dist.get_rank(), st["fragments"], st["full_amplicons"], st["pairs_written"], coll.calls))
     dist.barrier()
     dist.destroy_process_group()

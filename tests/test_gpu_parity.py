@@ -221,11 +221,11 @@ def test_full_size_properties(models, tmp_path):
                                                                (2, "g1_hiseq2500_pe", "Illumina_HiSeq2500", "3", "PE", "device"),
                                                                (3, "g2_xten_pe_nblock", "Illumina_HiSeqXTen", "2", "PE", "device")])
 def test_sharded_gpu_job_equals_whole_job(world, case, model, cov, layout, hooks, oracle_bin, models, golden_inputs, tmp_path):
-    """ONE job sharded by fragment lineage over `world` processes (sharing this box's single GPU, collectives over gloo)
-    must merge to exactly the unsharded job's FASTQ -- which in turn is the oracle's."""
+    """ONE job sharded by fragment lineage over `world` processes (sharing this box's single GPU, collectives over gloo):
+    every rank writes its FASTQ shard + index through the library's file sink, the native range merge
+    (scs_merge_fastq_shards) rebuilds the single-job files, and they must equal the unsharded job's -- the oracle's."""
     import socket
     import sys
-    from scssim_amd.dist import merge_fastq
     seed = "777"
     whole = str(tmp_path / "whole")
     _oracle_run(oracle_bin, golden_inputs[case], models[model], whole, ["-c", cov, "-l", layout], seed)
@@ -237,10 +237,12 @@ def test_sharded_gpu_job_equals_whole_job(world, case, model, cov, layout, hooks
                                        str(tmp_path / "shard"), cov, layout, seed, hooks], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = [p.communicate(timeout=600)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    for r in range(world):
+        assert os.path.getsize(str(tmp_path / "shard") + ".r%d_1.fq" % r) > 0 and os.path.exists(str(tmp_path / "shard") + ".r%d.idx" % r)
+    scssim_amd.merge_fastq_shards(str(tmp_path / "shard"), world, paired=True)
     for suffix in ("_1.fq", "_2.fq"):
-        pools = [open(str(tmp_path / "shard") + ".r%d%s" % (r, suffix), "rb").read() for r in range(world)]
-        assert all(len(p) > 0 for p in pools)
-        assert merge_fastq(pools) == open(whole + suffix, "rb").read(), "sharded GPU job differs from the whole job (%s)" % suffix
+        assert open(str(tmp_path / "shard") + suffix, "rb").read() == open(whole + suffix, "rb").read(), "sharded GPU job differs from the whole job (%s)" % suffix
+    assert not os.path.exists(str(tmp_path / "shard") + ".r0_1.fq"), "shards are removed after the merge"
 
 
 def test_device_hooks_over_rccl_single_rank(models, golden_inputs, oracle_bin, tmp_path):
@@ -273,6 +275,26 @@ open(%r, "wb").write(a[0])
     prefix = str(tmp_path / "orc")
     _oracle_run(oracle_bin, golden_inputs["g1_hiseq2500_pe"], models["Illumina_HiSeq2500"], prefix, ["-c", "2"], 5)
     assert open(str(tmp_path / "nccl_1.fq"), "rb").read() == open(prefix + "_1.fq", "rb").read()
+
+
+def test_rccl_inside_the_library_single_rank_and_cli(models, golden_inputs, oracle_bin, tmp_path):
+    """RCCL bound inside the library (scs_comm_unique_id / scs_comm_init, no Python hooks): a 1-rank communicator runs
+    every exchange of the sharded path through ncclAllReduce / ncclAllGather on the ctx stream; the job must equal the
+    plain one.  And the CLI's file sink (`scssim genreads`, reference file names) writes the same bytes."""
+    prefix = str(tmp_path / "orc")
+    _oracle_run(oracle_bin, golden_inputs["g1_hiseq2500_pe"], models["Illumina_HiSeq2500"], prefix, ["-c", "2"], 5)
+    g = scssim_amd.GenReads(profile=models["Illumina_HiSeq2500"], input_fasta=golden_inputs["g1_hiseq2500_pe"], coverage=2.0, seed=5)
+    g.comm_init(scssim_amd.comm_unique_id(), 0, 1)
+    g.create_frags(); g.amplify(); g.allocate_reads(0)
+    g.yield_reads_files(str(tmp_path / "lib"))
+    for suffix in ("_1.fq", "_2.fq"):
+        assert open(str(tmp_path / "lib") + suffix, "rb").read() == open(prefix + suffix, "rb").read()
+    exe = os.path.join(ROOT, "scssim_amd", "bin", "scssim")
+    r = subprocess.run([exe, "genreads", "-i", golden_inputs["g1_hiseq2500_pe"], "-m", models["Illumina_HiSeq2500"], "-c", "2", "-o", str(tmp_path / "cli"),
+                        "--seed", "5", "--gpus", "1"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    for suffix in ("_1.fq", "_2.fq"):
+        assert open(str(tmp_path / "cli") + suffix, "rb").read() == open(prefix + suffix, "rb").read()
 
 
 def test_bench_two_rank_control_flow(tmp_path):

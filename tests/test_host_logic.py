@@ -202,3 +202,35 @@ def test_fasta_index_matches_the_reference(case, golden_inputs, tmp_path):
     open(str(fa) + ".fai", "w").write("kept\n")
     scssim_amd.fasta_write_index(str(fa))
     assert open(str(fa) + ".fai").read() == "kept\n"
+
+
+def test_shard_merge_copies_byte_ranges_in_list_order(tmp_path):
+    """scs_merge_fastq_shards (host only): the whole job's file = the shards' list segments slot by slot, shard by shard.
+    Three shards with ragged / empty segments; PE and SE; shards removed unless asked to keep them."""
+    import random
+    import scssim_amd
+    rnd = random.Random(4)
+    for paired in (True, False):
+        pre = str(tmp_path / ("m_pe" if paired else "m_se"))
+        world, nslot = 3, 40
+        seg = [[[bytes(rnd.getrandbits(8) for _ in range(rnd.choice([0, 0, 1, 17, 4096, 70000]))) for _ in range(nslot)] for _ in range(world)] for _ in range(2)]
+        for r in range(world):
+            off = [[0], [0]]
+            for k in range(2 if paired else 1):
+                name = pre + ".r%d%s" % (r, ("_1.fq", "_2.fq")[k] if paired else ".fq")
+                with open(name, "wb") as f:
+                    for sl in range(nslot):
+                        f.write(seg[k][r][sl]); off[k].append(off[k][-1] + len(seg[k][r][sl]))
+            if not paired:
+                off[1] = [0] * (nslot + 1)
+            with open(pre + ".r%d.idx" % r, "w") as f:
+                f.write("# index\n")
+                for i in range(nslot + 1):
+                    f.write("%d\t%d\t%d\n" % (i, off[0][i], off[1][i]))
+        scssim_amd.merge_fastq_shards(pre, world, paired=paired, keep_shards=not paired)
+        for k in range(2 if paired else 1):
+            want = b"".join(seg[k][r][sl] for sl in range(nslot) for r in range(world))
+            assert open(pre + (("_1.fq", "_2.fq")[k] if paired else ".fq"), "rb").read() == want
+        assert os.path.exists(pre + ".r0.idx") == (not paired)
+    with pytest.raises(scssim_amd.ScsError):
+        scssim_amd.merge_fastq_shards(str(tmp_path / "absent"), 2)
