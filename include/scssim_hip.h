@@ -152,7 +152,8 @@ int         scs_comm_init(scs_ctx* ctx, const void* id, int rank, int nranks);
  * Sharded job: this shard's records go to <prefix>.r<rank>_1.fq / _2.fq (.fq) and <prefix>.r<rank>.idx lists the byte offset
  * at which each of the shard's list segments starts.  The whole job's file is the shards' segments interleaved in list
  * order, so scs_merge_fastq_shards rebuilds it by copying byte ranges (copy_file_range, a few threads) -- it parses no
- * record -- and the result equals the unsharded job's files byte for byte.  writer_threads <= 0: default (6). */
+ * record -- and the result equals the unsharded job's files byte for byte.  writer_threads: slices per file and batch written in parallel;
+ * <= 0 = 1, the fastest on tmpfs (writes into one file serialise on its inode lock; the two files always go in parallel). */
 int         scs_yield_reads_files(scs_ctx* ctx, const char* prefix, int writer_threads);
 int         scs_merge_fastq_shards(const char* prefix, int nranks, int paired, int keep_shards, char* errbuf, size_t errlen);
 

@@ -18,7 +18,7 @@ int  rccl_allgather(RcclComm* c, const void* d_send, void* d_recv, uint64_t byte
 void rccl_destroy(RcclComm* c);
 
 // ---- FASTQ files: SeqWriter (lib/seqwriter/SeqWriter.cpp:12-64) without its mutex: a batch is cut into slices that a few
-// threads pwrite() at their final offsets in parallel (page-cache copies are the cost of a tmpfs / buffered write).
+// one pwrite() per file and batch, the two files in parallel (page-cache copies are the cost of a tmpfs / buffered write).
 class FastqFiles {
 public:
     FastqFiles() = default;
@@ -31,7 +31,7 @@ public:
     // ~190 GB of FASTQ can be timed through D2H + write() into tmpfs without keeping them in the page cache
     void set_recycle(uint64_t bytes) { recycle_ = bytes; }
 private:
-    int fd_[2] = {-1, -1}; uint64_t pos_[2] = {0, 0}, total_[2] = {0, 0}, recycle_ = 0; int threads_ = 4; bool failed_ = false;
+    int fd_[2] = {-1, -1}; uint64_t pos_[2] = {0, 0}, total_[2] = {0, 0}, recycle_ = 0; int threads_ = 1; bool failed_ = false;
 };
 
 // Shard index: for every list segment slot (ALLOC_SLOTS of them) the byte offset in each of the shard's two files where

@@ -941,7 +941,7 @@ int scs_yield_reads_files(scs_ctx* c, const char* prefix, int writer_threads) {
         const std::string f1 = shard ? shard_path(pre, c->cfg.shard_rank, 0, pe) : pre + (pe ? "_1.fq" : ".fq");
         const std::string f2 = pe ? (shard ? shard_path(pre, c->cfg.shard_rank, 1, pe) : pre + "_2.fq") : std::string();
         FastqFiles files; std::string err;
-        if (!files.open(f1, f2, writer_threads > 0 ? writer_threads : 6, err)) throw ScsError(SCS_EIO, err);
+        if (!files.open(f1, f2, writer_threads > 0 ? writer_threads : 1, err)) throw ScsError(SCS_EIO, err);
         if (const char* rc = getenv("SCS_SINK_RECYCLE_MB")) files.set_recycle((uint64_t)atoll(rc) << 20);   // measurement only: see FastqFiles::set_recycle
         std::vector<uint64_t> so1, so2;
         double t = now_s(); OutTarget tg{false, nullptr, nullptr, 0, 0, files_sink, &files}; if (shard) { tg.seg_off1 = &so1; tg.seg_off2 = &so2; }
