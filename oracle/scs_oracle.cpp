@@ -1142,6 +1142,200 @@ int genreads(const scso_params& q) {
     return 0;
 }
 
+// ===========================================================================
+// simuvars: Genome::loadAbers (lib/genome/Genome.cpp:35-165), SNPOnChr::readSNPs (lib/snp/snp.cpp:147-203),
+// Genome::saveSequence (329-384), Genome::generateSegment (386-691), restated with the reference's own std::string
+// operations.  The reference's simuvars branch never calls srand (src/scssim.cpp:33-38), so its glibc rand() runs from
+// the default seed: the output is a pure function of the input files, and this restatement draws from rand() the same way.
+// ===========================================================================
+namespace simuvars {
+struct Cnv { long spos, epos; float cn, mcn; };
+struct Snv { long pos; char alt; bool het; };
+struct Ins { long pos; std::string seq; bool het; };
+struct Del { long pos; int len; bool het; };
+struct Snp { long pos; char nuc; };
+struct RawRec { std::string name, seq; };
+
+std::string abbr_chr(std::string c) {                                              // MyDefine.cpp:310-323 / snp.cpp aberOfChr
+    size_t i = c.find("chrom");
+    if (i == std::string::npos) { i = c.find("chr"); if (i != std::string::npos) c = c.substr(i + 3); }
+    else c = c.substr(i + 5);
+    return c;
+}
+char snp_complement(char n) {                                                      // snp.cpp SNP::getComplement
+    switch (n) { case 'A': return 'T'; case 'T': return 'A'; case 'C': return 'G'; case 'G': return 'C';
+                 case 'a': return 't'; case 't': return 'a'; case 'c': return 'g'; case 'g': return 'c'; default: return 'N'; }
+}
+long rand_int(long start, long end) { return (long)(start + (end - start) * (rand() / (RAND_MAX + 1.0))); }   // MyDefine.cpp:290-292
+
+std::vector<RawRec> load_raw_fasta(const std::string& path) {
+    std::ifstream ifs(path);
+    if (!ifs.is_open()) fail("could not open " + path);
+    std::vector<RawRec> recs; std::string line;
+    while (std::getline(ifs, line)) {
+        if (!line.empty() && line.back() == '\r') line.pop_back();
+        if (line.empty() || line[0] == ';') continue;
+        if (line[0] == '>') { std::string nm = line.substr(1); size_t e = nm.find_first_of(" \t"); if (e != std::string::npos) nm = nm.substr(0, e); recs.push_back(RawRec{abbr_chr(nm), ""}); }
+        else { if (recs.empty()) fail("FASTA sequence before header in " + path); recs.back().seq += line; }
+    }
+    if (recs.empty()) fail("ERROR: reference sequence cannot be empty!");
+    return recs;
+}
+
+struct Vars {
+    std::map<std::string, std::vector<Cnv>> cnvs; std::map<std::string, std::vector<Snv>> snvs;
+    std::map<std::string, std::vector<Ins>> inss; std::map<std::string, std::vector<Del>> dels; std::map<std::string, std::vector<Snp>> snps;
+};
+void load_vars(const std::string& path, Vars& V) {                                 // Genome.cpp:35-165
+    if (path.empty()) return;
+    std::ifstream ifs(path);
+    if (!ifs.is_open()) fail("can not open file " + path);
+    std::string line; int ln = 0;
+    auto bad = [&](const std::string& m) { fail("ERROR: " + m + " at line " + std::to_string(ln) + " in file " + path); };
+    while (std::getline(ifs, line)) {
+        ++ln;
+        if (line.empty() || line[0] == '#') continue;
+        auto f = split(line, '\t');
+        const std::string t = f[0];
+        auto typ = [&](const std::string& c) { if (c != "homo" && c != "het") bad("unrecognized variant type"); return c == "het"; };
+        if (t == "c") {
+            if (f.size() != 6) bad("wrong number of fields");
+            float cn = atof(f[4].c_str()), mcn = atof(f[5].c_str());
+            if (cn < mcn) bad("total copy number should be not lower than major copy number");
+            if (cn - mcn > mcn) mcn = cn - mcn;
+            V.cnvs[abbr_chr(f[1])].push_back(Cnv{atol(f[2].c_str()), atol(f[3].c_str()), cn, mcn});
+        } else if (t == "s") {
+            if (f.size() != 6) bad("wrong number of fields");
+            if (f[3].at(0) == f[4].at(0)) bad("the mutated allele should be not same as the reference allele");
+            V.snvs[abbr_chr(f[1])].push_back(Snv{atol(f[2].c_str()), f[4].at(0), typ(f[5])});
+        } else if (t == "i") {
+            if (f.size() != 5) bad("wrong number of fields");
+            V.inss[abbr_chr(f[1])].push_back(Ins{atol(f[2].c_str()), f[3], typ(f[4])});
+        } else if (t == "d") {
+            if (f.size() != 5) bad("wrong number of fields");
+            V.dels[abbr_chr(f[1])].push_back(Del{atol(f[2].c_str()), atoi(f[3].c_str()), typ(f[4])});
+        } else bad("unrecognized aberraton type");
+    }
+}
+void load_snps(const std::string& path, Vars& V) {                                 // snp.cpp:147-203 + SNP::SNP (12-36)
+    if (path.empty()) return;
+    FILE* f = fopen(path.c_str(), "r");
+    if (!f) fail("can not open SNP file " + path);
+    char buf[1000];
+    while (fgets(buf, 1000, f)) {
+        std::string line(buf);
+        while (!line.empty() && (line.back() == '\n' || line.back() == '\r')) line.pop_back();
+        auto e = split(line, '\t');
+        if (e.size() != 6) continue;                                               // the reference warns and skips
+        const std::string observed = e[3]; const char strand = e[4].empty() ? '+' : e[4][0]; char ref = e[5].empty() ? 'N' : e[5][0];
+        auto ob = split(observed, '/');
+        if (strand == '-') ref = snp_complement(ref);
+        char nuc = (ob[0].at(0) == ref) ? ob[1].at(0) : ob[0].at(0);
+        if (strand == '-') nuc = snp_complement(nuc);
+        V.snps[abbr_chr(e[1])].push_back(Snp{atol(e[2].c_str()), nuc});
+    }
+    fclose(f);
+}
+
+// Genome::generateSegment (Genome.cpp:386-691), ploidy = 2
+void generate_segment(std::vector<std::string>& seqs, const std::string& chrseq, const Vars& V, const std::string& chr, long s, long e, int CN, int mCN) {
+    if (CN == 0) return;
+    const int ploidy = 2;
+    std::string refSeq = chrseq.substr((size_t)(s - 1), (size_t)(e - s + 1));
+    for (auto& c : refSeq) c = (char)toupper(c);
+    const size_t refSize = refSeq.size();
+    std::vector<int> mIndx, seqReps; int i, j, k, n;
+    auto has = [](const std::vector<int>& v, int x) { return std::find(v.begin(), v.end(), x) != v.end(); };
+    if (CN < ploidy) {
+        for (i = 0; i < CN; i++) for (;;) { j = (int)rand_int(0, ploidy); if (!has(seqReps, j)) { seqReps.push_back(j); break; } }
+        for (i = 0; i < mCN; i++) mIndx.push_back(seqReps[i]);
+    } else {
+        for (i = 0; i < ploidy; i++) seqReps.push_back(1);
+        n = CN - ploidy; k = (int)rand_int(0, ploidy);
+        for (i = n; i >= 0; i--) {
+            if (seqReps[k] + i == mCN) { seqReps[k] += i; mIndx.push_back(k); break; }
+            else if (seqReps[k] + i == CN - mCN) { seqReps[k] += i; for (j = 0; j < ploidy; j++) if (j != k) mIndx.push_back(j); break; }
+        }
+        if (i >= 0) { n -= i; while (n > 0) { j = (int)rand_int(0, ploidy); if (j != k) { seqReps[j]++; n--; } } }
+        else { while (n > 0) { j = (int)rand_int(0, ploidy); seqReps[j]++; n--; } for (i = 0; i < ploidy; i++) mIndx.push_back(i); }
+    }
+    std::vector<std::string> seg;
+    if (CN < ploidy) for (i = 0; i < ploidy; i++) seg.push_back(has(seqReps, i) ? refSeq : std::string());
+    else for (i = 0; i < ploidy; i++) { std::string t; for (j = 0; j < seqReps[i]; j++) t += refSeq; seg.push_back(t); }
+    auto get = [](auto& m, const std::string& c) -> decltype(m.begin()->second)& { static decltype(m.begin()->second) empty; auto it = m.find(c); return it == m.end() ? empty : it->second; };
+    auto skip = [&](int kk, int hap) { const bool in = has(mIndx, hap); return (kk == 0 && !in) || (kk == 1 && in); };
+    k = 0;                                                                         // SNPs: alternately on the major / the other haplotypes
+    for (const Snp& sp : get(const_cast<Vars&>(V).snps, chr)) if (sp.pos >= s && sp.pos <= e) {
+        const size_t sindx = (size_t)(sp.pos - s);
+        for (j = 0; j < ploidy; j++) { if (skip(k, j)) continue; std::string& q = seg[j]; for (size_t t = 0; t < q.size() / refSize; t++) q[sindx + t * refSize] = sp.nuc; }
+        k = (k + 1) % 2;
+    }
+    k = 0;
+    for (const Snv& sv : get(const_cast<Vars&>(V).snvs, chr)) if (sv.pos >= s && sv.pos <= e) {
+        const size_t sindx = (size_t)(sv.pos - s);
+        for (j = 0; j < ploidy; j++) { if (sv.het && skip(k, j)) continue; std::string& q = seg[j]; for (size_t t = 0; t < q.size() / refSize; t++) q[sindx + t * refSize] = sv.alt; }
+        if (sv.het) k = (k + 1) % 2;
+    }
+    std::map<int, std::map<int, int>> insPer, delPer; std::vector<int> insLens(ploidy, 0), delLens(ploidy, 0);
+    k = 0;
+    for (const Ins& in : get(const_cast<Vars&>(V).inss, chr)) if (in.pos >= s && in.pos <= e) {
+        const int sindx = (int)(in.pos - s);
+        for (j = 0; j < ploidy; j++) {
+            if (in.het && skip(k, j)) continue;
+            int offset = 0; auto& done = insPer[j];
+            for (auto& m : done) if (m.first <= sindx) offset += m.second;
+            std::string& q = seg[j]; n = (int)(q.size() / (refSize + insLens[j])); const int len = (int)in.seq.size();
+            for (int t = 0; t < n; t++) q.insert((size_t)(sindx + offset) + (size_t)t * (refSize + insLens[j] + len), in.seq);
+            insLens[j] += len; done.insert(std::make_pair(sindx, len));
+        }
+        if (in.het) k = (k + 1) % 2;
+    }
+    for (const Del& dl : get(const_cast<Vars&>(V).dels, chr)) if (dl.pos >= s && dl.pos <= e) {   // k carries over from the insertions (Genome.cpp:613,658)
+        const int sindx = (int)(dl.pos - s);
+        for (j = 0; j < ploidy; j++) {
+            if (dl.het && skip(k, j)) continue;
+            int offset = 0;
+            for (auto& m : insPer[j]) if (m.first <= sindx) offset += m.second;
+            auto& done = delPer[j];
+            for (auto& m : done) if (m.first <= sindx) offset -= m.second;
+            if (sindx + offset < 0) continue;
+            std::string& q = seg[j]; n = (int)(q.size() / (refSize + insLens[j] - delLens[j]));
+            for (int t = 0; t < n; t++) q.erase((size_t)(sindx + offset) + (size_t)t * (refSize + insLens[j] - delLens[j] - dl.len), (size_t)dl.len);
+            delLens[j] += dl.len; done.insert(std::make_pair(sindx, dl.len));
+        }
+        if (dl.het) k = (k + 1) % 2;
+    }
+    for (i = 0; i < ploidy; i++) { for (auto& c : seg[i]) c = (char)toupper(c); seqs[i] += seg[i]; }
+}
+
+int run(const std::string& ref, const std::string& snp, const std::string& var, const std::string& out) {   // Genome::saveSequence (329-384)
+    Vars V; load_vars(var, V); load_snps(snp, V);
+    std::vector<RawRec> recs = load_raw_fasta(ref);
+    FILE* o = fopen(out.c_str(), "w");
+    if (!o) fail("can not open file " + out);
+    const int ploidy = 2, mCN = 1;
+    for (auto& r : recs) {
+        const long L = (long)r.seq.size(); long segStart = 1;
+        std::vector<std::string> hs(ploidy);
+        auto it = V.cnvs.find(r.name);
+        if (it != V.cnvs.end()) for (Cnv cv : it->second) {
+            if (segStart > L) break;
+            cv.epos = std::min(cv.epos, L);
+            if (segStart < cv.spos) generate_segment(hs, r.seq, V, r.name, segStart, cv.spos - 1, ploidy, mCN);
+            generate_segment(hs, r.seq, V, r.name, cv.spos, cv.epos, (int)cv.cn, (int)cv.mcn);
+            segStart = cv.epos + 1;
+        }
+        if (segStart <= L) generate_segment(hs, r.seq, V, r.name, segStart, L, ploidy, mCN);
+        for (int j = 0; j < ploidy; j++) {
+            fprintf(o, ">%s_%d_%ld\n", r.name.c_str(), j + 1, L);
+            for (size_t x = 0; x < hs[j].size(); x += 100) { fwrite(hs[j].data() + x, 1, std::min<size_t>(100, hs[j].size() - x), o); fputc('\n', o); }
+        }
+    }
+    fclose(o);
+    return 0;
+}
+}  // namespace simuvars
+
 }  // namespace
 
 extern "C" {
@@ -1201,7 +1395,14 @@ int scso_predict_counter(void* h, const uint8_t* window, int n, int is_read1, ui
 //   --rng ref|counter   --seed N   --fixed-time T   --dump PREFIX   -q (quiet)
 #include <getopt.h>
 int main(int argc, char** argv) {
-    if (argc < 2 || strcmp(argv[1], "genreads") != 0) { fprintf(stderr, "usage: scs_oracle genreads -i simu.fa -m model.profile -o prefix [options]\n"); return 1; }
+    if (argc >= 2 && strcmp(argv[1], "simuvars") == 0) {                          // the reference's simuvars CLI (src/scssim.cpp:108-170)
+        std::string ref, snp, var, out; static option so[] = {{"ref", 1, 0, 'r'}, {"snp", 1, 0, 's'}, {"var", 1, 0, 'v'}, {"output", 1, 0, 'o'}, {0, 0, 0, 0}};
+        int c; argc--; argv++;
+        while ((c = getopt_long(argc, argv, "r:s:v:o:", so, nullptr)) != -1) switch (c) { case 'r': ref = optarg; break; case 's': snp = optarg; break; case 'v': var = optarg; break; case 'o': out = optarg; break; default: return 1; }
+        if (ref.empty() || out.empty()) { fprintf(stderr, "Error: -r and -o are required\n"); return 1; }
+        try { return simuvars::run(ref, snp, var, out); } catch (const std::exception& e) { fprintf(stderr, "%s\n", e.what()); return 1; }
+    }
+    if (argc < 2 || strcmp(argv[1], "genreads") != 0) { fprintf(stderr, "usage: scs_oracle genreads -i simu.fa -m model.profile -o prefix [options] | scs_oracle simuvars -r ref.fa [-s snp.txt] [-v vars.txt] -o simu.fa\n"); return 1; }
     scso_params p; scso_default_params(&p);
     static option lo[] = {{"input", 1, 0, 'i'}, {"primers", 1, 0, 'p'}, {"gamma", 1, 0, 'r'}, {"model", 1, 0, 'm'}, {"layout", 1, 0, 'l'},
                           {"coverage", 1, 0, 'c'}, {"isize", 1, 0, 's'}, {"threads", 1, 0, 't'}, {"output", 1, 0, 'o'},

@@ -1,0 +1,34 @@
+"""simuvars: the oracle's restatement of Genome::loadAbers / saveSequence / generateSegment against the
+haplotype FASTA written by the compiled reference (tests/golden/simuvars, made by make_simuvars_golden.py)."""
+import gzip
+import hashlib
+import json
+import os
+import subprocess
+
+import pytest
+
+from conftest import GOLDEN
+
+SV = os.path.join(GOLDEN, "simuvars")
+MANIFEST = json.load(open(os.path.join(SV, "manifest.json")))
+
+
+@pytest.fixture(scope="module")
+def sv_inputs(tmp_path_factory):
+    d = tmp_path_factory.mktemp("sv")
+    ref = str(d / "ref.fa")
+    open(ref, "wb").write(gzip.open(os.path.join(SV, "ref.fa.gz")).read())
+    return {"ref": ref, "snp.txt": os.path.join(SV, "snp.txt"), "vars.txt": os.path.join(SV, "vars.txt"), "dir": d}
+
+
+@pytest.mark.parametrize("case", sorted(MANIFEST))
+def test_oracle_simuvars_matches_reference(case, oracle_bin, sv_inputs):
+    out = str(sv_inputs["dir"] / (case + ".fa"))
+    args = [sv_inputs.get(a, a) for a in MANIFEST[case]["args"]]
+    subprocess.check_call([oracle_bin, "simuvars", "-r", sv_inputs["ref"], "-o", out] + args)
+    data = open(out, "rb").read()
+    assert len(data) == MANIFEST[case]["bytes"]
+    assert hashlib.sha256(data).hexdigest() == MANIFEST[case]["sha256"]
+    if case == "full":
+        assert data == gzip.open(os.path.join(SV, "expected_full.fa.gz")).read()
