@@ -84,6 +84,15 @@ int         scs_upload_genome(scs_ctx* ctx, int n_records, const char* const* na
 int         scs_upload_genome_device(scs_ctx* ctx, int n_records, const char* const* names, const uint64_t* lens,
                                      const void* d_bases);
 
+/* `scssim simuvars` (src/scssim.cpp:33-38, 108-170) on the data plane: Genome::loadData (loadAbers lib/genome/Genome.cpp:35-165,
+ * loadSNPs -> lib/snp/snp.cpp:147-203, loadRefSeq 176-195) + Genome::saveSequence (329-384) / generateSegment (386-691).
+ * ref_fasta: plain reference (records chr<k>); snp_file / var_file: the reference's formats, either may be NULL.
+ * The host only plans (segments, copies, substitutions, insertions, deletions as a list of pieces; the reference's rand()
+ * draws reproduced); the two haplotypes of every chromosome are built in HBM from the resident reference and stay resident
+ * exactly as if scs_load_genome_fasta had read the simuvars output -- genreads can follow with no intermediate FASTA.
+ * out_fasta != NULL additionally writes that file, byte-identical to the reference's (records <chr>_<hap>_<reflen>, 100 columns). */
+int         scs_simuvars(scs_ctx* ctx, const char* ref_fasta, const char* snp_file, const char* var_file, const char* out_fasta);
+
 /* Malbac::createFrags -> Genome::splitToFrags + Fragment::createSequence
  * (lib/malbac/Malbac.cpp:143-145, lib/genome/Genome.cpp:753-782, lib/fragment/Fragment.cpp:40-50) */
 int         scs_create_frags(scs_ctx* ctx);
@@ -194,6 +203,10 @@ void        scs_profile_close(void* handle);
  * names joined by '\n'; checksum = FNV-1a over the upper-cased sequence bytes of all records in order. */
 int         scs_fasta_probe(const char* fasta_path, int* n_records, uint64_t* total_bases, uint64_t* checksum,
                             char* names_buf, size_t names_len, char* errbuf, size_t errlen);
+/* Host-only: plan scs_simuvars for these inputs and return the record count, the total haplotype bases and the FNV-1a
+ * checksum of the FASTA text scs_simuvars would write (no GPU; the test seam of the planner). */
+int         scs_simuvars_probe(const char* ref_fasta, const char* snp_file, const char* var_file, int* n_records, uint64_t* total_bases,
+                               uint64_t* checksum, char* errbuf, size_t errlen);
 /* Host-only: leave <fasta_path>.fai beside the file if there is none, exactly as scs_load_genome_fasta does (the
  * reference indexes its input through fastahack, lib/fastahack/Fasta.cpp:241-249: name, length, offset, bases per
  * line, bytes per line). */

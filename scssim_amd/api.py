@@ -86,6 +86,8 @@ def load_library():
     L.scs_profile_close.argtypes = [C.c_void_p]
     L.scs_fasta_probe.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]
     L.scs_fasta_write_index.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t]
+    L.scs_simuvars.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p]
+    L.scs_simuvars_probe.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_char_p, C.c_size_t]
     _lib = L
     return L
 
@@ -111,6 +113,18 @@ def comm_unique_id():
     if rc:
         raise ScsError(rc, L.scs_last_error(None).decode())
     return buf.raw
+
+
+def simuvars_probe(ref_fasta, snp_file=None, var_file=None):
+    """Host-only: (records, total haplotype bases, FNV-1a of the FASTA text) that GenReads.simuvars would produce."""
+    L = load_library()
+    n, tot, h = C.c_int(), C.c_uint64(), C.c_uint64()
+    err = C.create_string_buffer(512)
+    enc = lambda p: os.fsencode(p) if p else None
+    rc = L.scs_simuvars_probe(enc(ref_fasta), enc(snp_file), enc(var_file), C.byref(n), C.byref(tot), C.byref(h), err, 512)
+    if rc:
+        raise ScsError(rc, err.value.decode())
+    return n.value, tot.value, h.value
 
 
 def fasta_write_index(path):
@@ -239,6 +253,12 @@ class GenReads:
         n = len(names)
         bn = [s.encode() if isinstance(s, str) else s for s in names]
         self._ck(self._L.scs_upload_genome_device(self._ctx, n, (C.c_char_p * n)(*bn), (C.c_uint64 * n)(*[int(x) for x in lens]), C.c_void_p(int(d_bases))))
+
+    def simuvars(self, ref_fasta, snp_file=None, var_file=None, out_fasta=None):
+        """`scssim simuvars` on the data plane: the two haplotypes of every chromosome are built in HBM and stay resident
+        as the genreads input (no intermediate FASTA); out_fasta additionally writes the reference's simuvars file."""
+        enc = lambda p: os.fsencode(p) if p else None
+        self._ck(self._L.scs_simuvars(self._ctx, enc(ref_fasta), enc(snp_file), enc(var_file), enc(out_fasta)))
 
     def load_profile(self, path):           # Profile::train(file)
         self._ck(self._L.scs_load_profile(self._ctx, os.fsencode(path)))

@@ -3,6 +3,7 @@
 #include <stdint.h>
 #include <hip/hip_runtime.h>
 #include "scs_common.h"
+#include "scs_simuvars.h"
 
 namespace scs {
 
@@ -142,6 +143,8 @@ void launch_errs_semis(hipStream_t s, const uint8_t* g, DevGenomeIdx gx, DevFrag
                        DevAmps out, uint32_t out_base, DevErrPool pool, uint32_t* flags, const unsigned long long* binom, AmplifyParams p,
                        int64_t* primer_cnt, uint32_t* primer_delta);   // primer_cnt non-null: the pass's stock update rides along (unsharded job)
 void launch_encode_bases(hipStream_t s, uint8_t* g, uint64_t n);
+// simuvars: out[piece.dst ..] = upper(ref | literal pool), then the SNP / SNV alleles
+void launch_sv_build(hipStream_t s, const uint8_t* ref, const uint8_t* lit, const SvPiece* pieces, uint32_t np, const SvSubst* subs, uint32_t nsub, uint8_t* out, uint64_t total);
 void launch_genome_bits(hipStream_t s, const uint8_t* g, uint64_t n, uint64_t nwords, unsigned long long* gc_bits, unsigned long long* n_bits,
                         uint32_t* gc_cnt, uint32_t* n_cnt, uint64_t* gc_pref, uint64_t* n_pref, void* temp, size_t temp_bytes);
 void launch_amplify_init(hipStream_t s, int64_t* primer_cnt, int64_t copies, uint32_t* primer_delta, uint32_t* flags, unsigned long long* sums,

@@ -167,6 +167,40 @@ __global__ void k_encode_bases(uint8_t* __restrict__ g, uint64_t n) {
         *reinterpret_cast<uint4*>(g + i) = v;
     } else for (uint64_t k = i; k < n && k < i + 16; ++k) g[k] = (uint8_t)code(g[k]);
 }
+// ------------------------------------------------------------------------------------------------
+// simuvars on the data plane: the haplotype sequences that Genome::saveSequence / generateSegment
+// (lib/genome/Genome.cpp:329-691) assemble with std::string edits are materialised here from the host's plan: the output is
+// a concatenation of pieces, each a range of the reference (resident in HBM, as read from the FASTA) or of the literal
+// pool (inserted sequences), upper-cased (the toupper of Genome.cpp:393,684); SNP / SNV alleles are written afterwards.
+// A thread produces 16 consecutive output bytes: binary search for its first piece, then a walk.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_sv_build(const uint8_t* __restrict__ ref, const uint8_t* __restrict__ lit, const SvPiece* __restrict__ pieces, uint32_t np,
+                                                  uint8_t* __restrict__ out, uint64_t total) {
+    const uint64_t o = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
+    if (o >= total) return;
+    uint32_t lo = 0, hi = np;                                                      // last piece with dst <= o
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (pieces[mid].dst <= o) lo = mid; else hi = mid; }
+    SvPiece pc = pieces[lo]; uint32_t pi = lo;
+    uint32_t w[4] = {0, 0, 0, 0};
+    const uint32_t nb = (uint32_t)min((uint64_t)16, total - o);
+    for (uint32_t b = 0; b < nb; ++b) {
+        const uint64_t x = o + b;
+        while (x >= pc.dst + pc.len) pc = pieces[++pi];                            // pieces cover the output exactly: never runs past np
+        uint32_t c = (pc.lit ? lit : ref)[pc.src + (x - pc.dst)];
+        if (c >= 'a' && c <= 'z') c -= 32u;
+        w[b >> 2] |= c << (8u * (b & 3u));
+    }
+    if (nb == 16) *reinterpret_cast<uint4*>(out + o) = make_uint4(w[0], w[1], w[2], w[3]);
+    else for (uint32_t b = 0; b < nb; ++b) out[o + b] = (uint8_t)(w[b >> 2] >> (8u * (b & 3u)));
+}
+__global__ void k_sv_subst(const SvSubst* __restrict__ subs, uint32_t n, uint8_t* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[subs[i].dst] = (uint8_t)subs[i].ch;
+}
+void launch_sv_build(hipStream_t s, const uint8_t* ref, const uint8_t* lit, const SvPiece* pieces, uint32_t np, const SvSubst* subs, uint32_t nsub, uint8_t* out, uint64_t total) {
+    if (total && np) hipLaunchKernelGGL(k_sv_build, dim3((unsigned)((total + 16 * 256 - 1) / (16 * 256))), dim3(256), 0, s, ref, lit, pieces, np, out, total);
+    if (nsub) hipLaunchKernelGGL(k_sv_subst, dim3((nsub + 255) / 256), dim3(256), 0, s, subs, nsub, out);
+}
 void launch_encode_bases(hipStream_t s, uint8_t* g, uint64_t n) {
     if (n) hipLaunchKernelGGL(k_encode_bases, dim3((unsigned)((n + 16 * 256 - 1) / (16 * 256))), dim3(256), 0, s, g, n);
 }

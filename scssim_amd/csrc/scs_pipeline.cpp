@@ -315,7 +315,7 @@ void stage_genome(scs_ctx* c, const void* d_ascii = nullptr, const uint64_t* d_l
     for (size_t i = 0; i < c->recs.size(); ++i) { const uint64_t l = d_ascii ? d_lens[i] : c->recs[i].code.size(); c->rec_off.push_back(tot); c->rec_len.push_back(l); tot += l; }
     c->genome_bases = tot;
     c->genome.reserve(std::max<uint64_t>(tot, 16), c->stream);
-    if (d_ascii) { if (tot) HIP_OK(hipMemcpyAsync(c->genome.p, d_ascii, tot, hipMemcpyDeviceToDevice, c->stream)); }
+    if (d_ascii) { if (tot && d_ascii != c->genome.p) HIP_OK(hipMemcpyAsync(c->genome.p, d_ascii, tot, hipMemcpyDeviceToDevice, c->stream)); }   // simuvars builds in place
     else for (size_t i = 0; i < c->recs.size(); ++i)
         if (!c->recs[i].code.empty())
             HIP_OK(hipMemcpyAsync((uint8_t*)c->genome.p + c->rec_off[i], c->recs[i].code.data(), c->recs[i].code.size(), hipMemcpyHostToDevice, c->stream));
@@ -921,6 +921,56 @@ int scs_upload_genome_device(scs_ctx* c, int n, const char* const* names, const 
         stage_genome(c, d_bases, lens);
     });
 }
+// `scssim simuvars` (src/scssim.cpp:33-38: Genome::loadData + Genome::saveSequence) on the data plane
+int scs_simuvars(scs_ctx* c, const char* ref_fasta, const char* snp_file, const char* var_file, const char* out_fasta) {
+    return guarded(c, [&] {
+        if (!ref_fasta) throw ScsError(SCS_EINVAL, "reference sequence file not specified!");
+        hipStream_t s = c->stream;
+        std::vector<FastaRecord> ref; load_fasta(ref_fasta, ref, true);                // Genome::loadRefSeq (Genome.cpp:176-195): index names, .fai beside the file
+        if (c->cfg.verbose) fprintf(stderr, "\nReference sequence was loaded from file %s\n", ref_fasta);
+        std::vector<SvChrom> chroms; uint64_t rtot = 0;
+        for (auto& r : ref) { chroms.push_back(SvChrom{r.name, rtot, (uint64_t)r.code.size()}); rtot += r.code.size(); }
+        DevBuf d_ref, d_lit, d_pc, d_sb;
+        struct Rel { DevBuf* b[4]; ~Rel() { for (DevBuf* x : b) x->release(); } } rel{{&d_ref, &d_lit, &d_pc, &d_sb}};
+        d_ref.reserve(std::max<uint64_t>(rtot, 16), s);
+        for (size_t i = 0; i < ref.size(); ++i) if (!ref[i].code.empty()) HIP_OK(hipMemcpyAsync((uint8_t*)d_ref.p + chroms[i].off, ref[i].code.data(), ref[i].code.size(), hipMemcpyHostToDevice, s));
+        SvPlan P;
+        try { simuvars_plan(chroms, snp_file ? snp_file : "", var_file ? var_file : "", c->cfg.verbose != 0, P); }
+        catch (const std::exception& e) { HIP_OK(hipStreamSynchronize(s)); throw ScsError(SCS_EIO, e.what()); }
+        if (P.pieces.size() > 0xFFFFFFF0ull || P.substs.size() > 0xFFFFFFF0ull) throw ScsError(SCS_EOVERFLOW, "simuvars: too many edits");
+        upload(d_pc, P.pieces, s); upload(d_sb, P.substs, s);
+        d_lit.reserve(std::max<size_t>(P.literals.size(), 16), s);
+        if (!P.literals.empty()) HIP_OK(hipMemcpyAsync(d_lit.p, P.literals.data(), P.literals.size(), hipMemcpyHostToDevice, s));
+        c->genome.reserve(std::max<uint64_t>(P.total, 16), s);
+        launch_sv_build(s, d_ref.as<uint8_t>(), d_lit.as<uint8_t>(), d_pc.as<SvPiece>(), (uint32_t)P.pieces.size(), d_sb.as<SvSubst>(), (uint32_t)P.substs.size(), c->genome.as<uint8_t>(), P.total);
+        HIP_OK(hipStreamSynchronize(s));                                                 // the host vectors behind the uploads may go
+        { const hipError_t le = take_launch_error(); if (le != hipSuccess) throw ScsError(SCS_EDEVICE, std::string("simuvars kernel launch failed: ") + hipGetErrorString(le)); }
+        if (out_fasta && *out_fasta) {                                                   // Genome::saveSequence's file: >chr_hap_len, 100 columns (Genome.cpp:365-381)
+            FILE* o = fopen(out_fasta, "w");
+            if (!o) throw ScsError(SCS_EIO, std::string("can not open file ") + out_fasta);
+            const size_t chunk = 64u << 20; char* hb = nullptr; HIP_OK(hipHostMalloc((void**)&hb, chunk, hipHostMallocDefault));
+            std::vector<char> line_buf; uint64_t off = 0; bool okw = true;
+            for (size_t r = 0; r < P.rec_names.size() && okw; ++r) {
+                okw = fprintf(o, ">%s\n", P.rec_names[r].c_str()) > 0;
+                uint64_t col = 0;
+                for (uint64_t done = 0; done < P.rec_lens[r] && okw; done += chunk) {
+                    const size_t n = (size_t)std::min<uint64_t>(chunk, P.rec_lens[r] - done);
+                    HIP_OK(hipMemcpyAsync(hb, (uint8_t*)c->genome.p + off + done, n, hipMemcpyDeviceToHost, s)); HIP_OK(hipStreamSynchronize(s));
+                    line_buf.clear(); line_buf.reserve(n + n / 100 + 2);
+                    for (size_t i = 0; i < n;) { const size_t take = (size_t)std::min<uint64_t>(100 - col, n - i); line_buf.insert(line_buf.end(), hb + i, hb + i + take); i += take; col += take; if (col == 100) { line_buf.push_back('\n'); col = 0; } }
+                    okw = fwrite(line_buf.data(), 1, line_buf.size(), o) == line_buf.size();
+                }
+                if (col && okw) okw = fputc('\n', o) != EOF;
+                off += P.rec_lens[r];
+            }
+            (void)hipHostFree(hb);
+            if (fclose(o) != 0 || !okw) throw ScsError(SCS_EIO, std::string("writing ") + out_fasta + " failed");
+        }
+        c->recs.resize(P.rec_names.size());
+        for (size_t i = 0; i < P.rec_names.size(); ++i) encode_record(P.rec_names[i].c_str(), nullptr, 0, c->recs[i]);
+        stage_genome(c, c->genome.p, P.rec_lens.data());                                 // encode + bit index in place: ready for scs_create_frags
+    });
+}
 int scs_create_frags(scs_ctx* c) { return guarded(c, [&] { double t = now_s(); do_create_frags(c); c->st.t_stage[1] = now_s() - t; }); }
 int scs_amplify(scs_ctx* c) { return guarded(c, [&] { double t = now_s(); do_amplify(c); c->st.t_stage[2] = now_s() - t; }); }
 int scs_allocate_reads(scs_ctx* c, uint64_t reads) { return guarded(c, [&] { do_allocate(c, reads); }); }
@@ -1105,6 +1155,29 @@ int scs_fasta_probe(const char* path, int* n_records, uint64_t* total_bases, uin
     if (n_records) *n_records = (int)recs.size(); if (total_bases) *total_bases = tot; if (checksum) *checksum = h;
     if (names_buf && names_len) { strncpy(names_buf, names.c_str(), names_len - 1); names_buf[names_len - 1] = 0; }
     return SCS_OK;
+}
+// host-only: the simuvars plan applied to the host copy of the reference, folded into a checksum of the FASTA text that
+// scs_simuvars would write (test seam for the planner; the product builds the sequences on the device)
+int scs_simuvars_probe(const char* ref_fasta, const char* snp_file, const char* var_file, int* n_records, uint64_t* total_bases, uint64_t* checksum, char* errbuf, size_t errlen) {
+    if (!ref_fasta) return SCS_EINVAL;
+    try {
+        std::vector<FastaRecord> ref; load_fasta(ref_fasta, ref);
+        std::vector<SvChrom> chroms; std::vector<uint8_t> flat;
+        for (auto& r : ref) { chroms.push_back(SvChrom{r.name, (uint64_t)flat.size(), (uint64_t)r.code.size()}); flat.insert(flat.end(), r.code.begin(), r.code.end()); }
+        SvPlan P; simuvars_plan(chroms, snp_file ? snp_file : "", var_file ? var_file : "", false, P);
+        std::vector<uint8_t> out(P.total);
+        for (const SvPiece& pc : P.pieces) for (uint32_t i = 0; i < pc.len; ++i) { uint8_t ch = pc.lit ? (uint8_t)P.literals[pc.src + i] : flat[pc.src + i]; out[pc.dst + i] = (uint8_t)(ch >= 'a' && ch <= 'z' ? ch - 32 : ch); }
+        for (const SvSubst& sb : P.substs) out[sb.dst] = (uint8_t)sb.ch;
+        uint64_t h = 1469598103934665603ull, off = 0;
+        auto eat = [&](const char* p, size_t n) { for (size_t i = 0; i < n; ++i) { h ^= (uint8_t)p[i]; h *= 1099511628211ull; } };
+        for (size_t r = 0; r < P.rec_names.size(); ++r) {
+            const std::string hd = ">" + P.rec_names[r] + "\n"; eat(hd.data(), hd.size());
+            for (uint64_t x = 0; x < P.rec_lens[r]; x += 100) { eat((const char*)out.data() + off + x, (size_t)std::min<uint64_t>(100, P.rec_lens[r] - x)); eat("\n", 1); }
+            off += P.rec_lens[r];
+        }
+        if (n_records) *n_records = (int)P.rec_names.size(); if (total_bases) *total_bases = P.total; if (checksum) *checksum = h;
+        return SCS_OK;
+    } catch (const std::exception& e) { if (errbuf && errlen) { strncpy(errbuf, e.what(), errlen - 1); errbuf[errlen - 1] = 0; } return SCS_EIO; }
 }
 int scs_fasta_write_index(const char* path, char* errbuf, size_t errlen) {
     if (!path) return SCS_EINVAL;

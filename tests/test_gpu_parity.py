@@ -550,3 +550,91 @@ def test_mapped_buffers_parity(models, tmp_path):
     r = subprocess.run(["python", "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider"] + sel, cwd=ROOT, env=env,
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:]
+
+
+# ---- simuvars on the data plane -------------------------------------------------------------------------
+def _sv_inputs(tmp_path):
+    import gzip
+    sv = os.path.join(ROOT, "tests", "golden", "simuvars")
+    ref = str(tmp_path / "ref.fa")
+    open(ref, "wb").write(gzip.open(os.path.join(sv, "ref.fa.gz")).read())
+    return sv, ref
+
+
+def test_simuvars_cli_matches_reference_output(tmp_path):
+    """`scssim simuvars` (haplotypes assembled on the GPU from the host's piece plan) writes the file the compiled
+    reference wrote for the same inputs (tests/golden/simuvars: copy numbers 0..8, SNPs on both strands, SNVs, insertions,
+    deletions, het / homo), byte for byte; and without variation files the plain diploid copy."""
+    import gzip
+    import hashlib
+    import json
+    sv, ref = _sv_inputs(tmp_path)
+    man = json.load(open(os.path.join(sv, "manifest.json")))
+    exe = os.path.join(ROOT, "scssim_amd", "bin", "scssim")
+    out = str(tmp_path / "full.fa")
+    r = subprocess.run([exe, "simuvars", "-r", ref, "-s", os.path.join(sv, "snp.txt"), "-v", os.path.join(sv, "vars.txt"), "-o", out], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "CNV: 13" in r.stderr and "340 SNPs to simulate were loaded" in r.stderr
+    assert open(out, "rb").read() == gzip.open(os.path.join(sv, "expected_full.fa.gz")).read()
+    for case, extra in (("plain", []), ("snp_only", ["-s", os.path.join(sv, "snp.txt")])):
+        o2 = str(tmp_path / (case + ".fa"))
+        r = subprocess.run([exe, "simuvars", "-r", ref, "-o", o2] + extra, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        assert hashlib.sha256(open(o2, "rb").read()).hexdigest() == man[case]["sha256"]
+    bad = subprocess.run([exe, "simuvars", "-o", out], capture_output=True, text=True)
+    assert bad.returncode == 1 and "Use --ref to specify the reference file" in bad.stderr
+
+
+def test_simuvars_then_genreads_without_a_fasta(oracle_bin, models, tmp_path):
+    """BASELINE config 5's input path: the CNV-edited diploid genome goes from scs_simuvars straight into genreads, resident
+    in HBM -- and the reads equal the oracle's reads from the simuvars FASTA file (PE250, -s 500, copy numbers up to 8)."""
+    sv, ref = _sv_inputs(tmp_path)
+    fa = str(tmp_path / "simu.fa")
+    subprocess.check_call([oracle_bin, "simuvars", "-r", ref, "-s", os.path.join(sv, "snp.txt"), "-v", os.path.join(sv, "vars.txt"), "-o", fa])
+    prof = str(tmp_path / "pe250.profile")
+    subprocess.check_call(["python3", os.path.join(ROOT, "tools", "make_profile.py"), models["Illumina_HiSeqXTen"], prof, "--read-length", "250"])
+    prefix = str(tmp_path / "orc")
+    _oracle_run(oracle_bin, fa, prof, prefix, ["-c", "4", "-s", "500"], 61)
+    g = scssim_amd.GenReads(profile=prof, coverage=4.0, isize=500, seed=61)
+    g.simuvars(ref, os.path.join(sv, "snp.txt"), os.path.join(sv, "vars.txt"))
+    fq1, fq2 = g.run()
+    assert g.stats()["records"] == 6 and g.stats()["reads_requested"] == 610000 * 4 // 250
+    assert fq1 == open(prefix + "_1.fq", "rb").read()
+    assert fq2 == open(prefix + "_2.fq", "rb").read()
+
+
+def test_simuvars_random_variations_match_oracle(oracle_bin, tmp_path):
+    """A CNV-heavy random variation file (copy numbers 0..8, every major-copy split, hundreds of SNVs / insertions /
+    deletions, thousands of SNPs) on a 3 Mb two-record reference: GPU-built haplotypes == the oracle's std::string edits."""
+    rng = np.random.default_rng(77)
+    ref = str(tmp_path / "r.fa")
+    subprocess.check_call(["python3", os.path.join(ROOT, "tools", "make_genome.py"), "--lengths", "2000000,1000000", "--seed", "9", "--first-chr", "7", "--lower-frac", "0.05", "--ref-out", ref])
+    var, snp = str(tmp_path / "v.txt"), str(tmp_path / "s.txt")
+    with open(var, "w") as f:
+        for chrom, n in (("chr7", 2000000), ("chr8", 1000000)):
+            pos = 1000
+            while pos + 60000 < n:                                                  # sorted, non-overlapping CNV intervals
+                ln = int(rng.integers(5000, 40000)); cn = int(rng.integers(0, 9)); mcn = int(rng.integers((cn + 1) // 2, cn + 1))
+                f.write("c\t%s\t%d\t%d\t%d\t%d\n" % (chrom, pos, pos + ln, cn, mcn))
+                pos += ln + int(rng.integers(1, 30000))
+            for p in sorted(rng.choice(np.arange(500, n - 500), size=300, replace=False)):
+                kind = rng.integers(3)
+                ht = "het" if rng.random() < 0.5 else "homo"
+                if kind == 0:
+                    f.write("s\t%s\t%d\tN\t%s\t%s\n" % (chrom, p, "ACGT"[rng.integers(4)], ht))
+                elif kind == 1:
+                    f.write("i\t%s\t%d\t%s\t%s\n" % (chrom, p, "".join(rng.choice(list("acgt"), size=int(rng.integers(1, 30)))), ht))
+                else:
+                    f.write("d\t%s\t%d\t%d\t%s\n" % (chrom, p, int(rng.integers(1, 40)), ht))
+    with open(snp, "w") as f:
+        for chrom, n in (("chr7", 2000000), ("chr8", 1000000)):
+            for i, p in enumerate(sorted(rng.choice(np.arange(1, n), size=4000, replace=False))):
+                a, b = rng.choice(list("ACGT"), size=2, replace=False)
+                f.write("rs%d\t%s\t%d\t%s/%s\t%s\t%s\n" % (i, chrom, p, a, b, "+-"[rng.integers(2)], a))
+    want = str(tmp_path / "orc.fa")
+    subprocess.check_call([oracle_bin, "simuvars", "-r", ref, "-s", snp, "-v", var, "-o", want])
+    got = str(tmp_path / "gpu.fa")
+    g = scssim_amd.GenReads()
+    g.simuvars(ref, snp, var, got)
+    assert open(got, "rb").read() == open(want, "rb").read()
+    assert g.stats()["records"] == 4
