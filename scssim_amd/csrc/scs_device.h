@@ -158,7 +158,8 @@ void launch_pair_offsets(hipStream_t s, const uint32_t* rn, uint32_t ac, int pai
 size_t reads_lds_bytes(const DevTables& tb);          // dynamic LDS of one inject_errors workgroup for this profile
 void launch_reads(hipStream_t s, const uint8_t* g, DevErrPool spool, DevErrPool fpool,
                   const PairRec* pairs, uint32_t np, uint32_t amp_index_base, DevTables tb, const DevTables* d_tb, RngKey key, int paired, uint32_t slot,
-                  const uint32_t* ev_hdr, const uint4* ev_dat, const uint64_t* off1, const uint64_t* off2, char* out1, char* out2, uint32_t* flags);   // writes FASTQ text
+                  const uint32_t* ev_hdr, const uint4* ev_dat, const uint64_t* off1, const uint64_t* off2, char* out1, char* out2, uint32_t* flags,
+                  uint64_t cap1, uint64_t cap2);   // writes FASTQ text; cap: bytes of the batch's text in each file (records are checked against it)
 // the indel pass of a batch (n' and events per read, FASTQ record sizes per pair and mate), ahead of launch_reads
 void launch_indels(hipStream_t s, const PairRec* pairs, uint32_t np, int paired, DevTables tb, RngKey key, uint32_t slot, uint32_t* ev_hdr, uint4* ev_dat,
                    uint32_t* sizes1, uint32_t* sizes2, uint32_t* flags);

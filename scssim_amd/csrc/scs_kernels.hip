@@ -679,7 +679,7 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
                                               const uint32_t* __restrict__ ev_hdr, const uint4* __restrict__ ev_dat,
                                               const uint64_t* __restrict__ off1, const uint64_t* __restrict__ off2, char* __restrict__ out1, char* __restrict__ out2,
                                               uint32_t amp_index_base, char* __restrict__ slot_b, char* __restrict__ slot_q, uint32_t* __restrict__ lens,
-                                              uint32_t* __restrict__ flags) {
+                                              uint32_t* __restrict__ flags, uint64_t cap1, uint64_t cap2) {
     typedef RingGeo<QBIG> Geo;
     typedef RingBin<QBIG> Bin;
     constexpr int SLOTS = Geo::SLOTS, GROUP = Geo::GROUP, QROW = Geo::QROW, EPB = 64 + 4 * QROW;   // EPB: 16-byte entries per bin image
@@ -858,6 +858,9 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
     bo_b.carry = 0; bo_q.carry = 0x0A2B0A00u;                                      // "\n+\n" rides ahead of the qualities
 #pragma unroll
     for (int i = 0; i < 4; ++i) { bo_b.R[i] = bo_q.R[i] = 0; bo_b.H[i] = bo_q.H[i] = 0; if (i < 3) bo_b.P[i] = bo_q.P[i] = 0; }
+    // the record must lie inside the batch's text (its offset and size come from k_indels' n'; the walk below emits exactly
+    // n' characters per stream): a disagreement would be an internal error, reported, never a store outside the buffer
+    if (FROM_PAIRS && live && n_out > 0 && offs[pi] + rec_h + 2ull * (uint32_t)n_out + 4ull > (second_file ? cap2 : cap1)) { atomicOr(flags, (uint32_t)FLAG_INTERNAL); live = false; n_out = 0; }
     if (FROM_PAIRS && live && n_out > 0) {
         const uint32_t amp = amp_index_base + pr.amp, cnt = pr.att + 1u, d2 = dec_digits(cnt), h = rec_h;
         const uint32_t o1 = rec_rel + h, o2 = o1 + (uint32_t)n_out + 3u;          // where the bases / the qualities start
@@ -1759,14 +1762,17 @@ void launch_indels(hipStream_t s, const PairRec* pairs, uint32_t np, int paired,
 }
 void launch_reads(hipStream_t s, const uint8_t* g, DevErrPool spool, DevErrPool fpool,
                   const PairRec* pairs, uint32_t np, uint32_t amp_index_base, DevTables tb, const DevTables* d_tb, RngKey key, int paired, uint32_t slot,
-                  const uint32_t* ev_hdr, const uint4* ev_dat, const uint64_t* off1, const uint64_t* off2, char* out1, char* out2, uint32_t* flags) {
+                  const uint32_t* ev_hdr, const uint4* ev_dat, const uint64_t* off1, const uint64_t* off2, char* out1, char* out2, uint32_t* flags,
+                  uint64_t cap1, uint64_t cap2) {
     if (np == 0) return;
     (void)d_tb;
+    static const bool shrink = getenv("SCS_TEST_SHRINK_OUT") != nullptr;               // tests: provoke the record-bound guard
+    if (shrink) { cap1 /= 2; cap2 /= 2; }
     const uint32_t groups = cdiv(np, RB);
     launch_reads_kernel<true>(s, dim3(paired ? 2 * groups : groups), tb, g, spool, fpool, pairs, np, paired,
                               (const uint8_t*)nullptr, (const uint64_t*)nullptr, (const uint32_t*)nullptr, (const uint8_t*)nullptr, 0u, tb, key, slot,
                               (uint32_t)(paired ? 2ull * np : np), reads_force_replay(), ev_hdr, ev_dat, off1, off2, out1, out2, amp_index_base,
-                              (char*)nullptr, (char*)nullptr, (uint32_t*)nullptr, flags);
+                              (char*)nullptr, (char*)nullptr, (uint32_t*)nullptr, flags, cap1, cap2);
 }
 void launch_predict_windows(hipStream_t s, const uint8_t* windows, uint32_t n_reads, const uint64_t* uids, const uint32_t* atts,
                             const uint8_t* is_read1, DevTables tb, const DevTables* d_tb, RngKey key, uint32_t slot, char* slot_b, char* slot_q, uint32_t* lens, uint32_t* flags) {
@@ -1775,7 +1781,7 @@ void launch_predict_windows(hipStream_t s, const uint8_t* windows, uint32_t n_re
     DevErrPool none{};
     launch_reads_kernel<false>(s, dim3(cdiv(n_reads, RB)), tb, (const uint8_t*)nullptr, none, none, (const PairRec*)nullptr, 0u, 0,
                                windows, uids, atts, is_read1, n_reads, tb, key, slot, n_reads, reads_force_replay(), (const uint32_t*)nullptr, (const uint4*)nullptr,
-                               (const uint64_t*)nullptr, (const uint64_t*)nullptr, (char*)nullptr, (char*)nullptr, 0u, slot_b, slot_q, lens, flags);
+                               (const uint64_t*)nullptr, (const uint64_t*)nullptr, (char*)nullptr, (char*)nullptr, 0u, slot_b, slot_q, lens, flags, (uint64_t)0, (uint64_t)0);
 }
 void launch_philox(hipStream_t s, const uint32_t* ctr, uint32_t n, RngKey key, uint32_t* out) {
     if (n) hipLaunchKernelGGL(k_philox, dim3(cdiv(n, 256)), dim3(256), 0, s, ctr, n, key, out);

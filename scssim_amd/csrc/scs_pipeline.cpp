@@ -772,7 +772,7 @@ void do_yield(scs_ctx* c, const OutTarget& tg, uint64_t* n1_out, uint64_t* n2_ou
         c->tm_reads.begin(s);                                                      // the base pass writes the FASTQ text at the record offsets
         launch_reads(s, c->genome.as<uint8_t>(), c->semis.pool_view(), c->fulls.pool_view(), pr, np, 0,
                      c->dtb, c->d_tables.as<DevTables>(), c->key, paired, slot, c->ev_hdr.as<uint32_t>(), c->ev_dat.as<uint4>(),
-                     c->off1.as<uint64_t>(), c->off2.as<uint64_t>(), o1, o2, c->flags.as<uint32_t>());
+                     c->off1.as<uint64_t>(), c->off2.as<uint64_t>(), o1, o2, c->flags.as<uint32_t>(), b1, b2);
         c->tm_reads.end(s);
         c->tm_reads.add_units(np);
         { const hipError_t le = take_launch_error(); if (le != hipSuccess) throw ScsError(SCS_EDEVICE, std::string("k_reads launch failed: ") + hipGetErrorString(le)); }

@@ -638,3 +638,23 @@ def test_simuvars_random_variations_match_oracle(oracle_bin, tmp_path):
     g.simuvars(ref, snp, var, got)
     assert open(got, "rb").read() == open(want, "rb").read()
     assert g.stats()["records"] == 4
+
+
+def test_record_bound_guard_reports_instead_of_faulting(models, golden_inputs):
+    """k_reads checks every FASTQ record against the size of the batch's text before it writes (round 1 saw two GPU memory
+    faults from stores that trusted a length computed elsewhere: DESIGN.md section 9).  With the batch size mis-stated on
+    purpose (SCS_TEST_SHRINK_OUT halves it) the job must end with SCS_EOVERFLOW 'internal', not with a fault."""
+    import sys
+    code = '''
+import os, sys
+sys.path.insert(0, %r)
+import scssim_amd
+g = scssim_amd.GenReads(profile=%r, input_fasta=%r, coverage=2.0, seed=5)
+try:
+    g.run()
+except scssim_amd.ScsError as e:
+    assert e.code == 4 and "internal" in str(e), str(e)
+    print("GUARDED")
+''' % (ROOT, models["Illumina_HiSeq2500"], golden_inputs["g1_hiseq2500_pe"])
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SCS_TEST_SHRINK_OUT="1"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "GUARDED" in r.stdout, r.stdout + r.stderr
