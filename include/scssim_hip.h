@@ -178,7 +178,8 @@ int         scs_predict_batch(scs_ctx* ctx, const uint8_t* windows, size_t n_rea
 
 /* Philox4x32-10 on the device for n counters (ctr: n x 4, key: 2, out: n x 4; host pointers). */
 int         scs_philox_batch(scs_ctx* ctx, const uint32_t* ctr, size_t n, const uint32_t* key, uint32_t* out);
-/* det_log on the device (host pointers). */
+/* det_log on the device (host pointers); an argument <= 0 is evaluated as det_exp instead (the product-form Poisson's
+ * exp(-lambda), -256 <= x <= 0), so one entry point serves both deterministic functions. */
 int         scs_detlog_batch(scs_ctx* ctx, const double* x, size_t n, double* out);
 
 /* Download the amplicon tables (kind 0 = semi, 1 = full) for stage-level parity tests.  Any pointer

@@ -110,6 +110,25 @@ double det_log(double x) {
     return dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
 }
 
+// exp(x) for -256 <= x <= 0 (fdlibm's argument reduction and polynomial; IEEE + - * / only): the GPU computes the same bits
+double det_exp(double x) {
+    const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10, invln2 = 1.44269504088896338700e+00;
+    const double P1 = 1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03, P3 = 6.61375632143793436117e-05,
+                 P4 = -1.65339022054652515390e-06, P5 = 4.13813679705723846039e-08;
+    if (x >= 0) return 1.0;
+    if (x < -256.0) return 0.0;
+    const int k = (int)(invln2 * x - 0.5);                                         // x < 0: nearest integer
+    const double dk = (double)k;
+    const double hi = x - dk * ln2_hi, lo = dk * ln2_lo, r = hi - lo;
+    const double t = r * r;
+    const double c = r - t * (P1 + t * (P2 + t * (P3 + t * (P4 + t * P5))));
+    const double y = 1.0 - ((lo - (r * c) / (2.0 - c)) - hi);
+    uint64_t b; memcpy(&b, &y, 8);
+    b += (uint64_t)(int64_t)k << 52;                                               // * 2^k: k >= -370, y in [0.5, 2): no underflow
+    double out; memcpy(&out, &b, 8);
+    return out;
+}
+
 // ---------------------------------------------------------------------------
 // Random source.  Every draw site names its counter-mode key; in ref mode the
 // key is ignored and the reference's sequential streams are advanced instead.
@@ -210,6 +229,10 @@ struct Profile {
     //   x < tIns (#{x : x/2^32 <= insertRate}) -> insertion; else x < tIndel -> deletion, where the deletion test's own
     //   threshold tDel = #{x : x/2^32 < delRate/(1-insertRate)} is rescaled to the draws left: tIndel = tIns + ((2^32-tIns)*tDel >> 32)
     uint32_t tIns = 0, tIndel = 0;
+    // [REMAP] counter mode walks a read from indel event to indel event: the per-base tests are i.i.d. with probability
+    // p = tIndel / 2^32, so the number of event-free bases before the next event is geometric: gap >= g <=> x < tGap[g],
+    // tGap[g] = floor((1-p)^g 2^32); the event is an insertion when a second draw y < tKind = floor(2^32 tIns / tIndel)
+    std::vector<uint32_t> tGap; uint32_t tKind = 0;
     std::vector<double> insCdf, delCdf;
     std::vector<double> subs1, subs2;     // [84][bins][4]  (dist, then cdf in place)
     bool haveCdf2 = false;
@@ -387,6 +410,10 @@ Profile* load_profile(const std::string& path, bool paired, int isize) {
         const uint32_t tIns = count_true([ir](uint32_t x) { return (x / 4294967296.0) <= ir; });
         const uint32_t tDel = count_true([dr](uint32_t x) { return (x / 4294967296.0) < dr; });
         P->tIns = tIns; P->tIndel = tIns + (uint32_t)((((1ull << 32) - tIns) * (uint64_t)tDel) >> 32);
+        P->tGap.assign((size_t)P->L + 1, 0xFFFFFFFFu);
+        { const double q = 1.0 - (double)P->tIndel / 4294967296.0; double pw = 1.0;
+          for (int g = 1; g <= P->L; ++g) { pw = pw * q; const double v = std::floor(pw * 4294967296.0); P->tGap[(size_t)g] = v >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)v; } }
+        if (P->tIndel) { const double v = std::floor(4294967296.0 * ((double)P->tIns / (double)P->tIndel)); P->tKind = v >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)v; }
     }
     return P.release();
 }
@@ -423,21 +450,45 @@ int predict(const Profile& P, Rng& rng, const uint8_t* win, int n, bool isRead1,
     std::vector<int> indelLens; indelLens.reserve(n);
     std::vector<std::vector<uint8_t>> ins(n);
     int indelLength = 0;
+    auto gap = [&](uint32_t x, uint32_t rem) -> uint32_t {                       // [REMAP] event-free bases before the next event among `rem`
+        const std::vector<uint32_t>& T = P.tGap;
+        if (x < T[rem]) return rem;
+        uint32_t lo = 1, hi = rem;
+        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (x >= T[mid]) hi = mid; else lo = mid + 1; }
+        return lo - 1;
+    };
+    if (rng.counter) {
+        // [REMAP] stream A = gap, kind, gap, kind, ...: the walk jumps from event to event (same distribution as one test per base)
+        indelLens.assign(n, 0);
+        if (P.tIndel) for (int j = 0; j < n;) {
+            j += (int)gap(xa.next(), (uint32_t)(n - j));
+            if (j >= n) break;
+            const uint32_t y = xa.next();
+            const double u = rng.real(mk(ST_INDEL_LEN, aux, uid, j, 0));
+            if (y < P.tKind) {
+                int k = (int)rand_indx(P.insCdf.data(), P.insCdf.size(), u);
+                for (int t = 0; t < k; ++t) ins[j].push_back(0);                 // the inserted base is drawn from stream B when it is emitted (base pass below)
+                indelLength += k; indelLens[j] = k; j++;
+            } else {
+                int k = (int)rand_indx(P.delCdf.data(), P.delCdf.size(), u);
+                if (k > 0) { k = std::min(n - j, k); indelLength -= k; indelLens[j] = k; j += k; }
+                else j++;
+            }
+        }
+    } else
     for (int j = 0; j < n;) {                                                  // 1606-1622
         int k = 0; bool isIns = false;
-        const uint32_t xi = rng.counter ? xa.next() : 0u;                       // [REMAP] one draw per base in counter mode
-        double p = rng.counter ? 0.0 : drawA();                                 // getIndelSeq 1552-1570
-        if (rng.counter ? xi < P.tIns : p <= P.insertRate) {
+        double p = drawA();                                                     // getIndelSeq 1552-1570
+        if (p <= P.insertRate) {
             k = rand_indx(P.insCdf.data(), P.insCdf.size(), rng.real(mk(ST_INDEL_LEN, aux, uid, j, 0)));
             for (int t = 0; t < k; ++t) {
-                // [REMAP] counter mode: the inserted base is drawn from stream B when it is emitted (base pass below)
-                double u = rng.counter ? 0.0 : rng.integer(Key{});
+                double u = rng.integer(Key{});
                 ins[j].push_back((uint8_t)(long)(0 + (P.N - 1 - 0) * u));       // randomInteger(0, N-1): never 'T'
             }
             isIns = !ins[j].empty();
         } else {
-            if (!rng.counter) p = drawA();
-            if (rng.counter ? xi < P.tIndel : p < P.delRate / (1 - P.insertRate))
+            p = drawA();
+            if (p < P.delRate / (1 - P.insertRate))
                 k = rand_indx(P.delCdf.data(), P.delCdf.size(), rng.real(mk(ST_INDEL_LEN, aux, uid, j, 0)));
         }
         if (!isIns && k > 0) {                                                  // deletion
@@ -608,6 +659,13 @@ struct PrimerPool {
 
 // ---- a3: Malbac::setPrimers (Malbac.cpp:236-283) + poissRand (MyDefine.cpp:69-80) ------------
 long poiss_rand(Sim& S, double lambda, uint32_t call, uint32_t kind, uint64_t tuid) {
+    if (S.prm.counter && kind == 1 && lambda <= 256.0) {
+        // [REMAP] semi amplicons (lambda of a few units, 10^8 of them per cycle at whole-genome size): Knuth's loop in its
+        // product form -- p *= u until p < exp(-lambda) -- one multiply per draw instead of one logarithm
+        const double L = det_exp(-lambda); long x = -1; double pr = 1.0; uint32_t t = 0;
+        do { const double u = S.rng.grand(mk(ST_POISSON, kind | (call << 1), tuid, t / 4, t % 4)); t++; pr = pr * u; x++; } while (pr >= L);
+        return x;
+    }
     long x = -1; double log1 = 0, log2 = -lambda; uint32_t t = 0;
     do {
         double u = S.rng.grand(mk(ST_POISSON, kind | (call << 1), tuid, t / 4, t % 4)); t++;
@@ -1342,6 +1400,7 @@ extern "C" {
 
 void scso_philox4x32_10(const uint32_t* ctr, const uint32_t* key, uint32_t* out) { philox(ctr, key, out); }
 double scso_det_log(double x) { return det_log(x); }
+double scso_det_exp(double x) { return det_exp(x); }
 const char* scso_last_error(void) { return g_err.c_str(); }
 void scso_last_timings(double out[6]) { for (int i = 0; i < 6; ++i) out[i] = g_timings[i]; }
 

@@ -24,6 +24,7 @@ void scso_philox4x32_10(const uint32_t* ctr, const uint32_t* key, uint32_t* out)
 
 // Deterministic natural log (software, +,-,*,/ only; see scs_oracle.cpp).
 double scso_det_log(double x);
+double scso_det_exp(double x);   /* -256 <= x <= 0 */
 
 // Run the whole genreads pipeline.  Returns 0 on success; on failure a message
 // is left in scso_last_error().  `rng_mode`: 0 = reference streams, 1 = counter.

@@ -42,6 +42,7 @@ struct View { int64_t base; int32_t dir; uint32_t comp; };
 struct DevTables {
     int L, bins;
     uint32_t t_insert, t_delete, t_indel, t_ber;       // t_indel: one-draw indel test (scs_tables.h)
+    const uint32_t* gap_t; uint32_t t_kind;            // [REMAP] geometric gap between indel events (scs_tables.h): gap >= g <=> x < gap_t[g]
     const uint32_t* subs1; const uint32_t* subs2;   // [84][bins][4] thresholds (uint4 rows)
     const uint32_t* qual;                            // [16][bins][94]
     const uint4* qual_compact; int qual_big;         // [16*bins] compact rows, 64 B (small) or 224 B (big): layout in scs_tables.h

@@ -352,6 +352,22 @@ __device__ double det_log(double x) {
     return dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
 }
 
+// exp(x) for -256 <= x <= 0, the oracle's det_exp operation for operation (fdlibm's reduction and polynomial)
+__device__ double det_exp(double x) {
+    const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10, invln2 = 1.44269504088896338700e+00;
+    const double P1 = 1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03, P3 = 6.61375632143793436117e-05,
+                 P4 = -1.65339022054652515390e-06, P5 = 4.13813679705723846039e-08;
+    if (x >= 0) return 1.0;
+    if (x < -256.0) return 0.0;
+    const int k = (int)(invln2 * x - 0.5);
+    const double dk = (double)k;
+    const double hi = x - dk * ln2_hi, lo = dk * ln2_lo, r = hi - lo;
+    const double t = r * r;
+    const double c = r - t * (P1 + t * (P2 + t * (P3 + t * (P4 + t * P5))));
+    const double y = 1.0 - ((lo - (r * c) / (2.0 - c)) - hi);
+    return __longlong_as_double(__double_as_longlong(y) + ((long long)k << 52));
+}
+
 // K2  weights: Amplicon::getWeightedLength (Amplicon.cpp:396-400) x Profile::getGCFactor (Profile.cpp:1503-1513)
 __global__ void k_weights(DevAmps fulls, uint32_t n, DevTables tb, RngKey key, uint32_t frag_size, double* __restrict__ w) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -524,33 +540,47 @@ __device__ __noinline__ uint32_t call_global(const uint32_t* __restrict__ subs, 
     return k | (qv << 8);
 }
 
-// phase 1 of Profile::predict: the indel tests of every input base (getIndelSeq, Profile.cpp:1552-1570 / loop 1606-1630).
+// [REMAP] number of event-free bases before the next indel event among the `rem` bases left: the per-base tests of
+// getIndelSeq (Profile.cpp:1552-1570) are i.i.d. with probability p = t_indel / 2^32, so the gap is geometric and ONE draw
+// x gives it: gap >= g <=> x < T[g], T[g] = floor((1-p)^g 2^32) (non-increasing, host-built: scs_tables.h).  Returns rem when
+// no event falls among the bases left (86 % of 150-base reads with the shipped models: one compare).
+__device__ __forceinline__ uint32_t indel_gap(const uint32_t* __restrict__ T, uint32_t x, uint32_t rem) {
+    if (x < T[rem]) return rem;
+    uint32_t lo = 1, hi = rem;                                                     // first g in [1, rem] with x >= T[g] (g = rem qualifies)
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (x >= T[mid]) hi = mid; else lo = mid + 1; }
+    return lo - 1;
+}
+// phase 1 of Profile::predict: the indel events of a read (getIndelSeq, Profile.cpp:1552-1570 / loop 1606-1630): stream A
+// gives, event by event, the gap to the next event and its kind; the length is a keyed Philox draw.
 // put(i, v) stores event i (16 bits).  Returns n' (0 = the read does not fit its slot), the event count and the replay flag.
 struct IndelPass { int n_out; int nev; bool replay; };
 template <class Put>
 __device__ __forceinline__ IndelPass indel_pass(const DevTables& tb, RngKey key, uint32_t aux, uint64_t uid, uint32_t force_replay, uint32_t slot,
                                                 uint32_t* __restrict__ flags, Put put) {
-    const int n = tb.L; const uint32_t t_insert = tb.t_insert, t_indel = tb.t_indel;
+    const int n = tb.L; const uint32_t t_kind = tb.t_kind;
     int nev = 0, delta = 0; bool replay = false;
-    Xoshiro xa; xa.seed(draw4(key, ST_READ, aux, uid, 0));                         // stream A: the indel tests, in visiting order
-    for (int ji = 0; ji < n;) {
-        const uint32_t w0 = xa.next();
-        if (w0 < t_insert) {                                                       // p <= insertRate
-            const uint32_t k = rand_indx_thr(tb.ins_t, tb.ins_d, (uint32_t)tb.n_ins, draw4(key, ST_INDEL_LEN, aux, uid, (uint32_t)ji).w[0]);
+    Xoshiro xa; xa.seed(draw4(key, ST_READ, aux, uid, 0));                         // stream A: gap, kind, gap, kind, ...
+    if (tb.t_indel) for (int ji = 0; ji < n;) {
+        ji += (int)indel_gap(tb.gap_t, xa.next(), (uint32_t)(n - ji));
+        if (ji >= n) break;
+        const uint32_t y = xa.next();                                              // an event at base ji: insertion | deletion in the ratio of their rates
+        const uint32_t x = draw4(key, ST_INDEL_LEN, aux, uid, (uint32_t)ji).w[0];
+        if (y < t_kind) {
+            const uint32_t k = rand_indx_thr(tb.ins_t, tb.ins_d, (uint32_t)tb.n_ins, x);
             if (k > 0) {
                 if (nev < EV_MAX && ji < 1024 && k < 32u) put(nev, ev_pack((uint32_t)ji, 0u, k)); else replay = true;
                 ++nev; delta += (int)k;
             }
             ++ji;
-        } else if (w0 < t_indel) {                                                 // [REMAP] the same draw: p < delRate/(1-insertRate) rescaled to the draws left
-            const uint32_t k = rand_indx_thr(tb.del_t, tb.del_d, (uint32_t)tb.n_del, draw4(key, ST_INDEL_LEN, aux, uid, (uint32_t)ji).w[0]);
+        } else {
+            const uint32_t k = rand_indx_thr(tb.del_t, tb.del_d, (uint32_t)tb.n_del, x);
             if (k > 0) {
                 const int kk = (int)k < n - ji ? (int)k : n - ji;
                 if (nev < EV_MAX && ji < 1024 && kk < 32) put(nev, ev_pack((uint32_t)ji, 1u, (uint32_t)kk)); else replay = true;
                 ++nev; delta -= kk; ji += kk;
             }
             else ++ji;
-        } else ++ji;
+        }
     }
     if (force_replay && nev > 0) replay = true;
     if (n + delta < 50) { nev = 0; delta = 0; replay = false; }                    // Profile.cpp:1623-1630: drop all indels
@@ -687,7 +717,6 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
     // the table descriptor is a by-value kernel argument: pointers loaded from the kernarg segment are known to be
     // global (a descriptor fetched through a pointer makes every table access a FLAT load)
     const int n = tb.L, B = tb.bins;
-    const uint32_t t_insert = tb.t_insert, t_indel = tb.t_indel;
     const uint32_t WS = win_stride((uint32_t)n);
     Bin* s_ring = reinterpret_cast<Bin*>(s_dyn);                           // [SLOTS]
     int64_t* s_gbase = reinterpret_cast<int64_t*>(s_dyn);                  // [RB]  staging only: aliases the ring, which is filled later
@@ -817,7 +846,7 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
     const uint32_t aux = rd | (att << 1);
     LdsU16* my_ev = (LdsU16*)(s_ev + tid * EV_MAX);
     LdsU32* my_xa = (LdsU32*)(s_ev + tid * EV_MAX);                                // the same 16 bytes, as a stream-A state (replayed reads)
-    int nev = 0, n_out = 0; bool replay = false;
+    int nev = 0, n_out = 0; bool replay = false; uint32_t replay_first = 0;
     if (live) {
         if (FROM_PAIRS) {
             const uint32_t h = ev_hdr[r]; const uint4 e = ev_dat[r];
@@ -827,8 +856,9 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
             const IndelPass ip = indel_pass(tb, key, aux, uid, force_replay, slot, flags, [&](int i, uint32_t v) { my_ev[i] = (uint16_t)v; });
             n_out = ip.n_out; nev = ip.nev; replay = ip.replay;
         }
-        if (replay) {                                                              // phase 2 draws the tests again: stream A from its start
+        if (replay) {                                                              // phase 2 draws the events again: stream A from its start
             Xoshiro xa; xa.seed(draw4(key, ST_READ, aux, uid, 0));
+            replay_first = indel_gap(tb.gap_t, xa.next(), (uint32_t)n);             // where the first event sits
             my_xa[0] = xa.s0; my_xa[1] = xa.s1; my_xa[2] = xa.s2; my_xa[3] = xa.s3;
         }
     }
@@ -845,7 +875,7 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
     const bool ring_subs_ok = FROM_PAIRS ? true : !second;
     const uint32_t* __restrict__ ring_src = FROM_PAIRS ? subs : tb.subs1;
     int ji = 0, jo = 0, ins_left = 0, evi = 0;
-    uint32_t next_ev = replay ? 0u : nev > 0 ? ev_pos(my_ev[0]) : 0xFFFFFFFFu;     // input position of the next indel event (replayed reads: every base)
+    uint32_t next_ev = replay ? replay_first : nev > 0 ? ev_pos(my_ev[0]) : 0xFFFFFFFFu;   // input position of the next indel event
     // binIndx = j*binCount/n' (Profile.cpp:1668) as a multiply-high: exact while j*binCount*n' < 2^32 (checked on the host)
     const uint32_t mdiv = n_out > 0 ? 0xFFFFFFFFu / (uint32_t)n_out + 1u : 0u;     // ceil(2^32 / n')
     uint32_t nb = 0;                                                               // bin of my position jo
@@ -977,22 +1007,27 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
             if (mine && (ins_left > 0 || (uint32_t)ji == next_ev)) {               // rare lanes: inside an insertion / at an indel event
                 if (ins_left > 0) { c2 = scale_draw(xb.next(), 0, 3); --ins_left; }   // inserted base: randomInteger(0, N-1) -> never 'T'
                 else {
-                    if (replay) {                                                  // the indel tests of phase 1, drawn again (same stream, same order)
+                    if (replay) {                                                  // the events of phase 1, drawn again (same stream, same order)
                         Xoshiro xa; xa.s0 = my_xa[0]; xa.s1 = my_xa[1]; xa.s2 = my_xa[2]; xa.s3 = my_xa[3];
-                        while (ji < n) {
-                            const uint32_t w0 = xa.next();
-                            if (w0 < t_insert) {
-                                ins_left = (int)rand_indx_thr(tb.ins_t, tb.ins_d, (uint32_t)tb.n_ins, draw4(key, ST_INDEL_LEN, aux, uid, (uint32_t)ji).w[0]);
-                                break;
+                        for (;;) {                                                 // an event at base ji
+                            const uint32_t y = xa.next();
+                            const uint32_t x = draw4(key, ST_INDEL_LEN, aux, uid, (uint32_t)ji).w[0];
+                            if (y < tb.t_kind) ins_left = (int)rand_indx_thr(tb.ins_t, tb.ins_d, (uint32_t)tb.n_ins, x);
+                            else {
+                                const uint32_t k = rand_indx_thr(tb.del_t, tb.del_d, (uint32_t)tb.n_del, x);
+                                if (k > 0) {                                       // the walk resumes behind the deleted bases, which may start with an event again
+                                    ji += (int)k < n - ji ? (int)k : n - ji;
+                                    const uint32_t gq = ji < n ? indel_gap(tb.gap_t, xa.next(), (uint32_t)(n - ji)) : 1u;
+                                    if (gq == 0) continue;
+                                    c2 = win_get(my_win, ji); next_ev = (uint32_t)ji + gq; ++ji;
+                                    break;
+                                }
                             }
-                            if (w0 < t_indel) {
-                                const uint32_t k = rand_indx_thr(tb.del_t, tb.del_d, (uint32_t)tb.n_del, draw4(key, ST_INDEL_LEN, aux, uid, (uint32_t)ji).w[0]);
-                                if (k > 0) { ji += (int)k < n - ji ? (int)k : n - ji; continue; }
-                            }
+                            c2 = win_get(my_win, ji); ++ji;                         // base ji is kept (an insertion follows it, or nothing happened)
+                            next_ev = ji < n ? (uint32_t)ji + indel_gap(tb.gap_t, xa.next(), (uint32_t)(n - ji)) : 0xFFFFFFFFu;
                             break;
                         }
                         my_xa[0] = xa.s0; my_xa[1] = xa.s1; my_xa[2] = xa.s2; my_xa[3] = xa.s3;
-                        c2 = win_get(my_win, ji); ++ji; next_ev = (uint32_t)ji;    // a replayed read stops here at every base
                     } else {
                         while (evi < nev) {                                        // deletions starting here
                             const uint32_t ev = my_ev[evi];
@@ -1098,7 +1133,7 @@ __global__ void k_philox(const uint32_t* __restrict__ ctr, uint32_t n, RngKey ke
 }
 __global__ void k_detlog(const double* __restrict__ x, uint32_t n, double* __restrict__ out) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = det_log(x[i]);
+    if (i < n) out[i] = x[i] <= 0 ? det_exp(x[i]) : det_log(x[i]);   // the test entry serves both: arguments <= 0 go to det_exp
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1140,15 +1175,24 @@ __device__ __forceinline__ void poisson_semis_block(uint32_t block, DevAmps semi
     unsigned long long ks = 0;
     if (i >= n_semis && i <= n_cap) budget_s[i] = 0;                               // the scan runs over n_cap + 1 entries
     if (i < n_semis) {
-        const double log2 = -poisson_lambda(p, sl_len(semis.sl[i]));
+        const double lambda = poisson_lambda(p, sl_len(semis.sl[i])), log2 = -lambda;
         const uint64_t tuid = semis.uid[i];
         const uint32_t aux = 1u | (p.call << 1);
-        long x = -1; double log1 = 0; uint32_t n = 0; U4 d;
-        do {
-            if ((n & 3) == 0) d = draw4(p.key, ST_POISSON, aux, tuid, n >> 2);
-            const double u = (double)d.w[n & 3] / 4294967296.0; ++n;
-            log1 += det_log(u); ++x;
-        } while (log1 >= log2);
+        long x = -1; uint32_t n = 0; U4 d;
+        if (lambda <= 256.0) {                                                     // [REMAP] product form: p *= u until p < exp(-lambda)
+            const double L = det_exp(log2); double pr = 1.0;
+            do {
+                if ((n & 3) == 0) d = draw4(p.key, ST_POISSON, aux, tuid, n >> 2);
+                pr = pr * ((double)d.w[n & 3] / 4294967296.0); ++n; ++x;
+            } while (pr >= L);
+        } else {
+            double log1 = 0;
+            do {
+                if ((n & 3) == 0) d = draw4(p.key, ST_POISSON, aux, tuid, n >> 2);
+                const double u = (double)d.w[n & 3] / 4294967296.0; ++n;
+                log1 += det_log(u); ++x;
+            } while (log1 >= log2);
+        }
         budget_s[i] = (uint32_t)x & 0xFFFu; semis.primers[i] = (uint16_t)((uint32_t)x & 0xFFFu);      // 12-bit field (Amplicon.cpp:76-79)
         ks = (unsigned long long)x;
     }

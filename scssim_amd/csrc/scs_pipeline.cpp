@@ -153,7 +153,7 @@ struct scs_ctx {
     RngKey key{0, 0};
     // model
     ProfileTables prof; bool have_profile = false; DevTables dtb{};
-    DevBuf d_tables, t_qcompact, t_guide, t_subs1, t_subs2, t_qual, t_ins, t_del, t_isize, d_subs1, d_subs2, d_qual, d_ins, d_del, d_isize, d_gcmeans;
+    DevBuf d_tables, t_gap, t_qcompact, t_guide, t_subs1, t_subs2, t_qual, t_ins, t_del, t_isize, d_subs1, d_subs2, d_qual, d_ins, d_del, d_isize, d_gcmeans;
     // genome + fragments
     DevBuf gx_gc_bits, gx_n_bits, gx_gc_cnt, gx_n_cnt, gx_gc_pref, gx_n_pref, d_binom;
     std::vector<FastaRecord> recs; bool have_genome = false; DevBuf genome; std::vector<uint64_t> rec_off, rec_len; uint64_t genome_bases = 0;   // recs: names only once staged
@@ -282,13 +282,13 @@ void do_load_profile(scs_ctx* c, const char* path) {
     load_profile(path, c->cfg.paired != 0, c->cfg.isize, c->prof);
     ProfileTables& P = c->prof; hipStream_t s = c->stream;
     upload(c->t_subs1, P.subs1_t, s); upload(c->t_subs2, P.subs2_t, s); upload(c->t_qual, P.qual_t, s);
-    upload(c->t_guide, P.qual_guide, s); upload(c->t_qcompact, P.qual_compact, s); upload(c->t_ins, P.ins_t, s); upload(c->t_del, P.del_t, s); upload(c->t_isize, P.isize_t, s);
+    upload(c->t_guide, P.qual_guide, s); upload(c->t_qcompact, P.qual_compact, s); upload(c->t_ins, P.ins_t, s); upload(c->t_del, P.del_t, s); upload(c->t_isize, P.isize_t, s); upload(c->t_gap, P.gap_t, s);
     upload(c->d_subs1, P.subs1, s); upload(c->d_subs2, P.subs2, s); upload(c->d_qual, P.qual, s);
     upload(c->d_ins, P.ins_cdf, s); upload(c->d_del, P.del_cdf, s); upload(c->d_isize, P.isize_cdf, s);
     std::vector<double> gm(P.gc_means, P.gc_means + 101); upload(c->d_gcmeans, gm, s);
     HIP_OK(hipStreamSynchronize(s));
     DevTables& t = c->dtb;
-    t.L = P.read_length; t.bins = P.bins; t.t_insert = P.t_insert; t.t_delete = P.t_delete; t.t_indel = P.t_indel; t.t_ber = threshold_lt(c->cfg.ber);
+    t.L = P.read_length; t.bins = P.bins; t.t_insert = P.t_insert; t.t_delete = P.t_delete; t.t_indel = P.t_indel; t.t_ber = threshold_lt(c->cfg.ber); t.gap_t = c->t_gap.as<uint32_t>(); t.t_kind = P.t_kind;
     t.subs1 = c->t_subs1.as<uint32_t>(); t.subs2 = P.have_cdf2 ? c->t_subs2.as<uint32_t>() : nullptr; t.qual = c->t_qual.as<uint32_t>(); t.qual_guide = c->t_guide.as<uint8_t>(); t.qual_compact = c->t_qcompact.as<uint4>(); t.qual_big = P.qual_big ? 1 : 0;
     t.ins_t = c->t_ins.as<uint32_t>(); t.n_ins = (int)P.ins_t.size(); t.del_t = c->t_del.as<uint32_t>(); t.n_del = (int)P.del_t.size();
     t.isize_t = c->t_isize.as<uint32_t>(); t.n_isize = (int)P.isize_t.size(); t.isize_min = P.isize_min;
@@ -868,7 +868,7 @@ void scs_destroy(scs_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->cfg.device);
     (void)hipStreamSynchronize(c->stream);
-    for (DevBuf* b : {&c->d_tables, &c->t_qcompact, &c->t_guide, &c->t_subs1, &c->t_subs2, &c->t_qual, &c->t_ins, &c->t_del, &c->t_isize, &c->d_subs1, &c->d_subs2, &c->d_qual, &c->d_ins, &c->d_del,
+    for (DevBuf* b : {&c->d_tables, &c->t_gap, &c->t_qcompact, &c->t_guide, &c->t_subs1, &c->t_subs2, &c->t_qual, &c->t_ins, &c->t_del, &c->t_isize, &c->d_subs1, &c->d_subs2, &c->d_qual, &c->d_ins, &c->d_del,
                       &c->d_isize, &c->d_gcmeans, &c->genome, &c->gx_gc_bits, &c->gx_n_bits, &c->gx_gc_cnt, &c->gx_n_cnt, &c->gx_gc_pref, &c->gx_n_pref, &c->d_binom, &c->df_blob, &c->df_primers, &c->primer_cnt, &c->primer_delta,
                       &c->slots, &c->slot_tmpl, &c->valid, &c->valid_off, &c->valid_f, &c->valid_off_f, &c->scan_tmp, &c->flags, &c->weights, &c->read_numbers,
                       &c->pair_off, &c->pairs, &c->odd_before, &c->a_part, &c->a_tp, &c->a_probs, &c->a_quota, &c->a_poff, &c->a_plan, &c->a_crn, &c->a_scratch, &c->a_brow, &c->a_bmap, &c->a_send, &c->a_gath, &c->a_odd, &c->d_hostred, &c->d_tot, &c->d_stage, &c->d_mail, &c->budget_f, &c->budget_s, &c->slot_off_f,

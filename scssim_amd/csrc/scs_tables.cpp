@@ -252,6 +252,7 @@ void load_profile(const std::string& path, bool paired, int isize, ProfileTables
     T.t_insert = threshold_le(T.insert_rate);
     T.t_delete = threshold_lt(T.del_rate / (1 - T.insert_rate));
     T.t_indel = T.t_insert + (uint32_t)((((1ull << 32) - T.t_insert) * (uint64_t)T.t_delete) >> 32);
+    T.gap_t = indel_gap_table(T.t_indel, T.read_length); T.t_kind = indel_kind_threshold(T.t_insert, T.t_indel);
 }
 
 // ---------------------------------------------------------------- FASTA
@@ -266,6 +267,17 @@ static std::string index_name(const std::string& header) {      // Fasta.cpp:56-
     i = nm.find("chr");
     if (i != std::string::npos) return nm.substr(i + 3);
     return nm;
+}
+std::vector<uint32_t> indel_gap_table(uint32_t t_indel, int read_length) {
+    std::vector<uint32_t> t((size_t)read_length + 1, 0xFFFFFFFFu);
+    const double q = 1.0 - (double)t_indel / 4294967296.0; double pw = 1.0;
+    for (int g = 1; g <= read_length; ++g) { pw = pw * q; const double v = std::floor(pw * 4294967296.0); t[(size_t)g] = v >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)v; }
+    return t;
+}
+uint32_t indel_kind_threshold(uint32_t t_insert, uint32_t t_indel) {
+    if (t_indel == 0) return 0;
+    const double v = std::floor(4294967296.0 * ((double)t_insert / (double)t_indel));
+    return v >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)v;
 }
 void encode_record(const char* name, const char* seq, uint64_t len, FastaRecord& out) {
     out.name = index_name(name);

@@ -40,7 +40,15 @@ struct ProfileTables {
     // [REMAP] both tests from ONE draw x: x < t_insert -> insertion, else x < t_indel -> deletion, with the deletion
     // threshold rescaled to the draws left: t_indel = t_insert + ((2^32 - t_insert) * t_delete >> 32)
     uint32_t t_indel = 0;
+    // [REMAP] the indel tests of a read are i.i.d. Bernoulli(p = t_indel / 2^32) per visited base, so the number of
+    // event-free bases before the next event is geometric: gap >= g  <=>  x < gap_t[g], gap_t[g] = floor((1-p)^g * 2^32),
+    // g = 0 .. read_length (gap_t[0] = 2^32 - 1); one draw per EVENT instead of one per base.  Given an event it is an
+    // insertion when a second draw y < t_kind = floor(2^32 * t_insert / t_indel), else a deletion.
+    std::vector<uint32_t> gap_t; uint32_t t_kind = 0;
 };
+// shared with the oracle: the same loop in the same IEEE operations
+std::vector<uint32_t> indel_gap_table(uint32_t t_indel, int read_length);
+uint32_t indel_kind_threshold(uint32_t t_insert, uint32_t t_indel);
 
 // count of 32-bit draws x with (x / 2^32) < c  resp. <= c, clamped to 2^32-1
 uint32_t threshold_lt(double c);

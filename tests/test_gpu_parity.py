@@ -51,6 +51,14 @@ def test_det_log_device_bitwise(oracle_lib):
     got = g.det_log(x)
     want = np.array([oracle_lib.scso_det_log(float(v)) for v in x])
     assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
+    # det_exp (arguments <= 0 of the same entry point): the exp(-lambda) of the product-form Poisson draw
+    oracle_lib.scso_det_exp.restype = ctypes.c_double
+    oracle_lib.scso_det_exp.argtypes = [ctypes.c_double]
+    y = -np.concatenate([rng.random(20000) * 256, rng.random(5000) * 12, [0.0, 1e-12, 0.6931471805599453, 255.999, 256.0]])
+    got = g.det_log(y)
+    want = np.array([oracle_lib.scso_det_exp(float(v)) for v in y])
+    assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
+    assert np.max(np.abs(got - np.exp(y)) / np.exp(y)) < 4e-16
 
 
 @pytest.mark.parametrize("model", MODELS)

@@ -117,6 +117,16 @@ def _fnv(seq):
     return h
 
 
+def test_det_exp_is_accurate(oracle_lib):
+    oracle_lib.scso_det_exp.restype = ctypes.c_double
+    oracle_lib.scso_det_exp.argtypes = [ctypes.c_double]
+    rng = np.random.default_rng(5)
+    x = -np.concatenate([rng.random(5000) * 256, rng.random(2000) * 10, [0.0, 256.0]])
+    got = np.array([oracle_lib.scso_det_exp(float(v)) for v in x])
+    assert np.max(np.abs(got - np.exp(x)) / np.exp(x)) < 4e-16
+    assert oracle_lib.scso_det_exp(-300.0) == 0.0 and oracle_lib.scso_det_exp(0.0) == 1.0
+
+
 def test_fasta_staging_edge_cases(tmp_path):
     """mmap/memchr FASTA staging (lib/fastahack/Fasta.cpp:45-215 semantics): names lose a chr/chrom prefix and anything
     after the first blank; CRLF, comments, blank lines, lower case, a missing final newline and empty records are handled."""
