@@ -717,6 +717,35 @@ std::vector<uint64_t> binom_table(double ber, int n_min, int n_max) {
     return T;
 }
 
+// [REMAP] attach tries in counter mode.  A try of the reference (Fragment.cpp:76-82) draws spos uniformly from [27, len) and
+// the length from [amin, amax]; it fails outright when spos + alen > len.  Such tries are i.i.d., so (a) the number of them
+// before a try that fits is geometric with failure probability 1 - N/M and (b) the try that fits is uniform over the N
+// feasible pairs: every spos <= len - amax admits all W lengths (A positions), then position len - amin + 1 - d admits d
+// lengths, d = 1 .. D.
+struct AttachFit { uint32_t A, W, D, N; };
+AttachFit attach_fit_count(uint32_t len, uint32_t amin, uint32_t amax) {
+    AttachFit f; f.W = amax - amin + 1u;
+    f.A = len >= amax + 27u ? len - amax - 26u : 0u;
+    f.D = (len - amin - 26u) - f.A;
+    f.N = f.A * f.W + f.D * (f.D + 1u) / 2u;
+    return f;
+}
+void attach_fit_decode(const AttachFit& f, uint32_t len, uint32_t amin, uint32_t r, unsigned& spos, unsigned& alen) {
+    const uint32_t full = f.A * f.W;
+    if (r < full) { spos = 27u + r / f.W; alen = amin + r % f.W; return; }
+    const uint32_t q = r - full;
+    uint32_t d = (uint32_t)((1.0 + sqrt(1.0 + 8.0 * (double)q)) * 0.5);
+    while (d > 1u && d * (d - 1u) / 2u > q) --d;
+    while (d * (d + 1u) / 2u <= q) ++d;
+    alen = amin + (q - d * (d - 1u) / 2u);
+    spos = len - amin + 1u - d;
+}
+uint32_t attach_gap(double u, double qfail) {                                       // P(gap >= g) = qfail^g, capped at 51
+    double acc = qfail; uint32_t g = 0;
+    while (g < 51u && u < acc) { acc = acc * qfail; ++g; }
+    return g;
+}
+
 // ---- a4/a5: Fragment::amplify (Fragment.cpp:52-137) / Amplicon::amplify (Amplicon.cpp:156-240) --
 // T = template strand (c(F) or c(S)); appends created amplicons in creation order.
 void amplify_template(Sim& S, Rng& rng, PrimerPool& pool, bool fromFrag, uint64_t tuid, uint32_t parent,
@@ -732,9 +761,24 @@ void amplify_template(Sim& S, Rng& rng, PrimerPool& pool, bool fromFrag, uint64_
         // every try takes two draws from it (position, then length)
         Xoshiro xt;
         if (rng.counter) { uint32_t c[4] = {i, (uint32_t)tuid, (uint32_t)(tuid >> 32), ST_ATTACH | (aux << 8)}, o[4]; philox(c, rng.key, o); xt.seed(o); }
+        if (rng.counter) {
+            // [REMAP] the tries that do not fit are i.i.d.: their number before a fitting try is geometric (one draw), and the
+            // fitting try is uniform over the feasible (position, length) pairs (a 64-bit draw); tries that fit but land on
+            // an attached position or a primer type without stock fail as in the reference and count as tries
+            const AttachFit fit = attach_fit_count(length, (uint32_t)p.ampMin, (uint32_t)p.ampMax);
+            const double qfail = 1.0 - (double)fit.N / ((double)(length - 27) * (double)fit.W);
+            do {
+                tryTimes += (int)attach_gap(((double)xt.next() + 0.5) / 4294967296.0, qfail) + 1;
+                if (tryTimes > 50) break;
+                const uint64_t hi = xt.next(), lo = xt.next(), x64 = (hi << 32) | lo;
+                attach_fit_decode(fit, length, (uint32_t)p.ampMin, (uint32_t)(((unsigned __int128)x64 * fit.N) >> 64), spos, alen);
+                if (posAttached[spos] == 1) continue;
+                if (pool.take(T + spos)) break;
+            } while (1);
+        } else
         do {
-            const double u1 = rng.counter ? xt.next() / 4294967296.0 : rng.integer(Key{});
-            const double u2 = rng.counter ? xt.next() / 4294967296.0 : rng.real(Key{});
+            const double u1 = rng.integer(Key{});
+            const double u2 = rng.real(Key{});
             spos = (unsigned)(long)(27 + ((long)length - 27) * u1);
             alen = (unsigned)(p.ampMin + (double)(p.ampMax + 1 - p.ampMin) * u2);
             tryTimes++;

@@ -8,6 +8,7 @@
 // The stage list and the meaning of idx/aux/word per draw site are below.
 #pragma once
 #include <stdint.h>
+#include <math.h>
 
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
@@ -92,6 +93,39 @@ SCS_HD U4 draw4(RngKey key, uint32_t stage, uint32_t aux, uint64_t uid, uint32_t
 // returns the same value as the reference's double arithmetic.
 SCS_HD uint32_t scale_draw(uint32_t x, uint32_t start, uint32_t span) {
     return start + (uint32_t)(((uint64_t)span * x) >> 32);
+}
+
+// [REMAP] attach tries (Fragment.cpp:73-95, Amplicon.cpp:176-198).  A try draws spos uniformly from [27, len) and the
+// amplicon length from [amin, amax] and fails outright when spos + alen > len; those tries are i.i.d., so the number of
+// them before a FITTING try is geometric and the fitting try is uniform over the feasible pairs.  The feasible set of a
+// template of length len: the spos <= len - amax take every length (A positions x W lengths), then a triangle in which
+// the position len - amin + 1 - d admits d lengths (d = 1 .. D).  attach_fit_count = its size N (< 2^32 for len < 2^21);
+// attach_fit_decode maps r in [0, N) to the pair.
+struct AttachFit { uint32_t A, W, D, N; };
+SCS_HD AttachFit attach_fit_count(uint32_t len, uint32_t amin, uint32_t amax) {
+    AttachFit f; f.W = amax - amin + 1u;
+    f.A = len >= amax + 27u ? len - amax - 26u : 0u;                              // spos = 27 .. len - amax
+    const uint32_t d1 = len - amin - 26u;                                         // positions 27 .. len - amin in all (len >= amin + 27)
+    f.D = d1 - f.A;                                                               // the rest of them form the triangle: D <= W - 1
+    f.N = f.A * f.W + f.D * (f.D + 1u) / 2u;
+    return f;
+}
+SCS_HD void attach_fit_decode(const AttachFit& f, uint32_t len, uint32_t amin, uint32_t r, uint32_t& spos, uint32_t& alen) {
+    const uint32_t full = f.A * f.W;
+    if (r < full) { spos = 27u + r / f.W; alen = amin + r % f.W; return; }
+    const uint32_t q = r - full;                                                  // q in [0, D(D+1)/2): row d holds d entries, rows 1, 2, .. D
+    uint32_t d = (uint32_t)((1.0 + sqrt(1.0 + 8.0 * (double)q)) * 0.5);
+    while (d > 1u && d * (d - 1u) / 2u > q) --d;                                  // exact whatever the rounding of the square root
+    while (d * (d + 1u) / 2u <= q) ++d;
+    alen = amin + (q - d * (d - 1u) / 2u);
+    spos = len - amin + 1u - d;
+}
+// number of non-fitting tries before the next fitting one, capped at 51 (> 50 tries kill the primer): u uniform in (0, 1),
+// qfail = 1 - N / M.  P(gap >= g) = qfail^g, evaluated by repeated multiplication (the same IEEE products everywhere).
+SCS_HD uint32_t attach_gap(double u, double qfail) {
+    double acc = qfail; uint32_t g = 0;
+    while (g < 51u && u < acc) { acc = acc * qfail; ++g; }
+    return g;
 }
 
 // base codes: 0..3 = ACGT, 4 = N / anything else (MyDefine.cpp:352-367: complement of non-ACGT is 'N')

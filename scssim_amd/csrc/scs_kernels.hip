@@ -1280,6 +1280,8 @@ __global__ void __launch_bounds__(64) k_attach(const uint8_t* __restrict__ g, De
     __builtin_amdgcn_wave_barrier();
     uint32_t v = 0, c0 = 0, i = 0, tries = 0, spos = 0, alen = 0, pidx = 0;
     bool fresh = true, unresolved = false, need = false, dead = false;
+    const AttachFit fit = group_done ? AttachFit{0, 1, 0, 1} : attach_fit_count(len, p.amp_min, p.amp_max);
+    const double qfail = 1.0 - (double)fit.N / ((double)(len > 27 ? len - 27 : 1) * (double)fit.W);   // P(a try does not fit)
     unsigned long long lsum = 0; Xoshiro xt{};                                     // [REMAP] primer i's try stream, seeded by Philox block i
     while (__ballot(!group_done)) {
         if (!group_done) {
@@ -1288,14 +1290,15 @@ __global__ void __launch_bounds__(64) k_attach(const uint8_t* __restrict__ g, De
                 if (!need && ((bits[spos >> 5] >> (spos & 31)) & 1u)) need = true;       // a lower primer took this position meanwhile
                 while (need) {
                     // (a) my stream's next try that fits the template and lands on a free position: draws and LDS only, so the
-                    // lanes of the wave run it together without a memory wait per try ...
+                    // lanes of the wave run it together without a memory wait per candidate ...
                     bool cand = false;
                     while (!cand) {
-                        spos = scale_draw(xt.next(), 27, len - 27);                                   // randomInteger(27, length)
-                        alen = scale_draw(xt.next(), p.amp_min, p.amp_max + 1 - p.amp_min);           // (uint) randomDouble(minLen, maxLen+1)
-                        ++tries;
+                        // [REMAP] the tries that do not fit the template are skipped in one step: their number is geometric ...
+                        tries += attach_gap(((double)xt.next() + 0.5) / 4294967296.0, qfail) + 1u;
                         if (tries > 50) { dead = true; break; }
-                        if (spos + alen > len) continue;
+                        // ... and the try that fits is uniform over the feasible (position, length) pairs
+                        const unsigned long long x64 = ((unsigned long long)xt.next() << 32) | xt.next();
+                        attach_fit_decode(fit, len, p.amp_min, (uint32_t)__umul64hi(x64, (unsigned long long)fit.N), spos, alen);
                         if ((bits[spos >> 5] >> (spos & 31)) & 1u) continue;              // posAttached[spos]
                         cand = true;
                     }
