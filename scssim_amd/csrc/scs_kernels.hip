@@ -595,20 +595,23 @@ __device__ __forceinline__ IndelPass indel_pass(const DevTables& tb, RngKey key,
 //      header {n' | events << 16 | replay << 24 | live << 25} go to global memory.
 __global__ void __launch_bounds__(256) k_indels(const PairRec* __restrict__ pairs, uint32_t np, int paired, const DevTables tb, RngKey key, uint32_t slot,
                                                 uint32_t force_replay, uint32_t* __restrict__ ev_hdr, uint4* __restrict__ ev_dat,
-                                                uint32_t* __restrict__ sizes1, uint32_t* __restrict__ sizes2, uint32_t* __restrict__ flags) {
+                                                uint32_t* __restrict__ sizes1, uint32_t* __restrict__ sizes2, uint32_t* __restrict__ cls1, uint32_t* __restrict__ cls2,
+                                                uint32_t* __restrict__ flags) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t nreads = paired ? 2 * np : np;
     if (r >= nreads) return;
     const uint32_t pi = paired ? r >> 1 : r, rd = paired ? (r & 1u) : 0u;
     const uint64_t uid = pairs[pi].uid; const uint32_t att = pairs[pi].att, isz = pairs[pi].isz, amp = pairs[pi].amp;
     uint32_t* sz = rd ? sizes2 : sizes1;
-    if (isz == 0) { ev_hdr[r] = 0; sz[pi] = 0; return; }                            // hole: the insert-size loop gave up (Amplicon.cpp:484-489)
+    uint32_t* cls = rd ? cls2 : cls1;                                              // 1: the read has indel events (k_reads' general variant), 0: it has none
+    if (isz == 0) { ev_hdr[r] = 0; sz[pi] = 0; cls[pi] = 0; return; }               // hole: the insert-size loop gave up (Amplicon.cpp:484-489)
     unsigned long long e_lo = 0, e_hi = 0;
     const IndelPass ip = indel_pass(tb, key, rd | (att << 1), uid, force_replay, slot, flags, [&](int i, uint32_t v) {
         if (i < 4) e_lo |= (unsigned long long)v << (16 * i); else e_hi |= (unsigned long long)v << (16 * (i - 4));
     });
     ev_hdr[r] = (uint32_t)ip.n_out | ((uint32_t)ip.nev << 16) | (ip.replay ? 1u << 24 : 0u) | (1u << 25);
     ev_dat[r] = make_uint4((uint32_t)e_lo, (uint32_t)(e_lo >> 32), (uint32_t)e_hi, (uint32_t)(e_hi >> 32));
+    cls[pi] = (ip.nev > 0 || ip.replay) ? 1u : 0u;
     // "@<ampIdx>#<fragCount>[/1|/2]\n" + seq + "\n+\n" + qual + "\n"   (Amplicon.cpp:459-466,497-504)
     sz[pi] = ip.n_out == 0 ? 0u : 1u + dec_digits(amp) + 1u + dec_digits(att + 1) + (paired ? 2u : 0u) + 1u + 2u * (uint32_t)ip.n_out + 4u;
 }
@@ -701,7 +704,11 @@ struct BlockOut {
     }
 };
 
-template <bool FROM_PAIRS, bool QBIG>
+// CLS: 0 = the workgroup takes 256 consecutive pairs; 1 / 2 = it takes 256 consecutive entries of a LIST of pair indices:
+// the reads without any indel event (CLS 1: 86 % of 150-base reads with the shipped models) and the rest (CLS 2), split
+// by k_read_lists from k_indels' result.  The event-free reads need none of the event handling -- no lookahead for the
+// next event, exactly one output position per table bin -- and their waves run with every lane busy at every bin.
+template <bool FROM_PAIRS, bool QBIG, int CLS>
 __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, DevErrPool spool, DevErrPool fpool, const PairRec* __restrict__ pairs,
                                               uint32_t np, int paired, const uint8_t* __restrict__ windows, const uint64_t* __restrict__ uids,
                                               const uint32_t* __restrict__ atts, const uint8_t* __restrict__ is_read1, uint32_t n_explicit,
@@ -709,7 +716,9 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
                                               const uint32_t* __restrict__ ev_hdr, const uint4* __restrict__ ev_dat,
                                               const uint64_t* __restrict__ off1, const uint64_t* __restrict__ off2, char* __restrict__ out1, char* __restrict__ out2,
                                               uint32_t amp_index_base, char* __restrict__ slot_b, char* __restrict__ slot_q, uint32_t* __restrict__ lens,
-                                              uint32_t* __restrict__ flags, uint64_t cap1, uint64_t cap2) {
+                                              uint32_t* __restrict__ flags, uint64_t cap1, uint64_t cap2,
+                                              const uint32_t* __restrict__ list1, const uint32_t* __restrict__ list2, uint32_t nlist1, uint32_t nlist2) {
+    constexpr bool SIMPLE = CLS == 1;
     typedef RingGeo<QBIG> Geo;
     typedef RingBin<QBIG> Bin;
     constexpr int SLOTS = Geo::SLOTS, GROUP = Geo::GROUP, QROW = Geo::QROW, EPB = 64 + 4 * QROW;   // EPB: 16-byte entries per bin image
@@ -729,7 +738,10 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
     const bool second_file = FROM_PAIRS && paired && (blockIdx.x & 1u);
     const uint64_t* __restrict__ offs = second_file ? off2 : off1;
     char* __restrict__ outp = second_file ? out2 : out1;
-    const uint64_t off0 = FROM_PAIRS ? offs[(paired ? blockIdx.x >> 1 : blockIdx.x) * RB] : 0ull;
+    const uint32_t* __restrict__ wlist = second_file ? list2 : list1;              // CLS != 0: this mate's list
+    const uint32_t nwork = CLS == 0 ? np : (second_file ? nlist2 : nlist1), wq = (paired ? blockIdx.x >> 1 : blockIdx.x) * RB;
+    if (FROM_PAIRS && wq >= nwork) return;                                          // the grid covers the longer of the two mates' lists
+    const uint64_t off0 = FROM_PAIRS ? offs[CLS == 0 ? wq : wlist[wq]] : 0ull;      // lists ascend: the chunk's first record is its lowest
     const uint32_t adj = (uint32_t)(reinterpret_cast<uintptr_t>(outp) + off0) & 31u;
     char* __restrict__ wg_out = outp + off0 - adj;
 
@@ -750,7 +762,8 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
             rel = (uint32_t)(offs[p] - off0) + adj;
         };
         uint32_t keyp = 32u;
-        { const uint32_t p = q * RB + tid; if (p < np) { PairRec o; uint32_t rel, h; record_of(p, o, rel, h); keyp = (rel + h) & 31u; } }
+        auto pair_of = [&](uint32_t e) -> uint32_t { return e < nwork ? (CLS == 0 ? e : wlist[e]) : 0xFFFFFFFFu; };
+        { const uint32_t p = pair_of(q * RB + tid); if (p != 0xFFFFFFFFu) { PairRec o; uint32_t rel, h; record_of(p, o, rel, h); keyp = (rel + h) & 31u; } }
         if (tid < 64) s_cnt[tid] = 0;
         __syncthreads();
         const uint32_t rank = atomicAdd(&s_cnt[keyp], 1u);
@@ -764,7 +777,7 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
         __syncthreads();
         s_perm[s_cnt[keyp] + rank] = (uint32_t)tid;
         __syncthreads();
-        pi = q * RB + s_perm[tid]; valid = pi < np;
+        pi = pair_of(q * RB + s_perm[tid]); valid = pi != 0xFFFFFFFFu;
         r = paired ? 2 * pi + rd : pi;
         if (valid) { record_of(pi, pr, rec_rel, rec_h); uid = pr.uid; att = pr.att; }
         __syncthreads();                                                           // s_perm is read before the staging overwrites it
@@ -850,7 +863,7 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
     if (live) {
         if (FROM_PAIRS) {
             const uint32_t h = ev_hdr[r]; const uint4 e = ev_dat[r];
-            n_out = (int)(h & 0xFFFFu); nev = (int)((h >> 16) & 0xFFu); replay = (h >> 24) & 1u;
+            n_out = (int)(h & 0xFFFFu); nev = SIMPLE ? 0 : (int)((h >> 16) & 0xFFu); replay = SIMPLE ? false : (h >> 24) & 1u;
             my_xa[0] = e.x; my_xa[1] = e.y; my_xa[2] = e.z; my_xa[3] = e.w;          // 8 x 16-bit events
         } else {
             const IndelPass ip = indel_pass(tb, key, aux, uid, force_replay, slot, flags, [&](int i, uint32_t v) { my_ev[i] = (uint16_t)v; });
@@ -1000,11 +1013,12 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
             return true;
         };
         for (;;) {
-            const bool mine = jo < n_out && nb == (uint32_t)t;                     // my position jo falls into bin t
+            // my position jo falls into bin t (an event-free read has n' = binCount: position t, once)
+            const bool mine = SIMPLE ? jo < n_out : (jo < n_out && nb == (uint32_t)t);
             if (!__any(mine)) break;
             // ---- (A) the source base of this output position (Profile.cpp:1632-1654, walked lazily)
             uint32_t c2 = win_get(my_win, ji);                                     // the common case: the next window base
-            if (mine && (ins_left > 0 || (uint32_t)ji == next_ev)) {               // rare lanes: inside an insertion / at an indel event
+            if (!SIMPLE && mine && (ins_left > 0 || (uint32_t)ji == next_ev)) {    // rare lanes: inside an insertion / at an indel event
                 if (ins_left > 0) { c2 = scale_draw(xb.next(), 0, 3); --ins_left; }   // inserted base: randomInteger(0, N-1) -> never 'T'
                 else {
                     if (replay) {                                                  // the events of phase 1, drawn again (same stream, same order)
@@ -1099,8 +1113,9 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
                     }
                     cur_b = 0; cur_q = 0;
                 }
-                ++jo; nb = __umulhi(__umul24((uint32_t)jo, (uint32_t)B), mdiv);
+                ++jo; if (!SIMPLE) nb = __umulhi(__umul24((uint32_t)jo, (uint32_t)B), mdiv);
             }
+            if (SIMPLE) break;
         }
     }
     if (FROM_PAIRS && live && n_out > 0) {
@@ -1169,7 +1184,7 @@ __device__ __forceinline__ double poisson_lambda(const PoissonParams& p, uint32_
 // semis: lambda ~ 6 -> one thread per semi amplicon
 // n_cap: the host's upper bound of the semi count (grid size); the count itself is read from the device scalars
 __device__ __forceinline__ void poisson_semis_block(uint32_t block, DevAmps semis, uint32_t n_cap, const PoissonParams& p, uint32_t* __restrict__ budget_s,
-                                                    unsigned long long* __restrict__ sums) {
+                                                    unsigned long long* __restrict__ part) {
     const uint32_t i = block * blockDim.x + threadIdx.x;
     const uint32_t n_semis = (uint32_t)p.dev[DS_SEMIS_N];
     unsigned long long ks = 0;
@@ -1196,12 +1211,17 @@ __device__ __forceinline__ void poisson_semis_block(uint32_t block, DevAmps semi
         budget_s[i] = (uint32_t)x & 0xFFFu; semis.primers[i] = (uint16_t)((uint32_t)x & 0xFFFu);      // 12-bit field (Amplicon.cpp:76-79)
         ks = (unsigned long long)x;
     }
-    block_add_u64(ks, &sums[1]);
+    // the workgroup's sum goes to its own slot: half a million same-address atomics per call cost more than the draws
+    __shared__ unsigned long long s_w[4];
+    ks = wave_sum_u64(ks);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = ks;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
 }
 // fragments: lambda in the hundreds to thousands -> one 256-thread workgroup per fragment.  A round = 1024 draws: every
 // thread turns one Philox block into four logs (LDS, draw order); then the first wave adds them to log1 IN DRAW ORDER
 // (the rounding of the serial loop), eight at a time with one exit test per eight.
-__device__ __forceinline__ void poisson_frag_block(uint32_t t, DevFrags fr, const PoissonParams& p, uint32_t* __restrict__ budget_f, unsigned long long* __restrict__ sums) {
+__device__ __forceinline__ void poisson_frag_block(uint32_t t, DevFrags fr, const PoissonParams& p, uint32_t* __restrict__ budget_f, unsigned long long* __restrict__ part) {
     __shared__ double s_lg[1024];
     __shared__ int s_more;
     const int tid = threadIdx.x;
@@ -1230,14 +1250,34 @@ __device__ __forceinline__ void poisson_frag_block(uint32_t t, DevFrags fr, cons
         __syncthreads();
         if (!s_more) break;
     }
-    if (tid == 0) { budget_f[t] = (uint32_t)(int)x; atomicAdd(&sums[0], (unsigned long long)x); }
+    if (tid == 0) { budget_f[t] = (uint32_t)(int)x; part[blockIdx.x] = (unsigned long long)x; }
 }
 
 // one launch for both template kinds: workgroups [0, nf) take a fragment each, the rest 256 semi amplicons each
 __global__ void __launch_bounds__(256) k_poisson(DevFrags fr, DevAmps semis, uint32_t n_cap, PoissonParams p, uint32_t* __restrict__ budget_f,
-                                                 uint32_t* __restrict__ budget_s, unsigned long long* __restrict__ sums) {
-    if (blockIdx.x < fr.n) poisson_frag_block(blockIdx.x, fr, p, budget_f, sums);
-    else poisson_semis_block(blockIdx.x - fr.n, semis, n_cap, p, budget_s, sums);
+                                                 uint32_t* __restrict__ budget_s, unsigned long long* __restrict__ part) {
+    if (blockIdx.x < fr.n) poisson_frag_block(blockIdx.x, fr, p, budget_f, part);
+    else poisson_semis_block(blockIdx.x - fr.n, semis, n_cap, p, budget_s, part);
+}
+// *dst += sum of a u64 array (per-workgroup partials)
+__global__ void __launch_bounds__(1024) k_sum_u64_add(const unsigned long long* __restrict__ v, uint32_t n, unsigned long long* __restrict__ dst) {
+    __shared__ unsigned long long s_p[16];
+    unsigned long long a = 0;
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) a += v[i];
+    a = wave_sum_u64(a);
+    if ((threadIdx.x & 63) == 0) s_p[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) { unsigned long long t = 0; for (int k = 0; k < 16; ++k) t += s_p[k]; *dst += t; }
+}
+// sums[0] += budgets of the fragments (workgroups [0, nf)), sums[1] += budgets of the semi amplicons (the rest)
+__global__ void __launch_bounds__(1024) k_poisson_sums(const unsigned long long* __restrict__ part, uint32_t nf, uint32_t nb, unsigned long long* __restrict__ sums) {
+    __shared__ unsigned long long s_p[2][16];
+    unsigned long long a = 0, b = 0;
+    for (uint32_t i = threadIdx.x; i < nb; i += blockDim.x) { const unsigned long long v = part[i]; if (i < nf) a += v; else b += v; }
+    a = wave_sum_u64(a); b = wave_sum_u64(b);
+    if ((threadIdx.x & 63) == 0) { s_p[0][threadIdx.x >> 6] = a; s_p[1][threadIdx.x >> 6] = b; }
+    __syncthreads();
+    if (threadIdx.x < 2) { unsigned long long t = 0; for (int k = 0; k < 16; ++k) t += s_p[threadIdx.x][k]; sums[threadIdx.x] += t; }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1355,7 +1395,7 @@ __global__ void __launch_bounds__(64) k_attach(const uint8_t* __restrict__ g, De
             }
         } else (void)__ballot(false);
     }
-    if (FROM_FRAG) { lsum = wave_sum_u64(lsum); if (lane == 0 && lsum) atomicAdd(len_sum, lsum); }
+    if (FROM_FRAG) { lsum = wave_sum_u64(lsum); if (lane == 0) len_sum[blockIdx.x] = lsum; }   // per fragment; launch_attach_frags adds them up (no same-address atomics)
     if (gl == 0 && t < nt) valid[t] = v;
 }
 
@@ -1643,15 +1683,19 @@ static inline void note_launch(hipError_t e) { if (e != hipSuccess && g_launch_e
 hipError_t take_launch_error() { note_launch(hipGetLastError()); const hipError_t e = g_launch_err; g_launch_err = hipSuccess; return e; }
 
 void launch_attach_frags(hipStream_t s, const uint8_t* g, DevFrags fr, const uint32_t* slot_off, uint32_t* slots, uint32_t* slot_tmpl,
-                         uint32_t* valid, const int64_t* primer_cnt, uint32_t* primer_delta, unsigned long long* len_sum, AmplifyParams p) {
+                         uint32_t* valid, const int64_t* primer_cnt, uint32_t* primer_delta, unsigned long long* len_sum, unsigned long long* len_part, AmplifyParams p) {
     if (fr.n == 0) return;
     DevAmps none{}; DevErrPool np{};
-    hipLaunchKernelGGL((k_attach<true, 64>), dim3(fr.n), dim3(64), 0, s, g, fr, none, 0u, np, slot_off, slots, slot_tmpl, valid, primer_cnt, primer_delta, len_sum, p);
+    hipLaunchKernelGGL((k_attach<true, 64>), dim3(fr.n), dim3(64), 0, s, g, fr, none, 0u, np, slot_off, slots, slot_tmpl, valid, primer_cnt, primer_delta, len_part, p);
+    hipLaunchKernelGGL(k_sum_u64_add, dim3(1), dim3(1024), 0, s, len_part, fr.n, len_sum);
 }
 void launch_poisson(hipStream_t s, DevFrags fr, DevAmps semis, uint32_t n_semis, PoissonParams p, uint32_t* budget_f, uint32_t* budget_s,
-                    unsigned long long* sums) {
+                    unsigned long long* sums, unsigned long long* part) {
     const uint32_t semi_blocks = n_semis ? cdiv((uint64_t)n_semis + 1, 256) : 0u;
-    if (fr.n + semi_blocks) hipLaunchKernelGGL(k_poisson, dim3(fr.n + semi_blocks), dim3(256), 0, s, fr, semis, n_semis, p, budget_f, budget_s, sums);
+    if (fr.n + semi_blocks) {
+        hipLaunchKernelGGL(k_poisson, dim3(fr.n + semi_blocks), dim3(256), 0, s, fr, semis, n_semis, p, budget_f, budget_s, part);
+        hipLaunchKernelGGL(k_poisson_sums, dim3(1), dim3(1024), 0, s, part, fr.n, fr.n + semi_blocks, sums);
+    }
 }
 void launch_alloc_bpack(hipStream_t s, const double* w, const AllocPlan& pl, double* send) {
     hipLaunchKernelGGL(k_alloc_bpack, dim3(2 * ALLOC_SLOTS), dim3(256), 0, s, w, pl, send);
@@ -1780,20 +1824,20 @@ size_t reads_lds_bytes(const DevTables& tb) {
     const size_t ring = tb.qual_big ? RingGeo<true>::SLOTS * sizeof(RingBin<true>) : RingGeo<false>::SLOTS * sizeof(RingBin<false>);
     return ring + (size_t)RB * EV_MAX * 2 + (size_t)RB * win_stride((uint32_t)tb.L);
 }
-template <bool FROM_PAIRS, class... Args>
+template <bool FROM_PAIRS, int CLS, class... Args>
 static void launch_reads_kernel(hipStream_t s, dim3 grid, const DevTables& tb, Args... args) {
     const size_t lds = reads_lds_bytes(tb);
     // > 64 KB of dynamic LDS needs the opt-in; the limit is raised to exactly what this profile needs (once per size:
     // the call sits on the host's critical path of a small job)
-    static size_t opted_all[64][2] = {};                                           // per device (the attribute belongs to the device's code object)
+    static size_t opted_all[64][2] = {};                                           // per device and instantiation (the attribute belongs to the device's code object)
     int dev = 0; (void)hipGetDevice(&dev);
     size_t* opted = opted_all[dev & 63];
     if (tb.qual_big) {
-        if (opted[1] != lds) { note_launch(hipFuncSetAttribute((const void*)k_reads<FROM_PAIRS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); opted[1] = lds; }
-        hipLaunchKernelGGL((k_reads<FROM_PAIRS, true>), grid, dim3(RB), lds, s, args...);
+        if (opted[1] != lds) { note_launch(hipFuncSetAttribute((const void*)k_reads<FROM_PAIRS, true, CLS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); opted[1] = lds; }
+        hipLaunchKernelGGL((k_reads<FROM_PAIRS, true, CLS>), grid, dim3(RB), lds, s, args...);
     } else {
-        if (opted[0] != lds) { note_launch(hipFuncSetAttribute((const void*)k_reads<FROM_PAIRS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); opted[0] = lds; }
-        hipLaunchKernelGGL((k_reads<FROM_PAIRS, false>), grid, dim3(RB), lds, s, args...);
+        if (opted[0] != lds) { note_launch(hipFuncSetAttribute((const void*)k_reads<FROM_PAIRS, false, CLS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); opted[0] = lds; }
+        hipLaunchKernelGGL((k_reads<FROM_PAIRS, false, CLS>), grid, dim3(RB), lds, s, args...);
     }
 }
 static uint32_t reads_force_replay() {                                             // tests: every read with an indel takes the replay path
@@ -1801,34 +1845,57 @@ static uint32_t reads_force_replay() {                                          
     return v;
 }
 void launch_indels(hipStream_t s, const PairRec* pairs, uint32_t np, int paired, DevTables tb, RngKey key, uint32_t slot, uint32_t* ev_hdr, uint4* ev_dat,
-                   uint32_t* sizes1, uint32_t* sizes2, uint32_t* flags) {
+                   uint32_t* sizes1, uint32_t* sizes2, uint32_t* cls1, uint32_t* cls2, uint32_t* flags) {
     if (np == 0) return;
     const uint32_t nreads = paired ? 2 * np : np;
     (void)slot;                                                                    // the FASTQ record takes whatever length the read has (header field: 16 bits)
-    hipLaunchKernelGGL(k_indels, dim3(cdiv(nreads, 256)), dim3(256), 0, s, pairs, np, paired, tb, key, 65535u, reads_force_replay(), ev_hdr, ev_dat, sizes1, sizes2, flags);
+    hipLaunchKernelGGL(k_indels, dim3(cdiv(nreads, 256)), dim3(256), 0, s, pairs, np, paired, tb, key, 65535u, reads_force_replay(), ev_hdr, ev_dat, sizes1, sizes2, cls1, cls2, flags);
 }
+// event-free reads and the rest as two launches over their lists (k_read_lists); the grid of a launch covers the longer of
+// the two mates' lists
 void launch_reads(hipStream_t s, const uint8_t* g, DevErrPool spool, DevErrPool fpool,
                   const PairRec* pairs, uint32_t np, uint32_t amp_index_base, DevTables tb, const DevTables* d_tb, RngKey key, int paired, uint32_t slot,
                   const uint32_t* ev_hdr, const uint4* ev_dat, const uint64_t* off1, const uint64_t* off2, char* out1, char* out2, uint32_t* flags,
-                  uint64_t cap1, uint64_t cap2) {
+                  uint64_t cap1, uint64_t cap2, const uint32_t* slist1, const uint32_t* slist2, const uint32_t* clist1, const uint32_t* clist2, uint32_t nc1, uint32_t nc2) {
     if (np == 0) return;
     (void)d_tb;
     static const bool shrink = getenv("SCS_TEST_SHRINK_OUT") != nullptr;               // tests: provoke the record-bound guard
     if (shrink) { cap1 /= 2; cap2 /= 2; }
-    const uint32_t groups = cdiv(np, RB);
-    launch_reads_kernel<true>(s, dim3(paired ? 2 * groups : groups), tb, g, spool, fpool, pairs, np, paired,
+    const uint32_t ns1 = np - nc1, ns2 = paired ? np - nc2 : 0u;
+    const uint32_t gs = cdiv(std::max(ns1, ns2), RB), gc = cdiv(std::max(nc1, paired ? nc2 : 0u), RB);
+    if (gs) launch_reads_kernel<true, 1>(s, dim3(paired ? 2 * gs : gs), tb, g, spool, fpool, pairs, np, paired,
                               (const uint8_t*)nullptr, (const uint64_t*)nullptr, (const uint32_t*)nullptr, (const uint8_t*)nullptr, 0u, tb, key, slot,
                               (uint32_t)(paired ? 2ull * np : np), reads_force_replay(), ev_hdr, ev_dat, off1, off2, out1, out2, amp_index_base,
-                              (char*)nullptr, (char*)nullptr, (uint32_t*)nullptr, flags, cap1, cap2);
+                              (char*)nullptr, (char*)nullptr, (uint32_t*)nullptr, flags, cap1, cap2, slist1, slist2, ns1, ns2);
+    if (gc) launch_reads_kernel<true, 2>(s, dim3(paired ? 2 * gc : gc), tb, g, spool, fpool, pairs, np, paired,
+                              (const uint8_t*)nullptr, (const uint64_t*)nullptr, (const uint32_t*)nullptr, (const uint8_t*)nullptr, 0u, tb, key, slot,
+                              (uint32_t)(paired ? 2ull * np : np), reads_force_replay(), ev_hdr, ev_dat, off1, off2, out1, out2, amp_index_base,
+                              (char*)nullptr, (char*)nullptr, (uint32_t*)nullptr, flags, cap1, cap2, clist1, clist2, nc1, paired ? nc2 : 0u);
+}
+// the batch's reads split by class (k_indels' flags cls, their exclusive scans cpos): ascending lists of pair indices
+__global__ void k_read_lists(uint32_t np, int paired, const uint32_t* __restrict__ cls1, const uint32_t* __restrict__ cpos1, const uint32_t* __restrict__ cls2,
+                             const uint32_t* __restrict__ cpos2, uint32_t* __restrict__ slist1, uint32_t* __restrict__ slist2, uint32_t* __restrict__ clist1, uint32_t* __restrict__ clist2) {
+    const uint32_t pi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pi >= np) return;
+    { const uint32_t c = cpos1[pi]; if (cls1[pi]) clist1[c] = pi; else slist1[pi - c] = pi; }
+    if (paired) { const uint32_t c = cpos2[pi]; if (cls2[pi]) clist2[c] = pi; else slist2[pi - c] = pi; }
+}
+void launch_read_lists(hipStream_t s, uint32_t np, int paired, const uint32_t* cls1, uint32_t* cpos1, const uint32_t* cls2, uint32_t* cpos2,
+                       uint32_t* slist1, uint32_t* slist2, uint32_t* clist1, uint32_t* clist2, void* temp, size_t temp_bytes) {
+    if (np == 0) return;
+    exclusive_scan_u32(s, cls1, cpos1, np, temp, temp_bytes);
+    if (paired) exclusive_scan_u32(s, cls2, cpos2, np, temp, temp_bytes);
+    hipLaunchKernelGGL(k_read_lists, dim3(cdiv(np, 256)), dim3(256), 0, s, np, paired, cls1, cpos1, cls2, cpos2, slist1, slist2, clist1, clist2);
 }
 void launch_predict_windows(hipStream_t s, const uint8_t* windows, uint32_t n_reads, const uint64_t* uids, const uint32_t* atts,
                             const uint8_t* is_read1, DevTables tb, const DevTables* d_tb, RngKey key, uint32_t slot, char* slot_b, char* slot_q, uint32_t* lens, uint32_t* flags) {
     if (n_reads == 0) return;
     (void)d_tb;
     DevErrPool none{};
-    launch_reads_kernel<false>(s, dim3(cdiv(n_reads, RB)), tb, (const uint8_t*)nullptr, none, none, (const PairRec*)nullptr, 0u, 0,
+    launch_reads_kernel<false, 0>(s, dim3(cdiv(n_reads, RB)), tb, (const uint8_t*)nullptr, none, none, (const PairRec*)nullptr, 0u, 0,
                                windows, uids, atts, is_read1, n_reads, tb, key, slot, n_reads, reads_force_replay(), (const uint32_t*)nullptr, (const uint4*)nullptr,
-                               (const uint64_t*)nullptr, (const uint64_t*)nullptr, (char*)nullptr, (char*)nullptr, 0u, slot_b, slot_q, lens, flags, (uint64_t)0, (uint64_t)0);
+                               (const uint64_t*)nullptr, (const uint64_t*)nullptr, (char*)nullptr, (char*)nullptr, 0u, slot_b, slot_q, lens, flags, (uint64_t)0, (uint64_t)0,
+                               (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0u, 0u);
 }
 void launch_philox(hipStream_t s, const uint32_t* ctr, uint32_t n, RngKey key, uint32_t* out) {
     if (n) hipLaunchKernelGGL(k_philox, dim3(cdiv(n, 256)), dim3(256), 0, s, ctr, n, key, out);

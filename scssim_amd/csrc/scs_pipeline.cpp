@@ -163,7 +163,7 @@ struct scs_ctx {
     uint8_t* h_frag = nullptr; size_t h_frag_cap = 0; bool frag_copy_pending = false;   // its pinned staging copy
     // amplicons
     AmpStore semis, fulls;
-    DevBuf budget_f, budget_s, slot_off_f, slot_off_s, dsums; uint64_t* h_rb = nullptr;   // dsums: device scalars; h_rb: pinned, device-mapped mailbox (32 words)
+    DevBuf budget_f, budget_s, slot_off_f, slot_off_s, dsums, poisson_part; uint64_t* h_rb = nullptr;   // dsums: device scalars; h_rb: pinned, device-mapped mailbox (32 words)
     unsigned long long* d_rb = nullptr; uint64_t mail_seq = 0;                      // device address of h_rb; sequence of the last post
     Mail pend;                                                                     // counts of the passes launched since the last collect
     bool timing_gate = true; uint32_t timing_every = 1; uint64_t amplify_calls = 0, yield_calls = 0;   // scs_set_kernel_timing: events on every n-th call
@@ -173,7 +173,7 @@ struct scs_ctx {
     DevBuf slots, slot_tmpl, valid, valid_off, valid_f, valid_off_f, scan_tmp, flags;
     // allocation + reads
     DevBuf weights, read_numbers, pair_off, pairs, odd_before, a_part, a_tp, a_probs, a_quota, a_poff, a_plan, a_crn, a_scratch, a_brow, a_bmap, a_send, a_gath, a_odd; SegMap gmap{}; std::vector<uint32_t> h_read_numbers; uint64_t reads_requested = 0, n_pairs_planned = 0; bool allocated = false;
-    DevBuf slot_b, slot_q, lens, ev_hdr, ev_dat, sizes1, sizes2, off1, off2, out1, out2, out1b, out2b; SinkPipe* pipe = nullptr;
+    DevBuf slot_b, slot_q, lens, ev_hdr, ev_dat, sizes1, sizes2, off1, off2, out1, out2, out1b, out2b, rl_cls, rl_pos, rl_lists; SinkPipe* pipe = nullptr;
     hipStream_t copy_stream = nullptr; hipEvent_t ev_made[2] = {nullptr, nullptr};   // sink mode: D2H on its own stream, behind the batch's k_reads
     // sharded single job: collectives supplied by the caller + segment bookkeeping of the local amplicon lists
     scs_allreduce_fn allreduce = nullptr; scs_allgatherv_fn allgatherv = nullptr; void* coll_user = nullptr;
@@ -400,7 +400,8 @@ void set_primers_launch(scs_ctx* c, bool only_frags, uint32_t call, uint32_t ns_
     c->slot_off_f.reserve(((size_t)nf + 1) * 4, s); c->slot_off_s.reserve(((size_t)ns + 2) * 4, s);
     c->scan_tmp.reserve(scan_temp_bytes(std::max(nf, ns)), s);
     // sums[0..1] are zero here: the previous call's mail cleared them after reading (k_amplify_init zeroes them first)
-    launch_poisson(s, c->frags_view(), c->semis.view(), ns, p, c->budget_f.as<uint32_t>(), c->budget_s.as<uint32_t>(), c->dsums.as<unsigned long long>());
+    c->poisson_part.reserve(((size_t)nf + (size_t)ns / 256 + 4) * 8, s);
+    launch_poisson(s, c->frags_view(), c->semis.view(), ns, p, c->budget_f.as<uint32_t>(), c->budget_s.as<uint32_t>(), c->dsums.as<unsigned long long>(), c->poisson_part.as<unsigned long long>());
     exclusive_scan_u32_pair(s, c->budget_f.as<uint32_t>(), c->slot_off_f.as<uint32_t>(), nf, ns ? c->budget_s.as<uint32_t>() : nullptr, c->slot_off_s.as<uint32_t>(), ns, c->scan_tmp.p, c->scan_tmp.cap);
     const bool sh = c->sharded();                                                  // sharded: the budget sums ride on the next pass's all-reduce (and are cleared there)
     c->budgets_pending = sh;
@@ -453,7 +454,7 @@ void launch_pass(scs_ctx* c, bool from_frag, uint32_t pass, int rb_slot) {
     KernelTimer& tma = from_frag ? c->tm_attach_f : c->tm_attach;
     tma.begin(s);
     if (from_frag) launch_attach_frags(s, g, fr, slot_off, c->slots.as<uint32_t>(), c->slot_tmpl.as<uint32_t>(), valid.as<uint32_t>(),
-                                       c->primer_cnt.as<int64_t>(), c->primer_delta.as<uint32_t>(), c->dsums.as<unsigned long long>() + 4, p);
+                                       c->primer_cnt.as<int64_t>(), c->primer_delta.as<uint32_t>(), c->dsums.as<unsigned long long>() + 4, c->poisson_part.as<unsigned long long>(), p);
     else launch_attach_semis(s, g, fr, c->semis.view(), nt, c->semis.pool_view(), slot_off, c->slots.as<uint32_t>(), c->slot_tmpl.as<uint32_t>(),
                              valid.as<uint32_t>(), c->primer_cnt.as<int64_t>(), c->primer_delta.as<uint32_t>(), p);
     tma.end(s);
@@ -725,6 +726,10 @@ void do_yield(scs_ctx* c, const OutTarget& tg, uint64_t* n1_out, uint64_t* n2_ou
     c->ev_hdr.reserve(nreads_b * 4, s); c->ev_dat.reserve(nreads_b * 16, s);
     c->sizes1.reserve((batch + 1) * 4, s); c->sizes2.reserve((batch + 1) * 4, s); c->off1.reserve((batch + 1) * 8, s); c->off2.reserve((batch + 1) * 8, s);
     c->scan_tmp.reserve(scan_temp_bytes(batch), s);
+    // the reads of a batch split by class (with / without indel events): flags, their scans, four lists of pair indices
+    c->rl_cls.reserve((batch + 1) * 2 * 4, s); c->rl_pos.reserve((batch + 1) * 2 * 4, s); c->rl_lists.reserve(batch * 4 * 4, s);
+    uint32_t* cls1 = c->rl_cls.as<uint32_t>(); uint32_t* cls2 = cls1 + batch + 1; uint32_t* cpos1 = c->rl_pos.as<uint32_t>(); uint32_t* cpos2 = cpos1 + batch + 1;
+    uint32_t* slist1 = c->rl_lists.as<uint32_t>(); uint32_t* slist2 = slist1 + batch; uint32_t* clist1 = slist2 + batch; uint32_t* clist2 = clist1 + batch;
     uint64_t tot1 = 0, tot2 = 0, pairs_written = 0;
     // shard index: the pair index at which each list segment starts (pair_off at the segment's first amplicon)
     std::vector<uint64_t> bpair; size_t bnext = 0;
@@ -739,14 +744,16 @@ void do_yield(scs_ctx* c, const OutTarget& tg, uint64_t* n1_out, uint64_t* n2_ou
         const PairRec* pr = c->pairs.as<PairRec>() + p0;
         // the indel pass fixes every read's length, hence the record sizes and (prefix sums) the record offsets
         c->tm_indels.begin(s);
-        launch_indels(s, pr, np, paired, c->dtb, c->key, slot, c->ev_hdr.as<uint32_t>(), c->ev_dat.as<uint4>(), c->sizes1.as<uint32_t>(), c->sizes2.as<uint32_t>(), c->flags.as<uint32_t>());
+        launch_indels(s, pr, np, paired, c->dtb, c->key, slot, c->ev_hdr.as<uint32_t>(), c->ev_dat.as<uint4>(), c->sizes1.as<uint32_t>(), c->sizes2.as<uint32_t>(), cls1, cls2, c->flags.as<uint32_t>());
         c->tm_indels.end(s);
         c->tm_indels.add_units(np);
         exclusive_scan_u32_to_u64(s, c->sizes1.as<uint32_t>(), c->off1.as<uint64_t>(), np, c->scan_tmp.p, c->scan_tmp.cap);
         if (paired) exclusive_scan_u32_to_u64(s, c->sizes2.as<uint32_t>(), c->off2.as<uint64_t>(), np, c->scan_tmp.p, c->scan_tmp.cap);
-        { Mail m; m.add(c->off1.as<uint64_t>() + np, 8, 0); m.add(paired ? (const void*)(c->off2.as<uint64_t>() + np) : nullptr, 8, 1); mail_post(c, m, true); }
+        launch_read_lists(s, np, paired, cls1, cpos1, cls2, cpos2, slist1, slist2, clist1, clist2, c->scan_tmp.p, c->scan_tmp.cap);
+        { Mail m; m.add(c->off1.as<uint64_t>() + np, 8, 0); m.add(paired ? (const void*)(c->off2.as<uint64_t>() + np) : nullptr, 8, 1);
+          m.add(cpos1 + np, 4, 2); m.add(paired ? (const void*)(cpos2 + np) : nullptr, 4, 3); mail_post(c, m, true); }
         mail_wait(c);
-        const uint64_t b1 = c->h_rb[0], b2 = c->h_rb[1];
+        const uint64_t b1 = c->h_rb[0], b2 = c->h_rb[1]; const uint32_t nc1 = (uint32_t)c->h_rb[2], nc2 = (uint32_t)c->h_rb[3];
         while (bnext < bpair.size() && bpair[bnext] < p0 + np) {                     // a segment starts inside this batch: its record's byte offset
             uint64_t o1v = 0, o2v = 0; const uint64_t idx = bpair[bnext] - p0;
             HIP_OK(hipMemcpyAsync(&o1v, c->off1.as<uint64_t>() + idx, 8, hipMemcpyDeviceToHost, s));
@@ -772,7 +779,7 @@ void do_yield(scs_ctx* c, const OutTarget& tg, uint64_t* n1_out, uint64_t* n2_ou
         c->tm_reads.begin(s);                                                      // the base pass writes the FASTQ text at the record offsets
         launch_reads(s, c->genome.as<uint8_t>(), c->semis.pool_view(), c->fulls.pool_view(), pr, np, 0,
                      c->dtb, c->d_tables.as<DevTables>(), c->key, paired, slot, c->ev_hdr.as<uint32_t>(), c->ev_dat.as<uint4>(),
-                     c->off1.as<uint64_t>(), c->off2.as<uint64_t>(), o1, o2, c->flags.as<uint32_t>(), b1, b2);
+                     c->off1.as<uint64_t>(), c->off2.as<uint64_t>(), o1, o2, c->flags.as<uint32_t>(), b1, b2, slist1, slist2, clist1, clist2, nc1, nc2);
         c->tm_reads.end(s);
         c->tm_reads.add_units(np);
         { const hipError_t le = take_launch_error(); if (le != hipSuccess) throw ScsError(SCS_EDEVICE, std::string("k_reads launch failed: ") + hipGetErrorString(le)); }
@@ -871,8 +878,8 @@ void scs_destroy(scs_ctx* c) {
     for (DevBuf* b : {&c->d_tables, &c->t_gap, &c->t_qcompact, &c->t_guide, &c->t_subs1, &c->t_subs2, &c->t_qual, &c->t_ins, &c->t_del, &c->t_isize, &c->d_subs1, &c->d_subs2, &c->d_qual, &c->d_ins, &c->d_del,
                       &c->d_isize, &c->d_gcmeans, &c->genome, &c->gx_gc_bits, &c->gx_n_bits, &c->gx_gc_cnt, &c->gx_n_cnt, &c->gx_gc_pref, &c->gx_n_pref, &c->d_binom, &c->df_blob, &c->df_primers, &c->primer_cnt, &c->primer_delta,
                       &c->slots, &c->slot_tmpl, &c->valid, &c->valid_off, &c->valid_f, &c->valid_off_f, &c->scan_tmp, &c->flags, &c->weights, &c->read_numbers,
-                      &c->pair_off, &c->pairs, &c->odd_before, &c->a_part, &c->a_tp, &c->a_probs, &c->a_quota, &c->a_poff, &c->a_plan, &c->a_crn, &c->a_scratch, &c->a_brow, &c->a_bmap, &c->a_send, &c->a_gath, &c->a_odd, &c->d_hostred, &c->d_tot, &c->d_stage, &c->d_mail, &c->budget_f, &c->budget_s, &c->slot_off_f,
-                      &c->slot_off_s, &c->dsums, &c->slot_b, &c->slot_q, &c->lens, &c->ev_hdr, &c->ev_dat, &c->sizes1, &c->sizes2, &c->off1, &c->off2, &c->out1, &c->out2, &c->out1b, &c->out2b}) b->release();
+                      &c->pair_off, &c->pairs, &c->odd_before, &c->a_part, &c->a_tp, &c->a_probs, &c->a_quota, &c->a_poff, &c->a_plan, &c->a_crn, &c->a_scratch, &c->a_brow, &c->a_bmap, &c->a_send, &c->a_gath, &c->a_odd, &c->d_hostred, &c->d_tot, &c->d_stage, &c->d_mail, &c->budget_f, &c->budget_s, &c->poisson_part, &c->slot_off_f,
+                      &c->slot_off_s, &c->dsums, &c->slot_b, &c->slot_q, &c->lens, &c->ev_hdr, &c->ev_dat, &c->sizes1, &c->sizes2, &c->off1, &c->off2, &c->out1, &c->out2, &c->out1b, &c->out2b, &c->rl_cls, &c->rl_pos, &c->rl_lists}) b->release();
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     for (int k = 0; k < 2; ++k) if (c->ev_made[k]) (void)hipEventDestroy(c->ev_made[k]);
     c->semis.release(); c->fulls.release();
