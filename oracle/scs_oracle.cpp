@@ -937,10 +937,11 @@ double gc_factor(Sim& S, int gc, uint64_t uid) {
         return v;
     }
     // [REMAP] Marsaglia polar normal from keyed uniforms; log via det_log so a GPU can reproduce the bits.
-    for (uint32_t a = 0;; ++a) {
-        uint32_t c[4] = {a, (uint32_t)uid, (uint32_t)(uid >> 32), ST_WEIGHT}, o[4];
-        philox(c, S.rng.key, o);
-        double x = 2.0 * ((o[0] + 0.5) / 4294967296.0) - 1.0, y = 2.0 * ((o[1] + 0.5) / 4294967296.0) - 1.0;
+    uint32_t o[4] = {0, 0, 0, 0};
+    for (uint32_t a = 0;; ++a) {                                                   // attempt a = words 2(a&1), 2(a&1)+1 of Philox block a/2
+        if ((a & 1u) == 0) { uint32_t c[4] = {a >> 1, (uint32_t)uid, (uint32_t)(uid >> 32), ST_WEIGHT}; philox(c, S.rng.key, o); }
+        const uint32_t w0 = (a & 1u) ? o[2] : o[0], w1 = (a & 1u) ? o[3] : o[1];
+        double x = 2.0 * ((w0 + 0.5) / 4294967296.0) - 1.0, y = 2.0 * ((w1 + 0.5) / 4294967296.0) - 1.0;
         double r2 = x * x + y * y;
         if (r2 > 1.0 || r2 == 0.0) continue;
         double mult = sqrt(-2.0 * det_log(r2) / r2);

@@ -2,6 +2,7 @@
 #include "scs_comm.h"
 
 #include <dlfcn.h>
+#include <link.h>
 #include <errno.h>
 #include <fcntl.h>
 #include <string.h>
@@ -33,7 +34,16 @@ struct RcclApi {
 RcclApi& api() {
     static RcclApi a = [] {
         RcclApi r;
-        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) { r.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL); if (r.h) break; }
+        // a process that already carries RCCL (torch ships its own librccl.so, without a soname) shares that copy ...
+        std::string loaded;
+        dl_iterate_phdr([](struct dl_phdr_info* info, size_t, void* out) -> int {
+            const char* n = info->dlpi_name;
+            if (n && *n) { const char* base = strrchr(n, '/'); base = base ? base + 1 : n; if (strncmp(base, "librccl.so", 10) == 0) { *(std::string*)out = n; return 1; } }
+            return 0;
+        }, &loaded);
+        if (!loaded.empty()) r.h = dlopen(loaded.c_str(), RTLD_NOW | RTLD_NOLOAD);
+        // ... otherwise the system's
+        if (!r.h) for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) { r.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL); if (r.h) break; }
         if (!r.h) { r.why = std::string("RCCL not found: ") + (dlerror() ? dlerror() : "dlopen failed"); return r; }
         auto sym = [&](const char* n) { void* p = dlsym(r.h, n); if (!p && r.why.empty()) r.why = std::string("RCCL symbol missing: ") + n; return p; };
         r.GetUniqueId = (decltype(r.GetUniqueId))sym("ncclGetUniqueId"); r.CommInitRank = (decltype(r.CommInitRank))sym("ncclCommInitRank");

@@ -246,12 +246,21 @@ __global__ void __launch_bounds__(256) k_errs(const uint8_t* __restrict__ g, Dev
     // semi amplicon count that the next setPrimers reads
     if (primer_cnt) for (uint32_t i = w; i < 65536u; i += gridDim.x * blockDim.x) { const int64_t c = primer_cnt[i] - (int64_t)primer_delta[i]; primer_cnt[i] = c < 0 ? 0 : c; primer_delta[i] = 0; }
     if (FROM_FRAG && w == 0 && semis_n) *semis_n += valid_off[n_tmpl];
-    if (w >= n_slots) return;
-    const uint32_t t = slot_tmpl[w];
-    if (t == 0xFFFFFFFFu) return;                      // reserved but unused slot (aborted template)
-    const uint32_t i = w - slot_off[t];
+    // fragments: a thread per reserved slot (nearly all of them are used).  Semi amplicons: three quarters of the reserved
+    // slots stay unused (most primers find no place on a 1-2 kb template), so k_expand_items has listed the template of every
+    // amplicon actually made (slot_tmpl reused as that dense map) and the thread index IS the amplicon
+    uint32_t t, i;
+    if (FROM_FRAG) {
+        if (w >= n_slots) return;
+        t = slot_tmpl[w];
+        if (t == 0xFFFFFFFFu) return;                  // reserved but unused slot (aborted template)
+        i = w - slot_off[t];
+    } else {
+        if (w >= valid_off[n_tmpl]) return;
+        t = slot_tmpl[w]; i = w - valid_off[t];
+    }
     const uint32_t n_fwd = valid_off[t] + i, n_new = valid_off[n_tmpl];
-    const uint32_t sl = slots[w], spos = sl_spos(sl), alen = sl_len(sl);
+    const uint32_t sl = slots[slot_off[t] + i], spos = sl_spos(sl), alen = sl_len(sl);
     View tv; uint64_t perrs = 0, nuid; uint32_t plen = 0;
     if (FROM_FRAG) { tv = frag_view(fr.goff[t], fr.len[t], fr.strand[t]); nuid = semi_uid(fr.gidx_base + t, p.pass, i); }
     else {
@@ -378,10 +387,11 @@ __global__ void k_weights(DevAmps fulls, uint32_t n, DevTables tb, RngKey key, u
     double v = 0;
     if (gcp <= 100) {
         const double mean = tb.gc_means[gcp], sd = tb.gc_std;
-        for (uint32_t a = 0;; ++a) {                                              // [REMAP] Marsaglia polar, keyed
-            const U4 d = draw4(key, ST_WEIGHT, 0, uid, a);
-            const double x = 2.0 * (((double)d.w[0] + 0.5) / 4294967296.0) - 1.0;
-            const double y = 2.0 * (((double)d.w[1] + 0.5) / 4294967296.0) - 1.0;
+        U4 d{};
+        for (uint32_t a = 0;; ++a) {                                              // [REMAP] Marsaglia polar, keyed: attempt a = words 2(a&1), 2(a&1)+1 of block a/2
+            if ((a & 1u) == 0) d = draw4(key, ST_WEIGHT, 0, uid, a >> 1);
+            const double x = 2.0 * (((double)((a & 1u) ? d.w[2] : d.w[0]) + 0.5) / 4294967296.0) - 1.0;
+            const double y = 2.0 * (((double)((a & 1u) ? d.w[3] : d.w[1]) + 0.5) / 4294967296.0) - 1.0;
             const double r2 = x * x + y * y;
             if (r2 > 1.0 || r2 == 0.0) continue;
             const double mult = __dsqrt_rn(-2.0 * det_log(r2) / r2);
@@ -1313,8 +1323,10 @@ __global__ void __launch_bounds__(64) k_attach(const uint8_t* __restrict__ g, De
     }
     uint32_t* bits = s_bits + gi * WORDS;
     const uint32_t base_slot = t < nt ? slot_off[t] : 0, aux = (FROM_FRAG ? 0u : 1u) | (p.pass << 1);
-    for (uint32_t w = gl; w < budget; w += G) slot_tmpl[base_slot + w] = 0xFFFFFFFFu;   // my template's slots start out unused (k_errs skips those)
-    __threadfence_block();                                                         // ... before any commit below rewrites one of them
+    if (FROM_FRAG) {                                                               // (semi amplicons: k_expand_items lists the amplicons made instead)
+        for (uint32_t w = gl; w < budget; w += G) slot_tmpl[base_slot + w] = 0xFFFFFFFFu;   // my template's slots start out unused (k_errs skips those)
+        __threadfence_block();                                                     // ... before any commit below rewrites one of them
+    }
     bool group_done = !(t < nt && len >= p.amp_min + 27 && budget > 0);
     if (!group_done) for (uint32_t w = gl; w < (len + 31) / 32; w += G) bits[w] = 0;
     __builtin_amdgcn_wave_barrier();
@@ -1383,7 +1395,7 @@ __global__ void __launch_bounds__(64) k_attach(const uint8_t* __restrict__ g, De
         if (live && gl < commit_end) {                                                   // commit, in primer order
             atomicOr(&bits[spos >> 5], 1u << (spos & 31));
             atomicAdd(&primer_delta[pidx], 1u);
-            slots[base_slot + i] = pack_sl(spos, alen); slot_tmpl[base_slot + i] = t;
+            slots[base_slot + i] = pack_sl(spos, alen); if (FROM_FRAG) slot_tmpl[base_slot + i] = t;
             lsum += alen; unresolved = false;
         }
         __builtin_amdgcn_wave_barrier();
@@ -1780,11 +1792,19 @@ void launch_errs_frags(hipStream_t s, const uint8_t* g, DevGenomeIdx gx, DevFrag
     hipLaunchKernelGGL(k_errs<true>, dim3(primer_cnt ? std::max(cdiv(n_slots, 256), 256u) : cdiv(n_slots, 256)), dim3(256), 0, s, g, gx, fr, none, np, n_slots, slot_off, slots, slot_tmpl, valid_off, fr.n, out, out_base, pool, flags, binom, p,
                        primer_cnt, primer_delta, semis_n);
 }
+// the template of every amplicon a semi pass made, in creation order (valid_off = exclusive scan of the per-template counts)
+__global__ void k_expand_items(const uint32_t* __restrict__ valid_off, uint32_t n_tmpl, uint32_t* __restrict__ item_tmpl) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_tmpl) return;
+    const uint32_t b = valid_off[t], e = valid_off[t + 1];
+    for (uint32_t k = b; k < e; ++k) item_tmpl[k] = t;
+}
 void launch_errs_semis(hipStream_t s, const uint8_t* g, DevGenomeIdx gx, DevFrags fr, DevAmps semis, uint32_t n_semis, DevErrPool spool, uint32_t n_slots,
                        const uint32_t* slot_off, const uint32_t* slots, const uint32_t* slot_tmpl, const uint32_t* valid_off,
                        DevAmps out, uint32_t out_base, DevErrPool pool, uint32_t* flags, const unsigned long long* binom, AmplifyParams p,
                        int64_t* primer_cnt, uint32_t* primer_delta) {
     if (n_slots == 0) return;
+    hipLaunchKernelGGL(k_expand_items, dim3(cdiv(n_semis, 256)), dim3(256), 0, s, valid_off, n_semis, const_cast<uint32_t*>(slot_tmpl));
     hipLaunchKernelGGL(k_errs<false>, dim3(primer_cnt ? std::max(cdiv(n_slots, 256), 256u) : cdiv(n_slots, 256)), dim3(256), 0, s, g, gx, fr, semis, spool, n_slots, slot_off, slots, slot_tmpl, valid_off, n_semis, out, out_base, pool, flags, binom, p,
                        primer_cnt, primer_delta, (unsigned long long*)nullptr);
 }

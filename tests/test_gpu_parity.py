@@ -297,6 +297,24 @@ def test_rccl_inside_the_library_single_rank_and_cli(models, golden_inputs, orac
     g.yield_reads_files(str(tmp_path / "lib"))
     for suffix in ("_1.fq", "_2.fq"):
         assert open(str(tmp_path / "lib") + suffix, "rb").read() == open(prefix + suffix, "rb").read()
+    # the same inside a process that already carries RCCL (torch's own copy: what bench.py --gpus N runs in): the library
+    # binds to the loaded copy and works on a torch stream
+    import sys
+    code = '''
+import sys, torch
+sys.path.insert(0, %r)
+import scssim_amd
+torch.cuda.set_device(0)
+st = torch.cuda.Stream()
+g = scssim_amd.GenReads(profile=%r, input_fasta=%r, coverage=2.0, seed=5, stream=st.cuda_stream)
+g.comm_init(scssim_amd.comm_unique_id(), 0, 1)
+g.create_frags(); g.amplify(); g.allocate_reads(0)
+g.yield_reads_files(%r)
+''' % (ROOT, models["Illumina_HiSeq2500"], golden_inputs["g1_hiseq2500_pe"], str(tmp_path / "tor"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0, r.stdout + r.stderr
+    for suffix in ("_1.fq", "_2.fq"):
+        assert open(str(tmp_path / "tor") + suffix, "rb").read() == open(prefix + suffix, "rb").read()
     exe = os.path.join(ROOT, "scssim_amd", "bin", "scssim")
     r = subprocess.run([exe, "genreads", "-i", golden_inputs["g1_hiseq2500_pe"], "-m", models["Illumina_HiSeq2500"], "-c", "2", "-o", str(tmp_path / "cli"),
                         "--seed", "5", "--gpus", "1"], capture_output=True, text=True, timeout=300)
