@@ -144,6 +144,11 @@ void launch_errs_semis(hipStream_t s, const uint8_t* g, DevGenomeIdx gx, DevFrag
                        DevAmps out, uint32_t out_base, DevErrPool pool, uint32_t* flags, const unsigned long long* binom, AmplifyParams p,
                        int64_t* primer_cnt, uint32_t* primer_delta);   // primer_cnt non-null: the pass's stock update rides along (unsharded job)
 void launch_encode_bases(hipStream_t s, uint8_t* g, uint64_t n);
+// one chunk of a FASTA file parsed on the device (k_fa_*): st = {bases so far, headers so far, kind of the open line}; kind n bytes,
+// keep / pos n + 1 words; hdr = pairs {file offset of a header, bases before it}, at most hdr_cap of them
+size_t fasta_chunk_temp_bytes(uint32_t n);
+void launch_fasta_chunk(hipStream_t s, const uint8_t* raw, uint32_t n, unsigned long long chunk_off, unsigned long long* st, uint8_t* kind, uint32_t* keep, uint32_t* pos,
+                        uint8_t* out, unsigned long long* hdr, uint32_t hdr_cap, void* temp, size_t temp_bytes);
 // simuvars: out[piece.dst ..] = upper(ref | literal pool), then the SNP / SNV alleles
 void launch_sv_build(hipStream_t s, const uint8_t* ref, const uint8_t* lit, const SvPiece* pieces, uint32_t np, const SvSubst* subs, uint32_t nsub, uint8_t* out, uint64_t total);
 void launch_genome_bits(hipStream_t s, const uint8_t* g, uint64_t n, uint64_t nwords, unsigned long long* gc_bits, unsigned long long* n_bits,

@@ -168,6 +168,69 @@ __global__ void k_encode_bases(uint8_t* __restrict__ g, uint64_t n) {
     } else for (uint64_t k = i; k < n && k < i + 16; ++k) g[k] = (uint8_t)code(g[k]);
 }
 // ------------------------------------------------------------------------------------------------
+// FASTA parsed on the device (lib/fastahack/Fasta.cpp:45-215 index + 304-334 getSubSequence, Genome.cpp:176-195):
+// the file's raw bytes arrive in chunks; a byte is a base iff its LINE is a sequence line (not a '>' header, not a ';'
+// comment) and it is neither '\n' nor '\r'.  The line's kind is the kind of its first byte carried forward: an inclusive scan
+// with "the right operand wins if it starts a line" (kinds 1 header, 2 comment, 3 sequence; 0 = not a line start).  Kept
+// bytes are compacted behind the bases of the earlier chunks; headers (rare) are listed with their file offset and the
+// number of bases before them, from which the host takes the names and the record lengths.
+// ------------------------------------------------------------------------------------------------
+struct FaKindOp { __host__ __device__ uint8_t operator()(uint8_t a, uint8_t b) const { return b ? b : a; } };
+// st: [0] bases so far, [1] headers so far, [2] kind of the line open at the chunk's start (0 = the chunk starts a line)
+__global__ void __launch_bounds__(256) k_fa_kind(const uint8_t* __restrict__ raw, uint32_t n, const unsigned long long* __restrict__ st, uint8_t* __restrict__ kind) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t b = raw[i];
+    const bool start = i == 0 ? st[2] == 0 : raw[i - 1] == '\n';
+    uint8_t k = start ? (b == '>' ? 1 : b == ';' ? 2 : 3) : 0;
+    if (i == 0 && !start) k = (uint8_t)st[2];                                      // the line continues from the previous chunk
+    kind[i] = k;
+}
+__global__ void __launch_bounds__(256) k_fa_keep(const uint8_t* __restrict__ raw, const uint8_t* __restrict__ kind, uint32_t n, uint32_t* __restrict__ keep) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n) return;
+    if (i == n) { keep[i] = 0; return; }
+    const uint32_t b = raw[i];
+    keep[i] = (kind[i] == 3 && b != '\n' && b != '\r') ? 1u : 0u;
+}
+__global__ void __launch_bounds__(256) k_fa_scatter(const uint8_t* __restrict__ raw, const uint8_t* __restrict__ kind, const uint32_t* __restrict__ keep, const uint32_t* __restrict__ pos,
+                                                    uint32_t n, unsigned long long chunk_off, const unsigned long long* __restrict__ st, uint8_t* __restrict__ out,
+                                                    unsigned long long* __restrict__ hdr, uint32_t hdr_cap, unsigned long long* __restrict__ nhdr) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long base = st[0];
+    if (keep[i]) out[base + pos[i]] = raw[i];
+    const bool start = i == 0 ? st[2] == 0 : raw[i - 1] == '\n';
+    if (start && raw[i] == '>') {                                                  // a header: file offset, bases before it
+        const unsigned long long k = atomicAdd(nhdr, 1ull);
+        if (k < hdr_cap) { hdr[2 * k] = chunk_off + i; hdr[2 * k + 1] = base + pos[i]; }
+    }
+}
+// closes a chunk: bases so far += the chunk's, and the kind of the line left open at its end
+__global__ void k_fa_close(const uint8_t* __restrict__ raw, const uint8_t* __restrict__ kind, const uint32_t* __restrict__ pos, uint32_t n, unsigned long long* __restrict__ st) {
+    if (threadIdx.x || blockIdx.x) return;
+    st[0] += pos[n];
+    st[2] = raw[n - 1] == '\n' ? 0ull : (unsigned long long)kind[n - 1];
+}
+size_t fasta_chunk_temp_bytes(uint32_t n) {
+    size_t a = 0, b = 0;
+    (void)rocprim::inclusive_scan(nullptr, a, (const uint8_t*)nullptr, (uint8_t*)nullptr, (size_t)n, FaKindOp());
+    (void)rocprim::exclusive_scan(nullptr, b, (const uint32_t*)nullptr, (uint32_t*)nullptr, 0u, (size_t)n + 1, rocprim::plus<uint32_t>());
+    return (a > b ? a : b) + 256;
+}
+void launch_fasta_chunk(hipStream_t s, const uint8_t* raw, uint32_t n, unsigned long long chunk_off, unsigned long long* st, uint8_t* kind, uint32_t* keep, uint32_t* pos,
+                        uint8_t* out, unsigned long long* hdr, uint32_t hdr_cap, void* temp, size_t temp_bytes) {
+    if (n == 0) return;
+    const unsigned g = (unsigned)((n + 256) / 256 + 1);
+    hipLaunchKernelGGL(k_fa_kind, dim3(g), dim3(256), 0, s, raw, n, st, kind);
+    (void)rocprim::inclusive_scan(temp, temp_bytes, kind, kind, (size_t)n, FaKindOp(), s);
+    hipLaunchKernelGGL(k_fa_keep, dim3(g), dim3(256), 0, s, raw, kind, n, keep);
+    (void)rocprim::exclusive_scan(temp, temp_bytes, keep, pos, 0u, (size_t)n + 1, rocprim::plus<uint32_t>(), s);
+    hipLaunchKernelGGL(k_fa_scatter, dim3(g), dim3(256), 0, s, raw, kind, keep, pos, n, chunk_off, st, out, hdr, hdr_cap, st + 1);
+    hipLaunchKernelGGL(k_fa_close, dim3(1), dim3(64), 0, s, raw, kind, pos, n, st);
+}
+
+// ------------------------------------------------------------------------------------------------
 // simuvars on the data plane: the haplotype sequences that Genome::saveSequence / generateSegment
 // (lib/genome/Genome.cpp:329-691) assemble with std::string edits are materialised here from the host's plan: the output is
 // a concatenation of pieces, each a range of the reference (resident in HBM, as read from the FASTA) or of the literal
@@ -410,6 +473,13 @@ __global__ void k_weights(DevAmps fulls, uint32_t n, DevTables tb, RngKey key, u
 __global__ void k_plan_pairs(DevFrags fr, DevAmps semis, DevAmps fulls, uint32_t n_fulls, const uint32_t* __restrict__ read_numbers,
                              const uint32_t* __restrict__ pair_off, const SegMap gmap, DevTables tb, RngKey key, int paired,
                              PairRec* __restrict__ pairs, unsigned long long* __restrict__ holes) {
+    // the insert-size thresholds (a few hundred) go to LDS: the lookup is a nine-step bisection per attempt, and from global
+    // memory those dependent loads are what the kernel waits for
+    __shared__ uint32_t s_isz[1024];
+    const uint32_t n_isz = (uint32_t)tb.n_isize;
+    const bool isz_lds = n_isz <= 1024u;
+    if (isz_lds) for (uint32_t k = threadIdx.x; k < n_isz; k += blockDim.x) s_isz[k] = tb.isize_t[k];
+    __syncthreads();
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_fulls) return;
     int n = (int)read_numbers[i];
@@ -434,7 +504,7 @@ __global__ void k_plan_pairs(DevFrags fr, DevAmps semis, DevAmps fulls, uint32_t
                 r.att = att; r.pos = scale_draw(d.w[1], 0, amp_len - L + 1); r.isz = L;
                 dst[made++] = r; ++att; --n; continue;
             }
-            const uint32_t isz = (uint32_t)tb.isize_min + rand_indx_thr(tb.isize_t, tb.isize_d, (uint32_t)tb.n_isize, d.w[0]);
+            const uint32_t isz = (uint32_t)tb.isize_min + rand_indx_thr(isz_lds ? (const uint32_t*)s_isz : tb.isize_t, tb.isize_d, n_isz, d.w[0]);
             if (isz < L || isz > amp_len) { ++att; if (++fails > 1000) break; continue; }
             r.att = att; r.pos = scale_draw(d.w[1], 0, amp_len - isz + 1); r.isz = isz;
             dst[made++] = r; ++att; n -= 2;

@@ -7,6 +7,10 @@
 #include "scs_comm.h"
 
 #include <atomic>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -331,6 +335,71 @@ void stage_genome(scs_ctx* c, const void* d_ascii = nullptr, const uint64_t* d_l
     for (auto& r : c->recs) std::vector<uint8_t>().swap(r.code);
     c->have_genome = true; c->have_frags = false; c->amplified = false; c->allocated = false;
     c->st.records = c->recs.size(); c->st.genome_bases = tot;
+}
+
+// Genome::loadRefSeq for whole-genome inputs: the FASTA is mmap'ed and its RAW bytes go to the device in
+// 64 MB chunks through two pinned buffers (four host threads copy a chunk out of the page cache while the GPU works on the
+// one before); the device separates bases from line ends, headers and comments (k_fa_*), compacts them into the genome
+// buffer and lists the headers; the host only reads the header lines.  Then encode + bit index as for every genome.
+void stage_fasta_on_device(scs_ctx* c, const std::string& path_in) {
+    const std::string path = fasta_plain_path(path_in);
+    const int fd = open(path.c_str(), O_RDONLY);
+    if (fd < 0) throw ScsError(SCS_EIO, "could not open " + path);
+    struct stat st_;
+    if (fstat(fd, &st_) != 0) { close(fd); throw ScsError(SCS_EIO, "could not stat " + path); }
+    const size_t size = (size_t)st_.st_size;
+    if (size == 0) { close(fd); throw ScsError(SCS_EIO, "ERROR: reference sequence cannot be empty!"); }
+    const char* base = (const char*)mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+    if (base == MAP_FAILED) { close(fd); throw ScsError(SCS_EIO, "could not map " + path); }
+    (void)madvise((void*)base, size, MADV_SEQUENTIAL);
+    struct Unmap { const char* b; size_t n; int fd; ~Unmap() { munmap((void*)b, n); close(fd); } } unmap{base, size, fd};
+    hipStream_t s = c->stream;
+    const size_t CH = 64u << 20; const uint32_t hdr_cap = 1u << 20;
+    DevBuf d_raw[2], d_kind, d_keep, d_pos, d_st, d_hdr, d_tmp; char* h_raw[2] = {nullptr, nullptr}; hipEvent_t ev[2] = {nullptr, nullptr}; bool ev_used[2] = {false, false};
+    struct Rel { DevBuf* b[8]; char** h; hipEvent_t* e; ~Rel() { for (DevBuf* x : b) x->release(); for (int k = 0; k < 2; ++k) { if (h[k]) (void)hipHostFree(h[k]); if (e[k]) (void)hipEventDestroy(e[k]); } } }
+        rel{{&d_raw[0], &d_raw[1], &d_kind, &d_keep, &d_pos, &d_st, &d_hdr, &d_tmp}, h_raw, ev};
+    const size_t ch = std::min(CH, size);
+    for (int k = 0; k < 2; ++k) { d_raw[k].reserve(ch + 16, s); HIP_OK(hipHostMalloc((void**)&h_raw[k], ch, hipHostMallocDefault)); HIP_OK(hipEventCreateWithFlags(&ev[k], hipEventDisableTiming)); }
+    d_kind.reserve(ch + 16, s); d_keep.reserve((ch + 2) * 4, s); d_pos.reserve((ch + 2) * 4, s); d_st.reserve(64, s); d_hdr.reserve((size_t)hdr_cap * 16, s);
+    d_tmp.reserve(fasta_chunk_temp_bytes((uint32_t)ch), s);
+    HIP_OK(hipMemsetAsync(d_st.p, 0, 64, s));
+    c->genome.reserve(size + 16, s);                                              // the bases are fewer than the file's bytes
+    for (size_t off = 0, k = 0; off < size; off += ch, ++k) {
+        const int b = (int)(k & 1); const size_t n = std::min(ch, size - off);
+        if (ev_used[b]) HIP_OK(hipEventSynchronize(ev[b]));                       // the pinned buffer's last upload is done
+        {   // page cache -> pinned, four slices in parallel
+            std::vector<std::thread> th; const size_t parts = n >= (8u << 20) ? 4 : 1, per = (n + parts - 1) / parts;
+            for (size_t q = 1; q < parts; ++q) th.emplace_back([&, q] { const size_t o = q * per; if (o < n) memcpy(h_raw[b] + o, base + off + o, std::min(per, n - o)); });
+            memcpy(h_raw[b], base + off, std::min(per, n));
+            for (auto& t : th) t.join();
+        }
+        HIP_OK(hipMemcpyAsync(d_raw[b].p, h_raw[b], n, hipMemcpyHostToDevice, s));
+        HIP_OK(hipEventRecord(ev[b], s)); ev_used[b] = true;
+        launch_fasta_chunk(s, d_raw[b].as<uint8_t>(), (uint32_t)n, (unsigned long long)off, d_st.as<unsigned long long>(), d_kind.as<uint8_t>(), d_keep.as<uint32_t>(), d_pos.as<uint32_t>(),
+                           c->genome.as<uint8_t>(), d_hdr.as<unsigned long long>(), hdr_cap, d_tmp.p, d_tmp.cap);
+    }
+    unsigned long long stv[3] = {0, 0, 0};
+    HIP_OK(hipMemcpyAsync(stv, d_st.p, 24, hipMemcpyDeviceToHost, s)); HIP_OK(hipStreamSynchronize(s));
+    { const hipError_t le = take_launch_error(); if (le != hipSuccess) throw ScsError(SCS_EDEVICE, std::string("FASTA staging kernels: ") + hipGetErrorString(le)); }
+    const uint64_t total = stv[0], nh = stv[1];
+    if (nh > hdr_cap) throw ScsError(SCS_EOVERFLOW, "more than 2^20 FASTA records");
+    if (nh == 0) throw ScsError(SCS_EIO, total ? "malformed FASTA (sequence before header): " + path : std::string("ERROR: reference sequence cannot be empty!"));
+    std::vector<unsigned long long> hp(2 * nh);
+    HIP_OK(hipMemcpyAsync(hp.data(), d_hdr.p, hp.size() * 8, hipMemcpyDeviceToHost, s)); HIP_OK(hipStreamSynchronize(s));
+    std::vector<std::pair<uint64_t, uint64_t>> hs(nh);
+    for (uint64_t k = 0; k < nh; ++k) hs[k] = {hp[2 * k], hp[2 * k + 1]};
+    std::sort(hs.begin(), hs.end());                                               // by file offset (the list is filled by atomics)
+    if (hs[0].second != 0) throw ScsError(SCS_EIO, "malformed FASTA (sequence before header): " + path);
+    std::vector<uint64_t> hoff(nh), lens(nh);
+    c->recs.assign(nh, FastaRecord());
+    for (uint64_t k = 0; k < nh; ++k) {
+        hoff[k] = hs[k].first; lens[k] = (k + 1 < nh ? hs[k + 1].second : total) - hs[k].second;
+        const char* nl = (const char*)memchr(base + hoff[k], '\n', size - hoff[k]);
+        size_t hend = nl ? (size_t)(nl - base) : size; if (hend > hoff[k] && base[hend - 1] == '\r') --hend;
+        c->recs[k].name = fasta_index_name(std::string(base + hoff[k] + 1, base + hend));
+    }
+    fasta_write_fai(path, base, size, hoff, lens);                                 // fastahack leaves <file>.fai beside its input (Fasta.cpp:241-249)
+    stage_genome(c, c->genome.p, lens.data());
 }
 
 // ---------------------------------------------------------------- a1: Genome::splitToFrags (Genome.cpp:753-782)
@@ -908,7 +977,8 @@ int scs_read_length(const scs_ctx* c) { return c && c->have_profile ? c->prof.re
 int scs_load_genome_fasta(scs_ctx* c, const char* path) {
     return guarded(c, [&] {
         if (!path) throw ScsError(SCS_EINVAL, "null path");
-        load_fasta(path, c->recs, true); stage_genome(c);
+        if (getenv("SCS_HOST_FASTA")) { load_fasta(path, c->recs, true); stage_genome(c); }   // the host parser (what scs_fasta_probe checks); debugging aid
+        else stage_fasta_on_device(c, path);
         if (c->cfg.verbose) fprintf(stderr, "\nReference sequence was loaded from file %s\n", path);
     });
 }

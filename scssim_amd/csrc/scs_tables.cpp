@@ -289,6 +289,41 @@ void encode_record(const char* name, const char* seq, uint64_t len, FastaRecord&
 #include <sys/stat.h>
 #include <unistd.h>
 namespace scs {
+std::string fasta_index_name(const std::string& header_text) { return index_name(header_text); }
+std::string fasta_plain_path(const std::string& path_in) {
+    std::string path = path_in;
+    if (path.empty()) throw std::runtime_error("reference sequence file not specified!");
+    if (path.size() > 3 && path.compare(path.size() - 3, 3, ".gz") == 0) {      // Genome.cpp:183-187
+        const std::string plain = path.substr(0, path.size() - 3);
+        const std::string cmd = "gzip -cd " + path + " > " + plain;
+        if (system(cmd.c_str()) != 0) throw std::runtime_error("could not inflate " + path);
+        path = plain;
+    }
+    return path;
+}
+// fastahack's index entry (Fasta.cpp:241-249): first word of the name, length, offset of the first sequence byte, bases per
+// line, bytes per line -- the last three from the record's first sequence line
+void fasta_write_fai(const std::string& path, const char* base, size_t size, const std::vector<uint64_t>& hdr_off, const std::vector<uint64_t>& lens) {
+    const std::string fname = path + ".fai"; struct stat fst;
+    if (stat(fname.c_str(), &fst) == 0) return;
+    fprintf(stderr, "index file %s not found, generating...\n", fname.c_str());
+    FILE* fai = fopen(fname.c_str(), "w");
+    if (!fai) { fprintf(stderr, "could not open index file %s for writing! (continuing without it)\n", fname.c_str()); return; }
+    for (size_t r = 0; r < hdr_off.size(); ++r) {
+        const size_t hdr = (size_t)hdr_off[r], end = r + 1 < hdr_off.size() ? (size_t)hdr_off[r + 1] : size;
+        const char* nl = (const char*)memchr(base + hdr, '\n', end - hdr);
+        const size_t heol = nl ? (size_t)(nl - base) : end; size_t hend = heol; if (hend > hdr && base[hend - 1] == '\r') --hend;
+        size_t fl = heol + 1 < end ? heol + 1 : end;
+        while (fl < end && base[fl] == ';') { const char* e = (const char*)memchr(base + fl, '\n', end - fl); fl = e ? (size_t)(e - base) + 1 : end; }
+        const char* e = fl < end ? (const char*)memchr(base + fl, '\n', end - fl) : nullptr;
+        const size_t line_len = fl < end ? (e ? (size_t)(e - base) + 1 - fl : end - fl) : 0;
+        size_t line_blen = e ? line_len - 1 : line_len; if (line_blen && base[fl + line_blen - 1] == '\r') --line_blen;
+        const std::string full(base + hdr + 1, base + hend);
+        const std::string first = full.substr(0, full.find(' '));
+        fprintf(fai, "%s\t%llu\t%zu\t%zu\t%zu\n", first.c_str(), (unsigned long long)lens[r], fl, line_blen, line_len);
+    }
+    fclose(fai);
+}
 void load_fasta(const std::string& path_in, std::vector<FastaRecord>& out, bool make_index) {
     std::string path = path_in;
     if (path.empty()) throw std::runtime_error("reference sequence file not specified!");

@@ -684,3 +684,43 @@ except scssim_amd.ScsError as e:
 ''' % (ROOT, models["Illumina_HiSeq2500"], golden_inputs["g1_hiseq2500_pe"])
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SCS_TEST_SHRINK_OUT="1"), capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "GUARDED" in r.stdout, r.stdout + r.stderr
+
+
+def test_fasta_parsed_on_the_device_handles_ragged_text(oracle_bin, models, tmp_path):
+    """The device-side FASTA parser (raw file bytes -> bases, k_fa_*): CRLF line ends, ';' comment lines, blank lines, lower
+    case, ragged line widths, one record on a single 40 kb line, a header with a description, no newline at the end of the
+    file.  Same records as the host parser sees (names, lengths, checksum via the .fai and the job), same reads as the oracle."""
+    rng = np.random.default_rng(12)
+    rnd = lambda n: "".join(rng.choice(list("ACGTacgtN"), size=n, p=[0.24, 0.2, 0.2, 0.24, 0.03, 0.03, 0.02, 0.02, 0.02]))
+    a, b, c = rnd(30011), rnd(40000), rnd(25000)
+    fa = str(tmp_path / "ragged.fa")
+    with open(fa, "wb") as f:
+        f.write(b"\r\n>chr3_1_30011 first haplotype\r\n")
+        for i in range(0, len(a), 70):
+            f.write(a[i:i + 70].encode() + b"\r\n")
+            if i == 700:
+                f.write(b";a comment line in the middle of a record\r\n\r\n")
+        f.write(b">3_2_40000\n" + b.encode() + b"\n")                             # one line
+        f.write(b";comment before a header\n>chrom4_1_25000\n")
+        w = 0
+        for i, step in enumerate([13, 100, 1, 57] * 1000):
+            if w >= len(c):
+                break
+            f.write(c[w:w + step].encode() + b"\n"); w += step
+        f.write(b">4_2_9")                                                          # an empty record, and no final newline
+    names, total, _ = scssim_amd.fasta_probe(fa)                                    # the host parser's view
+    assert names == ["3_1_30011", "3_2_40000", "4_1_25000", "4_2_9"] and total == 95011
+    prefix = str(tmp_path / "orc")
+    _oracle_run(oracle_bin, fa, models["Illumina_HiSeq2500"], prefix, ["-c", "6"], 44, threads=2)
+    g = scssim_amd.GenReads(profile=models["Illumina_HiSeq2500"], input_fasta=fa, coverage=6.0, seed=44)
+    st = g.stats()
+    assert st["records"] == 4 and st["genome_bases"] == 95011
+    fq1, fq2 = g.run()
+    assert fq1 == open(prefix + "_1.fq", "rb").read() and fq2 == open(prefix + "_2.fq", "rb").read()
+    fai = [l.split("\t") for l in open(fa + ".fai").read().splitlines()]
+    assert [(l[0], int(l[1])) for l in fai] == [("chr3_1_30011", 30011), ("3_2_40000", 40000), ("chrom4_1_25000", 25000), ("4_2_9", 0)]
+    bad = str(tmp_path / "bad.fa")
+    open(bad, "w").write("ACGT\n>x_1_4\nACGT\n")
+    with pytest.raises(scssim_amd.ScsError) as e:
+        scssim_amd.GenReads(profile=models["Illumina_HiSeq2500"], input_fasta=bad)
+    assert "sequence before header" in str(e.value)
