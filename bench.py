@@ -151,30 +151,39 @@ def cpu_baseline(td, prof, names, seqs, sample_desc, coverage):
 
 def committed_counters(kernel_prefix):
     """Counters bench.py cannot collect itself, read from the newest committed rocprofv3 summaries of this same command
-    (profiles/r*_bench_pmc_hbm.csv: FETCH_SIZE / WRITE_SIZE in separate --pmc passes, KB -> bytes, per launch;
-    profiles/r*_bench_sq.csv: SQ_INSTS_VALU, SQ_THREAD_CYCLES_VALU ... per launch).  None when absent."""
+    (tools/profile_bench.sh -> profiles/r*_bench_pmc_hbm.csv: FETCH_SIZE / WRITE_SIZE in separate --pmc passes, KB -> bytes, per
+    launch; profiles/r*_bench_sq.csv: SQ_INSTS_VALU, active lanes, SQ_INSTS_SALU per launch).  A timed "launch" of k_reads is
+    its two class kernels (event-free reads, reads with indel events) back to back: their rows are added.  None when absent."""
     res = {}
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_pmc_hbm.csv")))
     if files:
+        tot = 0.0
         for line in open(files[-1]):
             if line.startswith("#") or line.startswith("kernel"):
                 continue
             name, fetch, write, n = line.rstrip("\n").rsplit(",", 3)
             if name.startswith(kernel_prefix):
-                res["traffic"] = (float(fetch) + float(write)) * 1024.0
-                res["traffic_source"] = os.path.relpath(files[-1], ROOT)
+                tot += (float(fetch) + float(write)) * 1024.0
+        if tot:
+            res["traffic"] = tot
+            res["traffic_source"] = os.path.relpath(files[-1], ROOT)
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_sq.csv")))
     if files:
+        valu = salu = lanes_w = 0.0
         for line in open(files[-1]):
             if line.startswith("#") or line.startswith("kernel"):
                 continue
             f = line.rstrip("\n").rsplit(",", 3)                      # kernel names contain commas
             if len(f) == 4 and f[0].startswith(kernel_prefix):
                 try:
-                    res["valu_insts_per_launch"] = float(f[1]); res["lanes_per_valu_inst"] = float(f[2]); res["salu_insts_per_launch"] = float(f[3])
-                    res["sq_source"] = os.path.relpath(files[-1], ROOT)
+                    v = float(f[1]); valu += v; lanes_w += v * float(f[2]); salu += float(f[3])
                 except ValueError:
                     pass
+        if valu:
+            res["valu_insts_per_launch"] = valu
+            res["lanes_per_valu_inst"] = lanes_w / valu
+            res["salu_insts_per_launch"] = salu
+            res["sq_source"] = os.path.relpath(files[-1], ROOT)
     return res
 
 
@@ -352,7 +361,7 @@ def main():
         out = {
             "metric": "paired-end read pairs/s (whole genreads job: MALBAC amplification + read allocation + read generation, PE150 30x)",
             "value": pairs_total / elapsed, "unit": "pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "strong" if world > 1 else "weak", "vs_baseline": None,
+            "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,   # the same job on 1, 2, 4, 8 GPUs
             "dtype": "u8/u32 (integer draws, byte sequences; fp64 only in the GC-weight draw and the allocation sums)", "data": "synthetic",
             "config": {"workload": ("configs[3] on %d GPU(s): %.0f Mb synthetic diploid genome (24 hg19-length records x 2 haplotypes, i.i.d. 30/20/20/30 %% ACGT, generated in HBM), "
                                     "PE150 %gx, HiSeq2500 model resampled to 150 bins, -p 100000 -r 1e-9 -s 260" % (world, sum(lens) / 1e6, a.coverage)),

@@ -356,7 +356,7 @@ def test_bench_single_gpu_contract(tmp_path):
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
-    assert d["unit"] == "pairs/s" and d["n_gpus"] == 1 and d["vs_baseline"] is None and "workload" in d["config"]
+    assert d["unit"] == "pairs/s" and d["n_gpus"] == 1 and d["vs_baseline"] is None and "workload" in d["config"] and d["scaling"] == "strong"
     rf = d["roofline"]
     assert rf["bound"] == "hbm" and 0 < rf["frac"] <= 1 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and rf["draws_per_s"] > 0
     assert d["cpu_baseline"]["kind"] in ("reference", "port") and d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] >= 1
