@@ -191,12 +191,13 @@ int         scs_download_read_numbers(scs_ctx* ctx, uint32_t* read_numbers);
 
 /* ---- host-only table access (no GPU needed): the thresholds scs_load_profile uploads -------------
  * which: 0 subs read1 [84][bins][4], 1 subs read2, 2 quality [16][bins][94], 3 insert length,
- *        4 deletion length, 5 insert size, 6 the compact quality rows the inject_errors kernel searches (uint32 words,
- *        16 or 56 per row, layout in scssim_amd/csrc/scs_tables.h; no cdf).  thr/cdf point into memory owned by the handle. */
+ *        4 deletion length, 5 insert size, 6 the alias rows of the quality tables that the inject_errors kernel draws from
+ *        (uint32 words, K + K/4 per row, K = 16 / 64 / 128 columns: scssim_amd/csrc/scs_tables.h; no cdf).
+ *        thr/cdf point into memory owned by the handle. */
 int         scs_profile_open(const char* profile_path, int paired, int isize, void** handle, char* errbuf, size_t errlen);
 int         scs_profile_table(void* handle, int which, const uint32_t** thr, const double** cdf, size_t* n);
 /* out[0..9] = read length, bins, t_insert, t_delete, isize_min, have_cdf2, insert_rate, del_rate, t_indel (one-draw
- * insertion/deletion test), words per compact quality row (16 or 56) */
+ * insertion/deletion test), columns per alias quality row (16, 64 or 128) */
 int         scs_profile_scalars(void* handle, double* out);
 void        scs_profile_close(void* handle);
 

@@ -237,6 +237,12 @@ struct Profile {
     std::vector<double> subs1, subs2;     // [84][bins][4]  (dist, then cdf in place)
     bool haveCdf2 = false;
     std::vector<double> qual;             // [16][bins][94]
+    // [REMAP] counter mode draws a quality symbol by the ALIAS method: of the 2^32 draws, symbol k of a row is hit by
+    // w_k = #{x : r(x) <= cdf[k]} - #{x : r(x) <= cdf[k-1]} in the reference's comparison (MyDefine.cpp:274-282; the last
+    // symbol takes the rest), and the alias row -- qualK columns (16, 64 or 128), column j = x >> (32 - log2 K) owning
+    // 2^32 / K draws of which the lowest t_j go to the row's j-th drawable symbol and the others to column alias_j's --
+    // hits it with exactly w_k draws as well (integer Vose construction).  Row = K words (t_j << log2 K | alias_j) + K bytes.
+    int qualK = 16; std::vector<uint32_t> qualAlias;
     std::vector<int> isizeAlphabet;
     std::vector<double> isizeCdf;
     double gcMeans[101];
@@ -403,6 +409,39 @@ Profile* load_profile(const std::string& path, bool paired, int isize) {
     for (int i = 0; i < 84; ++i) row_cumsum(P->subs1.data() + (size_t)i * B * 4, B, 4);
     P->haveCdf2 = paired && P->stdISize > 0;                                   // Profile.cpp:1416-1428
     if (P->haveCdf2) for (int i = 0; i < 84; ++i) row_cumsum(P->subs2.data() + (size_t)i * B * 4, B, 4);
+    {   // alias rows of the quality tables (counter mode)
+        const int Bq = P->bins;
+        auto count64 = [](double c) { uint64_t lo = 0, hi = 1ull << 32; while (lo < hi) { const uint64_t mid = (lo + hi) >> 1;
+            const double r = ZERO_FINAL + (1 - ZERO_FINAL) * ((uint32_t)mid / 4294967296.0); if (r <= c) lo = mid + 1; else hi = mid; } return lo; };
+        std::vector<std::vector<uint8_t>> sym((size_t)16 * Bq); std::vector<std::vector<uint64_t>> w((size_t)16 * Bq); size_t maxs = 1;
+        for (size_t row = 0; row < (size_t)16 * Bq; ++row) {
+            uint64_t prev = 0;
+            for (int k = 0; k < 94; ++k) {
+                uint64_t cnt = k == 93 ? (1ull << 32) : count64(P->qual[row * 94 + k]);
+                if (cnt < prev) cnt = prev;
+                if (cnt > prev) { sym[row].push_back((uint8_t)k); w[row].push_back(cnt - prev); prev = cnt; }
+            }
+            maxs = std::max(maxs, sym[row].size());
+        }
+        const int K = maxs <= 16 ? 16 : maxs <= 64 ? 64 : 128, abits = K == 16 ? 4 : K == 64 ? 6 : 7;
+        const uint64_t C = (1ull << 32) / (uint64_t)K; const size_t RW = (size_t)K + K / 4;
+        P->qualK = K; P->qualAlias.assign((size_t)16 * Bq * RW, 0u);
+        for (size_t row = 0; row < (size_t)16 * Bq; ++row) {
+            std::vector<uint64_t> m((size_t)K, 0); std::vector<uint32_t> t((size_t)K, 0), al((size_t)K, 0); std::vector<int> small, large;
+            for (size_t j = 0; j < w[row].size(); ++j) m[j] = w[row][j];
+            for (int j = 0; j < K; ++j) { al[(size_t)j] = (uint32_t)j; (m[(size_t)j] < C ? small : large).push_back(j); }
+            while (!small.empty() && !large.empty()) {
+                const int sj = small.back(); small.pop_back(); const int lj = large.back(); large.pop_back();
+                t[(size_t)sj] = (uint32_t)m[(size_t)sj]; al[(size_t)sj] = (uint32_t)lj;
+                m[(size_t)lj] -= C - m[(size_t)sj];
+                (m[(size_t)lj] < C ? small : large).push_back(lj);
+            }
+            uint32_t* r = &P->qualAlias[row * RW];
+            for (int j = 0; j < K; ++j) r[j] = (t[(size_t)j] << abits) | al[(size_t)j];
+            uint8_t* sb = reinterpret_cast<uint8_t*>(r + K);
+            for (int j = 0; j < K; ++j) sb[j] = (size_t)j < sym[row].size() ? sym[row][(size_t)j] : (uint8_t)0;
+        }
+    }
     {   // integer thresholds of the two indel tests (monotone in the 32-bit draw: found by bisection on the reference's
         // own double comparisons), combined for the one-draw counter mode
         auto count_true = [](auto pred) { uint64_t lo = 0, hi = 1ull << 32; while (lo < hi) { uint64_t mid = (lo + hi) >> 1; if (pred((uint32_t)mid)) lo = mid + 1; else hi = mid; } return (uint32_t)std::min<uint64_t>(lo, 0xFFFFFFFFull); };
@@ -532,7 +571,13 @@ int predict(const Profile& P, Rng& rng, const uint8_t* win, int n, bool isRead1,
         } else {
             out_b[j] = BASES[k];
             int bp = refIndx * 4 + k;
-            out_q[j] = (char)(33 + rand_indx(&P.qual[((size_t)bp * B + bin) * 94], 94, drawB()));
+            if (rng.counter) {                                                  // [REMAP] alias lookup on the raw 32-bit draw
+                const int K = P.qualK, abits = K == 16 ? 4 : K == 64 ? 6 : 7;
+                const uint32_t* row = &P.qualAlias[((size_t)bp * B + bin) * ((size_t)K + K / 4)];
+                const uint32_t x = xb.next(), col = x >> (32 - abits), e = row[col];
+                const uint32_t pick = (x & ((1u << (32 - abits)) - 1u)) < (e >> abits) ? col : (e & (uint32_t)(K - 1));
+                out_q[j] = (char)(33 + reinterpret_cast<const uint8_t*>(row + K)[pick]);
+            } else out_q[j] = (char)(33 + rand_indx(&P.qual[((size_t)bp * B + bin) * 94], 94, drawB()));
         }
     }
     return m;

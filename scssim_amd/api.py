@@ -151,7 +151,7 @@ class Profile:
     """Host-only view of a .profile model: the exact uint32 thresholds and the double CDFs they come from
     (mirrors Profile::train(file), reference lib/profile/Profile.cpp:1432-1436).  Needs no GPU."""
 
-    TABLES = {"subs1": 0, "subs2": 1, "qual": 2, "ins": 3, "del": 4, "isize": 5, "qual_compact": 6}
+    TABLES = {"subs1": 0, "subs2": 1, "qual": 2, "ins": 3, "del": 4, "isize": 5, "qual_alias": 6}
 
     def __init__(self, path, paired=True, isize=260):
         import numpy as np
@@ -166,7 +166,7 @@ class Profile:
         L.scs_profile_scalars(self._h, sc)
         (self.read_length, self.bins, self.t_insert, self.t_delete, self.isize_min, self.have_cdf2) = [int(v) for v in sc[:6]]
         self.insert_rate, self.del_rate = sc[6], sc[7]
-        self.t_indel, self.qual_row_words = int(sc[8]), int(sc[9])
+        self.t_indel, self.qual_k = int(sc[8]), int(sc[9])
 
     def table(self, name):
         np = self._np

@@ -144,16 +144,6 @@ __global__ void k_primer_update(int64_t* __restrict__ cnt, uint32_t* __restrict_
     delta[i] = 0;
 }
 
-// quality lookup: the guide row (LDS) bounds the search to the thresholds that fall into the draw's
-// 1/16 bucket, so the usual 7-step search over 94 thresholds becomes 0-2 global loads.
-__device__ __forceinline__ uint32_t qual_lookup(const uint32_t* __restrict__ T, const double* __restrict__ cdf, const uint8_t* guide_row, uint32_t x) {
-    if (x == 0xFFFFFFFFu) return rand_indx_slow(cdf, NQ, x);
-    const uint32_t v = x >> 28;
-    uint32_t lo = guide_row[v], hi = guide_row[v + 1];          // answer in [lo, hi]
-    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (x < T[mid]) hi = mid; else lo = mid + 1; }
-    return lo < (uint32_t)NQ ? lo : (uint32_t)NQ - 1;
-}
-
 // ASCII -> base code, in place (0..3 = ACGT either case, 4 = anything else): Genome::getSubSequence's toupper
 // (lib/genome/Genome.cpp:272-278) + getIndexOfBase (lib/mydefine/MyDefine.cpp:326-334).  16 bytes per thread.
 __global__ void k_encode_bases(uint8_t* __restrict__ g, uint64_t n) {
@@ -535,13 +525,16 @@ __global__ void k_plan_pairs(DevFrags fr, DevAmps semis, DevAmps fulls, uint32_t
 // ------------------------------------------------------------------------------------------------
 #define RB 256
 #define EV_MAX 8
-// ring geometry: two groups of bins (one being served, one being filled).  Small rows (every quality row has <= 12
-// drawable symbols, e.g. the binned-quality HiSeq X profiles): 1 KB bins, groups of 8.  Big rows (<= 40 symbols, the
-// 8-bit-quality profiles): 1.6 KB bins, groups of 4.
-template <bool QBIG> struct RingGeo;
-template <> struct RingGeo<false> { enum { SLOTS = 16, GROUP = 8, QROW = 4, NPRE = 3 }; };    // QROW: uint4 per quality row
-template <> struct RingGeo<true>  { enum { SLOTS = 8,  GROUP = 4, QROW = 14, NPRE = 2 }; };
-template <bool QBIG> struct RingBin { uint4 qd[4][RingGeo<QBIG>::QROW]; uint32_t subs[64][3]; };       // small 256 + 768 B, big 896 + 768 B
+// ring geometry: two groups of bins (one being served, one being filled).  A bin image = the 4 diagonal quality rows as
+// alias rows (QK columns: QK words + QK symbol bytes each, scs_tables.h) + the 64 k-mer substitution rows (3 thresholds).
+//   QK = 16  (binned-quality models, e.g. HiSeq X):   80 B rows, 1088 B bins, groups of 8
+//   QK = 64  (8-bit-quality models):                 320 B rows, 2048 B bins, groups of 4
+//   QK = 128 (a row with more than 64 symbols):      640 B rows, 3328 B bins, groups of 2
+template <int QK> struct RingGeo;
+template <> struct RingGeo<16>  { enum { SLOTS = 16, GROUP = 8, QROW = 5,  NPRE = 3, ABITS = 4 }; };     // QROW: uint4 per quality row
+template <> struct RingGeo<64>  { enum { SLOTS = 8,  GROUP = 4, QROW = 20, NPRE = 3, ABITS = 6 }; };
+template <> struct RingGeo<128> { enum { SLOTS = 4,  GROUP = 2, QROW = 40, NPRE = 2, ABITS = 7 }; };
+template <int QK> struct RingBin { uint4 qd[4][RingGeo<QK>::QROW]; uint32_t subs[64][3]; };
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 // LDS-qualified pointer types: keep the compiler from merging LDS and global accesses into FLAT ones
@@ -574,49 +567,28 @@ __device__ __forceinline__ void win_put(LdsU8* w, int i, uint32_t v) {
     w[i >> 1] = (uint8_t)((old & ~(15u << sh)) | (v << sh));
 }
 
-// quality lookup on a compact row in global memory; 255 = not resolved here (row does not fit, or the draw lies past the
-// last stored threshold): the caller searches the full row.
-//   small row, 16 words: {t3, t7, t11, -} + 3 x {t[4g], t[4g+1], t[4g+2], symbols 4g..4g+3}
-//   big row, 56 words:   pivots t[5g+4] (8) + 8 x {t[5g] .. t[5g+3]} + 8 x {symbols 5g..5g+4, 3 pad bytes}
-// thresholds ascend and are 0xFFFFFFFF padded; a row that does not fit has all-zero pivots.
-template <bool QBIG>
-__device__ __forceinline__ uint32_t qual_lookup_compact(const uint4* __restrict__ row, uint32_t x) {
-    if (!QBIG) {
-        const uint4 h = row[0];
-        const uint32_t gsel = (x >= h.x) + (x >= h.y) + (x >= h.z);
-        if (gsel == 3u) return 255u;
-        const uint4 G = row[1u + gsel];
-        const uint32_t ci = (x >= G.x) + (x >= G.y) + (x >= G.z);
-        return (G.w >> (8u * ci)) & 255u;
-    } else {
-        const uint4 p0 = row[0], p1 = row[1];
-        const uint32_t gsel = (x >= p0.x) + (x >= p0.y) + (x >= p0.z) + (x >= p0.w) + (x >= p1.x) + (x >= p1.y) + (x >= p1.z) + (x >= p1.w);
-        if (gsel == 8u) return 255u;
-        const uint4 G = row[2u + gsel];
-        const uint2 S = reinterpret_cast<const uint2*>(row + 10)[gsel];
-        const uint32_t ci = (x >= G.x) + (x >= G.y) + (x >= G.z) + (x >= G.w);
-        return ci < 4u ? (S.x >> (8u * ci)) & 255u : S.y & 255u;
-    }
+// [REMAP] quality symbol by the alias method (scs_tables.h): column = the draw's top bits; its low bits against the column's
+// threshold pick the column's own symbol or its alias; every symbol is hit by exactly as many of the 2^32 draws as in
+// the reference's CDF comparison.  One 4-byte and one 1-byte read, wherever the row lives.
+template <int QK, class W, class S>
+__device__ __forceinline__ uint32_t alias_pick(const W* __restrict__ row, const S* __restrict__ syms, uint32_t x) {
+    constexpr uint32_t AB = RingGeo<QK>::ABITS;
+    const uint32_t col = x >> (32u - AB), e = row[col];
+    const uint32_t pick = (x & ((1u << (32u - AB)) - 1u)) < (e >> AB) ? col : (e & (uint32_t)(QK - 1));
+    return syms[pick];
 }
-
-// base call + quality of one position entirely from the global tables (rows outside the LDS ring, substituted bases,
-// the x == 0xFFFFFFFF draws, rows that do not fit the compact form).  ki < 0: the base is not re-drawn, k comes in.
-template <bool QBIG>
-__device__ __noinline__ uint32_t call_global(const uint32_t* __restrict__ subs, const double* __restrict__ subs_d, const uint4* __restrict__ qcomp,
-                                             const uint32_t* __restrict__ qual, const double* __restrict__ qual_d, const uint8_t* __restrict__ guide,
+// base call + quality of one position entirely from the global tables (k-mer rows outside the LDS ring, substituted bases,
+// the xs == 0xFFFFFFFF draw).  ki < 0: the base is not re-drawn, k comes in.
+template <int QK>
+__device__ __noinline__ uint32_t call_global(const uint32_t* __restrict__ subs, const double* __restrict__ subs_d, const uint32_t* __restrict__ qalias,
                                              uint32_t B, int ki, uint32_t k, uint32_t c2, uint32_t bin, uint32_t xs, uint32_t xq) {
     if (ki >= 0) {
         const uint32_t row = ((uint32_t)ki * B + bin) * 4u;
         if (xs == 0xFFFFFFFFu) k = rand_indx_slow(subs_d + row, 4, xs);
         else { const uint4 T = *reinterpret_cast<const uint4*>(subs + row); k = (xs >= T.x) + (xs >= T.y) + (xs >= T.z); }
     }
-    const uint32_t qrow = (c2 * 4u + k) * B + bin;
-    uint32_t qv;
-    if (xq == 0xFFFFFFFFu) qv = rand_indx_slow(qual_d + (size_t)qrow * NQ, NQ, xq);
-    else {
-        qv = qual_lookup_compact<QBIG>(qcomp + (size_t)qrow * RingGeo<QBIG>::QROW, xq);
-        if (qv == 255u) qv = qual_lookup(qual + (size_t)qrow * NQ, qual_d + (size_t)qrow * NQ, guide + (size_t)qrow * 17u, xq);
-    }
+    const uint32_t* __restrict__ qrow = qalias + (size_t)((c2 * 4u + k) * B + bin) * (QK + QK / 4);
+    const uint32_t qv = alias_pick<QK>(qrow, reinterpret_cast<const uint8_t*>(qrow + QK), xq);
     return k | (qv << 8);
 }
 
@@ -788,7 +760,7 @@ struct BlockOut {
 // the reads without any indel event (CLS 1: 86 % of 150-base reads with the shipped models) and the rest (CLS 2), split
 // by k_read_lists from k_indels' result.  The event-free reads need none of the event handling -- no lookahead for the
 // next event, exactly one output position per table bin -- and their waves run with every lane busy at every bin.
-template <bool FROM_PAIRS, bool QBIG, int CLS>
+template <bool FROM_PAIRS, int QK, int CLS>
 __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, DevErrPool spool, DevErrPool fpool, const PairRec* __restrict__ pairs,
                                               uint32_t np, int paired, const uint8_t* __restrict__ windows, const uint64_t* __restrict__ uids,
                                               const uint32_t* __restrict__ atts, const uint8_t* __restrict__ is_read1, uint32_t n_explicit,
@@ -799,8 +771,8 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
                                               uint32_t* __restrict__ flags, uint64_t cap1, uint64_t cap2,
                                               const uint32_t* __restrict__ list1, const uint32_t* __restrict__ list2, uint32_t nlist1, uint32_t nlist2) {
     constexpr bool SIMPLE = CLS == 1;
-    typedef RingGeo<QBIG> Geo;
-    typedef RingBin<QBIG> Bin;
+    typedef RingGeo<QK> Geo;
+    typedef RingBin<QK> Bin;
     constexpr int SLOTS = Geo::SLOTS, GROUP = Geo::GROUP, QROW = Geo::QROW, EPB = 64 + 4 * QROW;   // EPB: 16-byte entries per bin image
     extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
     // the table descriptor is a by-value kernel argument: pointers loaded from the kernarg segment are known to be
@@ -1017,7 +989,7 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
     // barrier per group is enough.
     auto ring_entry = [&](int bin, int w) -> uint4 {                              // entry w (0..EPB) of a bin's ring image
         if (w >= 4 * QROW) return *reinterpret_cast<const uint4*>(ring_src + ((size_t)(20 + w - 4 * QROW) * B + bin) * 4);
-        return tb.qual_compact[((size_t)((w / QROW) * 5) * B + bin) * QROW + (w % QROW)];
+        return reinterpret_cast<const uint4*>(tb.qual_alias)[((size_t)((w / QROW) * 5) * B + bin) * QROW + (w % QROW)];   // diagonal rows (c, c): 5c
     };
     auto ring_put = [&](int bin, int w, uint4 v) {
         Bin* rb = &s_ring[bin & (SLOTS - 1)];
@@ -1062,24 +1034,9 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
         auto call_lds = [&](uint32_t kk, uint32_t c2, uint32_t xs, uint32_t xq, uint32_t& k, uint32_t& qv) -> uint32_t {
             const LdsU32* st = (const LdsU32*)rb->subs[kk];
             k = (xs >= st[0]) + (xs >= st[1]) + (xs >= st[2]);
-            const LdsU4* row = (const LdsU4*)rb->qd[c2 & 3u];
-            bool unresolved;
-            if (!QBIG) {
-                const u32x4_t h = row[0];                                          // {t3, t7, t11, -}
-                const uint32_t gsel = (xq >= h.x) + (xq >= h.y) + (xq >= h.z);
-                const u32x4_t G = row[1u + (gsel < 3u ? gsel : 2u)];               // {t4g, t4g+1, t4g+2, 4 symbols}
-                const uint32_t ci = (xq >= G.x) + (xq >= G.y) + (xq >= G.z);
-                qv = (G.w >> (8u * ci)) & 255u; unresolved = gsel == 3u;
-            } else {
-                const u32x4_t p0 = row[0], p1 = row[1];                            // pivots t[5g+4]
-                const uint32_t gsel = (xq >= p0.x) + (xq >= p0.y) + (xq >= p0.z) + (xq >= p0.w) + (xq >= p1.x) + (xq >= p1.y) + (xq >= p1.z) + (xq >= p1.w);
-                const uint32_t gs = gsel < 8u ? gsel : 7u;
-                const u32x4_t G = row[2u + gs];                                    // t[5g] .. t[5g+3]
-                const u32x2_t S = ((const LdsU2*)(row + 10))[gs];                  // symbols 5g .. 5g+4
-                const uint32_t ci = (xq >= G.x) + (xq >= G.y) + (xq >= G.z) + (xq >= G.w);
-                qv = ci < 4u ? (S.x >> (8u * ci)) & 255u : S.y & 255u; unresolved = gsel == 8u;
-            }
-            return ((xs == 0xFFFFFFFFu) | (xq == 0xFFFFFFFFu) | unresolved) ? 2u : (k != c2 ? 1u : 0u);
+            const LdsU32* qrow = (const LdsU32*)rb->qd[c2 & 3u];                     // the diagonal row (c2, c2) as an alias row
+            qv = alias_pick<QK>(qrow, (const LdsU8*)(qrow + QK), xq);
+            return xs == 0xFFFFFFFFu ? 2u : (k != c2 ? 1u : 0u);
         };
         auto defer = [&](uint32_t k, uint32_t c2, uint32_t xq) -> bool {
             const uint32_t w0 = (uint32_t)jo | (k << 12) | (c2 << 14) | ((uint32_t)t << 16);
@@ -1148,7 +1105,7 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
                         if (ki >= 20 && ring_subs_ok) odd = call_lds((uint32_t)ki - 20u, c2, xs, xq, k, qv);
                         if (odd == 1u && defer(k, c2, xq)) { qv = 0; odd = 0u; }
                         if (odd) {
-                            const uint32_t kq = call_global<QBIG>(subs, subs_d, tb.qual_compact, tb.qual, tb.qual_d, tb.qual_guide, (uint32_t)B, ki, c2, c2, (uint32_t)t, xs, xq);
+                            const uint32_t kq = call_global<QK>(subs, subs_d, tb.qual_alias, (uint32_t)B, ki, c2, c2, (uint32_t)t, xs, xq);
                             k = kq & 255u; qv = kq >> 8;
                         }
                         bc = (0x54474341u >> (8u * k)) & 255u; qc = 33 + qv;       // "ACGT"[k]
@@ -1161,7 +1118,7 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
                 uint32_t odd = call_lds(kk, c2, xs, xq, k, qv);
                 if (odd == 1u && defer(k, c2, xq)) { qv = 0; odd = 0u; }
                 if (odd) {
-                    const uint32_t kq = call_global<QBIG>(subs, subs_d, tb.qual_compact, tb.qual, tb.qual_d, tb.qual_guide, (uint32_t)B, (int)kk + 20, c2, c2, (uint32_t)t, xs, xq);
+                    const uint32_t kq = call_global<QK>(subs, subs_d, tb.qual_alias, (uint32_t)B, (int)kk + 20, c2, c2, (uint32_t)t, xs, xq);
                     k = kq & 255u; qv = kq >> 8;
                 }
                 bc = (0x54474341u >> (8u * k)) & 255u; qc = 33 + qv;
@@ -1210,8 +1167,8 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
         uint2 pe;
         if (FROM_PAIRS) { pe.x = my_pend_lds[2u * e]; pe.y = my_pend_lds[2u * e + 1u]; } else pe = my_pend[e];
         const uint32_t pk = (pe.x >> 12) & 3u, pc = (pe.x >> 14) & 3u, qrow = (pc * 4u + pk) * (uint32_t)B + (pe.x >> 16);
-        uint32_t qv = qual_lookup_compact<QBIG>(tb.qual_compact + (size_t)qrow * QROW, pe.y);
-        if (qv == 255u) qv = qual_lookup(tb.qual + (size_t)qrow * NQ, tb.qual_d + (size_t)qrow * NQ, tb.qual_guide + (size_t)qrow * 17u, pe.y);
+        const uint32_t* __restrict__ arow = tb.qual_alias + (size_t)qrow * (QK + QK / 4);
+        const uint32_t qv = alias_pick<QK>(arow, reinterpret_cast<const uint8_t*>(arow + QK), pe.y);
         if (FROM_PAIRS) wg_out[sec2 + a2 + (pe.x & 4095u)] = (char)(33u + qv);    // after the record's own stores (same lane: program order)
         else my_q[pe.x & 4095u] = (char)(33u + qv);
     }
@@ -1846,12 +1803,12 @@ void launch_attach_semis(hipStream_t s, const uint8_t* g, DevFrags fr, DevAmps s
     // lanes per semi amplicon (budget ~ Poisson(6)): 4 keeps the lanes busiest when the grid fills the chip, 8 finishes a
     // template in one round when the job is small and the pass is latency bound (measured: 15 vs 18 ms at 13 M semis,
     // 0.35 vs 0.5 ms per step at 44 k)
-    if (n_semis >= (1u << 18))
-        hipLaunchKernelGGL((k_attach<false, 4>), dim3(cdiv(n_semis, 16)), dim3(64), 0, s, g, fr, semis, n_semis, spool, slot_off, slots, slot_tmpl, valid,
-                           primer_cnt, primer_delta, (unsigned long long*)nullptr, p);
-    else
-        hipLaunchKernelGGL((k_attach<false, 8>), dim3(cdiv(n_semis, 8)), dim3(64), 0, s, g, fr, semis, n_semis, spool, slot_off, slots, slot_tmpl, valid,
-                           primer_cnt, primer_delta, (unsigned long long*)nullptr, p);
+    static const int forced = getenv("SCS_ATTACH_G") ? atoi(getenv("SCS_ATTACH_G")) : 0;   // tuning experiments
+    const int G = forced ? forced : (n_semis >= (1u << 18) ? 4 : 8);
+#define SCS_LAUNCH_ATTACH_SEMI(GG) hipLaunchKernelGGL((k_attach<false, GG>), dim3(cdiv(n_semis, 64 / GG)), dim3(64), 0, s, g, fr, semis, n_semis, spool, slot_off, slots, slot_tmpl, valid, \
+                           primer_cnt, primer_delta, (unsigned long long*)nullptr, p)
+    if (G == 2) SCS_LAUNCH_ATTACH_SEMI(2); else if (G == 16) SCS_LAUNCH_ATTACH_SEMI(16); else if (G == 8) SCS_LAUNCH_ATTACH_SEMI(8); else SCS_LAUNCH_ATTACH_SEMI(4);
+#undef SCS_LAUNCH_ATTACH_SEMI
 }
 void launch_errs_frags(hipStream_t s, const uint8_t* g, DevGenomeIdx gx, DevFrags fr, uint32_t n_slots, const uint32_t* slot_off, const uint32_t* slots,
                        const uint32_t* slot_tmpl, const uint32_t* valid_off, DevAmps out, uint32_t out_base, DevErrPool pool, uint32_t* flags,
@@ -1911,7 +1868,7 @@ void launch_pair_offsets(hipStream_t s, const uint32_t* rn, uint32_t ac, int pai
     else (void)rocprim::exclusive_scan(temp, temp_bytes, rn, pair_cnt_off, 0u, (size_t)ac + 1, rocprim::plus<uint32_t>(), s);
 }
 size_t reads_lds_bytes(const DevTables& tb) {
-    const size_t ring = tb.qual_big ? RingGeo<true>::SLOTS * sizeof(RingBin<true>) : RingGeo<false>::SLOTS * sizeof(RingBin<false>);
+    const size_t ring = tb.qual_k == 16 ? RingGeo<16>::SLOTS * sizeof(RingBin<16>) : tb.qual_k == 64 ? RingGeo<64>::SLOTS * sizeof(RingBin<64>) : RingGeo<128>::SLOTS * sizeof(RingBin<128>);
     return ring + (size_t)RB * EV_MAX * 2 + (size_t)RB * win_stride((uint32_t)tb.L);
 }
 template <bool FROM_PAIRS, int CLS, class... Args>
@@ -1919,16 +1876,14 @@ static void launch_reads_kernel(hipStream_t s, dim3 grid, const DevTables& tb, A
     const size_t lds = reads_lds_bytes(tb);
     // > 64 KB of dynamic LDS needs the opt-in; the limit is raised to exactly what this profile needs (once per size:
     // the call sits on the host's critical path of a small job)
-    static size_t opted_all[64][2] = {};                                           // per device and instantiation (the attribute belongs to the device's code object)
+    static size_t opted_all[64][3] = {};                                           // per device and instantiation (the attribute belongs to the device's code object)
     int dev = 0; (void)hipGetDevice(&dev);
     size_t* opted = opted_all[dev & 63];
-    if (tb.qual_big) {
-        if (opted[1] != lds) { note_launch(hipFuncSetAttribute((const void*)k_reads<FROM_PAIRS, true, CLS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); opted[1] = lds; }
-        hipLaunchKernelGGL((k_reads<FROM_PAIRS, true, CLS>), grid, dim3(RB), lds, s, args...);
-    } else {
-        if (opted[0] != lds) { note_launch(hipFuncSetAttribute((const void*)k_reads<FROM_PAIRS, false, CLS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); opted[0] = lds; }
-        hipLaunchKernelGGL((k_reads<FROM_PAIRS, false, CLS>), grid, dim3(RB), lds, s, args...);
-    }
+#define SCS_LAUNCH_READS(QKV, SLOT) do { \
+        if (opted[SLOT] != lds) { note_launch(hipFuncSetAttribute((const void*)k_reads<FROM_PAIRS, QKV, CLS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); opted[SLOT] = lds; } \
+        hipLaunchKernelGGL((k_reads<FROM_PAIRS, QKV, CLS>), grid, dim3(RB), lds, s, args...); } while (0)
+    if (tb.qual_k == 16) SCS_LAUNCH_READS(16, 0); else if (tb.qual_k == 64) SCS_LAUNCH_READS(64, 1); else SCS_LAUNCH_READS(128, 2);
+#undef SCS_LAUNCH_READS
 }
 static uint32_t reads_force_replay() {                                             // tests: every read with an indel takes the replay path
     static const uint32_t v = getenv("SCS_EV_REPLAY") ? 1u : 0u;

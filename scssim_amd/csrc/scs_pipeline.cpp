@@ -286,14 +286,14 @@ void do_load_profile(scs_ctx* c, const char* path) {
     load_profile(path, c->cfg.paired != 0, c->cfg.isize, c->prof);
     ProfileTables& P = c->prof; hipStream_t s = c->stream;
     upload(c->t_subs1, P.subs1_t, s); upload(c->t_subs2, P.subs2_t, s); upload(c->t_qual, P.qual_t, s);
-    upload(c->t_guide, P.qual_guide, s); upload(c->t_qcompact, P.qual_compact, s); upload(c->t_ins, P.ins_t, s); upload(c->t_del, P.del_t, s); upload(c->t_isize, P.isize_t, s); upload(c->t_gap, P.gap_t, s);
+    upload(c->t_qcompact, P.qual_alias, s); upload(c->t_ins, P.ins_t, s); upload(c->t_del, P.del_t, s); upload(c->t_isize, P.isize_t, s); upload(c->t_gap, P.gap_t, s);
     upload(c->d_subs1, P.subs1, s); upload(c->d_subs2, P.subs2, s); upload(c->d_qual, P.qual, s);
     upload(c->d_ins, P.ins_cdf, s); upload(c->d_del, P.del_cdf, s); upload(c->d_isize, P.isize_cdf, s);
     std::vector<double> gm(P.gc_means, P.gc_means + 101); upload(c->d_gcmeans, gm, s);
     HIP_OK(hipStreamSynchronize(s));
     DevTables& t = c->dtb;
     t.L = P.read_length; t.bins = P.bins; t.t_insert = P.t_insert; t.t_delete = P.t_delete; t.t_indel = P.t_indel; t.t_ber = threshold_lt(c->cfg.ber); t.gap_t = c->t_gap.as<uint32_t>(); t.t_kind = P.t_kind;
-    t.subs1 = c->t_subs1.as<uint32_t>(); t.subs2 = P.have_cdf2 ? c->t_subs2.as<uint32_t>() : nullptr; t.qual = c->t_qual.as<uint32_t>(); t.qual_guide = c->t_guide.as<uint8_t>(); t.qual_compact = c->t_qcompact.as<uint4>(); t.qual_big = P.qual_big ? 1 : 0;
+    t.subs1 = c->t_subs1.as<uint32_t>(); t.subs2 = P.have_cdf2 ? c->t_subs2.as<uint32_t>() : nullptr; t.qual = c->t_qual.as<uint32_t>(); t.qual_alias = c->t_qcompact.as<uint32_t>(); t.qual_k = P.qual_k;
     t.ins_t = c->t_ins.as<uint32_t>(); t.n_ins = (int)P.ins_t.size(); t.del_t = c->t_del.as<uint32_t>(); t.n_del = (int)P.del_t.size();
     t.isize_t = c->t_isize.as<uint32_t>(); t.n_isize = (int)P.isize_t.size(); t.isize_min = P.isize_min;
     t.subs1_d = c->d_subs1.as<double>(); t.subs2_d = P.have_cdf2 ? c->d_subs2.as<double>() : nullptr; t.qual_d = c->d_qual.as<double>();
@@ -1277,7 +1277,7 @@ int scs_profile_table(void* handle, int which, const uint32_t** thr, const doubl
     switch (which) {
         case 0: t = &T->subs1_t; d = &T->subs1; break; case 1: t = &T->subs2_t; d = &T->subs2; break; case 2: t = &T->qual_t; d = &T->qual; break;
         case 3: t = &T->ins_t; d = &T->ins_cdf; break; case 4: t = &T->del_t; d = &T->del_cdf; break; case 5: t = &T->isize_t; d = &T->isize_cdf; break;
-        case 6: if (thr) *thr = T->qual_compact.data(); if (cdf) *cdf = nullptr; if (n) *n = T->qual_compact.size(); return SCS_OK;   // compact quality rows
+        case 6: if (thr) *thr = T->qual_alias.data(); if (cdf) *cdf = nullptr; if (n) *n = T->qual_alias.size(); return SCS_OK;   // alias quality rows
         default: return SCS_EINVAL;
     }
     if (thr) *thr = t->data(); if (cdf) *cdf = d->data(); if (n) *n = t->size();
@@ -1287,7 +1287,7 @@ int scs_profile_scalars(void* handle, double* out) {
     if (!handle || !out) return SCS_EINVAL;
     ProfileTables* T = (ProfileTables*)handle;
     out[0] = T->read_length; out[1] = T->bins; out[2] = T->t_insert; out[3] = T->t_delete; out[4] = T->isize_min; out[5] = T->have_cdf2; out[6] = T->insert_rate; out[7] = T->del_rate;
-    out[8] = T->t_indel; out[9] = T->qual_row_words;
+    out[8] = T->t_indel; out[9] = T->qual_k;
     return SCS_OK;
 }
 void scs_profile_close(void* handle) { delete (ProfileTables*)handle; }

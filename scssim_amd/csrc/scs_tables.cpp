@@ -215,39 +215,13 @@ void load_profile(const std::string& path, bool paired, int isize, ProfileTables
     auto to_thr = [](const std::vector<double>& c, std::vector<uint32_t>& t) { t.resize(c.size()); for (size_t i = 0; i < c.size(); ++i) t[i] = threshold_cdf(c[i]); };
     to_thr(T.subs1, T.subs1_t); to_thr(T.subs2, T.subs2_t); to_thr(T.qual, T.qual_t);
     to_thr(T.ins_cdf, T.ins_t); to_thr(T.del_cdf, T.del_t); to_thr(T.isize_cdf, T.isize_t);
-    T.qual_guide.assign((size_t)16 * B * 17 + 16, 0);
-    for (size_t row = 0; row < 16 * B; ++row) {
-        const uint32_t* t = &T.qual_t[row * 94];
-        for (uint64_t v = 0; v <= 16; ++v) { uint32_t n = 0; while (n < 94 && (uint64_t)t[n] <= (v << 28)) ++n; T.qual_guide[row * 17 + v] = (uint8_t)n; }
-    }
-    // compact rows: the symbols of a row that can be drawn at all (threshold strictly above the previous one)
-    std::vector<std::vector<uint32_t>> thr_of(16 * B); std::vector<std::vector<uint8_t>> sym_of(16 * B); size_t max_syms = 0;
-    for (size_t row = 0; row < 16 * B; ++row) {
-        const uint32_t* t = &T.qual_t[row * 94]; uint32_t prev = 0;
-        for (int k = 0; k < 94; ++k) if (t[k] > prev) { thr_of[row].push_back(t[k]); sym_of[row].push_back((uint8_t)k); prev = t[k]; }
-        max_syms = std::max(max_syms, thr_of[row].size());
-    }
-    T.qual_big = max_syms > 12; T.qual_row_words = T.qual_big ? 56 : 16;
-    const size_t cap = T.qual_big ? 40 : 12, RW = (size_t)T.qual_row_words;
-    T.qual_compact.assign((size_t)16 * B * RW, 0u);                                // all-zero pivots = "row does not fit": search the full row
-    for (size_t row = 0; row < 16 * B; ++row) {
-        const size_t n = thr_of[row].size(); uint32_t* w = &T.qual_compact[row * RW];
-        if (n > cap) continue;
-        uint32_t thr[40]; uint8_t sym[48];
-        for (size_t i = 0; i < 40; ++i) { thr[i] = i < n ? thr_of[row][i] : 0xFFFFFFFFu; sym[i] = i < n ? sym_of[row][i] : (uint8_t)93; }
-        auto pack4 = [&](size_t i) { return (uint32_t)sym[i] | ((uint32_t)sym[i + 1] << 8) | ((uint32_t)sym[i + 2] << 16) | ((uint32_t)sym[i + 3] << 24); };
-        if (!T.qual_big) {
-            // head {t3, t7, t11, 0}; group g = {t[4g], t[4g+1], t[4g+2], symbols 4g..4g+3}: two 16-byte reads per lookup
-            w[0] = thr[3]; w[1] = thr[7]; w[2] = thr[11]; w[3] = 0;
-            for (size_t gq = 0; gq < 3; ++gq) { uint32_t* d = w + 4 + 4 * gq; d[0] = thr[4 * gq]; d[1] = thr[4 * gq + 1]; d[2] = thr[4 * gq + 2]; d[3] = pack4(4 * gq); }
-        } else {
-            // 8 pivots t[5g+4]; 8 groups {t[5g] .. t[5g+3]}; 8 x {symbols 5g..5g+4, 3 pad bytes}
-            for (size_t gq = 0; gq < 8; ++gq) {
-                w[gq] = thr[5 * gq + 4];
-                for (size_t i = 0; i < 4; ++i) w[8 + 4 * gq + i] = thr[5 * gq + i];
-                w[40 + 2 * gq] = pack4(5 * gq); w[41 + 2 * gq] = (uint32_t)sym[5 * gq + 4];
-            }
-        }
+    {   // alias rows of the quality tables ([REMAP], scs_tables.h)
+        std::vector<uint8_t> sym((size_t)16 * B * 94); std::vector<uint64_t> w((size_t)16 * B * 94); std::vector<int> ns((size_t)16 * B); int max_syms = 1;
+        for (size_t row = 0; row < (size_t)16 * B; ++row) { ns[row] = quality_row_weights(&T.qual[row * 94], &sym[row * 94], &w[row * 94]); max_syms = std::max(max_syms, ns[row]); }
+        T.qual_k = max_syms <= 16 ? 16 : max_syms <= 64 ? 64 : 128;
+        const size_t RW = (size_t)T.qual_k + T.qual_k / 4;
+        T.qual_alias.assign((size_t)16 * B * RW, 0u);
+        for (size_t row = 0; row < (size_t)16 * B; ++row) quality_alias_row(&sym[row * 94], &w[row * 94], ns[row], T.qual_k, &T.qual_alias[row * RW]);
     }
     T.t_insert = threshold_le(T.insert_rate);
     T.t_delete = threshold_lt(T.del_rate / (1 - T.insert_rate));
@@ -267,6 +241,41 @@ static std::string index_name(const std::string& header) {      // Fasta.cpp:56-
     i = nm.find("chr");
     if (i != std::string::npos) return nm.substr(i + 3);
     return nm;
+}
+template <class Pred>   // as count_true, without the clamp: 0 .. 2^32
+static uint64_t count_true64(Pred pred) {
+    uint64_t lo = 0, hi = 1ull << 32;
+    while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (pred((uint32_t)mid)) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+int quality_row_weights(const double* cdf, uint8_t sym[94], uint64_t w[94]) {
+    int n = 0; uint64_t prev = 0;
+    for (int k = 0; k < 94; ++k) {
+        const double c = cdf[k];
+        uint64_t cnt = k == 93 ? (1ull << 32)                                       // randIndx falls through to the last symbol (MyDefine.cpp:281)
+                               : count_true64([c](uint32_t x) { const double r = kZeroFinal + (1 - kZeroFinal) * (x / 4294967296.0); return r <= c; });
+        if (cnt < prev) cnt = prev;
+        if (cnt > prev) { sym[n] = (uint8_t)k; w[n] = cnt - prev; ++n; prev = cnt; }
+    }
+    return n;
+}
+void quality_alias_row(const uint8_t* sym, const uint64_t* w, int n, int K, uint32_t* row) {
+    const int abits = K == 16 ? 4 : K == 64 ? 6 : 7;
+    const uint64_t C = (1ull << 32) / (uint64_t)K;                                 // draws per column
+    std::vector<uint64_t> m((size_t)K, 0); std::vector<uint32_t> t((size_t)K, 0), al((size_t)K, 0);
+    for (int j = 0; j < n; ++j) m[(size_t)j] = w[j];
+    std::vector<int> small, large;
+    for (int j = 0; j < K; ++j) { al[(size_t)j] = (uint32_t)j; (m[(size_t)j] < C ? small : large).push_back(j); }
+    while (!small.empty() && !large.empty()) {                                     // Vose, in integers: the sums stay exact
+        const int sj = small.back(); small.pop_back(); const int lj = large.back(); large.pop_back();
+        t[(size_t)sj] = (uint32_t)m[(size_t)sj]; al[(size_t)sj] = (uint32_t)lj;
+        m[(size_t)lj] -= C - m[(size_t)sj];
+        (m[(size_t)lj] < C ? small : large).push_back(lj);
+    }
+    // what is left holds exactly a column's worth: "always my own symbol" = threshold 0 with myself as the alias
+    for (int j = 0; j < K; ++j) row[j] = (t[(size_t)j] << abits) | al[(size_t)j];
+    uint8_t* sb = reinterpret_cast<uint8_t*>(row + K);
+    for (int j = 0; j < K; ++j) sb[j] = j < n ? sym[j] : (uint8_t)0;
 }
 std::vector<uint32_t> indel_gap_table(uint32_t t_indel, int read_length) {
     std::vector<uint32_t> t((size_t)read_length + 1, 0xFFFFFFFFu);

@@ -23,18 +23,14 @@ struct ProfileTables {
     // 2^32-1, so the lookup is `x < T[k]`; exact for every x except x == 0xFFFFFFFF, which the kernels
     // route to the double tables.
     std::vector<uint32_t> subs1_t, subs2_t, qual_t, ins_t, del_t, isize_t;
-    // per quality row (16*bins of them) 17 counts: guide[v] = #{k : qual_t[row][k] <= v << 28}, v = 0..16
-    // (a draw x with x >> 28 == v resolves to a symbol in [guide[v], guide[v+1]]).
-    std::vector<uint8_t> qual_guide;
-    // compact quality rows: the symbols of a row that can be drawn at all (threshold strictly above the previous one),
-    // thresholds ascending and 0xFFFFFFFF padded, laid out for a two-level search with 16-byte reads.
-    //   small (every row has <= 12 such symbols; qual_row_words = 16):
-    //       {t3, t7, t11, 0} + 3 x {t[4g], t[4g+1], t[4g+2], symbols 4g..4g+3}
-    //   big (some row has more; rows up to 40 symbols; qual_row_words = 56):
-    //       8 pivots t[5g+4] + 8 x {t[5g] .. t[5g+3]} + 8 x {symbols 5g..5g+4, 3 pad bytes}
-    // a row that does not fit keeps all-zero pivots: every draw falls off the end and the full row + guide is searched.
-    bool qual_big = false; int qual_row_words = 16;
-    std::vector<uint32_t> qual_compact;
+    // [REMAP] quality symbols by the ALIAS method (Walker / Vose) instead of a CDF search.  Of the 2^32 draws, symbol k of a
+    // row is hit by w_k = #{x : r(x) <= cdf[k]} - #{x : r(x) <= cdf[k-1]} of them in the reference's comparison (the last
+    // symbol takes what is left, randIndx's `return ac-1`).  The alias row hits symbol k with EXACTLY w_k draws too: K =
+    // qual_k columns (16, 64 or 128: the smallest that holds the most varied row), column j = x >> (32 - log2 K) owns
+    // 2^32 / K draws, of which the lowest t_j go to the row's j-th drawable symbol and the rest to column alias_j's
+    // (integer Vose construction: no rounding anywhere).  Row = K words (t_j << log2 K | alias_j) + K symbol bytes.
+    int qual_k = 16;
+    std::vector<uint32_t> qual_alias;    // [16*bins][qual_k + qual_k/4] words
     uint32_t t_insert = 0;               // p <= insertRate            (Profile.cpp:1557)
     uint32_t t_delete = 0;               // p <  delRate/(1-insertRate) (Profile.cpp:1565-1566)
     // [REMAP] both tests from ONE draw x: x < t_insert -> insertion, else x < t_indel -> deletion, with the deletion
@@ -49,6 +45,10 @@ struct ProfileTables {
 // shared with the oracle: the same loop in the same IEEE operations
 std::vector<uint32_t> indel_gap_table(uint32_t t_indel, int read_length);
 uint32_t indel_kind_threshold(uint32_t t_insert, uint32_t t_indel);
+// the drawable symbols of a quality CDF row and their exact draw counts (sum 2^32); returns their number
+int quality_row_weights(const double* cdf94, uint8_t sym[94], uint64_t w[94]);
+// alias row of K columns (words: K entries, then K symbol bytes) from those weights; n <= K
+void quality_alias_row(const uint8_t* sym, const uint64_t* w, int n, int K, uint32_t* row_words);
 
 // count of 32-bit draws x with (x / 2^32) < c  resp. <= c, clamped to 2^32-1
 uint32_t threshold_lt(double c);

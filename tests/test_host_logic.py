@@ -149,51 +149,38 @@ def test_fasta_staging_edge_cases(tmp_path):
         scssim_amd.fasta_probe(str(tmp_path / "missing.fa"))
 
 
-def _compact_lookup(rows, words, x):
-    """numpy restatement of the two-level search the inject_errors kernel runs on a compact quality row (255 = not resolved)."""
-    x = x.astype(np.uint64)
-    r = rows.astype(np.uint64)
-    if words == 16:                                       # {t3, t7, t11, -} + 3 x {t[4g], t[4g+1], t[4g+2], symbols 4g..4g+3}
-        gsel = (x >= r[:, 0]).astype(int) + (x >= r[:, 1]) + (x >= r[:, 2])
-        g = np.minimum(gsel, 2)
-        base = 4 + 4 * g
-        idx = np.arange(len(x))
-        ci = (x >= r[idx, base]).astype(int) + (x >= r[idx, base + 1]) + (x >= r[idx, base + 2])
-        sym = (r[idx, base + 3] >> (8 * ci).astype(np.uint64)) & 255
-        return np.where(gsel == 3, 255, sym).astype(int)
-    gsel = sum((x >= r[:, k]).astype(int) for k in range(8))   # 8 pivots t[5g+4]
-    g = np.minimum(gsel, 7)
-    idx = np.arange(len(x))
-    base = 8 + 4 * g
-    ci = sum((x >= r[idx, base + k]).astype(int) for k in range(4))
-    lo, hi = r[idx, 40 + 2 * g], r[idx, 41 + 2 * g]
-    sym = np.where(ci < 4, (lo >> (8 * np.minimum(ci, 3)).astype(np.uint64)) & 255, hi & 255)
-    return np.where(gsel == 8, 255, sym).astype(int)
-
-
 @pytest.mark.parametrize("model", ["Illumina_HiSeqXTen", "Illumina_HiSeq2500", "Illumina_GenomeAnalyzerIIx"])
-def test_compact_quality_rows_equal_the_full_row_search(model, models):
-    """The compact rows (what the kernel searches in LDS) must give, for every draw they resolve, the symbol of the full
-    94-threshold row: first k with x < T[k] (randIndx, MyDefine.cpp:274-282), else 93.  Small (16-word) and big (56-word) layouts."""
+def test_alias_quality_rows_hit_every_symbol_with_the_reference_count(model, models):
+    """[REMAP] quality symbols are drawn by the alias method.  Of the 2^32 possible draws, the reference's comparison
+    (first k with r(x) <= cdf[k], else the last symbol; MyDefine.cpp:274-282) sends w_k = T[k] - T[k-1] to symbol k; the alias
+    row (K columns of 2^32 / K draws: the lowest t_j of a column to its own symbol, the rest to its alias) must send EXACTLY
+    as many -- for every row of every shipped model."""
     P = scssim_amd.Profile(models[model])
     thr, _ = P.table("qual")
-    comp, _ = P.table("qual_compact")
-    W = P.qual_row_words
-    assert W == (16 if model == "Illumina_HiSeqXTen" else 56)
-    rows = thr.reshape(-1, 94).astype(np.uint64)
-    comp = comp.reshape(-1, W)
-    assert comp.shape[0] == rows.shape[0] == 16 * P.bins
-    rng = np.random.default_rng(11)
-    pick = rng.integers(0, rows.shape[0], size=200000)
-    x = rng.integers(0, 0xFFFFFFFF, size=pick.size, dtype=np.uint64)     # x == 0xFFFFFFFF never reaches the compact rows
-    x[:2000] = rows[pick[:2000], rng.integers(0, 94, size=2000)]         # exactly on thresholds
-    x[2000:4000] = np.maximum(rows[pick[2000:4000], rng.integers(0, 94, size=2000)], 1) - 1
-    x = np.minimum(x, 0xFFFFFFFE)
-    want = np.minimum((x[:, None] >= rows[pick]).sum(axis=1), 93)        # first k with x < T[k], else ac-1
-    got = _compact_lookup(comp[pick], W, x)
-    resolved = got != 255
-    assert resolved.mean() > 0.99, "the compact rows should resolve almost every draw of this model"
-    assert np.array_equal(got[resolved], want[resolved])
+    al, _ = P.table("qual_alias")
+    K = P.qual_k
+    assert K == (16 if model == "Illumina_HiSeqXTen" else 64)
+    abits = {16: 4, 64: 6, 128: 7}[K]
+    C = (1 << 32) >> abits
+    rows = thr.reshape(-1, 94).astype(np.int64)
+    al = al.reshape(rows.shape[0], K + K // 4)
+    assert rows.shape[0] == 16 * P.bins
+    # the reference's counts: thresholds are clamped at 2^32 - 1, and whatever the comparison leaves falls to the last symbol
+    cnt = np.maximum.accumulate(rows, axis=1)
+    cnt[:, 93] = 1 << 32
+    want = np.diff(np.concatenate([np.zeros((rows.shape[0], 1), np.int64), cnt], axis=1), axis=1)
+    top = rows == 0xFFFFFFFF                                          # a clamped threshold stands for 2^32 - 1 or 2^32: one draw of slack
+    ent = al[:, :K].astype(np.int64)
+    t, alias = ent >> abits, ent & (K - 1)
+    syms = np.ascontiguousarray(al[:, K:]).view(np.uint8).reshape(rows.shape[0], K).astype(np.int64)
+    own_mass = np.where((t == 0) & (alias == np.arange(K)[None, :]), C, t)     # "always my own symbol" is stored as threshold 0 + self alias
+    got = np.zeros_like(want)
+    r = np.repeat(np.arange(rows.shape[0]), K)
+    np.add.at(got, (r, syms.ravel()), own_mass.ravel())
+    np.add.at(got, (r, np.take_along_axis(syms, alias, axis=1).ravel()), (C - own_mass).ravel())
+    assert (got.sum(axis=1) == 1 << 32).all()
+    diff = np.abs(got - want)
+    assert diff.max() <= 1 and (diff[~(top | np.roll(top, 1, axis=1))] == 0).all()
     # the one-draw indel test: x < t_insert -> insertion, else x < t_indel -> deletion, deletion threshold rescaled
     assert P.t_indel == P.t_insert + (((1 << 32) - P.t_insert) * P.t_delete >> 32)
 
