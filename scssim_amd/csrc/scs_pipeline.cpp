@@ -791,14 +791,39 @@ void do_yield(scs_ctx* c, const OutTarget& tg, uint64_t* n1_out, uint64_t* n2_ou
         c->pipe->start(tg.sink, tg.user, paired != 0, c->cfg.device); guard.p = c->pipe;
     }
     uint64_t bi = 0;
+    // Per batch a PRE-PASS (indel events -> record sizes -> offsets, class lists; k_indels + scans) must finish before the host
+    // can launch the base pass (it needs the batch's byte counts and class counts).  The pre-pass of batch i+1 is therefore
+    // queued BEFORE the base pass of batch i, into a second set of buffers: while the host waits for its mail the GPU
+    // still has a base pass to run.
     const uint64_t nreads_b = paired ? 2 * batch : batch;
-    c->ev_hdr.reserve(nreads_b * 4, s); c->ev_dat.reserve(nreads_b * 16, s);
-    c->sizes1.reserve((batch + 1) * 4, s); c->sizes2.reserve((batch + 1) * 4, s); c->off1.reserve((batch + 1) * 8, s); c->off2.reserve((batch + 1) * 8, s);
+    c->ev_hdr.reserve(2 * nreads_b * 4, s); c->ev_dat.reserve(2 * nreads_b * 16, s);
+    c->sizes1.reserve(2 * (batch + 1) * 4, s); c->sizes2.reserve(2 * (batch + 1) * 4, s); c->off1.reserve(2 * (batch + 1) * 8, s); c->off2.reserve(2 * (batch + 1) * 8, s);
     c->scan_tmp.reserve(scan_temp_bytes(batch), s);
     // the reads of a batch split by class (with / without indel events): flags, their scans, four lists of pair indices
-    c->rl_cls.reserve((batch + 1) * 2 * 4, s); c->rl_pos.reserve((batch + 1) * 2 * 4, s); c->rl_lists.reserve(batch * 4 * 4, s);
-    uint32_t* cls1 = c->rl_cls.as<uint32_t>(); uint32_t* cls2 = cls1 + batch + 1; uint32_t* cpos1 = c->rl_pos.as<uint32_t>(); uint32_t* cpos2 = cpos1 + batch + 1;
-    uint32_t* slist1 = c->rl_lists.as<uint32_t>(); uint32_t* slist2 = slist1 + batch; uint32_t* clist1 = slist2 + batch; uint32_t* clist2 = clist1 + batch;
+    c->rl_cls.reserve(2 * (batch + 1) * 2 * 4, s); c->rl_pos.reserve(2 * (batch + 1) * 2 * 4, s); c->rl_lists.reserve(2 * batch * 4 * 4, s);
+    struct BatchSet { uint32_t* ev_hdr; uint4* ev_dat; uint32_t *sizes1, *sizes2; uint64_t *off1, *off2; uint32_t *cls1, *cls2, *cpos1, *cpos2, *slist1, *slist2, *clist1, *clist2; } bs[2];
+    for (int k = 0; k < 2; ++k) {
+        bs[k].ev_hdr = c->ev_hdr.as<uint32_t>() + k * nreads_b; bs[k].ev_dat = c->ev_dat.as<uint4>() + k * nreads_b;
+        bs[k].sizes1 = c->sizes1.as<uint32_t>() + k * (batch + 1); bs[k].sizes2 = c->sizes2.as<uint32_t>() + k * (batch + 1);
+        bs[k].off1 = c->off1.as<uint64_t>() + k * (batch + 1); bs[k].off2 = c->off2.as<uint64_t>() + k * (batch + 1);
+        bs[k].cls1 = c->rl_cls.as<uint32_t>() + k * 2 * (batch + 1); bs[k].cls2 = bs[k].cls1 + batch + 1;
+        bs[k].cpos1 = c->rl_pos.as<uint32_t>() + k * 2 * (batch + 1); bs[k].cpos2 = bs[k].cpos1 + batch + 1;
+        bs[k].slist1 = c->rl_lists.as<uint32_t>() + k * 4 * batch; bs[k].slist2 = bs[k].slist1 + batch; bs[k].clist1 = bs[k].slist2 + batch; bs[k].clist2 = bs[k].clist1 + batch;
+    }
+    auto prepass = [&](uint64_t p0, const BatchSet& B) {
+        const uint32_t np = (uint32_t)std::min<uint64_t>(batch, P - p0);
+        const PairRec* pr = c->pairs.as<PairRec>() + p0;
+        // the indel pass fixes every read's length, hence the record sizes and (prefix sums) the record offsets
+        c->tm_indels.begin(s);
+        launch_indels(s, pr, np, paired, c->dtb, c->key, slot, B.ev_hdr, B.ev_dat, B.sizes1, B.sizes2, B.cls1, B.cls2, c->flags.as<uint32_t>());
+        c->tm_indels.end(s);
+        c->tm_indels.add_units(np);
+        exclusive_scan_u32_to_u64(s, B.sizes1, B.off1, np, c->scan_tmp.p, c->scan_tmp.cap);
+        if (paired) exclusive_scan_u32_to_u64(s, B.sizes2, B.off2, np, c->scan_tmp.p, c->scan_tmp.cap);
+        launch_read_lists(s, np, paired, B.cls1, B.cpos1, B.cls2, B.cpos2, B.slist1, B.slist2, B.clist1, B.clist2, c->scan_tmp.p, c->scan_tmp.cap);
+        Mail m; m.add(B.off1 + np, 8, 0); m.add(paired ? (const void*)(B.off2 + np) : nullptr, 8, 1);
+        m.add(B.cpos1 + np, 4, 2); m.add(paired ? (const void*)(B.cpos2 + np) : nullptr, 4, 3); mail_post(c, m, true);
+    };
     uint64_t tot1 = 0, tot2 = 0, pairs_written = 0;
     // shard index: the pair index at which each list segment starts (pair_off at the segment's first amplicon)
     std::vector<uint64_t> bpair; size_t bnext = 0;
@@ -808,25 +833,18 @@ void do_yield(scs_ctx* c, const OutTarget& tg, uint64_t* n1_out, uint64_t* n2_ou
         HIP_OK(hipStreamSynchronize(s));
         bpair.assign(v.begin(), v.end()); tg.seg_off1->assign(ALLOC_SLOTS + 1, 0); if (tg.seg_off2) tg.seg_off2->assign(ALLOC_SLOTS + 1, 0);
     }
-    for (uint64_t p0 = 0; p0 < P; p0 += batch) {
+    if (P) prepass(0, bs[0]);
+    for (uint64_t p0 = 0, it = 0; p0 < P; p0 += batch, ++it) {
         const uint32_t np = (uint32_t)std::min<uint64_t>(batch, P - p0);
         const PairRec* pr = c->pairs.as<PairRec>() + p0;
-        // the indel pass fixes every read's length, hence the record sizes and (prefix sums) the record offsets
-        c->tm_indels.begin(s);
-        launch_indels(s, pr, np, paired, c->dtb, c->key, slot, c->ev_hdr.as<uint32_t>(), c->ev_dat.as<uint4>(), c->sizes1.as<uint32_t>(), c->sizes2.as<uint32_t>(), cls1, cls2, c->flags.as<uint32_t>());
-        c->tm_indels.end(s);
-        c->tm_indels.add_units(np);
-        exclusive_scan_u32_to_u64(s, c->sizes1.as<uint32_t>(), c->off1.as<uint64_t>(), np, c->scan_tmp.p, c->scan_tmp.cap);
-        if (paired) exclusive_scan_u32_to_u64(s, c->sizes2.as<uint32_t>(), c->off2.as<uint64_t>(), np, c->scan_tmp.p, c->scan_tmp.cap);
-        launch_read_lists(s, np, paired, cls1, cpos1, cls2, cpos2, slist1, slist2, clist1, clist2, c->scan_tmp.p, c->scan_tmp.cap);
-        { Mail m; m.add(c->off1.as<uint64_t>() + np, 8, 0); m.add(paired ? (const void*)(c->off2.as<uint64_t>() + np) : nullptr, 8, 1);
-          m.add(cpos1 + np, 4, 2); m.add(paired ? (const void*)(cpos2 + np) : nullptr, 4, 3); mail_post(c, m, true); }
-        mail_wait(c);
+        const BatchSet& B = bs[it & 1];
+        mail_wait(c);                                                              // this batch's byte and class counts
         const uint64_t b1 = c->h_rb[0], b2 = c->h_rb[1]; const uint32_t nc1 = (uint32_t)c->h_rb[2], nc2 = (uint32_t)c->h_rb[3];
+        if (p0 + batch < P) prepass(p0 + batch, bs[(it + 1) & 1]);                 // the next batch's pre-pass goes in ahead of this batch's base pass
         while (bnext < bpair.size() && bpair[bnext] < p0 + np) {                     // a segment starts inside this batch: its record's byte offset
             uint64_t o1v = 0, o2v = 0; const uint64_t idx = bpair[bnext] - p0;
-            HIP_OK(hipMemcpyAsync(&o1v, c->off1.as<uint64_t>() + idx, 8, hipMemcpyDeviceToHost, s));
-            if (paired) HIP_OK(hipMemcpyAsync(&o2v, c->off2.as<uint64_t>() + idx, 8, hipMemcpyDeviceToHost, s));
+            HIP_OK(hipMemcpyAsync(&o1v, B.off1 + idx, 8, hipMemcpyDeviceToHost, s));
+            if (paired) HIP_OK(hipMemcpyAsync(&o2v, B.off2 + idx, 8, hipMemcpyDeviceToHost, s));
             HIP_OK(hipStreamSynchronize(s));
             (*tg.seg_off1)[bnext] = tot1 + o1v; if (tg.seg_off2) (*tg.seg_off2)[bnext] = tot2 + o2v;
             ++bnext;
@@ -847,8 +865,8 @@ void do_yield(scs_ctx* c, const OutTarget& tg, uint64_t* n1_out, uint64_t* n2_ou
         }
         c->tm_reads.begin(s);                                                      // the base pass writes the FASTQ text at the record offsets
         launch_reads(s, c->genome.as<uint8_t>(), c->semis.pool_view(), c->fulls.pool_view(), pr, np, 0,
-                     c->dtb, c->d_tables.as<DevTables>(), c->key, paired, slot, c->ev_hdr.as<uint32_t>(), c->ev_dat.as<uint4>(),
-                     c->off1.as<uint64_t>(), c->off2.as<uint64_t>(), o1, o2, c->flags.as<uint32_t>(), b1, b2, slist1, slist2, clist1, clist2, nc1, nc2);
+                     c->dtb, c->d_tables.as<DevTables>(), c->key, paired, slot, B.ev_hdr, B.ev_dat,
+                     B.off1, B.off2, o1, o2, c->flags.as<uint32_t>(), b1, b2, B.slist1, B.slist2, B.clist1, B.clist2, nc1, nc2);
         c->tm_reads.end(s);
         c->tm_reads.add_units(np);
         { const hipError_t le = take_launch_error(); if (le != hipSuccess) throw ScsError(SCS_EDEVICE, std::string("k_reads launch failed: ") + hipGetErrorString(le)); }
