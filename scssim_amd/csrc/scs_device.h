@@ -18,6 +18,7 @@ struct DevFrags {
     const uint32_t* primers;   // budget of the current pass (Fragment::primerNum)
     uint32_t n;
     uint64_t gidx_base;        // global index of local fragment 0 (sharding)
+    const uint8_t* has_n;      // 1: the fragment contains a non-ACGT base (k_frag_has_n); windows of the others skip the N count
 };
 
 // ---- amplicons (reference: Amplicon + AmpliconNode list, lib/amplicon/Amplicon.h:47-76) -----------
@@ -143,6 +144,7 @@ void launch_errs_semis(hipStream_t s, const uint8_t* g, DevGenomeIdx gx, DevFrag
                        DevAmps out, uint32_t out_base, DevErrPool pool, uint32_t* flags, const unsigned long long* binom, AmplifyParams p,
                        int64_t* primer_cnt, uint32_t* primer_delta);   // primer_cnt non-null: the pass's stock update rides along (unsharded job)
 void launch_encode_bases(hipStream_t s, uint8_t* g, uint64_t n);
+void launch_frag_has_n(hipStream_t s, const uint64_t* goff, const uint32_t* len, uint32_t nf, DevGenomeIdx gx, uint8_t* has_n);
 // one chunk of a FASTA file parsed on the device (k_fa_*): st = {bases so far, headers so far, kind of the open line}; kind n bytes,
 // keep / pos n + 1 words; hdr = pairs {file offset of a header, bases before it}, at most hdr_cap of them
 size_t fasta_chunk_temp_bytes(uint32_t n);

@@ -279,6 +279,15 @@ __device__ __forceinline__ uint64_t bit_rank(const unsigned long long* __restric
     return pref[w] + (uint64_t)__popcll(bits[w] & ((1ull << r) - 1ull));
 }
 
+__global__ void k_frag_has_n(const uint64_t* __restrict__ goff, const uint32_t* __restrict__ len, uint32_t nf, DevGenomeIdx gx, uint8_t* __restrict__ has_n) {
+    const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= nf) return;
+    has_n[f] = bit_rank(gx.n_bits, gx.n_pref, goff[f] + len[f]) != bit_rank(gx.n_bits, gx.n_pref, goff[f]) ? 1 : 0;
+}
+void launch_frag_has_n(hipStream_t s, const uint64_t* goff, const uint32_t* len, uint32_t nf, DevGenomeIdx gx, uint8_t* has_n) {
+    if (nf) hipLaunchKernelGGL(k_frag_has_n, dim3((nf + 255) / 256), dim3(256), 0, s, goff, len, nf, gx, has_n);
+}
+
 // ------------------------------------------------------------------------------------------------
 // K1b  new amplicon records: one thread per attached primer.  GC content of the window from the bit
 //      index (+ the parent semi's substitutions), amplification errors as K ~ Binomial(l-8, ber) and K
@@ -327,7 +336,8 @@ __global__ void __launch_bounds__(256) k_errs(const uint8_t* __restrict__ g, Dev
     const int64_t first = tv.base + (int64_t)tv.dir * (int64_t)spos;
     const uint64_t ga = (uint64_t)(tv.dir > 0 ? first : first - (int64_t)(alen - 1)), gb = ga + alen;
     int gc = (int)(bit_rank(gx.gc_bits, gx.gc_pref, gb) - bit_rank(gx.gc_bits, gx.gc_pref, ga));
-    int nn = (int)(bit_rank(gx.n_bits, gx.n_pref, gb) - bit_rank(gx.n_bits, gx.n_pref, ga));
+    // the N count costs four more scattered loads: skipped for the templates of a fragment without any N (nearly all)
+    int nn = fr.has_n[FROM_FRAG ? t : semis.parent[t]] ? (int)(bit_rank(gx.n_bits, gx.n_pref, gb) - bit_rank(gx.n_bits, gx.n_pref, ga)) : 0;
     if (!FROM_FRAG) for_each_err(perrs, spool.data, [&](uint32_t e) {
         const uint32_t tp = plen - 1 - err_pos(e);
         if (tp >= spos && tp < spos + alen) {
