@@ -1,6 +1,8 @@
 // scs_kernels.hip -- gfx950 (CDNA4, wave64) kernels of the genreads hot path.
 // Integer / byte work bounded by HBM and the per-lane Philox rate; no MFMA by design.
 // Built with -ffp-contract=off: the few fp64 expressions must round exactly like the CPU oracle.
+#include <utility>
+#include <type_traits>
 #include "scs_device.h"
 
 #include <algorithm>
@@ -540,6 +542,9 @@ __global__ void k_plan_pairs(DevFrags fr, DevAmps semis, DevAmps fulls, uint32_t
 //   QK = 16  (binned-quality models, e.g. HiSeq X):   80 B rows, 1088 B bins, groups of 8
 //   QK = 64  (8-bit-quality models):                 320 B rows, 2048 B bins, groups of 4
 //   QK = 128 (a row with more than 64 symbols):      640 B rows, 3328 B bins, groups of 2
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>), in order: an unrolled loop whose index is a compile-time constant
+template <class F, int... I>
+__device__ __forceinline__ void unroll_steps(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
 template <int QK> struct RingGeo;
 template <> struct RingGeo<16>  { enum { SLOTS = 16, GROUP = 8, QROW = 5,  NPRE = 3, ABITS = 4 }; };     // QROW: uint4 per quality row
 template <> struct RingGeo<64>  { enum { SLOTS = 8,  GROUP = 4, QROW = 20, NPRE = 3, ABITS = 6 }; };
@@ -584,14 +589,15 @@ template <int QK, class W, class S>
 __device__ __forceinline__ uint32_t alias_pick(const W* __restrict__ row, const S* __restrict__ syms, uint32_t x) {
     constexpr uint32_t AB = RingGeo<QK>::ABITS;
     const uint32_t col = x >> (32u - AB), e = row[col];
-    const uint32_t pick = (x & ((1u << (32u - AB)) - 1u)) < (e >> AB) ? col : (e & (uint32_t)(QK - 1));
+    // e = t << AB | alias: (x's low bits) < t  <=>  (low bits << AB | QK-1) < e  (both sides compared with their low AB bits in place)
+    const uint32_t pick = ((x << AB) | (uint32_t)(QK - 1)) < e ? col : (e & (uint32_t)(QK - 1));
     return syms[pick];
 }
 // base call + quality of one position entirely from the global tables (k-mer rows outside the LDS ring, substituted bases,
 // the xs == 0xFFFFFFFF draw).  ki < 0: the base is not re-drawn, k comes in.
 template <int QK>
-__device__ __noinline__ uint32_t call_global(const uint32_t* __restrict__ subs, const double* __restrict__ subs_d, const uint32_t* __restrict__ qalias,
-                                             uint32_t B, int ki, uint32_t k, uint32_t c2, uint32_t bin, uint32_t xs, uint32_t xq) {
+__device__ __forceinline__ uint32_t call_global_body(const uint32_t* __restrict__ subs, const double* __restrict__ subs_d, const uint32_t* __restrict__ qalias,
+                                                     uint32_t B, int ki, uint32_t k, uint32_t c2, uint32_t bin, uint32_t xs, uint32_t xq) {
     if (ki >= 0) {
         const uint32_t row = ((uint32_t)ki * B + bin) * 4u;
         if (xs == 0xFFFFFFFFu) k = rand_indx_slow(subs_d + row, 4, xs);
@@ -600,6 +606,33 @@ __device__ __noinline__ uint32_t call_global(const uint32_t* __restrict__ subs, 
     const uint32_t* __restrict__ qrow = qalias + (size_t)((c2 * 4u + k) * B + bin) * (QK + QK / 4);
     const uint32_t qv = alias_pick<QK>(qrow, reinterpret_cast<const uint8_t*>(qrow + QK), xq);
     return k | (qv << 8);
+}
+template <int QK>
+__device__ __noinline__ uint32_t call_global(const uint32_t* __restrict__ subs, const double* __restrict__ subs_d, const uint32_t* __restrict__ qalias,
+                                             uint32_t B, int ki, uint32_t k, uint32_t c2, uint32_t bin, uint32_t xs, uint32_t xq) {
+    return call_global_body<QK>(subs, subs_d, qalias, B, ki, k, c2, bin, xs, xq);
+}
+// Everything the uniform walk of the event-free class (k_reads, CLS 1) keeps off its straight path, for the few lanes that
+// need it at a position: a k-mer that is not a clean 3-mer (the read's first two bases, an N in the window), a substituted
+// base (its quality row (c2, k) is not in the ring: set aside in slot `room` of `pend`, or fetched from global memory when
+// there is no room), the x == 0xFFFFFFFF draw.  x1, x2: the next two draws of stream B; a position without a k-mer row
+// consumes only the first (ONE is set).  Returns k (4 = 'N') | quality << 8 | deferred << 16 | ONE << 17.
+#define RARE_DEFERRED (1u << 16)
+#define RARE_ONE (1u << 17)
+template <int QK>
+__device__ __noinline__ uint32_t rare_call(const uint32_t* __restrict__ subs, const double* __restrict__ subs_d, const uint32_t* __restrict__ qalias, uint32_t B,
+                                           uint32_t c0, uint32_t c1, uint32_t c2, uint32_t t, uint32_t x1, uint32_t x2, uint32_t k_lds, uint32_t room,
+                                           __attribute__((address_space(3))) uint32_t* pend) {
+    const int ki = kmer_index(c0, c1, c2);
+    if (ki < 0) {
+        if (c2 > 3u) return 4u | (scale_draw(x1, 0, 20) << 8) | RARE_ONE;          // getRandBaseQuality
+        return call_global_body<QK>(subs, subs_d, qalias, B, -1, c2, c2, t, 0u, x1) | RARE_ONE;
+    }
+    if (ki >= 20 && x1 != 0xFFFFFFFFu && room != 0xFFFFFFFFu) {
+        pend[2u * room] = t | (k_lds << 12) | (c2 << 14) | (t << 16); pend[2u * room + 1u] = x2;
+        return k_lds | RARE_DEFERRED;
+    }
+    return call_global_body<QK>(subs, subs_d, qalias, B, ki, c2, c2, t, x1, x2);
 }
 
 // [REMAP] number of event-free bases before the next indel event among the `rem` bases left: the per-base tests of
@@ -1032,6 +1065,53 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
     uint2* my_pend = FROM_PAIRS ? nullptr : reinterpret_cast<uint2*>(my_q + slot - 8 * PEND_MAX);
     LdsU32* my_pend_lds = (LdsU32*)(s_win + (size_t)tid * WS);                     // rows are dword aligned (win_stride)
 
+    if constexpr (SIMPLE && FROM_PAIRS) {
+        // The event-free class: every read emits exactly position t at bin t, so the whole walk is WAVE-UNIFORM -- window base
+        // t (a dword of 8 bases is fetched every 8th step), output word t >> 2, a 16-character block at t & 15 == 15 -- and
+        // is unrolled by 16: ring slot, word index and block boundaries are compile-time, the per-position work is the two
+        // draws, the two table lookups and two shift-ors.  Lanes without a read run along on an all-'A' window and store
+        // nothing; the few lanes that need more at a position go through rare_call.
+        const bool mine = live && n_out > 0;
+        const LdsU8* ring8 = (const LdsU8*)s_dyn;
+        const LdsU32* win32 = (const LdsU32*)my_win;
+        uint32_t wreg = 0, sel = 0, qacc = 0;
+        if (!mine) { c0 = 0; c1 = 0; }
+        for (int t0 = 0; t0 < B; t0 += 16) {
+            unroll_steps([&](auto U) {
+                constexpr int u = decltype(U)::value;
+                const int t = t0 + u;
+                if (t >= B) return;
+                if ((u & (GROUP - 1)) == 0 && t > 0) { commit(t); __syncthreads(); prefetch(t + GROUP); }
+                if ((u & 7) == 0) { wreg = win32[t >> 3]; if (!mine) wreg = 0; }
+                const uint32_t c2 = wreg & 15u; wreg >>= 4;
+                Xoshiro s1 = xb; const uint32_t x1 = s1.next();
+                xb = s1; const uint32_t x2 = xb.next();
+                const LdsU8* bin8 = ring8 + (u & (SLOTS - 1)) * sizeof(Bin);
+                const uint32_t kk = ((c0 << 4) | (c1 << 2) | c2) & 63u;
+                const LdsU32* st = (const LdsU32*)(bin8 + 4 * QROW * 16 + kk * 12u);
+                uint32_t k = (x1 >= st[0]) + (x1 >= st[1]) + (x1 >= st[2]);
+                const LdsU32* qrow = (const LdsU32*)(bin8 + (c2 & 3u) * (uint32_t)(QROW * 16));   // the diagonal row (c2, c2) as an alias row
+                uint32_t qv = alias_pick<QK>(qrow, (const LdsU8*)(qrow + QK), x2);
+                if (mine && (((c0 | c1 | c2) > 3u) | (k != c2) | (x1 == 0xFFFFFFFFu))) {
+                    const uint32_t room = (npend < PEND_MAX && (uint32_t)(t + 1) >= 16u * (npend + 1u)) ? npend : 0xFFFFFFFFu;   // see `defer` below
+                    const uint32_t rr = rare_call<QK>(subs, subs_d, tb.qual_alias, (uint32_t)B, c0, c1, c2, (uint32_t)t, x1, x2, k, room, my_pend_lds);
+                    k = rr & 7u; qv = (rr >> 8) & 255u; npend += (rr >> 16) & 1u;
+                    if (rr & RARE_ONE) xb = s1;
+                }
+                sel |= k << (8 * (u & 3)); qacc |= qv << (8 * (u & 3));               // base selectors and raw qualities, four to a word
+                c0 = c1; c1 = c2;
+                if ((u & 3) == 3 || t == B - 1) {
+                    uint32_t wb = __builtin_amdgcn_perm(0x4Eu, 0x54474341u, sel), wq = qacc + 0x21212121u;   // selector 0..3 -> "ACGT", 4 -> 'N'; + 33
+                    if constexpr ((u & 3) != 3) { const uint32_t m = (1u << (8 * ((u & 3) + 1))) - 1u; wb &= m; wq &= m; }   // the read's last, partial word
+                    bo_b.R[u >> 2] = wb; bo_q.R[u >> 2] = wq; sel = 0; qacc = 0;
+                    if (u == 15 && t != B - 1 && mine) {
+                        bo_b.block(wg_out, sec1, a1, (uint32_t)t >> 4);
+                        bo_q.block(wg_out, sec2, a2, (uint32_t)t >> 4);
+                    }
+                }
+            }, std::make_integer_sequence<int, 16>{});
+        }
+    } else
     for (int t = 0; t < B; ++t) {
         if ((t & (GROUP - 1)) == 0 && t > 0) {
             commit(t);
