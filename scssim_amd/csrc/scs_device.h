@@ -46,6 +46,7 @@ struct DevTables {
     const uint32_t* gap_t; uint32_t t_kind;            // [REMAP] geometric gap between indel events (scs_tables.h): gap >= g <=> x < gap_t[g]
     const uint32_t* subs1; const uint32_t* subs2;   // [84][bins][4] thresholds (uint4 rows)
     const uint32_t* qual;                            // [16][bins][94]
+    const uint4* ring1; const uint4* ring2;          // per mate, per bin (padded to a multiple of 8 bins): the bin's image in k_reads' LDS ring (RingBin), ready to copy
     const uint32_t* qual_alias; int qual_k;          // [16*bins] alias rows of qual_k (16 / 64 / 128) columns: qual_k words + qual_k symbol bytes (scs_tables.h)
     const uint32_t* ins_t; int n_ins;
     const uint32_t* del_t; int n_del;

@@ -495,7 +495,8 @@ __global__ void k_plan_pairs(DevFrags fr, DevAmps semis, DevAmps fulls, uint32_t
     const View uv = shift_view(semi_tmpl_view(frag_view(fr.goff[f], fr.len[f], fr.strand[f]), sl_spos(ssl), l1), s2);
     PairRec r; r.amp = i;                                                          // index in the whole job's list (record names)
     for (uint32_t k = 0; k < gmap.n; ++k) if (i - gmap.lo[k] < gmap.cnt[k]) { r.amp = (uint32_t)(gmap.go[k] + (i - gmap.lo[k])); break; }
-    r.base = uv.base; r.flags = (uv.comp & 1u) | (uv.dir < 0 ? 2u : 0u); r.k1 = (int32_t)(l1 - 1 - s2);
+    r.base = uv.base; r.k1 = (int32_t)(l1 - 1 - s2);
+    r.flags = (uv.comp & 1u) | (uv.dir < 0 ? 2u : 0u) | (fr.has_n[f] ? 4u : 0u);   // bit 2: the fragment holds a non-ACGT base
     r.e1 = semis.errs[sm]; r.e2 = fulls.errs[i]; r.uid = fulls.uid[i]; r.pad = 0;
     uint32_t made = 0;
     if (amp_len >= L) {
@@ -546,9 +547,9 @@ __global__ void k_plan_pairs(DevFrags fr, DevAmps semis, DevAmps fulls, uint32_t
 template <class F, int... I>
 __device__ __forceinline__ void unroll_steps(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
 template <int QK> struct RingGeo;
-template <> struct RingGeo<16>  { enum { SLOTS = 16, GROUP = 8, QROW = 5,  NPRE = 3, ABITS = 4 }; };     // QROW: uint4 per quality row
-template <> struct RingGeo<64>  { enum { SLOTS = 8,  GROUP = 4, QROW = 20, NPRE = 3, ABITS = 6 }; };
-template <> struct RingGeo<128> { enum { SLOTS = 4,  GROUP = 2, QROW = 40, NPRE = 2, ABITS = 7 }; };
+template <> struct RingGeo<16>  { enum { SLOTS = 16, GROUP = 8, QROW = 5,  ABITS = 4 }; };     // QROW: uint4 per quality row
+template <> struct RingGeo<64>  { enum { SLOTS = 8,  GROUP = 4, QROW = 20, ABITS = 6 }; };
+template <> struct RingGeo<128> { enum { SLOTS = 4,  GROUP = 2, QROW = 40, ABITS = 7 }; };
 template <int QK> struct RingBin { uint4 qd[4][RingGeo<QK>::QROW]; uint32_t subs[64][3]; };
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
@@ -612,27 +613,37 @@ __device__ __noinline__ uint32_t call_global(const uint32_t* __restrict__ subs, 
                                              uint32_t B, int ki, uint32_t k, uint32_t c2, uint32_t bin, uint32_t xs, uint32_t xq) {
     return call_global_body<QK>(subs, subs_d, qalias, B, ki, k, c2, bin, xs, xq);
 }
-// Everything the uniform walk of the event-free class (k_reads, CLS 1) keeps off its straight path, for the few lanes that
-// need it at a position: a k-mer that is not a clean 3-mer (the read's first two bases, an N in the window), a substituted
-// base (its quality row (c2, k) is not in the ring: set aside in slot `room` of `pend`, or fetched from global memory when
-// there is no room), the x == 0xFFFFFFFF draw.  x1, x2: the next two draws of stream B; a position without a k-mer row
-// consumes only the first (ONE is set).  Returns k (4 = 'N') | quality << 8 | deferred << 16 | ONE << 17.
-#define RARE_DEFERRED (1u << 16)
-#define RARE_ONE (1u << 17)
+// The uniform walk of the event-free class (k_reads, CLS 1) sets a substituted base's quality aside in LDS; a read that runs
+// out of room for that (or draws x == 0xFFFFFFFF, whose base call needs the double tables) is made AGAIN here, one lane at
+// a time, from the genome and the global tables, and its bases and qualities are stored over what the walk wrote.  Rare
+// (three substitutions within the first 24 bases, ...): correctness path, no care for speed.  gb / gf: the window's first
+// base and its flags (bit0 complement, bit1 backwards) as in the staging; e1 / e2: the error words of the pair record.
 template <int QK>
-__device__ __noinline__ uint32_t rare_call(const uint32_t* __restrict__ subs, const double* __restrict__ subs_d, const uint32_t* __restrict__ qalias, uint32_t B,
-                                           uint32_t c0, uint32_t c1, uint32_t c2, uint32_t t, uint32_t x1, uint32_t x2, uint32_t k_lds, uint32_t room,
-                                           __attribute__((address_space(3))) uint32_t* pend) {
-    const int ki = kmer_index(c0, c1, c2);
-    if (ki < 0) {
-        if (c2 > 3u) return 4u | (scale_draw(x1, 0, 20) << 8) | RARE_ONE;          // getRandBaseQuality
-        return call_global_body<QK>(subs, subs_d, qalias, B, -1, c2, c2, t, 0u, x1) | RARE_ONE;
+__device__ __noinline__ void redo_read(const uint8_t* __restrict__ g, int64_t gb, uint32_t gf, const uint32_t* __restrict__ spool, const uint32_t* __restrict__ fpool,
+                                       uint64_t e1, uint64_t e2, int k1, uint32_t pos, uint32_t isz, uint32_t rd, int n, uint32_t B,
+                                       const uint32_t* __restrict__ subs, const double* __restrict__ subs_d, const uint32_t* __restrict__ qalias,
+                                       U4 seed, char* __restrict__ out_b, char* __restrict__ out_q) {
+    Xoshiro xb; xb.seed(seed);
+    uint32_t c0 = 5u, c1 = 5u;
+    for (int t = 0; t < n; ++t) {
+        uint32_t c2 = g[(gf & 2u) ? gb - t : gb + t];
+        if ((gf & 1u) && c2 < 4u) c2 = 3u - c2;
+        for_each_err(e1, spool, [&](uint32_t e) {
+            const int tt = k1 - (int)err_pos(e); const int k = rd ? (int)(pos + isz - 1) - tt : tt - (int)pos;
+            if (k == t) c2 = rd ? err_alt(e) : 3u - err_alt(e);
+        });
+        for_each_err(e2, fpool, [&](uint32_t e) {
+            const int tt = (int)err_pos(e); const int k = rd ? (int)(pos + isz - 1) - tt : tt - (int)pos;
+            if (k == t) c2 = rd ? 3u - err_alt(e) : err_alt(e);
+        });
+        const int ki = kmer_index(c0, c1, c2);
+        const uint32_t xs = ki >= 0 ? xb.next() : 0u, xq = xb.next();
+        uint32_t bc, qc;
+        if (ki < 0 && c2 > 3u) { bc = 'N'; qc = 33u + scale_draw(xq, 0, 20); }
+        else { const uint32_t kq = call_global_body<QK>(subs, subs_d, qalias, B, ki, c2, c2, (uint32_t)t, xs, xq); bc = (0x54474341u >> (8u * (kq & 255u))) & 255u; qc = 33u + (kq >> 8); }
+        out_b[t] = (char)bc; out_q[t] = (char)qc;
+        c0 = c1; c1 = c2;
     }
-    if (ki >= 20 && x1 != 0xFFFFFFFFu && room != 0xFFFFFFFFu) {
-        pend[2u * room] = t | (k_lds << 12) | (c2 << 14) | (t << 16); pend[2u * room + 1u] = x2;
-        return k_lds | RARE_DEFERRED;
-    }
-    return call_global_body<QK>(subs, subs_d, qalias, B, ki, c2, c2, t, x1, x2);
 }
 
 // [REMAP] number of event-free bases before the next indel event among the `rem` bases left: the per-base tests of
@@ -677,7 +688,7 @@ __device__ __forceinline__ IndelPass indel_pass(const DevTables& tb, RngKey key,
             else ++ji;
         }
     }
-    if (force_replay && nev > 0) replay = true;
+    if ((force_replay & 1u) && nev > 0) replay = true;
     if (n + delta < 50) { nev = 0; delta = 0; replay = false; }                    // Profile.cpp:1623-1630: drop all indels
     int n_out = n + delta;
     if (n_out > (int)slot) { atomicOr(flags, (uint32_t)FLAG_READSLOT); n_out = 0; nev = 0; replay = false; }
@@ -696,9 +707,9 @@ __global__ void __launch_bounds__(256) k_indels(const PairRec* __restrict__ pair
     const uint32_t nreads = paired ? 2 * np : np;
     if (r >= nreads) return;
     const uint32_t pi = paired ? r >> 1 : r, rd = paired ? (r & 1u) : 0u;
-    const uint64_t uid = pairs[pi].uid; const uint32_t att = pairs[pi].att, isz = pairs[pi].isz, amp = pairs[pi].amp;
+    const uint64_t uid = pairs[pi].uid; const uint32_t att = pairs[pi].att, isz = pairs[pi].isz, amp = pairs[pi].amp, has_n = pairs[pi].flags & 4u;
     uint32_t* sz = rd ? sizes2 : sizes1;
-    uint32_t* cls = rd ? cls2 : cls1;                                              // 1: the read has indel events (k_reads' general variant), 0: it has none
+    uint32_t* cls = rd ? cls2 : cls1;                                              // 1: the read has indel events or may see an N (k_reads' general variant), 0: neither
     if (isz == 0) { ev_hdr[r] = 0; sz[pi] = 0; cls[pi] = 0; return; }               // hole: the insert-size loop gave up (Amplicon.cpp:484-489)
     unsigned long long e_lo = 0, e_hi = 0;
     const IndelPass ip = indel_pass(tb, key, rd | (att << 1), uid, force_replay, slot, flags, [&](int i, uint32_t v) {
@@ -706,7 +717,7 @@ __global__ void __launch_bounds__(256) k_indels(const PairRec* __restrict__ pair
     });
     ev_hdr[r] = (uint32_t)ip.n_out | ((uint32_t)ip.nev << 16) | (ip.replay ? 1u << 24 : 0u) | (1u << 25);
     ev_dat[r] = make_uint4((uint32_t)e_lo, (uint32_t)(e_lo >> 32), (uint32_t)e_hi, (uint32_t)(e_hi >> 32));
-    cls[pi] = (ip.nev > 0 || ip.replay) ? 1u : 0u;
+    cls[pi] = (ip.nev > 0 || ip.replay || has_n || (force_replay & 4u)) ? 1u : 0u;                        // the uniform walk takes ACGT-only windows without events
     // "@<ampIdx>#<fragCount>[/1|/2]\n" + seq + "\n+\n" + qual + "\n"   (Amplicon.cpp:459-466,497-504)
     sz[pi] = ip.n_out == 0 ? 0u : 1u + dec_digits(amp) + 1u + dec_digits(att + 1) + (paired ? 2u : 0u) + 1u + 2u * (uint32_t)ip.n_out + 4u;
 }
@@ -816,7 +827,7 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
     constexpr bool SIMPLE = CLS == 1;
     typedef RingGeo<QK> Geo;
     typedef RingBin<QK> Bin;
-    constexpr int SLOTS = Geo::SLOTS, GROUP = Geo::GROUP, QROW = Geo::QROW, EPB = 64 + 4 * QROW;   // EPB: 16-byte entries per bin image
+    constexpr int SLOTS = Geo::SLOTS, GROUP = Geo::GROUP, QROW = Geo::QROW;
     extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
     // the table descriptor is a by-value kernel argument: pointers loaded from the kernarg segment are known to be
     // global (a descriptor fetched through a pointer makes every table access a FLAT load)
@@ -826,7 +837,13 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
     int64_t* s_gbase = reinterpret_cast<int64_t*>(s_dyn);                  // [RB]  staging only: aliases the ring, which is filled later
     uint32_t* s_gflag = reinterpret_cast<uint32_t*>(s_gbase + RB);         // [RB]  bit0 complement, bit1 direction -1, bit2 valid
     uint16_t* s_ev = reinterpret_cast<uint16_t*>(s_dyn + SLOTS * sizeof(Bin));   // [RB][EV_MAX]; a replayed read keeps its stream-A state here
-    uint8_t* s_win = reinterpret_cast<uint8_t*>(s_ev + RB * EV_MAX);       // [RB][WS]
+    // rows: [RB][WS] windows behind the event slots; the uniform walk (UNI) has no events and keeps each lane's 16 bytes
+    // IN FRONT of its window instead -- two pending-quality slots, the later ones overlay the consumed start of the window
+    constexpr bool UNI = SIMPLE && FROM_PAIRS;
+    constexpr uint32_t WOFF = UNI ? 16u : 0u;
+    const uint32_t ROW = WS + WOFF;
+    uint8_t* s_win = UNI ? reinterpret_cast<uint8_t*>(s_ev) : reinterpret_cast<uint8_t*>(s_ev + RB * EV_MAX);
+    uint32_t* s_head = reinterpret_cast<uint32_t*>(s_dyn + SLOTS * sizeof(Bin) + RB * EV_MAX * 2 + (size_t)RB * WS);   // [64] UNI: threshold rows of the 1- and 2-mers
     const int tid = threadIdx.x, lane = tid & 63, wib = tid >> 6;
 
     // the workgroup's records are contiguous: stores address them as a uniform base (aligned down to a sector) + a 32-bit offset
@@ -884,7 +901,7 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
     bool live = valid && (!FROM_PAIRS || pr.isz != 0);
 
     // ---- stage the windows (coalesced), then patch the amplification errors
-    LdsU8* my_win = (LdsU8*)(s_win + (size_t)tid * WS);
+    LdsU8* my_win = (LdsU8*)(s_win + (size_t)tid * ROW + WOFF);
     if (FROM_PAIRS) {
         int64_t gb = 0; uint32_t gf = 0;
         if (live) {
@@ -921,7 +938,7 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
                     uint32_t v = cv[u];
                     if (f & 1u) v ^= 0x03030303u & ~(((v >> 2) & 0x01010101u) * 3u);   // complement: 3 - c for ACGT codes, N (4) stays
                     const uint32_t pk = (v & 0xFu) | ((v >> 4) & 0xF0u) | ((v >> 8) & 0xF00u) | ((v >> 12) & 0xF000u);
-                    if ((f & 4u) && k4 < n) *reinterpret_cast<uint16_t*>(s_win + (size_t)rr * WS + (k4 >> 1)) = (uint16_t)pk;
+                    if ((f & 4u) && k4 < n) *reinterpret_cast<uint16_t*>(s_win + (size_t)rr * ROW + WOFF + (k4 >> 1)) = (uint16_t)pk;
                 }
             }
         }
@@ -946,7 +963,7 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
             const uint32_t row = idx / hb, b = idx % hb;
             const uint32_t lo = windows[base_off + (size_t)row * n + 2 * b] & 15u;
             const uint32_t hi = 2 * b + 1 < (uint32_t)n ? windows[base_off + (size_t)row * n + 2 * b + 1] & 15u : 0u;
-            s_win[(size_t)row * WS + b] = (uint8_t)(lo | (hi << 4));
+            s_win[(size_t)row * ROW + WOFF + b] = (uint8_t)(lo | (hi << 4));
         }
     }
 
@@ -959,7 +976,7 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
         if (FROM_PAIRS) {
             const uint32_t h = ev_hdr[r]; const uint4 e = ev_dat[r];
             n_out = (int)(h & 0xFFFFu); nev = SIMPLE ? 0 : (int)((h >> 16) & 0xFFu); replay = SIMPLE ? false : (h >> 24) & 1u;
-            my_xa[0] = e.x; my_xa[1] = e.y; my_xa[2] = e.z; my_xa[3] = e.w;          // 8 x 16-bit events
+            if (!UNI) { my_xa[0] = e.x; my_xa[1] = e.y; my_xa[2] = e.z; my_xa[3] = e.w; }   // 8 x 16-bit events
         } else {
             const IndelPass ip = indel_pass(tb, key, aux, uid, force_replay, slot, flags, [&](int i, uint32_t v) { my_ev[i] = (uint16_t)v; });
             n_out = ip.n_out; nev = ip.nev; replay = ip.replay;
@@ -981,7 +998,6 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
     const double* __restrict__ subs_d = second ? tb.subs2_d : tb.subs1_d;
     // the ring holds the substitution rows of the workgroup's mate (explicit-window mode: of read 1)
     const bool ring_subs_ok = FROM_PAIRS ? true : !second;
-    const uint32_t* __restrict__ ring_src = FROM_PAIRS ? subs : tb.subs1;
     int ji = 0, jo = 0, ins_left = 0, evi = 0;
     uint32_t next_ev = replay ? replay_first : nev > 0 ? ev_pos(my_ev[0]) : 0xFFFFFFFFu;   // input position of the next indel event
     // binIndx = j*binCount/n' (Profile.cpp:1668) as a multiply-high: exact while j*binCount*n' < 2^32 (checked on the host)
@@ -1030,25 +1046,25 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
     // bins of the next group are prefetched into registers one group ahead and written to LDS at the group boundary,
     // into the half that group gq-2 used -- every wave left that group before the previous boundary's barrier, so one
     // barrier per group is enough.
-    auto ring_entry = [&](int bin, int w) -> uint4 {                              // entry w (0..EPB) of a bin's ring image
-        if (w >= 4 * QROW) return *reinterpret_cast<const uint4*>(ring_src + ((size_t)(20 + w - 4 * QROW) * B + bin) * 4);
-        return reinterpret_cast<const uint4*>(tb.qual_alias)[((size_t)((w / QROW) * 5) * B + bin) * QROW + (w % QROW)];   // diagonal rows (c, c): 5c
-    };
-    auto ring_put = [&](int bin, int w, uint4 v) {
-        Bin* rb = &s_ring[bin & (SLOTS - 1)];
-        if (w < 4 * QROW) reinterpret_cast<uint4*>(rb->qd)[w] = v;
-        else { uint32_t* d = rb->subs[w - 4 * QROW]; d[0] = v.x; d[1] = v.y; d[2] = v.z; }
-    };
-    uint4 pre[Geo::NPRE];
-    auto prefetch = [&](int first) {                                              // bins [first, first+GROUP) -> registers
+    // the bins' images come ready-made from global memory (DevTables::ring1/2): a group of GROUP bins is one contiguous run of
+    // GROUP * EPB 16-byte entries there and in the ring
+    constexpr int GE = GROUP * (int)(sizeof(Bin) / 16), NPRE = (GE + RB - 1) / RB;
+    const uint4* __restrict__ ring_img = (FROM_PAIRS && second && tb.ring2) ? tb.ring2 : tb.ring1;
+    u32x4_t* ring16 = reinterpret_cast<u32x4_t*>(s_dyn);
+    u32x4_t pre[NPRE];
+    auto prefetch = [&](int first) __attribute__((always_inline)) {               // bins [first, first+GROUP) -> registers
+        // (unconditional loads: past the table's end the last group is fetched again, and an entry index past the group's is clamped)
+        const u32x4_t* __restrict__ src = reinterpret_cast<const u32x4_t*>(ring_img) + (size_t)min(first, ((B + 7) & ~7) - GROUP) * (sizeof(Bin) / 16);
 #pragma unroll
-        for (int u = 0; u < Geo::NPRE; ++u) { const int idx = tid + u * RB; const int bin = first + idx / EPB; pre[u] = (idx < GROUP * EPB && bin < B) ? ring_entry(bin, idx % EPB) : make_uint4(0, 0, 0, 0); }
+        for (int u = 0; u < NPRE; ++u) pre[u] = src[min(tid + u * RB, GE - 1)];
     };
-    auto commit = [&](int first) {                                                // registers -> LDS slots of bins [first, first+GROUP)
+    auto commit = [&](int first) __attribute__((always_inline)) {                 // registers -> LDS slots of bins [first, first+GROUP)
+        u32x4_t* dst = ring16 + (first & (SLOTS - 1)) * (int)(sizeof(Bin) / 16);
 #pragma unroll
-        for (int u = 0; u < Geo::NPRE; ++u) { const int idx = tid + u * RB; const int bin = first + idx / EPB; if (idx < GROUP * EPB && bin < B) ring_put(bin, idx % EPB, pre[u]); }
+        for (int u = 0; u < NPRE; ++u) { const int idx = tid + u * RB; if (idx < GE) dst[idx] = pre[u]; }
     };
-    for (int idx = tid; idx < min(B, GROUP) * EPB; idx += RB) ring_put(idx / EPB, idx % EPB, ring_entry(idx / EPB, idx % EPB));
+    for (int idx = tid; idx < GE; idx += RB) ring16[idx] = reinterpret_cast<const u32x4_t*>(ring_img)[idx];
+    if (UNI && tid < 64) s_head[tid] = reinterpret_cast<const uint32_t*>(ring_img + (size_t)((B + 7) & ~7) * (sizeof(Bin) / 16))[tid];
     prefetch(GROUP);
     __syncthreads();
 
@@ -1063,54 +1079,68 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
     const bool can_defer = !FROM_PAIRS && n_out + 15 + (int)(8 * PEND_MAX) <= (int)slot;
     uint32_t npend = 0;
     uint2* my_pend = FROM_PAIRS ? nullptr : reinterpret_cast<uint2*>(my_q + slot - 8 * PEND_MAX);
-    LdsU32* my_pend_lds = (LdsU32*)(s_win + (size_t)tid * WS);                     // rows are dword aligned (win_stride)
+    LdsU32* my_pend_lds = (LdsU32*)(s_win + (size_t)tid * ROW);                    // rows are dword aligned (win_stride)
 
-    if constexpr (SIMPLE && FROM_PAIRS) {
-        // The event-free class: every read emits exactly position t at bin t, so the whole walk is WAVE-UNIFORM -- window base
-        // t (a dword of 8 bases is fetched every 8th step), output word t >> 2, a 16-character block at t & 15 == 15 -- and
-        // is unrolled by 16: ring slot, word index and block boundaries are compile-time, the per-position work is the two
-        // draws, the two table lookups and two shift-ors.  Lanes without a read run along on an all-'A' window and store
-        // nothing; the few lanes that need more at a position go through rare_call.
+    bool redo = false;                                                             // UNI: the read is made again after the pass (redo_read)
+    if constexpr (UNI) {
+        // The event-free, ACGT-only class: every read emits exactly position t at bin t and every position takes exactly two
+        // draws, so the whole walk is WAVE-UNIFORM -- window base t (a dword of 8 bases is fetched every 8th step), output
+        // word t >> 2, a 16-character block at t & 15 == 15 -- and, between two blocks, STRAIGHT-LINE code: ring slot, word
+        // index and table addresses are compile-time or lane arithmetic, nothing branches, and the compiler overlaps the LDS
+        // lookups of neighbouring positions.  A substituted base needs the quality row (c2, k), which only global memory
+        // holds; its quality does not feed back into the walk, so (position, k, c2, draw) is set aside with an unconditional
+        // LDS store (lanes without one store to a dummy word) and resolved after the pass.  Slots: two in front of the
+        // window, the later ones over the window's consumed start -- entry e >= 2 over dwords 2(e-2), 2(e-2)+1, fetched once
+        // t >= 16(e-2)+8.  No room, or the draw 0xFFFFFFFF: the read is flagged and made again by redo_read.
+        // Lanes without a read run along on an all-'A' window and store nothing.
         const bool mine = live && n_out > 0;
         const LdsU8* ring8 = (const LdsU8*)s_dyn;
         const LdsU32* win32 = (const LdsU32*)my_win;
+        const LdsU8* head8 = (const LdsU8*)s_head;
+        LdsU8* row8 = (LdsU8*)my_pend_lds;
+        LdsU8* dummy8 = (LdsU8*)(s_head + 62);
+        const bool force_redo = (force_replay & 2u) != 0;
         uint32_t wreg = 0, sel = 0, qacc = 0;
-        if (!mine) { c0 = 0; c1 = 0; }
-        for (int t0 = 0; t0 < B; t0 += 16) {
-            unroll_steps([&](auto U) {
+        c0 = 0; c1 = 0;
+        auto steps = [&](auto FULL, int t0) __attribute__((always_inline)) {
+            unroll_steps([&](auto U) __attribute__((always_inline)) {
                 constexpr int u = decltype(U)::value;
+                constexpr bool full = decltype(FULL)::value;                       // all 16 positions exist, none is the read's last
                 const int t = t0 + u;
-                if (t >= B) return;
-                if ((u & (GROUP - 1)) == 0 && t > 0) { commit(t); __syncthreads(); prefetch(t + GROUP); }
+                if (!full && t >= B) return;
+                if ((u & (GROUP - 1)) == 0 && (u > 0 || t0 > 0)) { commit(t); __syncthreads(); prefetch(t + GROUP); }
                 if ((u & 7) == 0) { wreg = win32[t >> 3]; if (!mine) wreg = 0; }
-                const uint32_t c2 = wreg & 15u; wreg >>= 4;
-                Xoshiro s1 = xb; const uint32_t x1 = s1.next();
-                xb = s1; const uint32_t x2 = xb.next();
+                const uint32_t c2 = wreg & 3u; wreg >>= 4;
+                const uint32_t x1 = xb.next(), x2 = xb.next();
                 const LdsU8* bin8 = ring8 + (u & (SLOTS - 1)) * sizeof(Bin);
-                const uint32_t kk = ((c0 << 4) | (c1 << 2) | c2) & 63u;
-                const LdsU32* st = (const LdsU32*)(bin8 + 4 * QROW * 16 + kk * 12u);
-                uint32_t k = (x1 >= st[0]) + (x1 >= st[1]) + (x1 >= st[2]);
-                const LdsU32* qrow = (const LdsU32*)(bin8 + (c2 & 3u) * (uint32_t)(QROW * 16));   // the diagonal row (c2, c2) as an alias row
-                uint32_t qv = alias_pick<QK>(qrow, (const LdsU8*)(qrow + QK), x2);
-                if (mine && (((c0 | c1 | c2) > 3u) | (k != c2) | (x1 == 0xFFFFFFFFu))) {
-                    const uint32_t room = (npend < PEND_MAX && (uint32_t)(t + 1) >= 16u * (npend + 1u)) ? npend : 0xFFFFFFFFu;   // see `defer` below
-                    const uint32_t rr = rare_call<QK>(subs, subs_d, tb.qual_alias, (uint32_t)B, c0, c1, c2, (uint32_t)t, x1, x2, k, room, my_pend_lds);
-                    k = rr & 7u; qv = (rr >> 8) & 255u; npend += (rr >> 16) & 1u;
-                    if (rr & RARE_ONE) xb = s1;
-                }
+                const LdsU8* st8 = bin8 + 4 * QROW * 16 + ((c0 << 4) | (c1 << 2) | c2) * 12u;
+                if (u < 2) { const LdsU8* h8 = head8 + (u == 0 ? c2 : 4u + c1 * 4u + c2) * 12u; st8 = t0 == 0 ? h8 : st8; }   // the read's first two bases: 1-mer / 2-mer rows
+                const LdsU32* st = (const LdsU32*)st8;
+                const uint32_t k = (x1 >= st[0]) + (x1 >= st[1]) + (x1 >= st[2]);
+                const LdsU32* qrow = (const LdsU32*)(bin8 + c2 * (uint32_t)(QROW * 16));   // the diagonal row (c2, c2) as an alias row
+                const uint32_t qv = alias_pick<QK>(qrow, (const LdsU8*)(qrow + QK), x2);
+                const bool bad = mine && ((k != c2) | (x1 == 0xFFFFFFFFu));
+                const bool wr = bad && (int)(16u * npend) - 24 <= t && x1 != 0xFFFFFFFFu && !force_redo;
+                redo |= bad && !wr;
+                LdsU8* slot8 = wr ? row8 + 8u * npend : dummy8;
+                *(LdsU2*)slot8 = u32x2_t{(uint32_t)t | (k << 12) | (c2 << 14) | ((uint32_t)t << 16), x2};
+                npend += wr ? 1u : 0u;
                 sel |= k << (8 * (u & 3)); qacc |= qv << (8 * (u & 3));               // base selectors and raw qualities, four to a word
                 c0 = c1; c1 = c2;
-                if ((u & 3) == 3 || t == B - 1) {
-                    uint32_t wb = __builtin_amdgcn_perm(0x4Eu, 0x54474341u, sel), wq = qacc + 0x21212121u;   // selector 0..3 -> "ACGT", 4 -> 'N'; + 33
+                if ((u & 3) == 3 || (!full && t == B - 1)) {
+                    uint32_t wb = __builtin_amdgcn_perm(0x4Eu, 0x54474341u, sel), wq = qacc + 0x21212121u;   // selector 0..3 -> "ACGT"; + 33
                     if constexpr ((u & 3) != 3) { const uint32_t m = (1u << (8 * ((u & 3) + 1))) - 1u; wb &= m; wq &= m; }   // the read's last, partial word
                     bo_b.R[u >> 2] = wb; bo_q.R[u >> 2] = wq; sel = 0; qacc = 0;
-                    if (u == 15 && t != B - 1 && mine) {
+                    if (u == 15 && (full || t != B - 1) && mine) {
                         bo_b.block(wg_out, sec1, a1, (uint32_t)t >> 4);
                         bo_q.block(wg_out, sec2, a2, (uint32_t)t >> 4);
                     }
                 }
             }, std::make_integer_sequence<int, 16>{});
-        }
+        };
+        int t0 = 0;
+        for (; t0 + 16 < B; t0 += 16) steps(std::true_type{}, t0);                  // (a block that ends the read goes to the checked variant)
+        steps(std::false_type{}, t0);
     } else
     for (int t = 0; t < B; ++t) {
         if ((t & (GROUP - 1)) == 0 && t > 0) {
@@ -1261,6 +1291,15 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
         const uint32_t qv = alias_pick<QK>(arow, reinterpret_cast<const uint8_t*>(arow + QK), pe.y);
         if (FROM_PAIRS) wg_out[sec2 + a2 + (pe.x & 4095u)] = (char)(33u + qv);    // after the record's own stores (same lane: program order)
         else my_q[pe.x & 4095u] = (char)(33u + qv);
+    }
+    if constexpr (UNI) {
+        if (redo) {
+            const int64_t dir = (pr.flags & 2u) ? -1 : 1; const uint32_t comp = pr.flags & 1u;
+            const int64_t gb = rd == 0 ? pr.base + dir * (int64_t)pr.pos : pr.base + dir * (int64_t)(pr.pos + pr.isz - 1);
+            const uint32_t gf = rd == 0 ? (comp | ((dir < 0) ? 2u : 0u)) : ((comp ^ 1u) | ((dir < 0) ? 0u : 2u));
+            redo_read<QK>(g, gb, gf, spool.data, fpool.data, pr.e1, pr.e2, pr.k1, pr.pos, pr.isz, rd, n, (uint32_t)B, subs, subs_d, tb.qual_alias,
+                          draw4(key, ST_READ, aux, uid, 1), wg_out + sec1 + a1, wg_out + sec2 + a2);
+        }
     }
     if (live && !FROM_PAIRS) {
         lens[r] = (uint32_t)n_out;
@@ -1959,7 +1998,7 @@ void launch_pair_offsets(hipStream_t s, const uint32_t* rn, uint32_t ac, int pai
 }
 size_t reads_lds_bytes(const DevTables& tb) {
     const size_t ring = tb.qual_k == 16 ? RingGeo<16>::SLOTS * sizeof(RingBin<16>) : tb.qual_k == 64 ? RingGeo<64>::SLOTS * sizeof(RingBin<64>) : RingGeo<128>::SLOTS * sizeof(RingBin<128>);
-    return ring + (size_t)RB * EV_MAX * 2 + (size_t)RB * win_stride((uint32_t)tb.L);
+    return ring + (size_t)RB * EV_MAX * 2 + (size_t)RB * win_stride((uint32_t)tb.L) + 256;   // + the head rows of the uniform walk
 }
 template <bool FROM_PAIRS, int CLS, class... Args>
 static void launch_reads_kernel(hipStream_t s, dim3 grid, const DevTables& tb, Args... args) {
@@ -1975,8 +2014,8 @@ static void launch_reads_kernel(hipStream_t s, dim3 grid, const DevTables& tb, A
     if (tb.qual_k == 16) SCS_LAUNCH_READS(16, 0); else if (tb.qual_k == 64) SCS_LAUNCH_READS(64, 1); else SCS_LAUNCH_READS(128, 2);
 #undef SCS_LAUNCH_READS
 }
-static uint32_t reads_force_replay() {                                             // tests: every read with an indel takes the replay path
-    static const uint32_t v = getenv("SCS_EV_REPLAY") ? 1u : 0u;
+static uint32_t reads_force_replay() {                                             // tests: bit 0: every read with an indel takes the replay path;
+    static const uint32_t v = (getenv("SCS_EV_REPLAY") ? 1u : 0u) | (getenv("SCS_TEST_REDO") ? 2u : 0u) | (getenv("SCS_TEST_GENERAL") ? 4u : 0u);   // bit 1: every event-free read with a substitution is redone (redo_read)
     return v;
 }
 void launch_indels(hipStream_t s, const PairRec* pairs, uint32_t np, int paired, DevTables tb, RngKey key, uint32_t slot, uint32_t* ev_hdr, uint4* ev_dat,

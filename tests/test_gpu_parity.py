@@ -94,6 +94,21 @@ def test_predict_batch_matches_oracle(model, models, oracle_lib):
     assert len(lens) > 3, "indels did not occur; the test would not exercise the prefix-sum path"
 
 
+def _fastq_diff(got, want, limit=12):
+    """Where two FASTQ texts differ: record number, line of the record, column (for assertion messages)."""
+    if got == want:
+        return ""
+    out = ["sizes %d / %d" % (len(got), len(want))]
+    gl, wl = got.split(b"\n"), want.split(b"\n")
+    for i, (a, b) in enumerate(zip(gl, wl)):
+        if a != b:
+            cols = [k for k in range(min(len(a), len(b))) if a[k] != b[k]]
+            out.append("record %d (%s) line %d: cols %s got %r want %r" % (i // 4, wl[4 * (i // 4)].decode(), i % 4, cols[:8], bytes(a[c] for c in cols[:8]), bytes(b[c] for c in cols[:8])))
+            if len(out) > limit:
+                break
+    return "\n".join(out)
+
+
 CASES = [("g1_hiseq2500_pe", "Illumina_HiSeq2500", ["-c", "3"], "PE", 3.0, 260, {}),
          ("g2_xten_pe_nblock", "Illumina_HiSeqXTen", ["-c", "4", "-s", "300"], "PE", 4.0, 300, {}),
          ("g3_hiseq2000_se", "Illumina_HiSeq2000", ["-c", "2", "-l", "SE"], "SE", 2.0, 260, {}),
@@ -143,7 +158,7 @@ def test_full_pipeline_fastq_bit_exact(case, model, oargs, layout, cov, isize, e
     assert np.array_equal(rn, want_rn), "read allocation differs"
     fq1, fq2 = g.yield_reads()
     if layout == "PE":
-        assert fq1 == open(prefix + "_1.fq", "rb").read()
+        assert fq1 == open(prefix + "_1.fq", "rb").read(), _fastq_diff(fq1, open(prefix + "_1.fq", "rb").read())
         assert fq2 == open(prefix + "_2.fq", "rb").read()
     else:
         assert fq1 == open(prefix + ".fq", "rb").read()
