@@ -75,6 +75,13 @@ struct Xoshiro {
         s[2] ^= t; s[3] = rotl(s[3], 11);
         return result;
     }
+    // [REMAP] one step, two words: the xoshiro128++ output and the same scrambler on the other two state words (stream B of a read)
+    inline void next2(uint32_t& a, uint32_t& b) {
+        a = rotl(s[0] + s[3], 7) + s[0]; b = rotl(s[1] + s[2], 7) + s[1];
+        const uint32_t t = s[1] << 9;
+        s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3];
+        s[2] ^= t; s[3] = rotl(s[3], 11);
+    }
 };
 
 // ---------------------------------------------------------------------------
@@ -474,9 +481,10 @@ int predict(const Profile& P, Rng& rng, const uint8_t* win, int n, bool isRead1,
     const uint32_t rd = isRead1 ? 0u : 1u;
     const uint32_t aux = rd | (attempt << 1);
     // [REMAP] counter mode: each read owns two xoshiro128++ streams seeded by Philox blocks 0 and 1 of ST_READ --
-    // A feeds the indel tests, B the substitution / quality draws -- consumed in the reference's own order (a draw
-    // is only taken where the reference takes one).  Indel lengths (rare) stay keyed Philox draws; an inserted base is
-    // drawn from B at the moment it is emitted, ahead of that position's substitution / quality draws.
+    // A feeds the indel tests, B the base pass.  B advances in STEPS of two words (Xoshiro::next2): every output position
+    // takes one step -- its first word is the substitution draw (unused where the k-mer has no row), its second the
+    // quality draw (quality symbol, or the quality of an 'N') -- and an inserted base takes a step of its own, ahead of its
+    // position's (first word = the base).  Indel lengths (rare) stay keyed Philox draws.
     Xoshiro xa, xb;
     if (rng.counter) {
         uint32_t c[4] = {0, (uint32_t)uid, (uint32_t)(uid >> 32), ST_READ | (aux << 8)}, o[4];
@@ -557,24 +565,28 @@ int predict(const Profile& P, Rng& rng, const uint8_t* win, int n, bool isRead1,
     const int B = P.bins;
     const std::vector<double>& subs = (isRead1 || !P.haveCdf2) ? P.subs1 : P.subs2;   // 1523-1550
     for (int j = 0; j < m; ++j) {                                               // 1666-1694
-        if (rng.counter && inserted[j]) src[j] = (uint8_t)(long)(0 + (P.N - 1 - 0) * drawBi());   // [REMAP] before this position's other draws
+        uint32_t xs = 0, xq = 0;
+        if (rng.counter) {
+            if (inserted[j]) { xb.next2(xs, xq); src[j] = (uint8_t)(long)(0 + (P.N - 1 - 0) * (xs / 4294967296.0)); }   // [REMAP] a step of its own, before the position's
+            xb.next2(xs, xq);
+        }
         uint8_t c0 = j >= 2 ? src[j - 2] : 5, c1 = j >= 1 ? src[j - 1] : 5, c2 = src[j];
         int refIndx = c2 < 4 ? c2 : -1;
         int bin = j * B / m;
         int ki = kmer_index(c0, c1, c2);
         int k;
         if (ki < 0) k = refIndx;
-        else k = rand_indx(&subs[((size_t)ki * B + bin) * 4], 4, drawB());
+        else k = rand_indx(&subs[((size_t)ki * B + bin) * 4], 4, rng.counter ? xs / 4294967296.0 : drawB());
         if (k < 0) {
             out_b[j] = 'N';
-            out_q[j] = (char)(long)(33 + (53 - 33) * drawBi());                 // getRandBaseQuality 1578-1580
+            out_q[j] = (char)(long)(33 + (53 - 33) * (rng.counter ? xq / 4294967296.0 : drawBi()));   // getRandBaseQuality 1578-1580
         } else {
             out_b[j] = BASES[k];
             int bp = refIndx * 4 + k;
             if (rng.counter) {                                                  // [REMAP] alias lookup on the raw 32-bit draw
                 const int K = P.qualK, abits = K == 16 ? 4 : K == 64 ? 6 : 7;
                 const uint32_t* row = &P.qualAlias[((size_t)bp * B + bin) * ((size_t)K + K / 4)];
-                const uint32_t x = xb.next(), col = x >> (32 - abits), e = row[col];
+                const uint32_t x = xq, col = x >> (32 - abits), e = row[col];
                 const uint32_t pick = (x & ((1u << (32 - abits)) - 1u)) < (e >> abits) ? col : (e & (uint32_t)(K - 1));
                 out_q[j] = (char)(33 + reinterpret_cast<const uint8_t*>(row + K)[pick]);
             } else out_q[j] = (char)(33 + rand_indx(&P.qual[((size_t)bp * B + bin) * 94], 94, drawB()));

@@ -82,6 +82,15 @@ struct Xoshiro {
         s2 ^= t; s3 = (s3 << 11) | (s3 >> 21);
         return result;
     }
+    // [REMAP] ONE step, TWO words: a = the xoshiro128++ output (scrambler on s0, s3), b = the same scrambler on the other two
+    // state words (s1, s2).  Stream B of a read (substitution / quality draws) advances one step per output position.
+    SCS_HD void next2(uint32_t& a, uint32_t& b) {
+        const uint32_t p = s0 + s3, q = s1 + s2;
+        a = ((p << 7) | (p >> 25)) + s0; b = ((q << 7) | (q >> 25)) + s1;
+        const uint32_t t = s1 << 9;
+        s2 ^= s0; s3 ^= s1; s1 ^= s2; s0 ^= s3;
+        s2 ^= t; s3 = (s3 << 11) | (s3 >> 21);
+    }
 };
 
 SCS_HD U4 draw4(RngKey key, uint32_t stage, uint32_t aux, uint64_t uid, uint32_t idx) {

@@ -637,7 +637,7 @@ __device__ __noinline__ void redo_read(const uint8_t* __restrict__ g, int64_t gb
             if (k == t) c2 = rd ? 3u - err_alt(e) : err_alt(e);
         });
         const int ki = kmer_index(c0, c1, c2);
-        const uint32_t xs = ki >= 0 ? xb.next() : 0u, xq = xb.next();
+        uint32_t xs, xq; xb.next2(xs, xq);
         uint32_t bc, qc;
         if (ki < 0 && c2 > 3u) { bc = 'N'; qc = 33u + scale_draw(xq, 0, 20); }
         else { const uint32_t kq = call_global_body<QK>(subs, subs_d, qalias, B, ki, c2, c2, (uint32_t)t, xs, xq); bc = (0x54474341u >> (8u * (kq & 255u))) & 255u; qc = 33u + (kq >> 8); }
@@ -1100,7 +1100,7 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
         LdsU8* row8 = (LdsU8*)my_pend_lds;
         LdsU8* dummy8 = (LdsU8*)(s_head + 62);
         const bool force_redo = (force_replay & 2u) != 0;
-        uint32_t wreg = 0, sel = 0, qacc = 0;
+        uint32_t wreg = 0, sel = 0, qacc = 0, nbad = 0;
         c0 = 0; c1 = 0;
         auto steps = [&](auto FULL, int t0) __attribute__((always_inline)) {
             unroll_steps([&](auto U) __attribute__((always_inline)) {
@@ -1111,7 +1111,7 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
                 if ((u & (GROUP - 1)) == 0 && (u > 0 || t0 > 0)) { commit(t); __syncthreads(); prefetch(t + GROUP); }
                 if ((u & 7) == 0) { wreg = win32[t >> 3]; if (!mine) wreg = 0; }
                 const uint32_t c2 = wreg & 3u; wreg >>= 4;
-                const uint32_t x1 = xb.next(), x2 = xb.next();
+                uint32_t x1, x2; xb.next2(x1, x2);                                   // one step of stream B per position
                 const LdsU8* bin8 = ring8 + (u & (SLOTS - 1)) * sizeof(Bin);
                 const LdsU8* st8 = bin8 + 4 * QROW * 16 + ((c0 << 4) | (c1 << 2) | c2) * 12u;
                 if (u < 2) { const LdsU8* h8 = head8 + (u == 0 ? c2 : 4u + c1 * 4u + c2) * 12u; st8 = t0 == 0 ? h8 : st8; }   // the read's first two bases: 1-mer / 2-mer rows
@@ -1119,11 +1119,12 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
                 const uint32_t k = (x1 >= st[0]) + (x1 >= st[1]) + (x1 >= st[2]);
                 const LdsU32* qrow = (const LdsU32*)(bin8 + c2 * (uint32_t)(QROW * 16));   // the diagonal row (c2, c2) as an alias row
                 const uint32_t qv = alias_pick<QK>(qrow, (const LdsU8*)(qrow + QK), x2);
-                const bool bad = mine && ((k != c2) | (x1 == 0xFFFFFFFFu));
-                const bool wr = bad && (int)(16u * npend) - 24 <= t && x1 != 0xFFFFFFFFu && !force_redo;
-                redo |= bad && !wr;
+                // (bitwise, not short-circuit: no divergent region between two positions; lanes without a read count along, ignored later)
+                const bool sub = k != c2, ugly = x1 == 0xFFFFFFFFu;
+                const bool wr = sub & !ugly & (npend <= ((uint32_t)t + 24u) >> 4) & !force_redo;   // entry e fits once 16e - 24 <= t
+                nbad += (sub | ugly) ? 1u : 0u;                                       // nbad != npend after the pass: the read is made again
                 LdsU8* slot8 = wr ? row8 + 8u * npend : dummy8;
-                *(LdsU2*)slot8 = u32x2_t{(uint32_t)t | (k << 12) | (c2 << 14) | ((uint32_t)t << 16), x2};
+                *(LdsU2*)slot8 = u32x2_t{((((c2 << 2) | k) << 12)) | ((uint32_t)t * 0x10001u), x2};   // position | k << 12 | c2 << 14 | bin << 16
                 npend += wr ? 1u : 0u;
                 sel |= k << (8 * (u & 3)); qacc |= qv << (8 * (u & 3));               // base selectors and raw qualities, four to a word
                 c0 = c1; c1 = c2;
@@ -1141,6 +1142,8 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
         int t0 = 0;
         for (; t0 + 16 < B; t0 += 16) steps(std::true_type{}, t0);                  // (a block that ends the read goes to the checked variant)
         steps(std::false_type{}, t0);
+        redo = mine && nbad != npend;
+        if (!mine) npend = 0;
     } else
     for (int t = 0; t < B; ++t) {
         if ((t & (GROUP - 1)) == 0 && t > 0) {
@@ -1176,7 +1179,7 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
             // ---- (A) the source base of this output position (Profile.cpp:1632-1654, walked lazily)
             uint32_t c2 = win_get(my_win, ji);                                     // the common case: the next window base
             if (!SIMPLE && mine && (ins_left > 0 || (uint32_t)ji == next_ev)) {    // rare lanes: inside an insertion / at an indel event
-                if (ins_left > 0) { c2 = scale_draw(xb.next(), 0, 3); --ins_left; }   // inserted base: randomInteger(0, N-1) -> never 'T'
+                if (ins_left > 0) { uint32_t xi, xu; xb.next2(xi, xu); c2 = scale_draw(xi, 0, 3); --ins_left; }   // inserted base (a step of its own): randomInteger(0, N-1) -> never 'T'
                 else {
                     if (replay) {                                                  // the events of phase 1, drawn again (same stream, same order)
                         Xoshiro xa; xa.s0 = my_xa[0]; xa.s1 = my_xa[1]; xa.s2 = my_xa[2]; xa.s3 = my_xa[3];
@@ -1217,8 +1220,7 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
             if (__any(mine && ((c0 | c1 | c2) > 3u || !ring_subs_ok))) {           // some read of the wave: first two bases, an N in the k-mer
                 if (mine) {
                     const int ki = kmer_index(c0, c1, c2);
-                    const uint32_t xs = ki >= 0 ? xb.next() : 0u;                  // drawn only when the k-mer is in the table
-                    const uint32_t xq = xb.next();
+                    uint32_t xs, xq; xb.next2(xs, xq);                             // (xs unused when the k-mer has no row)
                     if (ki < 0 && c2 > 3u) { bc = 'N'; qc = 33 + scale_draw(xq, 0, 20); }   // getRandBaseQuality
                     else {
                         uint32_t k = c2, qv = 0, odd = 2u;
@@ -1232,7 +1234,7 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
                     }
                 }
             } else if (mine) {                                                     // the whole wave on clean k-mers
-                const uint32_t xs = xb.next(), xq = xb.next();
+                uint32_t xs, xq; xb.next2(xs, xq);
                 const uint32_t kk = (c0 << 4) | (c1 << 2) | c2;
                 uint32_t k, qv;
                 uint32_t odd = call_lds(kk, c2, xs, xq, k, qv);

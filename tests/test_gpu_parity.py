@@ -579,6 +579,21 @@ def test_replayed_indel_reads_match_oracle(models, tmp_path):
     assert r.returncode == 0, r.stdout[-3000:]
 
 
+@pytest.mark.parametrize("knob", ["SCS_TEST_REDO", "SCS_TEST_GENERAL"])
+def test_read_class_fallbacks_match_oracle(knob, models, tmp_path):
+    """The base pass has a straight-line variant for event-free, ACGT-only reads.  A read of it that runs out of room for a
+    substituted base's quality (or draws 0xFFFFFFFF) is made again by a scalar fallback (redo_read): SCS_TEST_REDO=1 sends every
+    such read with a substitution through it.  SCS_TEST_GENERAL=1 sends every read through the general variant instead.  Same
+    parity checks, in child processes (the knobs are read once per process)."""
+    if os.environ.get(knob):
+        pytest.skip("already inside the %s run" % knob)
+    env = dict(os.environ, **{knob: "1"})
+    sel = ["tests/test_gpu_parity.py::test_full_pipeline_fastq_bit_exact", "tests/test_gpu_parity.py::test_medium_genome_bit_exact"]
+    r = subprocess.run(["python", "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider"] + sel, cwd=ROOT, env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:]
+
+
 def test_mapped_buffers_parity(models, tmp_path):
     """Device buffers above 64 MB live in a reserved address range and grow by mapping more memory behind them (HIP virtual
     memory management).  The parity cases are far smaller, so they run once more in a child process with the threshold at
