@@ -7,7 +7,8 @@ OUT=$ROOT/gpurun_out/diag_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 ARGS="--steps 1 --warmup 0 --no-extra-legs --no-cpu-baseline --genome-mb 300 $*"
-rocprofv3 --list-avail > $OUT/avail.txt 2>&1 || true
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/p0 -o t -- python3 $ROOT/bench.py $ARGS > $OUT/p0.log 2>&1
+cp $(find $OUT/p0 -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv; rm -rf $OUT/p0
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS --output-format csv -d $OUT/p1 -o a -- python3 $ROOT/bench.py $ARGS > $OUT/p1.log 2>&1
 echo "p1 done"
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_SALU SQ_INSTS_SALU --output-format csv -d $OUT/p2 -o b -- python3 $ROOT/bench.py $ARGS > $OUT/p2.log 2>&1
@@ -28,4 +29,4 @@ with open(out + "/summary.txt", "w") as o:
             o.write("   %-24s %.4g total  %.4g per launch (%d launches)\n" % (c, x, x / len(n[(k, c)]), len(n[(k, c)])))
 PY
 rm -rf $OUT/p1 $OUT/p2
-cat $OUT/summary.txt | head -80
+head -8 $OUT/kernel_stats.csv | cut -c1-120; head -32 $OUT/summary.txt
