@@ -154,7 +154,7 @@ void launch_fasta_chunk(hipStream_t s, const uint8_t* raw, uint32_t n, unsigned 
 // simuvars: out[piece.dst ..] = upper(ref | literal pool), then the SNP / SNV alleles
 void launch_sv_build(hipStream_t s, const uint8_t* ref, const uint8_t* lit, const SvPiece* pieces, uint32_t np, const SvSubst* subs, uint32_t nsub, uint8_t* out, uint64_t total);
 void launch_genome_bits(hipStream_t s, const uint8_t* g, uint64_t n, uint64_t nwords, unsigned long long* gc_bits, unsigned long long* n_bits,
-                        uint32_t* gc_cnt, uint32_t* n_cnt, uint64_t* gc_pref, uint64_t* n_pref, void* temp, size_t temp_bytes);
+                        uint32_t* gc_cnt, uint32_t* n_cnt, uint64_t* gc_pref, uint64_t* n_pref, void* temp, size_t temp_bytes, uint32_t* g2);   // g2: the genome at two bits per base ((nwords + 1) * 4 words)
 void launch_amplify_init(hipStream_t s, int64_t* primer_cnt, int64_t copies, uint32_t* primer_delta, uint32_t* flags, unsigned long long* sums,
                          unsigned long long nf_all, unsigned long long frag_len_all, unsigned long long total_primers, uint32_t* pool_head_a, uint32_t* pool_head_b);
 void launch_primer_update(hipStream_t s, int64_t* primer_cnt, uint32_t* primer_delta);
@@ -163,8 +163,9 @@ void launch_plan_pairs(hipStream_t s, DevFrags fr, DevAmps semis, DevAmps fulls,
                        SegMap gmap, DevTables tb, RngKey key, int paired, PairRec* pairs, unsigned long long* holes);
 void launch_pair_offsets(hipStream_t s, const uint32_t* rn, uint32_t ac, int paired, uint32_t* pair_cnt_off, void* temp, size_t temp_bytes);
 // reads of pairs [p0, p0+np): slot layout [2*np][slot] bases / quals (SE: [np][slot])
-size_t reads_lds_bytes(const DevTables& tb);          // dynamic LDS of one inject_errors workgroup for this profile
-void launch_reads(hipStream_t s, const uint8_t* g, DevErrPool spool, DevErrPool fpool,
+size_t reads_lds_bytes(const DevTables& tb, bool uni = false);   // uni: the uniform-walk variant (event-free ACGT-only reads)
+//          // dynamic LDS of one inject_errors workgroup for this profile
+void launch_reads(hipStream_t s, const uint8_t* g, const uint32_t* g2, DevErrPool spool, DevErrPool fpool,
                   const PairRec* pairs, uint32_t np, uint32_t amp_index_base, DevTables tb, const DevTables* d_tb, RngKey key, int paired, uint32_t slot,
                   const uint32_t* ev_hdr, const uint4* ev_dat, const uint64_t* off1, const uint64_t* off2, char* out1, char* out2, uint32_t* flags,
                   uint64_t cap1, uint64_t cap2,   // writes FASTQ text; cap: bytes of the batch's text in each file (records are checked against it)

@@ -265,16 +265,27 @@ void launch_encode_bases(hipStream_t s, uint8_t* g, uint64_t n) {
 // and the any-N test of ANY window are O(1) (countGC, lib/mydefine/MyDefine.cpp:434-452, without
 // re-reading the 1-2 kb window per amplicon; GC-ness and N-ness are strand-invariant).
 // ------------------------------------------------------------------------------------------------
+// Also the genome with TWO BITS PER BASE (g2: base i in bits 2 (i & 15) of word i >> 4, a non-ACGT base as 0): the windows of
+// reads that cannot see an N (k_reads' uniform walk) are gathered from it -- a quarter of the bytes, and already in the form
+// the walk keeps them in LDS.
 __global__ void k_genome_bits(const uint8_t* __restrict__ g, uint64_t n, uint64_t nwords, unsigned long long* __restrict__ gc_bits,
-                              unsigned long long* __restrict__ n_bits, uint32_t* __restrict__ gc_cnt, uint32_t* __restrict__ n_cnt) {
+                              unsigned long long* __restrict__ n_bits, uint32_t* __restrict__ gc_cnt, uint32_t* __restrict__ n_cnt, uint32_t* __restrict__ g2) {
     const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (w > nwords) return;
-    unsigned long long gm = 0, nm = 0;
+    unsigned long long gm = 0, nm = 0; uint32_t p0 = 0, p1 = 0, p2 = 0, p3 = 0;
     if (w < nwords) {
         const uint64_t b0 = w * 64;
-        for (int k = 0; k < 64; ++k) { const uint64_t i = b0 + k; if (i < n) { const uint32_t c = g[i]; gm |= (unsigned long long)is_gc(c) << k; nm |= (unsigned long long)(c > 3) << k; } }
+        for (int k = 0; k < 64; ++k) {
+            const uint64_t i = b0 + k;
+            if (i < n) {
+                const uint32_t c = g[i]; gm |= (unsigned long long)is_gc(c) << k; nm |= (unsigned long long)(c > 3) << k;
+                const uint32_t v = (c & 3u) << (2 * (k & 15));
+                if (k < 16) p0 |= v; else if (k < 32) p1 |= v; else if (k < 48) p2 |= v; else p3 |= v;
+            }
+        }
     }
     gc_bits[w] = gm; n_bits[w] = nm; gc_cnt[w] = __popcll(gm); n_cnt[w] = __popcll(nm);
+    reinterpret_cast<uint4*>(g2)[w] = make_uint4(p0, p1, p2, p3);
 }
 __device__ __forceinline__ uint64_t bit_rank(const unsigned long long* __restrict__ bits, const uint64_t* __restrict__ pref, uint64_t x) {
     const uint64_t w = x >> 6; const uint32_t r = (uint32_t)(x & 63);
@@ -577,6 +588,16 @@ __device__ __forceinline__ uint32_t dec_digits(uint32_t v) {
     return v < 10u ? 1u : v < 100u ? 2u : v < 1000u ? 3u : v < 10000u ? 4u : v < 100000u ? 5u : v < 1000000u ? 6u :
            v < 10000000u ? 7u : v < 100000000u ? 8u : v < 1000000000u ? 9u : 10u;
 }
+__device__ __forceinline__ void win_put2(LdsU8* w, int i, uint32_t v) {           // two bits per base
+    LdsU32* d = (LdsU32*)w + (i >> 4); const uint32_t sh = 2u * (uint32_t)(i & 15);
+    *d = (*d & ~(3u << sh)) | (v << sh);
+}
+// row of the uniform walk: 16 bytes of pending-quality slots + the window at two bits per base, an odd number of dwords in all
+__host__ __device__ static inline uint32_t uni_row_bytes(uint32_t n) {
+    uint32_t d = 4u + ((n + 15u) >> 4);
+    if ((d & 1u) == 0) ++d;
+    return 4u * d;
+}
 __device__ __forceinline__ uint32_t win_get(const LdsU8* w, int i) { return ((uint32_t)w[i >> 1] >> ((i & 1) * 4)) & 15u; }
 __device__ __forceinline__ void win_put(LdsU8* w, int i, uint32_t v) {
     const uint32_t sh = (uint32_t)(i & 1) * 4u, old = w[i >> 1];
@@ -857,11 +878,12 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
     uint16_t* s_ev = reinterpret_cast<uint16_t*>(s_dyn + SLOTS * sizeof(Bin));   // [RB][EV_MAX]; a replayed read keeps its stream-A state here
     // rows: [RB][WS] windows behind the event slots; the uniform walk (UNI) has no events and keeps each lane's 16 bytes
     // IN FRONT of its window instead -- two pending-quality slots, the later ones overlay the consumed start of the window
+    // and the window itself with TWO bits per base (its reads see no N): uni_row_bytes
     constexpr bool UNI = SIMPLE && FROM_PAIRS;
     constexpr uint32_t WOFF = UNI ? 16u : 0u;
-    const uint32_t ROW = WS + WOFF;
+    const uint32_t ROW = UNI ? uni_row_bytes((uint32_t)n) : WS;
     uint8_t* s_win = UNI ? reinterpret_cast<uint8_t*>(s_ev) : reinterpret_cast<uint8_t*>(s_ev + RB * EV_MAX);
-    uint32_t* s_head = reinterpret_cast<uint32_t*>(s_dyn + SLOTS * sizeof(Bin) + RB * EV_MAX * 2 + (size_t)RB * WS);   // [64] UNI: threshold rows of the 1- and 2-mers
+    uint32_t* s_head = reinterpret_cast<uint32_t*>(s_dyn + SLOTS * sizeof(Bin) + (size_t)RB * ROW);   // [64] UNI: threshold rows of the 1- and 2-mers
     const int tid = threadIdx.x, lane = tid & 63, wib = tid >> 6;
 
     // the workgroup's records are contiguous: stores address them as a uniform base (aligned down to a sector) + a 32-bit offset
@@ -931,6 +953,32 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
         __syncthreads();
         // a lane takes 4 consecutive window bases = one dword of the genome (byte-reversed when the view runs backwards),
         // complements them in place and packs them into two LDS bytes: one load instruction covers 256 bases of a read
+        if constexpr (UNI) {
+            // windows from the two-bit genome (its reads see no N): W2 dwords of 16 bases per read.  A read takes W2 + 1 lanes of an
+            // instruction -- lane j loads word T + j (T - j when the view runs backwards; T = the word of the window's first
+            // base) and borrows lane j + 1's word for the funnel shift to the window's bit offset -- so one load instruction
+            // serves 64 / (W2 + 1) reads (5 at L = 150).  Backwards: the 16 bases are reversed in the dword; complement: ~.
+            const uint32_t* __restrict__ g2 = reinterpret_cast<const uint32_t*>(windows);   // pair mode: the `windows` argument carries the two-bit genome
+            const int W2 = (n + 15) >> 4, LPR = W2 + 1, RPI = WAVE / LPR;
+            const int r5 = lane / LPR, j = lane - r5 * LPR;
+            for (int i0 = 0; i0 < WAVE; i0 += RPI) {
+                const int rq = i0 + r5; const bool on = r5 < RPI && rq < WAVE;
+                const int rr = wib * WAVE + (on ? rq : 0);
+                const uint32_t f = s_gflag[rr]; const int64_t b0 = s_gbase[rr];
+                const bool bwd = (f & 2u) != 0;
+                const int64_t T = b0 >> 4; const uint32_t q = (uint32_t)b0 & 15u;
+                const uint32_t own = g2[bwd ? T - j : T + j];                    // (always inside the padded array)
+                const uint32_t nbr = (uint32_t)__shfl_down((int)own, 1);
+                uint32_t v = bwd ? __builtin_amdgcn_alignbit(own, nbr, 2u * (q + 1u)) : __builtin_amdgcn_alignbit(nbr, own, 2u * q);
+                if (bwd) {
+                    if (q == 15u) v = own;
+                    v = __builtin_bitreverse32(v);                              // reverses the bases AND the two bits of each: swap those back
+                    v = ((v >> 1) & 0x55555555u) | ((v & 0x55555555u) << 1);
+                }
+                if (f & 1u) v = ~v;                                               // complement: 3 - c
+                if (on && (f & 4u) && j < W2) reinterpret_cast<uint32_t*>(s_win + (size_t)rr * ROW + WOFF)[j] = v;
+            }
+        } else
         for (int kb = 0; kb < n; kb += 4 * WAVE) {                                  // one round for L <= 256
             const int k4 = kb + 4 * lane;
             constexpr int FLY = 32;                                                 // reads whose loads are in flight per lane: the gather is HBM-latency bound
@@ -966,11 +1014,11 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
             // read 1: t - pos ; read 2: pos + isz - 1 - t, complemented
             for_each_err(pr.e1, spool.data, [&](uint32_t e) {
                 const int t = pr.k1 - (int)err_pos(e); const int k = rd ? (int)(pr.pos + pr.isz - 1) - t : t - (int)pr.pos;
-                if (k >= 0 && k < n) win_put(my_win, k, rd ? err_alt(e) : 3u - err_alt(e));
+                if (k >= 0 && k < n) { if (UNI) win_put2(my_win, k, rd ? err_alt(e) : 3u - err_alt(e)); else win_put(my_win, k, rd ? err_alt(e) : 3u - err_alt(e)); }
             });
             for_each_err(pr.e2, fpool.data, [&](uint32_t e) {
                 const int t = (int)err_pos(e); const int k = rd ? (int)(pr.pos + pr.isz - 1) - t : t - (int)pr.pos;
-                if (k >= 0 && k < n) win_put(my_win, k, rd ? 3u - err_alt(e) : err_alt(e));
+                if (k >= 0 && k < n) { if (UNI) win_put2(my_win, k, rd ? 3u - err_alt(e) : err_alt(e)); else win_put(my_win, k, rd ? 3u - err_alt(e) : err_alt(e)); }
             });
         }
     } else {
@@ -1109,8 +1157,9 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
         // lookups of neighbouring positions.  A substituted base needs the quality row (c2, k), which only global memory
         // holds; its quality does not feed back into the walk, so (position, k, c2, draw) is set aside with an unconditional
         // LDS store (lanes without one store to a dummy word) and resolved after the pass.  Slots: two in front of the
-        // window, the later ones over the window's consumed start -- entry e >= 2 over dwords 2(e-2), 2(e-2)+1, fetched once
-        // t >= 16(e-2)+8.  No room, or the draw 0xFFFFFFFF: the read is flagged and made again by redo_read.
+        // window, the later ones over the window's consumed start -- entry e >= 2 over dwords 2(e-2), 2(e-2)+1 (16 bases
+        // each), both in a register once t >= 32(e-2)+16.  No room, or the draw 0xFFFFFFFF: the read is flagged and made
+        // again by redo_read.
         // Lanes without a read run along on an all-'A' window and store nothing.
         const bool mine = live && n_out > 0;
         const LdsU8* ring8 = (const LdsU8*)s_dyn;
@@ -1142,8 +1191,8 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
                         bo_q.block(wg_out, sec2, a2, (uint32_t)(t0 >> 4) - 1u);
                     }
                 }
-                if ((u & 7) == 0) { wreg = win32[t >> 3]; if (!mine) wreg = 0; }
-                const uint32_t c2 = wreg & 3u; wreg >>= 4;
+                if (u == 0) { wreg = win32[t0 >> 4]; if (!mine) wreg = 0; }        // the block's 16 bases
+                const uint32_t c2 = wreg & 3u; wreg >>= 2;
                 uint32_t x1, x2; xb.next2(x1, x2);                                   // one step of stream B per position
                 const LdsU8* bin8 = ring8 + (u & (SLOTS - 1)) * sizeof(Bin);
                 const LdsU8* st8 = bin8 + 4 * QROW * 16 + ((c0 << 4) | (c1 << 2) | c2) * 12u;
@@ -1154,7 +1203,7 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
                 const uint32_t qv = alias_pick<QK>(qrow, (const LdsU8*)(qrow + QK), x2);
                 // (bitwise, not short-circuit: no divergent region between two positions; lanes without a read count along, ignored later)
                 const bool sub = k != c2, ugly = x1 == 0xFFFFFFFFu;
-                const bool wr = sub & !ugly & (npend <= ((uint32_t)t + 24u) >> 4) & !force_redo;   // entry e fits once 16e - 24 <= t
+                const bool wr = sub & !ugly & (npend <= ((uint32_t)t + 48u) >> 5) & !force_redo;   // entry e fits once 32e - 48 <= t
                 nbad += (sub | ugly) ? 1u : 0u;                                       // nbad != npend after the pass: the read is made again
                 LdsU8* slot8 = wr ? row8 + 8u * npend : dummy8;
                 *(LdsU2*)slot8 = u32x2_t{((((c2 << 2) | k) << 12)) | ((uint32_t)t * 0x10001u), x2};   // position | k << 12 | c2 << 14 | bin << 16
@@ -1997,8 +2046,8 @@ void launch_errs_semis(hipStream_t s, const uint8_t* g, DevGenomeIdx gx, DevFrag
                        primer_cnt, primer_delta, (unsigned long long*)nullptr);
 }
 void launch_genome_bits(hipStream_t s, const uint8_t* g, uint64_t n, uint64_t nwords, unsigned long long* gc_bits, unsigned long long* n_bits,
-                        uint32_t* gc_cnt, uint32_t* n_cnt, uint64_t* gc_pref, uint64_t* n_pref, void* temp, size_t temp_bytes) {
-    hipLaunchKernelGGL(k_genome_bits, dim3(cdiv(nwords + 1, 256)), dim3(256), 0, s, g, n, nwords, gc_bits, n_bits, gc_cnt, n_cnt);
+                        uint32_t* gc_cnt, uint32_t* n_cnt, uint64_t* gc_pref, uint64_t* n_pref, void* temp, size_t temp_bytes, uint32_t* g2) {
+    hipLaunchKernelGGL(k_genome_bits, dim3(cdiv(nwords + 1, 256)), dim3(256), 0, s, g, n, nwords, gc_bits, n_bits, gc_cnt, n_cnt, g2);
     (void)rocprim::exclusive_scan(temp, temp_bytes, rocprim::make_transform_iterator((const uint32_t*)gc_cnt, Widen()), gc_pref, (uint64_t)0, nwords + 1, rocprim::plus<uint64_t>(), s);
     (void)rocprim::exclusive_scan(temp, temp_bytes, rocprim::make_transform_iterator((const uint32_t*)n_cnt, Widen()), n_pref, (uint64_t)0, nwords + 1, rocprim::plus<uint64_t>(), s);
 }
@@ -2028,13 +2077,14 @@ void launch_pair_offsets(hipStream_t s, const uint32_t* rn, uint32_t ac, int pai
     if (paired) (void)rocprim::exclusive_scan(temp, temp_bytes, rocprim::make_transform_iterator(rn, HalfUp()), pair_cnt_off, 0u, (size_t)ac + 1, rocprim::plus<uint32_t>(), s);
     else (void)rocprim::exclusive_scan(temp, temp_bytes, rn, pair_cnt_off, 0u, (size_t)ac + 1, rocprim::plus<uint32_t>(), s);
 }
-size_t reads_lds_bytes(const DevTables& tb) {
+size_t reads_lds_bytes(const DevTables& tb, bool uni) {
     const size_t ring = tb.qual_k == 16 ? RingGeo<16>::SLOTS * sizeof(RingBin<16>) : tb.qual_k == 64 ? RingGeo<64>::SLOTS * sizeof(RingBin<64>) : RingGeo<128>::SLOTS * sizeof(RingBin<128>);
-    return ring + (size_t)RB * EV_MAX * 2 + (size_t)RB * win_stride((uint32_t)tb.L) + 256;   // + the head rows of the uniform walk
+    if (uni) return ring + (size_t)RB * uni_row_bytes((uint32_t)tb.L) + 256;       // + the head rows
+    return ring + (size_t)RB * EV_MAX * 2 + (size_t)RB * win_stride((uint32_t)tb.L);
 }
 template <bool FROM_PAIRS, int CLS, class... Args>
 static void launch_reads_kernel(hipStream_t s, dim3 grid, const DevTables& tb, Args... args) {
-    const size_t lds = reads_lds_bytes(tb);
+    const size_t lds = reads_lds_bytes(tb, FROM_PAIRS && CLS == 1);
     // > 64 KB of dynamic LDS needs the opt-in; the limit is raised to exactly what this profile needs (once per size:
     // the call sits on the host's critical path of a small job)
     static size_t opted_all[64][3] = {};                                           // per device and instantiation (the attribute belongs to the device's code object)
@@ -2055,11 +2105,11 @@ void launch_indels(hipStream_t s, const PairRec* pairs, uint32_t np, int paired,
     if (np == 0) return;
     const uint32_t nreads = paired ? 2 * np : np;
     (void)slot;                                                                    // the FASTQ record takes whatever length the read has (header field: 16 bits)
-    hipLaunchKernelGGL(k_indels, dim3(cdiv(nreads, 256)), dim3(256), 0, s, pairs, np, paired, tb, key, 65535u, reads_force_replay(), ev_hdr, ev_dat, sizes1, sizes2, cls1, cls2, flags);
+    hipLaunchKernelGGL(k_indels, dim3(cdiv(nreads, 256)), dim3(256), 0, s, pairs, np, paired, tb, key, 65535u, reads_force_replay() | (tb.L > 1008 ? 4u : 0u) /* the uniform walk gathers a read with at most 64 lanes */, ev_hdr, ev_dat, sizes1, sizes2, cls1, cls2, flags);
 }
 // event-free reads and the rest as two launches over their lists (k_read_lists); the grid of a launch covers the longer of
 // the two mates' lists
-void launch_reads(hipStream_t s, const uint8_t* g, DevErrPool spool, DevErrPool fpool,
+void launch_reads(hipStream_t s, const uint8_t* g, const uint32_t* g2, DevErrPool spool, DevErrPool fpool,
                   const PairRec* pairs, uint32_t np, uint32_t amp_index_base, DevTables tb, const DevTables* d_tb, RngKey key, int paired, uint32_t slot,
                   const uint32_t* ev_hdr, const uint4* ev_dat, const uint64_t* off1, const uint64_t* off2, char* out1, char* out2, uint32_t* flags,
                   uint64_t cap1, uint64_t cap2, const uint32_t* slist1, const uint32_t* slist2, const uint32_t* clist1, const uint32_t* clist2, uint32_t nc1, uint32_t nc2) {
@@ -2070,7 +2120,7 @@ void launch_reads(hipStream_t s, const uint8_t* g, DevErrPool spool, DevErrPool 
     const uint32_t ns1 = np - nc1, ns2 = paired ? np - nc2 : 0u;
     const uint32_t gs = cdiv(std::max(ns1, ns2), RB), gc = cdiv(std::max(nc1, paired ? nc2 : 0u), RB);
     if (gs) launch_reads_kernel<true, 1>(s, dim3(paired ? 2 * gs : gs), tb, g, spool, fpool, pairs, np, paired,
-                              (const uint8_t*)nullptr, (const uint64_t*)nullptr, (const uint32_t*)nullptr, (const uint8_t*)nullptr, 0u, tb, key, slot,
+                              reinterpret_cast<const uint8_t*>(g2), (const uint64_t*)nullptr, (const uint32_t*)nullptr, (const uint8_t*)nullptr, 0u, tb, key, slot,
                               (uint32_t)(paired ? 2ull * np : np), reads_force_replay(), ev_hdr, ev_dat, off1, off2, out1, out2, amp_index_base,
                               (char*)nullptr, (char*)nullptr, (uint32_t*)nullptr, flags, cap1, cap2, slist1, slist2, ns1, ns2);
     if (gc) launch_reads_kernel<true, 2>(s, dim3(paired ? 2 * gc : gc), tb, g, spool, fpool, pairs, np, paired,

@@ -160,7 +160,7 @@ struct scs_ctx {
     DevBuf d_tables, t_gap, t_qcompact, t_guide, t_ring1, t_ring2, t_subs1, t_subs2, t_qual, t_ins, t_del, t_isize, d_subs1, d_subs2, d_qual, d_ins, d_del, d_isize, d_gcmeans;
     // genome + fragments
     DevBuf gx_gc_bits, gx_n_bits, gx_gc_cnt, gx_n_cnt, gx_gc_pref, gx_n_pref, d_binom;
-    std::vector<FastaRecord> recs; bool have_genome = false; DevBuf genome; std::vector<uint64_t> rec_off, rec_len; uint64_t genome_bases = 0;   // recs: names only once staged
+    std::vector<FastaRecord> recs; bool have_genome = false; DevBuf genome, genome2; std::vector<uint64_t> rec_off, rec_len; uint64_t genome_bases = 0;   // recs: names only once staged
     std::vector<uint64_t> f_goff; std::vector<uint32_t> f_len; std::vector<int8_t> f_strand; std::vector<uint32_t> f_primers;
     uint64_t f_gidx_base = 0; bool have_frags = false;
     DevBuf df_blob, df_primers, df_hasn; size_t df_len_off = 0, df_strand_off = 0;           // fragments: offsets | lengths | strands in one block
@@ -344,8 +344,9 @@ void stage_genome(scs_ctx* c, const void* d_ascii = nullptr, const uint64_t* d_l
         hipStream_t s = c->stream; const uint64_t nw = (tot + 63) / 64;
         c->gx_gc_bits.reserve((nw + 1) * 8, s); c->gx_n_bits.reserve((nw + 1) * 8, s); c->gx_gc_cnt.reserve((nw + 2) * 4, s); c->gx_n_cnt.reserve((nw + 2) * 4, s);
         c->gx_gc_pref.reserve((nw + 2) * 8, s); c->gx_n_pref.reserve((nw + 2) * 8, s); c->scan_tmp.reserve(scan_temp_bytes(nw + 1), s);
+        c->genome2.reserve((nw + 1) * 16 + 256, s);                               // two bits per base, 64 bytes of slack in front and 192 behind (the window gather over-reads by up to a dozen words)
         launch_genome_bits(s, c->genome.as<uint8_t>(), tot, nw, c->gx_gc_bits.as<unsigned long long>(), c->gx_n_bits.as<unsigned long long>(), c->gx_gc_cnt.as<uint32_t>(),
-                           c->gx_n_cnt.as<uint32_t>(), c->gx_gc_pref.as<uint64_t>(), c->gx_n_pref.as<uint64_t>(), c->scan_tmp.p, c->scan_tmp.cap);
+                           c->gx_n_cnt.as<uint32_t>(), c->gx_gc_pref.as<uint64_t>(), c->gx_n_pref.as<uint64_t>(), c->scan_tmp.p, c->scan_tmp.cap, c->genome2.as<uint32_t>() + 16);
     }
     HIP_OK(hipStreamSynchronize(c->stream));
     for (auto& r : c->recs) std::vector<uint8_t>().swap(r.code);
@@ -884,7 +885,7 @@ void do_yield(scs_ctx* c, const OutTarget& tg, uint64_t* n1_out, uint64_t* n2_ou
             o1 = d1.as<char>(); o2 = d2.as<char>();
         }
         c->tm_reads.begin(s);                                                      // the base pass writes the FASTQ text at the record offsets
-        launch_reads(s, c->genome.as<uint8_t>(), c->semis.pool_view(), c->fulls.pool_view(), pr, np, 0,
+        launch_reads(s, c->genome.as<uint8_t>(), c->genome2.as<uint32_t>() + 16, c->semis.pool_view(), c->fulls.pool_view(), pr, np, 0,
                      c->dtb, c->d_tables.as<DevTables>(), c->key, paired, slot, B.ev_hdr, B.ev_dat,
                      B.off1, B.off2, o1, o2, c->flags.as<uint32_t>(), b1, b2, B.slist1, B.slist2, B.clist1, B.clist2, nc1, nc2);
         c->tm_reads.end(s);
@@ -983,7 +984,7 @@ void scs_destroy(scs_ctx* c) {
     (void)hipSetDevice(c->cfg.device);
     (void)hipStreamSynchronize(c->stream);
     for (DevBuf* b : {&c->d_tables, &c->t_gap, &c->t_qcompact, &c->t_guide, &c->t_ring1, &c->t_ring2, &c->t_subs1, &c->t_subs2, &c->t_qual, &c->t_ins, &c->t_del, &c->t_isize, &c->d_subs1, &c->d_subs2, &c->d_qual, &c->d_ins, &c->d_del,
-                      &c->d_isize, &c->d_gcmeans, &c->genome, &c->gx_gc_bits, &c->gx_n_bits, &c->gx_gc_cnt, &c->gx_n_cnt, &c->gx_gc_pref, &c->gx_n_pref, &c->d_binom, &c->df_blob, &c->df_primers, &c->df_hasn, &c->primer_cnt, &c->primer_delta,
+                      &c->d_isize, &c->d_gcmeans, &c->genome, &c->genome2, &c->gx_gc_bits, &c->gx_n_bits, &c->gx_gc_cnt, &c->gx_n_cnt, &c->gx_gc_pref, &c->gx_n_pref, &c->d_binom, &c->df_blob, &c->df_primers, &c->df_hasn, &c->primer_cnt, &c->primer_delta,
                       &c->slots, &c->slot_tmpl, &c->valid, &c->valid_off, &c->valid_f, &c->valid_off_f, &c->scan_tmp, &c->flags, &c->weights, &c->read_numbers,
                       &c->pair_off, &c->pairs, &c->odd_before, &c->a_part, &c->a_tp, &c->a_probs, &c->a_quota, &c->a_poff, &c->a_plan, &c->a_crn, &c->a_scratch, &c->a_brow, &c->a_bmap, &c->a_send, &c->a_gath, &c->a_odd, &c->d_hostred, &c->d_tot, &c->d_stage, &c->d_mail, &c->budget_f, &c->budget_s, &c->poisson_part, &c->slot_off_f,
                       &c->slot_off_s, &c->dsums, &c->slot_b, &c->slot_q, &c->lens, &c->ev_hdr, &c->ev_dat, &c->sizes1, &c->sizes2, &c->off1, &c->off2, &c->out1, &c->out2, &c->out1b, &c->out2b, &c->rl_cls, &c->rl_pos, &c->rl_lists}) b->release();
