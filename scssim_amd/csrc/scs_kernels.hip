@@ -1171,19 +1171,72 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
         char* __restrict__ spare = reinterpret_cast<char*>(flags) + 128;               // 32 bytes nobody reads (the flags buffer is 256 bytes)
         uint32_t wreg = 0, sel = 0, qacc = 0, nbad = 0;
         c0 = 0; c1 = 0;
-        auto steps = [&](auto FULL, int t0) __attribute__((always_inline)) {
+        // SOFTWARE PIPELINE, one position deep.  The compiler's scheduler waits for an LDS read right where it issues it; here
+        // every read gets a stage's worth of independent work before its use.  Step u runs, in this order,
+        //   finish_a(u-1): thresholds and alias entry of the previous position are back -> its base k, its alias column -> issue the symbol read
+        //   start(u):      this position's window base, stream-B step, table addresses -> issue the threshold and alias-entry reads
+        //   finish_b(u-1): the symbol is back -> pending-quality bookkeeping, the output words
+        // with the ring's refill (commit, barrier, prefetch) between finish_a and start: every ring read of a group is issued
+        // before its wave arrives at the next group's barrier, as the refill's slot reuse assumes.
+        uint32_t aT0 = 0, aT1 = 0, aT2 = 0, aE = 0, aX1 = 0, aX2 = 0, aC2 = 0; const LdsU8* aQ = ring8;   // start -> finish_a
+        uint32_t bK = 0, bC2 = 0, bX2 = 0, bSym = 0; bool bUgly = false;                                   // finish_a -> finish_b
+        auto start = [&](auto U, int t0) __attribute__((always_inline)) {
+            constexpr int u = decltype(U)::value;
+            if (u == 0) { wreg = win32[t0 >> 4]; if (!mine) wreg = 0; }            // the block's 16 bases
+            const uint32_t c2 = wreg & 3u; wreg >>= 2;
+            uint32_t x1, x2; xb.next2(x1, x2);                                       // one step of stream B per position
+            const LdsU8* bin8 = ring8 + (u & (SLOTS - 1)) * sizeof(Bin);
+            const LdsU8* st8 = bin8 + 4 * QROW * 16 + ((c0 << 4) | (c1 << 2) | c2) * 12u;
+            if (u < 2) { const LdsU8* h8 = head8 + (u == 0 ? c2 : 4u + c1 * 4u + c2) * 12u; st8 = t0 == 0 ? h8 : st8; }   // the read's first two bases: 1-mer / 2-mer rows
+            const LdsU32* st = (const LdsU32*)st8;
+            const LdsU32* qrow = (const LdsU32*)(bin8 + c2 * (uint32_t)(QROW * 16));   // the diagonal row (c2, c2) as an alias row
+            aT0 = st[0]; aT1 = st[1]; aT2 = st[2]; aE = qrow[x2 >> (32u - Geo::ABITS)];
+            aQ = (const LdsU8*)(qrow + QK); aX1 = x1; aX2 = x2; aC2 = c2;
+            c0 = c1; c1 = c2;
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto finish_a = [&]() __attribute__((always_inline)) {
+            bK = (aX1 >= aT0) + (aX1 >= aT1) + (aX1 >= aT2);
+            const uint32_t col = aX2 >> (32u - Geo::ABITS);
+            const uint32_t pick = ((aX2 << Geo::ABITS) | (uint32_t)(QK - 1)) < aE ? col : (aE & (uint32_t)(QK - 1));   // alias_pick
+            bSym = aQ[pick];
+            bC2 = aC2; bX2 = aX2; bUgly = aX1 == 0xFFFFFFFFu;
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto finish_b = [&](auto U, int t, bool last) __attribute__((always_inline)) {   // t: the position being finished, u = t & 15
+            constexpr int u = decltype(U)::value;
+            // (bitwise, not short-circuit: no divergent region between two positions; lanes without a read count along, ignored later)
+            const bool sub = bK != bC2;
+            const bool wr = sub & !bUgly & (npend <= ((uint32_t)t + 48u) >> 5) & !force_redo;   // entry e fits once 32e - 48 <= t
+            nbad += (sub | bUgly) ? 1u : 0u;                                          // nbad != npend after the pass: the read is made again
+            LdsU8* slot8 = wr ? row8 + 8u * npend : dummy8;
+            *(LdsU2*)slot8 = u32x2_t{((((bC2 << 2) | bK) << 12)) | ((uint32_t)t * 0x10001u), bX2};   // position | k << 12 | c2 << 14 | bin << 16
+            npend += wr ? 1u : 0u;
+            sel |= bK << (8 * (u & 3)); qacc |= bSym << (8 * (u & 3));                // base selectors and raw qualities, four to a word
+            if ((u & 3) == 3 || last) {
+                uint32_t wb = __builtin_amdgcn_perm(0x4Eu, 0x54474341u, sel), wq = qacc + 0x21212121u;   // selector 0..3 -> "ACGT"; + 33
+                if constexpr ((u & 3) != 3) { const uint32_t m = (1u << (8 * ((u & 3) + 1))) - 1u; wb &= m; wq &= m; }   // the read's last, partial word
+                bo_b.R[u >> 2] = wb; bo_q.R[u >> 2] = wq; sel = 0; qacc = 0;
+            }
+        };
+        // MODE 2: all 16 positions exist, t0 >= 48: the previous block (m >= 2) leaves as straight-line stores; 1: all 16 exist, t0 < 48
+        // (blocks 0 and 1, stored at t0 = 16 and 32, may hold a stream's first, partial sector: branching stores); 0: the read's last block
+        auto steps = [&](auto MODE, int t0) __attribute__((always_inline)) {
             unroll_steps([&](auto U) __attribute__((always_inline)) {
                 constexpr int u = decltype(U)::value;
-                constexpr bool full = decltype(FULL)::value;                       // all 16 positions exist, none is the read's last, t0 >= 48
+                constexpr int mode = decltype(MODE)::value;
                 const int t = t0 + u;
-                if (!full && t >= B) return;
+                if (mode == 0 && t >= B) return;
+                if (u > 0 || t0 > 0) finish_a();
                 if ((u & (GROUP - 1)) == 0 && (u > 0 || t0 > 0)) { commit(t); __syncthreads(); prefetch(t + GROUP); }
+                start(U, t0);
+                if (u > 0 || t0 > 0) finish_b(std::integral_constant<int, (u + 15) & 15>{}, t - 1, false);
                 // The previous 16 characters leave HERE, right behind the ring's loads.  On this hardware loads and stores complete
                 // out of order with each other, so a wait for a load (the next commit) is a wait for EVERY outstanding store too
                 // (s_waitcnt vmcnt(0)); placed here that wait comes a whole group of positions after the stores, when their round
-                // trip to L2 is over.  (The raw words R[] of the stored block are not overwritten before u = 3.)
+                // trip to L2 is over.  (The raw words R[] of the stored block are not overwritten before u = 4.)
                 if (u == 0 && t0 > 0) {
-                    if constexpr (full) {                                         // blocks m >= 2: straight-line
+                    if constexpr (mode == 2) {
                         bo_b.block_flat(wg_out, sec1, a1, (uint32_t)(t0 >> 4) - 1u, spare, mine);
                         bo_q.block_flat(wg_out, sec2, a2, (uint32_t)(t0 >> 4) - 1u, spare, mine);
                     } else if (mine) {
@@ -1191,36 +1244,14 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
                         bo_q.block(wg_out, sec2, a2, (uint32_t)(t0 >> 4) - 1u);
                     }
                 }
-                if (u == 0) { wreg = win32[t0 >> 4]; if (!mine) wreg = 0; }        // the block's 16 bases
-                const uint32_t c2 = wreg & 3u; wreg >>= 2;
-                uint32_t x1, x2; xb.next2(x1, x2);                                   // one step of stream B per position
-                const LdsU8* bin8 = ring8 + (u & (SLOTS - 1)) * sizeof(Bin);
-                const LdsU8* st8 = bin8 + 4 * QROW * 16 + ((c0 << 4) | (c1 << 2) | c2) * 12u;
-                if (u < 2) { const LdsU8* h8 = head8 + (u == 0 ? c2 : 4u + c1 * 4u + c2) * 12u; st8 = t0 == 0 ? h8 : st8; }   // the read's first two bases: 1-mer / 2-mer rows
-                const LdsU32* st = (const LdsU32*)st8;
-                const uint32_t k = (x1 >= st[0]) + (x1 >= st[1]) + (x1 >= st[2]);
-                const LdsU32* qrow = (const LdsU32*)(bin8 + c2 * (uint32_t)(QROW * 16));   // the diagonal row (c2, c2) as an alias row
-                const uint32_t qv = alias_pick<QK>(qrow, (const LdsU8*)(qrow + QK), x2);
-                // (bitwise, not short-circuit: no divergent region between two positions; lanes without a read count along, ignored later)
-                const bool sub = k != c2, ugly = x1 == 0xFFFFFFFFu;
-                const bool wr = sub & !ugly & (npend <= ((uint32_t)t + 48u) >> 5) & !force_redo;   // entry e fits once 32e - 48 <= t
-                nbad += (sub | ugly) ? 1u : 0u;                                       // nbad != npend after the pass: the read is made again
-                LdsU8* slot8 = wr ? row8 + 8u * npend : dummy8;
-                *(LdsU2*)slot8 = u32x2_t{((((c2 << 2) | k) << 12)) | ((uint32_t)t * 0x10001u), x2};   // position | k << 12 | c2 << 14 | bin << 16
-                npend += wr ? 1u : 0u;
-                sel |= k << (8 * (u & 3)); qacc |= qv << (8 * (u & 3));               // base selectors and raw qualities, four to a word
-                c0 = c1; c1 = c2;
-                if ((u & 3) == 3 || (!full && t == B - 1)) {
-                    uint32_t wb = __builtin_amdgcn_perm(0x4Eu, 0x54474341u, sel), wq = qacc + 0x21212121u;   // selector 0..3 -> "ACGT"; + 33
-                    if constexpr ((u & 3) != 3) { const uint32_t m = (1u << (8 * ((u & 3) + 1))) - 1u; wb &= m; wq &= m; }   // the read's last, partial word
-                    bo_b.R[u >> 2] = wb; bo_q.R[u >> 2] = wq; sel = 0; qacc = 0;
-                }
             }, std::make_integer_sequence<int, 16>{});
         };
         int t0 = 0;
-        for (; t0 < 48 && t0 + 16 < B; t0 += 16) steps(std::false_type{}, t0);      // blocks 0 and 1 (stored at t0 = 16, 32) may hold a stream's first, partial sector
-        for (; t0 + 16 < B; t0 += 16) steps(std::true_type{}, t0);
-        steps(std::false_type{}, t0);                                              // (the block that ends the read: checked variant)
+        for (; t0 < 48 && t0 + 16 < B; t0 += 16) steps(std::integral_constant<int, 1>{}, t0);
+        for (; t0 + 16 < B; t0 += 16) steps(std::integral_constant<int, 2>{}, t0);
+        steps(std::integral_constant<int, 0>{}, t0);
+        finish_a();                                                                 // drain: the read's last position
+        unroll_steps([&](auto U) __attribute__((always_inline)) { if (decltype(U)::value == ((B - 1) & 15)) finish_b(U, B - 1, true); }, std::make_integer_sequence<int, 16>{});
         redo = mine && nbad != npend;
         if (!mine) npend = 0;
     } else
