@@ -171,11 +171,11 @@ void launch_reads(hipStream_t s, const uint8_t* g, const uint32_t* g2, DevErrPoo
                   uint64_t cap1, uint64_t cap2,   // writes FASTQ text; cap: bytes of the batch's text in each file (records are checked against it)
                   const uint32_t* slist1, const uint32_t* slist2, const uint32_t* clist1, const uint32_t* clist2, uint32_t nc1, uint32_t nc2);   // launch_read_lists' lists; nc: reads with indel events per mate
 // splits the batch's reads into those without indel events and the rest (cls from launch_indels): ascending pair-index lists per mate
-void launch_read_lists(hipStream_t s, uint32_t np, int paired, const uint32_t* cls1, uint32_t* cpos1, const uint32_t* cls2, uint32_t* cpos2,
-                       uint32_t* slist1, uint32_t* slist2, uint32_t* clist1, uint32_t* clist2, void* temp, size_t temp_bytes);
+void launch_read_lists(hipStream_t s, uint32_t np, int paired, const uint32_t* sizes1, const uint64_t* off1, const uint32_t* sizes2, const uint64_t* off2,
+                       uint32_t* slist1, uint32_t* slist2, uint32_t* clist1, uint32_t* clist2);
 // the indel pass of a batch (n' and events per read, FASTQ record sizes per pair and mate), ahead of launch_reads
 void launch_indels(hipStream_t s, const PairRec* pairs, uint32_t np, int paired, DevTables tb, RngKey key, uint32_t slot, uint32_t* ev_hdr, uint4* ev_dat,
-                   uint32_t* sizes1, uint32_t* sizes2, uint32_t* cls1, uint32_t* cls2, uint32_t* flags);
+                   uint32_t* sizes1, uint32_t* sizes2, uint32_t* flags);
 void launch_predict_windows(hipStream_t s, const uint8_t* windows, uint32_t n_reads, const uint64_t* uids, const uint32_t* atts,
                             const uint8_t* is_read1, DevTables tb, const DevTables* d_tb, RngKey key, uint32_t slot, char* slot_b, char* slot_q,
                             uint32_t* lens, uint32_t* flags);
@@ -195,6 +195,10 @@ hipError_t take_launch_error();
 size_t scan_temp_bytes(size_t n);
 void exclusive_scan_u32(hipStream_t s, const uint32_t* in, uint32_t* out, size_t n, void* temp, size_t temp_bytes);
 void exclusive_scan_u32_pair(hipStream_t s, const uint32_t* in0, uint32_t* out0, size_t n0, const uint32_t* in1, uint32_t* out1, size_t n1, void* temp, size_t temp_bytes);
+// record sizes (class flag in bit 31) -> byte offsets in the low OFF_BITS bits, count of flagged reads above (one scan for both)
+#define OFF_BITS 40
+#define OFF_MASK ((1ull << OFF_BITS) - 1ull)
+void exclusive_scan_sizes(hipStream_t s, const uint32_t* in, uint64_t* out, size_t n, void* temp, size_t temp_bytes);
 void exclusive_scan_u32_to_u64(hipStream_t s, const uint32_t* in, uint64_t* out, size_t n, void* temp, size_t temp_bytes);
 
 }  // namespace scs

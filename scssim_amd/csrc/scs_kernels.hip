@@ -722,7 +722,7 @@ __device__ __forceinline__ IndelPass indel_pass(const DevTables& tb, RngKey key,
 //      header {n' | events << 16 | replay << 24 | live << 25} go to global memory.
 __global__ void __launch_bounds__(256) k_indels(const PairRec* __restrict__ pairs, uint32_t np, int paired, const DevTables tb, RngKey key, uint32_t slot,
                                                 uint32_t force_replay, uint32_t* __restrict__ ev_hdr, uint4* __restrict__ ev_dat,
-                                                uint32_t* __restrict__ sizes1, uint32_t* __restrict__ sizes2, uint32_t* __restrict__ cls1, uint32_t* __restrict__ cls2,
+                                                uint32_t* __restrict__ sizes1, uint32_t* __restrict__ sizes2,
                                                 uint32_t* __restrict__ flags) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t nreads = paired ? 2 * np : np;
@@ -730,17 +730,16 @@ __global__ void __launch_bounds__(256) k_indels(const PairRec* __restrict__ pair
     const uint32_t pi = paired ? r >> 1 : r, rd = paired ? (r & 1u) : 0u;
     const uint64_t uid = pairs[pi].uid; const uint32_t att = pairs[pi].att, isz = pairs[pi].isz, amp = pairs[pi].amp, has_n = pairs[pi].flags & 4u;
     uint32_t* sz = rd ? sizes2 : sizes1;
-    uint32_t* cls = rd ? cls2 : cls1;                                              // 1: the read has indel events or may see an N (k_reads' general variant), 0: neither
-    if (isz == 0) { ev_hdr[r] = 0; sz[pi] = 0; cls[pi] = 0; return; }               // hole: the insert-size loop gave up (Amplicon.cpp:484-489)
+    if (isz == 0) { ev_hdr[r] = 0; sz[pi] = 0; return; }               // hole: the insert-size loop gave up (Amplicon.cpp:484-489)
     unsigned long long e_lo = 0, e_hi = 0;
     const IndelPass ip = indel_pass(tb, key, rd | (att << 1), uid, force_replay, slot, flags, [&](int i, uint32_t v) {
         if (i < 4) e_lo |= (unsigned long long)v << (16 * i); else e_hi |= (unsigned long long)v << (16 * (i - 4));
     });
     ev_hdr[r] = (uint32_t)ip.n_out | ((uint32_t)ip.nev << 16) | (ip.replay ? 1u << 24 : 0u) | (1u << 25);
     ev_dat[r] = make_uint4((uint32_t)e_lo, (uint32_t)(e_lo >> 32), (uint32_t)e_hi, (uint32_t)(e_hi >> 32));
-    cls[pi] = (ip.nev > 0 || ip.replay || has_n || (force_replay & 4u)) ? 1u : 0u;                        // the uniform walk takes ACGT-only windows without events
+    const uint32_t cls = (ip.nev > 0 || ip.replay || has_n || (force_replay & 4u)) ? 1u : 0u;            // the uniform walk takes ACGT-only windows without events
     // "@<ampIdx>#<fragCount>[/1|/2]\n" + seq + "\n+\n" + qual + "\n"   (Amplicon.cpp:459-466,497-504)
-    sz[pi] = ip.n_out == 0 ? 0u : 1u + dec_digits(amp) + 1u + dec_digits(att + 1) + (paired ? 2u : 0u) + 1u + 2u * (uint32_t)ip.n_out + 4u;
+    sz[pi] = (ip.n_out == 0 ? 0u : 1u + dec_digits(amp) + 1u + dec_digits(att + 1) + (paired ? 2u : 0u) + 1u + 2u * (uint32_t)ip.n_out + 4u) | (cls << 31);   // bit 31: the class rides along into the offsets' scan
 }
 
 // ---- FASTQ text straight from the base pass (pair mode).  A record is two byte streams per read: the name line + bases +
@@ -893,7 +892,7 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
     const uint32_t* __restrict__ wlist = second_file ? list2 : list1;              // CLS != 0: this mate's list
     const uint32_t nwork = CLS == 0 ? np : (second_file ? nlist2 : nlist1), wq = (paired ? blockIdx.x >> 1 : blockIdx.x) * RB;
     if (FROM_PAIRS && wq >= nwork) return;                                          // the grid covers the longer of the two mates' lists
-    const uint64_t off0 = FROM_PAIRS ? offs[CLS == 0 ? wq : wlist[wq]] : 0ull;      // lists ascend: the chunk's first record is its lowest
+    const uint64_t off0 = FROM_PAIRS ? (offs[CLS == 0 ? wq : wlist[wq]] & OFF_MASK) : 0ull;      // lists ascend: the chunk's first record is its lowest
     const uint32_t adj = (uint32_t)(reinterpret_cast<uintptr_t>(outp) + off0) & 31u;
     char* __restrict__ wg_out = outp + off0 - adj;
 
@@ -911,7 +910,7 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
             o = pairs[p];
             const uint32_t amp = amp_index_base + o.amp, cnt = o.att + 1u;
             h = 1u + dec_digits(amp) + 1u + dec_digits(cnt) + (paired ? 2u : 0u) + 1u;   // "@<amp>#<cnt>[/1|/2]\n"
-            rel = (uint32_t)(offs[p] - off0) + adj;
+            rel = (uint32_t)((offs[p] & OFF_MASK) - off0) + adj;
         };
         uint32_t keyp = 32u;
         auto pair_of = [&](uint32_t e) -> uint32_t { return e < nwork ? (CLS == 0 ? e : wlist[e]) : 0xFFFFFFFFu; };
@@ -1080,7 +1079,7 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
     for (int i = 0; i < 4; ++i) { bo_b.R[i] = bo_q.R[i] = 0; bo_b.H[i] = bo_q.H[i] = 0; if (i < 3) bo_b.P[i] = bo_q.P[i] = 0; }
     // the record must lie inside the batch's text (its offset and size come from k_indels' n'; the walk below emits exactly
     // n' characters per stream): a disagreement would be an internal error, reported, never a store outside the buffer
-    if (FROM_PAIRS && live && n_out > 0 && offs[pi] + rec_h + 2ull * (uint32_t)n_out + 4ull > (second_file ? cap2 : cap1)) { atomicOr(flags, (uint32_t)FLAG_INTERNAL); live = false; n_out = 0; }
+    if (FROM_PAIRS && live && n_out > 0 && (offs[pi] & OFF_MASK) + rec_h + 2ull * (uint32_t)n_out + 4ull > (second_file ? cap2 : cap1)) { atomicOr(flags, (uint32_t)FLAG_INTERNAL); live = false; n_out = 0; }
     if (FROM_PAIRS && live && n_out > 0) {
         const uint32_t amp = amp_index_base + pr.amp, cnt = pr.att + 1u, d2 = dec_digits(cnt), h = rec_h;
         const uint32_t o1 = rec_rel + h, o2 = o1 + (uint32_t)n_out + 3u;          // where the bases / the qualities start
@@ -2132,11 +2131,11 @@ static uint32_t reads_force_replay() {                                          
     return v;
 }
 void launch_indels(hipStream_t s, const PairRec* pairs, uint32_t np, int paired, DevTables tb, RngKey key, uint32_t slot, uint32_t* ev_hdr, uint4* ev_dat,
-                   uint32_t* sizes1, uint32_t* sizes2, uint32_t* cls1, uint32_t* cls2, uint32_t* flags) {
+                   uint32_t* sizes1, uint32_t* sizes2, uint32_t* flags) {
     if (np == 0) return;
     const uint32_t nreads = paired ? 2 * np : np;
     (void)slot;                                                                    // the FASTQ record takes whatever length the read has (header field: 16 bits)
-    hipLaunchKernelGGL(k_indels, dim3(cdiv(nreads, 256)), dim3(256), 0, s, pairs, np, paired, tb, key, 65535u, reads_force_replay() | (tb.L > 1008 ? 4u : 0u) /* the uniform walk gathers a read with at most 64 lanes */, ev_hdr, ev_dat, sizes1, sizes2, cls1, cls2, flags);
+    hipLaunchKernelGGL(k_indels, dim3(cdiv(nreads, 256)), dim3(256), 0, s, pairs, np, paired, tb, key, 65535u, reads_force_replay() | (tb.L > 1008 ? 4u : 0u) /* the uniform walk gathers a read with at most 64 lanes */, ev_hdr, ev_dat, sizes1, sizes2, flags);
 }
 // event-free reads and the rest as two launches over their lists (k_read_lists); the grid of a launch covers the longer of
 // the two mates' lists
@@ -2160,19 +2159,18 @@ void launch_reads(hipStream_t s, const uint8_t* g, const uint32_t* g2, DevErrPoo
                               (char*)nullptr, (char*)nullptr, (uint32_t*)nullptr, flags, cap1, cap2, clist1, clist2, nc1, paired ? nc2 : 0u);
 }
 // the batch's reads split by class (k_indels' flags cls, their exclusive scans cpos): ascending lists of pair indices
-__global__ void k_read_lists(uint32_t np, int paired, const uint32_t* __restrict__ cls1, const uint32_t* __restrict__ cpos1, const uint32_t* __restrict__ cls2,
-                             const uint32_t* __restrict__ cpos2, uint32_t* __restrict__ slist1, uint32_t* __restrict__ slist2, uint32_t* __restrict__ clist1, uint32_t* __restrict__ clist2) {
+// (class = bit 31 of the record size as k_indels left it; position in the class's list = the scanned offset's bits above OFF_BITS)
+__global__ void k_read_lists(uint32_t np, int paired, const uint32_t* __restrict__ sizes1, const uint64_t* __restrict__ off1, const uint32_t* __restrict__ sizes2,
+                             const uint64_t* __restrict__ off2, uint32_t* __restrict__ slist1, uint32_t* __restrict__ slist2, uint32_t* __restrict__ clist1, uint32_t* __restrict__ clist2) {
     const uint32_t pi = blockIdx.x * blockDim.x + threadIdx.x;
     if (pi >= np) return;
-    { const uint32_t c = cpos1[pi]; if (cls1[pi]) clist1[c] = pi; else slist1[pi - c] = pi; }
-    if (paired) { const uint32_t c = cpos2[pi]; if (cls2[pi]) clist2[c] = pi; else slist2[pi - c] = pi; }
+    { const uint32_t c = (uint32_t)(off1[pi] >> OFF_BITS); if (sizes1[pi] >> 31) clist1[c] = pi; else slist1[pi - c] = pi; }
+    if (paired) { const uint32_t c = (uint32_t)(off2[pi] >> OFF_BITS); if (sizes2[pi] >> 31) clist2[c] = pi; else slist2[pi - c] = pi; }
 }
-void launch_read_lists(hipStream_t s, uint32_t np, int paired, const uint32_t* cls1, uint32_t* cpos1, const uint32_t* cls2, uint32_t* cpos2,
-                       uint32_t* slist1, uint32_t* slist2, uint32_t* clist1, uint32_t* clist2, void* temp, size_t temp_bytes) {
+void launch_read_lists(hipStream_t s, uint32_t np, int paired, const uint32_t* sizes1, const uint64_t* off1, const uint32_t* sizes2, const uint64_t* off2,
+                       uint32_t* slist1, uint32_t* slist2, uint32_t* clist1, uint32_t* clist2) {
     if (np == 0) return;
-    exclusive_scan_u32(s, cls1, cpos1, np, temp, temp_bytes);
-    if (paired) exclusive_scan_u32(s, cls2, cpos2, np, temp, temp_bytes);
-    hipLaunchKernelGGL(k_read_lists, dim3(cdiv(np, 256)), dim3(256), 0, s, np, paired, cls1, cpos1, cls2, cpos2, slist1, slist2, clist1, clist2);
+    hipLaunchKernelGGL(k_read_lists, dim3(cdiv(np, 256)), dim3(256), 0, s, np, paired, sizes1, off1, sizes2, off2, slist1, slist2, clist1, clist2);
 }
 void launch_predict_windows(hipStream_t s, const uint8_t* windows, uint32_t n_reads, const uint64_t* uids, const uint32_t* atts,
                             const uint8_t* is_read1, DevTables tb, const DevTables* d_tb, RngKey key, uint32_t slot, char* slot_b, char* slot_q, uint32_t* lens, uint32_t* flags) {
@@ -2244,6 +2242,12 @@ void exclusive_scan_u32_pair(hipStream_t s, const uint32_t* in0, uint32_t* out0,
     if (n0 <= SMALL_SCAN_MAX && n1 <= SMALL_SCAN_MAX && in1) { hipLaunchKernelGGL(k_scan_small, dim3(2), dim3(1024), 0, s, in0, out0, (uint32_t)n0, in1, out1, (uint32_t)n1); return; }
     exclusive_scan_u32(s, in0, out0, n0, temp, temp_bytes);
     if (in1) exclusive_scan_u32(s, in1, out1, n1, temp, temp_bytes);
+}
+// record sizes -> record offsets AND the class flags -> list positions in ONE scan: k_indels leaves the read's class in bit 31 of
+// its record size; the scanned value carries the byte offset in its low 40 bits and the count of flagged reads above
+struct SizeCls { __host__ __device__ uint64_t operator()(uint32_t v) const { return (uint64_t)(v & 0x7FFFFFFFu) | ((uint64_t)(v >> 31) << OFF_BITS); } };
+void exclusive_scan_sizes(hipStream_t s, const uint32_t* in, uint64_t* out, size_t n, void* temp, size_t temp_bytes) {
+    (void)rocprim::exclusive_scan(temp, temp_bytes, rocprim::make_transform_iterator(in, SizeCls()), out, (uint64_t)0, n + 1, rocprim::plus<uint64_t>(), s);
 }
 void exclusive_scan_u32_to_u64(hipStream_t s, const uint32_t* in, uint64_t* out, size_t n, void* temp, size_t temp_bytes) {
     (void)rocprim::exclusive_scan(temp, temp_bytes, rocprim::make_transform_iterator(in, Widen()), out, (uint64_t)0, n + 1, rocprim::plus<uint64_t>(), s);

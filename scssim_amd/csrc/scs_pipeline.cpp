@@ -836,14 +836,13 @@ void do_yield(scs_ctx* c, const OutTarget& tg, uint64_t* n1_out, uint64_t* n2_ou
         const PairRec* pr = c->pairs.as<PairRec>() + p0;
         // the indel pass fixes every read's length, hence the record sizes and (prefix sums) the record offsets
         c->tm_indels.begin(s);
-        launch_indels(s, pr, np, paired, c->dtb, c->key, slot, B.ev_hdr, B.ev_dat, B.sizes1, B.sizes2, B.cls1, B.cls2, c->flags.as<uint32_t>());
+        launch_indels(s, pr, np, paired, c->dtb, c->key, slot, B.ev_hdr, B.ev_dat, B.sizes1, B.sizes2, c->flags.as<uint32_t>());
         c->tm_indels.end(s);
         c->tm_indels.add_units(np);
-        exclusive_scan_u32_to_u64(s, B.sizes1, B.off1, np, c->scan_tmp.p, c->scan_tmp.cap);
-        if (paired) exclusive_scan_u32_to_u64(s, B.sizes2, B.off2, np, c->scan_tmp.p, c->scan_tmp.cap);
-        launch_read_lists(s, np, paired, B.cls1, B.cpos1, B.cls2, B.cpos2, B.slist1, B.slist2, B.clist1, B.clist2, c->scan_tmp.p, c->scan_tmp.cap);
-        Mail m; m.add(B.off1 + np, 8, 0); m.add(paired ? (const void*)(B.off2 + np) : nullptr, 8, 1);
-        m.add(B.cpos1 + np, 4, 2); m.add(paired ? (const void*)(B.cpos2 + np) : nullptr, 4, 3); mail_post(c, m, true);
+        exclusive_scan_sizes(s, B.sizes1, B.off1, np, c->scan_tmp.p, c->scan_tmp.cap);   // byte offsets + positions in the class lists: one scan per mate
+        if (paired) exclusive_scan_sizes(s, B.sizes2, B.off2, np, c->scan_tmp.p, c->scan_tmp.cap);
+        launch_read_lists(s, np, paired, B.sizes1, B.off1, B.sizes2, B.off2, B.slist1, B.slist2, B.clist1, B.clist2);
+        Mail m; m.add(B.off1 + np, 8, 0); m.add(paired ? (const void*)(B.off2 + np) : nullptr, 8, 1); mail_post(c, m, true);
     };
     uint64_t tot1 = 0, tot2 = 0, pairs_written = 0;
     // shard index: the pair index at which each list segment starts (pair_off at the segment's first amplicon)
@@ -860,14 +859,14 @@ void do_yield(scs_ctx* c, const OutTarget& tg, uint64_t* n1_out, uint64_t* n2_ou
         const PairRec* pr = c->pairs.as<PairRec>() + p0;
         const BatchSet& B = bs[it & 1];
         mail_wait(c);                                                              // this batch's byte and class counts
-        const uint64_t b1 = c->h_rb[0], b2 = c->h_rb[1]; const uint32_t nc1 = (uint32_t)c->h_rb[2], nc2 = (uint32_t)c->h_rb[3];
+        const uint64_t b1 = c->h_rb[0] & OFF_MASK, b2 = c->h_rb[1] & OFF_MASK; const uint32_t nc1 = (uint32_t)(c->h_rb[0] >> OFF_BITS), nc2 = (uint32_t)(c->h_rb[1] >> OFF_BITS);
         if (p0 + batch < P) prepass(p0 + batch, bs[(it + 1) & 1]);                 // the next batch's pre-pass goes in ahead of this batch's base pass
         while (bnext < bpair.size() && bpair[bnext] < p0 + np) {                     // a segment starts inside this batch: its record's byte offset
             uint64_t o1v = 0, o2v = 0; const uint64_t idx = bpair[bnext] - p0;
             HIP_OK(hipMemcpyAsync(&o1v, B.off1 + idx, 8, hipMemcpyDeviceToHost, s));
             if (paired) HIP_OK(hipMemcpyAsync(&o2v, B.off2 + idx, 8, hipMemcpyDeviceToHost, s));
             HIP_OK(hipStreamSynchronize(s));
-            (*tg.seg_off1)[bnext] = tot1 + o1v; if (tg.seg_off2) (*tg.seg_off2)[bnext] = tot2 + o2v;
+            (*tg.seg_off1)[bnext] = tot1 + (o1v & OFF_MASK); if (tg.seg_off2) (*tg.seg_off2)[bnext] = tot2 + (o2v & OFF_MASK);
             ++bnext;
         }
         char *o1, *o2;
