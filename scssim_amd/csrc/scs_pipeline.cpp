@@ -804,7 +804,10 @@ void do_yield(scs_ctx* c, const OutTarget& tg, uint64_t* n1_out, uint64_t* n2_ou
     launch_plan_pairs(s, c->frags_view(), c->semis.view(), c->fulls.view(), c->fulls.n, c->read_numbers.as<uint32_t>(), c->pair_off.as<uint32_t>(), c->gmap, c->dtb, c->key, paired, c->pairs.as<PairRec>(),
                       c->dsums.as<unsigned long long>() + DS_HOLES);
     const bool to_sink = !tg.device && tg.sink;
-    const uint64_t batch = std::min<uint64_t>(std::max<uint64_t>(P, 1), to_sink ? (1ull << 19) : (1ull << 21));   // sink: smaller batches, pinned double buffers
+    // pairs per batch: 8 M with the text staying in HBM (5 GB of text per batch: the base pass' grids are long enough for their tails and
+    // the per-batch pre-pass not to matter: 2 M -> 8 M gave -11 % on the stage), 512 k towards a sink (pinned double buffers)
+    static const int batch_shift = getenv("SCS_TEST_BATCH_SHIFT") ? atoi(getenv("SCS_TEST_BATCH_SHIFT")) : 0;   // tests: many small batches
+    const uint64_t batch = std::min<uint64_t>(std::max<uint64_t>(P, 1), batch_shift ? (1ull << batch_shift) : to_sink ? (1ull << 19) : (1ull << 23));
     struct PipeGuard { SinkPipe* p; ~PipeGuard() { if (p) (void)p->finish(); } } guard{nullptr};
     if (to_sink) {
         if (!c->pipe) { c->pipe = new SinkPipe; HIP_OK(hipEventCreateWithFlags(&c->pipe->ev[0], hipEventDisableTiming)); HIP_OK(hipEventCreateWithFlags(&c->pipe->ev[1], hipEventDisableTiming)); }

@@ -579,6 +579,19 @@ def test_replayed_indel_reads_match_oracle(models, tmp_path):
     assert r.returncode == 0, r.stdout[-3000:]
 
 
+def test_many_small_batches_match_oracle(models, tmp_path):
+    """The read stage works batch by batch (8 M pairs with the text staying in HBM, 512 k towards a sink), the next batch's
+    pre-pass queued ahead of the current base pass into a second set of buffers.  The parity cases fit one batch, so they run once
+    more in a child process with 4096-pair batches (SCS_TEST_BATCH_SHIFT=12): dozens of batches, ragged last one."""
+    if os.environ.get("SCS_TEST_BATCH_SHIFT"):
+        pytest.skip("already inside the small-batch run")
+    env = dict(os.environ, SCS_TEST_BATCH_SHIFT="12")
+    sel = ["tests/test_gpu_parity.py::test_full_pipeline_fastq_bit_exact", "tests/test_gpu_parity.py::test_medium_genome_bit_exact"]
+    r = subprocess.run(["python", "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider"] + sel, cwd=ROOT, env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:]
+
+
 @pytest.mark.parametrize("knob", ["SCS_TEST_REDO", "SCS_TEST_GENERAL"])
 def test_read_class_fallbacks_match_oracle(knob, models, tmp_path):
     """The base pass has a straight-line variant for event-free, ACGT-only reads.  A read of it that runs out of room for a
