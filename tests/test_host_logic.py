@@ -231,3 +231,50 @@ def test_shard_merge_copies_byte_ranges_in_list_order(tmp_path):
         assert os.path.exists(pre + ".r0.idx") == (not paired)
     with pytest.raises(scssim_amd.ScsError):
         scssim_amd.merge_fastq_shards(str(tmp_path / "absent"), 2)
+
+
+def test_two_word_stream_step_is_sound():
+    """[REMAP] stream B of a read advances one xoshiro128 step per output position and takes TWO words from it: the xoshiro128++
+    output (scrambler on state words s0, s3) for the substitution draw and the same scrambler on the other two words (s1, s2)
+    for the quality draw (scs_common.h Xoshiro::next2, mirrored in the oracle).  A numpy restatement over 4096 independent
+    streams x 512 steps: both words uniform (chi-square over their top byte), uncorrelated with each other within a step and
+    across consecutive steps, and the first word is bit for bit the published generator's output."""
+    rng = np.random.default_rng(5)
+    s = [rng.integers(1, 1 << 32, size=4096, dtype=np.uint64).astype(np.uint32) for _ in range(4)]
+
+    def rotl(x, k):
+        return ((x << np.uint32(k)) | (x >> np.uint32(32 - k))).astype(np.uint32)
+
+    def reference_next(st):                                # xoshiro128++ 1.0 (Blackman & Vigna), one stream, python ints
+        s0, s1, s2, s3 = st
+        m = 0xFFFFFFFF
+        r = ((((s0 + s3) & m) << 7 | ((s0 + s3) & m) >> 25) + s0) & m
+        t = (s1 << 9) & m
+        s2 ^= s0; s3 ^= s1; s1 ^= s2; s0 ^= s3; s2 ^= t; s3 = ((s3 << 11) | (s3 >> 21)) & m
+        return r, [s0, s1, s2, s3]
+
+    ref_state = [int(w[0]) for w in s]
+    A, Bw = [], []
+    for step in range(512):
+        a = (rotl(s[0] + s[3], 7) + s[0]).astype(np.uint32)
+        b = (rotl(s[1] + s[2], 7) + s[1]).astype(np.uint32)
+        t = (s[1] << np.uint32(9)).astype(np.uint32)
+        s[2] = s[2] ^ s[0]; s[3] = s[3] ^ s[1]; s[1] = s[1] ^ s[2]; s[0] = s[0] ^ s[3]
+        s[2] = s[2] ^ t; s[3] = rotl(s[3], 11)
+        A.append(a); Bw.append(b)
+        if step < 64:
+            r, ref_state = reference_next(ref_state)
+            assert int(a[0]) == r
+    A = np.array(A, dtype=np.float64) / 2.0 ** 32
+    Bn = np.array(Bw, dtype=np.float64) / 2.0 ** 32
+    n = A.size
+    for x in (A, Bn):
+        assert abs(x.mean() - 0.5) < 4 * np.sqrt(1.0 / 12 / n)
+        counts = np.bincount((x.ravel() * 256).astype(np.int64), minlength=256)
+        chi2 = ((counts - n / 256.0) ** 2 / (n / 256.0)).sum()
+        assert chi2 < 255 + 5 * np.sqrt(2 * 255), chi2
+    def corr(x, y):
+        return float(np.corrcoef(x.ravel(), y.ravel())[0, 1])
+    lim = 5.0 / np.sqrt(n)
+    assert abs(corr(A, Bn)) < lim
+    assert abs(corr(Bn[:-1], A[1:])) < lim and abs(corr(A[:-1], Bn[1:])) < lim and abs(corr(Bn[:-1], Bn[1:])) < lim
