@@ -1129,7 +1129,7 @@ void allocate_reads(Sim& S, std::vector<double>& w, long reads, std::vector<unsi
     for (size_t c = 0; c < chunks.size(); ++c) {                                  // batchSampling, one task per chunk, FIFO
         Chunk& ch = chunks[c];
         for (unsigned t = 0; t < ch.quota; ++t) {
-            const double u = S.rng.real(mk(ST_ALLOC_CHUNK, 0, c, t, 0));
+            const double u = S.rng.real(mk(ST_ALLOC_CHUNK, 0, c, t >> 2, (int)(t & 3)));   // [REMAP] draw t = word t & 3 of block t >> 2
             unsigned j = ctr ? first_le(ch.cdf.data(), (unsigned)ch.cdf.size(), u) : rand_indx(ch.cdf.data(), ch.cdf.size(), u);
             readNumbers[ch.s + j] += 1;
         }

@@ -28,7 +28,7 @@ enum Stage : uint32_t {
     ST_ERRALT      = 5,   // uid = NEW amplicon uid, aux = kind, idx = j | (a/4)<<16, word a%4  (Fragment.cpp:107-110)
     ST_WEIGHT      = 6,   // uid = full uid, idx = attempt, words 0,1                           (Profile.cpp:1503-1513)
     ST_ALLOC_TOP   = 7,   // uid = 0, idx = t, word 0                                           (MyDefine.cpp:242-245)
-    ST_ALLOC_CHUNK = 8,   // uid = chunk, idx = t, word 0                                       (MyDefine.cpp:191-201)
+    ST_ALLOC_CHUNK = 8,   // uid = chunk, idx = t >> 2, word t & 3                                      (MyDefine.cpp:191-201)
     ST_PAIR        = 9,   // uid = full uid, idx = attempt, word0 insert size, word1 position   (Amplicon.cpp:483-491)
     ST_READ        = 10,  // uid = full uid, aux = rd | attempt<<1: block 0 seeds the read's xoshiro128++ stream A (insertion /
                           //   deletion tests, Profile.cpp:1556-1566), block 1 stream B (substitution, quality, random quality of

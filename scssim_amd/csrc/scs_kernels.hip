@@ -1870,18 +1870,37 @@ __global__ void __launch_bounds__(64) k_alloc_sample(const double* __restrict__ 
     const double* __restrict__ v = r.brow < 0 ? w + r.local0 : brow + (size_t)r.brow * ALLOC_CHUNK;
     const double t = tp[r.c];
     double carry = 0;
-    for (uint32_t b = 0; b < r.n; b += WAVE) {
-        double s = b + lane < r.n ? v[b + lane] / t : 0.0;                             // p[i]/totalProb (MyDefine.cpp:224)
+    // the chunk's weights first, all loads in flight together (a load per round of the scan below was a memory round trip per
+    // round: sixteen in a row)
+    constexpr int ROUNDS = (ALLOC_CHUNK + WAVE - 1) / WAVE;
+    double pv[ROUNDS];
+#pragma unroll
+    for (int k = 0; k < ROUNDS; ++k) pv[k] = (uint32_t)(k * WAVE) + lane < r.n ? v[k * WAVE + lane] : 0.0;
+#pragma unroll
+    for (int k = 0; k < ROUNDS; ++k) {
+        const uint32_t b = (uint32_t)(k * WAVE);
+        if (b >= r.n) break;
+        double s = b + lane < r.n ? pv[k] / t : 0.0;                                    // p[i]/totalProb (MyDefine.cpp:224)
 #pragma unroll
         for (int d = 1; d < WAVE; d <<= 1) { const double u = shfl_up_f64(s, d); if ((int)lane >= d) s = s + u; }
         if (b + lane < r.n) { s_cdf[b + lane] = carry + s; s_cnt[b + lane] = 0; }
         carry = carry + shfl_f64(s, 63);
     }
     __builtin_amdgcn_wave_barrier();
-    for (uint32_t k = lane; k < nq; k += WAVE) {
-        const U4 d = draw4(key, ST_ALLOC_CHUNK, 0, r.c, k);
-        const double x = 2.2204e-16 + (1 - 2.2204e-16) * ((double)d.w[0] / 4294967296.0);
-        atomicAdd(&s_cnt[first_le(s_cdf, r.n, x)], 1u);
+    // [REMAP] draw k of the chunk = word k & 3 of Philox block k >> 2: a lane takes a whole block, and its four bisections run
+    // interleaved (each is ten dependent LDS reads: four in flight instead of one)
+    for (uint32_t j = lane; 4u * j < nq; j += WAVE) {
+        const U4 d = draw4(key, ST_ALLOC_CHUNK, 0, r.c, j);
+        double x[4]; uint32_t lo[4], hi[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { x[i] = 2.2204e-16 + (1 - 2.2204e-16) * ((double)d.w[i] / 4294967296.0); lo[i] = 0; hi[i] = r.n; }
+        for (uint32_t span = r.n; span; span >>= 1) {                                  // ceil(log2(n + 1)) rounds settle every one (first_le)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (lo[i] < hi[i]) { const uint32_t mid = (lo[i] + hi[i]) >> 1; if (x[i] <= s_cdf[mid]) hi[i] = mid; else lo[i] = mid + 1; }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) if (4u * j + (uint32_t)i < nq) atomicAdd(&s_cnt[lo[i] < r.n ? lo[i] : r.n - 1], 1u);
     }
     __builtin_amdgcn_wave_barrier();
     for (uint32_t i = lane; i < r.n; i += WAVE) {
