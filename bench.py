@@ -184,6 +184,12 @@ def committed_counters(kernel_prefix):
             res["lanes_per_valu_inst"] = lanes_w / valu
             res["salu_insts_per_launch"] = salu
             res["sq_source"] = os.path.relpath(files[-1], ROOT)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_meta.json")))
+    if files:
+        try:
+            res["profile_pairs_per_launch"] = float(json.load(open(files[-1]))["pairs_per_launch"])
+        except (OSError, ValueError, KeyError):
+            pass
     return res
 
 
@@ -341,6 +347,13 @@ def main():
         prefix = {"k_reads": "scs::k_reads", "k_indels": "scs::k_indels", "k_attach<semi>": "scs::k_attach<false", "k_attach<frag>": "scs::k_attach<true",
                   "k_errs<semi->full>": "scs::k_errs<false>", "k_errs<frag->semi>": "scs::k_errs<true>"}[dom]
         cc = committed_counters(prefix)
+        # the committed counters are per launch of the profiled command (one GPU, 8 M-pair batches); a sharded run launches smaller
+        # batches: scaled by pairs per launch (the k_reads / k_indels counters are proportional to the pairs of a launch)
+        if dom in ("k_reads", "k_indels") and cc.get("profile_pairs_per_launch") and kd["launches"]:
+            scale = (kd["units"] / kd["launches"]) / cc["profile_pairs_per_launch"]
+            for key in ("traffic", "valu_insts_per_launch", "salu_insts_per_launch"):
+                if key in cc:
+                    cc[key] *= scale
         roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": cc.get("traffic"), "traffic_source": cc.get("traffic_source"), "algorithmic_bytes": note,
                 "algorithmic_bytes_per_launch": alg / max(1, kd["launches"]), "avg_launch_ms": kd["ms"] / max(1, kd["launches"]),

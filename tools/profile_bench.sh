@@ -23,6 +23,13 @@ K=$(find $OUT/trace -name "*kernel_stats.csv" | head -1)
 python3 $ROOT/tools/pmc_summary.py $F $W $OUT/bench_pmc_hbm.csv "python3 bench.py $ARGS"
 python3 $ROOT/tools/sq_summary.py $S $OUT/bench_sq.csv "python3 bench.py $ARGS"
 cp $K $OUT/bench_kernel_stats.csv
+# launch geometry of the profiled command (bench.py scales the per-launch counters by it)
+python3 - $OUT/bench_trace.log $OUT/bench_meta.json <<'PY'
+import json, sys
+d = json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1])
+ppl = d["config"]["pairs_per_step"] * d["steps"] / d["roofline"]["timed_launches"]
+json.dump({"pairs_per_launch": ppl, "note": "k_reads launches of the profiled command: %d launches over %d timed job(s) of %d pairs" % (d["roofline"]["timed_launches"], d["steps"], d["config"]["pairs_per_step"])}, open(sys.argv[2], "w"), indent=1)
+PY
 # the raw per-dispatch tables are large: keep the summaries only
 rm -rf $OUT/fetch $OUT/write $OUT/sq $OUT/trace
 ls -la $OUT
