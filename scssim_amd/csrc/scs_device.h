@@ -169,13 +169,15 @@ void launch_reads(hipStream_t s, const uint8_t* g, const uint32_t* g2, DevErrPoo
                   const PairRec* pairs, uint32_t np, uint32_t amp_index_base, DevTables tb, const DevTables* d_tb, RngKey key, int paired, uint32_t slot,
                   const uint32_t* ev_hdr, const uint4* ev_dat, const uint64_t* off1, const uint64_t* off2, char* out1, char* out2, uint32_t* flags,
                   uint64_t cap1, uint64_t cap2,   // writes FASTQ text; cap: bytes of the batch's text in each file (records are checked against it)
-                  const uint32_t* slist1, const uint32_t* slist2, const uint32_t* clist1, const uint32_t* clist2, uint32_t nc1, uint32_t nc2);   // launch_read_lists' lists; nc: reads with indel events per mate
+                  const uint32_t* slist1, const uint32_t* slist2, const uint32_t* clist1, const uint32_t* clist2, uint32_t nc1, uint32_t nc2,
+                  const uint32_t* dlist1, const uint32_t* dlist2, uint32_t nd1, uint32_t nd2);   // launch_read_lists' lists; nc: reads with indel events per mate
 // splits the batch's reads into those without indel events and the rest (cls from launch_indels): ascending pair-index lists per mate
-void launch_read_lists(hipStream_t s, uint32_t np, int paired, const uint32_t* sizes1, const uint64_t* off1, const uint32_t* sizes2, const uint64_t* off2,
-                       uint32_t* slist1, uint32_t* slist2, uint32_t* clist1, uint32_t* clist2);
+void launch_read_lists(hipStream_t s, uint32_t np, int paired, const uint32_t* sizes1, const uint64_t* off1, const uint32_t* d1f1, uint32_t* d1p1,
+                       const uint32_t* sizes2, const uint64_t* off2, const uint32_t* d1f2, uint32_t* d1p2,
+                       uint32_t* slist1, uint32_t* slist2, uint32_t* clist1, uint32_t* clist2, uint32_t* dlist1, uint32_t* dlist2, void* temp, size_t temp_bytes);
 // the indel pass of a batch (n' and events per read, FASTQ record sizes per pair and mate), ahead of launch_reads
 void launch_indels(hipStream_t s, const PairRec* pairs, uint32_t np, int paired, DevTables tb, RngKey key, uint32_t slot, uint32_t* ev_hdr, uint4* ev_dat,
-                   uint32_t* sizes1, uint32_t* sizes2, uint32_t* flags);
+                   uint32_t* sizes1, uint32_t* sizes2, uint32_t* d1f1, uint32_t* d1f2, uint32_t* flags);
 void launch_predict_windows(hipStream_t s, const uint8_t* windows, uint32_t n_reads, const uint64_t* uids, const uint32_t* atts,
                             const uint8_t* is_read1, DevTables tb, const DevTables* d_tb, RngKey key, uint32_t slot, char* slot_b, char* slot_q,
                             uint32_t* lens, uint32_t* flags);

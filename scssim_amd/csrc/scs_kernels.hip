@@ -643,10 +643,13 @@ template <int QK>
 __device__ __noinline__ void redo_read(const uint8_t* __restrict__ g, int64_t gb, uint32_t gf, const uint32_t* __restrict__ spool, const uint32_t* __restrict__ fpool,
                                        uint64_t e1, uint64_t e2, int k1, uint32_t pos, uint32_t isz, uint32_t rd, int n, uint32_t B,
                                        const uint32_t* __restrict__ subs, const double* __restrict__ subs_d, const uint32_t* __restrict__ qalias,
-                                       U4 seed, char* __restrict__ out_b, char* __restrict__ out_q) {
+                                       U4 seed, char* __restrict__ out_b, char* __restrict__ out_q, uint32_t del_pos) {
+    // (del_pos: the one deleted base of a read of the one-deletion class, 0xFFFF for none: n - 1 positions, bins j * n / (n - 1) = j)
     Xoshiro xb; xb.seed(seed);
     uint32_t c0 = 5u, c1 = 5u;
-    for (int t = 0; t < n; ++t) {
+    const int np = del_pos == 0xFFFFu ? n : n - 1;
+    for (int tp = 0; tp < np; ++tp) {
+        const int t = tp + ((uint32_t)tp >= del_pos ? 1 : 0);                      // window base of output position tp
         uint32_t c2 = g[(gf & 2u) ? gb - t : gb + t];
         if ((gf & 1u) && c2 < 4u) c2 = 3u - c2;
         for_each_err(e1, spool, [&](uint32_t e) {
@@ -661,8 +664,8 @@ __device__ __noinline__ void redo_read(const uint8_t* __restrict__ g, int64_t gb
         uint32_t xs, xq; xb.next2(xs, xq);
         uint32_t bc, qc;
         if (ki < 0 && c2 > 3u) { bc = 'N'; qc = 33u + scale_draw(xq, 0, 20); }
-        else { const uint32_t kq = call_global_body<QK>(subs, subs_d, qalias, B, ki, c2, c2, (uint32_t)t, xs, xq); bc = (0x54474341u >> (8u * (kq & 255u))) & 255u; qc = 33u + (kq >> 8); }
-        out_b[t] = (char)bc; out_q[t] = (char)qc;
+        else { const uint32_t kq = call_global_body<QK>(subs, subs_d, qalias, B, ki, c2, c2, (uint32_t)tp, xs, xq); bc = (0x54474341u >> (8u * (kq & 255u))) & 255u; qc = 33u + (kq >> 8); }
+        out_b[tp] = (char)bc; out_q[tp] = (char)qc;
         c0 = c1; c1 = c2;
     }
 }
@@ -722,7 +725,7 @@ __device__ __forceinline__ IndelPass indel_pass(const DevTables& tb, RngKey key,
 //      header {n' | events << 16 | replay << 24 | live << 25} go to global memory.
 __global__ void __launch_bounds__(256) k_indels(const PairRec* __restrict__ pairs, uint32_t np, int paired, const DevTables tb, RngKey key, uint32_t slot,
                                                 uint32_t force_replay, uint32_t* __restrict__ ev_hdr, uint4* __restrict__ ev_dat,
-                                                uint32_t* __restrict__ sizes1, uint32_t* __restrict__ sizes2,
+                                                uint32_t* __restrict__ sizes1, uint32_t* __restrict__ sizes2, uint32_t* __restrict__ d1f1, uint32_t* __restrict__ d1f2,
                                                 uint32_t* __restrict__ flags) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t nreads = paired ? 2 * np : np;
@@ -730,14 +733,18 @@ __global__ void __launch_bounds__(256) k_indels(const PairRec* __restrict__ pair
     const uint32_t pi = paired ? r >> 1 : r, rd = paired ? (r & 1u) : 0u;
     const uint64_t uid = pairs[pi].uid; const uint32_t att = pairs[pi].att, isz = pairs[pi].isz, amp = pairs[pi].amp, has_n = pairs[pi].flags & 4u;
     uint32_t* sz = rd ? sizes2 : sizes1;
-    if (isz == 0) { ev_hdr[r] = 0; sz[pi] = 0; return; }               // hole: the insert-size loop gave up (Amplicon.cpp:484-489)
+    uint32_t* d1f = rd ? d1f2 : d1f1;                                              // 1: the read's only event is the deletion of one base (k_reads' one-deletion walk)
+    if (isz == 0) { ev_hdr[r] = 0; sz[pi] = 0; d1f[pi] = 0; return; }               // hole: the insert-size loop gave up (Amplicon.cpp:484-489)
     unsigned long long e_lo = 0, e_hi = 0;
     const IndelPass ip = indel_pass(tb, key, rd | (att << 1), uid, force_replay, slot, flags, [&](int i, uint32_t v) {
         if (i < 4) e_lo |= (unsigned long long)v << (16 * i); else e_hi |= (unsigned long long)v << (16 * (i - 4));
     });
     ev_hdr[r] = (uint32_t)ip.n_out | ((uint32_t)ip.nev << 16) | (ip.replay ? 1u << 24 : 0u) | (1u << 25);
     ev_dat[r] = make_uint4((uint32_t)e_lo, (uint32_t)(e_lo >> 32), (uint32_t)e_hi, (uint32_t)(e_hi >> 32));
-    const uint32_t cls = (ip.nev > 0 || ip.replay || has_n || (force_replay & 4u)) ? 1u : 0u;            // the uniform walk takes ACGT-only windows without events
+    const uint32_t e0 = (uint32_t)e_lo & 0xFFFFu;
+    const bool d1 = ip.nev == 1 && !ip.replay && !has_n && !(force_replay & 12u) && ev_del(e0) && ev_len(e0) == 1u && ip.n_out == tb.L - 1 && tb.bins == tb.L;
+    d1f[pi] = d1 ? 1u : 0u;
+    const uint32_t cls = ((ip.nev > 0 || ip.replay || has_n || (force_replay & 4u)) && !d1) ? 1u : 0u;   // the uniform walk takes ACGT-only windows without events
     // "@<ampIdx>#<fragCount>[/1|/2]\n" + seq + "\n+\n" + qual + "\n"   (Amplicon.cpp:459-466,497-504)
     sz[pi] = (ip.n_out == 0 ? 0u : 1u + dec_digits(amp) + 1u + dec_digits(att + 1) + (paired ? 2u : 0u) + 1u + 2u * (uint32_t)ip.n_out + 4u) | (cls << 31);   // bit 31: the class rides along into the offsets' scan
 }
@@ -862,7 +869,8 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
                                               uint32_t amp_index_base, char* __restrict__ slot_b, char* __restrict__ slot_q, uint32_t* __restrict__ lens,
                                               uint32_t* __restrict__ flags, uint64_t cap1, uint64_t cap2,
                                               const uint32_t* __restrict__ list1, const uint32_t* __restrict__ list2, uint32_t nlist1, uint32_t nlist2) {
-    constexpr bool SIMPLE = CLS == 1;
+    constexpr bool SIMPLE = CLS == 1 || CLS == 3;                                 // 3: the uniform walk for reads with ONE deletion of ONE base (below)
+    constexpr bool D1 = CLS == 3;
     typedef RingGeo<QK> Geo;
     typedef RingBin<QK> Bin;
     constexpr int SLOTS = Geo::SLOTS, GROUP = Geo::GROUP, QROW = Geo::QROW;
@@ -1036,11 +1044,12 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
     const uint32_t aux = rd | (att << 1);
     LdsU16* my_ev = (LdsU16*)(s_ev + tid * EV_MAX);
     LdsU32* my_xa = (LdsU32*)(s_ev + tid * EV_MAX);                                // the same 16 bytes, as a stream-A state (replayed reads)
-    int nev = 0, n_out = 0; bool replay = false; uint32_t replay_first = 0;
+    int nev = 0, n_out = 0; bool replay = false; uint32_t replay_first = 0, del_pos = 0xFFFFu;
     if (live) {
         if (FROM_PAIRS) {
             const uint32_t h = ev_hdr[r]; const uint4 e = ev_dat[r];
             n_out = (int)(h & 0xFFFFu); nev = SIMPLE ? 0 : (int)((h >> 16) & 0xFFu); replay = SIMPLE ? false : (h >> 24) & 1u;
+            if (D1) del_pos = ev_pos(e.x & 0xFFFFu);                                 // its one event: the deleted base
             if (!UNI) { my_xa[0] = e.x; my_xa[1] = e.y; my_xa[2] = e.z; my_xa[3] = e.w; }   // 8 x 16-bit events
         } else {
             const IndelPass ip = indel_pass(tb, key, aux, uid, force_replay, slot, flags, [&](int i, uint32_t v) { my_ev[i] = (uint16_t)v; });
@@ -1168,8 +1177,13 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
         LdsU8* dummy8 = (LdsU8*)(s_head + 62);
         const bool force_redo = (force_replay & 2u) != 0;
         char* __restrict__ spare = reinterpret_cast<char*>(flags) + 128;               // 32 bytes nobody reads (the flags buffer is 256 bytes)
-        uint32_t wreg = 0, sel = 0, qacc = 0, nbad = 0;
+        uint32_t wreg = 0, wnext = 0, sel = 0, qacc = 0, nbad = 0;
         c0 = 0; c1 = 0;
+        // D1 (CLS 3): the reads with exactly ONE indel event, the deletion of ONE base, run the same walk.  Their n' = L - 1 positions
+        // fall into bins j * L / (L - 1) = j, one step of stream B each; only the source base differs: position j reads window
+        // base j before the deleted base and j + 1 from it on (a shift by one two-bit field, the next dword kept beside the
+        // current one).  NP: the positions of a read of this class.
+        const int NP = D1 ? B - 1 : B;
         // SOFTWARE PIPELINE, one position deep.  The compiler's scheduler waits for an LDS read right where it issues it; here
         // every read gets a stage's worth of independent work before its use.  Step u runs, in this order,
         //   finish_a(u-1): thresholds and alias entry of the previous position are back -> its base k, its alias column -> issue the symbol read
@@ -1181,8 +1195,16 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
         uint32_t bK = 0, bC2 = 0, bX2 = 0, bSym = 0; bool bUgly = false;                                   // finish_a -> finish_b
         auto start = [&](auto U, int t0) __attribute__((always_inline)) {
             constexpr int u = decltype(U)::value;
-            if (u == 0) { wreg = win32[t0 >> 4]; if (!mine) wreg = 0; }            // the block's 16 bases
-            const uint32_t c2 = wreg & 3u; wreg >>= 2;
+            uint32_t c2;
+            if constexpr (D1) {
+                if (u == 0) { wreg = t0 == 0 ? win32[0] : wnext; wnext = win32[(t0 >> 4) + 1]; if (!mine) { wreg = 0; wnext = 0; } }   // 16 bases + the 16 behind them
+                const bool after = (uint32_t)(t0 + u) >= del_pos;                    // from the deleted base on: the next window base
+                if (u < 15) c2 = __builtin_amdgcn_ubfe(wreg, 2u * u + (after ? 2u : 0u), 2u);
+                else c2 = after ? (wnext & 3u) : (wreg >> 30);
+            } else {
+                if (u == 0) { wreg = win32[t0 >> 4]; if (!mine) wreg = 0; }        // the block's 16 bases
+                c2 = wreg & 3u; wreg >>= 2;
+            }
             uint32_t x1, x2; xb.next2(x1, x2);                                       // one step of stream B per position
             const LdsU8* bin8 = ring8 + (u & (SLOTS - 1)) * sizeof(Bin);
             const LdsU8* st8 = bin8 + 4 * QROW * 16 + ((c0 << 4) | (c1 << 2) | c2) * 12u;
@@ -1225,7 +1247,7 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
                 constexpr int u = decltype(U)::value;
                 constexpr int mode = decltype(MODE)::value;
                 const int t = t0 + u;
-                if (mode == 0 && t >= B) return;
+                if (mode == 0 && t >= NP) return;
                 if (u > 0 || t0 > 0) finish_a();
                 if ((u & (GROUP - 1)) == 0 && (u > 0 || t0 > 0)) { commit(t); __syncthreads(); prefetch(t + GROUP); }
                 start(U, t0);
@@ -1246,11 +1268,11 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
             }, std::make_integer_sequence<int, 16>{});
         };
         int t0 = 0;
-        for (; t0 < 48 && t0 + 16 < B; t0 += 16) steps(std::integral_constant<int, 1>{}, t0);
-        for (; t0 + 16 < B; t0 += 16) steps(std::integral_constant<int, 2>{}, t0);
+        for (; t0 < 48 && t0 + 16 < NP; t0 += 16) steps(std::integral_constant<int, 1>{}, t0);
+        for (; t0 + 16 < NP; t0 += 16) steps(std::integral_constant<int, 2>{}, t0);
         steps(std::integral_constant<int, 0>{}, t0);
         finish_a();                                                                 // drain: the read's last position
-        unroll_steps([&](auto U) __attribute__((always_inline)) { if (decltype(U)::value == ((B - 1) & 15)) finish_b(U, B - 1, true); }, std::make_integer_sequence<int, 16>{});
+        unroll_steps([&](auto U) __attribute__((always_inline)) { if (decltype(U)::value == ((NP - 1) & 15)) finish_b(U, NP - 1, true); }, std::make_integer_sequence<int, 16>{});
         redo = mine && nbad != npend;
         if (!mine) npend = 0;
     } else
@@ -1409,7 +1431,7 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
             const int64_t gb = rd == 0 ? pr.base + dir * (int64_t)pr.pos : pr.base + dir * (int64_t)(pr.pos + pr.isz - 1);
             const uint32_t gf = rd == 0 ? (comp | ((dir < 0) ? 2u : 0u)) : ((comp ^ 1u) | ((dir < 0) ? 0u : 2u));
             redo_read<QK>(g, gb, gf, spool.data, fpool.data, pr.e1, pr.e2, pr.k1, pr.pos, pr.isz, rd, n, (uint32_t)B, subs, subs_d, tb.qual_alias,
-                          draw4(key, ST_READ, aux, uid, 1), wg_out + sec1 + a1, wg_out + sec2 + a2);
+                          draw4(key, ST_READ, aux, uid, 1), wg_out + sec1 + a1, wg_out + sec2 + a2, D1 ? del_pos : 0xFFFFu);
         }
     }
     if (live && !FROM_PAIRS) {
@@ -2133,10 +2155,10 @@ size_t reads_lds_bytes(const DevTables& tb, bool uni) {
 }
 template <bool FROM_PAIRS, int CLS, class... Args>
 static void launch_reads_kernel(hipStream_t s, dim3 grid, const DevTables& tb, Args... args) {
-    const size_t lds = reads_lds_bytes(tb, FROM_PAIRS && CLS == 1);
+    const size_t lds = reads_lds_bytes(tb, FROM_PAIRS && (CLS == 1 || CLS == 3));
     // > 64 KB of dynamic LDS needs the opt-in; the limit is raised to exactly what this profile needs (once per size:
     // the call sits on the host's critical path of a small job)
-    static size_t opted_all[64][3] = {};                                           // per device and instantiation (the attribute belongs to the device's code object)
+    static size_t opted_all[64][3] = {};                                           // (static per instantiation <FROM_PAIRS, CLS>)                                           // per device and instantiation (the attribute belongs to the device's code object)
     int dev = 0; (void)hipGetDevice(&dev);
     size_t* opted = opted_all[dev & 63];
 #define SCS_LAUNCH_READS(QKV, SLOT) do { \
@@ -2146,50 +2168,79 @@ static void launch_reads_kernel(hipStream_t s, dim3 grid, const DevTables& tb, A
 #undef SCS_LAUNCH_READS
 }
 static uint32_t reads_force_replay() {                                             // tests: bit 0: every read with an indel takes the replay path;
-    static const uint32_t v = (getenv("SCS_EV_REPLAY") ? 1u : 0u) | (getenv("SCS_TEST_REDO") ? 2u : 0u) | (getenv("SCS_TEST_GENERAL") ? 4u : 0u);   // bit 1: every event-free read with a substitution is redone (redo_read)
+    static const uint32_t v = (getenv("SCS_EV_REPLAY") ? 1u : 0u) | (getenv("SCS_TEST_REDO") ? 2u : 0u) | (getenv("SCS_TEST_GENERAL") ? 4u : 0u) | (getenv("SCS_TEST_NO_D1") ? 8u : 0u);   // bit 1: every event-free read with a substitution is redone (redo_read)
     return v;
 }
 void launch_indels(hipStream_t s, const PairRec* pairs, uint32_t np, int paired, DevTables tb, RngKey key, uint32_t slot, uint32_t* ev_hdr, uint4* ev_dat,
-                   uint32_t* sizes1, uint32_t* sizes2, uint32_t* flags) {
+                   uint32_t* sizes1, uint32_t* sizes2, uint32_t* d1f1, uint32_t* d1f2, uint32_t* flags) {
     if (np == 0) return;
     const uint32_t nreads = paired ? 2 * np : np;
     (void)slot;                                                                    // the FASTQ record takes whatever length the read has (header field: 16 bits)
-    hipLaunchKernelGGL(k_indels, dim3(cdiv(nreads, 256)), dim3(256), 0, s, pairs, np, paired, tb, key, 65535u, reads_force_replay() | (tb.L > 1008 ? 4u : 0u) /* the uniform walk gathers a read with at most 64 lanes */, ev_hdr, ev_dat, sizes1, sizes2, flags);
+    hipLaunchKernelGGL(k_indels, dim3(cdiv(nreads, 256)), dim3(256), 0, s, pairs, np, paired, tb, key, 65535u, reads_force_replay() | (tb.L > 1008 ? 4u : 0u) /* the uniform walk gathers a read with at most 64 lanes */, ev_hdr, ev_dat, sizes1, sizes2, d1f1, d1f2, flags);
 }
 // event-free reads and the rest as two launches over their lists (k_read_lists); the grid of a launch covers the longer of
 // the two mates' lists
 void launch_reads(hipStream_t s, const uint8_t* g, const uint32_t* g2, DevErrPool spool, DevErrPool fpool,
                   const PairRec* pairs, uint32_t np, uint32_t amp_index_base, DevTables tb, const DevTables* d_tb, RngKey key, int paired, uint32_t slot,
                   const uint32_t* ev_hdr, const uint4* ev_dat, const uint64_t* off1, const uint64_t* off2, char* out1, char* out2, uint32_t* flags,
-                  uint64_t cap1, uint64_t cap2, const uint32_t* slist1, const uint32_t* slist2, const uint32_t* clist1, const uint32_t* clist2, uint32_t nc1, uint32_t nc2) {
+                  uint64_t cap1, uint64_t cap2, const uint32_t* slist1, const uint32_t* slist2, const uint32_t* clist1, const uint32_t* clist2, uint32_t nc1, uint32_t nc2,
+                  const uint32_t* dlist1, const uint32_t* dlist2, uint32_t nd1, uint32_t nd2) {
     if (np == 0) return;
     (void)d_tb;
     static const bool shrink = getenv("SCS_TEST_SHRINK_OUT") != nullptr;               // tests: provoke the record-bound guard
     if (shrink) { cap1 /= 2; cap2 /= 2; }
-    const uint32_t ns1 = np - nc1, ns2 = paired ? np - nc2 : 0u;
-    const uint32_t gs = cdiv(std::max(ns1, ns2), RB), gc = cdiv(std::max(nc1, paired ? nc2 : 0u), RB);
+    const uint32_t ns1 = np - nc1 - nd1, ns2 = paired ? np - nc2 - nd2 : 0u;
+    const uint32_t gs = cdiv(std::max(ns1, ns2), RB), gc = cdiv(std::max(nc1, paired ? nc2 : 0u), RB), gd = cdiv(std::max(nd1, paired ? nd2 : 0u), RB);
+    // The three class kernels write disjoint records: the two small ones go to side streams and run BESIDE the big one (each alone
+    // leaves the chip half empty through its first and last wave of workgroups); the caller's stream waits for both.
+    struct Side { hipStream_t st[2] = {nullptr, nullptr}; hipEvent_t fork = nullptr, join[2] = {nullptr, nullptr}; };
+    static Side sides[64];
+    int dev = 0; (void)hipGetDevice(&dev);
+    Side& sd = sides[dev & 63];
+    static const bool serial = getenv("SCS_READS_SERIAL") != nullptr;
+    if (!serial && !sd.fork) {
+        note_launch(hipEventCreateWithFlags(&sd.fork, hipEventDisableTiming));
+        for (int k = 0; k < 2; ++k) { note_launch(hipStreamCreateWithFlags(&sd.st[k], hipStreamNonBlocking)); note_launch(hipEventCreateWithFlags(&sd.join[k], hipEventDisableTiming)); }
+    }
+    hipStream_t s_main = s;
+    hipStream_t s_c = serial ? s : sd.st[0], s_d = serial ? s : sd.st[1];
+    if (!serial && (gc || gd)) { note_launch(hipEventRecord(sd.fork, s_main)); if (gc) note_launch(hipStreamWaitEvent(s_c, sd.fork, 0)); if (gd) note_launch(hipStreamWaitEvent(s_d, sd.fork, 0)); }
+    if (gd) launch_reads_kernel<true, 3>(s_d, dim3(paired ? 2 * gd : gd), tb, g, spool, fpool, pairs, np, paired,
+                              reinterpret_cast<const uint8_t*>(g2), (const uint64_t*)nullptr, (const uint32_t*)nullptr, (const uint8_t*)nullptr, 0u, tb, key, slot,
+                              (uint32_t)(paired ? 2ull * np : np), reads_force_replay(), ev_hdr, ev_dat, off1, off2, out1, out2, amp_index_base,
+                              (char*)nullptr, (char*)nullptr, (uint32_t*)nullptr, flags, cap1, cap2, dlist1, dlist2, nd1, paired ? nd2 : 0u);
     if (gs) launch_reads_kernel<true, 1>(s, dim3(paired ? 2 * gs : gs), tb, g, spool, fpool, pairs, np, paired,
                               reinterpret_cast<const uint8_t*>(g2), (const uint64_t*)nullptr, (const uint32_t*)nullptr, (const uint8_t*)nullptr, 0u, tb, key, slot,
                               (uint32_t)(paired ? 2ull * np : np), reads_force_replay(), ev_hdr, ev_dat, off1, off2, out1, out2, amp_index_base,
                               (char*)nullptr, (char*)nullptr, (uint32_t*)nullptr, flags, cap1, cap2, slist1, slist2, ns1, ns2);
-    if (gc) launch_reads_kernel<true, 2>(s, dim3(paired ? 2 * gc : gc), tb, g, spool, fpool, pairs, np, paired,
+    if (gc) launch_reads_kernel<true, 2>(s_c, dim3(paired ? 2 * gc : gc), tb, g, spool, fpool, pairs, np, paired,
                               (const uint8_t*)nullptr, (const uint64_t*)nullptr, (const uint32_t*)nullptr, (const uint8_t*)nullptr, 0u, tb, key, slot,
                               (uint32_t)(paired ? 2ull * np : np), reads_force_replay(), ev_hdr, ev_dat, off1, off2, out1, out2, amp_index_base,
                               (char*)nullptr, (char*)nullptr, (uint32_t*)nullptr, flags, cap1, cap2, clist1, clist2, nc1, paired ? nc2 : 0u);
+    if (!serial) {
+        if (gc) { note_launch(hipEventRecord(sd.join[0], s_c)); note_launch(hipStreamWaitEvent(s_main, sd.join[0], 0)); }
+        if (gd) { note_launch(hipEventRecord(sd.join[1], s_d)); note_launch(hipStreamWaitEvent(s_main, sd.join[1], 0)); }
+    }
 }
 // the batch's reads split by class (k_indels' flags cls, their exclusive scans cpos): ascending lists of pair indices
-// (class = bit 31 of the record size as k_indels left it; position in the class's list = the scanned offset's bits above OFF_BITS)
-__global__ void k_read_lists(uint32_t np, int paired, const uint32_t* __restrict__ sizes1, const uint64_t* __restrict__ off1, const uint32_t* __restrict__ sizes2,
-                             const uint64_t* __restrict__ off2, uint32_t* __restrict__ slist1, uint32_t* __restrict__ slist2, uint32_t* __restrict__ clist1, uint32_t* __restrict__ clist2) {
+// (general class = bit 31 of the record size as k_indels left it, its list position = the scanned offset's bits above OFF_BITS; the
+// one-deletion class = its flag array and that array's scan; the event-free class takes what is left)
+__global__ void k_read_lists(uint32_t np, int paired, const uint32_t* __restrict__ sizes1, const uint64_t* __restrict__ off1, const uint32_t* __restrict__ d1f1,
+                             const uint32_t* __restrict__ d1p1, const uint32_t* __restrict__ sizes2, const uint64_t* __restrict__ off2, const uint32_t* __restrict__ d1f2,
+                             const uint32_t* __restrict__ d1p2, uint32_t* __restrict__ slist1, uint32_t* __restrict__ slist2, uint32_t* __restrict__ clist1,
+                             uint32_t* __restrict__ clist2, uint32_t* __restrict__ dlist1, uint32_t* __restrict__ dlist2) {
     const uint32_t pi = blockIdx.x * blockDim.x + threadIdx.x;
     if (pi >= np) return;
-    { const uint32_t c = (uint32_t)(off1[pi] >> OFF_BITS); if (sizes1[pi] >> 31) clist1[c] = pi; else slist1[pi - c] = pi; }
-    if (paired) { const uint32_t c = (uint32_t)(off2[pi] >> OFF_BITS); if (sizes2[pi] >> 31) clist2[c] = pi; else slist2[pi - c] = pi; }
+    { const uint32_t c = (uint32_t)(off1[pi] >> OFF_BITS), d = d1p1[pi]; if (sizes1[pi] >> 31) clist1[c] = pi; else if (d1f1[pi]) dlist1[d] = pi; else slist1[pi - c - d] = pi; }
+    if (paired) { const uint32_t c = (uint32_t)(off2[pi] >> OFF_BITS), d = d1p2[pi]; if (sizes2[pi] >> 31) clist2[c] = pi; else if (d1f2[pi]) dlist2[d] = pi; else slist2[pi - c - d] = pi; }
 }
-void launch_read_lists(hipStream_t s, uint32_t np, int paired, const uint32_t* sizes1, const uint64_t* off1, const uint32_t* sizes2, const uint64_t* off2,
-                       uint32_t* slist1, uint32_t* slist2, uint32_t* clist1, uint32_t* clist2) {
+void launch_read_lists(hipStream_t s, uint32_t np, int paired, const uint32_t* sizes1, const uint64_t* off1, const uint32_t* d1f1, uint32_t* d1p1,
+                       const uint32_t* sizes2, const uint64_t* off2, const uint32_t* d1f2, uint32_t* d1p2,
+                       uint32_t* slist1, uint32_t* slist2, uint32_t* clist1, uint32_t* clist2, uint32_t* dlist1, uint32_t* dlist2, void* temp, size_t temp_bytes) {
     if (np == 0) return;
-    hipLaunchKernelGGL(k_read_lists, dim3(cdiv(np, 256)), dim3(256), 0, s, np, paired, sizes1, off1, sizes2, off2, slist1, slist2, clist1, clist2);
+    exclusive_scan_u32(s, d1f1, d1p1, np, temp, temp_bytes);
+    if (paired) exclusive_scan_u32(s, d1f2, d1p2, np, temp, temp_bytes);
+    hipLaunchKernelGGL(k_read_lists, dim3(cdiv(np, 256)), dim3(256), 0, s, np, paired, sizes1, off1, d1f1, d1p1, sizes2, off2, d1f2, d1p2, slist1, slist2, clist1, clist2, dlist1, dlist2);
 }
 void launch_predict_windows(hipStream_t s, const uint8_t* windows, uint32_t n_reads, const uint64_t* uids, const uint32_t* atts,
                             const uint8_t* is_read1, DevTables tb, const DevTables* d_tb, RngKey key, uint32_t slot, char* slot_b, char* slot_q, uint32_t* lens, uint32_t* flags) {

@@ -824,28 +824,31 @@ void do_yield(scs_ctx* c, const OutTarget& tg, uint64_t* n1_out, uint64_t* n2_ou
     c->sizes1.reserve(2 * (batch + 1) * 4, s); c->sizes2.reserve(2 * (batch + 1) * 4, s); c->off1.reserve(2 * (batch + 1) * 8, s); c->off2.reserve(2 * (batch + 1) * 8, s);
     c->scan_tmp.reserve(scan_temp_bytes(batch), s);
     // the reads of a batch split by class (with / without indel events): flags, their scans, four lists of pair indices
-    c->rl_cls.reserve(2 * (batch + 1) * 2 * 4, s); c->rl_pos.reserve(2 * (batch + 1) * 2 * 4, s); c->rl_lists.reserve(2 * batch * 4 * 4, s);
-    struct BatchSet { uint32_t* ev_hdr; uint4* ev_dat; uint32_t *sizes1, *sizes2; uint64_t *off1, *off2; uint32_t *cls1, *cls2, *cpos1, *cpos2, *slist1, *slist2, *clist1, *clist2; } bs[2];
+    c->rl_cls.reserve(2 * (batch + 1) * 2 * 4, s); c->rl_pos.reserve(2 * (batch + 1) * 2 * 4, s); c->rl_lists.reserve(2 * batch * 6 * 4, s);
+    struct BatchSet { uint32_t* ev_hdr; uint4* ev_dat; uint32_t *sizes1, *sizes2; uint64_t *off1, *off2; uint32_t *cls1, *cls2, *cpos1, *cpos2, *slist1, *slist2, *clist1, *clist2, *dlist1, *dlist2; } bs[2];   // cls / cpos: the one-deletion class' flags and their scan
     for (int k = 0; k < 2; ++k) {
         bs[k].ev_hdr = c->ev_hdr.as<uint32_t>() + k * nreads_b; bs[k].ev_dat = c->ev_dat.as<uint4>() + k * nreads_b;
         bs[k].sizes1 = c->sizes1.as<uint32_t>() + k * (batch + 1); bs[k].sizes2 = c->sizes2.as<uint32_t>() + k * (batch + 1);
         bs[k].off1 = c->off1.as<uint64_t>() + k * (batch + 1); bs[k].off2 = c->off2.as<uint64_t>() + k * (batch + 1);
         bs[k].cls1 = c->rl_cls.as<uint32_t>() + k * 2 * (batch + 1); bs[k].cls2 = bs[k].cls1 + batch + 1;
         bs[k].cpos1 = c->rl_pos.as<uint32_t>() + k * 2 * (batch + 1); bs[k].cpos2 = bs[k].cpos1 + batch + 1;
-        bs[k].slist1 = c->rl_lists.as<uint32_t>() + k * 4 * batch; bs[k].slist2 = bs[k].slist1 + batch; bs[k].clist1 = bs[k].slist2 + batch; bs[k].clist2 = bs[k].clist1 + batch;
+        bs[k].slist1 = c->rl_lists.as<uint32_t>() + k * 6 * batch; bs[k].slist2 = bs[k].slist1 + batch; bs[k].clist1 = bs[k].slist2 + batch; bs[k].clist2 = bs[k].clist1 + batch;
+        bs[k].dlist1 = bs[k].clist2 + batch; bs[k].dlist2 = bs[k].dlist1 + batch;
     }
     auto prepass = [&](uint64_t p0, const BatchSet& B) {
         const uint32_t np = (uint32_t)std::min<uint64_t>(batch, P - p0);
         const PairRec* pr = c->pairs.as<PairRec>() + p0;
         // the indel pass fixes every read's length, hence the record sizes and (prefix sums) the record offsets
         c->tm_indels.begin(s);
-        launch_indels(s, pr, np, paired, c->dtb, c->key, slot, B.ev_hdr, B.ev_dat, B.sizes1, B.sizes2, c->flags.as<uint32_t>());
+        launch_indels(s, pr, np, paired, c->dtb, c->key, slot, B.ev_hdr, B.ev_dat, B.sizes1, B.sizes2, B.cls1, B.cls2, c->flags.as<uint32_t>());
         c->tm_indels.end(s);
         c->tm_indels.add_units(np);
         exclusive_scan_sizes(s, B.sizes1, B.off1, np, c->scan_tmp.p, c->scan_tmp.cap);   // byte offsets + positions in the class lists: one scan per mate
         if (paired) exclusive_scan_sizes(s, B.sizes2, B.off2, np, c->scan_tmp.p, c->scan_tmp.cap);
-        launch_read_lists(s, np, paired, B.sizes1, B.off1, B.sizes2, B.off2, B.slist1, B.slist2, B.clist1, B.clist2);
-        Mail m; m.add(B.off1 + np, 8, 0); m.add(paired ? (const void*)(B.off2 + np) : nullptr, 8, 1); mail_post(c, m, true);
+        launch_read_lists(s, np, paired, B.sizes1, B.off1, B.cls1, B.cpos1, B.sizes2, B.off2, B.cls2, B.cpos2, B.slist1, B.slist2, B.clist1, B.clist2, B.dlist1, B.dlist2,
+                          c->scan_tmp.p, c->scan_tmp.cap);
+        Mail m; m.add(B.off1 + np, 8, 0); m.add(paired ? (const void*)(B.off2 + np) : nullptr, 8, 1);
+        m.add(B.cpos1 + np, 4, 2); m.add(paired ? (const void*)(B.cpos2 + np) : nullptr, 4, 3); mail_post(c, m, true);
     };
     uint64_t tot1 = 0, tot2 = 0, pairs_written = 0;
     // shard index: the pair index at which each list segment starts (pair_off at the segment's first amplicon)
@@ -862,7 +865,7 @@ void do_yield(scs_ctx* c, const OutTarget& tg, uint64_t* n1_out, uint64_t* n2_ou
         const PairRec* pr = c->pairs.as<PairRec>() + p0;
         const BatchSet& B = bs[it & 1];
         mail_wait(c);                                                              // this batch's byte and class counts
-        const uint64_t b1 = c->h_rb[0] & OFF_MASK, b2 = c->h_rb[1] & OFF_MASK; const uint32_t nc1 = (uint32_t)(c->h_rb[0] >> OFF_BITS), nc2 = (uint32_t)(c->h_rb[1] >> OFF_BITS);
+        const uint64_t b1 = c->h_rb[0] & OFF_MASK, b2 = c->h_rb[1] & OFF_MASK; const uint32_t nc1 = (uint32_t)(c->h_rb[0] >> OFF_BITS), nc2 = (uint32_t)(c->h_rb[1] >> OFF_BITS), nd1 = (uint32_t)c->h_rb[2], nd2 = (uint32_t)c->h_rb[3];
         if (p0 + batch < P) prepass(p0 + batch, bs[(it + 1) & 1]);                 // the next batch's pre-pass goes in ahead of this batch's base pass
         while (bnext < bpair.size() && bpair[bnext] < p0 + np) {                     // a segment starts inside this batch: its record's byte offset
             uint64_t o1v = 0, o2v = 0; const uint64_t idx = bpair[bnext] - p0;
@@ -889,7 +892,7 @@ void do_yield(scs_ctx* c, const OutTarget& tg, uint64_t* n1_out, uint64_t* n2_ou
         c->tm_reads.begin(s);                                                      // the base pass writes the FASTQ text at the record offsets
         launch_reads(s, c->genome.as<uint8_t>(), c->genome2.as<uint32_t>() + 16, c->semis.pool_view(), c->fulls.pool_view(), pr, np, 0,
                      c->dtb, c->d_tables.as<DevTables>(), c->key, paired, slot, B.ev_hdr, B.ev_dat,
-                     B.off1, B.off2, o1, o2, c->flags.as<uint32_t>(), b1, b2, B.slist1, B.slist2, B.clist1, B.clist2, nc1, nc2);
+                     B.off1, B.off2, o1, o2, c->flags.as<uint32_t>(), b1, b2, B.slist1, B.slist2, B.clist1, B.clist2, nc1, nc2, B.dlist1, B.dlist2, nd1, nd2);
         c->tm_reads.end(s);
         c->tm_reads.add_units(np);
         { const hipError_t le = take_launch_error(); if (le != hipSuccess) throw ScsError(SCS_EDEVICE, std::string("k_reads launch failed: ") + hipGetErrorString(le)); }
