@@ -178,6 +178,8 @@ struct scs_ctx {
     // allocation + reads
     DevBuf weights, read_numbers, pair_off, pairs, odd_before, a_part, a_tp, a_probs, a_quota, a_poff, a_plan, a_crn, a_scratch, a_brow, a_bmap, a_send, a_gath, a_odd; SegMap gmap{}; std::vector<uint32_t> h_read_numbers; uint64_t reads_requested = 0, n_pairs_planned = 0; bool allocated = false;
     DevBuf slot_b, slot_q, lens, ev_hdr, ev_dat, sizes1, sizes2, off1, off2, out1, out2, out1b, out2b, rl_cls, rl_pos, rl_lists; SinkPipe* pipe = nullptr;
+    hipStream_t pre_stream = nullptr; hipEvent_t ev_pre[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr}, ev_plan = nullptr;   // the reads stage's pre-pass on its own stream, beside the previous batch's base pass
+    hipStream_t mail_stream = nullptr;                                             // the stream of the last post (mail_wait watches it)
     hipStream_t copy_stream = nullptr; hipEvent_t ev_made[2] = {nullptr, nullptr};   // sink mode: D2H on its own stream, behind the batch's k_reads
     // sharded single job: collectives supplied by the caller + segment bookkeeping of the local amplicon lists
     scs_allreduce_fn allreduce = nullptr; scs_allgatherv_fn allgatherv = nullptr; void* coll_user = nullptr;
@@ -234,8 +236,9 @@ struct scs_ctx {
 namespace {
 
 // ---- mailbox: device scalars -> pinned host words, no copy and no stream sync (k_mail)
-void mail_post(scs_ctx* c, const Mail& m, bool last) {                            // last: the post the host will wait for
-    launch_mail(c->stream, m.src, m.wd, m.dst, m.n, m.clear, c->d_rb, last ? ++c->mail_seq : 0ull);
+void mail_post(scs_ctx* c, const Mail& m, bool last, hipStream_t st = nullptr) {   // last: the post the host will wait for; st: the ctx stream unless given
+    c->mail_stream = st ? st : c->stream;
+    launch_mail(c->mail_stream, m.src, m.wd, m.dst, m.n, m.clear, c->d_rb, last ? ++c->mail_seq : 0ull);
 }
 void mail_wait(scs_ctx* c) {                                                      // everything posted so far has landed in h_rb
     volatile uint64_t* flag = c->h_rb + MAIL_SEQ_SLOT;
@@ -246,7 +249,7 @@ void mail_wait(scs_ctx* c) {                                                    
         if (*flag == c->mail_seq) break;
         if (spin < 20000) { __builtin_ia32_pause(); continue; }
         if ((spin & 0x3F) == 0) {
-            const hipError_t q = hipStreamQuery(c->stream);
+            const hipError_t q = hipStreamQuery(c->mail_stream ? c->mail_stream : c->stream);
             if (q == hipSuccess) { if (*flag == c->mail_seq) break; throw ScsError(SCS_EDEVICE, "mailbox: stream drained without the expected post"); }
             if (q != hipErrorNotReady) throw ScsError(SCS_EDEVICE, std::string("mailbox: ") + hipGetErrorString(q));
         }
@@ -835,7 +838,22 @@ void do_yield(scs_ctx* c, const OutTarget& tg, uint64_t* n1_out, uint64_t* n2_ou
         bs[k].slist1 = c->rl_lists.as<uint32_t>() + k * 6 * batch; bs[k].slist2 = bs[k].slist1 + batch; bs[k].clist1 = bs[k].slist2 + batch; bs[k].clist2 = bs[k].clist1 + batch;
         bs[k].dlist1 = bs[k].clist2 + batch; bs[k].dlist2 = bs[k].dlist1 + batch;
     }
-    auto prepass = [&](uint64_t p0, const BatchSet& B) {
+    // The pre-pass runs on a stream of its own, BESIDE the previous batch's base pass (it is memory-bound and short, the base pass
+    // compute-bound).  Its buffer set must be free (the base pass two batches back, which read it, is over: ev_free) and the
+    // base pass of its batch starts when the host has seen its mail.  SCS_READS_SERIAL=1: everything on the ctx stream.
+    static const bool serial_pre = getenv("SCS_READS_SERIAL") != nullptr;
+    hipStream_t ps = s; bool free_rec[2] = {false, false};
+    if (!serial_pre) {
+        if (!c->pre_stream) {
+            HIP_OK(hipStreamCreateWithFlags(&c->pre_stream, hipStreamNonBlocking)); HIP_OK(hipEventCreateWithFlags(&c->ev_plan, hipEventDisableTiming));
+            for (int k = 0; k < 2; ++k) { HIP_OK(hipEventCreateWithFlags(&c->ev_pre[k], hipEventDisableTiming)); HIP_OK(hipEventCreateWithFlags(&c->ev_free[k], hipEventDisableTiming)); }
+        }
+        ps = c->pre_stream;
+        HIP_OK(hipEventRecord(c->ev_plan, s)); HIP_OK(hipStreamWaitEvent(ps, c->ev_plan, 0));   // the pair records (and everything before) are made
+    }
+    auto prepass = [&](uint64_t p0, const BatchSet& B, int k) {
+        hipStream_t s = ps;                                                        // (shadows the ctx stream inside the pre-pass)
+        if (ps != c->stream && free_rec[k]) HIP_OK(hipStreamWaitEvent(ps, c->ev_free[k], 0));
         const uint32_t np = (uint32_t)std::min<uint64_t>(batch, P - p0);
         const PairRec* pr = c->pairs.as<PairRec>() + p0;
         // the indel pass fixes every read's length, hence the record sizes and (prefix sums) the record offsets
@@ -848,7 +866,8 @@ void do_yield(scs_ctx* c, const OutTarget& tg, uint64_t* n1_out, uint64_t* n2_ou
         launch_read_lists(s, np, paired, B.sizes1, B.off1, B.cls1, B.cpos1, B.sizes2, B.off2, B.cls2, B.cpos2, B.slist1, B.slist2, B.clist1, B.clist2, B.dlist1, B.dlist2,
                           c->scan_tmp.p, c->scan_tmp.cap);
         Mail m; m.add(B.off1 + np, 8, 0); m.add(paired ? (const void*)(B.off2 + np) : nullptr, 8, 1);
-        m.add(B.cpos1 + np, 4, 2); m.add(paired ? (const void*)(B.cpos2 + np) : nullptr, 4, 3); mail_post(c, m, true);
+        m.add(B.cpos1 + np, 4, 2); m.add(paired ? (const void*)(B.cpos2 + np) : nullptr, 4, 3); mail_post(c, m, true, s);
+        if (ps != c->stream) HIP_OK(hipEventRecord(c->ev_pre[k], ps));
     };
     uint64_t tot1 = 0, tot2 = 0, pairs_written = 0;
     // shard index: the pair index at which each list segment starts (pair_off at the segment's first amplicon)
@@ -859,14 +878,15 @@ void do_yield(scs_ctx* c, const OutTarget& tg, uint64_t* n1_out, uint64_t* n2_ou
         HIP_OK(hipStreamSynchronize(s));
         bpair.assign(v.begin(), v.end()); tg.seg_off1->assign(ALLOC_SLOTS + 1, 0); if (tg.seg_off2) tg.seg_off2->assign(ALLOC_SLOTS + 1, 0);
     }
-    if (P) prepass(0, bs[0]);
+    if (P) prepass(0, bs[0], 0);
     for (uint64_t p0 = 0, it = 0; p0 < P; p0 += batch, ++it) {
         const uint32_t np = (uint32_t)std::min<uint64_t>(batch, P - p0);
         const PairRec* pr = c->pairs.as<PairRec>() + p0;
         const BatchSet& B = bs[it & 1];
         mail_wait(c);                                                              // this batch's byte and class counts
         const uint64_t b1 = c->h_rb[0] & OFF_MASK, b2 = c->h_rb[1] & OFF_MASK; const uint32_t nc1 = (uint32_t)(c->h_rb[0] >> OFF_BITS), nc2 = (uint32_t)(c->h_rb[1] >> OFF_BITS), nd1 = (uint32_t)c->h_rb[2], nd2 = (uint32_t)c->h_rb[3];
-        if (p0 + batch < P) prepass(p0 + batch, bs[(it + 1) & 1]);                 // the next batch's pre-pass goes in ahead of this batch's base pass
+        if (ps != s) HIP_OK(hipStreamWaitEvent(s, c->ev_pre[it & 1], 0));          // (the host has seen the pre-pass' mail already: ordering for the device's sake)
+        if (p0 + batch < P) prepass(p0 + batch, bs[(it + 1) & 1], (int)((it + 1) & 1));   // the next batch's pre-pass starts now, beside this batch's base pass
         while (bnext < bpair.size() && bpair[bnext] < p0 + np) {                     // a segment starts inside this batch: its record's byte offset
             uint64_t o1v = 0, o2v = 0; const uint64_t idx = bpair[bnext] - p0;
             HIP_OK(hipMemcpyAsync(&o1v, B.off1 + idx, 8, hipMemcpyDeviceToHost, s));
@@ -895,6 +915,7 @@ void do_yield(scs_ctx* c, const OutTarget& tg, uint64_t* n1_out, uint64_t* n2_ou
                      B.off1, B.off2, o1, o2, c->flags.as<uint32_t>(), b1, b2, B.slist1, B.slist2, B.clist1, B.clist2, nc1, nc2, B.dlist1, B.dlist2, nd1, nd2);
         c->tm_reads.end(s);
         c->tm_reads.add_units(np);
+        if (ps != s) { HIP_OK(hipEventRecord(c->ev_free[it & 1], s)); free_rec[it & 1] = true; }   // this batch's buffer set is free for the pre-pass after next
         { const hipError_t le = take_launch_error(); if (le != hipSuccess) throw ScsError(SCS_EDEVICE, std::string("k_reads launch failed: ") + hipGetErrorString(le)); }
         if (pp) {
             for (int f = 0; f < 2; ++f) {                                           // per-slot pinned buffers, grown on demand (capacity kept in a 16-byte header)
@@ -994,6 +1015,7 @@ void scs_destroy(scs_ctx* c) {
                       &c->pair_off, &c->pairs, &c->odd_before, &c->a_part, &c->a_tp, &c->a_probs, &c->a_quota, &c->a_poff, &c->a_plan, &c->a_crn, &c->a_scratch, &c->a_brow, &c->a_bmap, &c->a_send, &c->a_gath, &c->a_odd, &c->d_hostred, &c->d_tot, &c->d_stage, &c->d_mail, &c->budget_f, &c->budget_s, &c->poisson_part, &c->slot_off_f,
                       &c->slot_off_s, &c->dsums, &c->slot_b, &c->slot_q, &c->lens, &c->ev_hdr, &c->ev_dat, &c->sizes1, &c->sizes2, &c->off1, &c->off2, &c->out1, &c->out2, &c->out1b, &c->out2b, &c->rl_cls, &c->rl_pos, &c->rl_lists}) b->release();
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    if (c->pre_stream) { (void)hipStreamDestroy(c->pre_stream); (void)hipEventDestroy(c->ev_plan); for (int k = 0; k < 2; ++k) { (void)hipEventDestroy(c->ev_pre[k]); (void)hipEventDestroy(c->ev_free[k]); } }
     for (int k = 0; k < 2; ++k) if (c->ev_made[k]) (void)hipEventDestroy(c->ev_made[k]);
     c->semis.release(); c->fulls.release();
     for (KernelTimer* t : {&c->tm_errscan, &c->tm_errscan_f, &c->tm_reads, &c->tm_attach, &c->tm_indels, &c->tm_attach_f}) t->release();
