@@ -545,7 +545,15 @@ __global__ void k_plan_pairs(DevFrags fr, DevAmps semis, DevAmps fulls, uint32_t
 //         whole 32-byte aligned sectors (BlockOut); the workgroup's reads are handed to its lanes ordered by the sector
 //         phase of their records, so that the lanes of a wave cross sector boundaries together.  Explicit-window mode
 //         writes sequence/quality slots.
-//     LDS per workgroup at L = 150: 13-16 KB ring + 4 KB events + 19 KB windows -> 4 workgroups per CU.
+//     Three instantiations per batch in pair mode (CLS; lists from k_indels + k_read_lists), launched side by side:
+//       1  reads without indel events in fragments without a non-ACGT base: the UNIFORM WALK -- position t at bin t, one
+//          step of stream B per position, windows from the two-bit genome, straight-line code unrolled by 16 positions
+//          with a one-position software pipeline, substituted bases' qualities set aside in LDS (redo_read when that
+//          runs out of room);
+//       3  the same walk for reads whose only event is the deletion of one base (n' = L - 1: bins j L / (L - 1) = j);
+//       2  everything else: the general loop described above.  (0: explicit-window mode, the general loop.)
+//     LDS per workgroup at L = 150: 16 KB ring + 15 KB rows (uniform walks) / 4 KB events + 19 KB windows (general)
+//     -> 4 workgroups per CU.
 // ------------------------------------------------------------------------------------------------
 #define RB 256
 #define EV_MAX 8
