@@ -327,8 +327,8 @@ def main():
         if dom in ("k_reads", "k_indels"):
             # per pair: insert-size template bytes (mean 261 at -s 260) + the FASTQ bytes of both records; the
             # indel pass alone: the pair record read + 20 B per read written
-            alg = (261.0 * kd["units"] + fq_bytes) if dom == "k_reads" else (64.0 + 2 * 20.0 + 8.0) * kd["units"]
-            note = ("(261 B template + FASTQ bytes of both records) x %d pairs over %d launches" if dom == "k_reads" else "(64 B pair record + 2 x 20 B events + 8 B sizes) x %d pairs over %d launches") % (kd["units"], kd["launches"])
+            alg = (261.0 * kd["units"] + fq_bytes) if dom == "k_reads" else (56.0 + 2 * 20.0 + 8.0) * kd["units"]
+            note = ("(261 B template + FASTQ bytes of both records) x %d pairs over %d launches" if dom == "k_reads" else "(56 B pair record + 2 x 20 B events + 8 B sizes) x %d pairs over %d launches") % (kd["units"], kd["launches"])
             draws = 4.0 * L * kd["units"] if dom == "k_reads" else 2.0 * L * kd["units"]
             draws_note = "k_reads: 2 draws (substitution, quality) per output base x 2 mates" if dom == "k_reads" else "k_indels: 1 draw per input base x 2 mates"
             survey_alg = None
@@ -385,9 +385,9 @@ def main():
             "stages_s_per_step": {k: v / a.steps for k, v in stage.items()},
             "kernels_ms_per_step": {k: v["ms"] / a.steps for k, v in ktimes.items()},
             "setup_s": {"genome_generated_in_hbm": t_gen, "genome_staged_(encode+bit_index)": t_up},
-            # whole job against HBM: the implementation's compulsory bytes (68 B per amplicon, 64 B pair record written + read,
+            # whole job against HBM: the implementation's compulsory bytes (68 B per amplicon, 56 B pair record written + read,
             # 40 B events, 261 B template + FASTQ per pair); SURVEY 8(d)'s model (1526 B per amplicon) beside it
-            "whole_job_GBps": {"compulsory": (68.0 * amps_all + (261.0 + 168.0) * pairs_total + fq_bytes_all) / elapsed / 1e9,
+            "whole_job_GBps": {"compulsory": (68.0 * amps_all + (261.0 + 152.0) * pairs_total + fq_bytes_all) / elapsed / 1e9,
                                "survey_8d_model": (1526.0 * amps_all + 261.0 * pairs_total + fq_bytes_all) / elapsed / 1e9},
         }
         if world == 1 and not a.no_extra_legs:

@@ -106,13 +106,12 @@ enum DevFlag : uint32_t { FLAG_ERRCAP = 1, FLAG_ERRPOOL = 2, FLAG_READSLOT = 4, 
 
 // one planned read pair (or SE read) with its amplicon already resolved to an index map into the genome:
 // U[t] = maybe_comp(G[base + dir*t]) patched by the semi's errors (at t = k1 - pos(e), value comp(alt))
-// and then the full amplicon's own (at t = pos(e), value alt).  64 bytes = one cache line per pair.
+// and then the full amplicon's own (at t = pos(e), value alt).  56 bytes per pair.
 struct PairRec {
     uint32_t amp, att, pos, isz;      // isz == 0: hole
-    int64_t  base; uint32_t flags;    // flags: bit0 complement, bit1 direction is -1
+    int64_t  base; uint32_t flags;    // flags: bit0 complement, bit1 direction is -1, bit2 the fragment holds a non-ACGT base
     int32_t  k1;                      // l_semi - 1 - spos_full
     uint64_t e1, e2, uid;             // error words of the semi / the full amplicon; lineage uid
-    uint64_t pad;
 };
 
 // ---- launch wrappers (scs_kernels.hip) --------------------------------------------------------------

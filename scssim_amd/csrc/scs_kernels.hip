@@ -508,7 +508,7 @@ __global__ void k_plan_pairs(DevFrags fr, DevAmps semis, DevAmps fulls, uint32_t
     for (uint32_t k = 0; k < gmap.n; ++k) if (i - gmap.lo[k] < gmap.cnt[k]) { r.amp = (uint32_t)(gmap.go[k] + (i - gmap.lo[k])); break; }
     r.base = uv.base; r.k1 = (int32_t)(l1 - 1 - s2);
     r.flags = (uv.comp & 1u) | (uv.dir < 0 ? 2u : 0u) | (fr.has_n[f] ? 4u : 0u);   // bit 2: the fragment holds a non-ACGT base
-    r.e1 = semis.errs[sm]; r.e2 = fulls.errs[i]; r.uid = fulls.uid[i]; r.pad = 0;
+    r.e1 = semis.errs[sm]; r.e2 = fulls.errs[i]; r.uid = fulls.uid[i];
     uint32_t made = 0;
     if (amp_len >= L) {
         uint32_t att = 0, fails = 0;
