@@ -828,13 +828,13 @@ void do_yield(scs_ctx* c, const OutTarget& tg, uint64_t* n1_out, uint64_t* n2_ou
     c->scan_tmp.reserve(scan_temp_bytes(batch), s);
     // the reads of a batch split by class (with / without indel events): flags, their scans, four lists of pair indices
     c->rl_cls.reserve(2 * (batch + 1) * 2 * 4, s); c->rl_pos.reserve(2 * (batch + 1) * 2 * 4, s); c->rl_lists.reserve(2 * batch * 6 * 4, s);
-    struct BatchSet { uint32_t* ev_hdr; uint4* ev_dat; uint32_t *sizes1, *sizes2; uint64_t *off1, *off2; uint32_t *cls1, *cls2, *cpos1, *cpos2, *slist1, *slist2, *clist1, *clist2, *dlist1, *dlist2; } bs[2];   // cls / cpos: the one-deletion class' flags and their scan
+    struct BatchSet { uint32_t* ev_hdr; uint4* ev_dat; uint32_t *sizes1, *sizes2; uint64_t *off1, *off2; uint32_t *d1f1, *d1f2, *d1p1, *d1p2, *slist1, *slist2, *clist1, *clist2, *dlist1, *dlist2; } bs[2];   // d1f / d1p: the one-deletion class' flags and their scan
     for (int k = 0; k < 2; ++k) {
         bs[k].ev_hdr = c->ev_hdr.as<uint32_t>() + k * nreads_b; bs[k].ev_dat = c->ev_dat.as<uint4>() + k * nreads_b;
         bs[k].sizes1 = c->sizes1.as<uint32_t>() + k * (batch + 1); bs[k].sizes2 = c->sizes2.as<uint32_t>() + k * (batch + 1);
         bs[k].off1 = c->off1.as<uint64_t>() + k * (batch + 1); bs[k].off2 = c->off2.as<uint64_t>() + k * (batch + 1);
-        bs[k].cls1 = c->rl_cls.as<uint32_t>() + k * 2 * (batch + 1); bs[k].cls2 = bs[k].cls1 + batch + 1;
-        bs[k].cpos1 = c->rl_pos.as<uint32_t>() + k * 2 * (batch + 1); bs[k].cpos2 = bs[k].cpos1 + batch + 1;
+        bs[k].d1f1 = c->rl_cls.as<uint32_t>() + k * 2 * (batch + 1); bs[k].d1f2 = bs[k].d1f1 + batch + 1;
+        bs[k].d1p1 = c->rl_pos.as<uint32_t>() + k * 2 * (batch + 1); bs[k].d1p2 = bs[k].d1p1 + batch + 1;
         bs[k].slist1 = c->rl_lists.as<uint32_t>() + k * 6 * batch; bs[k].slist2 = bs[k].slist1 + batch; bs[k].clist1 = bs[k].slist2 + batch; bs[k].clist2 = bs[k].clist1 + batch;
         bs[k].dlist1 = bs[k].clist2 + batch; bs[k].dlist2 = bs[k].dlist1 + batch;
     }
@@ -858,15 +858,15 @@ void do_yield(scs_ctx* c, const OutTarget& tg, uint64_t* n1_out, uint64_t* n2_ou
         const PairRec* pr = c->pairs.as<PairRec>() + p0;
         // the indel pass fixes every read's length, hence the record sizes and (prefix sums) the record offsets
         c->tm_indels.begin(s);
-        launch_indels(s, pr, np, paired, c->dtb, c->key, slot, B.ev_hdr, B.ev_dat, B.sizes1, B.sizes2, B.cls1, B.cls2, c->flags.as<uint32_t>());
+        launch_indels(s, pr, np, paired, c->dtb, c->key, slot, B.ev_hdr, B.ev_dat, B.sizes1, B.sizes2, B.d1f1, B.d1f2, c->flags.as<uint32_t>());
         c->tm_indels.end(s);
         c->tm_indels.add_units(np);
         exclusive_scan_sizes(s, B.sizes1, B.off1, np, c->scan_tmp.p, c->scan_tmp.cap);   // byte offsets + positions in the class lists: one scan per mate
         if (paired) exclusive_scan_sizes(s, B.sizes2, B.off2, np, c->scan_tmp.p, c->scan_tmp.cap);
-        launch_read_lists(s, np, paired, B.sizes1, B.off1, B.cls1, B.cpos1, B.sizes2, B.off2, B.cls2, B.cpos2, B.slist1, B.slist2, B.clist1, B.clist2, B.dlist1, B.dlist2,
+        launch_read_lists(s, np, paired, B.sizes1, B.off1, B.d1f1, B.d1p1, B.sizes2, B.off2, B.d1f2, B.d1p2, B.slist1, B.slist2, B.clist1, B.clist2, B.dlist1, B.dlist2,
                           c->scan_tmp.p, c->scan_tmp.cap);
         Mail m; m.add(B.off1 + np, 8, 0); m.add(paired ? (const void*)(B.off2 + np) : nullptr, 8, 1);
-        m.add(B.cpos1 + np, 4, 2); m.add(paired ? (const void*)(B.cpos2 + np) : nullptr, 4, 3); mail_post(c, m, true, s);
+        m.add(B.d1p1 + np, 4, 2); m.add(paired ? (const void*)(B.d1p2 + np) : nullptr, 4, 3); mail_post(c, m, true, s);
         if (ps != c->stream) HIP_OK(hipEventRecord(c->ev_pre[k], ps));
     };
     uint64_t tot1 = 0, tot2 = 0, pairs_written = 0;
