@@ -483,7 +483,9 @@ __global__ void k_weights(DevAmps fulls, uint32_t n, DevTables tb, RngKey key, u
 // K4a  plan pairs: one thread per full amplicon runs the attempt loop of Amplicon::yieldReads
 //      (Amplicon.cpp:448-491): insert size, rejection, position.
 // ------------------------------------------------------------------------------------------------
-__global__ void k_plan_pairs(DevFrags fr, DevAmps semis, DevAmps fulls, uint32_t n_fulls, const uint32_t* __restrict__ read_numbers,
+// (amplicons [first, first + n_fulls): the reads stage plans a batch's pairs right before the batch's pre-pass.  An amplicon
+// whose pairs straddle two batches is planned by both -- the same records twice -- and its holes are counted by the first)
+__global__ void k_plan_pairs(DevFrags fr, DevAmps semis, DevAmps fulls, uint32_t first, uint32_t n_fulls, uint32_t pair_lo, const uint32_t* __restrict__ read_numbers,
                              const uint32_t* __restrict__ pair_off, const SegMap gmap, DevTables tb, RngKey key, int paired,
                              PairRec* __restrict__ pairs, unsigned long long* __restrict__ holes) {
     // the insert-size thresholds (a few hundred) go to LDS: the lookup is a nine-step bisection per attempt, and from global
@@ -493,8 +495,9 @@ __global__ void k_plan_pairs(DevFrags fr, DevAmps semis, DevAmps fulls, uint32_t
     const bool isz_lds = n_isz <= 1024u;
     if (isz_lds) for (uint32_t k = threadIdx.x; k < n_isz; k += blockDim.x) s_isz[k] = tb.isize_t[k];
     __syncthreads();
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_fulls) return;
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_fulls) return;
+    const uint32_t i = first + j;
     int n = (int)read_numbers[i];
     if (n == 0) return;
     const uint32_t want = pair_off[i + 1] - pair_off[i];
@@ -526,7 +529,7 @@ __global__ void k_plan_pairs(DevFrags fr, DevAmps semis, DevAmps fulls, uint32_t
     }
     r.att = 0; r.pos = 0; r.isz = 0;
     for (uint32_t q = made; q < want; ++q) dst[q] = r;                             // holes
-    if (made < want) atomicAdd(holes, (unsigned long long)(want - made));          // rare: the host reports pairs produced = planned - holes
+    if (made < want && pair_off[i] >= pair_lo) atomicAdd(holes, (unsigned long long)(want - made));   // rare: the host reports pairs produced = planned - holes
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2147,10 +2150,23 @@ void launch_weights(hipStream_t s, DevAmps fulls, uint32_t n, DevTables tb, RngK
     if (n == 0) return;
     hipLaunchKernelGGL(k_weights, dim3(cdiv(n, 256)), dim3(256), 0, s, fulls, n, tb, key, frag_size, w);
 }
-void launch_plan_pairs(hipStream_t s, DevFrags fr, DevAmps semis, DevAmps fulls, uint32_t n_fulls, const uint32_t* read_numbers, const uint32_t* pair_off,
-                       SegMap gmap, DevTables tb, RngKey key, int paired, PairRec* pairs, unsigned long long* holes) {
+void launch_plan_pairs(hipStream_t s, DevFrags fr, DevAmps semis, DevAmps fulls, uint32_t first, uint32_t n_fulls, uint32_t pair_lo, const uint32_t* read_numbers,
+                       const uint32_t* pair_off, SegMap gmap, DevTables tb, RngKey key, int paired, PairRec* pairs, unsigned long long* holes) {
     if (n_fulls == 0) return;
-    hipLaunchKernelGGL(k_plan_pairs, dim3(cdiv(n_fulls, 256)), dim3(256), 0, s, fr, semis, fulls, n_fulls, read_numbers, pair_off, gmap, tb, key, paired, pairs, holes);
+    hipLaunchKernelGGL(k_plan_pairs, dim3(cdiv(n_fulls, 256)), dim3(256), 0, s, fr, semis, fulls, first, n_fulls, pair_lo, read_numbers, pair_off, gmap, tb, key, paired, pairs, holes);
+}
+// bounds[b] = the amplicon that holds pair b * batch (the first i with pair_off[i + 1] > b * batch), b = 0 .. nb; bounds[nb] = ac
+__global__ void k_batch_bounds(const uint32_t* __restrict__ pair_off, uint32_t ac, unsigned long long batch, uint32_t nb, uint32_t* __restrict__ bounds) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b > nb) return;
+    if (b == nb) { bounds[b] = ac; return; }
+    const unsigned long long p = (unsigned long long)b * batch;
+    uint32_t lo = 0, hi = ac;                                                        // first i in [0, ac) with pair_off[i + 1] > p
+    while (lo < hi) { const uint32_t mid = lo + (hi - lo) / 2; if (pair_off[mid + 1] > p) hi = mid; else lo = mid + 1; }
+    bounds[b] = lo;
+}
+void launch_batch_bounds(hipStream_t s, const uint32_t* pair_off, uint32_t ac, unsigned long long batch, uint32_t nb, uint32_t* bounds) {
+    hipLaunchKernelGGL(k_batch_bounds, dim3(cdiv(nb + 1, 256)), dim3(256), 0, s, pair_off, ac, batch, nb, bounds);
 }
 void launch_pair_offsets(hipStream_t s, const uint32_t* rn, uint32_t ac, int paired, uint32_t* pair_cnt_off, void* temp, size_t temp_bytes) {
     if (paired) (void)rocprim::exclusive_scan(temp, temp_bytes, rocprim::make_transform_iterator(rn, HalfUp()), pair_cnt_off, 0u, (size_t)ac + 1, rocprim::plus<uint32_t>(), s);

@@ -177,7 +177,7 @@ struct scs_ctx {
     DevBuf slots, slot_tmpl, valid, valid_off, valid_f, valid_off_f, scan_tmp, flags;
     // allocation + reads
     DevBuf weights, read_numbers, pair_off, pairs, odd_before, a_part, a_tp, a_probs, a_quota, a_poff, a_plan, a_crn, a_scratch, a_brow, a_bmap, a_send, a_gath, a_odd; SegMap gmap{}; std::vector<uint32_t> h_read_numbers; uint64_t reads_requested = 0, n_pairs_planned = 0; bool allocated = false;
-    DevBuf slot_b, slot_q, lens, ev_hdr, ev_dat, sizes1, sizes2, off1, off2, out1, out2, out1b, out2b, rl_cls, rl_pos, rl_lists; SinkPipe* pipe = nullptr;
+    DevBuf slot_b, slot_q, lens, ev_hdr, ev_dat, sizes1, sizes2, off1, off2, out1, out2, out1b, out2b, rl_cls, rl_pos, rl_lists, d_bounds; SinkPipe* pipe = nullptr;
     hipStream_t pre_stream = nullptr; hipEvent_t ev_pre[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr}, ev_plan = nullptr;   // the reads stage's pre-pass on its own stream, beside the previous batch's base pass
     hipStream_t mail_stream = nullptr;                                             // the stream of the last post (mail_wait watches it)
     hipStream_t copy_stream = nullptr; hipEvent_t ev_made[2] = {nullptr, nullptr};   // sink mode: D2H on its own stream, behind the batch's k_reads
@@ -804,13 +804,20 @@ void do_yield(scs_ctx* c, const OutTarget& tg, uint64_t* n1_out, uint64_t* n2_ou
     const uint32_t L = (uint32_t)c->prof.read_length, slot = ((L + 64 + 63) / 64) * 64;
     c->pairs.reserve(std::max<size_t>(P * sizeof(PairRec), 16), s);
     HIP_OK(hipMemsetAsync(c->dsums.as<unsigned long long>() + DS_HOLES, 0, 8, s));
-    launch_plan_pairs(s, c->frags_view(), c->semis.view(), c->fulls.view(), c->fulls.n, c->read_numbers.as<uint32_t>(), c->pair_off.as<uint32_t>(), c->gmap, c->dtb, c->key, paired, c->pairs.as<PairRec>(),
-                      c->dsums.as<unsigned long long>() + DS_HOLES);
     const bool to_sink = !tg.device && tg.sink;
     // pairs per batch: 8 M with the text staying in HBM (5 GB of text per batch: the base pass' grids are long enough for their tails and
     // the per-batch pre-pass not to matter: 2 M -> 8 M gave -11 % on the stage), 512 k towards a sink (pinned double buffers)
     static const int batch_shift = getenv("SCS_TEST_BATCH_SHIFT") ? atoi(getenv("SCS_TEST_BATCH_SHIFT")) : 0;   // tests: many small batches
     const uint64_t batch = std::min<uint64_t>(std::max<uint64_t>(P, 1), batch_shift ? (1ull << batch_shift) : to_sink ? (1ull << 19) : (1ull << 23));
+    // The pairs are planned (k_plan_pairs: insert sizes, positions, the amplicon resolved to an index map) batch by batch, at the
+    // head of each batch's pre-pass: bounds[b] = the amplicon that holds the batch's first pair.
+    const uint32_t nbatch = (uint32_t)((P + batch - 1) / batch);
+    std::vector<uint32_t> bounds(nbatch + 1, 0);
+    if (P) {
+        c->d_bounds.reserve(((size_t)nbatch + 1) * 4, s);
+        launch_batch_bounds(s, c->pair_off.as<uint32_t>(), c->fulls.n, batch, nbatch, c->d_bounds.as<uint32_t>());
+        HIP_OK(hipMemcpyAsync(bounds.data(), c->d_bounds.p, ((size_t)nbatch + 1) * 4, hipMemcpyDeviceToHost, s)); HIP_OK(hipStreamSynchronize(s));
+    }
     struct PipeGuard { SinkPipe* p; ~PipeGuard() { if (p) (void)p->finish(); } } guard{nullptr};
     if (to_sink) {
         if (!c->pipe) { c->pipe = new SinkPipe; HIP_OK(hipEventCreateWithFlags(&c->pipe->ev[0], hipEventDisableTiming)); HIP_OK(hipEventCreateWithFlags(&c->pipe->ev[1], hipEventDisableTiming)); }
@@ -856,6 +863,11 @@ void do_yield(scs_ctx* c, const OutTarget& tg, uint64_t* n1_out, uint64_t* n2_ou
         if (ps != c->stream && free_rec[k]) HIP_OK(hipStreamWaitEvent(ps, c->ev_free[k], 0));
         const uint32_t np = (uint32_t)std::min<uint64_t>(batch, P - p0);
         const PairRec* pr = c->pairs.as<PairRec>() + p0;
+        {   // this batch's pair records: its amplicons, the one that straddles the next batch's start included
+            const uint32_t b = (uint32_t)(p0 / batch), a_lo = bounds[b], a_hi = std::min<uint32_t>(c->fulls.n, bounds[b + 1] + 1u);
+            launch_plan_pairs(s, c->frags_view(), c->semis.view(), c->fulls.view(), a_lo, a_hi - a_lo, (uint32_t)p0, c->read_numbers.as<uint32_t>(), c->pair_off.as<uint32_t>(),
+                              c->gmap, c->dtb, c->key, paired, c->pairs.as<PairRec>(), c->dsums.as<unsigned long long>() + DS_HOLES);
+        }
         // the indel pass fixes every read's length, hence the record sizes and (prefix sums) the record offsets
         c->tm_indels.begin(s);
         launch_indels(s, pr, np, paired, c->dtb, c->key, slot, B.ev_hdr, B.ev_dat, B.sizes1, B.sizes2, B.d1f1, B.d1f2, c->flags.as<uint32_t>());
@@ -1013,7 +1025,7 @@ void scs_destroy(scs_ctx* c) {
                       &c->d_isize, &c->d_gcmeans, &c->genome, &c->genome2, &c->gx_gc_bits, &c->gx_n_bits, &c->gx_gc_cnt, &c->gx_n_cnt, &c->gx_gc_pref, &c->gx_n_pref, &c->d_binom, &c->df_blob, &c->df_primers, &c->df_hasn, &c->primer_cnt, &c->primer_delta,
                       &c->slots, &c->slot_tmpl, &c->valid, &c->valid_off, &c->valid_f, &c->valid_off_f, &c->scan_tmp, &c->flags, &c->weights, &c->read_numbers,
                       &c->pair_off, &c->pairs, &c->odd_before, &c->a_part, &c->a_tp, &c->a_probs, &c->a_quota, &c->a_poff, &c->a_plan, &c->a_crn, &c->a_scratch, &c->a_brow, &c->a_bmap, &c->a_send, &c->a_gath, &c->a_odd, &c->d_hostred, &c->d_tot, &c->d_stage, &c->d_mail, &c->budget_f, &c->budget_s, &c->poisson_part, &c->slot_off_f,
-                      &c->slot_off_s, &c->dsums, &c->slot_b, &c->slot_q, &c->lens, &c->ev_hdr, &c->ev_dat, &c->sizes1, &c->sizes2, &c->off1, &c->off2, &c->out1, &c->out2, &c->out1b, &c->out2b, &c->rl_cls, &c->rl_pos, &c->rl_lists}) b->release();
+                      &c->slot_off_s, &c->dsums, &c->slot_b, &c->slot_q, &c->lens, &c->ev_hdr, &c->ev_dat, &c->sizes1, &c->sizes2, &c->off1, &c->off2, &c->out1, &c->out2, &c->out1b, &c->out2b, &c->rl_cls, &c->rl_pos, &c->rl_lists, &c->d_bounds}) b->release();
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->pre_stream) { (void)hipStreamDestroy(c->pre_stream); (void)hipEventDestroy(c->ev_plan); for (int k = 0; k < 2; ++k) { (void)hipEventDestroy(c->ev_pre[k]); (void)hipEventDestroy(c->ev_free[k]); } }
     for (int k = 0; k < 2; ++k) if (c->ev_made[k]) (void)hipEventDestroy(c->ev_made[k]);
