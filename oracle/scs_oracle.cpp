@@ -430,7 +430,9 @@ Profile* load_profile(const std::string& path, bool paired, int isize) {
             }
             maxs = std::max(maxs, sym[row].size());
         }
-        const int K = maxs <= 16 ? 16 : maxs <= 64 ? 64 : 128, abits = K == 16 ? 4 : K == 64 ? 6 : 7;
+        int K = maxs <= 16 ? 16 : maxs <= 64 ? 64 : 128;
+        if (const char* f = getenv("SCS_TEST_QK")) K = std::max(K, atoi(f) >= 128 ? 128 : atoi(f) >= 64 ? 64 : 16);   // tests: more columns than needed (the 128-column kernels; the product reads the same variable)
+        const int abits = K == 16 ? 4 : K == 64 ? 6 : 7;
         const uint64_t C = (1ull << 32) / (uint64_t)K; const size_t RW = (size_t)K + K / 4;
         P->qualK = K; P->qualAlias.assign((size_t)16 * Bq * RW, 0u);
         for (size_t row = 0; row < (size_t)16 * Bq; ++row) {

@@ -219,6 +219,7 @@ void load_profile(const std::string& path, bool paired, int isize, ProfileTables
         std::vector<uint8_t> sym((size_t)16 * B * 94); std::vector<uint64_t> w((size_t)16 * B * 94); std::vector<int> ns((size_t)16 * B); int max_syms = 1;
         for (size_t row = 0; row < (size_t)16 * B; ++row) { ns[row] = quality_row_weights(&T.qual[row * 94], &sym[row * 94], &w[row * 94]); max_syms = std::max(max_syms, ns[row]); }
         T.qual_k = max_syms <= 16 ? 16 : max_syms <= 64 ? 64 : 128;
+        if (const char* f = getenv("SCS_TEST_QK")) T.qual_k = std::max(T.qual_k, atoi(f) >= 128 ? 128 : atoi(f) >= 64 ? 64 : 16);   // tests: more columns than needed (no shipped model needs the 128-column kernels; the oracle reads the same variable)
         const size_t RW = (size_t)T.qual_k + T.qual_k / 4;
         T.qual_alias.assign((size_t)16 * B * RW, 0u);
         for (size_t row = 0; row < (size_t)16 * B; ++row) quality_alias_row(&sym[row * 94], &w[row * 94], ns[row], T.qual_k, &T.qual_alias[row * RW]);

@@ -579,6 +579,20 @@ def test_replayed_indel_reads_match_oracle(models, tmp_path):
     assert r.returncode == 0, r.stdout[-3000:]
 
 
+@pytest.mark.parametrize("qk", ["64", "128"])
+def test_wider_alias_rows_match_oracle(qk, models, tmp_path):
+    """k_reads is instantiated for quality alias rows of 16, 64 and 128 columns; a model gets the smallest that holds its most
+    varied row, and no shipped model needs 128.  SCS_TEST_QK makes the table builder (and the oracle's) use at least that many
+    columns, so the wider instantiations run the same parity checks (child processes: the tables are built once per process)."""
+    if os.environ.get("SCS_TEST_QK"):
+        pytest.skip("already inside the wide-row run")
+    env = dict(os.environ, SCS_TEST_QK=qk)
+    sel = ["tests/test_gpu_parity.py::test_full_pipeline_fastq_bit_exact", "tests/test_gpu_parity.py::test_predict_batch_matches_oracle"]
+    r = subprocess.run(["python", "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider"] + sel, cwd=ROOT, env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:]
+
+
 def test_many_small_batches_match_oracle(models, tmp_path):
     """The read stage works batch by batch (8 M pairs with the text staying in HBM, 512 k towards a sink), the next batch's
     pre-pass queued ahead of the current base pass into a second set of buffers.  The parity cases fit one batch, so they run once
