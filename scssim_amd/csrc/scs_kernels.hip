@@ -977,7 +977,7 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
             // base) and borrows lane j + 1's word for the funnel shift to the window's bit offset -- so one load instruction
             // serves 64 / (W2 + 1) reads (5 at L = 150).  Backwards: the 16 bases are reversed in the dword; complement: ~.
             const uint32_t* __restrict__ g2 = reinterpret_cast<const uint32_t*>(windows);   // pair mode: the `windows` argument carries the two-bit genome
-            const int W2 = (n + 15) >> 4, LPR = W2 + 1, RPI = WAVE / LPR;
+            const int W2 = (n + 15) >> 4, LPR = W2 + 1, RPI = LPR <= WAVE ? WAVE / LPR : 1;   // (L <= 1008: the host sends longer reads to the general variant)
             const int r5 = lane / LPR, j = lane - r5 * LPR;
             for (int i0 = 0; i0 < WAVE; i0 += RPI) {
                 const int rq = i0 + r5; const bool on = r5 < RPI && rq < WAVE;
@@ -2214,7 +2214,9 @@ void launch_reads(hipStream_t s, const uint8_t* g, const uint32_t* g2, DevErrPoo
     static const bool shrink = getenv("SCS_TEST_SHRINK_OUT") != nullptr;               // tests: provoke the record-bound guard
     if (shrink) { cap1 /= 2; cap2 /= 2; }
     const uint32_t ns1 = np - nc1 - nd1, ns2 = paired ? np - nc2 - nd2 : 0u;
-    const uint32_t gs = cdiv(std::max(ns1, ns2), RB), gc = cdiv(std::max(nc1, paired ? nc2 : 0u), RB), gd = cdiv(std::max(nd1, paired ? nd2 : 0u), RB);
+    uint32_t gs = cdiv(std::max(ns1, ns2), RB), gd = cdiv(std::max(nd1, paired ? nd2 : 0u), RB);
+    const uint32_t gc = cdiv(std::max(nc1, paired ? nc2 : 0u), RB);
+    if (tb.L > 1008) { gs = 0; gd = 0; }                                           // reads this long all sit in the general list (launch_indels); what is left in the others are holes: nothing to write
     // The three class kernels write disjoint records: the two small ones go to side streams and run BESIDE the big one (each alone
     // leaves the chip half empty through its first and last wave of workgroups); the caller's stream waits for both.
     struct Side { hipStream_t st[2] = {nullptr, nullptr}; hipEvent_t fork = nullptr, join[2] = {nullptr, nullptr}; };

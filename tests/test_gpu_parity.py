@@ -454,6 +454,23 @@ def test_bench_profile_pe150_bit_exact(oracle_bin, models, tmp_path):
     assert fq2 == open(prefix + "_2.fq", "rb").read()
 
 
+def test_very_long_reads_take_the_general_variant(oracle_bin, models, tmp_path):
+    """The uniform walk gathers a read's window with at most 64 lanes (16 bases each): reads longer than 1008 bases all go through the
+    general variant.  A model resampled to 1040 bins, single-end, on a 1 Mb genome, byte for byte against the oracle."""
+    fa = str(tmp_path / "simu.fa")
+    subprocess.check_call(["python3", os.path.join(ROOT, "tools", "make_genome.py"), "--lengths", "1000000", "--seed", "7", "--simu-out", fa])
+    prof = str(tmp_path / "se1040.profile")
+    subprocess.check_call(["python3", os.path.join(ROOT, "tools", "make_profile.py"), models["Illumina_HiSeq2500"], prof, "--read-length", "1040"])
+    prefix = str(tmp_path / "orc")
+    _oracle_run(oracle_bin, fa, prof, prefix, ["-c", "4", "-l", "SE"], 77, threads=min(32, os.cpu_count() or 1))
+    g = scssim_amd.GenReads(profile=prof, input_fasta=fa, coverage=4.0, layout="SE", seed=77)
+    assert g.read_length == 1040
+    fq1, _ = g.run()
+    want = open(prefix + ".fq", "rb").read()
+    assert len(want) > 100000
+    assert fq1 == want, _fastq_diff(fq1, want)
+
+
 def _md5_file(path):
     import hashlib
     h = hashlib.md5()
