@@ -454,6 +454,30 @@ def test_bench_profile_pe150_bit_exact(oracle_bin, models, tmp_path):
     assert fq2 == open(prefix + "_2.fq", "rb").read()
 
 
+@pytest.mark.parametrize("rl,layout", [(17, "SE"), (36, "PE"), (51, "PE"), (75, "SE"), (257, "PE")])
+def test_odd_read_lengths_bit_exact(rl, layout, oracle_bin, models, tmp_path):
+    """Read lengths around the walk's block sizes (16-position blocks, 16-base window dwords, the 50-base floor under which indels
+    are dropped): a model resampled to the length, 1 Mb genome, byte for byte against the oracle."""
+    fa = str(tmp_path / "simu.fa")
+    subprocess.check_call(["python3", os.path.join(ROOT, "tools", "make_genome.py"), "--lengths", "1000000", "--seed", "9", "--simu-out", fa])
+    prof = str(tmp_path / "m.profile")
+    subprocess.check_call(["python3", os.path.join(ROOT, "tools", "make_profile.py"), models["Illumina_HiSeq2500"], prof, "--read-length", str(rl)])
+    prefix = str(tmp_path / "orc")
+    isz = max(260, 2 * rl)
+    _oracle_run(oracle_bin, fa, prof, prefix, ["-c", "1", "-l", layout, "-s", str(isz)], 300 + rl, threads=min(32, os.cpu_count() or 1))
+    g = scssim_amd.GenReads(profile=prof, input_fasta=fa, coverage=1.0, layout=layout, isize=isz, seed=300 + rl)
+    assert g.read_length == rl
+    fq1, fq2 = g.run()
+    if layout == "PE":
+        w1, w2 = open(prefix + "_1.fq", "rb").read(), open(prefix + "_2.fq", "rb").read()
+        assert fq1 == w1, _fastq_diff(fq1, w1)
+        assert fq2 == w2, _fastq_diff(fq2, w2)
+    else:
+        w1 = open(prefix + ".fq", "rb").read()
+        assert fq1 == w1, _fastq_diff(fq1, w1)
+    assert len(w1) > 50000
+
+
 def test_very_long_reads_take_the_general_variant(oracle_bin, models, tmp_path):
     """The uniform walk gathers a read's window with at most 64 lanes (16 bases each): reads longer than 1008 bases all go through the
     general variant.  A model resampled to 1040 bins, single-end, on a 1 Mb genome, byte for byte against the oracle."""
