@@ -637,6 +637,43 @@ def test_wider_alias_rows_match_oracle(qk, models, tmp_path):
     assert r.returncode == 0, r.stdout[-3000:]
 
 
+def test_device_resident_output_matches_oracle(oracle_bin, models, golden_inputs, tmp_path):
+    """scs_yield_reads_device leaves the FASTQ text in caller-owned device memory (the boundary a GPU-side consumer binds): the same
+    bytes as the files of the oracle; too small a buffer is reported, not overrun.  (The small-batch run repeats this test: many
+    batches into one contiguous buffer.)"""
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    hip.hipFree.argtypes = [ctypes.c_void_p]
+
+    def dmalloc(n):
+        p = ctypes.c_void_p()
+        assert hip.hipMalloc(ctypes.byref(p), n) == 0
+        return p
+
+    def dtoh(p, n):
+        buf = ctypes.create_string_buffer(n)
+        assert hip.hipMemcpy(buf, p, n, 2) == 0                     # hipMemcpyDeviceToHost (synchronises)
+        return buf.raw
+    case, model, oargs, layout, cov, isize, extra = CASES[0]
+    seed = 4242
+    prefix = str(tmp_path / "orc")
+    _oracle_run(oracle_bin, golden_inputs[case], models[model], prefix, oargs, seed)
+    w1, w2 = open(prefix + "_1.fq", "rb").read(), open(prefix + "_2.fq", "rb").read()
+    g = scssim_amd.GenReads(profile=models[model], input_fasta=golden_inputs[case], coverage=cov, isize=isize, layout=layout, seed=seed, **extra)
+    g.create_frags(); g.amplify(); g.allocate_reads(0)
+    c1, c2 = len(w1) + 4096, len(w2) + 4096
+    b1, b2 = dmalloc(c1), dmalloc(c2)
+    try:
+        n1, n2, pairs = g.yield_reads_device(b1, c1, b2, c2)
+        assert (n1, n2) == (len(w1), len(w2)) and pairs == w1.count(b"\n") // 4
+        assert dtoh(b1, n1) == w1 and dtoh(b2, n2) == w2
+        with pytest.raises(scssim_amd.ScsError):
+            g.yield_reads_device(b1, len(w1) // 2, b2, c2)
+    finally:
+        hip.hipFree(b1); hip.hipFree(b2)
+
+
 def test_many_small_batches_match_oracle(models, tmp_path):
     """The read stage works batch by batch (8 M pairs with the text staying in HBM, 512 k towards a sink), the next batch's
     pre-pass queued ahead of the current base pass into a second set of buffers.  The parity cases fit one batch, so they run once
@@ -645,7 +682,7 @@ def test_many_small_batches_match_oracle(models, tmp_path):
         pytest.skip("already inside the small-batch run")
     env = dict(os.environ, SCS_TEST_BATCH_SHIFT="12")
     sel = ["tests/test_gpu_parity.py::test_full_pipeline_fastq_bit_exact", "tests/test_gpu_parity.py::test_medium_genome_bit_exact",
-           "tests/test_gpu_parity.py::test_very_long_reads_take_the_general_variant"]
+           "tests/test_gpu_parity.py::test_very_long_reads_take_the_general_variant", "tests/test_gpu_parity.py::test_device_resident_output_matches_oracle"]
     r = subprocess.run(["python", "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider"] + sel, cwd=ROOT, env=env,
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:]
