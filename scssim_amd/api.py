@@ -321,6 +321,22 @@ class GenReads:
         self._ck(self._L.scs_yield_reads_device(self._ctx, d_fq1, cap1, d_fq2, cap2, C.byref(n1), C.byref(n2), C.byref(pairs)))
         return n1.value, n2.value, pairs.value
 
+    def run_genreads(self, collect=True):
+        """scs_run_genreads: createFrags + amplify + allocate + yield in ONE call of the C ABI (main()'s genreads branch,
+        src/scssim.cpp:59-65)."""
+        out1, out2 = bytearray(), bytearray()
+
+        def on_batch(_u, p1, n1, p2, n2):
+            if collect:
+                if n1:
+                    out1.extend(C.string_at(p1, n1))
+                if n2:
+                    out2.extend(C.string_at(p2, n2))
+            return 0
+        cb = _SINK(on_batch)
+        self._ck(self._L.scs_run_genreads(self._ctx, cb, None))
+        return bytes(out1), bytes(out2)
+
     def run(self, collect=True):
         self.create_frags()
         self.amplify()

@@ -637,6 +637,26 @@ def test_wider_alias_rows_match_oracle(qk, models, tmp_path):
     assert r.returncode == 0, r.stdout[-3000:]
 
 
+def test_one_call_entry_and_timer_switches(models, golden_inputs):
+    """scs_run_genreads (the whole job in one call of the C ABI) writes what the four stage calls write; scs_set_kernel_timing switches
+    the HIP-event timers of the hot kernels off and on again."""
+    case, model, oargs, layout, cov, isize, extra = CASES[0]
+    kw = dict(profile=models[model], input_fasta=golden_inputs[case], coverage=cov, isize=isize, layout=layout, seed=99, **extra)
+    a = scssim_amd.GenReads(**kw)
+    f1, f2 = a.run()
+    b = scssim_amd.GenReads(**kw)
+    b.set_kernel_timing(names=[], every=1)                              # no timers
+    g1, g2 = b.run_genreads()
+    assert (g1, g2) == (f1, f2) and len(f1) > 1000
+    assert all(v["launches"] == 0 for v in b.kernel_times().values())
+    b.set_kernel_timing(names=None, every=1)                            # all of them
+    b.set_seed(99)
+    h1, h2 = b.run_genreads()
+    assert (h1, h2) == (f1, f2)
+    kt = b.kernel_times()
+    assert kt["k_reads"]["launches"] >= 1 and kt["k_reads"]["ms"] > 0 and kt["k_attach<semi>"]["launches"] >= 1
+
+
 def test_device_resident_output_matches_oracle(oracle_bin, models, golden_inputs, tmp_path):
     """scs_yield_reads_device leaves the FASTQ text in caller-owned device memory (the boundary a GPU-side consumer binds): the same
     bytes as the files of the oracle; too small a buffer is reported, not overrun.  (The small-batch run repeats this test: many
