@@ -254,15 +254,37 @@ def main():
             cli_sample = bases[o20:o20 + rl[i20]].cpu().numpy()
     del bases
     torch.cuda.empty_cache()
+    coll_path = None
     if world > 1:
         if cpu_coll:                                                 # 1-GPU rehearsal: torch.distributed (gloo) hooks
             from scssim_amd.dist import Collectives
             coll = Collectives(stream=stream)
             g.set_collectives(coll, device_hooks=True)
+            coll_path = "rehearsal: torch.distributed (%s) hooks staged through the CPU" % backend
         else:                                                        # RCCL inside the library: rank 0's id to every rank
-            ids = [scssim_amd.comm_unique_id() if rank == 0 else None]
+            why = ""
+            try:
+                ids = [scssim_amd.comm_unique_id() if rank == 0 else None]
+            except Exception as e:                                   # the broadcast below must still be entered by every rank
+                ids, why = [None], repr(e)
             dist.broadcast_object_list(ids, src=0)
-            g.comm_init(ids[0], rank, world)
+            if ids[0] is not None:
+                try:
+                    g.comm_init(ids[0], rank, world)
+                except Exception as e:
+                    why = repr(e)
+            else:
+                why = why or "rank 0 could not create a communicator id"
+            good = torch.tensor([0 if why else 1], dtype=torch.int32, device=dev)
+            dist.all_reduce(good, op=dist.ReduceOp.MIN)
+            coll_path = "RCCL communicator inside the library (scs_comm_init)"
+            if int(good[0]) == 0:                                    # every rank takes the same path: the device hooks over torch's RCCL group
+                if why:
+                    print("rank %d: scs_comm_init failed (%s); collectives through torch.distributed's RCCL group" % (rank, why), file=sys.stderr)
+                from scssim_amd.dist import Collectives
+                coll = Collectives(stream=stream)
+                g.set_collectives(coll, device_hooks=True)
+                coll_path = "torch.distributed RCCL group on the library's HBM buffers (device hooks)"
 
     ktimes = {}
 
@@ -380,6 +402,7 @@ def main():
                                     "PE150 %gx, HiSeq2500 model resampled to 150 bins, -p 100000 -r 1e-9 -s 260" % (world, sum(lens) / 1e6, a.coverage)),
                        "pairs_per_step": pairs_total // a.steps, "amplicons_per_step": amps_all // a.steps, "fastq_bytes_per_step": fq_bytes_all // a.steps,
                        "sharding": ("one job over %d GPUs by fragment lineage; per-pass primer-stock all-reduce + allocation partials over RCCL; a FASTQ shard per rank" % world) if world > 1 else "single GPU",
+                       "collectives": coll_path,
                        "output": "FASTQ text generated batch by batch into HBM buffers (NULL sink)"},
             "roofline": roof,
             "stages_s_per_step": {k: v / a.steps for k, v in stage.items()},

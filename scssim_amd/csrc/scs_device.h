@@ -161,6 +161,7 @@ void launch_weights(hipStream_t s, DevAmps fulls, uint32_t n, DevTables tb, RngK
 void launch_plan_pairs(hipStream_t s, DevFrags fr, DevAmps semis, DevAmps fulls, uint32_t first, uint32_t n_fulls, uint32_t pair_lo, const uint32_t* read_numbers,
                        const uint32_t* pair_off, SegMap gmap, DevTables tb, RngKey key, int paired, PairRec* pairs, unsigned long long* holes);   // amplicons [first, first + n_fulls); holes counted for pairs from pair_lo on
 void launch_batch_bounds(hipStream_t s, const uint32_t* pair_off, uint32_t ac, unsigned long long batch, uint32_t nb, uint32_t* bounds);
+void launch_parity_pair_offsets(hipStream_t s, uint32_t* rn, uint32_t ac, uint32_t* pair_cnt_off, void* temp, size_t temp_bytes);   // PE, one shard: parity fix + pair offsets in one scan
 void launch_pair_offsets(hipStream_t s, const uint32_t* rn, uint32_t ac, int paired, uint32_t* pair_cnt_off, void* temp, size_t temp_bytes);
 // reads of pairs [p0, p0+np): slot layout [2*np][slot] bases / quals (SE: [np][slot])
 size_t reads_lds_bytes(const DevTables& tb, bool uni = false);   // uni: the uniform-walk variant (event-free ACGT-only reads)

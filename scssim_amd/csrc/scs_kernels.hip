@@ -454,29 +454,64 @@ __device__ double det_exp(double x) {
 }
 
 // K2  weights: Amplicon::getWeightedLength (Amplicon.cpp:396-400) x Profile::getGCFactor (Profile.cpp:1503-1513)
-__global__ void k_weights(DevAmps fulls, uint32_t n, DevTables tb, RngKey key, uint32_t frag_size, double* __restrict__ w) {
+// [REMAP] Marsaglia polar, keyed: attempt a = words 2(a&1), 2(a&1)+1 of Philox block a/2 of the amplicon's uid; the first
+// attempt inside the unit disc whose value is not negative counts.  Four of five amplicons are served by attempt 0 and one in
+// 15 needs an attempt of a later block (or drew a negative value): written as ONE loop, nearly every wave pays a second
+// Philox block and two or three more logarithm / square root / division rounds for its few unlucky lanes.  So the
+// workgroup's first pass takes the first accepted attempt of block 0 without branching, and the amplicons it leaves are
+// queued in LDS and finished by the workgroup's first lanes, densely.
+struct GcDraw { double y, r2; bool in; };
+__device__ __forceinline__ GcDraw gc_attempt(uint32_t wx, uint32_t wy) {
+    const double x = 2.0 * (((double)wx + 0.5) / 4294967296.0) - 1.0;
+    const double y = 2.0 * (((double)wy + 0.5) / 4294967296.0) - 1.0;
+    const double r2 = x * x + y * y;
+    return GcDraw{y, r2, !(r2 > 1.0 || r2 == 0.0)};
+}
+__device__ __forceinline__ double gc_value(double mean, double sd, double y, double r2) {
+    const double mult = __dsqrt_rn(-2.0 * det_log(r2) / r2);
+    return mean + sd * (y * mult);
+}
+constexpr int WEIGHTS_BLOCK = 1024;
+__global__ __launch_bounds__(WEIGHTS_BLOCK) void k_weights(DevAmps fulls, uint32_t n, DevTables tb, RngKey key, uint32_t frag_size, double* __restrict__ w) {
+    __shared__ uint32_t s_retry[WEIGHTS_BLOCK];                                    // thread | first attempt still to try << 16
+    __shared__ uint32_t s_n;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t len = sl_len(fulls.sl[i]);
-    const uint32_t gcp = 100u * fulls.gc[i] / len;
-    const uint64_t uid = fulls.uid[i];
-    double v = 0;
-    if (gcp <= 100) {
-        const double mean = tb.gc_means[gcp], sd = tb.gc_std;
-        U4 d{};
-        for (uint32_t a = 0;; ++a) {                                              // [REMAP] Marsaglia polar, keyed: attempt a = words 2(a&1), 2(a&1)+1 of block a/2
-            if ((a & 1u) == 0) d = draw4(key, ST_WEIGHT, 0, uid, a >> 1);
-            const double x = 2.0 * (((double)((a & 1u) ? d.w[2] : d.w[0]) + 0.5) / 4294967296.0) - 1.0;
-            const double y = 2.0 * (((double)((a & 1u) ? d.w[3] : d.w[1]) + 0.5) / 4294967296.0) - 1.0;
-            const double r2 = x * x + y * y;
-            if (r2 > 1.0 || r2 == 0.0) continue;
-            const double mult = __dsqrt_rn(-2.0 * det_log(r2) / r2);
-            v = mean + sd * (y * mult);
-            if (v < 0) continue;
-            break;
+    const double scale = (double)(frag_size * frag_size), sd = tb.gc_std;
+    if (i < n) {
+        const uint32_t len = sl_len(fulls.sl[i]);
+        const uint32_t gcp = 100u * fulls.gc[i] / len;
+        if (gcp > 100) w[i] = 0.0 * (double)len / scale;
+        else {
+            const U4 d = draw4(key, ST_WEIGHT, 0, fulls.uid[i], 0);
+            const GcDraw a0 = gc_attempt(d.w[0], d.w[1]), a1 = gc_attempt(d.w[2], d.w[3]);
+            const bool any = a0.in || a1.in;
+            double v = -1.0;
+            if (any) v = gc_value(tb.gc_means[gcp], sd, a0.in ? a0.y : a1.y, a0.in ? a0.r2 : a1.r2);
+            if (v < 0) s_retry[atomicAdd(&s_n, 1u)] = threadIdx.x | ((any && a0.in ? 1u : 2u) << 16);
+            else w[i] = v * (double)len / scale;
         }
     }
-    w[i] = v * (double)len / (double)(frag_size * frag_size);
+    __syncthreads();
+    const uint32_t nr = s_n;
+    for (uint32_t k = threadIdx.x; k < nr; k += blockDim.x) {
+        const uint32_t e = s_retry[k], j = blockIdx.x * blockDim.x + (e & 0xFFFFu);
+        const uint32_t len = sl_len(fulls.sl[j]);
+        const double mean = tb.gc_means[100u * fulls.gc[j] / len];
+        const uint64_t uid = fulls.uid[j];
+        uint32_t a = e >> 16;
+        U4 d = draw4(key, ST_WEIGHT, 0, uid, a >> 1);
+        double v;
+        for (;; ++a) {
+            if ((a & 1u) == 0 && a != (e >> 16)) d = draw4(key, ST_WEIGHT, 0, uid, a >> 1);
+            const GcDraw t = (a & 1u) ? gc_attempt(d.w[2], d.w[3]) : gc_attempt(d.w[0], d.w[1]);
+            if (!t.in) continue;
+            v = gc_value(mean, sd, t.y, t.r2);
+            if (v >= 0) break;
+        }
+        w[j] = v * (double)len / scale;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2149,7 +2184,7 @@ void launch_primer_update(hipStream_t s, int64_t* primer_cnt, uint32_t* primer_d
 }
 void launch_weights(hipStream_t s, DevAmps fulls, uint32_t n, DevTables tb, RngKey key, uint32_t frag_size, double* w) {
     if (n == 0) return;
-    hipLaunchKernelGGL(k_weights, dim3(cdiv(n, 256)), dim3(256), 0, s, fulls, n, tb, key, frag_size, w);
+    hipLaunchKernelGGL(k_weights, dim3(cdiv(n, (uint32_t)WEIGHTS_BLOCK)), dim3(WEIGHTS_BLOCK), 0, s, fulls, n, tb, key, frag_size, w);
 }
 void launch_plan_pairs(hipStream_t s, DevFrags fr, DevAmps semis, DevAmps fulls, uint32_t first, uint32_t n_fulls, uint32_t pair_lo, const uint32_t* read_numbers,
                        const uint32_t* pair_off, SegMap gmap, DevTables tb, RngKey key, int paired, PairRec* pairs, unsigned long long* holes) {
@@ -2168,6 +2203,36 @@ __global__ void k_batch_bounds(const uint32_t* __restrict__ pair_off, uint32_t a
 }
 void launch_batch_bounds(hipStream_t s, const uint32_t* pair_off, uint32_t ac, unsigned long long batch, uint32_t nb, uint32_t* bounds) {
     hipLaunchKernelGGL(k_batch_bounds, dim3(cdiv(nb + 1, 256)), dim3(256), 0, s, pair_off, ac, batch, nb, bounds);
+}
+// PE on one shard: the parity fix (Malbac.cpp:399-407) and the pair offsets in ONE scan.  The scanned value carries the
+// odd entries so far (high word) beside the halves rn >> 1 (low word); the j-th odd entry becomes rn + 1 for even j and
+// rn - 1 for odd j, so the pairs before entry i are the halves before it + the even j below its odd count -- the store
+// of the scan's result at i writes pair_off[i] and the fixed rn[i] (12 bytes per amplicon instead of 28 over three passes)
+struct PackOddHalf { __host__ __device__ uint64_t operator()(uint32_t v) const { return ((uint64_t)(v & 1u) << 32) | (uint64_t)(v >> 1); } };
+struct ParityOut {
+    struct Ref {
+        uint32_t* rn; uint32_t* pair_off; size_t ac, i;
+        __device__ const Ref& operator=(uint64_t sum) const {
+            const uint32_t odd = (uint32_t)(sum >> 32);
+            pair_off[i] = (uint32_t)sum + ((odd + 1u) >> 1);
+            if (i < ac) { const uint32_t v = rn[i]; if (v & 1u) rn[i] = (odd & 1u) ? v - 1u : v + 1u; }
+            return *this;
+        }
+    };
+    using iterator_category = std::random_access_iterator_tag; using value_type = uint64_t; using difference_type = std::ptrdiff_t;
+    using pointer = void; using reference = Ref;
+    uint32_t* rn; uint32_t* pair_off; size_t ac, at;
+    __host__ __device__ Ref operator[](difference_type k) const { return Ref{rn, pair_off, ac, at + (size_t)k}; }
+    __host__ __device__ Ref operator*() const { return Ref{rn, pair_off, ac, at}; }
+    __host__ __device__ ParityOut operator+(difference_type k) const { return ParityOut{rn, pair_off, ac, at + (size_t)k}; }
+    __host__ __device__ ParityOut operator-(difference_type k) const { return ParityOut{rn, pair_off, ac, at - (size_t)k}; }
+    __host__ __device__ ParityOut& operator+=(difference_type k) { at += (size_t)k; return *this; }
+    __host__ __device__ ParityOut& operator++() { ++at; return *this; }
+    __host__ __device__ difference_type operator-(const ParityOut& o) const { return (difference_type)at - (difference_type)o.at; }
+};
+void launch_parity_pair_offsets(hipStream_t s, uint32_t* rn, uint32_t ac, uint32_t* pair_cnt_off, void* temp, size_t temp_bytes) {
+    (void)rocprim::exclusive_scan(temp, temp_bytes, rocprim::make_transform_iterator((const uint32_t*)rn, PackOddHalf()), ParityOut{rn, pair_cnt_off, (size_t)ac, 0},
+                                  (uint64_t)0, (size_t)ac + 1, rocprim::plus<uint64_t>(), s);
 }
 void launch_pair_offsets(hipStream_t s, const uint32_t* rn, uint32_t ac, int paired, uint32_t* pair_cnt_off, void* temp, size_t temp_bytes) {
     if (paired) (void)rocprim::exclusive_scan(temp, temp_bytes, rocprim::make_transform_iterator(rn, HalfUp()), pair_cnt_off, 0u, (size_t)ac + 1, rocprim::plus<uint32_t>(), s);
@@ -2292,6 +2357,10 @@ size_t scan_temp_bytes(size_t n) {
     (void)rocprim::exclusive_scan(nullptr, a, (const uint32_t*)nullptr, (uint32_t*)nullptr, 0u, n + 1, rocprim::plus<uint32_t>());
     (void)rocprim::exclusive_scan(nullptr, b, rocprim::make_transform_iterator((const uint32_t*)nullptr, Widen()),
                                   (uint64_t*)nullptr, (uint64_t)0, n + 1, rocprim::plus<uint64_t>());
+    size_t c3 = 0;
+    (void)rocprim::exclusive_scan(nullptr, c3, rocprim::make_transform_iterator((const uint32_t*)nullptr, PackOddHalf()), ParityOut{nullptr, nullptr, 0, 0},
+                                  (uint64_t)0, n + 1, rocprim::plus<uint64_t>());
+    b = std::max(b, c3);
     return (a > b ? a : b) + 256;
 }
 // exclusive scan of up to two small arrays in ONE launch (one 1024-thread workgroup each; out gets n+1 entries).  The

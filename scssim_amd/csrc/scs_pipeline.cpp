@@ -743,7 +743,8 @@ void do_allocate(scs_ctx* c, uint64_t reads) {
     if (multi) c->reduce_dev(d_tp, (uint64_t)nch + 1, 8);
     launch_alloc_quota(s, d_tp, nch, reads, d_sum_rn, &st->sum_quota, c->a_quota.as<uint32_t>(), c->a_probs.as<double>(), c->a_scratch.as<double>(), c->key);
     launch_alloc_sample(s, d_w, c->a_brow.as<double>(), c->a_bmap.as<int>(), pl, d_tp, c->a_quota.as<uint32_t>(), c->key, d_rn);
-    if (c->cfg.paired) {
+    if (c->cfg.paired && !multi) launch_parity_pair_offsets(s, d_rn, ac, c->pair_off.as<uint32_t>(), c->scan_tmp.p, c->scan_tmp.cap);
+    else if (c->cfg.paired) {
         launch_alloc_odd_scan(s, d_rn, ac, c->odd_before.as<uint32_t>(), c->scan_tmp.p, c->scan_tmp.cap);
         unsigned long long* table = nullptr;
         if (multi) {   // odd entries of every segment of every shard, in list order
@@ -754,7 +755,7 @@ void do_allocate(scs_ctx* c, uint64_t reads) {
         }
         launch_alloc_parity(s, d_rn, c->odd_before.as<uint32_t>(), ac, pl, table);
     }
-    launch_pair_offsets(s, d_rn, ac, c->cfg.paired != 0, c->pair_off.as<uint32_t>(), c->scan_tmp.p, c->scan_tmp.cap);
+    if (!c->cfg.paired || multi) launch_pair_offsets(s, d_rn, ac, c->cfg.paired != 0, c->pair_off.as<uint32_t>(), c->scan_tmp.p, c->scan_tmp.cap);
     { Mail m; m.add(ac ? (const void*)(c->pair_off.as<uint32_t>() + ac) : nullptr, 4, 0); mail_post(c, m, true); }
     mail_wait(c);
     c->n_pairs_planned = (uint32_t)c->h_rb[0];
