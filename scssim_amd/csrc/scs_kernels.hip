@@ -1928,37 +1928,46 @@ __global__ void k_alloc_top_draws(const double* __restrict__ probs, uint32_t nch
 }
 // batchSampling (MyDefine.cpp:191-201) of one chunk: the chunk-local CDF (scan1000 of p / tp) lives in LDS only; the
 // chunk's quota of draws is counted in LDS and added to this shard's read numbers in one coalesced pass
-__global__ void __launch_bounds__(64) k_alloc_sample(const double* __restrict__ w, const double* __restrict__ brow, const int* __restrict__ bmap, AllocPlan pl,
-                                                     const double* __restrict__ tp, const uint32_t* __restrict__ quota, RngKey key, uint32_t* __restrict__ rn) {
+__global__ void __launch_bounds__(256) k_alloc_sample(const double* __restrict__ w, const double* __restrict__ brow, const int* __restrict__ bmap, AllocPlan pl,
+                                                      const double* __restrict__ tp, const uint32_t* __restrict__ quota, RngKey key, uint32_t* __restrict__ rn) {
+    constexpr int ROUNDS = (ALLOC_CHUNK + WAVE - 1) / WAVE, WAVES = 4, MINE = ROUNDS / WAVES;   // four waves per chunk: with one, its 12 KB of LDS left a CU 13 waves
+    static_assert(ROUNDS % WAVES == 0, "rounds of scan1000 divide among the waves");
     __shared__ double s_cdf[ALLOC_CHUNK];
     __shared__ uint32_t s_cnt[ALLOC_CHUNK];
-    const uint32_t q = blockIdx.x, lane = threadIdx.x;
+    __shared__ double s_tot[ROUNDS];
+    const uint32_t q = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
     const ChunkRef r = chunk_ref(pl, q);
     const uint32_t nq = quota[r.c];
     if (nq == 0) return;
     const double* __restrict__ v = r.brow < 0 ? w + r.local0 : brow + (size_t)r.brow * ALLOC_CHUNK;
     const double t = tp[r.c];
-    double carry = 0;
-    // the chunk's weights first, all loads in flight together (a load per round of the scan below was a memory round trip per
-    // round: sixteen in a row)
-    constexpr int ROUNDS = (ALLOC_CHUNK + WAVE - 1) / WAVE;
-    double pv[ROUNDS];
+    // scan1000 = a wave-wide scan inside every round of 64 + the running sum of the rounds' totals in front of it: the rounds are
+    // scanned by the four waves side by side (all their loads in flight together), the carries added afterwards -- the same
+    // additions in the same order as the one-wave form
+    double pv[MINE];
 #pragma unroll
-    for (int k = 0; k < ROUNDS; ++k) pv[k] = (uint32_t)(k * WAVE) + lane < r.n ? v[k * WAVE + lane] : 0.0;
+    for (int m = 0; m < MINE; ++m) { const uint32_t i = (uint32_t)((wv + WAVES * m) * WAVE) + lane; pv[m] = i < r.n ? v[i] : 0.0; }
 #pragma unroll
-    for (int k = 0; k < ROUNDS; ++k) {
-        const uint32_t b = (uint32_t)(k * WAVE);
-        if (b >= r.n) break;
-        double s = b + lane < r.n ? pv[k] / t : 0.0;                                    // p[i]/totalProb (MyDefine.cpp:224)
+    for (int m = 0; m < MINE; ++m) {
+        const uint32_t k = wv + WAVES * m, i = k * WAVE + lane;
+        double s = i < r.n ? pv[m] / t : 0.0;                                          // p[i]/totalProb (MyDefine.cpp:224)
 #pragma unroll
         for (int d = 1; d < WAVE; d <<= 1) { const double u = shfl_up_f64(s, d); if ((int)lane >= d) s = s + u; }
-        if (b + lane < r.n) { s_cdf[b + lane] = carry + s; s_cnt[b + lane] = 0; }
-        carry = carry + shfl_f64(s, 63);
+        pv[m] = s;
+        if (lane == 63) s_tot[k] = s;
     }
-    __builtin_amdgcn_wave_barrier();
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < MINE; ++m) {
+        const uint32_t k = wv + WAVES * m, i = k * WAVE + lane;
+        double carry = 0;
+        for (uint32_t z = 0; z < k; ++z) carry = carry + s_tot[z];
+        if (i < r.n) { s_cdf[i] = carry + pv[m]; s_cnt[i] = 0; }
+    }
+    __syncthreads();
     // [REMAP] draw k of the chunk = word k & 3 of Philox block k >> 2: a lane takes a whole block, and its four bisections run
     // interleaved (each is ten dependent LDS reads: four in flight instead of one)
-    for (uint32_t j = lane; 4u * j < nq; j += WAVE) {
+    for (uint32_t j = tid; 4u * j < nq; j += blockDim.x) {
         const U4 d = draw4(key, ST_ALLOC_CHUNK, 0, r.c, j);
         double x[4]; uint32_t lo[4], hi[4];
 #pragma unroll
@@ -1971,8 +1980,8 @@ __global__ void __launch_bounds__(64) k_alloc_sample(const double* __restrict__ 
 #pragma unroll
         for (int i = 0; i < 4; ++i) if (4u * j + (uint32_t)i < nq) atomicAdd(&s_cnt[lo[i] < r.n ? lo[i] : r.n - 1], 1u);
     }
-    __builtin_amdgcn_wave_barrier();
-    for (uint32_t i = lane; i < r.n; i += WAVE) {
+    __syncthreads();
+    for (uint32_t i = tid; i < r.n; i += blockDim.x) {
         const uint32_t c = s_cnt[i];
         if (!c) continue;
         if (r.brow < 0) rn[r.local0 + i] += c;
@@ -2113,7 +2122,7 @@ void launch_alloc_quota(hipStream_t s, const double* tp, uint32_t nch, unsigned 
 }
 void launch_alloc_sample(hipStream_t s, const double* w, const double* brow, const int* bmap, const AllocPlan& pl, const double* tp, const uint32_t* quota, RngKey key, uint32_t* rn) {
     const uint32_t nq = pl.n_interior + pl.n_boundary;
-    if (nq) hipLaunchKernelGGL(k_alloc_sample, dim3(nq), dim3(64), 0, s, w, brow, bmap, pl, tp, quota, key, rn);
+    if (nq) hipLaunchKernelGGL(k_alloc_sample, dim3(nq), dim3(256), 0, s, w, brow, bmap, pl, tp, quota, key, rn);
 }
 void launch_alloc_odd_scan(hipStream_t s, const uint32_t* rn, uint32_t ac, uint32_t* odd_before, void* temp, size_t temp_bytes) {
     (void)rocprim::exclusive_scan(temp, temp_bytes, rocprim::make_transform_iterator(rn, OddBit()), odd_before, 0u, (size_t)ac + 1, rocprim::plus<uint32_t>(), s);
