@@ -308,6 +308,7 @@ void launch_frag_has_n(hipStream_t s, const uint64_t* goff, const uint32_t* len,
 //      Amplicon.cpp:200-226), alt-base rejection draws, packed record written at its final
 //      (reference -t 1 list) position.
 // ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t u4_word(const U4& d, uint32_t k) { return k == 0 ? d.w[0] : k == 1 ? d.w[1] : k == 2 ? d.w[2] : d.w[3]; }
 template <bool FROM_FRAG>
 __global__ void __launch_bounds__(256) k_errs(const uint8_t* __restrict__ g, DevGenomeIdx gx, DevFrags fr, DevAmps semis, DevErrPool spool,
                                               uint32_t n_slots, const uint32_t* __restrict__ slot_off, const uint32_t* __restrict__ slots,
@@ -368,37 +369,49 @@ __global__ void __launch_bounds__(256) k_errs(const uint8_t* __restrict__ g, Dev
     uint32_t K = 0;
     while (K < (uint32_t)BINOM_KMAX && x64 >= Tn[K]) ++K;
     uint64_t packed = 0;
-    if (K) {
-        uint32_t pos[BINOM_KMAX]; uint32_t cnt = 0, q = 0; U4 d = d0;
+    // the K positions (sorted) and then the K entries: in four registers for K <= 4; the 2 amplicons in 10 000 with more keep
+    // them in their slice of the overflow pool, where the entries end up anyway (two 16-entry register arrays cost the kernel
+    // a wave per SIMD, and it lives on its waves in flight: a chain of dependent gathers)
+    auto resolve = [&](uint32_t j) {                                               // entry of the error at position j; its GC change goes to gcn
+        const uint32_t base = FROM_FRAG ? view_base(g, tv, spos + j) : semi_tmpl_base(g, tv, plen, perrs, spool.data, spos + j);
+        uint32_t alt, a = 0;
+        do {                                                                       // do { n = rand } while (bases[n] == base)
+            const U4 e = draw4(p.key, ST_ERRALT, kind, nuid, j | ((a >> 2) << 16));
+            alt = u4_word(e, a & 3) >> 30; ++a;                                    // trunc(4 * x / 2^32)
+        } while (alt == base);
+        gcn += (is_gc(alt) ? 1 : 0) - (is_gc(base) ? 1 : 0);
+        return err_pack(j, alt);
+    };
+    if (K && K <= 4) {
+        uint64_t P = 0;                                                            // sorted positions, 16 bits each
+        uint32_t cnt = 0, q = 0; U4 d = d0;
         while (cnt < K) {
             if ((q & 3) == 0) d = draw4(p.key, ST_ERR, kind, nuid, 1 + (q >> 2));
-            const uint32_t cand = 8 + scale_draw(d.w[q & 3], 0, ntr); ++q;
-            bool dup = false;
-            for (uint32_t z = 0; z < cnt; ++z) dup |= pos[z] == cand;
+            const uint32_t cand = 8 + scale_draw(u4_word(d, q & 3), 0, ntr); ++q;
+            bool dup = false; uint32_t below = 0;
+            for (uint32_t z = 0; z < cnt; ++z) { const uint32_t v = (uint32_t)(P >> (16 * z)) & 0xFFFFu; dup |= v == cand; below += v < cand ? 1u : 0u; }
             if (!dup) {                                                            // insert sorted
-                uint32_t z = cnt++;
-                while (z > 0 && pos[z - 1] > cand) { pos[z] = pos[z - 1]; --z; }
-                pos[z] = cand;
+                const uint64_t low = (1ull << (16 * below)) - 1ull;
+                P = (P & low) | ((uint64_t)cand << (16 * below)) | ((P & ~low) << 16);
+                ++cnt;
             }
         }
-        uint32_t ent[BINOM_KMAX]; int delta = 0;
-        for (uint32_t z = 0; z < K; ++z) {
-            const uint32_t j = pos[z];
-            const uint32_t base = FROM_FRAG ? view_base(g, tv, spos + j) : semi_tmpl_base(g, tv, plen, perrs, spool.data, spos + j);
-            uint32_t alt, a = 0;
-            do {                                                                   // do { n = rand } while (bases[n] == base)
-                const U4 e = draw4(p.key, ST_ERRALT, kind, nuid, j | ((a >> 2) << 16));
-                alt = e.w[a & 3] >> 30; ++a;                                       // trunc(4 * x / 2^32)
-            } while (alt == base);
-            delta += (is_gc(alt) ? 1 : 0) - (is_gc(base) ? 1 : 0);
-            ent[z] = err_pack(j, alt);
-        }
-        gcn += delta;
-        if (K <= 4) { for (uint32_t z = 0; z < K; ++z) packed |= (uint64_t)ent[z] << (16 * z); }
+        for (uint32_t z = 0; z < K; ++z) packed |= (uint64_t)resolve((uint32_t)(P >> (16 * z)) & 0xFFFFu) << (16 * z);
+    } else if (K) {
+        const uint32_t off = atomicAdd(pool.head, K);
+        if (off + K > pool.cap) atomicOr(flags, (uint32_t)FLAG_ERRPOOL);
         else {
-            const uint32_t off = atomicAdd(pool.head, K);
-            if (off + K > pool.cap) atomicOr(flags, (uint32_t)FLAG_ERRPOOL);
-            else { for (uint32_t z = 0; z < K; ++z) pool.data[off + z] = ent[z]; packed = ERR_OVERFLOW_BIT | ((uint64_t)K << 32) | off; }
+            uint32_t* pos = pool.data + off;
+            uint32_t cnt = 0, q = 0; U4 d = d0;
+            while (cnt < K) {
+                if ((q & 3) == 0) d = draw4(p.key, ST_ERR, kind, nuid, 1 + (q >> 2));
+                const uint32_t cand = 8 + scale_draw(u4_word(d, q & 3), 0, ntr); ++q;
+                bool dup = false;
+                for (uint32_t z = 0; z < cnt; ++z) dup |= pos[z] == cand;
+                if (!dup) { uint32_t z = cnt++; while (z > 0 && pos[z - 1] > cand) { pos[z] = pos[z - 1]; --z; } pos[z] = cand; }
+            }
+            for (uint32_t z = 0; z < K; ++z) pos[z] = resolve(pos[z]);
+            packed = ERR_OVERFLOW_BIT | ((uint64_t)K << 32) | off;
         }
     }
     if (gcn < 0) gcn = 0;                                                          // max(0, gcNum)
