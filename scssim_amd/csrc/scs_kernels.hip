@@ -1650,7 +1650,7 @@ __global__ void __launch_bounds__(1024) k_poisson_sums(const unsigned long long*
 //      would.  The result is identical to running the sequential loop.
 // ------------------------------------------------------------------------------------------------
 template <bool FROM_FRAG, int G>
-__global__ void __launch_bounds__(64) k_attach(const uint8_t* __restrict__ g, DevFrags fr, DevAmps semis, uint32_t n_semis, DevErrPool spool,
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(G == 4 ? 8 : 1, 8))) k_attach(const uint8_t* __restrict__ g, DevFrags fr, DevAmps semis, uint32_t n_semis, DevErrPool spool,
                                                const uint32_t* __restrict__ slot_off, uint32_t* __restrict__ slots, uint32_t* __restrict__ slot_tmpl,
                                                uint32_t* __restrict__ valid, const int64_t* __restrict__ primer_cnt, uint32_t* __restrict__ primer_delta,
                                                unsigned long long* __restrict__ len_sum, AmplifyParams p) {
