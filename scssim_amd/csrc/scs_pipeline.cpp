@@ -178,6 +178,8 @@ struct scs_ctx {
     // allocation + reads
     DevBuf weights, read_numbers, pair_off, pairs, odd_before, a_part, a_tp, a_probs, a_quota, a_poff, a_plan, a_crn, a_scratch, a_brow, a_bmap, a_send, a_gath, a_odd; SegMap gmap{}; std::vector<uint32_t> h_read_numbers; uint64_t reads_requested = 0, n_pairs_planned = 0; bool allocated = false;
     DevBuf slot_b, slot_q, lens, ev_hdr, ev_dat, sizes1, sizes2, off1, off2, out1, out2, out1b, out2b, rl_cls, rl_pos, rl_lists, d_bounds; SinkPipe* pipe = nullptr;
+    hipStream_t errs_stream = nullptr; hipEvent_t ev_att = nullptr, ev_errs = nullptr; bool errs_pending = false;   // k_errs<semi->full> of a cycle runs beside the fragment pass that follows it
+    DevBuf slots_fr, slot_tmpl_fr;                        // the fragment passes' own slot arrays (the semi pass's are still being read then)
     hipStream_t pre_stream = nullptr; hipEvent_t ev_pre[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr}, ev_plan = nullptr;   // the reads stage's pre-pass on its own stream, beside the previous batch's base pass
     hipStream_t mail_stream = nullptr;                                             // the stream of the last post (mail_wait watches it)
     hipStream_t copy_stream = nullptr; hipEvent_t ev_made[2] = {nullptr, nullptr};   // sink mode: D2H on its own stream, behind the batch's k_reads
@@ -522,6 +524,7 @@ void shard_exchange(scs_ctx* c, const uint32_t* new_semis) {
 
 // ---------------------------------------------------------------- one amplification pass (a4 / a5): launches only, no host sync.
 // rb_slot: where the number of amplicons created is read back to (pinned host memory, stream-ordered).
+static void join_errs(scs_ctx* c) { if (c->errs_pending) { HIP_OK(hipStreamWaitEvent(c->stream, c->ev_errs, 0)); c->errs_pending = false; } }
 void launch_pass(scs_ctx* c, bool from_frag, uint32_t pass, int rb_slot) {
     hipStream_t s = c->stream;
     const uint32_t nt = from_frag ? (uint32_t)c->f_len.size() : c->budget_ns;
@@ -536,7 +539,8 @@ void launch_pass(scs_ctx* c, bool from_frag, uint32_t pass, int rb_slot) {
     // the two passes of a group keep their own count arrays: their totals are mailed together at the group's collect
     DevBuf& valid = from_frag ? c->valid_f : c->valid; DevBuf& valid_off = from_frag ? c->valid_off_f : c->valid_off;
     valid.reserve(((size_t)nt + 1) * 4, s); valid_off.reserve(((size_t)nt + 1) * 4, s);
-    c->slots.reserve((size_t)n_slots * 4, s); c->slot_tmpl.reserve((size_t)n_slots * 4, s);   // k_attach marks its own slots unused first
+    DevBuf& slots = from_frag ? c->slots_fr : c->slots; DevBuf& slot_tmpl = from_frag ? c->slot_tmpl_fr : c->slot_tmpl;
+    slots.reserve((size_t)n_slots * 4, s); slot_tmpl.reserve((size_t)n_slots * 4, s);   // k_attach marks its own slots unused first
     c->scan_tmp.reserve(scan_temp_bytes(nt), s);
     AmpStore& out = from_frag ? c->semis : c->fulls;
     out.reserve((uint64_t)out.n + n_slots, s);
@@ -546,9 +550,9 @@ void launch_pass(scs_ctx* c, bool from_frag, uint32_t pass, int rb_slot) {
     const uint8_t* g = c->genome.as<uint8_t>();
     KernelTimer& tma = from_frag ? c->tm_attach_f : c->tm_attach;
     tma.begin(s);
-    if (from_frag) launch_attach_frags(s, g, fr, slot_off, c->slots.as<uint32_t>(), c->slot_tmpl.as<uint32_t>(), valid.as<uint32_t>(),
+    if (from_frag) launch_attach_frags(s, g, fr, slot_off, slots.as<uint32_t>(), slot_tmpl.as<uint32_t>(), valid.as<uint32_t>(),
                                        c->primer_cnt.as<int64_t>(), c->primer_delta.as<uint32_t>(), c->dsums.as<unsigned long long>() + 4, c->poisson_part.as<unsigned long long>(), p);
-    else launch_attach_semis(s, g, fr, c->semis.view(), nt, c->semis.pool_view(), slot_off, c->slots.as<uint32_t>(), c->slot_tmpl.as<uint32_t>(),
+    else launch_attach_semis(s, g, fr, c->semis.view(), nt, c->semis.pool_view(), slot_off, slots.as<uint32_t>(), slot_tmpl.as<uint32_t>(),
                              valid.as<uint32_t>(), c->primer_cnt.as<int64_t>(), c->primer_delta.as<uint32_t>(), p);
     tma.end(s);
     tma.add_units(nt);
@@ -557,15 +561,31 @@ void launch_pass(scs_ctx* c, bool from_frag, uint32_t pass, int rb_slot) {
     // the stock update rides on k_errs (launched with at least 256 workgroups: one primer type per thread); a sharded job
     // all-reduces the decrements first
     const bool ride = !c->sharded();
-    tm.begin(s);
+    // k_errs<semi->full> writes only the new full amplicons, which nothing reads before the allocation: it runs on its own
+    // stream beside the fragment pass that follows (its chain of dependent gathers beside the attach kernel's ALU work); the
+    // stock update it used to carry runs on the main stream.  Joined before the next setPrimers rewrites the slot offsets.
+    hipStream_t es = s;
+    if (!from_frag && !getenv("SCS_ERRS_INLINE")) {
+        if (!c->errs_stream) {
+            HIP_OK(hipStreamCreateWithFlags(&c->errs_stream, hipStreamNonBlocking));
+            HIP_OK(hipEventCreateWithFlags(&c->ev_att, hipEventDisableTiming)); HIP_OK(hipEventCreateWithFlags(&c->ev_errs, hipEventDisableTiming));
+        }
+        HIP_OK(hipEventRecord(c->ev_att, s)); HIP_OK(hipStreamWaitEvent(c->errs_stream, c->ev_att, 0));
+        es = c->errs_stream;
+    }
+    tm.begin(es);
     const DevGenomeIdx gx{c->gx_gc_bits.as<unsigned long long>(), c->gx_n_bits.as<unsigned long long>(), c->gx_gc_pref.as<uint64_t>(), c->gx_n_pref.as<uint64_t>()};
-    if (from_frag) launch_errs_frags(s, g, gx, fr, n_slots, slot_off, c->slots.as<uint32_t>(), c->slot_tmpl.as<uint32_t>(), valid_off.as<uint32_t>(),
+    if (from_frag) launch_errs_frags(s, g, gx, fr, n_slots, slot_off, slots.as<uint32_t>(), slot_tmpl.as<uint32_t>(), valid_off.as<uint32_t>(),
                                      out.view(), out.n, out.pool_view(), c->flags.as<uint32_t>(), c->d_binom.as<unsigned long long>(), p,
                                      ride ? c->primer_cnt.as<int64_t>() : nullptr, c->primer_delta.as<uint32_t>(), c->dsums.as<unsigned long long>() + DS_SEMIS_N);
-    else launch_errs_semis(s, g, gx, fr, c->semis.view(), nt, c->semis.pool_view(), n_slots, slot_off, c->slots.as<uint32_t>(), c->slot_tmpl.as<uint32_t>(),
+    else launch_errs_semis(es, g, gx, fr, c->semis.view(), nt, c->semis.pool_view(), n_slots, slot_off, slots.as<uint32_t>(), slot_tmpl.as<uint32_t>(),
                            valid_off.as<uint32_t>(), out.view(), out.n, out.pool_view(), c->flags.as<uint32_t>(), c->d_binom.as<unsigned long long>(), p,
-                           ride ? c->primer_cnt.as<int64_t>() : nullptr, c->primer_delta.as<uint32_t>());
-    tm.end(s);
+                           ride && es == s ? c->primer_cnt.as<int64_t>() : nullptr, c->primer_delta.as<uint32_t>());
+    tm.end(es);
+    if (es != s) {
+        HIP_OK(hipEventRecord(c->ev_errs, es)); c->errs_pending = true;
+        if (ride) launch_primer_update(s, c->primer_cnt.as<int64_t>(), c->primer_delta.as<uint32_t>());
+    }
     if (c->sharded()) shard_exchange(c, from_frag ? valid_off.as<uint32_t>() + nt : nullptr);
     {   // counts of this pass -> mailbox (read by the host at the group's sync): new amplicons, and for a semi pass the
         // fulls made from the semis of each fragment pass (segments)
@@ -628,6 +648,7 @@ void do_amplify(scs_ctx* c) {
         // ONE wait per cycle: the counts of the previous group and this cycle's budgets come back together.  setPrimers runs
         // on the device's own semi count; the host only bounds it (count so far + slots of the fragment pass in flight).
         collect_post(c, false);
+        join_errs(c);
         set_primers_launch(c, false, i + 1, c->semis.n + semis_in_flight);
         mail_wait(c);
         collect_read(c, open_fulls, open_semis);
@@ -637,6 +658,7 @@ void do_amplify(scs_ctx* c) {
         open_fulls = 4; open_semis = i < 4 ? 5 : -1; semis_in_flight = i < 4 ? c->slots_f : 0;
         if (c->cfg.verbose) { fprintf(stderr, "semi amplicon amplification done!\n"); if (i < 4) fprintf(stderr, "fragment amplification done!\n"); }
     }
+    join_errs(c);
     c->pend.add(c->flags.p, 4, 30);                                              // the overflow flags ride on the last collect: one wait, not two
     collect_post(c, true); mail_wait(c); collect_read(c, open_fulls, open_semis);
     flags_eval(c);
@@ -1024,10 +1046,11 @@ void scs_destroy(scs_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     for (DevBuf* b : {&c->d_tables, &c->t_gap, &c->t_qcompact, &c->t_guide, &c->t_ring1, &c->t_ring2, &c->t_subs1, &c->t_subs2, &c->t_qual, &c->t_ins, &c->t_del, &c->t_isize, &c->d_subs1, &c->d_subs2, &c->d_qual, &c->d_ins, &c->d_del,
                       &c->d_isize, &c->d_gcmeans, &c->genome, &c->genome2, &c->gx_gc_bits, &c->gx_n_bits, &c->gx_gc_cnt, &c->gx_n_cnt, &c->gx_gc_pref, &c->gx_n_pref, &c->d_binom, &c->df_blob, &c->df_primers, &c->df_hasn, &c->primer_cnt, &c->primer_delta,
-                      &c->slots, &c->slot_tmpl, &c->valid, &c->valid_off, &c->valid_f, &c->valid_off_f, &c->scan_tmp, &c->flags, &c->weights, &c->read_numbers,
+                      &c->slots, &c->slot_tmpl, &c->slots_fr, &c->slot_tmpl_fr, &c->valid, &c->valid_off, &c->valid_f, &c->valid_off_f, &c->scan_tmp, &c->flags, &c->weights, &c->read_numbers,
                       &c->pair_off, &c->pairs, &c->odd_before, &c->a_part, &c->a_tp, &c->a_probs, &c->a_quota, &c->a_poff, &c->a_plan, &c->a_crn, &c->a_scratch, &c->a_brow, &c->a_bmap, &c->a_send, &c->a_gath, &c->a_odd, &c->d_hostred, &c->d_tot, &c->d_stage, &c->d_mail, &c->budget_f, &c->budget_s, &c->poisson_part, &c->slot_off_f,
                       &c->slot_off_s, &c->dsums, &c->slot_b, &c->slot_q, &c->lens, &c->ev_hdr, &c->ev_dat, &c->sizes1, &c->sizes2, &c->off1, &c->off2, &c->out1, &c->out2, &c->out1b, &c->out2b, &c->rl_cls, &c->rl_pos, &c->rl_lists, &c->d_bounds}) b->release();
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    if (c->errs_stream) { (void)hipStreamDestroy(c->errs_stream); (void)hipEventDestroy(c->ev_att); (void)hipEventDestroy(c->ev_errs); }
     if (c->pre_stream) { (void)hipStreamDestroy(c->pre_stream); (void)hipEventDestroy(c->ev_plan); for (int k = 0; k < 2; ++k) { (void)hipEventDestroy(c->ev_pre[k]); (void)hipEventDestroy(c->ev_free[k]); } }
     for (int k = 0; k < 2; ++k) if (c->ev_made[k]) (void)hipEventDestroy(c->ev_made[k]);
     c->semis.release(); c->fulls.release();
