@@ -2230,6 +2230,7 @@ void launch_batch_bounds(hipStream_t s, const uint32_t* pair_off, uint32_t ac, u
 // odd entries so far (high word) beside the halves rn >> 1 (low word); the j-th odd entry becomes rn + 1 for even j and
 // rn - 1 for odd j, so the pairs before entry i are the halves before it + the even j below its odd count -- the store
 // of the scan's result at i writes pair_off[i] and the fixed rn[i] (12 bytes per amplicon instead of 28 over three passes)
+using ScanCfg = rocprim::scan_config<256, 16, rocprim::block_load_method::block_load_transpose, rocprim::block_store_method::block_store_transpose, rocprim::block_scan_algorithm::using_warp_scan>;   // rocPRIM ships no tuned scan for gfx950: 4096 items per workgroup for the one scan over all amplicons (6.3 -> 4.6 ms; the reads stage's scans of 8 M entries beside other kernels are better off with the default's small tiles)
 struct PackOddHalf { __host__ __device__ uint64_t operator()(uint32_t v) const { return ((uint64_t)(v & 1u) << 32) | (uint64_t)(v >> 1); } };
 struct ParityOut {
     struct Ref {
@@ -2253,7 +2254,7 @@ struct ParityOut {
     __host__ __device__ difference_type operator-(const ParityOut& o) const { return (difference_type)at - (difference_type)o.at; }
 };
 void launch_parity_pair_offsets(hipStream_t s, uint32_t* rn, uint32_t ac, uint32_t* pair_cnt_off, void* temp, size_t temp_bytes) {
-    (void)rocprim::exclusive_scan(temp, temp_bytes, rocprim::make_transform_iterator((const uint32_t*)rn, PackOddHalf()), ParityOut{rn, pair_cnt_off, (size_t)ac, 0},
+    (void)rocprim::exclusive_scan<ScanCfg>(temp, temp_bytes, rocprim::make_transform_iterator((const uint32_t*)rn, PackOddHalf()), ParityOut{rn, pair_cnt_off, (size_t)ac, 0},
                                   (uint64_t)0, (size_t)ac + 1, rocprim::plus<uint64_t>(), s);
 }
 void launch_pair_offsets(hipStream_t s, const uint32_t* rn, uint32_t ac, int paired, uint32_t* pair_cnt_off, void* temp, size_t temp_bytes) {
@@ -2380,7 +2381,7 @@ size_t scan_temp_bytes(size_t n) {
     (void)rocprim::exclusive_scan(nullptr, b, rocprim::make_transform_iterator((const uint32_t*)nullptr, Widen()),
                                   (uint64_t*)nullptr, (uint64_t)0, n + 1, rocprim::plus<uint64_t>());
     size_t c3 = 0;
-    (void)rocprim::exclusive_scan(nullptr, c3, rocprim::make_transform_iterator((const uint32_t*)nullptr, PackOddHalf()), ParityOut{nullptr, nullptr, 0, 0},
+    (void)rocprim::exclusive_scan<ScanCfg>(nullptr, c3, rocprim::make_transform_iterator((const uint32_t*)nullptr, PackOddHalf()), ParityOut{nullptr, nullptr, 0, 0},
                                   (uint64_t)0, n + 1, rocprim::plus<uint64_t>());
     b = std::max(b, c3);
     return (a > b ? a : b) + 256;

@@ -68,7 +68,9 @@ struct DevBuf {
     }
     void reserve(size_t bytes, hipStream_t s, size_t keep_bytes = 0) {
         if (bytes <= cap) return;
-        size_t ncap = std::max(bytes, cap + cap / 2);
+        // a mapped buffer grows in place, chunk by chunk: it takes what is asked for plus 3 % (growing it by half, as a block that
+        // must be copied is, mapped tens of GB in the middle of a job whose amplicon count came out 0.01 % above the last one's)
+        size_t ncap = va ? bytes + bytes / 32 : std::max(bytes, cap + cap / 2);
         if (va) { map_more(std::min((ncap + kGran - 1) / kGran * kGran, va)); if (bytes > cap) throw ScsError(SCS_EOVERFLOW, "device buffer larger than its address range"); return; }
         if (ncap > virtual_from() && virtual_ok()) {
             void* base = nullptr;
@@ -103,7 +105,7 @@ struct AmpStore {            // SoA amplicon arrays (DevAmps) with capacity mana
     void reserve(uint64_t want, hipStream_t s) {
         if (want > 0xFFFFFFF0ull) throw ScsError(SCS_EOVERFLOW, "amplicon count exceeds 2^32 (reference limit: Malbac.cpp:376,386)");
         if (want <= cap) return;
-        uint64_t ncap = std::max<uint64_t>(want, (uint64_t)cap + cap / 2);
+        uint64_t ncap = uid.va ? want + want / 32 : std::max<uint64_t>(want, (uint64_t)cap + cap / 2);   // (mapped arrays grow in place: see DevBuf::reserve)
         ncap = std::min<uint64_t>(std::max<uint64_t>(ncap, 1u << 16), 0xFFFFFFF0ull);
         parent.reserve(ncap * 4, s, (size_t)n * 4); sl.reserve(ncap * 4, s, (size_t)n * 4);
         gc.reserve(ncap * 2, s, (size_t)n * 2); primers.reserve(ncap * 2, s, (size_t)n * 2);
