@@ -193,6 +193,27 @@ def committed_counters(kernel_prefix):
     return res
 
 
+def committed_lane_table():
+    """Active lanes per VALU instruction of every kernel in the newest committed SQ summary (profiles/r*_bench_sq.csv): the
+    lane-utilisation side of the kernels that are bound by instruction issue rather than by HBM."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_sq.csv")))
+    if not files:
+        return None
+    rows = {}
+    for line in open(files[-1]):
+        if line.startswith("#") or line.startswith("kernel"):
+            continue
+        f = line.rstrip("\n").rsplit(",", 3)
+        if len(f) != 4 or not f[0].startswith("scs::"):
+            continue
+        try:
+            rows[f[0][5:]] = {"lanes_per_valu_inst": float(f[2]), "valu_insts_per_launch": float(f[1]), "salu_per_valu": float(f[3]) / max(1.0, float(f[1]))}
+        except ValueError:
+            pass
+    top = dict(sorted(rows.items(), key=lambda kv: -kv[1]["valu_insts_per_launch"])[:12])   # the twelve with the most instructions per launch
+    return {"source": os.path.relpath(files[-1], ROOT), "kernels": top} if top else None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -405,6 +426,7 @@ def main():
                        "collectives": coll_path,
                        "output": "FASTQ text generated batch by batch into HBM buffers (NULL sink)"},
             "roofline": roof,
+            "lane_utilisation": committed_lane_table(),
             "stages_s_per_step": {k: v / a.steps for k, v in stage.items()},
             "kernels_ms_per_step": {k: v["ms"] / a.steps for k, v in ktimes.items()},
             "setup_s": {"genome_generated_in_hbm": t_gen, "genome_staged_(encode+bit_index)": t_up},
