@@ -209,6 +209,10 @@ int         scs_fasta_probe(const char* fasta_path, int* n_records, uint64_t* to
  * checksum of the FASTA text scs_simuvars would write (no GPU; the test seam of the planner). */
 int         scs_simuvars_probe(const char* ref_fasta, const char* snp_file, const char* var_file, int* n_records, uint64_t* total_bases,
                                uint64_t* checksum, char* errbuf, size_t errlen);
+/* Test seam of the device-buffer policy (needs a GPU, touches no ctx): a library buffer is reserved with first_bytes, then
+ * with second_bytes; caps[0..1] receive its usable capacity after each step and *in_place whether the second step kept its
+ * address.  Buffers above 64 MB (SCS_VMM_FROM_MB) live in a reserved address range and grow in place, by the request + 3 %. */
+int         scs_devbuf_probe(int device, uint64_t first_bytes, uint64_t second_bytes, uint64_t* caps, int* in_place);
 /* Host-only: leave <fasta_path>.fai beside the file if there is none, exactly as scs_load_genome_fasta does (the
  * reference indexes its input through fastahack, lib/fastahack/Fasta.cpp:241-249: name, length, offset, bases per
  * line, bytes per line). */

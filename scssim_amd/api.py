@@ -136,6 +136,18 @@ def fasta_write_index(path):
         raise ScsError(rc, err.value.decode())
 
 
+def devbuf_probe(first_bytes, second_bytes, device=0):
+    """Test seam (needs a GPU): capacities of a library device buffer after reserve(first) and reserve(second), and
+    whether the second reserve kept the buffer's address."""
+    L = load_library()
+    L.scs_devbuf_probe.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_int)]
+    caps, same = (C.c_uint64 * 2)(), C.c_int()
+    rc = L.scs_devbuf_probe(device, first_bytes, second_bytes, caps, C.byref(same))
+    if rc:
+        raise ScsError(rc, (L.scs_last_error(None) or b"").decode())
+    return caps[0], caps[1], bool(same.value)
+
+
 def fasta_probe(path):
     """Host-only: (names, total bases, FNV-1a checksum of the upper-cased sequence) as the library stages the file."""
     L = load_library()

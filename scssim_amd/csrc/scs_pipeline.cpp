@@ -1337,6 +1337,19 @@ int scs_fasta_probe(const char* path, int* n_records, uint64_t* total_bases, uin
     if (names_buf && names_len) { strncpy(names_buf, names.c_str(), names_len - 1); names_buf[names_len - 1] = 0; }
     return SCS_OK;
 }
+int scs_devbuf_probe(int device, uint64_t first_bytes, uint64_t second_bytes, uint64_t* caps, int* in_place) {
+    if (!caps) return SCS_EINVAL;
+    DevBuf b;
+    try {
+        HIP_OK(hipSetDevice(device));
+        b.reserve((size_t)first_bytes, nullptr); caps[0] = b.cap;
+        const void* at = b.p;
+        b.reserve((size_t)second_bytes, nullptr); caps[1] = b.cap;
+        if (in_place) *in_place = b.p == at ? 1 : 0;
+        b.release();
+        return SCS_OK;
+    } catch (const std::exception& e) { b.release(); g_create_error = e.what(); return SCS_EDEVICE; }
+}
 // host-only: the simuvars plan applied to the host copy of the reference, folded into a checksum of the FASTA text that
 // scs_simuvars would write (test seam for the planner; the product builds the sequences on the device)
 int scs_simuvars_probe(const char* ref_fasta, const char* snp_file, const char* var_file, int* n_records, uint64_t* total_bases, uint64_t* checksum, char* errbuf, size_t errlen) {

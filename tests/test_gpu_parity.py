@@ -726,6 +726,19 @@ def test_read_class_fallbacks_match_oracle(knob, models, tmp_path):
     assert r.returncode == 0, r.stdout[-3000:]
 
 
+def test_mapped_buffer_grows_in_place_by_what_is_asked():
+    """A device buffer above 64 MB lives in a reserved address range and grows by mapping more memory behind it: it must keep
+    its address and take the request + 3 % (rounded to the 128 MB mapping unit), not half its size again -- a whole-genome job
+    whose slot count came out 0.01 % above the previous job's used to map ~25 GB in the middle of a timed step.  A small
+    buffer is a plain block: it moves, and grows by half so that it is not copied at every step."""
+    GB, MB = 1 << 30, 1 << 20
+    c0, c1, same = scssim_amd.devbuf_probe(2 * GB, 2 * GB + MB)
+    assert 2 * GB <= c0 <= 2 * GB + 128 * MB
+    assert same and 2 * GB + MB <= c1 <= c0 + (2 * GB) // 25 + 128 * MB, (c0, c1, same)
+    a0, a1, _ = scssim_amd.devbuf_probe(MB, MB + 1)
+    assert a0 >= MB and a1 >= MB + MB // 2, (a0, a1)
+
+
 def test_mapped_buffers_parity(models, tmp_path):
     """Device buffers above 64 MB live in a reserved address range and grow by mapping more memory behind them (HIP virtual
     memory management).  The parity cases are far smaller, so they run once more in a child process with the threshold at
