@@ -310,12 +310,14 @@ void launch_frag_has_n(hipStream_t s, const uint64_t* goff, const uint32_t* len,
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t u4_word(const U4& d, uint32_t k) { return k == 0 ? d.w[0] : k == 1 ? d.w[1] : k == 2 ? d.w[2] : d.w[3]; }
 template <bool FROM_FRAG>
-__global__ void __launch_bounds__(256) k_errs(const uint8_t* __restrict__ g, DevGenomeIdx gx, DevFrags fr, DevAmps semis, DevErrPool spool,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) k_errs(const uint8_t* __restrict__ g, DevGenomeIdx gx, DevFrags fr, DevAmps semis, DevErrPool spool,
                                               uint32_t n_slots, const uint32_t* __restrict__ slot_off, const uint32_t* __restrict__ slots,
                                               const uint32_t* __restrict__ slot_tmpl, const uint32_t* __restrict__ valid_off, uint32_t n_tmpl,
                                               DevAmps out, uint32_t out_base, DevErrPool pool, uint32_t* __restrict__ flags,
                                               const unsigned long long* __restrict__ binom, AmplifyParams p,
                                               int64_t* __restrict__ primer_cnt, uint32_t* __restrict__ primer_delta, unsigned long long* __restrict__ semis_n) {
+    __shared__ uint16_t s_item[4][256], s_res[4][256];                             // per wave: the errors of its amplicons (owner lane | index << 6), and what came back
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
     // the pass epilogue rides along (unsharded job; a sharded one all-reduces the decrements first and launches
     // k_primer_update): primer stock -= this pass's decrements, clamped ([REMAP] snapshot per pass), and the device-side
@@ -324,97 +326,136 @@ __global__ void __launch_bounds__(256) k_errs(const uint8_t* __restrict__ g, Dev
     if (FROM_FRAG && w == 0 && semis_n) *semis_n += valid_off[n_tmpl];
     // fragments: a thread per reserved slot (nearly all of them are used).  Semi amplicons: three quarters of the reserved
     // slots stay unused (most primers find no place on a 1-2 kb template), so k_expand_items has listed the template of every
-    // amplicon actually made (slot_tmpl reused as that dense map) and the thread index IS the amplicon
-    uint32_t t, i;
+    // amplicon actually made (slot_tmpl reused as that dense map) and the thread index IS the amplicon.
+    // (no lane leaves before the wave has resolved its errors together: see below)
+    uint32_t t = 0, i = 0;
+    bool active;
     if (FROM_FRAG) {
-        if (w >= n_slots) return;
-        t = slot_tmpl[w];
-        if (t == 0xFFFFFFFFu) return;                  // reserved but unused slot (aborted template)
-        i = w - slot_off[t];
+        active = w < n_slots;
+        if (active) { t = slot_tmpl[w]; active = t != 0xFFFFFFFFu; }              // reserved but unused slot (aborted template)
+        if (active) i = w - slot_off[t];
     } else {
-        if (w >= valid_off[n_tmpl]) return;
-        t = slot_tmpl[w]; i = w - valid_off[t];
-    }
-    const uint32_t n_fwd = valid_off[t] + i, n_new = valid_off[n_tmpl];
-    const uint32_t sl = slots[slot_off[t] + i], spos = sl_spos(sl), alen = sl_len(sl);
-    View tv; uint64_t perrs = 0, nuid; uint32_t plen = 0;
-    if (FROM_FRAG) { tv = frag_view(fr.goff[t], fr.len[t], fr.strand[t]); nuid = semi_uid(fr.gidx_base + t, p.pass, i); }
-    else {
-        const uint32_t f = semis.parent[t], psl = semis.sl[t];
-        plen = sl_len(psl); perrs = semis.errs[t];
-        tv = semi_tmpl_view(frag_view(fr.goff[f], fr.len[f], fr.strand[f]), sl_spos(psl), plen);
-        nuid = full_uid(semis.uid[t], p.pass, i);
+        active = w < valid_off[n_tmpl];
+        if (active) { t = slot_tmpl[w]; i = w - valid_off[t]; }
     }
     const uint32_t kind = FROM_FRAG ? 0u : 1u;
-    // ---- GC / N of the template window [spos, spos+alen)
-    const int64_t first = tv.base + (int64_t)tv.dir * (int64_t)spos;
-    const uint64_t ga = (uint64_t)(tv.dir > 0 ? first : first - (int64_t)(alen - 1)), gb = ga + alen;
-    int gc = (int)(bit_rank(gx.gc_bits, gx.gc_pref, gb) - bit_rank(gx.gc_bits, gx.gc_pref, ga));
-    // the N count costs four more scattered loads: skipped for the templates of a fragment without any N (nearly all)
-    int nn = fr.has_n[FROM_FRAG ? t : semis.parent[t]] ? (int)(bit_rank(gx.n_bits, gx.n_pref, gb) - bit_rank(gx.n_bits, gx.n_pref, ga)) : 0;
-    if (!FROM_FRAG) for_each_err(perrs, spool.data, [&](uint32_t e) {
-        const uint32_t tp = plen - 1 - err_pos(e);
-        if (tp >= spos && tp < spos + alen) {
-            const uint32_t orig = g[tv.base + (int64_t)tv.dir * (int64_t)tp];
-            if (orig > 3) --nn; else gc -= is_gc(orig) ? 1 : 0;
-            gc += is_gc(err_alt(e)) ? 1 : 0;                                       // complement keeps GC-ness
+    uint32_t n_fwd = 0, spos = 0, alen = 0, plen = 0, K = 0, ntr = 0; uint64_t perrs = 0, nuid = 0, P = 0; int gcn = 0;
+    View tv{0, 1, 0}; U4 d0{};
+    if (active) {
+        n_fwd = valid_off[t] + i;
+        const uint32_t sl = slots[slot_off[t] + i];
+        spos = sl_spos(sl); alen = sl_len(sl);
+        if (FROM_FRAG) { tv = frag_view(fr.goff[t], fr.len[t], fr.strand[t]); nuid = semi_uid(fr.gidx_base + t, p.pass, i); }
+        else {
+            const uint32_t f = semis.parent[t], psl = semis.sl[t];
+            plen = sl_len(psl); perrs = semis.errs[t];
+            tv = semi_tmpl_view(frag_view(fr.goff[f], fr.len[f], fr.strand[f]), sl_spos(psl), plen);
+            nuid = full_uid(semis.uid[t], p.pass, i);
         }
-    });
-    int gcn = nn > 0 ? 0 : gc;                                                     // countGC: 0 if any N
-    // ---- error count and positions
-    const uint32_t ntr = alen - 8;
-    const U4 d0 = draw4(p.key, ST_ERR, kind, nuid, 0);
-    const unsigned long long x64 = ((unsigned long long)d0.w[0] << 32) | d0.w[1];
-    const unsigned long long* __restrict__ Tn = binom + (size_t)(ntr - (p.amp_min - 8)) * BINOM_KMAX;
-    uint32_t K = 0;
-    while (K < (uint32_t)BINOM_KMAX && x64 >= Tn[K]) ++K;
-    uint64_t packed = 0;
-    // the K positions (sorted) and then the K entries: in four registers for K <= 4; the 2 amplicons in 10 000 with more keep
-    // them in their slice of the overflow pool, where the entries end up anyway (two 16-entry register arrays cost the kernel
-    // a wave per SIMD, and it lives on its waves in flight: a chain of dependent gathers)
-    auto resolve = [&](uint32_t j) {                                               // entry of the error at position j; its GC change goes to gcn
-        const uint32_t base = FROM_FRAG ? view_base(g, tv, spos + j) : semi_tmpl_base(g, tv, plen, perrs, spool.data, spos + j);
-        uint32_t alt, a = 0;
-        do {                                                                       // do { n = rand } while (bases[n] == base)
-            const U4 e = draw4(p.key, ST_ERRALT, kind, nuid, j | ((a >> 2) << 16));
-            alt = u4_word(e, a & 3) >> 30; ++a;                                    // trunc(4 * x / 2^32)
-        } while (alt == base);
-        gcn += (is_gc(alt) ? 1 : 0) - (is_gc(base) ? 1 : 0);
-        return err_pack(j, alt);
-    };
-    if (K && K <= 4) {
-        uint64_t P = 0;                                                            // sorted positions, 16 bits each
-        uint32_t cnt = 0, q = 0; U4 d = d0;
-        while (cnt < K) {
-            if ((q & 3) == 0) d = draw4(p.key, ST_ERR, kind, nuid, 1 + (q >> 2));
-            const uint32_t cand = 8 + scale_draw(u4_word(d, q & 3), 0, ntr); ++q;
-            bool dup = false; uint32_t below = 0;
-            for (uint32_t z = 0; z < cnt; ++z) { const uint32_t v = (uint32_t)(P >> (16 * z)) & 0xFFFFu; dup |= v == cand; below += v < cand ? 1u : 0u; }
-            if (!dup) {                                                            // insert sorted
-                const uint64_t low = (1ull << (16 * below)) - 1ull;
-                P = (P & low) | ((uint64_t)cand << (16 * below)) | ((P & ~low) << 16);
-                ++cnt;
+        // ---- GC / N of the template window [spos, spos+alen)
+        const int64_t first = tv.base + (int64_t)tv.dir * (int64_t)spos;
+        const uint64_t ga = (uint64_t)(tv.dir > 0 ? first : first - (int64_t)(alen - 1)), gb = ga + alen;
+        int gc = (int)(bit_rank(gx.gc_bits, gx.gc_pref, gb) - bit_rank(gx.gc_bits, gx.gc_pref, ga));
+        // the N count costs four more scattered loads: skipped for the templates of a fragment without any N (nearly all)
+        int nn = fr.has_n[FROM_FRAG ? t : semis.parent[t]] ? (int)(bit_rank(gx.n_bits, gx.n_pref, gb) - bit_rank(gx.n_bits, gx.n_pref, ga)) : 0;
+        if (!FROM_FRAG) for_each_err(perrs, spool.data, [&](uint32_t e) {
+            const uint32_t tp = plen - 1 - err_pos(e);
+            if (tp >= spos && tp < spos + alen) {
+                const uint32_t orig = g[tv.base + (int64_t)tv.dir * (int64_t)tp];
+                if (orig > 3) --nn; else gc -= is_gc(orig) ? 1 : 0;
+                gc += is_gc(err_alt(e)) ? 1 : 0;                                   // complement keeps GC-ness
+            }
+        });
+        gcn = nn > 0 ? 0 : gc;                                                     // countGC: 0 if any N
+        // ---- error count and positions
+        ntr = alen - 8;
+        d0 = draw4(p.key, ST_ERR, kind, nuid, 0);
+        const unsigned long long x64 = ((unsigned long long)d0.w[0] << 32) | d0.w[1];
+        const unsigned long long* __restrict__ Tn = binom + (size_t)(ntr - (p.amp_min - 8)) * BINOM_KMAX;
+        while (K < (uint32_t)BINOM_KMAX && x64 >= Tn[K]) ++K;
+        // the K positions, sorted: 16 bits each of one register for K <= 4; the 2 amplicons in 10 000 with more keep them (and
+        // then their entries) in their slice of the overflow pool (two 16-entry register arrays cost the kernel a wave per SIMD)
+        if (K && K <= 4) {
+            uint32_t cnt = 0, q = 0; U4 d = d0;
+            while (cnt < K) {
+                if ((q & 3) == 0) d = draw4(p.key, ST_ERR, kind, nuid, 1 + (q >> 2));
+                const uint32_t cand = 8 + scale_draw(u4_word(d, q & 3), 0, ntr); ++q;
+                bool dup = false; uint32_t below = 0;
+                for (uint32_t z = 0; z < cnt; ++z) { const uint32_t v = (uint32_t)(P >> (16 * z)) & 0xFFFFu; dup |= v == cand; below += v < cand ? 1u : 0u; }
+                if (!dup) {                                                        // insert sorted
+                    const uint64_t low = (1ull << (16 * below)) - 1ull;
+                    P = (P & low) | ((uint64_t)cand << (16 * below)) | ((P & ~low) << 16);
+                    ++cnt;
+                }
             }
         }
-        for (uint32_t z = 0; z < K; ++z) packed |= (uint64_t)resolve((uint32_t)(P >> (16 * z)) & 0xFFFFu) << (16 * z);
+    }
+    // entry of the error at position j of an amplicon (template base through the parent's substitutions, alternative base by
+    // rejection) and its GC change
+    auto resolve = [&](View v, uint32_t pl, uint64_t pe, uint32_t sp, uint64_t uid, uint32_t j, int& dgc) {
+        const uint32_t base = FROM_FRAG ? view_base(g, v, sp + j) : semi_tmpl_base(g, v, pl, pe, spool.data, sp + j);
+        uint32_t alt, a = 0;
+        do {                                                                       // do { n = rand } while (bases[n] == base)
+            const U4 e = draw4(p.key, ST_ERRALT, kind, uid, j | ((a >> 2) << 16));
+            alt = u4_word(e, a & 3) >> 30; ++a;                                    // trunc(4 * x / 2^32)
+        } while (alt == base);
+        dgc = (is_gc(alt) ? 1 : 0) - (is_gc(base) ? 1 : 0);
+        return err_pack(j, alt);
+    };
+    // ---- the wave resolves its errors together: 0.51 per amplicon, but 60 % of the amplicons have none and a lane with three
+    // kept the other 63 waiting three rounds.  Every error becomes an item (owner lane, index); a lane takes ONE item, fetches
+    // the owner's view by shuffles, and hands the entry back through LDS.
+    const uint32_t cnt = K <= 4 ? K : 0u;
+    uint32_t incl = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t v = __shfl_up(incl, d); if ((int)lane >= d) incl += v; }
+    const uint32_t pre = incl - cnt, total = __shfl(incl, 63);
+    for (uint32_t z = 0; z < cnt; ++z) s_item[wv][pre + z] = (uint16_t)(lane | (z << 6));
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t b = 0; b < total; b += 64) {
+        const uint32_t it = b + lane; const bool valid = it < total;
+        const uint32_t e = valid ? s_item[wv][it] : 0u, o = e & 63u, z = e >> 6;
+        View ov; uint64_t ope, ouid, oP;
+        {
+            const uint32_t lo = __shfl((uint32_t)(uint64_t)tv.base, o), hi = __shfl((uint32_t)((uint64_t)tv.base >> 32), o);
+            ov.base = (int64_t)(((uint64_t)hi << 32) | lo);
+            const uint32_t fl = __shfl((uint32_t)(tv.dir > 0 ? 1u : 0u) | (tv.comp << 1), o);
+            ov.dir = (fl & 1u) ? 1 : -1; ov.comp = fl >> 1;
+            ope = ((uint64_t)__shfl((uint32_t)(perrs >> 32), o) << 32) | __shfl((uint32_t)perrs, o);
+            ouid = ((uint64_t)__shfl((uint32_t)(nuid >> 32), o) << 32) | __shfl((uint32_t)nuid, o);
+            oP = ((uint64_t)__shfl((uint32_t)(P >> 32), o) << 32) | __shfl((uint32_t)P, o);
+        }
+        const uint32_t opl = __shfl(plen, o), osp = __shfl(spos, o);
+        if (valid) {
+            int dgc;
+            const uint32_t ent = resolve(ov, opl, ope, osp, ouid, (uint32_t)(oP >> (16 * z)) & 0xFFFFu, dgc);
+            s_res[wv][it] = (uint16_t)(ent | ((uint32_t)(dgc + 1) << 13));        // entry: 13 bits; GC change + 1 above
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (!active) return;
+    uint64_t packed = 0;
+    if (cnt) {
+        for (uint32_t z = 0; z < cnt; ++z) { const uint32_t r = s_res[wv][pre + z]; packed |= (uint64_t)(r & 0x1FFFu) << (16 * z); gcn += (int)(r >> 13) - 1; }
     } else if (K) {
         const uint32_t off = atomicAdd(pool.head, K);
         if (off + K > pool.cap) atomicOr(flags, (uint32_t)FLAG_ERRPOOL);
         else {
             uint32_t* pos = pool.data + off;
-            uint32_t cnt = 0, q = 0; U4 d = d0;
-            while (cnt < K) {
+            uint32_t c2 = 0, q = 0; U4 d = d0;
+            while (c2 < K) {
                 if ((q & 3) == 0) d = draw4(p.key, ST_ERR, kind, nuid, 1 + (q >> 2));
                 const uint32_t cand = 8 + scale_draw(u4_word(d, q & 3), 0, ntr); ++q;
                 bool dup = false;
-                for (uint32_t z = 0; z < cnt; ++z) dup |= pos[z] == cand;
-                if (!dup) { uint32_t z = cnt++; while (z > 0 && pos[z - 1] > cand) { pos[z] = pos[z - 1]; --z; } pos[z] = cand; }
+                for (uint32_t z = 0; z < c2; ++z) dup |= pos[z] == cand;
+                if (!dup) { uint32_t z = c2++; while (z > 0 && pos[z - 1] > cand) { pos[z] = pos[z - 1]; --z; } pos[z] = cand; }
             }
-            for (uint32_t z = 0; z < K; ++z) pos[z] = resolve(pos[z]);
+            for (uint32_t z = 0; z < K; ++z) { int dgc; pos[z] = resolve(tv, plen, perrs, spos, nuid, pos[z], dgc); gcn += dgc; }
             packed = ERR_OVERFLOW_BIT | ((uint64_t)K << 32) | off;
         }
     }
     if (gcn < 0) gcn = 0;                                                          // max(0, gcNum)
+    const uint32_t n_new = valid_off[n_tmpl];
     const uint32_t dst = out_base + (n_new - 1 - n_fwd);                          // reversed within the pass: insertLinkList prepends
     out.parent[dst] = t; out.sl[dst] = pack_sl(spos, alen); out.gc[dst] = (uint16_t)gcn; out.primers[dst] = 0;
     out.uid[dst] = nuid; out.errs[dst] = packed;
