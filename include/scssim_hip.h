@@ -128,6 +128,14 @@ int         scs_run_genreads(scs_ctx* ctx, scs_sink_fn sink, void* user);
 
 int         scs_get_stats(const scs_ctx* ctx, scs_stats* out);
 
+/* Integrity of text that never leaves the GPU (a NULL sink) or crosses PCIe: with on != 0 every batch of the next scs_yield_reads /
+ * scs_yield_reads_files gets a 64-bit checksum per mate, computed by a kernel where the text lies in HBM -- the text as
+ * little-endian 64-bit words w_i (the last zero-padded): sum_i fmix64(w_i + (i + 1) * 0x9E3779B97F4A7C15) mod 2^64, fmix64 = the
+ * MurmurHash3 finaliser.  scs_batch_checksums: out[2 b], out[2 b + 1] = batch b's two mates, in record order (cap: entries of
+ * out); *n_batches = batches of the last call.  Not computed for scs_yield_reads_device. */
+int         scs_set_batch_checksums(scs_ctx* ctx, int on);
+int         scs_batch_checksums(const scs_ctx* ctx, uint64_t* out, size_t cap, size_t* n_batches);
+
 /* ---- one job over several GPUs (scs_config.shard_rank / shard_count: fragment-lineage sharding) -------------
  * The reference is single-process; these are the exchange steps its globals imply once fragments are split over
  * ranks: Malbac::setPrimers totals (Malbac.cpp:242-262,282), the primer stock (Malbac.cpp:91-103) and the weight
@@ -155,16 +163,27 @@ int         scs_set_collectives_device(scs_ctx* ctx, scs_allreduce_dev_fn allred
 #define SCS_COMM_ID_BYTES 128
 int         scs_comm_unique_id(void* id_out);
 int         scs_comm_init(scs_ctx* ctx, const void* id, int rank, int nranks);
+/* ranks of the ctx's communicator as RCCL reports them (ncclCommCount); 0 without a communicator */
+int         scs_comm_count(const scs_ctx* ctx);
+/* ncclCommAbort on the ctx's communicator, callable from ANOTHER thread than the one blocked in a collective: how a driver
+ * that has seen a rank die releases its own rank before it leaves (the ctx is only good for scs_destroy afterwards) */
+int         scs_comm_abort(scs_ctx* ctx);
 
 /* ---- FASTQ straight to files (SeqWriter, lib/seqwriter/SeqWriter.cpp:12-64; opened by Malbac::yieldReads, Malbac.cpp:426-435)
- * Whole job (shard_count == 1): <prefix>_1.fq / <prefix>_2.fq, or <prefix>.fq for SE -- the reference's files.
+ * writers <= 1: the reference's files.  Whole job (shard_count == 1): <prefix>_1.fq / <prefix>_2.fq, or <prefix>.fq for SE.
  * Sharded job: this shard's records go to <prefix>.r<rank>_1.fq / _2.fq (.fq) and <prefix>.r<rank>.idx lists the byte offset
  * at which each of the shard's list segments starts.  The whole job's file is the shards' segments interleaved in list
  * order, so scs_merge_fastq_shards rebuilds it by copying byte ranges (copy_file_range, a few threads) -- it parses no
- * record -- and the result equals the unsharded job's files byte for byte.  writer_threads: slices per file and batch written in parallel;
- * <= 0 = 1, the fastest on tmpfs (writes into one file serialise on its inode lock; the two files always go in parallel). */
-int         scs_yield_reads_files(scs_ctx* ctx, const char* prefix, int writer_threads);
+ * record -- and the result equals the unsharded job's files byte for byte.
+ * writers = K > 1 (at most 64): buffered writes into ONE file serialise on its inode lock (5.7 GB/s per file on the GPU
+ * box's tmpfs whatever the thread count), so the job's (shard's) records are cut into K contiguous ranges, made round-robin,
+ * and written by K threads into K PART files per mate: <base>.p00_1.fq ... <base>.p<K-1>_1.fq (+ _2.fq; .p<kk>.fq for SE),
+ * base = <prefix> or <prefix>.r<rank>.  Their concatenation in that order IS the single file (`cat <base>.p*_1.fq`);
+ * <base>.parts lists their sizes; scs_merge_fastq_parts / scs_merge_fastq_shards read parts and single files alike. */
+int         scs_yield_reads_files(scs_ctx* ctx, const char* prefix, int writers);
 int         scs_merge_fastq_shards(const char* prefix, int nranks, int paired, int keep_shards, char* errbuf, size_t errlen);
+/* host only: <prefix>.p*_1.fq ... -> <prefix>_1.fq ... (byte-range copies; parts removed unless keep_parts) */
+int         scs_merge_fastq_parts(const char* prefix, int paired, int keep_parts, char* errbuf, size_t errlen);
 
 /* ---- kernel-level entry points (unit parity tests; same kernels as the pipeline) ------------ */
 

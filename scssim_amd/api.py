@@ -102,6 +102,40 @@ def merge_fastq_shards(prefix, nranks, paired=True, keep_shards=False):
         raise ScsError(rc, err.value.decode())
 
 
+def merge_fastq_parts(prefix, paired=True, keep_parts=False):
+    """Host-only: <prefix>.p*_1.fq ... (written by yield_reads_files(prefix, writers=K)) -> <prefix>_1.fq ... by byte-range
+    copies; the parts and <prefix>.parts are removed unless keep_parts."""
+    L = load_library()
+    L.scs_merge_fastq_parts.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_char_p, C.c_size_t]
+    err = C.create_string_buffer(512)
+    rc = L.scs_merge_fastq_parts(os.fsencode(prefix), int(paired), int(keep_parts), err, 512)
+    if rc:
+        raise ScsError(rc, err.value.decode())
+
+
+def part_paths(base, parts, paired=True, suffix=".fq"):
+    """The files yield_reads_files(base, writers=parts) writes, per mate, in record order."""
+    mates = ("_1", "_2") if paired else ("",)
+    if parts <= 1:
+        return [[base + m + suffix] for m in mates]
+    return [[base + ".p%02d" % k + m + suffix for k in range(parts)] for m in mates]
+
+
+def text_checksum(data):
+    """The library's batch checksum (scs_set_batch_checksums) of a bytes-like object, in numpy: the text as little-endian 64-bit
+    words w_i (the last zero-padded), sum_i fmix64(w_i + (i + 1) * 0x9E3779B97F4A7C15) mod 2^64."""
+    import numpy as np
+    b = np.frombuffer(data, np.uint8)
+    pad = (-len(b)) % 8
+    if pad:
+        b = np.concatenate([b, np.zeros(pad, np.uint8)])
+    w = b.view("<u8").astype(np.uint64)
+    with np.errstate(over="ignore"):
+        x = w + (np.arange(1, len(w) + 1, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15))
+        x ^= x >> np.uint64(33); x *= np.uint64(0xFF51AFD7ED558CCD); x ^= x >> np.uint64(33); x *= np.uint64(0xC4CEB9FE1A85EC53); x ^= x >> np.uint64(33)
+        return int(np.add.reduce(x, dtype=np.uint64)) if len(x) else 0
+
+
 COMM_ID_BYTES = 128
 
 
@@ -318,9 +352,11 @@ class GenReads:
         cb = _SINK(sink) if sink is not None else _SINK()
         self._ck(self._L.scs_yield_reads(self._ctx, cb, None))
 
-    def yield_reads_files(self, prefix, writer_threads=0):
-        """Malbac::yieldReads + SeqWriter: <prefix>_1.fq/_2.fq (.fq), or this shard's <prefix>.r<rank>_*.fq + .idx."""
-        self._ck(self._L.scs_yield_reads_files(self._ctx, os.fsencode(prefix), int(writer_threads)))
+    def yield_reads_files(self, prefix, writers=0):
+        """Malbac::yieldReads + SeqWriter: <prefix>_1.fq/_2.fq (.fq), or this shard's <prefix>.r<rank>_*.fq + .idx.
+        writers = K > 1: K part files per mate (<base>.p00_1.fq ...: contiguous record ranges, one writer thread each; their
+        concatenation is the single file) + <base>.parts."""
+        self._ck(self._L.scs_yield_reads_files(self._ctx, os.fsencode(prefix), int(writers)))
 
     def comm_init(self, comm_id, rank, nranks):
         """RCCL inside the library: every rank of a sharded job calls this with rank 0's comm_unique_id()."""
@@ -362,6 +398,20 @@ class GenReads:
             open(prefix + "_2.fq", "wb").write(fq2)
         else:
             open(prefix + ".fq", "wb").write(fq1)
+
+    def set_batch_checksums(self, on=True):
+        """Every batch of the following yield_reads* calls gets a 64-bit checksum per mate, computed on the device."""
+        self._L.scs_set_batch_checksums.argtypes = [C.c_void_p, C.c_int]
+        self._ck(self._L.scs_set_batch_checksums(self._ctx, int(on)))
+
+    def batch_checksums(self):
+        """[(mate 1, mate 2), ...] of the last yield call's batches, in record order (see text_checksum)."""
+        self._L.scs_batch_checksums.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+        n = C.c_size_t()
+        self._ck(self._L.scs_batch_checksums(self._ctx, None, 0, C.byref(n)))
+        out = (C.c_uint64 * (2 * n.value))()
+        self._ck(self._L.scs_batch_checksums(self._ctx, out, 2 * n.value, C.byref(n)))
+        return [(out[2 * i], out[2 * i + 1]) for i in range(n.value)]
 
     # ---- introspection
     def stats(self):

@@ -11,6 +11,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <thread>
@@ -26,6 +27,8 @@ struct RcclApi {
     ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
@@ -48,6 +51,7 @@ RcclApi& api() {
         auto sym = [&](const char* n) { void* p = dlsym(r.h, n); if (!p && r.why.empty()) r.why = std::string("RCCL symbol missing: ") + n; return p; };
         r.GetUniqueId = (decltype(r.GetUniqueId))sym("ncclGetUniqueId"); r.CommInitRank = (decltype(r.CommInitRank))sym("ncclCommInitRank");
         r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy"); r.AllReduce = (decltype(r.AllReduce))sym("ncclAllReduce");
+        r.CommAbort = (decltype(r.CommAbort))sym("ncclCommAbort"); r.CommCount = (decltype(r.CommCount))sym("ncclCommCount");
         r.AllGather = (decltype(r.AllGather))sym("ncclAllGather"); r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
         return r;
     }();
@@ -59,7 +63,7 @@ bool ok(ncclResult_t r, const char* what, std::string& err) {
 }
 }  // namespace
 
-struct RcclComm { ncclComm_t comm = nullptr; int rank = 0, nranks = 1; };
+struct RcclComm { ncclComm_t comm = nullptr; int rank = 0, nranks = 1; std::atomic<bool> aborted{false}; };
 
 int rccl_unique_id(void* id128, std::string& err) {
     RcclApi& a = api();
@@ -85,59 +89,96 @@ int rccl_allreduce_sum(RcclComm* c, void* d, uint64_t n, int elem_bytes, hipStre
 int rccl_allgather(RcclComm* c, const void* d_send, void* d_recv, uint64_t bytes, hipStream_t s, std::string& err) {
     return ok(api().AllGather(d_send, d_recv, (size_t)bytes, ncclUint8, c->comm, s), "ncclAllGather", err) ? 0 : 1;
 }
-void rccl_destroy(RcclComm* c) { if (!c) return; if (c->comm && api().CommDestroy) (void)api().CommDestroy(c->comm); delete c; }
+void rccl_destroy(RcclComm* c) { if (!c) return; if (c->comm && !c->aborted.load() && api().CommDestroy) (void)api().CommDestroy(c->comm); delete c; }
+int rccl_count(RcclComm* c) { int n = 0; if (!c || !c->comm || !api().CommCount || api().CommCount(c->comm, &n) != ncclSuccess) return 0; return n; }
+void rccl_abort(RcclComm* c) { if (c && c->comm && api().CommAbort && !c->aborted.exchange(true)) (void)api().CommAbort(c->comm); }
 
 // ------------------------------------------------------------------------------------------------ files
-FastqFiles::~FastqFiles() { (void)close(); }
-bool FastqFiles::open(const std::string& p1, const std::string& p2, int threads, std::string& err) {
-    threads_ = std::max(1, threads);
-    fd_[0] = ::open(p1.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
-    if (fd_[0] < 0) { err = "Error: can not open fastq file to save results:\n" + p1; return false; }
-    if (!p2.empty()) { fd_[1] = ::open(p2.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644); if (fd_[1] < 0) { err = "Error: can not open fastq file to save results:\n" + p2; return false; } }
-    pos_[0] = pos_[1] = 0; total_[0] = total_[1] = 0; failed_ = false;
-    return true;
-}
 static bool pwrite_all(int fd, const char* p, size_t n, uint64_t off) {
     while (n) { const ssize_t w = ::pwrite(fd, p, n, (off_t)off); if (w < 0) { if (errno == EINTR) continue; return false; } p += w; n -= (size_t)w; off += (uint64_t)w; }
     return true;
 }
-// A batch = one pwrite() per file, the two files in parallel.  More writers per file do not help: writes into ONE file
-// serialise on its inode lock (measured on the GPU box's tmpfs: 5.7 GB/s per file with 1, 4, 8 or 16 threads slicing it,
-// against 39 GB/s for 8 threads on 8 files), and filling a shared mapping of the file from several threads is slower still
-// (3.8 GB/s: the page faults contend).  `threads_` > 1 slices a file anyway for file systems where it pays.
-bool FastqFiles::write(const char* a, size_t na, const char* b, size_t nb) {
-    if (failed_) return false;
-    struct Slice { int fd; const char* p; size_t n; uint64_t off; };
-    std::vector<Slice> sl;
-    const size_t grain = 8u << 20;
-    auto cut = [&](int k, const char* p, size_t n) {
-        if (!n || fd_[k] < 0) return;
-        if (recycle_ && pos_[k] > recycle_) { if (ftruncate(fd_[k], 0) != 0) failed_ = true; pos_[k] = 0; }
-        const size_t parts = std::max<size_t>(1, std::min<size_t>((size_t)threads_, n / grain)), per = (n + parts - 1) / parts;
-        for (size_t o = 0; o < n; o += per) sl.push_back(Slice{fd_[k], p + o, std::min(per, n - o), pos_[k] + o});
-        pos_[k] += n; total_[k] += n;
-    };
-    cut(0, a, na); cut(1, b, nb);
-    if (sl.empty()) return !failed_;
-    std::vector<std::thread> th; std::vector<char> okv(sl.size(), 1);
-    for (size_t i = 1; i < sl.size(); ++i) th.emplace_back([&, i] { okv[i] = pwrite_all(sl[i].fd, sl[i].p, sl[i].n, sl[i].off); });
-    okv[0] = pwrite_all(sl[0].fd, sl[0].p, sl[0].n, sl[0].off);
-    for (auto& t : th) t.join();
-    for (char v : okv) if (!v) failed_ = true;
-    return !failed_;
+static const unsigned char kBgzfEof[28] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0, 0x42, 0x43, 0x02, 0, 0x1b, 0, 0x03, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+std::string part_path(const std::string& base, int part, int parts, int mate, bool paired, const std::string& suffix) {
+    std::string p = base;
+    if (parts > 1) { char t[16]; snprintf(t, sizeof t, ".p%02d", part); p += t; }
+    if (paired) p += mate == 0 ? "_1" : "_2";
+    return p + suffix;
 }
-bool FastqFiles::close() {
-    bool good = !failed_;
-    for (int k = 0; k < 2; ++k) if (fd_[k] >= 0) {
-        if (::close(fd_[k]) != 0) good = false;
-        fd_[k] = -1;
+std::string parts_index_path(const std::string& base) { return base + ".parts"; }
+
+FastqParts::~FastqParts() { std::string e; (void)close(e); }
+bool FastqParts::open(const std::string& base, bool paired, int parts, const std::string& suffix, bool bgzf_eof, std::string& err) {
+    base_ = base; paired_ = paired; eof_ = bgzf_eof; regions = std::max(1, parts);
+    part_.assign((size_t)regions, Part());
+    (void)::unlink(parts_index_path(base).c_str());                                  // a stale index must not describe the new files
+    for (int k = 0; k < regions; ++k) for (int m = 0; m < (paired ? 2 : 1); ++m) {
+        const std::string p = part_path(base, k, regions, m, paired, suffix);
+        if (k == 0 && m == 0) first_ = p;
+        part_[k].fd[m] = ::open(p.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+        if (part_[k].fd[m] < 0) { err = "Error: can not open fastq file to save results:\n" + p; return false; }
     }
-    return good;
+    return true;
+}
+// One writer thread per region (SinkPipe); a region's two files are written one after the other -- except for the single
+// region of the reference's two-file layout, whose second file gets a thread of its own for the batch.
+int FastqParts::put(int region, const char* a, size_t na, const char* b, size_t nb) {
+    if (region < 0 || region >= (int)part_.size()) return 1;
+    Part& P = part_[region];
+    if (P.failed) return 1;
+    bool ok2 = true; std::thread t2;
+    const bool par = regions == 1 && nb && na && P.fd[1] >= 0;
+    if (par) t2 = std::thread([&] { ok2 = pwrite_all(P.fd[1], b, nb, P.pos[1]); });
+    bool ok1 = !na || pwrite_all(P.fd[0], a, na, P.pos[0]);
+    if (par) t2.join(); else if (nb && P.fd[1] >= 0) ok2 = pwrite_all(P.fd[1], b, nb, P.pos[1]);
+    P.pos[0] += na; if (P.fd[1] >= 0) P.pos[1] += nb;
+    if (!ok1 || !ok2) { P.failed = true; return 1; }
+    return 0;
+}
+bool FastqParts::close(std::string& err) {
+    bool good = true, any = false;
+    for (auto& P : part_) for (int m = 0; m < 2; ++m) if (P.fd[m] >= 0) {
+        any = true;
+        if (eof_ && !P.failed) { if (pwrite_all(P.fd[m], (const char*)kBgzfEof, sizeof kBgzfEof, P.pos[m])) P.pos[m] += sizeof kBgzfEof; else P.failed = true; }
+        if (::close(P.fd[m]) != 0) P.failed = true;
+        P.fd[m] = -1;
+        if (P.failed) good = false;
+    }
+    if (!good) { err = "writing " + first_ + " failed"; return false; }
+    if (any && regions > 1) {
+        FILE* f = fopen(parts_index_path(base_).c_str(), "w");
+        if (!f) { err = "can not write " + parts_index_path(base_); return false; }
+        fprintf(f, "# scssim FASTQ parts: part, bytes in file 1, bytes in file 2 (the files' concatenation in this order is the whole file)\n");
+        for (size_t k = 0; k < part_.size(); ++k) fprintf(f, "%zu\t%llu\t%llu\n", k, (unsigned long long)part_[k].pos[0], (unsigned long long)part_[k].pos[1]);
+        if (fclose(f) != 0) { err = "can not write " + parts_index_path(base_); return false; }
+    }
+    return true;
 }
 
-std::string shard_path(const std::string& prefix, int rank, int file, bool paired) {
-    return prefix + ".r" + std::to_string(rank) + (paired ? (file == 0 ? "_1.fq" : "_2.fq") : ".fq");
+bool LogicalFile::open(const std::string& base, int mate, bool paired, const std::string& suffix, std::string& err) {
+    close();
+    std::vector<uint64_t> sizes; int parts = 1;
+    if (FILE* f = fopen(parts_index_path(base).c_str(), "r")) {
+        char line[256];
+        while (fgets(line, sizeof line, f)) { if (line[0] == '#') continue; unsigned long long k, a, b; if (sscanf(line, "%llu %llu %llu", &k, &a, &b) == 3) sizes.push_back(mate == 0 ? a : b); }
+        fclose(f);
+        if (sizes.empty()) { err = "malformed parts index " + parts_index_path(base); return false; }
+        parts = (int)sizes.size();
+    }
+    for (int k = 0; k < parts; ++k) {
+        const std::string p = part_path(base, k, parts, mate, paired, suffix);
+        const int d = ::open(p.c_str(), O_RDONLY);
+        if (d < 0) { err = "can not open " + p; close(); return false; }
+        struct stat st_; if (fstat(d, &st_) != 0) { ::close(d); err = "can not stat " + p; close(); return false; }
+        if (!sizes.empty() && (uint64_t)st_.st_size != sizes[(size_t)k]) { ::close(d); err = p + " does not have the size its index states"; close(); return false; }
+        fd.push_back(d); start.push_back(size); path.push_back(p); size += (uint64_t)st_.st_size;
+    }
+    return true;
 }
+void LogicalFile::close() { for (int d : fd) if (d >= 0) ::close(d); fd.clear(); start.clear(); path.clear(); size = 0; }
+
+std::string shard_base(const std::string& prefix, int rank) { return prefix + ".r" + std::to_string(rank); }
 std::string shard_index_path(const std::string& prefix, int rank) { return prefix + ".r" + std::to_string(rank) + ".idx"; }
 
 bool write_shard_index(const std::string& path, const std::vector<uint64_t>& off1, const std::vector<uint64_t>& off2, std::string& err) {
@@ -176,41 +217,83 @@ static bool copy_range(int in, int out, uint64_t off_in, uint64_t off_out, uint6
     }
     return true;
 }
-bool merge_shards(const std::string& prefix, int nranks, bool paired, bool keep_shards, std::string& err) {
+// bytes [off_in, off_in + n) of a logical file (its parts in order) -> out at off_out
+static bool copy_logical(const LogicalFile& in, int out, uint64_t off_in, uint64_t off_out, uint64_t n) {
+    if (off_in + n > in.size) return false;
+    size_t k = (size_t)(std::upper_bound(in.start.begin(), in.start.end(), off_in) - in.start.begin()) - 1;
+    while (n) {
+        const uint64_t end = k + 1 < in.start.size() ? in.start[k + 1] : in.size, take = std::min<uint64_t>(n, end - off_in);
+        if (take && !copy_range(in.fd[k], out, off_in - in.start[k], off_out, take)) return false;
+        off_in += take; off_out += take; n -= take; ++k;
+    }
+    return true;
+}
+struct CopyJob { const LogicalFile* in; int out; uint64_t off_in, off_out, n; };
+static bool run_copies(const std::vector<CopyJob>& jobs) {
+    const unsigned nt = std::max(1u, std::min<unsigned>(8u, std::thread::hardware_concurrency()));
+    std::vector<std::thread> th; std::vector<char> okv(nt, 1);
+    for (unsigned t = 0; t < nt; ++t) th.emplace_back([&, t] {
+        for (size_t j = t; j < jobs.size(); j += nt) if (!copy_logical(*jobs[j].in, jobs[j].out, jobs[j].off_in, jobs[j].off_out, jobs[j].n)) { okv[t] = 0; return; }
+    });
+    for (auto& t : th) t.join();
+    for (char v : okv) if (!v) return false;
+    return true;
+}
+static void unlink_logical(const std::string& base, const std::vector<LogicalFile>& lf) {
+    for (auto& l : lf) for (auto& p : l.path) (void)::unlink(p.c_str());
+    (void)::unlink(parts_index_path(base).c_str());
+}
+bool merge_parts(const std::string& base, bool paired, const std::string& suffix, bool keep, std::string& err) {
+    const int nm = paired ? 2 : 1;
+    std::vector<LogicalFile> in((size_t)nm); int ofd[2] = {-1, -1}; bool good = true;
+    for (int m = 0; m < nm && good; ++m) good = in[(size_t)m].open(base, m, paired, suffix, err);
+    if (good && in[0].fd.size() == 1 && in[0].path[0] == part_path(base, 0, 1, 0, paired, suffix)) { for (auto& l : in) l.close(); return true; }   // already the single files
+    std::vector<CopyJob> jobs;
+    for (int m = 0; m < nm && good; ++m) {
+        const std::string out = part_path(base, 0, 1, m, paired, suffix);
+        ofd[m] = ::open(out.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+        if (ofd[m] < 0) { err = "Error: can not open fastq file to save results:\n" + out; good = false; break; }
+        for (size_t k = 0; k < in[(size_t)m].fd.size(); ++k) {
+            const uint64_t st = in[(size_t)m].start[k], en = k + 1 < in[(size_t)m].start.size() ? in[(size_t)m].start[k + 1] : in[(size_t)m].size;
+            if (en > st) jobs.push_back(CopyJob{&in[(size_t)m], ofd[m], st, st, en - st});
+        }
+    }
+    if (good && !run_copies(jobs)) { good = false; err = "copying a part failed"; }
+    for (int m = 0; m < 2; ++m) if (ofd[m] >= 0 && ::close(ofd[m]) != 0) { good = false; err = "closing the merged file failed"; }
+    if (good && !keep) unlink_logical(base, in);
+    for (auto& l : in) l.close();
+    return good;
+}
+bool merge_shards(const std::string& prefix, int nranks, bool paired, bool keep_shards, std::string& err, const std::string& suffix) {
     if (nranks < 1) { err = "merge_shards: bad rank count"; return false; }
     std::vector<std::vector<uint64_t>> o1(nranks), o2(nranks);
     for (int r = 0; r < nranks; ++r) if (!read_shard_index(shard_index_path(prefix, r), o1[r], o2[r], err)) return false;
     const size_t nslot = o1[0].size() - 1;
     for (int r = 0; r < nranks; ++r) if (o1[r].size() != nslot + 1) { err = "shard indexes disagree on the number of segments"; return false; }
-    struct Job { int file, rank; uint64_t in, out, n; };
-    std::vector<Job> jobs; uint64_t out[2] = {0, 0};
-    for (size_t s = 0; s < nslot; ++s) for (int r = 0; r < nranks; ++r) for (int k = 0; k < (paired ? 2 : 1); ++k) {
+    const int nm = paired ? 2 : 1;
+    std::vector<LogicalFile> in((size_t)nranks * 2); bool good = true;
+    for (int r = 0; r < nranks && good; ++r) for (int k = 0; k < nm && good; ++k) good = in[(size_t)r * 2 + k].open(shard_base(prefix, r), k, paired, suffix, err);
+    int ofd[2] = {-1, -1};
+    const std::string out_name[2] = {part_path(prefix, 0, 1, 0, paired, suffix), part_path(prefix, 0, 1, 1, paired, suffix)};
+    for (int k = 0; k < nm && good; ++k) { ofd[k] = ::open(out_name[k].c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644); if (ofd[k] < 0) { err = "Error: can not open fastq file to save results:\n" + out_name[k]; good = false; } }
+    std::vector<CopyJob> jobs; uint64_t out[2] = {0, 0};
+    if (good) for (size_t s = 0; s < nslot; ++s) for (int r = 0; r < nranks; ++r) for (int k = 0; k < nm; ++k) {
         const std::vector<uint64_t>& o = k ? o2[r] : o1[r];
         const uint64_t n = o[s + 1] - o[s];
-        if (n) jobs.push_back(Job{k, r, o[s], out[k], n});
+        if (n) jobs.push_back(CopyJob{&in[(size_t)r * 2 + k], ofd[k], o[s], out[k], n});
         out[k] += n;
     }
-    int ofd[2] = {-1, -1}; std::vector<int> ifd((size_t)nranks * 2, -1); bool good = true;
-    const std::string out_name[2] = {prefix + (paired ? "_1.fq" : ".fq"), prefix + "_2.fq"};
-    for (int k = 0; k < (paired ? 2 : 1) && good; ++k) { ofd[k] = ::open(out_name[k].c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644); if (ofd[k] < 0) { err = "Error: can not open fastq file to save results:\n" + out_name[k]; good = false; } }
-    for (int r = 0; r < nranks && good; ++r) for (int k = 0; k < (paired ? 2 : 1); ++k) {
-        ifd[(size_t)r * 2 + k] = ::open(shard_path(prefix, r, k, paired).c_str(), O_RDONLY);
-        if (ifd[(size_t)r * 2 + k] < 0) { err = "can not open shard " + shard_path(prefix, r, k, paired); good = false; break; }
-    }
     if (good) {
-        for (int k = 0; k < (paired ? 2 : 1); ++k) if (ftruncate(ofd[k], (off_t)out[k]) != 0) { /* sparse pre-size is an optimisation only */ }
-        const unsigned nt = std::max(1u, std::min<unsigned>(8u, std::thread::hardware_concurrency()));
-        std::vector<std::thread> th; std::vector<char> okv(nt, 1);
-        for (unsigned t = 0; t < nt; ++t) th.emplace_back([&, t] {
-            for (size_t j = t; j < jobs.size(); j += nt) if (!copy_range(ifd[(size_t)jobs[j].rank * 2 + jobs[j].file], ofd[jobs[j].file], jobs[j].in, jobs[j].out, jobs[j].n)) { okv[t] = 0; return; }
-        });
-        for (auto& t : th) t.join();
-        for (char v : okv) if (!v) { good = false; err = "copying a shard range failed"; }
+        for (int k = 0; k < nm; ++k) if (ftruncate(ofd[k], (off_t)out[k]) != 0) { /* sparse pre-size is an optimisation only */ }
+        if (!run_copies(jobs)) { good = false; err = "copying a shard range failed"; }
     }
-    for (int fd : ifd) if (fd >= 0) ::close(fd);
     for (int k = 0; k < 2; ++k) if (ofd[k] >= 0 && ::close(ofd[k]) != 0) { good = false; err = "closing " + out_name[k] + " failed"; }
     if (good && !keep_shards)
-        for (int r = 0; r < nranks; ++r) { for (int k = 0; k < (paired ? 2 : 1); ++k) (void)::unlink(shard_path(prefix, r, k, paired).c_str()); (void)::unlink(shard_index_path(prefix, r).c_str()); }
+        for (int r = 0; r < nranks; ++r) {
+            std::vector<LogicalFile> mine; for (int k = 0; k < nm; ++k) mine.push_back(in[(size_t)r * 2 + k]);
+            unlink_logical(shard_base(prefix, r), mine); (void)::unlink(shard_index_path(prefix, r).c_str());
+        }
+    for (auto& l : in) l.close();
     return good;
 }
 

@@ -158,12 +158,15 @@ void launch_amplify_init(hipStream_t s, int64_t* primer_cnt, int64_t copies, uin
                          unsigned long long nf_all, unsigned long long frag_len_all, unsigned long long total_primers, uint32_t* pool_head_a, uint32_t* pool_head_b);
 void launch_primer_update(hipStream_t s, int64_t* primer_cnt, uint32_t* primer_delta);
 void launch_weights(hipStream_t s, DevAmps fulls, uint32_t n, DevTables tb, RngKey key, uint32_t frag_size, double* w);
-void launch_plan_pairs(hipStream_t s, DevFrags fr, DevAmps semis, DevAmps fulls, uint32_t first, uint32_t n_fulls, uint32_t pair_lo, const uint32_t* read_numbers,
-                       const uint32_t* pair_off, SegMap gmap, DevTables tb, RngKey key, int paired, PairRec* pairs, unsigned long long* holes);   // amplicons [first, first + n_fulls); holes counted for pairs from pair_lo on
+void launch_plan_pairs(hipStream_t s, DevFrags fr, DevAmps semis, DevAmps fulls, uint32_t first, uint32_t n_fulls, uint32_t pair_lo, uint32_t pair_hi, const uint32_t* read_numbers,
+                       const uint32_t* pair_off, SegMap gmap, DevTables tb, RngKey key, int paired, PairRec* pairs, unsigned long long* holes);   // amplicons [first, first + n_fulls); writes (and counts the holes of) the pairs [pair_lo, pair_hi) only
 void launch_batch_bounds(hipStream_t s, const uint32_t* pair_off, uint32_t ac, unsigned long long batch, uint32_t nb, uint32_t* bounds);
 void launch_parity_pair_offsets(hipStream_t s, uint32_t* rn, uint32_t ac, uint32_t* pair_cnt_off, void* temp, size_t temp_bytes);   // PE, one shard: parity fix + pair offsets in one scan
 void launch_pair_offsets(hipStream_t s, const uint32_t* rn, uint32_t ac, int paired, uint32_t* pair_cnt_off, void* temp, size_t temp_bytes);
 // reads of pairs [p0, p0+np): slot layout [2*np][slot] bases / quals (SE: [np][slot])
+// the two side streams the small class kernels of a batch run on beside the big one, with their fork / join events: owned by
+// the ctx whose batches they order (created by the first launch_reads that uses them, on the current device)
+struct ReadsSide { hipStream_t st[2] = {nullptr, nullptr}; hipEvent_t fork = nullptr, join[2] = {nullptr, nullptr}; void release(); };
 size_t reads_lds_bytes(const DevTables& tb, bool uni = false);   // uni: the uniform-walk variant (event-free ACGT-only reads)
 //          // dynamic LDS of one inject_errors workgroup for this profile
 void launch_reads(hipStream_t s, const uint8_t* g, const uint32_t* g2, DevErrPool spool, DevErrPool fpool,
@@ -171,7 +174,7 @@ void launch_reads(hipStream_t s, const uint8_t* g, const uint32_t* g2, DevErrPoo
                   const uint32_t* ev_hdr, const uint4* ev_dat, const uint64_t* off1, const uint64_t* off2, char* out1, char* out2, uint32_t* flags,
                   uint64_t cap1, uint64_t cap2,   // writes FASTQ text; cap: bytes of the batch's text in each file (records are checked against it)
                   const uint32_t* slist1, const uint32_t* slist2, const uint32_t* clist1, const uint32_t* clist2, uint32_t nc1, uint32_t nc2,
-                  const uint32_t* dlist1, const uint32_t* dlist2, uint32_t nd1, uint32_t nd2);   // launch_read_lists' lists; nc: reads with indel events per mate
+                  const uint32_t* dlist1, const uint32_t* dlist2, uint32_t nd1, uint32_t nd2, struct ReadsSide* side);   // launch_read_lists' lists; nc: reads with indel events per mate; side: below (null: one stream)
 // splits the batch's reads into those without indel events and the rest (cls from launch_indels): ascending pair-index lists per mate
 void launch_read_lists(hipStream_t s, uint32_t np, int paired, const uint32_t* sizes1, const uint64_t* off1, const uint32_t* d1f1, uint32_t* d1p1,
                        const uint32_t* sizes2, const uint64_t* off2, const uint32_t* d1f2, uint32_t* d1p2,
@@ -182,6 +185,7 @@ void launch_indels(hipStream_t s, const PairRec* pairs, uint32_t np, int paired,
 void launch_predict_windows(hipStream_t s, const uint8_t* windows, uint32_t n_reads, const uint64_t* uids, const uint32_t* atts,
                             const uint8_t* is_read1, DevTables tb, const DevTables* d_tb, RngKey key, uint32_t slot, char* slot_b, char* slot_q,
                             uint32_t* lens, uint32_t* flags);
+void launch_text_checksum(hipStream_t s, const char* text, uint64_t nbytes, unsigned long long* out);   // *out = position-mixed 64-bit sum of the text (16-byte aligned) in HBM
 void launch_philox(hipStream_t s, const uint32_t* ctr, uint32_t n, RngKey key, uint32_t* out);
 void launch_detlog(hipStream_t s, const double* x, uint32_t n, double* out);
 

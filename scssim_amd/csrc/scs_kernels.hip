@@ -573,8 +573,10 @@ __global__ __launch_bounds__(WEIGHTS_BLOCK) void k_weights(DevAmps fulls, uint32
 //      (Amplicon.cpp:448-491): insert size, rejection, position.
 // ------------------------------------------------------------------------------------------------
 // (amplicons [first, first + n_fulls): the reads stage plans a batch's pairs right before the batch's pre-pass.  An amplicon
-// whose pairs straddle two batches is planned by both -- the same records twice -- and its holes are counted by the first)
-__global__ void k_plan_pairs(DevFrags fr, DevAmps semis, DevAmps fulls, uint32_t first, uint32_t n_fulls, uint32_t pair_lo, const uint32_t* __restrict__ read_numbers,
+// whose pairs straddle two batches runs its attempt loop in both, but every batch WRITES only the pair records of its own
+// range [pair_lo, pair_hi) and counts only the holes among them: each record is written once -- the base pass of the batch
+// before may still be reading its part of the amplicon's records on another stream -- and each hole is counted once)
+__global__ void k_plan_pairs(DevFrags fr, DevAmps semis, DevAmps fulls, uint32_t first, uint32_t n_fulls, uint32_t pair_lo, uint32_t pair_hi, const uint32_t* __restrict__ read_numbers,
                              const uint32_t* __restrict__ pair_off, const SegMap gmap, DevTables tb, RngKey key, int paired,
                              PairRec* __restrict__ pairs, unsigned long long* __restrict__ holes) {
     // the insert-size thresholds (a few hundred) go to LDS: the lookup is a nine-step bisection per attempt, and from global
@@ -589,8 +591,10 @@ __global__ void k_plan_pairs(DevFrags fr, DevAmps semis, DevAmps fulls, uint32_t
     const uint32_t i = first + j;
     int n = (int)read_numbers[i];
     if (n == 0) return;
-    const uint32_t want = pair_off[i + 1] - pair_off[i];
-    PairRec* dst = pairs + pair_off[i];
+    const uint32_t po = pair_off[i], want = pair_off[i + 1] - po;
+    if (po >= pair_hi || po + want <= pair_lo) return;                               // none of its pairs lies in this batch
+    PairRec* dst = pairs + po;
+    const uint32_t q_lo = pair_lo > po ? pair_lo - po : 0u, q_hi = pair_hi - po < want ? pair_hi - po : want;   // its pairs [q_lo, q_hi) are this batch's
     const uint32_t fsl = fulls.sl[i], amp_len = sl_len(fsl), s2 = sl_spos(fsl);
     const uint32_t L = (uint32_t)tb.L;
     // resolve U = full amplicon sequence to an index map once (Amplicon::getSequence, Amplicon.cpp:266-340, without the copies)
@@ -604,21 +608,24 @@ __global__ void k_plan_pairs(DevFrags fr, DevAmps semis, DevAmps fulls, uint32_t
     uint32_t made = 0;
     if (amp_len >= L) {
         uint32_t att = 0, fails = 0;
-        while (n > 0 && made < want) {
+        while (n > 0 && made < q_hi) {                                               // (what lies beyond q_hi is the next batch's)
             const U4 d = draw4(key, ST_PAIR, 0, r.uid, att);
             if (!paired) {
                 r.att = att; r.pos = scale_draw(d.w[1], 0, amp_len - L + 1); r.isz = L;
-                dst[made++] = r; ++att; --n; continue;
+                if (made >= q_lo && made < q_hi) dst[made] = r;
+                ++made; ++att; --n; continue;
             }
             const uint32_t isz = (uint32_t)tb.isize_min + rand_indx_thr(isz_lds ? (const uint32_t*)s_isz : tb.isize_t, tb.isize_d, n_isz, d.w[0]);
             if (isz < L || isz > amp_len) { ++att; if (++fails > 1000) break; continue; }
             r.att = att; r.pos = scale_draw(d.w[1], 0, amp_len - isz + 1); r.isz = isz;
-            dst[made++] = r; ++att; n -= 2;
+            if (made >= q_lo && made < q_hi) dst[made] = r;
+            ++made; ++att; n -= 2;
         }
     }
     r.att = 0; r.pos = 0; r.isz = 0;
-    for (uint32_t q = made; q < want; ++q) dst[q] = r;                             // holes
-    if (made < want && pair_off[i] >= pair_lo) atomicAdd(holes, (unsigned long long)(want - made));   // rare: the host reports pairs produced = planned - holes
+    const uint32_t h_lo = made > q_lo ? made : q_lo;
+    for (uint32_t q = h_lo; q < q_hi; ++q) dst[q] = r;                             // holes
+    if (h_lo < q_hi) atomicAdd(holes, (unsigned long long)(q_hi - h_lo));            // rare: the host reports pairs produced = planned - holes
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2249,10 +2256,10 @@ void launch_weights(hipStream_t s, DevAmps fulls, uint32_t n, DevTables tb, RngK
     if (n == 0) return;
     hipLaunchKernelGGL(k_weights, dim3(cdiv(n, (uint32_t)WEIGHTS_BLOCK)), dim3(WEIGHTS_BLOCK), 0, s, fulls, n, tb, key, frag_size, w);
 }
-void launch_plan_pairs(hipStream_t s, DevFrags fr, DevAmps semis, DevAmps fulls, uint32_t first, uint32_t n_fulls, uint32_t pair_lo, const uint32_t* read_numbers,
+void launch_plan_pairs(hipStream_t s, DevFrags fr, DevAmps semis, DevAmps fulls, uint32_t first, uint32_t n_fulls, uint32_t pair_lo, uint32_t pair_hi, const uint32_t* read_numbers,
                        const uint32_t* pair_off, SegMap gmap, DevTables tb, RngKey key, int paired, PairRec* pairs, unsigned long long* holes) {
     if (n_fulls == 0) return;
-    hipLaunchKernelGGL(k_plan_pairs, dim3(cdiv(n_fulls, 256)), dim3(256), 0, s, fr, semis, fulls, first, n_fulls, pair_lo, read_numbers, pair_off, gmap, tb, key, paired, pairs, holes);
+    hipLaunchKernelGGL(k_plan_pairs, dim3(cdiv(n_fulls, 256)), dim3(256), 0, s, fr, semis, fulls, first, n_fulls, pair_lo, pair_hi, read_numbers, pair_off, gmap, tb, key, paired, pairs, holes);
 }
 // bounds[b] = the amplicon that holds pair b * batch (the first i with pair_off[i + 1] > b * batch), b = 0 .. nb; bounds[nb] = ac
 __global__ void k_batch_bounds(const uint32_t* __restrict__ pair_off, uint32_t ac, unsigned long long batch, uint32_t nb, uint32_t* __restrict__ bounds) {
@@ -2302,6 +2309,11 @@ void launch_pair_offsets(hipStream_t s, const uint32_t* rn, uint32_t ac, int pai
     if (paired) (void)rocprim::exclusive_scan(temp, temp_bytes, rocprim::make_transform_iterator(rn, HalfUp()), pair_cnt_off, 0u, (size_t)ac + 1, rocprim::plus<uint32_t>(), s);
     else (void)rocprim::exclusive_scan(temp, temp_bytes, rn, pair_cnt_off, 0u, (size_t)ac + 1, rocprim::plus<uint32_t>(), s);
 }
+void ReadsSide::release() {
+    for (int k = 0; k < 2; ++k) { if (st[k]) (void)hipStreamDestroy(st[k]); if (join[k]) (void)hipEventDestroy(join[k]); st[k] = nullptr; join[k] = nullptr; }
+    if (fork) (void)hipEventDestroy(fork);
+    fork = nullptr;
+}
 size_t reads_lds_bytes(const DevTables& tb, bool uni) {
     const size_t ring = tb.qual_k == 16 ? RingGeo<16>::SLOTS * sizeof(RingBin<16>) : tb.qual_k == 64 ? RingGeo<64>::SLOTS * sizeof(RingBin<64>) : RingGeo<128>::SLOTS * sizeof(RingBin<128>);
     if (uni) return ring + (size_t)RB * uni_row_bytes((uint32_t)tb.L) + 256;       // + the head rows
@@ -2338,7 +2350,7 @@ void launch_reads(hipStream_t s, const uint8_t* g, const uint32_t* g2, DevErrPoo
                   const PairRec* pairs, uint32_t np, uint32_t amp_index_base, DevTables tb, const DevTables* d_tb, RngKey key, int paired, uint32_t slot,
                   const uint32_t* ev_hdr, const uint4* ev_dat, const uint64_t* off1, const uint64_t* off2, char* out1, char* out2, uint32_t* flags,
                   uint64_t cap1, uint64_t cap2, const uint32_t* slist1, const uint32_t* slist2, const uint32_t* clist1, const uint32_t* clist2, uint32_t nc1, uint32_t nc2,
-                  const uint32_t* dlist1, const uint32_t* dlist2, uint32_t nd1, uint32_t nd2) {
+                  const uint32_t* dlist1, const uint32_t* dlist2, uint32_t nd1, uint32_t nd2, ReadsSide* side) {
     if (np == 0) return;
     (void)d_tb;
     static const bool shrink = getenv("SCS_TEST_SHRINK_OUT") != nullptr;               // tests: provoke the record-bound guard
@@ -2349,11 +2361,10 @@ void launch_reads(hipStream_t s, const uint8_t* g, const uint32_t* g2, DevErrPoo
     if (tb.L > 1008) { gs = 0; gd = 0; }                                           // reads this long all sit in the general list (launch_indels); what is left in the others are holes: nothing to write
     // The three class kernels write disjoint records: the two small ones go to side streams and run BESIDE the big one (each alone
     // leaves the chip half empty through its first and last wave of workgroups); the caller's stream waits for both.
-    struct Side { hipStream_t st[2] = {nullptr, nullptr}; hipEvent_t fork = nullptr, join[2] = {nullptr, nullptr}; };
-    static Side sides[64];
-    int dev = 0; (void)hipGetDevice(&dev);
-    Side& sd = sides[dev & 63];
-    static const bool serial = getenv("SCS_READS_SERIAL") != nullptr;
+    // (side: the caller's two side streams and fork / join events -- they belong to its ctx, created on first use, destroyed with it)
+    static const bool serial_env = getenv("SCS_READS_SERIAL") != nullptr;
+    const bool serial = serial_env || !side;
+    ReadsSide none; ReadsSide& sd = side ? *side : none;
     if (!serial && !sd.fork) {
         note_launch(hipEventCreateWithFlags(&sd.fork, hipEventDisableTiming));
         for (int k = 0; k < 2; ++k) { note_launch(hipStreamCreateWithFlags(&sd.st[k], hipStreamNonBlocking)); note_launch(hipEventCreateWithFlags(&sd.join[k], hipEventDisableTiming)); }
@@ -2407,6 +2418,34 @@ void launch_predict_windows(hipStream_t s, const uint8_t* windows, uint32_t n_re
                                windows, uids, atts, is_read1, n_reads, tb, key, slot, n_reads, reads_force_replay(), (const uint32_t*)nullptr, (const uint4*)nullptr,
                                (const uint64_t*)nullptr, (const uint64_t*)nullptr, (char*)nullptr, (char*)nullptr, 0u, slot_b, slot_q, lens, flags, (uint64_t)0, (uint64_t)0,
                                (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0u, 0u);
+}
+// Checksum of a batch's FASTQ text where it lies in HBM (scs_set_batch_checksums): the text as little-endian 64-bit words w_i
+// (the last one zero-padded), sum over i of fmix64(w_i + (i + 1) * 0x9E3779B97F4A7C15) mod 2^64 -- every word's position is mixed
+// into its term, the sum is commutative, so the result does not depend on the order the waves' partial sums arrive in.
+// HBM-bound: one read of the text, 16 bytes per lane and step.
+__device__ __forceinline__ unsigned long long fmix64(unsigned long long x) {
+    x ^= x >> 33; x *= 0xFF51AFD7ED558CCDull; x ^= x >> 33; x *= 0xC4CEB9FE1A85EC53ull; x ^= x >> 33; return x;
+}
+__global__ void __launch_bounds__(256) k_text_checksum(const unsigned long long* __restrict__ text, unsigned long long nbytes, unsigned long long* __restrict__ out) {
+    const unsigned long long nw = nbytes >> 3, rem = nbytes & 7ull, stride = (unsigned long long)gridDim.x * blockDim.x * 2ull;
+    unsigned long long acc = 0;
+    for (unsigned long long i = ((unsigned long long)blockIdx.x * blockDim.x + threadIdx.x) * 2ull; i < nw; i += stride) {
+        if (i + 1 < nw) { const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(text + i); acc += fmix64(v.x + (i + 1) * 0x9E3779B97F4A7C15ull) + fmix64(v.y + (i + 2) * 0x9E3779B97F4A7C15ull); }
+        else acc += fmix64(text[i] + (i + 1) * 0x9E3779B97F4A7C15ull);
+    }
+    if (rem && blockIdx.x == 0 && threadIdx.x == 0) {                               // the last, partial word
+        const unsigned char* t = reinterpret_cast<const unsigned char*>(text + nw); unsigned long long w = 0;
+        for (unsigned long long b = 0; b < rem; ++b) w |= (unsigned long long)t[b] << (8 * b);
+        acc += fmix64(w + (nw + 1) * 0x9E3779B97F4A7C15ull);
+    }
+    acc = wave_sum_u64(acc);
+    if ((threadIdx.x & 63) == 0 && acc) atomicAdd(out, acc);
+}
+void launch_text_checksum(hipStream_t s, const char* text, uint64_t nbytes, unsigned long long* out) {
+    (void)hipMemsetAsync(out, 0, 8, s);
+    if (nbytes == 0) return;
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>(4096, (nbytes / 16 + 255) / 256 + 1);
+    hipLaunchKernelGGL(k_text_checksum, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const unsigned long long*>(text), (unsigned long long)nbytes, out);
 }
 void launch_philox(hipStream_t s, const uint32_t* ctr, uint32_t n, RngKey key, uint32_t* out) {
     if (n) hipLaunchKernelGGL(k_philox, dim3(cdiv(n, 256)), dim3(256), 0, s, ctr, n, key, out);

@@ -182,9 +182,11 @@ struct scs_ctx {
     DevBuf slot_b, slot_q, lens, ev_hdr, ev_dat, sizes1, sizes2, off1, off2, out1, out2, out1b, out2b, rl_cls, rl_pos, rl_lists, d_bounds; SinkPipe* pipe = nullptr;
     hipStream_t errs_stream = nullptr; hipEvent_t ev_att = nullptr, ev_errs = nullptr; bool errs_pending = false;   // k_errs<semi->full> of a cycle runs beside the fragment pass that follows it
     DevBuf slots_fr, slot_tmpl_fr;                        // the fragment passes' own slot arrays (the semi pass's are still being read then)
+    bool want_cks = false; DevBuf d_cks; std::vector<uint64_t> cks;   // scs_set_batch_checksums: per batch and mate, computed where the text lies in HBM
+    ReadsSide reads_side;                                 // k_reads' two small class kernels run beside the big one on these (per ctx: two contexts on one device do not share events)
     hipStream_t pre_stream = nullptr; hipEvent_t ev_pre[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr}, ev_plan = nullptr;   // the reads stage's pre-pass on its own stream, beside the previous batch's base pass
     hipStream_t mail_stream = nullptr;                                             // the stream of the last post (mail_wait watches it)
-    hipStream_t copy_stream = nullptr; hipEvent_t ev_made[2] = {nullptr, nullptr};   // sink mode: D2H on its own stream, behind the batch's k_reads
+    hipStream_t copy_stream = nullptr; hipEvent_t ev_made[2] = {nullptr, nullptr}, ev_d2h[2] = {nullptr, nullptr};   // sink mode: D2H on its own stream, behind the batch's k_reads
     // sharded single job: collectives supplied by the caller + segment bookkeeping of the local amplicon lists
     scs_allreduce_fn allreduce = nullptr; scs_allgatherv_fn allgatherv = nullptr; void* coll_user = nullptr;
     scs_allreduce_dev_fn allreduce_dev = nullptr; scs_allgather_dev_fn allgather_dev = nullptr; void* coll_dev_user = nullptr;
@@ -788,35 +790,69 @@ void do_allocate(scs_ctx* c, uint64_t reads) {
 }
 
 // ---------------------------------------------------------------- a10/a11/a13/a16: yieldReads
-// FASTQ sink pipeline (replaces the mutexed ofstream of lib/seqwriter/SeqWriter.cpp:41-54): batches are
-// copied D2H into two pinned buffer pairs asynchronously; a writer thread waits for each copy's event and hands the
-// batch to the caller's sink IN ORDER while the GPU already produces the next batch.
+// FASTQ sink pipeline (replaces the mutexed ofstream of lib/seqwriter/SeqWriter.cpp:41-54).  A batch's text is
+// copied D2H on the copy stream into a free pinned slot and handed to the writer thread of its REGION (BatchSink: the job's
+// records are cut into `regions` contiguous ranges, visited round-robin, one writer thread and one pair of files each), which
+// waits for the copy's event, writes, and frees the slot -- while the GPU already produces the next batches.  regions + 2
+// slots: every writer can hold one while one is being filled and one crosses PCIe.
 struct SinkPipe {
+    struct Slot { char* h[2] = {nullptr, nullptr}; size_t cap[2] = {0, 0}; hipEvent_t ev = nullptr; bool busy = false; };
     struct Job { int slot; size_t n1, n2; };
-    char* h1[2] = {nullptr, nullptr}; char* h2[2] = {nullptr, nullptr}; size_t cap1 = 0, cap2 = 0;
-    hipEvent_t ev[2]; bool busy[2] = {false, false};
-    std::mutex mu; std::condition_variable cv; std::vector<Job> q; bool done = false, failed = false;
-    std::thread th; scs_sink_fn sink; void* user; bool paired; int device;
-    void start(scs_sink_fn f, void* u, bool pe, int dev) {
-        sink = f; user = u; paired = pe; device = dev; done = failed = false; busy[0] = busy[1] = false; q.clear();
-        th = std::thread([this] {
+    struct Writer { std::thread th; std::vector<Job> q; };
+    std::vector<Slot> slots; std::vector<Writer> writers;
+    std::mutex mu; std::condition_variable cv; bool done = false, failed = false;
+    BatchSink* sink = nullptr; bool paired = true; int device = 0;
+    void start(BatchSink* f, bool pe, int dev) {
+        sink = f; paired = pe; device = dev; done = failed = false;
+        const size_t want = (size_t)std::max(1, f->regions) + 2;
+        while (slots.size() < want) { Slot sl; HIP_OK(hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming)); slots.push_back(sl); }
+        for (auto& sl : slots) sl.busy = false;
+        writers = std::vector<Writer>((size_t)std::max(1, f->regions));
+        for (size_t w = 0; w < writers.size(); ++w) writers[w].th = std::thread([this, w] {
             (void)hipSetDevice(device);
+            Writer& W = writers[w];
             for (;;) {
                 Job j;
-                { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [this] { return !q.empty() || done; }); if (q.empty()) return; j = q.front(); q.erase(q.begin()); }
-                bool bad = hipEventSynchronize(ev[j.slot]) != hipSuccess;
-                if (!bad && !failed) bad = sink(user, h1[j.slot], j.n1, paired ? h2[j.slot] : nullptr, j.n2) != 0;
-                { std::lock_guard<std::mutex> lk(mu); busy[j.slot] = false; if (bad) failed = true; }
+                { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return !W.q.empty() || done; }); if (W.q.empty()) return; j = W.q.front(); W.q.erase(W.q.begin()); }
+                Slot& sl = slots[(size_t)j.slot];
+                bool bad = hipEventSynchronize(sl.ev) != hipSuccess;
+                if (!bad && !failed) bad = sink->put((int)w, sl.h[0], j.n1, paired ? sl.h[1] : nullptr, j.n2) != 0;
+                { std::lock_guard<std::mutex> lk(mu); sl.busy = false; if (bad) failed = true; }
                 cv.notify_all();
             }
         });
     }
-    int acquire(int slot) { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return !busy[slot]; }); busy[slot] = true; return failed ? 1 : 0; }
-    void submit(int slot, size_t n1, size_t n2) { { std::lock_guard<std::mutex> lk(mu); q.push_back(Job{slot, n1, n2}); } cv.notify_all(); }
-    bool finish() { { std::lock_guard<std::mutex> lk(mu); done = true; } cv.notify_all(); if (th.joinable()) th.join(); return !failed; }
+    // a free pinned slot with room for the batch (blocks while every slot is with a writer); -1: the sink failed
+    int acquire(size_t need1, size_t need2) {
+        int k = -1;
+        { std::unique_lock<std::mutex> lk(mu);
+          cv.wait(lk, [&] { if (failed) return true; for (size_t i = 0; i < slots.size(); ++i) if (!slots[i].busy) { k = (int)i; return true; } return false; });
+          if (failed) return -1;
+          slots[(size_t)k].busy = true; }
+        Slot& sl = slots[(size_t)k];
+        for (int f = 0; f < 2; ++f) {
+            const size_t need = f == 0 ? need1 : need2;
+            if (need > sl.cap[f]) {
+                if (sl.h[f]) HIP_OK(hipHostFree(sl.h[f]));
+                sl.h[f] = nullptr; sl.cap[f] = 0;
+                const size_t nc = std::max<size_t>(need + need / 8, 1 << 20);
+                HIP_OK(hipHostMalloc((void**)&sl.h[f], nc, hipHostMallocDefault)); sl.cap[f] = nc;
+            }
+        }
+        return k;
+    }
+    void submit(int region, int slot, size_t n1, size_t n2) { { std::lock_guard<std::mutex> lk(mu); writers[(size_t)region].q.push_back(Job{slot, n1, n2}); } cv.notify_all(); }
+    bool finish() { { std::lock_guard<std::mutex> lk(mu); done = true; } cv.notify_all(); for (auto& W : writers) if (W.th.joinable()) W.th.join(); writers.clear(); return !failed; }
+    void release() { for (auto& sl : slots) { for (int f = 0; f < 2; ++f) if (sl.h[f]) (void)hipHostFree(sl.h[f]); if (sl.ev) (void)hipEventDestroy(sl.ev); } slots.clear(); }
+};
+// a caller's scs_sink_fn as a BatchSink: one region, the batches in record order
+struct CallbackSink : BatchSink {
+    scs_sink_fn fn; void* user;
+    CallbackSink(scs_sink_fn f, void* u) : fn(f), user(u) {}
+    int put(int, const char* a, size_t na, const char* b, size_t nb) override { return fn(user, a, na, b, nb); }
 };
 
-struct OutTarget { bool device; char* d1; char* d2; size_t cap1, cap2; scs_sink_fn sink; void* user;
+struct OutTarget { bool device; char* d1; char* d2; size_t cap1, cap2; BatchSink* sink;
                    std::vector<uint64_t>* seg_off1 = nullptr; std::vector<uint64_t>* seg_off2 = nullptr; };   // seg_off: byte offset of each list segment's first record (shard index)
 
 void do_yield(scs_ctx* c, const OutTarget& tg, uint64_t* n1_out, uint64_t* n2_out, uint64_t* pairs_out) {
@@ -830,10 +866,12 @@ void do_yield(scs_ctx* c, const OutTarget& tg, uint64_t* n1_out, uint64_t* n2_ou
     c->pairs.reserve(std::max<size_t>(P * sizeof(PairRec), 16), s);
     HIP_OK(hipMemsetAsync(c->dsums.as<unsigned long long>() + DS_HOLES, 0, 8, s));
     const bool to_sink = !tg.device && tg.sink;
+    const int regions = to_sink ? std::max(1, tg.sink->regions) : 1;
     // pairs per batch: 8 M with the text staying in HBM (5 GB of text per batch: the base pass' grids are long enough for their tails and
-    // the per-batch pre-pass not to matter: 2 M -> 8 M gave -11 % on the stage), 512 k towards a sink (pinned double buffers)
+    // the per-batch pre-pass not to matter: 2 M -> 8 M gave -11 % on the stage), 512 k towards a sink (pinned slots; 256 k when many
+    // writers each hold one)
     static const int batch_shift = getenv("SCS_TEST_BATCH_SHIFT") ? atoi(getenv("SCS_TEST_BATCH_SHIFT")) : 0;   // tests: many small batches
-    const uint64_t batch = std::min<uint64_t>(std::max<uint64_t>(P, 1), batch_shift ? (1ull << batch_shift) : to_sink ? (1ull << 19) : (1ull << 23));
+    const uint64_t batch = std::min<uint64_t>(std::max<uint64_t>(P, 1), batch_shift ? (1ull << batch_shift) : to_sink ? (regions > 4 ? 1ull << 18 : 1ull << 19) : (1ull << 23));
     // The pairs are planned (k_plan_pairs: insert sizes, positions, the amplicon resolved to an index map) batch by batch, at the
     // head of each batch's pre-pass: bounds[b] = the amplicon that holds the batch's first pair.
     const uint32_t nbatch = (uint32_t)((P + batch - 1) / batch);
@@ -843,13 +881,22 @@ void do_yield(scs_ctx* c, const OutTarget& tg, uint64_t* n1_out, uint64_t* n2_ou
         launch_batch_bounds(s, c->pair_off.as<uint32_t>(), c->fulls.n, batch, nbatch, c->d_bounds.as<uint32_t>());
         HIP_OK(hipMemcpyAsync(bounds.data(), c->d_bounds.p, ((size_t)nbatch + 1) * 4, hipMemcpyDeviceToHost, s)); HIP_OK(hipStreamSynchronize(s));
     }
+    // The order the batches are made in.  One region: record order.  Several (a sink with that many writers): region k owns the
+    // contiguous batches [k nbatch / regions, (k + 1) nbatch / regions) and the regions are visited round-robin, so every writer
+    // always has a batch of its own range on the way while each range still arrives in record order.
+    std::vector<uint32_t> order, region_of; order.reserve(nbatch); region_of.reserve(nbatch);
+    {
+        std::vector<uint32_t> next((size_t)regions), end((size_t)regions);
+        for (int k = 0; k < regions; ++k) { next[(size_t)k] = (uint32_t)((uint64_t)nbatch * k / regions); end[(size_t)k] = (uint32_t)((uint64_t)nbatch * (k + 1) / regions); }
+        while (order.size() < nbatch) for (int k = 0; k < regions; ++k) if (next[(size_t)k] < end[(size_t)k]) { order.push_back(next[(size_t)k]++); region_of.push_back((uint32_t)k); }
+    }
     struct PipeGuard { SinkPipe* p; ~PipeGuard() { if (p) (void)p->finish(); } } guard{nullptr};
     if (to_sink) {
-        if (!c->pipe) { c->pipe = new SinkPipe; HIP_OK(hipEventCreateWithFlags(&c->pipe->ev[0], hipEventDisableTiming)); HIP_OK(hipEventCreateWithFlags(&c->pipe->ev[1], hipEventDisableTiming)); }
-        if (!c->copy_stream) { HIP_OK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking)); for (int k = 0; k < 2; ++k) HIP_OK(hipEventCreateWithFlags(&c->ev_made[k], hipEventDisableTiming)); }
-        c->pipe->start(tg.sink, tg.user, paired != 0, c->cfg.device); guard.p = c->pipe;
+        if (!c->pipe) c->pipe = new SinkPipe;
+        if (!c->copy_stream) { HIP_OK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking)); for (int k = 0; k < 2; ++k) { HIP_OK(hipEventCreateWithFlags(&c->ev_made[k], hipEventDisableTiming)); HIP_OK(hipEventCreateWithFlags(&c->ev_d2h[k], hipEventDisableTiming)); } }
+        c->pipe->start(tg.sink, paired != 0, c->cfg.device); guard.p = c->pipe;
     }
-    uint64_t bi = 0;
+    uint64_t bi = 0;                                                               // batches handed to the sink so far
     // Per batch a PRE-PASS (indel events -> record sizes -> offsets, class lists; k_indels + scans) must finish before the host
     // can launch the base pass (it needs the batch's byte counts and class counts).  The pre-pass of batch i+1 is therefore
     // queued BEFORE the base pass of batch i, into a second set of buffers: while the host waits for its mail the GPU
@@ -890,7 +937,7 @@ void do_yield(scs_ctx* c, const OutTarget& tg, uint64_t* n1_out, uint64_t* n2_ou
         const PairRec* pr = c->pairs.as<PairRec>() + p0;
         {   // this batch's pair records: its amplicons, the one that straddles the next batch's start included
             const uint32_t b = (uint32_t)(p0 / batch), a_lo = bounds[b], a_hi = std::min<uint32_t>(c->fulls.n, bounds[b + 1] + 1u);
-            launch_plan_pairs(s, c->frags_view(), c->semis.view(), c->fulls.view(), a_lo, a_hi - a_lo, (uint32_t)p0, c->read_numbers.as<uint32_t>(), c->pair_off.as<uint32_t>(),
+            launch_plan_pairs(s, c->frags_view(), c->semis.view(), c->fulls.view(), a_lo, a_hi - a_lo, (uint32_t)p0, (uint32_t)(p0 + np), c->read_numbers.as<uint32_t>(), c->pair_off.as<uint32_t>(),
                               c->gmap, c->dtb, c->key, paired, c->pairs.as<PairRec>(), c->dsums.as<unsigned long long>() + DS_HOLES);
         }
         // the indel pass fixes every read's length, hence the record sizes and (prefix sums) the record offsets
@@ -907,81 +954,94 @@ void do_yield(scs_ctx* c, const OutTarget& tg, uint64_t* n1_out, uint64_t* n2_ou
         if (ps != c->stream) HIP_OK(hipEventRecord(c->ev_pre[k], ps));
     };
     uint64_t tot1 = 0, tot2 = 0, pairs_written = 0;
-    // shard index: the pair index at which each list segment starts (pair_off at the segment's first amplicon)
-    std::vector<uint64_t> bpair; size_t bnext = 0;
+    // shard index: the pair index at which each list segment starts (pair_off at the segment's first amplicon); the byte offset of
+    // that record = the bytes of the batches before its batch (known once every batch is made) + its offset inside the batch
+    std::vector<uint64_t> bpair; std::vector<uint64_t> bb1(nbatch, 0), bb2(nbatch, 0);
+    struct SegAt { size_t seg; uint32_t b; uint64_t o1, o2; }; std::vector<SegAt> seg_at;
     if (tg.seg_off1) {
         std::vector<uint32_t> v(ALLOC_SLOTS + 1, 0);
         for (int k = 0; k <= ALLOC_SLOTS; ++k) HIP_OK(hipMemcpyAsync(&v[k], c->pair_off.as<uint32_t>() + c->seg_lo[k], 4, hipMemcpyDeviceToHost, s));
         HIP_OK(hipStreamSynchronize(s));
         bpair.assign(v.begin(), v.end()); tg.seg_off1->assign(ALLOC_SLOTS + 1, 0); if (tg.seg_off2) tg.seg_off2->assign(ALLOC_SLOTS + 1, 0);
     }
-    if (P) prepass(0, bs[0], 0);
-    for (uint64_t p0 = 0, it = 0; p0 < P; p0 += batch, ++it) {
+    bool d2h_rec[2] = {false, false};
+    c->cks.clear();
+    if (c->want_cks && !tg.device) c->d_cks.reserve(std::max<size_t>((size_t)nbatch * 16, 16), s);
+    if (P) prepass((uint64_t)order[0] * batch, bs[0], 0);
+    for (uint64_t it = 0; it < nbatch; ++it) {
+        const uint32_t bidx = order[it]; const uint64_t p0 = (uint64_t)bidx * batch;
         const uint32_t np = (uint32_t)std::min<uint64_t>(batch, P - p0);
         const PairRec* pr = c->pairs.as<PairRec>() + p0;
         const BatchSet& B = bs[it & 1];
         mail_wait(c);                                                              // this batch's byte and class counts
         const uint64_t b1 = c->h_rb[0] & OFF_MASK, b2 = c->h_rb[1] & OFF_MASK; const uint32_t nc1 = (uint32_t)(c->h_rb[0] >> OFF_BITS), nc2 = (uint32_t)(c->h_rb[1] >> OFF_BITS), nd1 = (uint32_t)c->h_rb[2], nd2 = (uint32_t)c->h_rb[3];
         if (ps != s) HIP_OK(hipStreamWaitEvent(s, c->ev_pre[it & 1], 0));          // (the host has seen the pre-pass' mail already: ordering for the device's sake)
-        if (p0 + batch < P) prepass(p0 + batch, bs[(it + 1) & 1], (int)((it + 1) & 1));   // the next batch's pre-pass starts now, beside this batch's base pass
-        while (bnext < bpair.size() && bpair[bnext] < p0 + np) {                     // a segment starts inside this batch: its record's byte offset
-            uint64_t o1v = 0, o2v = 0; const uint64_t idx = bpair[bnext] - p0;
+        if (it + 1 < nbatch) prepass((uint64_t)order[it + 1] * batch, bs[(it + 1) & 1], (int)((it + 1) & 1));   // the next batch's pre-pass starts now, beside this batch's base pass
+        bb1[bidx] = b1; bb2[bidx] = b2;
+        for (size_t j = (size_t)(std::lower_bound(bpair.begin(), bpair.end(), p0) - bpair.begin()); j < bpair.size() && bpair[j] < p0 + np; ++j) {   // segments that start inside this batch
+            uint64_t o1v = 0, o2v = 0; const uint64_t idx = bpair[j] - p0;
             HIP_OK(hipMemcpyAsync(&o1v, B.off1 + idx, 8, hipMemcpyDeviceToHost, s));
             if (paired) HIP_OK(hipMemcpyAsync(&o2v, B.off2 + idx, 8, hipMemcpyDeviceToHost, s));
             HIP_OK(hipStreamSynchronize(s));
-            (*tg.seg_off1)[bnext] = tot1 + (o1v & OFF_MASK); if (tg.seg_off2) (*tg.seg_off2)[bnext] = tot2 + (o2v & OFF_MASK);
-            ++bnext;
+            seg_at.push_back(SegAt{j, bidx, o1v & OFF_MASK, o2v & OFF_MASK});
         }
         char *o1, *o2;
-        SinkPipe* pp = to_sink ? c->pipe : nullptr; const int sl = (int)(bi & 1);
+        SinkPipe* pp = to_sink ? c->pipe : nullptr; const int dsl = (int)(bi & 1);
         if (tg.device) {
             if (tot1 + b1 > tg.cap1 || tot2 + b2 > tg.cap2) throw ScsError(SCS_EOVERFLOW, "scs_yield_reads_device: output buffer too small");
             o1 = tg.d1 + tot1; o2 = tg.d2 ? tg.d2 + tot2 : nullptr;
         } else {
-            // sink mode: two device buffers, like the two pinned ones.  The slot is free once the writer has handed its last
-            // batch to the sink (which implies that batch's D2H is done), so k_reads of this batch may overwrite it while
-            // the previous batch is still crossing PCIe on the copy stream.
-            if (pp && pp->acquire(sl)) throw ScsError(SCS_EIO, "sink aborted");
-            DevBuf& d1 = (pp && sl) ? c->out1b : c->out1; DevBuf& d2 = (pp && sl) ? c->out2b : c->out2;
-            d1.reserve(std::max<uint64_t>(b1 + b1 / 16, 16), s); d2.reserve(std::max<uint64_t>(b2 + b2 / 16, 16), s);
+            // sink mode: two device buffers.  One is free for this batch's k_reads once the D2H of the batch two back has left it
+            // (ev_d2h: the stream waits, not the host), so the text of a batch crosses PCIe beside the next batch's kernels.
+            DevBuf& d1 = (pp && dsl) ? c->out1b : c->out1; DevBuf& d2 = (pp && dsl) ? c->out2b : c->out2;
+            const uint64_t want1 = std::max<uint64_t>(b1 + b1 / 16, 16), want2 = std::max<uint64_t>(b2 + b2 / 16, 16);
+            if (pp && d2h_rec[dsl]) {
+                if (want1 > d1.cap || want2 > d2.cap) HIP_OK(hipEventSynchronize(c->ev_d2h[dsl]));   // the buffer is about to move: its last copy must be out
+                else HIP_OK(hipStreamWaitEvent(s, c->ev_d2h[dsl], 0));
+            }
+            d1.reserve(want1, s); d2.reserve(want2, s);
             o1 = d1.as<char>(); o2 = d2.as<char>();
         }
         c->tm_reads.begin(s);                                                      // the base pass writes the FASTQ text at the record offsets
         launch_reads(s, c->genome.as<uint8_t>(), c->genome2.as<uint32_t>() + 16, c->semis.pool_view(), c->fulls.pool_view(), pr, np, 0,
                      c->dtb, c->d_tables.as<DevTables>(), c->key, paired, slot, B.ev_hdr, B.ev_dat,
-                     B.off1, B.off2, o1, o2, c->flags.as<uint32_t>(), b1, b2, B.slist1, B.slist2, B.clist1, B.clist2, nc1, nc2, B.dlist1, B.dlist2, nd1, nd2);
+                     B.off1, B.off2, o1, o2, c->flags.as<uint32_t>(), b1, b2, B.slist1, B.slist2, B.clist1, B.clist2, nc1, nc2, B.dlist1, B.dlist2, nd1, nd2, &c->reads_side);
         c->tm_reads.end(s);
         c->tm_reads.add_units(np);
+        if (c->want_cks && !tg.device) {
+            launch_text_checksum(s, o1, b1, c->d_cks.as<unsigned long long>() + 2 * (size_t)bidx);
+            launch_text_checksum(s, o2, paired ? b2 : 0, c->d_cks.as<unsigned long long>() + 2 * (size_t)bidx + 1);
+        }
         if (ps != s) { HIP_OK(hipEventRecord(c->ev_free[it & 1], s)); free_rec[it & 1] = true; }   // this batch's buffer set is free for the pre-pass after next
         { const hipError_t le = take_launch_error(); if (le != hipSuccess) throw ScsError(SCS_EDEVICE, std::string("k_reads launch failed: ") + hipGetErrorString(le)); }
         if (pp) {
-            for (int f = 0; f < 2; ++f) {                                           // per-slot pinned buffers, grown on demand (capacity kept in a 16-byte header)
-                char*& h = f == 0 ? pp->h1[sl] : pp->h2[sl]; const size_t need = f == 0 ? b1 : b2;
-                size_t have = 0; if (h) { have = ((size_t*)h)[-1]; }
-                if (need > have) {
-                    if (h) HIP_OK(hipHostFree((size_t*)h - 2));
-                    const size_t nc = std::max<size_t>(need + need / 8, 1 << 20); void* raw = nullptr;
-                    HIP_OK(hipHostMalloc(&raw, nc + 16, hipHostMallocDefault));
-                    ((size_t*)raw)[1] = nc; h = (char*)((size_t*)raw + 2);
-                }
-            }
-            HIP_OK(hipEventRecord(c->ev_made[sl], s));                              // the batch's text is complete ...
-            HIP_OK(hipStreamWaitEvent(c->copy_stream, c->ev_made[sl], 0));          // ... and crosses PCIe on the copy stream, beside the next batch's kernels
-            if (b1) HIP_OK(hipMemcpyAsync(pp->h1[sl], o1, b1, hipMemcpyDeviceToHost, c->copy_stream));
-            if (b2) HIP_OK(hipMemcpyAsync(pp->h2[sl], o2, b2, hipMemcpyDeviceToHost, c->copy_stream));
-            HIP_OK(hipEventRecord(pp->ev[sl], c->copy_stream));
-            pp->submit(sl, b1, b2);
+            HIP_OK(hipEventRecord(c->ev_made[dsl], s));                             // the batch's text is complete ...
+            const int hs = pp->acquire(b1, b2);                                     // (a pinned slot no writer holds: the host waits here when the sink is the slower side)
+            if (hs < 0) throw ScsError(SCS_EIO, "sink aborted");
+            SinkPipe::Slot& H = pp->slots[(size_t)hs];
+            HIP_OK(hipStreamWaitEvent(c->copy_stream, c->ev_made[dsl], 0));         // ... and crosses PCIe on the copy stream, beside the next batch's kernels
+            if (b1) HIP_OK(hipMemcpyAsync(H.h[0], o1, b1, hipMemcpyDeviceToHost, c->copy_stream));
+            if (b2) HIP_OK(hipMemcpyAsync(H.h[1], o2, b2, hipMemcpyDeviceToHost, c->copy_stream));
+            HIP_OK(hipEventRecord(H.ev, c->copy_stream));
+            HIP_OK(hipEventRecord(c->ev_d2h[dsl], c->copy_stream)); d2h_rec[dsl] = true;
+            pp->submit((int)region_of[it], hs, b1, b2);
             ++bi;
         }
         tot1 += b1; tot2 += b2;
     }
-    for (; bnext < bpair.size(); ++bnext) { (*tg.seg_off1)[bnext] = tot1; if (tg.seg_off2) (*tg.seg_off2)[bnext] = tot2; }
+    if (tg.seg_off1) {                                                               // record order = batch order: the bytes before each batch
+        std::vector<uint64_t> pre1(nbatch + 1, 0), pre2(nbatch + 1, 0);
+        for (uint32_t b = 0; b < nbatch; ++b) { pre1[b + 1] = pre1[b] + bb1[b]; pre2[b + 1] = pre2[b] + bb2[b]; }
+        for (size_t j = 0; j < bpair.size(); ++j) { (*tg.seg_off1)[j] = tot1; if (tg.seg_off2) (*tg.seg_off2)[j] = tot2; }   // segments that start behind the last pair
+        for (const SegAt& a : seg_at) { (*tg.seg_off1)[a.seg] = pre1[a.b] + a.o1; if (tg.seg_off2) (*tg.seg_off2)[a.seg] = pre2[a.b] + a.o2; }
+    }
     // pairs produced = planned - holes; a hole arises only when > 1000 insert sizes in a row miss [readLength, ampliconLen]
     // (Amplicon.cpp:484-489): k_plan_pairs counted them on the device
     { Mail m; m.add(c->flags.p, 4, 30); m.add(c->dsums.as<unsigned long long>() + DS_HOLES, 8, 2); mail_post(c, m, true); }   // flags + hole count land before the final synchronize: no second round trip
     HIP_OK(hipStreamSynchronize(s));
     if (to_sink) { HIP_OK(hipStreamSynchronize(c->copy_stream)); guard.p = nullptr; if (!c->pipe->finish()) throw ScsError(SCS_EIO, "sink aborted"); }
     mail_wait(c); flags_eval(c);
+    if (c->want_cks && !tg.device && nbatch) { c->cks.assign((size_t)nbatch * 2, 0); HIP_OK(hipMemcpyAsync(c->cks.data(), c->d_cks.p, (size_t)nbatch * 16, hipMemcpyDeviceToHost, s)); HIP_OK(hipStreamSynchronize(s)); }
     pairs_written = P - c->h_rb[2];
     c->tm_reads.collect(); c->tm_indels.collect();
     c->st.pairs_written = pairs_written; c->st.reads_written = paired ? 2 * pairs_written : pairs_written;
@@ -1050,19 +1110,17 @@ void scs_destroy(scs_ctx* c) {
                       &c->d_isize, &c->d_gcmeans, &c->genome, &c->genome2, &c->gx_gc_bits, &c->gx_n_bits, &c->gx_gc_cnt, &c->gx_n_cnt, &c->gx_gc_pref, &c->gx_n_pref, &c->d_binom, &c->df_blob, &c->df_primers, &c->df_hasn, &c->primer_cnt, &c->primer_delta,
                       &c->slots, &c->slot_tmpl, &c->slots_fr, &c->slot_tmpl_fr, &c->valid, &c->valid_off, &c->valid_f, &c->valid_off_f, &c->scan_tmp, &c->flags, &c->weights, &c->read_numbers,
                       &c->pair_off, &c->pairs, &c->odd_before, &c->a_part, &c->a_tp, &c->a_probs, &c->a_quota, &c->a_poff, &c->a_plan, &c->a_crn, &c->a_scratch, &c->a_brow, &c->a_bmap, &c->a_send, &c->a_gath, &c->a_odd, &c->d_hostred, &c->d_tot, &c->d_stage, &c->d_mail, &c->budget_f, &c->budget_s, &c->poisson_part, &c->slot_off_f,
-                      &c->slot_off_s, &c->dsums, &c->slot_b, &c->slot_q, &c->lens, &c->ev_hdr, &c->ev_dat, &c->sizes1, &c->sizes2, &c->off1, &c->off2, &c->out1, &c->out2, &c->out1b, &c->out2b, &c->rl_cls, &c->rl_pos, &c->rl_lists, &c->d_bounds}) b->release();
+                      &c->slot_off_s, &c->dsums, &c->slot_b, &c->slot_q, &c->lens, &c->ev_hdr, &c->ev_dat, &c->sizes1, &c->sizes2, &c->off1, &c->off2, &c->out1, &c->out2, &c->out1b, &c->out2b, &c->rl_cls, &c->rl_pos, &c->rl_lists, &c->d_bounds, &c->d_cks}) b->release();
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->errs_stream) { (void)hipStreamDestroy(c->errs_stream); (void)hipEventDestroy(c->ev_att); (void)hipEventDestroy(c->ev_errs); }
     if (c->pre_stream) { (void)hipStreamDestroy(c->pre_stream); (void)hipEventDestroy(c->ev_plan); for (int k = 0; k < 2; ++k) { (void)hipEventDestroy(c->ev_pre[k]); (void)hipEventDestroy(c->ev_free[k]); } }
-    for (int k = 0; k < 2; ++k) if (c->ev_made[k]) (void)hipEventDestroy(c->ev_made[k]);
+    for (int k = 0; k < 2; ++k) { if (c->ev_made[k]) (void)hipEventDestroy(c->ev_made[k]); if (c->ev_d2h[k]) (void)hipEventDestroy(c->ev_d2h[k]); }
+    c->reads_side.release();
     c->semis.release(); c->fulls.release();
     for (KernelTimer* t : {&c->tm_errscan, &c->tm_errscan_f, &c->tm_reads, &c->tm_attach, &c->tm_indels, &c->tm_attach_f}) t->release();
     if (c->h_rb) (void)hipHostFree(c->h_rb);
     if (c->h_frag) (void)hipHostFree(c->h_frag);
-    if (c->pipe) {
-        for (int k = 0; k < 2; ++k) { if (c->pipe->h1[k]) (void)hipHostFree((size_t*)c->pipe->h1[k] - 2); if (c->pipe->h2[k]) (void)hipHostFree((size_t*)c->pipe->h2[k] - 2); (void)hipEventDestroy(c->pipe->ev[k]); }
-        delete c->pipe;
-    }
+    if (c->pipe) { c->pipe->release(); delete c->pipe; }
     if (c->rccl) rccl_destroy(c->rccl);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -1156,31 +1214,42 @@ int scs_create_frags(scs_ctx* c) { return guarded(c, [&] { double t = now_s(); d
 int scs_amplify(scs_ctx* c) { return guarded(c, [&] { double t = now_s(); do_amplify(c); c->st.t_stage[2] = now_s() - t; }); }
 int scs_allocate_reads(scs_ctx* c, uint64_t reads) { return guarded(c, [&] { do_allocate(c, reads); }); }
 int scs_yield_reads(scs_ctx* c, scs_sink_fn sink, void* user) {
-    return guarded(c, [&] { double t = now_s(); OutTarget tg{false, nullptr, nullptr, 0, 0, sink, user}; do_yield(c, tg, nullptr, nullptr, nullptr); c->st.t_stage[5] = now_s() - t; });
+    return guarded(c, [&] {
+        double t = now_s(); CallbackSink cb(sink, user);
+        OutTarget tg{false, nullptr, nullptr, 0, 0, sink ? &cb : nullptr}; do_yield(c, tg, nullptr, nullptr, nullptr); c->st.t_stage[5] = now_s() - t;
+    });
 }
 int scs_yield_reads_device(scs_ctx* c, void* d1, size_t cap1, void* d2, size_t cap2, uint64_t* n1, uint64_t* n2, uint64_t* pairs) {
     return guarded(c, [&] {
         if (!d1 || (c->cfg.paired && !d2)) throw ScsError(SCS_EINVAL, "scs_yield_reads_device: null output buffer");
-        double t = now_s(); OutTarget tg{true, (char*)d1, (char*)d2, cap1, cap2, nullptr, nullptr}; do_yield(c, tg, n1, n2, pairs); c->st.t_stage[5] = now_s() - t;
+        double t = now_s(); OutTarget tg{true, (char*)d1, (char*)d2, cap1, cap2, nullptr}; do_yield(c, tg, n1, n2, pairs); c->st.t_stage[5] = now_s() - t;
     });
 }
-static int files_sink(void* user, const char* a, size_t na, const char* b, size_t nb) { return ((FastqFiles*)user)->write(a, na, b, nb) ? 0 : 1; }
-int scs_yield_reads_files(scs_ctx* c, const char* prefix, int writer_threads) {
+// SeqWriter (lib/seqwriter/SeqWriter.cpp:12-64).  writers <= 1: the reference's files <prefix>_1.fq / _2.fq (.fq) -- a shard of a
+// sharded job: <prefix>.r<rank>_1.fq ... + <prefix>.r<rank>.idx.  writers = K > 1: K part files per mate, each a contiguous
+// range of the job's (shard's) records written by its own thread, + <base>.parts (scs_comm.h: FastqParts).
+int scs_yield_reads_files(scs_ctx* c, const char* prefix, int writers) {
     return guarded(c, [&] {
         if (!prefix || !*prefix) throw ScsError(SCS_EINVAL, "scs_yield_reads_files: no output prefix");
+        if (writers > 64) throw ScsError(SCS_EINVAL, "scs_yield_reads_files: at most 64 writers");
         const bool pe = c->cfg.paired != 0, shard = c->cfg.shard_count > 1; const std::string pre = prefix;
-        const std::string f1 = shard ? shard_path(pre, c->cfg.shard_rank, 0, pe) : pre + (pe ? "_1.fq" : ".fq");
-        const std::string f2 = pe ? (shard ? shard_path(pre, c->cfg.shard_rank, 1, pe) : pre + "_2.fq") : std::string();
-        FastqFiles files; std::string err;
-        if (!files.open(f1, f2, writer_threads > 0 ? writer_threads : 1, err)) throw ScsError(SCS_EIO, err);
-        if (const char* rc = getenv("SCS_SINK_RECYCLE_MB")) files.set_recycle((uint64_t)atoll(rc) << 20);   // measurement only: see FastqFiles::set_recycle
+        const std::string base = shard ? shard_base(pre, c->cfg.shard_rank) : pre;
+        FastqParts files; std::string err;
+        if (!files.open(base, pe, writers > 1 ? writers : 1, ".fq", false, err)) throw ScsError(SCS_EIO, err);
         std::vector<uint64_t> so1, so2;
-        double t = now_s(); OutTarget tg{false, nullptr, nullptr, 0, 0, files_sink, &files}; if (shard) { tg.seg_off1 = &so1; tg.seg_off2 = &so2; }
+        double t = now_s(); OutTarget tg{false, nullptr, nullptr, 0, 0, &files}; if (shard) { tg.seg_off1 = &so1; tg.seg_off2 = &so2; }
         do_yield(c, tg, nullptr, nullptr, nullptr);
-        if (!files.close()) throw ScsError(SCS_EIO, "writing " + f1 + " failed");
+        if (!files.close(err)) throw ScsError(SCS_EIO, err);
         if (shard && !write_shard_index(shard_index_path(pre, c->cfg.shard_rank), so1, so2, err)) throw ScsError(SCS_EIO, err);
         c->st.t_stage[5] = now_s() - t;
     });
+}
+int scs_merge_fastq_parts(const char* prefix, int paired, int keep_parts, char* errbuf, size_t errlen) {
+    if (!prefix) return SCS_EINVAL;
+    std::string err;
+    if (merge_parts(prefix, paired != 0, ".fq", keep_parts != 0, err)) return SCS_OK;
+    if (errbuf && errlen) { strncpy(errbuf, err.c_str(), errlen - 1); errbuf[errlen - 1] = 0; }
+    return SCS_EIO;
 }
 int scs_merge_fastq_shards(const char* prefix, int nranks, int paired, int keep_shards, char* errbuf, size_t errlen) {
     if (!prefix) return SCS_EINVAL;
@@ -1216,6 +1285,8 @@ int scs_comm_init(scs_ctx* c, const void* id, int rank, int nranks) {
         c->allreduce_dev = rccl_allreduce_hook; c->allgather_dev = rccl_allgather_hook; c->coll_dev_user = c;
     });
 }
+int scs_comm_count(const scs_ctx* c) { return c && c->rccl ? rccl_count(c->rccl) : 0; }
+int scs_comm_abort(scs_ctx* c) { if (!c) return SCS_EINVAL; if (c->rccl) rccl_abort(c->rccl); return SCS_OK; }
 int scs_run_genreads(scs_ctx* c, scs_sink_fn sink, void* user) {
     int rc; double t = now_s();
     if ((rc = scs_create_frags(c))) return rc;
@@ -1231,6 +1302,13 @@ int scs_set_collectives(scs_ctx* c, scs_allreduce_fn ar, scs_allgatherv_fn ag, v
 int scs_set_collectives_device(scs_ctx* c, scs_allreduce_dev_fn ar, scs_allgather_dev_fn ag, void* user) {
     if (!c) return SCS_EINVAL;
     c->allreduce_dev = ar; c->allgather_dev = ag; c->coll_dev_user = user; return SCS_OK;
+}
+int scs_set_batch_checksums(scs_ctx* c, int on) { if (!c) return SCS_EINVAL; c->want_cks = on != 0; return SCS_OK; }
+int scs_batch_checksums(const scs_ctx* c, uint64_t* out, size_t cap, size_t* n_batches) {
+    if (!c || !n_batches) return SCS_EINVAL;
+    *n_batches = c->cks.size() / 2;
+    if (out) memcpy(out, c->cks.data(), std::min(cap, c->cks.size()) * 8);
+    return SCS_OK;
 }
 int scs_get_stats(const scs_ctx* c, scs_stats* out) { if (!c || !out) return SCS_EINVAL; *out = c->st; return SCS_OK; }
 

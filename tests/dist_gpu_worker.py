@@ -8,6 +8,7 @@ sys.path.insert(0, ROOT)
 
 def main():
     fasta, profile, prefix, coverage, layout, seed, hooks = sys.argv[1:8]
+    writers = int(sys.argv[8]) if len(sys.argv) > 8 else 0   # > 1: the shard is written as that many part files per mate
     import torch.distributed as dist
     import scssim_amd
     from scssim_amd.dist import Collectives
@@ -20,7 +21,7 @@ def main():
                             stream=stream.cuda_stream, shard_rank=dist.get_rank(), shard_count=dist.get_world_size())
     g.set_collectives(coll, device_hooks=(hooks == "device"))
     g.create_frags(); g.amplify(); g.allocate_reads(0)
-    g.yield_reads_files(prefix)                     # this rank's shard + index: <prefix>.r<rank>_1.fq / _2.fq / .idx
+    g.yield_reads_files(prefix, writers)            # this rank's shard + index: <prefix>.r<rank>_1.fq / _2.fq / .idx (or its parts)
     st = g.stats()
     print("rank %d: %d fragments, %d fulls, %d pairs, collectives %s" % (dist.get_rank(), st["fragments"], st["full_amplicons"], st["pairs_written"], coll.calls))
     dist.barrier()

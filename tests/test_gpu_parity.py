@@ -498,6 +498,31 @@ def test_very_long_reads_take_the_general_variant(oracle_bin, models, tmp_path):
     assert g.stats()["pairs_written"] == want.count(b"\n") // 4
 
 
+@pytest.mark.parametrize("case", ["g1", "medium"])
+def test_insert_size_give_up_path_bit_exact(case, oracle_bin, models, golden_inputs, tmp_path):
+    """-s 1500: the mean insert is as long as the amplicons (1000-2000 bases), so most insert-size draws are rejected
+    (`isize > ampLen`, Amplicon.cpp:484-489) and many amplicons give up after 1000 fails in a row: their planned pairs become
+    holes in the record numbering.  FASTQ byte for byte against the oracle (which reproduces the reference in this regime), the
+    holes counted once each -- also with a batch boundary inside an amplicon (the small-batch run repeats this test)."""
+    if case == "g1":
+        fa, prof, cov, seed = golden_inputs["g1_hiseq2500_pe"], models["Illumina_HiSeq2500"], 6.0, 15
+    else:
+        fa = str(tmp_path / "simu.fa")
+        subprocess.check_call(["python3", os.path.join(ROOT, "tools", "make_genome.py"), "--lengths", "7000000,5000000", "--seed", "31", "--n-block", "20000", "--simu-out", fa])
+        prof, cov, seed = models["Illumina_HiSeqXTen"], 3.0, 16
+    prefix = str(tmp_path / "orc")
+    _oracle_run(oracle_bin, fa, prof, prefix, ["-c", "%g" % cov, "-s", "1500"], seed, threads=min(32, os.cpu_count() or 1))
+    g = scssim_amd.GenReads(profile=prof, input_fasta=fa, coverage=cov, isize=1500, seed=seed)
+    fq1, fq2 = g.run()
+    w1, w2 = open(prefix + "_1.fq", "rb").read(), open(prefix + "_2.fq", "rb").read()
+    assert fq1 == w1, _fastq_diff(fq1, w1)
+    assert fq2 == w2
+    st = g.stats()
+    made = w1.count(b"\n") // 4
+    assert st["pairs_written"] == made and st["reads_written"] == 2 * made
+    assert 0 < made < 0.9 * (st["reads_requested"] // 2), "the give-up path was not reached"
+
+
 def _md5_file(path):
     import hashlib
     h = hashlib.md5()
@@ -702,7 +727,8 @@ def test_many_small_batches_match_oracle(models, tmp_path):
         pytest.skip("already inside the small-batch run")
     env = dict(os.environ, SCS_TEST_BATCH_SHIFT="12")
     sel = ["tests/test_gpu_parity.py::test_full_pipeline_fastq_bit_exact", "tests/test_gpu_parity.py::test_medium_genome_bit_exact",
-           "tests/test_gpu_parity.py::test_very_long_reads_take_the_general_variant", "tests/test_gpu_parity.py::test_device_resident_output_matches_oracle"]
+           "tests/test_gpu_parity.py::test_very_long_reads_take_the_general_variant", "tests/test_gpu_parity.py::test_device_resident_output_matches_oracle",
+           "tests/test_gpu_parity.py::test_insert_size_give_up_path_bit_exact"]
     r = subprocess.run(["python", "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider"] + sel, cwd=ROOT, env=env,
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:]

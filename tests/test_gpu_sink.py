@@ -1,0 +1,186 @@
+"""GPU tests of the FASTQ sink (SeqWriter's replacement): part files written by several writer threads, the
+shards of a sharded job written in parts, and what a job leaves behind when its sink fails.  Run with `-m gpu`."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+import scssim_amd
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle(oracle_bin, fasta, profile, prefix, args, seed, threads=8):
+    subprocess.check_call([oracle_bin, "genreads", "-i", fasta, "-m", profile, "-o", prefix, "--rng", "counter", "--seed", str(seed), "-t", str(threads), "-q"] + args)
+
+
+def _cat(files):
+    return b"".join(open(f, "rb").read() for f in files)
+
+
+_CHILD = '''
+import os, sys
+sys.path.insert(0, %(root)r)
+import scssim_amd
+g = scssim_amd.GenReads(profile=%(prof)r, input_fasta=%(fa)r, coverage=%(cov)r, layout=%(layout)r, seed=%(seed)d)
+g.create_frags(); g.amplify(); g.allocate_reads(0)
+for K in %(ks)r:
+    g.yield_reads_files(%(out)r + "_k%%d" %% K, K)
+print("pairs", g.stats()["pairs_written"])
+'''
+
+
+@pytest.mark.parametrize("case,layout,shift,ks", [("medium", "PE", "12", (2, 3, 7)), ("g1", "PE", "9", (4, 64)), ("g3", "SE", "9", (3,))])
+def test_part_files_concatenate_to_the_oracle_files(case, layout, shift, ks, oracle_bin, models, golden_inputs, tmp_path):
+    """scs_yield_reads_files with K writers: the job's records are cut into K contiguous ranges whose batches are made round-robin
+    and written by K threads into K part files per mate.  `cat` of the parts in order must be the oracle's file, for K below,
+    at and far above the number of batches (empty parts), PE and SE.  Child processes: small batches (SCS_TEST_BATCH_SHIFT) so
+    that every region has many."""
+    if case == "medium":
+        fa = str(tmp_path / "simu.fa")
+        subprocess.check_call(["python3", os.path.join(ROOT, "tools", "make_genome.py"), "--lengths", "7000000,5000000", "--seed", "31", "--n-block", "20000", "--simu-out", fa])
+        prof, cov, seed = models["Illumina_HiSeqXTen"], 4.0, 8
+    elif case == "g1":
+        fa, prof, cov, seed = golden_inputs["g1_hiseq2500_pe"], models["Illumina_HiSeq2500"], 3.0, 21
+    else:
+        fa, prof, cov, seed = golden_inputs["g3_hiseq2000_se"], models["Illumina_HiSeq2000"], 2.0, 22
+    prefix = str(tmp_path / "orc")
+    _oracle(oracle_bin, fa, prof, prefix, ["-c", "%g" % cov, "-l", layout], seed, threads=min(32, os.cpu_count() or 1))
+    out = str(tmp_path / "gpu")
+    code = _CHILD % dict(root=ROOT, prof=prof, fa=fa, cov=cov, layout=layout, seed=seed, ks=tuple(ks), out=out)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SCS_TEST_BATCH_SHIFT=shift), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    paired = layout == "PE"
+    want = [open(prefix + s, "rb").read() for s in (("_1.fq", "_2.fq") if paired else (".fq",))]
+    assert len(want[0]) > 100000
+    for K in ks:
+        base = out + "_k%d" % K
+        files = scssim_amd.part_paths(base, K, paired)
+        assert all(os.path.exists(f) for m in files for f in m)
+        for m in range(len(want)):
+            assert _cat(files[m]) == want[m], "K = %d, mate %d" % (K, m + 1)
+        sizes = [l.split("\t") for l in open(base + ".parts").read().splitlines() if not l.startswith("#")]
+        assert [int(x[1]) for x in sizes] == [os.path.getsize(f) for f in files[0]]
+        if case == "medium":
+            assert min(os.path.getsize(f) for f in files[0]) > 0, "every writer had work"
+    # ... and the host-side merge rebuilds the reference's file names from them
+    base = out + "_k%d" % ks[0]
+    scssim_amd.merge_fastq_parts(base, paired=paired)
+    for m, f in enumerate(scssim_amd.part_paths(base, 1, paired)):
+        assert open(f[0], "rb").read() == want[m]
+
+
+def test_sharded_job_written_in_parts_merges_to_the_whole_job(oracle_bin, models, golden_inputs, tmp_path):
+    """Two shards (two processes on this box's GPU, gloo hooks), each writing its shard as 3 part files per mate with small
+    batches: the native range merge reads the parts as one logical file per shard and rebuilds the unsharded job's files."""
+    import socket
+    case, model, cov, seed, world = "g2_xten_pe_nblock", "Illumina_HiSeqXTen", "3", "778", 2
+    whole = str(tmp_path / "whole")
+    _oracle(oracle_bin, golden_inputs[case], models[model], whole, ["-c", cov], seed)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = str(s.getsockname()[1]); s.close()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=port, LOCAL_RANK="0", SCS_TEST_BATCH_SHIFT="9")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_gpu_worker.py"), golden_inputs[case], models[model],
+                                       str(tmp_path / "shard"), cov, "PE", seed, "device", "3"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    assert os.path.exists(str(tmp_path / "shard") + ".r1.p02_2.fq") and os.path.exists(str(tmp_path / "shard") + ".r0.parts")
+    scssim_amd.merge_fastq_shards(str(tmp_path / "shard"), world, paired=True)
+    for suffix in ("_1.fq", "_2.fq"):
+        assert open(str(tmp_path / "shard") + suffix, "rb").read() == open(whole + suffix, "rb").read(), suffix
+    assert not os.path.exists(str(tmp_path / "shard") + ".r0.p00_1.fq")
+
+
+def test_failing_sink_aborts_the_job_and_the_ctx_stays_usable(models, golden_inputs, tmp_path):
+    """A sink that reports an error (a full disk, a closed pipe) ends the call with SCS_EIO -- no hang with batches in flight --
+    and an output file that cannot be opened is reported before anything runs; the ctx then produces the right reads again."""
+    g = scssim_amd.GenReads(profile=models["Illumina_HiSeq2500"], input_fasta=golden_inputs["g1_hiseq2500_pe"], coverage=2.0, seed=5)
+    good = g.run()
+    g.create_frags(); g.amplify(); g.allocate_reads(0)
+    calls = [0]
+
+    def bad_sink(_u, _p1, n1, _p2, n2):
+        calls[0] += 1
+        return 1
+    with pytest.raises(scssim_amd.ScsError) as e:
+        g.yield_reads_sink(bad_sink)
+    assert e.value.code == 2 and calls[0] >= 1
+    with pytest.raises(scssim_amd.ScsError) as e:
+        g.yield_reads_files(str(tmp_path / "no_such_dir" / "x"), 3)
+    assert e.value.code == 2 and "can not open fastq file" in str(e.value)
+    assert g.run() == good
+
+
+def _cli(args, env=None, timeout=300):
+    import signal
+    exe = os.path.join(ROOT, "scssim_amd", "bin", "scssim")
+    p = subprocess.Popen([exe, "genreads"] + args, env=dict(os.environ, **(env or {})), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+    try:
+        _, err = p.communicate(timeout=timeout)
+    finally:
+        left = subprocess.run(["pgrep", "-g", str(p.pid)], capture_output=True, text=True).stdout.split()
+        try:
+            os.killpg(p.pid, signal.SIGKILL)
+        except ProcessLookupError:
+            pass
+    return p.returncode, err, left
+
+
+def test_cli_forks_two_ranks_on_one_gpu_and_merges_their_shards(oracle_bin, models, golden_inputs, tmp_path):
+    """`scssim genreads --gpus 2 --one-device --host-collectives`: the CLI's multi-rank path end to end on this box's one GPU --
+    fork before the first HIP call, the communicator id down the pipes, a shard + index per rank (exchanges through host memory
+    shared by the ranks: RCCL refuses two ranks on one device), rank 0's watcher reaping rank 1, the native merge -- and the
+    files equal the oracle's.  Then with part files per rank and --keep-shards."""
+    fa, prof = golden_inputs["g2_xten_pe_nblock"], models["Illumina_HiSeqXTen"]
+    prefix = str(tmp_path / "orc")
+    _oracle(oracle_bin, fa, prof, prefix, ["-c", "3"], 31)
+    want = [open(prefix + s, "rb").read() for s in ("_1.fq", "_2.fq")]
+    out = str(tmp_path / "cli")
+    rc, err, left = _cli(["-i", fa, "-m", prof, "-c", "3", "-o", out, "--seed", "31", "--gpus", "2", "--one-device", "--host-collectives"])
+    assert rc == 0, err
+    assert "2 ranks, collectives: host memory" in err and not left
+    assert [open(out + s, "rb").read() for s in ("_1.fq", "_2.fq")] == want
+    assert not os.path.exists(out + ".r0_1.fq") and not os.path.exists(out + ".r1.idx")
+    out = str(tmp_path / "cli3")
+    rc, err, left = _cli(["-i", fa, "-m", prof, "-c", "3", "-o", out, "--seed", "31", "--gpus", "3", "--one-device", "--host-collectives", "--writers", "2", "--keep-shards"],
+                         env={"SCS_TEST_BATCH_SHIFT": "9"})
+    assert rc == 0, err
+    assert os.path.exists(out + ".r2.p01_2.fq") and os.path.exists(out + ".r2.idx") and not os.path.exists(out + "_1.fq")
+    scssim_amd.merge_fastq_shards(out, 3, paired=True)
+    assert [open(out + s, "rb").read() for s in ("_1.fq", "_2.fq")] == want
+
+
+@pytest.mark.parametrize("where,who", [("amplify", 1), ("reads", 1), ("comm", 2), ("amplify", 0)])
+def test_cli_rank_failure_ends_the_job(where, who, models, golden_inputs, tmp_path):
+    """A rank that dies mid-job (injected: SCS_TEST_FAIL_AT / SCS_TEST_FAIL_RANK) leaves its siblings inside an exchange that
+    never completes.  Rank 0's watcher must notice, end the other ranks and exit non-zero within seconds -- no hang, no orphan
+    holding the GPU; when rank 0 itself fails it ends its children first."""
+    import time
+    fa, prof = golden_inputs["g1_hiseq2500_pe"], models["Illumina_HiSeq2500"]
+    t0 = time.time()
+    rc, err, left = _cli(["-i", fa, "-m", prof, "-c", "2", "-o", str(tmp_path / "f"), "--seed", "3", "--gpus", "3", "--one-device", "--host-collectives"],
+                         env={"SCS_TEST_FAIL_AT": where, "SCS_TEST_FAIL_RANK": str(who)}, timeout=120)
+    assert rc in (2, 3) and time.time() - t0 < 90, (rc, err)
+    assert not left, "ranks left behind: %s" % left
+    assert ("rank %d of the sharded job failed" % who) in err or "test failure injected" in err
+    assert not os.path.exists(str(tmp_path / "f") + "_1.fq")
+
+
+def test_cli_writers_and_unopenable_output(oracle_bin, models, golden_inputs, tmp_path):
+    """--writers K on one GPU: part files whose concatenation is the reference's file; an output that cannot be opened ends with the
+    reference's exit(-1) (SeqWriter.cpp:17-33)."""
+    fa, prof = golden_inputs["g1_hiseq2500_pe"], models["Illumina_HiSeq2500"]
+    prefix = str(tmp_path / "orc")
+    _oracle(oracle_bin, fa, prof, prefix, ["-c", "2"], 99)
+    out = str(tmp_path / "w")
+    rc, err, _ = _cli(["-i", fa, "-m", prof, "-c", "2", "-o", out, "--seed", "99", "--writers", "3"], env={"SCS_TEST_BATCH_SHIFT": "8"})
+    assert rc == 0, err
+    files = scssim_amd.part_paths(out, 3, True)
+    for m, s in enumerate(("_1.fq", "_2.fq")):
+        assert _cat(files[m]) == open(prefix + s, "rb").read()
+    rc, err, _ = _cli(["-i", fa, "-m", prof, "-c", "2", "-o", str(tmp_path / "nodir" / "x"), "--seed", "99"])
+    assert rc == 255 and "can not open fastq file" in err

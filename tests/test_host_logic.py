@@ -233,6 +233,92 @@ def test_shard_merge_copies_byte_ranges_in_list_order(tmp_path):
         scssim_amd.merge_fastq_shards(str(tmp_path / "absent"), 2)
 
 
+def test_cli_sharded_job_fails_fast_when_its_ranks_cannot_start(golden_inputs, models, tmp_path):
+    """`scssim genreads --gpus 3` forks its ranks before the first HIP call.  Here (no GPU) every rank fails in scs_create; with a
+    failure injected into rank 2 it dies before that.  Either way rank 0 must come back with a non-zero status at once -- not sit
+    in waitpid or in a collective -- and leave no rank behind (the fork / watch / reap path; the GPU suite runs it to the end)."""
+    import signal
+    import subprocess
+    import time
+    exe = os.path.join(ROOT, "scssim_amd", "bin", "scssim")
+    for extra, env in (([], {}), (["--host-collectives", "--one-device"], {"SCS_TEST_FAIL_AT": "start", "SCS_TEST_FAIL_RANK": "2"})):
+        t0 = time.time()
+        p = subprocess.Popen([exe, "genreads", "-i", golden_inputs["g1_hiseq2500_pe"], "-m", models["Illumina_HiSeq2500"], "-o", str(tmp_path / "o"), "--gpus", "3", "--seed", "1"] + extra,
+                             env=dict(os.environ, **env), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+        try:
+            _, err = p.communicate(timeout=120)
+        finally:
+            try:
+                os.killpg(p.pid, signal.SIGKILL)                      # whatever the job left behind
+            except ProcessLookupError:
+                pass
+        if p.returncode == 0:
+            pytest.skip("a GPU is present: the job ran")
+        assert time.time() - t0 < 60 and p.returncode in (1, 2, 3), err
+        assert "no HIP device" in err or "failed" in err
+
+
+def test_part_files_are_one_logical_file_for_both_merges(tmp_path):
+    """A sink with K writers leaves K part files per mate (<base>.p00_1.fq ...) + <base>.parts; their concatenation is the
+    single file.  Host only: scs_merge_fastq_parts rebuilds the reference's two files from them, and scs_merge_fastq_shards
+    reads a shard that was written in parts (segments straddling part boundaries, empty parts) like a plain one."""
+    import random
+    import scssim_amd
+    rnd = random.Random(11)
+    blob = lambda n: bytes(rnd.getrandbits(8) for _ in range(n))
+    # (1) parts -> the two files
+    for paired in (True, False):
+        pre = str(tmp_path / ("p_pe" if paired else "p_se"))
+        K = 5
+        data = [[blob(rnd.choice([0, 1, 33, 5000, 70001])) for _ in range(K)] for _ in range(2 if paired else 1)]
+        paths = scssim_amd.part_paths(pre, K, paired)
+        for m, files in enumerate(paths):
+            for k, f in enumerate(files):
+                open(f, "wb").write(data[m][k])
+        with open(pre + ".parts", "w") as f:
+            f.write("# parts\n")
+            for k in range(K):
+                f.write("%d\t%d\t%d\n" % (k, len(data[0][k]), len(data[1][k]) if paired else 0))
+        scssim_amd.merge_fastq_parts(pre, paired=paired, keep_parts=not paired)
+        for m, files in enumerate(scssim_amd.part_paths(pre, 1, paired)):
+            assert open(files[0], "rb").read() == b"".join(data[m])
+        assert os.path.exists(paths[0][0]) == (not paired) and os.path.exists(pre + ".parts") == (not paired)
+    # (2) shards written in parts
+    pre = str(tmp_path / "sp"); world, nslot = 2, 40
+    seg = [[[blob(rnd.choice([0, 3, 900, 40000])) for _ in range(nslot)] for _ in range(world)] for _ in range(2)]
+    for r in range(world):
+        K = 3 + r
+        off = [[0], [0]]
+        for m in range(2):
+            whole = b"".join(seg[m][r])
+            for sl in range(nslot):
+                off[m].append(off[m][-1] + len(seg[m][r][sl]))
+            cuts = sorted(rnd.randrange(0, len(whole) + 1) for _ in range(K - 1))
+            cuts = [0] + cuts + [len(whole)]
+            if r == 1:
+                cuts[1] = 0                                           # an empty first part
+            for k, f in enumerate(scssim_amd.part_paths(pre + ".r%d" % r, K, True)[m]):
+                open(f, "wb").write(whole[cuts[k]:cuts[k + 1]])
+            off[m].append(cuts)
+        with open(pre + ".r%d.parts" % r, "w") as f:
+            for k in range(K):
+                f.write("%d\t%d\t%d\n" % (k, off[0][-1][k + 1] - off[0][-1][k], off[1][-1][k + 1] - off[1][-1][k]))
+        with open(pre + ".r%d.idx" % r, "w") as f:
+            for i in range(nslot + 1):
+                f.write("%d\t%d\t%d\n" % (i, off[0][i], off[1][i]))
+    scssim_amd.merge_fastq_shards(pre, world, paired=True)
+    for m, suffix in enumerate(("_1.fq", "_2.fq")):
+        assert open(pre + suffix, "rb").read() == b"".join(seg[m][r][sl] for sl in range(nslot) for r in range(world))
+    assert not os.path.exists(pre + ".r0.p00_1.fq") and not os.path.exists(pre + ".r1.parts")
+    # a part whose size disagrees with the index is refused, not copied
+    pre = str(tmp_path / "bad")
+    for f in scssim_amd.part_paths(pre, 2, False)[0]:
+        open(f, "wb").write(b"xx")
+    open(pre + ".parts", "w").write("0\t2\t0\n1\t3\t0\n")
+    with pytest.raises(scssim_amd.ScsError):
+        scssim_amd.merge_fastq_parts(pre, paired=False)
+
+
 def test_two_word_stream_step_is_sound():
     """[REMAP] stream B of a read advances one xoshiro128 step per output position and takes TWO words from it: the xoshiro128++
     output (scrambler on state words s0, s3) for the substitution draw and the same scrambler on the other two words (s1, s2)
