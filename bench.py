@@ -40,6 +40,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+VALU_PEAK_MEASURED = 7.72e11   # wave-instructions/s: the best integer issue rate tools/valu_peak.hip reached (3.18 cycles, profiles/r02_valu_peak.log)
+VALU_PEAK_SPEC = 256 * 4 * 2.4e9 / 2   # the guide's 2-cycle wave64 issue per SIMD (v_fma_f32): 1.23e12/s
 HG19 = [249250621, 243199373, 198022430, 191154276, 180915260, 171115067, 159138663, 146364022, 141213431, 135534747,
         135006516, 133851895, 115169878, 107349540, 102531392, 90354753, 81195210, 78077248, 59128983, 63025520,
         48129895, 51304566, 155270560, 59373566]
@@ -124,11 +126,26 @@ def cpu_baseline(td, prof, names, seqs, sample_desc, coverage):
         secs = time.perf_counter() - t0
         if r.returncode == 0 and os.path.exists(fa + ".ref_1.fq"):
             pairs = sum(1 for _ in open(fa + ".ref_1.fq", "rb")) // 4
+            aff = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
             out = dict(value=pairs / secs, unit="pairs/s", cores=cores, kind="reference",
-                       sample="%s: %d pairs in %.1f s wall of `scssim genreads -t %d` (whole process: load + amplify + reads + files)" % (sample_desc, pairs, secs, cores))
+                       sample="%s: %d pairs in %.1f s wall of `scssim genreads -t %d` (whole process: load + amplify + reads + files)" % (sample_desc, pairs, secs, cores),
+                       affinity="%d CPUs in the affinity mask, cgroup CPU quota %d cores; the reference pins worker i to CPU i (ThreadPool.cpp:26-39)" % (aff, cores))
         for suf in (".ref_1.fq", ".ref_2.fq"):
             if os.path.exists(fa + suf):
                 os.remove(fa + suf)
+        if out:                                                     # -t 1 beside -t cores, on the sample's first quarter (the rate per core)
+            n1 = max(100000, len(seqs[0]) // 4)
+            fa1 = os.path.join(td, "cpu_sample_t1.fa")
+            write_simu_fasta(fa1, ["1_1_%d" % n1, "1_2_%d" % n1], [seqs[0][:n1], seqs[0][:n1]])
+            t0 = time.perf_counter()
+            r = subprocess.run([ref, "genreads", "-i", fa1, "-m", prof, "-c", "%g" % coverage, "-t", "1", "-o", fa1 + ".ref"], capture_output=True, text=True)
+            secs = time.perf_counter() - t0
+            if r.returncode == 0 and os.path.exists(fa1 + ".ref_1.fq"):
+                pairs = sum(1 for _ in open(fa1 + ".ref_1.fq", "rb")) // 4
+                out["one_thread"] = dict(value=pairs / secs, unit="pairs/s", cores=1, sample="first %.2f Mb of the same sample: %d pairs in %.1f s of `scssim genreads -t 1`" % (n1 / 1e6, pairs, secs))
+            for suf in (".ref_1.fq", ".ref_2.fq", "", ".fai"):
+                if os.path.exists(fa1 + suf):
+                    os.remove(fa1 + suf)
     if os.path.exists(oracle):
         r = subprocess.run([oracle, "genreads", "-i", fa, "-m", prof, "-c", "%g" % coverage, "-t", str(cores), "-o", fa + ".cpu", "--rng", "counter", "--seed", "7"],
                            capture_output=True, text=True)
@@ -214,6 +231,148 @@ def committed_lane_table():
     return {"source": os.path.relpath(files[-1], ROOT), "kernels": top} if top else None
 
 
+class Cleaner:
+    """Unlinks the files of finished steps on background threads (os.unlink releases the GIL), so that tmpfs holds about one
+    step's FASTQ at a time.  gate(limit): wait until at most `limit` bytes are still queued -- the next step's sink starts behind it,
+    INSIDE the timed region."""
+
+    def __init__(self, threads=4):
+        import queue
+        import threading
+        self.q = queue.Queue()
+        self.lock = threading.Lock()
+        self.cv = threading.Condition(self.lock)
+        self.outstanding = 0
+        self.freed = 0
+        self.th = [threading.Thread(target=self._run, daemon=True) for _ in range(threads)]
+        for t in self.th:
+            t.start()
+
+    def _run(self):
+        while True:
+            p = self.q.get()
+            if p is None:
+                return
+            try:
+                n = os.path.getsize(p)
+                os.unlink(p)
+            except OSError:
+                n = 0
+            with self.cv:
+                self.outstanding -= n if n <= self.outstanding else self.outstanding
+                self.freed += n
+                self.cv.notify_all()
+
+    def add(self, paths):
+        sized = []
+        for p in paths:
+            try:
+                sized.append((os.path.getsize(p), p))
+            except OSError:
+                pass
+        with self.cv:
+            self.outstanding += sum(n for n, _ in sized)
+        for _, p in sorted(sized, reverse=True):
+            self.q.put(p)
+
+    def gate(self, limit):
+        t0 = time.perf_counter()
+        with self.cv:
+            while self.outstanding > limit:
+                self.cv.wait(0.05)
+        return time.perf_counter() - t0
+
+    def close(self):
+        self.gate(0)
+        for _ in self.th:
+            self.q.put(None)
+
+
+def roofline_of(ktimes, fq_bytes, L, dom=None):
+    """roofline object of the dominant kernel of a set of timed launches (HIP events on the stream each kernel is launched on)."""
+    dom = dom or max(ktimes, key=lambda k: ktimes[k]["ms"])
+    kd = ktimes[dom]
+    if dom in ("k_reads", "k_indels"):
+        # per pair: insert-size template bytes (mean 261 at -s 260) + the FASTQ bytes of both records (SURVEY 8(d)); the
+        # indel pass alone: the pair record read + 20 B per read written
+        alg = (261.0 * kd["units"] + fq_bytes) if dom == "k_reads" else (56.0 + 2 * 20.0 + 8.0) * kd["units"]
+        note = ("(261 B template + FASTQ bytes of both records) x %d pairs over %d launches" if dom == "k_reads" else "(56 B pair record + 2 x 20 B events + 8 B sizes) x %d pairs over %d launches") % (kd["units"], kd["launches"])
+        draws = 4.0 * L * kd["units"] if dom == "k_reads" else 2.0 * L * kd["units"]
+        draws_note = "k_reads: 2 draws (substitution, quality) per output base x 2 mates" if dom == "k_reads" else "k_indels: 1 draw per input base x 2 mates"
+        survey_alg = None
+    else:
+        # amplification: the implementation's compulsory bytes per created amplicon (28 B record written, 8 B slot written and
+        # read back, 8 primer bases read, 4 B stock counter RMW, ~20 B of the parent's record read); SURVEY 8(d)'s 1526 B
+        # (the 1-2 kb template window read once) is not what this design moves -- GC comes from the bit index and the
+        # error count from one binomial draw -- so it is kept as a second figure only (it would put frac above 1)
+        made = ktimes["k_errs<semi->full>"]["units"] + ktimes["k_errs<frag->semi>"]["units"]
+        alg = 68.0 * made * kd["ms"] / max(1e-9, sum(ktimes[k]["ms"] for k in ktimes if k.startswith("k_attach") or k.startswith("k_errs")))
+        note = "68 B compulsory per created amplicon x %d amplicons, share of %s in the amplification time" % (made, dom)
+        draws = None; draws_note = None
+        survey_alg = 1526.0 * made
+    achieved = alg / (kd["ms"] * 1e-3) / 1e9 if kd["ms"] > 0 else 0.0
+    prefix = {"k_reads": "scs::k_reads", "k_indels": "scs::k_indels", "k_attach<semi>": "scs::k_attach<false", "k_attach<frag>": "scs::k_attach<true",
+              "k_errs<semi->full>": "scs::k_errs<false>", "k_errs<frag->semi>": "scs::k_errs<true>"}[dom]
+    cc = committed_counters(prefix)
+    # the committed counters are per launch of the profiled command (one GPU, 8 M-pair batches); a sharded run launches smaller
+    # batches: scaled by pairs per launch (the k_reads / k_indels counters are proportional to the pairs of a launch)
+    if dom in ("k_reads", "k_indels") and cc.get("profile_pairs_per_launch") and kd["launches"]:
+        scale = (kd["units"] / kd["launches"]) / cc["profile_pairs_per_launch"]
+        for key in ("traffic", "valu_insts_per_launch", "salu_insts_per_launch"):
+            if key in cc:
+                cc[key] *= scale
+    roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": cc.get("traffic"), "traffic_source": cc.get("traffic_source"), "algorithmic_bytes": note,
+            "algorithmic_bytes_per_launch": alg / max(1, kd["launches"]), "avg_launch_ms": kd["ms"] / max(1, kd["launches"]),
+            "timed_launches": kd["launches"], "pairs_per_launch": kd["units"] / max(1, kd["launches"]) if dom in ("k_reads", "k_indels") else None}
+    if draws:
+        roof["draws_per_s"] = draws / (kd["ms"] * 1e-3)
+        roof["draws"] = draws_note
+    if "valu_insts_per_launch" in cc:
+        # VALU issue: 256 CUs x 4 SIMDs at 2.4 GHz.  Priced against the BEST rate tools/valu_peak.hip reached with independent integer
+        # chains (3.18 cycles per wave-instruction: 7.72e11/s, profiles/r02_valu_peak.log); the microarchitecture guide's 2-cycle
+        # issue (1.23e12/s, quoted for v_fma_f32) beside it
+        per_s = cc["valu_insts_per_launch"] / (kd["ms"] * 1e-3 / max(1, kd["launches"]))
+        roof["valu"] = {"insts_per_launch": cc["valu_insts_per_launch"], "lanes_per_inst": cc.get("lanes_per_valu_inst"),
+                        "salu_per_valu": cc.get("salu_insts_per_launch", 0) / max(1.0, cc["valu_insts_per_launch"]),
+                        "issue_frac": per_s / VALU_PEAK_MEASURED, "issue_frac_vs_2_cycle_spec": per_s / VALU_PEAK_SPEC,
+                        "peak_wave_insts_per_s": VALU_PEAK_MEASURED, "spec_wave_insts_per_s": VALU_PEAK_SPEC, "source": cc.get("sq_source")}
+    if survey_alg:
+        roof["survey_model_bytes"] = survey_alg
+    return roof
+
+
+def small_config(torch, scssim_amd, dev, stream, prof, mb, cov, label, shm, steps=5):
+    """One of the smaller BASELINE configurations as an extra line of the same record: the whole job with the text left in HBM
+    (`steps` steps) and once with its two FASTQ files on tmpfs."""
+    lens = [int(mb * 1e6)]
+    names, rl, bases = synth_genome(torch, dev, lens, 7000 + int(mb))
+    g = scssim_amd.GenReads(profile=prof, coverage=cov, isize=260, layout="PE", seed=1, device=dev.index, stream=stream.cuda_stream)
+    g.upload_genome_device(names, rl, bases.data_ptr())
+    del bases
+
+    def one(i, files=None):
+        g.set_seed(500 + i)
+        g.create_frags(); g.amplify(); g.allocate_reads(0)
+        if files:
+            g.yield_reads_files(files)
+        else:
+            g.yield_reads_sink(None)
+        return g.stats()["pairs_written"]
+    one(0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter(); pairs = sum(one(1 + i) for i in range(steps)); torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    sd = tempfile.mkdtemp(prefix="scsbench_small_", dir=shm)
+    try:
+        one(50, os.path.join(sd, "w"))                              # (pins the sink's buffers)
+        t1 = time.perf_counter(); pf = one(51, os.path.join(sd, "r")); tf = time.perf_counter() - t1
+    finally:
+        shutil.rmtree(sd, ignore_errors=True)
+    g.close()
+    return {"workload": label, "pairs_per_step": pairs // steps, "generation_hbm_pairs_per_s": pairs / dt, "ms_per_step_hbm": 1e3 * dt / steps,
+            "with_two_fastq_files_on_tmpfs_pairs_per_s": pf / tf, "ms_per_step_files": 1e3 * tf}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -221,8 +380,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--genome-mb", type=float, default=0.0, help="scale the 24 hg19-like records to this many Mb (default: the real 3096 Mb)")
     ap.add_argument("--coverage", type=float, default=30.0)
+    ap.add_argument("--writers", type=int, default=0, help="part files per mate and writer threads of the FASTQ sink (default: host cores - 4, at most 12)")
+    ap.add_argument("--out-dir", default="", help="where the timed steps write their FASTQ part files (default: a fresh directory on /dev/shm)")
+    ap.add_argument("--hbm-only", action="store_true", help="time the steps with a NULL sink (text generated into HBM buffers, no files): the generation_hbm leg as the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra-legs", action="store_true", help="skip the sink-inclusive and CLI legs")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the generation-only, D2H-only, small-configuration and CLI legs")
     ap.add_argument("--cpu-sample-mb", type=float, default=4.0)
     a = ap.parse_args()
 
@@ -252,6 +414,7 @@ def main():
     cdev = torch.device("cpu") if cpu_coll else dev
 
     td = tempfile.mkdtemp(prefix="scsbench_")
+    shm = "/dev/shm" if os.path.isdir("/dev/shm") else td
     prof = make_profile(td)
     lens = record_lengths(a.genome_mb)
     t_gen = time.perf_counter()
@@ -298,171 +461,159 @@ def main():
                 why = why or "rank 0 could not create a communicator id"
             good = torch.tensor([0 if why else 1], dtype=torch.int32, device=dev)
             dist.all_reduce(good, op=dist.ReduceOp.MIN)
-            coll_path = "RCCL communicator inside the library (scs_comm_init)"
+            coll_path = "RCCL communicator inside the library (scs_comm_init): ncclCommCount = %d ranks" % g.comm_count()
             if int(good[0]) == 0:                                    # every rank takes the same path: the device hooks over torch's RCCL group
                 if why:
                     print("rank %d: scs_comm_init failed (%s); collectives through torch.distributed's RCCL group" % (rank, why), file=sys.stderr)
                 from scssim_amd.dist import Collectives
                 coll = Collectives(stream=stream)
                 g.set_collectives(coll, device_hooks=True)
-                coll_path = "torch.distributed RCCL group on the library's HBM buffers (device hooks)"
+                coll_path = "torch.distributed RCCL group on the library's HBM buffers (device hooks), %d ranks" % dist.get_world_size()
 
-    ktimes = {}
+    cores = host_cores()
+    writers = a.writers or max(1, min(12, cores // max(1, world if world > 1 and not cpu_coll else 1) - 4))
+    out_dir = a.out_dir or tempfile.mkdtemp(prefix="scsbench_out_", dir=shm)
+    os.makedirs(out_dir, exist_ok=True)
+    cleaner = Cleaner(threads=4)
+    GATE_BYTES = 40 << 30                                            # a step's sink starts when at most this much of the older steps' text is still on tmpfs
 
-    def acc(kt, names_):
+    def acc(ktimes, kt, names_):
         for k in names_:
             d = ktimes.setdefault(k, dict(launches=0, ms=0.0, units=0))
             for f in ("launches", "ms", "units"):
                 d[f] += kt[k][f]
 
-    stage = dict(frags=0.0, amplify=0.0, allocate=0.0, reads=0.0)
-
-    def step(i, files=None):
+    def step(i, ktimes, stage, mode):
+        """one whole job with a fresh seed; mode: 'files' (K part files per mate), 'null' (text stays in HBM), or a sink callable"""
         g.set_seed(1000 + i)
         t0 = time.perf_counter(); g.create_frags()
         t1 = time.perf_counter(); g.amplify()
-        acc(g.kernel_times(), ("k_errs<semi->full>", "k_errs<frag->semi>", "k_attach<semi>", "k_attach<frag>"))
+        acc(ktimes, g.kernel_times(), ("k_errs<semi->full>", "k_errs<frag->semi>", "k_attach<semi>", "k_attach<frag>"))
         t2 = time.perf_counter(); g.allocate_reads(0)
         t3 = time.perf_counter()
-        if files:
-            g.yield_reads_files(files)                               # the library's file sink (SeqWriter): D2H + one pwrite() per file, in parallel
-        else:
+        waited = 0.0
+        if mode == "files":
+            waited = cleaner.gate(GATE_BYTES)
+            base = os.path.join(out_dir, "step%d" % i)
+            g.yield_reads_files(base, writers)                       # the library's file sink (SeqWriter): D2H + `writers` threads, one part file per mate each
+            lbase = base + (".r%d" % rank if world > 1 else "")
+            files = [f for m in scssim_amd.part_paths(lbase, writers, True) for f in m] + [lbase + ".parts", lbase + ".idx"]
+            cleaner.add([f for f in files if os.path.exists(f)])
+        elif mode == "null":
             g.yield_reads_sink(None)                                 # generate into HBM batch buffers and count
+        else:
+            g.yield_reads_sink(mode)
         t4 = time.perf_counter()
-        acc(g.kernel_times(), ("k_reads", "k_indels"))
-        for k, v in (("frags", t1 - t0), ("amplify", t2 - t1), ("allocate", t3 - t2), ("reads", t4 - t3)):
-            stage[k] += v
+        acc(ktimes, g.kernel_times(), ("k_reads", "k_indels"))
+        for k, v in (("frags", t1 - t0), ("amplify", t2 - t1), ("allocate", t3 - t2), ("reads", t4 - t3 - waited), ("wait_for_cleanup", waited)):
+            stage[k] = stage.get(k, 0.0) + v
         return g.stats()
 
-    for i in range(a.warmup):                                        # the first step also maps the device buffers
-        step(i)
-    ktimes.clear()
-    for k in stage:
-        stage[k] = 0.0
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    pairs_total, fq_bytes, amps_total, last = 0, 0, 0, None
-    for i in range(a.steps):
-        last = step(a.warmup + i)
-        pairs_total += last["pairs_written"]
-        fq_bytes += sum(last["fastq_bytes"])
-        amps_total += last["semi_amplicons"] + last["full_amplicons"]
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t[0])
-        pt = torch.tensor([pairs_total, fq_bytes, amps_total], dtype=torch.int64, device=cdev)
-        dist.all_reduce(pt)
-        pairs_total, fq_bytes_all, amps_all = int(pt[0]), int(pt[1]), int(pt[2])
-    else:
-        fq_bytes_all, amps_all = fq_bytes, amps_total
+    def timed(n_warm, n_steps, mode, first):
+        """n_warm untimed + n_steps timed steps; returns (elapsed, pairs, fastq bytes, amplicons, kernel times, stage seconds)"""
+        kt, stage = {}, {}
+        for i in range(n_warm):                                      # the first step also maps the device buffers and pins the sink's
+            step(first + i, kt, stage, mode)
+        kt.clear(); stage.clear()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        pairs = fqb = amps = 0
+        for i in range(n_steps):
+            last = step(first + n_warm + i, kt, stage, mode)
+            pairs += last["pairs_written"]; fqb += sum(last["fastq_bytes"]); amps += last["semi_amplicons"] + last["full_amplicons"]
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t[0])
+            pt = torch.tensor([pairs, fqb, amps], dtype=torch.int64, device=cdev)
+            dist.all_reduce(pt)
+            pairs, fqb_all, amps = int(pt[0]), int(pt[1]), int(pt[2])
+        else:
+            fqb_all = fqb
+        return dict(elapsed=elapsed, pairs=pairs, fq_bytes_local=fqb, fq_bytes=fqb_all, amps=amps, ktimes=kt, stage={k: v / n_steps for k, v in stage.items()})
+
+    main_mode = "null" if a.hbm_only else "files"
+    R = timed(a.warmup, a.steps, main_mode, 0)
+    cleaner.gate(0)                                                  # (outside the timed region: the last step's files)
 
     if rank == 0:
         L = g.read_length
-        dom = max(ktimes, key=lambda k: ktimes[k]["ms"])
-        kd = ktimes[dom]
-        if dom in ("k_reads", "k_indels"):
-            # per pair: insert-size template bytes (mean 261 at -s 260) + the FASTQ bytes of both records; the
-            # indel pass alone: the pair record read + 20 B per read written
-            alg = (261.0 * kd["units"] + fq_bytes) if dom == "k_reads" else (56.0 + 2 * 20.0 + 8.0) * kd["units"]
-            note = ("(261 B template + FASTQ bytes of both records) x %d pairs over %d launches" if dom == "k_reads" else "(56 B pair record + 2 x 20 B events + 8 B sizes) x %d pairs over %d launches") % (kd["units"], kd["launches"])
-            draws = 4.0 * L * kd["units"] if dom == "k_reads" else 2.0 * L * kd["units"]
-            draws_note = "k_reads: 2 draws (substitution, quality) per output base x 2 mates" if dom == "k_reads" else "k_indels: 1 draw per input base x 2 mates"
-            survey_alg = None
-        else:
-            # amplification: the implementation's compulsory bytes per created amplicon (28 B record written, 8 B slot written and
-            # read back, 8 primer bases read, 4 B stock counter RMW, ~20 B of the parent's record read); SURVEY 8(d)'s 1526 B
-            # (the 1-2 kb template window read once) is not what this design moves -- GC comes from the bit index and the
-            # error count from one binomial draw -- so it is kept as a second figure only (it would put frac above 1)
-            made = ktimes["k_errs<semi->full>"]["units"] + ktimes["k_errs<frag->semi>"]["units"]
-            per = 68.0
-            alg = per * made * kd["ms"] / max(1e-9, sum(ktimes[k]["ms"] for k in ktimes if k.startswith("k_attach") or k.startswith("k_errs")))
-            note = "68 B compulsory per created amplicon x %d amplicons, share of %s in the amplification time" % (made, dom)
-            draws = None; draws_note = None
-            survey_alg = 1526.0 * made
-        achieved = alg / (kd["ms"] * 1e-3) / 1e9 if kd["ms"] > 0 else 0.0
-        prefix = {"k_reads": "scs::k_reads", "k_indels": "scs::k_indels", "k_attach<semi>": "scs::k_attach<false", "k_attach<frag>": "scs::k_attach<true",
-                  "k_errs<semi->full>": "scs::k_errs<false>", "k_errs<frag->semi>": "scs::k_errs<true>"}[dom]
-        cc = committed_counters(prefix)
-        # the committed counters are per launch of the profiled command (one GPU, 8 M-pair batches); a sharded run launches smaller
-        # batches: scaled by pairs per launch (the k_reads / k_indels counters are proportional to the pairs of a launch)
-        if dom in ("k_reads", "k_indels") and cc.get("profile_pairs_per_launch") and kd["launches"]:
-            scale = (kd["units"] / kd["launches"]) / cc["profile_pairs_per_launch"]
-            for key in ("traffic", "valu_insts_per_launch", "salu_insts_per_launch"):
-                if key in cc:
-                    cc[key] *= scale
-        roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": cc.get("traffic"), "traffic_source": cc.get("traffic_source"), "algorithmic_bytes": note,
-                "algorithmic_bytes_per_launch": alg / max(1, kd["launches"]), "avg_launch_ms": kd["ms"] / max(1, kd["launches"]),
-                "timed_launches": kd["launches"], "timing": "HIP events on the ctx stream around every launch of the timed region"}
-        if draws:
-            roof["draws_per_s"] = draws / (kd["ms"] * 1e-3)
-            roof["draws"] = draws_note
-        if "valu_insts_per_launch" in cc:
-            # VALU issue: 256 CUs x 4 SIMDs, one wave64 VALU instruction per 4 cycles per SIMD at 2.4 GHz (measured integer-op
-            # issue rate: tools/valu_peak.hip) = 614 G wave-instructions/s
-            peak_valu = 256 * 4 * 2.4e9 / 4
-            roof["valu"] = {"insts_per_launch": cc["valu_insts_per_launch"], "lanes_per_inst": cc.get("lanes_per_valu_inst"),
-                            "salu_per_valu": cc.get("salu_insts_per_launch", 0) / max(1.0, cc["valu_insts_per_launch"]),
-                            "issue_frac": cc["valu_insts_per_launch"] / (kd["ms"] * 1e-3 / max(1, kd["launches"])) / peak_valu,
-                            "peak_wave_insts_per_s": peak_valu, "source": cc.get("sq_source")}
-        if survey_alg:
-            roof["survey_model_bytes"] = survey_alg
+        elapsed, pairs_total = R["elapsed"], R["pairs"]
         out = {
-            "metric": "paired-end read pairs/s (whole genreads job: MALBAC amplification + read allocation + read generation, PE150 30x)",
+            "metric": "paired-end read pairs/s (whole genreads job: MALBAC amplification + read allocation + read generation + FASTQ files, PE150 30x)",
             "value": pairs_total / elapsed, "unit": "pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,   # the same job on 1, 2, 4, 8 GPUs
             "dtype": "u8/u32 (integer draws, byte sequences; fp64 only in the GC-weight draw and the allocation sums)", "data": "synthetic",
             "config": {"workload": ("configs[3] on %d GPU(s): %.0f Mb synthetic diploid genome (24 hg19-length records x 2 haplotypes, i.i.d. 30/20/20/30 %% ACGT, generated in HBM), "
                                     "PE150 %gx, HiSeq2500 model resampled to 150 bins, -p 100000 -r 1e-9 -s 260" % (world, sum(lens) / 1e6, a.coverage)),
-                       "pairs_per_step": pairs_total // a.steps, "amplicons_per_step": amps_all // a.steps, "fastq_bytes_per_step": fq_bytes_all // a.steps,
+                       "pairs_per_step": pairs_total // a.steps, "amplicons_per_step": R["amps"] // a.steps, "fastq_bytes_per_step": R["fq_bytes"] // a.steps,
                        "sharding": ("one job over %d GPUs by fragment lineage; per-pass primer-stock all-reduce + allocation partials over RCCL; a FASTQ shard per rank" % world) if world > 1 else "single GPU",
                        "collectives": coll_path,
-                       "output": "FASTQ text generated batch by batch into HBM buffers (NULL sink)"},
-            "roofline": roof,
-            "lane_utilisation": committed_lane_table(),
-            "stages_s_per_step": {k: v / a.steps for k, v in stage.items()},
-            "kernels_ms_per_step": {k: v["ms"] / a.steps for k, v in ktimes.items()},
+                       "output": ("FASTQ text generated batch by batch into HBM buffers (NULL sink): --hbm-only" if a.hbm_only else
+                                  "plain FASTQ files on tmpfs (%s): %d part files per mate%s, each a contiguous range of the records written by its own thread (scs_yield_reads_files, writers = %d; "
+                                  "`cat` of the parts in order is the reference's <prefix>_1.fq / _2.fq); every step writes fresh files, the step before's are unlinked by 4 background threads "
+                                  "while it runs (a step's sink starts when <= 40 GB of them are left: `wait_for_cleanup` in stages_s_per_step, inside the timed region)"
+                                  % (out_dir, writers, " and rank" if world > 1 else "", writers)),
+                       "sink_GBps": None if a.hbm_only else R["fq_bytes"] / max(1e-9, R["stage"]["reads"] * a.steps) / 1e9,
+                       "host_cores": cores},
+            "stages_s_per_step": R["stage"],
+            "kernels_ms_per_step": {k: v["ms"] / a.steps for k, v in R["ktimes"].items()},
             "setup_s": {"genome_generated_in_hbm": t_gen, "genome_staged_(encode+bit_index)": t_up},
-            # whole job against HBM: the implementation's compulsory bytes (68 B per amplicon, 56 B pair record written + read,
-            # 40 B events, 261 B template + FASTQ per pair); SURVEY 8(d)'s model (1526 B per amplicon) beside it
-            "whole_job_GBps": {"compulsory": (68.0 * amps_all + (261.0 + 152.0) * pairs_total + fq_bytes_all) / elapsed / 1e9,
-                               "survey_8d_model": (1526.0 * amps_all + 261.0 * pairs_total + fq_bytes_all) / elapsed / 1e9},
+            "lane_utilisation": committed_lane_table(),
         }
-        if world == 1 and not a.no_extra_legs:
-            # ---- sink-inclusive: the same job, FASTQ through D2H + write(2) to tmpfs
-            shm = "/dev/shm" if os.path.isdir("/dev/shm") else td
-            sd = tempfile.mkdtemp(prefix="scsbench_sink_", dir=shm)
-            try:
-                os.environ["SCS_SINK_RECYCLE_MB"] = "4096"            # rewind each file every 4 GB: bounded page cache
-                for k in stage:
-                    stage[k] = 0.0
-                t1 = time.perf_counter()
-                st = step(a.warmup + a.steps, os.path.join(sd, "bench_sink"))
-                dt = time.perf_counter() - t1
-                del os.environ["SCS_SINK_RECYCLE_MB"]
-                nbytes = sum(st["fastq_bytes"])
-                # the same batches once more through a sink that only counts: D2H into the pinned buffers, nothing written --
-                # what PCIe allows (the file rate above it is the page cache's)
-                seen = [0]
+        roof_src, roof_fq, roof_note = R["ktimes"], R["fq_bytes_local"], "HIP events on the ctx stream around every launch of the timed region"
+        H = None
+        if world == 1 and not a.no_extra_legs and not a.hbm_only:
+            # ---- generation only: the same job with a NULL sink -- the text is written into HBM batch buffers (8 M pairs per launch)
+            # and counted.  What the kernels do when nothing has to cross PCIe; the dominant kernel's roofline is taken here.
+            H = timed(1, 5, "null", 100)
+            out["generation_hbm"] = {"value": H["pairs"] / H["elapsed"], "unit": "pairs/s", "steps": 5, "ms_per_step": 1e3 * H["elapsed"] / 5, "stages_s_per_step": H["stage"],
+                                     "kernels_ms_per_step": {k: v["ms"] / 5 for k, v in H["ktimes"].items()},
+                                     "what": "the same job, FASTQ text generated batch by batch into HBM buffers and counted (NULL sink): no PCIe, no files",
+                                     # whole job against HBM: the implementation's compulsory bytes (68 B per amplicon, 56 B pair record written + read,
+                                     # 40 B events, 261 B template + FASTQ per pair); SURVEY 8(d)'s model (1526 B per amplicon) beside it
+                                     "whole_job_GBps": {"compulsory": (68.0 * H["amps"] + (261.0 + 152.0) * H["pairs"] + H["fq_bytes"]) / H["elapsed"] / 1e9,
+                                                        "survey_8d_model": (1526.0 * H["amps"] + 261.0 * H["pairs"] + H["fq_bytes"]) / H["elapsed"] / 1e9}}
+            roof_src, roof_fq = H["ktimes"], H["fq_bytes_local"]
+            roof_note = "HIP events on the ctx stream around every launch of the generation_hbm leg (5 steps, 8 M pairs per launch); the timed region's launches (sink batches) under in_timed_region"
+        roof = roofline_of(roof_src, roof_fq, L, "k_reads" if H else None)
+        roof["timing"] = roof_note
+        if H:
+            in_t = roofline_of(R["ktimes"], R["fq_bytes_local"], L, roof["kernel"])
+            roof["in_timed_region"] = {k: in_t[k] for k in ("achieved", "frac", "avg_launch_ms", "timed_launches", "pairs_per_launch", "algorithmic_bytes_per_launch")}
+            amp = {k: v for k, v in H["ktimes"].items() if k.startswith("k_attach") or k.startswith("k_errs")}
+            made = H["ktimes"]["k_errs<semi->full>"]["units"] + H["ktimes"]["k_errs<frag->semi>"]["units"]
+            amp_ms = sum(v["ms"] for v in amp.values())
+            lanes = (committed_lane_table() or {}).get("kernels", {})
+            # amplification has its own entry: this design's compulsory 68 B per created amplicon over the four kernels' time
+            out["roofline_amplification"] = {"bound": "hbm (latency / issue bound in practice)", "achieved": 68.0 * made / max(1e-9, amp_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                             "frac": 68.0 * made / max(1e-9, amp_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "compulsory_bytes_per_amplicon": 68, "amplicons": made, "kernels_ms": {k: v["ms"] for k, v in amp.items()},
+                                             "survey_8d_model_frac": 1526.0 * made / max(1e-9, amp_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                             "lanes_per_valu_inst": {k: v["lanes_per_valu_inst"] for k, v in lanes.items() if k.startswith("k_attach") or k.startswith("k_errs")},
+                                             "salu_per_valu": {k: v["salu_per_valu"] for k, v in lanes.items() if k.startswith("k_attach") or k.startswith("k_errs")}}
+        out["roofline"] = roof
+        if world == 1 and not a.no_extra_legs and not a.hbm_only:
+            # ---- D2H only: the same batches through a sink that only counts -- what PCIe allows
+            seen = [0]
 
-                def count_only(_u, _p1, n1, _p2, n2):
-                    seen[0] += n1 + n2
-                    return 0
-                t2 = time.perf_counter(); g.yield_reads_sink(count_only); t_d2h = time.perf_counter() - t2
-                out["sink_inclusive"] = {"value": st["pairs_written"] / dt, "unit": "pairs/s", "seconds": dt, "fastq_bytes": nbytes,
-                                         "reads_stage_s": stage["reads"], "sink_GBps": nbytes / max(1e-9, stage["reads"]) / 1e9,
-                                         "what": "one more step through scs_yield_reads_files: FASTQ D2H into pinned double buffers + one pwrite() per file and batch into two tmpfs files (rewound every 4 GB: page freeing included)",
-                                         "d2h_only": {"value": st["pairs_written"] / (dt - stage["reads"] + t_d2h), "unit": "pairs/s", "reads_stage_s": t_d2h,
-                                                      "GBps": seen[0] / max(1e-9, t_d2h) / 1e9, "what": "the same step with a sink that only counts the bytes it is handed (D2H, no file)"}}
-            finally:
-                shutil.rmtree(sd, ignore_errors=True)
+            def count_only(_u, _p1, n1, _p2, n2):
+                seen[0] += n1 + n2
+                return 0
+            D = timed(0, 1, count_only, 200)
+            out["d2h_only"] = {"value": D["pairs"] / D["elapsed"], "unit": "pairs/s", "seconds": D["elapsed"], "GBps": seen[0] / max(1e-9, D["stage"]["reads"]) / 1e9,
+                               "what": "one step with a sink that only counts the bytes it is handed: D2H into pinned slots, nothing written"}
+            # ---- the sweep north_star asks for (1 Mb -> 3 Gb) in one record: configs[1] and configs[2]'s sizes, same model and options
+            try:
+                out["sweep"] = [small_config(torch, scssim_amd, dev, stream, prof, 1.0, a.coverage, "configs[1]: 1 Mb x 2 haplotypes, PE150 %gx" % a.coverage, shm),
+                                small_config(torch, scssim_amd, dev, stream, prof, 63.02552, a.coverage, "configs[2] size: 63 Mb (chr20) x 2 haplotypes, PE150 %gx" % a.coverage, shm)]
+            except Exception as e:                                   # an extra leg must not cost the record
+                out["sweep"] = {"error": repr(e)}
             # ---- CLI wall at chr20 size
             cli = os.path.join(ROOT, "scssim_amd", "bin", "scssim")
             if cli_sample is not None and os.path.exists(cli):
@@ -488,8 +639,11 @@ def main():
             out["cpu_baseline"] = cpu_baseline(td, prof, ["1_1_%d" % n, "1_2_%d" % n], [cpu_sample, cpu_sample],
                                                "first %.1f Mb of chromosome 1 of the bench genome (x 2 haplotypes), PE150 %gx, same profile and options" % (n / 1e6, a.coverage), a.coverage)
         print(json.dumps(out))
+    cleaner.close()
     g.close()
     shutil.rmtree(td, ignore_errors=True)
+    if not a.out_dir:
+        shutil.rmtree(out_dir, ignore_errors=True)
     if dist.is_initialized():
         dist.destroy_process_group()
 

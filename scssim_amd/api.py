@@ -363,6 +363,11 @@ class GenReads:
         self._id = C.create_string_buffer(bytes(comm_id), COMM_ID_BYTES)
         self._ck(self._L.scs_comm_init(self._ctx, self._id, int(rank), int(nranks)))
 
+    def comm_count(self):
+        """Ranks of the ctx's RCCL communicator as RCCL reports them (ncclCommCount); 0 without one."""
+        self._L.scs_comm_count.argtypes = [C.c_void_p]
+        return int(self._L.scs_comm_count(self._ctx))
+
     def yield_reads_device(self, d_fq1, cap1, d_fq2, cap2):
         """FASTQ pool stays in HBM: d_fq1/d_fq2 are device pointers (e.g. torch uint8 tensors' data_ptr())."""
         n1, n2, pairs = C.c_uint64(), C.c_uint64(), C.c_uint64()

@@ -358,11 +358,12 @@ def test_bench_two_rank_control_flow(tmp_path):
     assert d["value"] > 0 and abs(d["value"] - d["config"]["pairs_per_step"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 0.05
     assert 350000 < d["config"]["pairs_per_step"] < 450000                         # the whole 4 Mb job at 30x, PE150: ~400 k pairs
     assert 0 < d["roofline"]["frac"] <= 1 and "cpu_baseline" not in d
+    assert "part files per mate and rank" in d["config"]["output"] and d["config"]["sink_GBps"] > 0      # every rank wrote its shard's parts
 
 
 def test_bench_single_gpu_contract(tmp_path):
-    """bench.py at N = 1 on a scaled-down genome: every leg runs (timed steps, sink-inclusive step, CLI wall, CPU baseline)
-    and the JSON line carries the contract's fields."""
+    """bench.py at N = 1 on a scaled-down genome: every leg runs (timed steps through the file sink, generation only, D2H only, the
+    small configurations, CLI wall, CPU baseline at -t 1 and -t cores) and the JSON line carries the contract's fields."""
     import json
     import sys
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--genome-mb", "6", "--cpu-sample-mb", "0.2"],
@@ -375,7 +376,11 @@ def test_bench_single_gpu_contract(tmp_path):
     rf = d["roofline"]
     assert rf["bound"] == "hbm" and 0 < rf["frac"] <= 1 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and rf["draws_per_s"] > 0
     assert d["cpu_baseline"]["kind"] in ("reference", "port") and d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] >= 1
-    assert d["sink_inclusive"]["value"] > 0 and d["sink_inclusive"]["fastq_bytes"] > 0
+    assert d["cpu_baseline"].get("one_thread", {}).get("value", 0) > 0 or d["cpu_baseline"]["kind"] == "port"
+    assert "part files per mate" in d["config"]["output"] and "/" in d["config"]["output"] and d["config"]["sink_GBps"] > 0
+    assert d["generation_hbm"]["value"] > d["value"] and d["d2h_only"]["value"] > 0
+    assert rf["kernel"] == "k_reads" and rf["in_timed_region"]["timed_launches"] > 0 and d["roofline_amplification"]["frac"] > 0
+    assert isinstance(d["sweep"], list) and len(d["sweep"]) == 2 and all(x["generation_hbm_pairs_per_s"] > 0 for x in d["sweep"])
     assert d["cli_wall"].get("value", 0) > 0, d["cli_wall"]
     assert abs(d["value"] - d["config"]["pairs_per_step"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 0.05
 
