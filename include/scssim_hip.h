@@ -56,6 +56,7 @@ typedef struct scs_stats {
     uint64_t fastq_bytes[2];
     uint64_t algorithmic_bytes;  /* 1526 B per created amplicon + per pair (isize + FASTQ bytes) */
     double   t_stage[8];         /* seconds: load, frags, amplify, weights, allocate, yield, -, total */
+    uint64_t sink_bytes[2];      /* bytes handed to the sink per mate: fastq_bytes, or their BGZF blocks' (scs_yield_reads_files_ex) */
 } scs_stats;
 
 void        scs_default_config(scs_config* cfg);
@@ -181,6 +182,16 @@ int         scs_comm_abort(scs_ctx* ctx);
  * base = <prefix> or <prefix>.r<rank>.  Their concatenation in that order IS the single file (`cat <base>.p*_1.fq`);
  * <base>.parts lists their sizes; scs_merge_fastq_parts / scs_merge_fastq_shards read parts and single files alike. */
 int         scs_yield_reads_files(scs_ctx* ctx, const char* prefix, int writers);
+/* The same with two more choices.
+ * generations = G > 1: writers x G parts per mate, made generation by generation (the first `writers` parts, then the next ...):
+ *   part p is complete -- closed, final -- as soon as part p + writers exists, so a consumer can stream the early parts while the
+ *   job runs and the page cache holds a couple of generations instead of the whole job's text (at most 99 parts).
+ * bgzf != 0: the files are <...>.fq.gz in BGZF (blocked gzip: what `bgzip` writes; gzip / zcat, htslib, bwa, samtools read it).
+ *   The blocks are made ON THE GPU from the text where it lies in HBM (scs_bgzf.hip: one dynamic-Huffman deflate block of
+ *   literals per 63 KB of text, CRC-32 included), so 3-4x fewer bytes cross PCIe and reach the file system -- the two walls of a
+ *   job.  `zcat` of a part is the text of that part; every part ends with the BGZF end-of-file block.  An extension: the
+ *   reference writes plain text only.  The shards of a sharded job stay shards (compressed byte ranges cannot be spliced). */
+int         scs_yield_reads_files_ex(scs_ctx* ctx, const char* prefix, int writers, int generations, int bgzf);
 int         scs_merge_fastq_shards(const char* prefix, int nranks, int paired, int keep_shards, char* errbuf, size_t errlen);
 /* host only: <prefix>.p*_1.fq ... -> <prefix>_1.fq ... (byte-range copies; parts removed unless keep_parts) */
 int         scs_merge_fastq_parts(const char* prefix, int paired, int keep_parts, char* errbuf, size_t errlen);
@@ -232,6 +243,11 @@ int         scs_simuvars_probe(const char* ref_fasta, const char* snp_file, cons
  * with second_bytes; caps[0..1] receive its usable capacity after each step and *in_place whether the second step kept its
  * address.  Buffers above 64 MB (SCS_VMM_FROM_MB) live in a reserved address range and grow in place, by the request + 3 %. */
 int         scs_devbuf_probe(int device, uint64_t first_bytes, uint64_t second_bytes, uint64_t* caps, int* in_place);
+/* Host-only test seam of the BGZF kernels (scs_yield_reads_files_ex, bgzf): their arithmetic -- Huffman lengths, header, chunked
+ * bit packing, chunked CRC-32 combined by carry-less multiplication, the stored fallback when a block's deflate data exceeds
+ * lds_out_cap (0 = the kernels' limit) -- run on the CPU over the same functions; out receives the BGZF blocks of the text
+ * (no end-of-file block), *n_out their size (out may be NULL to ask for it).  The checker is zlib. */
+int         scs_bgzf_probe(const void* text, uint64_t nbytes, uint32_t lds_out_cap, void* out, uint64_t cap, uint64_t* n_out);
 /* Host-only: leave <fasta_path>.fai beside the file if there is none, exactly as scs_load_genome_fasta does (the
  * reference indexes its input through fastahack, lib/fastahack/Fasta.cpp:241-249: name, length, offset, bases per
  * line, bytes per line). */

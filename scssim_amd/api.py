@@ -32,7 +32,7 @@ class _Stats(C.Structure):
     _fields_ = [("records", C.c_uint64), ("genome_bases", C.c_uint64), ("fragments", C.c_uint64),
                 ("semi_amplicons", C.c_uint64), ("full_amplicons", C.c_uint64), ("primers_left", C.c_uint64),
                 ("reads_requested", C.c_uint64), ("pairs_written", C.c_uint64), ("reads_written", C.c_uint64),
-                ("fastq_bytes", C.c_uint64 * 2), ("algorithmic_bytes", C.c_uint64), ("t_stage", C.c_double * 8)]
+                ("fastq_bytes", C.c_uint64 * 2), ("algorithmic_bytes", C.c_uint64), ("t_stage", C.c_double * 8), ("sink_bytes", C.c_uint64 * 2)]
 
 
 _SINK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t)
@@ -134,6 +134,35 @@ def text_checksum(data):
         x = w + (np.arange(1, len(w) + 1, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15))
         x ^= x >> np.uint64(33); x *= np.uint64(0xFF51AFD7ED558CCD); x ^= x >> np.uint64(33); x *= np.uint64(0xC4CEB9FE1A85EC53); x ^= x >> np.uint64(33)
         return int(np.add.reduce(x, dtype=np.uint64)) if len(x) else 0
+
+
+def bgzf_probe(data, lds_out_cap=0):
+    """Host-only: the BGZF blocks the device kernels would make of `data` (their arithmetic on the CPU; no end-of-file block)."""
+    L = load_library()
+    L.scs_bgzf_probe.argtypes = [C.c_char_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
+    n = C.c_uint64()
+    data = bytes(data)
+    rc = L.scs_bgzf_probe(data, len(data), lds_out_cap, None, 0, C.byref(n))
+    if rc:
+        raise ScsError(rc, "scs_bgzf_probe")
+    out = C.create_string_buffer(max(1, n.value))
+    rc = L.scs_bgzf_probe(data, len(data), lds_out_cap, out, n.value, C.byref(n))
+    if rc:
+        raise ScsError(rc, "scs_bgzf_probe")
+    return out.raw[:n.value]
+
+
+def bgzf_blocks(data):
+    """Split BGZF bytes into (block bytes, ISIZE) after checking every block's frame: gzip magic, the BC subfield, BSIZE."""
+    out, o = [], 0
+    while o < len(data):
+        h = data[o:o + 18]
+        assert len(h) == 18 and h[:4] == b"\x1f\x8b\x08\x04" and h[10:16] == b"\x06\x00BC\x02\x00", "not a BGZF block at %d" % o
+        size = int.from_bytes(h[16:18], "little") + 1
+        assert o + size <= len(data) and size <= 65536
+        out.append((data[o:o + size], int.from_bytes(data[o + size - 4:o + size], "little")))
+        o += size
+    return out
 
 
 COMM_ID_BYTES = 128
@@ -352,11 +381,13 @@ class GenReads:
         cb = _SINK(sink) if sink is not None else _SINK()
         self._ck(self._L.scs_yield_reads(self._ctx, cb, None))
 
-    def yield_reads_files(self, prefix, writers=0):
+    def yield_reads_files(self, prefix, writers=0, generations=1, bgzf=False):
         """Malbac::yieldReads + SeqWriter: <prefix>_1.fq/_2.fq (.fq), or this shard's <prefix>.r<rank>_*.fq + .idx.
         writers = K > 1: K part files per mate (<base>.p00_1.fq ...: contiguous record ranges, one writer thread each; their
-        concatenation is the single file) + <base>.parts."""
-        self._ck(self._L.scs_yield_reads_files(self._ctx, os.fsencode(prefix), int(writers)))
+        concatenation is the single file) + <base>.parts.  generations = G > 1: K x G parts made generation by generation (part p
+        is final once part p + K exists).  bgzf: <...>.fq.gz, BGZF blocks made on the GPU."""
+        self._L.scs_yield_reads_files_ex.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_int]
+        self._ck(self._L.scs_yield_reads_files_ex(self._ctx, os.fsencode(prefix), int(writers), int(generations), int(bool(bgzf))))
 
     def comm_init(self, comm_id, rank, nranks):
         """RCCL inside the library: every rank of a sharded job calls this with rank 0's comm_unique_id()."""
@@ -422,8 +453,9 @@ class GenReads:
     def stats(self):
         st = _Stats()
         self._ck(self._L.scs_get_stats(self._ctx, C.byref(st)))
-        d = {k: getattr(st, k) for k, _ in _Stats._fields_ if k not in ("fastq_bytes", "t_stage")}
+        d = {k: getattr(st, k) for k, _ in _Stats._fields_ if k not in ("fastq_bytes", "t_stage", "sink_bytes")}
         d["fastq_bytes"] = list(st.fastq_bytes)
+        d["sink_bytes"] = list(st.sink_bytes)
         d["t_stage"] = list(st.t_stage)
         return d
 

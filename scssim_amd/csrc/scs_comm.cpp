@@ -109,24 +109,51 @@ std::string part_path(const std::string& base, int part, int parts, int mate, bo
 std::string parts_index_path(const std::string& base) { return base + ".parts"; }
 
 FastqParts::~FastqParts() { std::string e; (void)close(e); }
-bool FastqParts::open(const std::string& base, bool paired, int parts, const std::string& suffix, bool bgzf_eof, std::string& err) {
-    base_ = base; paired_ = paired; eof_ = bgzf_eof; regions = std::max(1, parts);
-    part_.assign((size_t)regions, Part());
-    (void)::unlink(parts_index_path(base).c_str());                                  // a stale index must not describe the new files
-    for (int k = 0; k < regions; ++k) for (int m = 0; m < (paired ? 2 : 1); ++m) {
-        const std::string p = part_path(base, k, regions, m, paired, suffix);
-        if (k == 0 && m == 0) first_ = p;
-        part_[k].fd[m] = ::open(p.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
-        if (part_[k].fd[m] < 0) { err = "Error: can not open fastq file to save results:\n" + p; return false; }
+bool FastqParts::open_part(int k, std::string& err) {
+    Part& P = part_[(size_t)k];
+    if (P.opened) return true;
+    for (int m = 0; m < (paired_ ? 2 : 1); ++m) {
+        const std::string p = part_path(base_, k, regions, m, paired_, suffix_);
+        P.fd[m] = ::open(p.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+        if (P.fd[m] < 0) { err = "Error: can not open fastq file to save results:\n" + p; P.failed = true; return false; }
     }
+    P.opened = true;
     return true;
 }
-// One writer thread per region (SinkPipe); a region's two files are written one after the other -- except for the single
-// region of the reference's two-file layout, whose second file gets a thread of its own for the batch.
+void FastqParts::finish_part(int k) {                                                // the part is complete: BGZF end-of-file block, close
+    Part& P = part_[(size_t)k];
+    if (!P.opened || P.done) return;
+    for (int m = 0; m < 2; ++m) if (P.fd[m] >= 0) {
+        if (eof_ && !P.failed) { if (pwrite_all(P.fd[m], (const char*)kBgzfEof, sizeof kBgzfEof, P.pos[m])) P.pos[m] += sizeof kBgzfEof; else P.failed = true; }
+        if (::close(P.fd[m]) != 0) P.failed = true;
+        P.fd[m] = -1;
+    }
+    P.done = true;
+}
+bool FastqParts::open(const std::string& base, bool paired, int nwriters, int generations, const std::string& suffix, bool bgzf_eof, std::string& err) {
+    base_ = base; paired_ = paired; eof_ = bgzf_eof; suffix_ = suffix;
+    writers = std::max(1, nwriters); regions = writers * std::max(1, generations);
+    part_.assign((size_t)regions, Part()); cur_.assign((size_t)writers, -1);
+    first_ = part_path(base, 0, regions, 0, paired, suffix);
+    (void)::unlink(parts_index_path(base).c_str());                                  // a stale index must not describe the new files
+    // the first generation's files are opened here, so that an output that cannot be written is reported before the job runs;
+    // the later ones when their first batch arrives (a part's existence tells a consumer that the part `writers` before it is final)
+    for (int k = 0; k < writers; ++k) if (!open_part(k, err)) return false;
+    return true;
+}
+// One writer thread per region r % writers (SinkPipe); a region's two files are written one after the other -- except for the
+// single region of the reference's two-file layout, whose second file gets a thread of its own for the batch.
 int FastqParts::put(int region, const char* a, size_t na, const char* b, size_t nb) {
     if (region < 0 || region >= (int)part_.size()) return 1;
-    Part& P = part_[region];
-    if (P.failed) return 1;
+    int& cur = cur_[(size_t)(region % writers)];
+    if (cur != region) {                                                            // this writer moves on to its next generation's part
+        if (cur >= 0) finish_part(cur);
+        for (int k = cur < 0 ? region % writers : cur + writers; k < region; k += writers) { std::string e; if (open_part(k, e)) finish_part(k); }   // (ranges without a batch: empty parts)
+        cur = region;
+    }
+    Part& P = part_[(size_t)region];
+    std::string err;
+    if (P.failed || P.done || !open_part(region, err)) return 1;
     bool ok2 = true; std::thread t2;
     const bool par = regions == 1 && nb && na && P.fd[1] >= 0;
     if (par) t2 = std::thread([&] { ok2 = pwrite_all(P.fd[1], b, nb, P.pos[1]); });
@@ -137,15 +164,14 @@ int FastqParts::put(int region, const char* a, size_t na, const char* b, size_t 
     return 0;
 }
 bool FastqParts::close(std::string& err) {
-    bool good = true, any = false;
-    for (auto& P : part_) for (int m = 0; m < 2; ++m) if (P.fd[m] >= 0) {
-        any = true;
-        if (eof_ && !P.failed) { if (pwrite_all(P.fd[m], (const char*)kBgzfEof, sizeof kBgzfEof, P.pos[m])) P.pos[m] += sizeof kBgzfEof; else P.failed = true; }
-        if (::close(P.fd[m]) != 0) P.failed = true;
-        P.fd[m] = -1;
-        if (P.failed) good = false;
+    bool good = true; const bool any = !part_.empty();
+    for (size_t k = 0; k < part_.size(); ++k) {
+        std::string e;
+        if (!part_[k].opened && !part_[k].failed) (void)open_part((int)k, e);      // a range that got no batch: an empty part, so that the set is whole
+        finish_part((int)k);
+        if (part_[k].failed) { good = false; if (err.empty()) err = e.empty() ? "writing " + part_path(base_, (int)k, regions, 0, paired_, suffix_) + " failed" : e; }
     }
-    if (!good) { err = "writing " + first_ + " failed"; return false; }
+    if (!good) return false;
     if (any && regions > 1) {
         FILE* f = fopen(parts_index_path(base_).c_str(), "w");
         if (!f) { err = "can not write " + parts_index_path(base_); return false; }
@@ -153,6 +179,7 @@ bool FastqParts::close(std::string& err) {
         for (size_t k = 0; k < part_.size(); ++k) fprintf(f, "%zu\t%llu\t%llu\n", k, (unsigned long long)part_[k].pos[0], (unsigned long long)part_[k].pos[1]);
         if (fclose(f) != 0) { err = "can not write " + parts_index_path(base_); return false; }
     }
+    part_.clear();
     return true;
 }
 

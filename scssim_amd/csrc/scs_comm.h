@@ -25,26 +25,31 @@ void rccl_abort(RcclComm* c);                                                   
 // of ITS range, in order, to ITS OWN pair of files: buffered writes into one file serialise on its inode lock (measured on
 // the GPU box's tmpfs: 5.7 GB/s per file from 1, 4, 8 or 16 threads; 39 GB/s for 8 threads on 8 files).
 struct BatchSink {
-    int regions = 1;                                       // how many ranges the job's records are cut into (= writer threads)
-    // called by region's writer thread, the batches of a region in record order; a / b: the two mates' text (b null: single end)
+    int regions = 1;                                       // how many contiguous ranges the job's records are cut into (one part file per mate each)
+    int writers = 1;                                       // threads: region r is written by thread r % writers; regions = writers x generations
+    // called by the region's writer thread, the batches of a region in record order; a / b: the two mates' text (b null: single end)
     virtual int put(int region, const char* a, size_t na, const char* b, size_t nb) = 0;   // 0 = ok
     virtual ~BatchSink() {}
 };
-// regions == 1: the reference's files <base>_1.fq / <base>_2.fq (or <base>.fq), the two written in parallel.
-// regions  > 1: part files <base>.p<kk>_1.fq / _2.fq (.p<kk>.fq), kk = 00 .. regions-1 -- their concatenation in that order
-// IS the single file (`cat <base>.p*_1.fq`) -- and an index <base>.parts with their sizes.
-// suffix: ".fq", or ".fq.gz" for BGZF text (close() then ends every part with the BGZF end-of-file block).
+// parts == 1: the reference's files <base>_1.fq / <base>_2.fq (or <base>.fq), the two written in parallel.
+// parts  > 1: part files <base>.p<kk>_1.fq / _2.fq (.p<kk>.fq), kk = 00 .. parts-1 -- their concatenation in that order
+// IS the single file (`cat <base>.p*_1.fq`) -- and an index <base>.parts with their sizes.  parts = writers x generations:
+// the records are made generation by generation (the first parts / writers parts, then the next ...), so the early parts are
+// complete -- closed, final -- long before the job ends: part p is complete as soon as part p + writers exists.  A consumer
+// can stream them, and the page cache holds a couple of generations instead of the whole job's text.
+// suffix: ".fq", or ".fq.gz" for BGZF text (close() / the part's completion then ends it with the BGZF end-of-file block).
 class FastqParts : public BatchSink {
 public:
     ~FastqParts() override;
-    bool open(const std::string& base, bool paired, int parts, const std::string& suffix, bool bgzf_eof, std::string& err);
+    bool open(const std::string& base, bool paired, int writers, int generations, const std::string& suffix, bool bgzf_eof, std::string& err);
     int put(int region, const char* a, size_t na, const char* b, size_t nb) override;
     bool close(std::string& err);                          // sizes final, index written (parts > 1)
     uint64_t bytes(int mate) const { uint64_t t = 0; for (auto& p : part_) t += p.pos[mate]; return t; }
     const std::string& first_path() const { return first_; }
 private:
-    struct Part { int fd[2] = {-1, -1}; uint64_t pos[2] = {0, 0}; bool failed = false; };
-    std::vector<Part> part_; std::string base_, first_; bool paired_ = true, eof_ = false;
+    struct Part { int fd[2] = {-1, -1}; uint64_t pos[2] = {0, 0}; bool failed = false, opened = false, done = false; };
+    bool open_part(int k, std::string& err); void finish_part(int k);
+    std::vector<Part> part_; std::vector<int> cur_; std::string base_, first_, suffix_; bool paired_ = true, eof_ = false;
 };
 std::string part_path(const std::string& base, int part, int parts, int mate, bool paired, const std::string& suffix);
 std::string parts_index_path(const std::string& base);                                 // <base>.parts

@@ -5,6 +5,7 @@
 #include "scs_device.h"
 #include "scs_tables.h"
 #include "scs_comm.h"
+#include "scs_bgzf.h"
 
 #include <atomic>
 #include <fcntl.h>
@@ -182,6 +183,9 @@ struct scs_ctx {
     DevBuf slot_b, slot_q, lens, ev_hdr, ev_dat, sizes1, sizes2, off1, off2, out1, out2, out1b, out2b, rl_cls, rl_pos, rl_lists, d_bounds; SinkPipe* pipe = nullptr;
     hipStream_t errs_stream = nullptr; hipEvent_t ev_att = nullptr, ev_errs = nullptr; bool errs_pending = false;   // k_errs<semi->full> of a cycle runs beside the fragment pass that follows it
     DevBuf slots_fr, slot_tmpl_fr;                        // the fragment passes' own slot arrays (the semi pass's are still being read then)
+    // BGZF made on the device (scs_bgzf.hip): per mate the blocks' plans / sizes / offsets, two sets of output buffers, the CRC tables; the
+    // blocks' total per batch reaches the host through a small pinned array (h_z) behind an event, one batch late (see do_yield)
+    DevBuf z_plan[2], z_sizes[2], z_offs[2], z_out[2][2], z_crc; uint32_t* h_z = nullptr; hipEvent_t ev_z[2] = {nullptr, nullptr};
     bool want_cks = false; DevBuf d_cks; std::vector<uint64_t> cks;   // scs_set_batch_checksums: per batch and mate, computed where the text lies in HBM
     ReadsSide reads_side;                                 // k_reads' two small class kernels run beside the big one on these (per ctx: two contexts on one device do not share events)
     hipStream_t pre_stream = nullptr; hipEvent_t ev_pre[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr}, ev_plan = nullptr;   // the reads stage's pre-pass on its own stream, beside the previous batch's base pass
@@ -793,21 +797,22 @@ void do_allocate(scs_ctx* c, uint64_t reads) {
 // FASTQ sink pipeline (replaces the mutexed ofstream of lib/seqwriter/SeqWriter.cpp:41-54).  A batch's text is
 // copied D2H on the copy stream into a free pinned slot and handed to the writer thread of its REGION (BatchSink: the job's
 // records are cut into `regions` contiguous ranges, visited round-robin, one writer thread and one pair of files each), which
-// waits for the copy's event, writes, and frees the slot -- while the GPU already produces the next batches.  regions + 2
-// slots: every writer can hold one while one is being filled and one crosses PCIe.
+// waits for the copy's event, writes, and frees the slot -- while the GPU already produces the next batches.  writers + 2
+// slots: every writer can hold one while one is being filled and one crosses PCIe.  (regions = writers x generations: writer w
+// serves the regions r = w mod writers, one after the other.)
 struct SinkPipe {
     struct Slot { char* h[2] = {nullptr, nullptr}; size_t cap[2] = {0, 0}; hipEvent_t ev = nullptr; bool busy = false; };
-    struct Job { int slot; size_t n1, n2; };
+    struct Job { int slot, region; size_t n1, n2; };
     struct Writer { std::thread th; std::vector<Job> q; };
     std::vector<Slot> slots; std::vector<Writer> writers;
     std::mutex mu; std::condition_variable cv; bool done = false, failed = false;
     BatchSink* sink = nullptr; bool paired = true; int device = 0;
     void start(BatchSink* f, bool pe, int dev) {
         sink = f; paired = pe; device = dev; done = failed = false;
-        const size_t want = (size_t)std::max(1, f->regions) + 2;
+        const size_t nw = (size_t)std::max(1, f->writers), want = nw + 2;
         while (slots.size() < want) { Slot sl; HIP_OK(hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming)); slots.push_back(sl); }
         for (auto& sl : slots) sl.busy = false;
-        writers = std::vector<Writer>((size_t)std::max(1, f->regions));
+        writers = std::vector<Writer>(nw);
         for (size_t w = 0; w < writers.size(); ++w) writers[w].th = std::thread([this, w] {
             (void)hipSetDevice(device);
             Writer& W = writers[w];
@@ -816,7 +821,7 @@ struct SinkPipe {
                 { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return !W.q.empty() || done; }); if (W.q.empty()) return; j = W.q.front(); W.q.erase(W.q.begin()); }
                 Slot& sl = slots[(size_t)j.slot];
                 bool bad = hipEventSynchronize(sl.ev) != hipSuccess;
-                if (!bad && !failed) bad = sink->put((int)w, sl.h[0], j.n1, paired ? sl.h[1] : nullptr, j.n2) != 0;
+                if (!bad && !failed) bad = sink->put(j.region, sl.h[0], j.n1, paired ? sl.h[1] : nullptr, j.n2) != 0;
                 { std::lock_guard<std::mutex> lk(mu); sl.busy = false; if (bad) failed = true; }
                 cv.notify_all();
             }
@@ -841,7 +846,7 @@ struct SinkPipe {
         }
         return k;
     }
-    void submit(int region, int slot, size_t n1, size_t n2) { { std::lock_guard<std::mutex> lk(mu); writers[(size_t)region].q.push_back(Job{slot, n1, n2}); } cv.notify_all(); }
+    void submit(int region, int slot, size_t n1, size_t n2) { { std::lock_guard<std::mutex> lk(mu); writers[(size_t)region % writers.size()].q.push_back(Job{slot, region, n1, n2}); } cv.notify_all(); }
     bool finish() { { std::lock_guard<std::mutex> lk(mu); done = true; } cv.notify_all(); for (auto& W : writers) if (W.th.joinable()) W.th.join(); writers.clear(); return !failed; }
     void release() { for (auto& sl : slots) { for (int f = 0; f < 2; ++f) if (sl.h[f]) (void)hipHostFree(sl.h[f]); if (sl.ev) (void)hipEventDestroy(sl.ev); } slots.clear(); }
 };
@@ -853,7 +858,8 @@ struct CallbackSink : BatchSink {
 };
 
 struct OutTarget { bool device; char* d1; char* d2; size_t cap1, cap2; BatchSink* sink;
-                   std::vector<uint64_t>* seg_off1 = nullptr; std::vector<uint64_t>* seg_off2 = nullptr; };   // seg_off: byte offset of each list segment's first record (shard index)
+                   std::vector<uint64_t>* seg_off1 = nullptr; std::vector<uint64_t>* seg_off2 = nullptr;
+                   bool bgzf = false; };                                          // bgzf: the sink gets BGZF blocks made on the device instead of the text   // seg_off: byte offset of each list segment's first record (shard index)
 
 void do_yield(scs_ctx* c, const OutTarget& tg, uint64_t* n1_out, uint64_t* n2_out, uint64_t* pairs_out) {
     if (!c->allocated) throw ScsError(SCS_EINVAL, "scs_yield_reads: call scs_allocate_reads first");
@@ -871,7 +877,7 @@ void do_yield(scs_ctx* c, const OutTarget& tg, uint64_t* n1_out, uint64_t* n2_ou
     // the per-batch pre-pass not to matter: 2 M -> 8 M gave -11 % on the stage), 512 k towards a sink (pinned slots; 256 k when many
     // writers each hold one)
     static const int batch_shift = getenv("SCS_TEST_BATCH_SHIFT") ? atoi(getenv("SCS_TEST_BATCH_SHIFT")) : 0;   // tests: many small batches
-    const uint64_t batch = std::min<uint64_t>(std::max<uint64_t>(P, 1), batch_shift ? (1ull << batch_shift) : to_sink ? (regions > 4 ? 1ull << 18 : 1ull << 19) : (1ull << 23));
+    const uint64_t batch = std::min<uint64_t>(std::max<uint64_t>(P, 1), batch_shift ? (1ull << batch_shift) : to_sink ? (tg.sink->writers > 4 ? 1ull << 18 : 1ull << 19) : (1ull << 23));
     // The pairs are planned (k_plan_pairs: insert sizes, positions, the amplicon resolved to an index map) batch by batch, at the
     // head of each batch's pre-pass: bounds[b] = the amplicon that holds the batch's first pair.
     const uint32_t nbatch = (uint32_t)((P + batch - 1) / batch);
@@ -881,20 +887,30 @@ void do_yield(scs_ctx* c, const OutTarget& tg, uint64_t* n1_out, uint64_t* n2_ou
         launch_batch_bounds(s, c->pair_off.as<uint32_t>(), c->fulls.n, batch, nbatch, c->d_bounds.as<uint32_t>());
         HIP_OK(hipMemcpyAsync(bounds.data(), c->d_bounds.p, ((size_t)nbatch + 1) * 4, hipMemcpyDeviceToHost, s)); HIP_OK(hipStreamSynchronize(s));
     }
-    // The order the batches are made in.  One region: record order.  Several (a sink with that many writers): region k owns the
-    // contiguous batches [k nbatch / regions, (k + 1) nbatch / regions) and the regions are visited round-robin, so every writer
-    // always has a batch of its own range on the way while each range still arrives in record order.
+    // The order the batches are made in.  One region: record order.  Several (a sink with `writers` threads and regions = writers x
+    // generations): region r owns the contiguous batches [r nbatch / regions, (r + 1) nbatch / regions); generation after generation,
+    // the `writers` regions of a generation are visited round-robin, so every writer always has a batch of its own range on the way
+    // while each range still arrives in record order -- and a generation's parts are complete when the next one starts.
+    const int n_writers = to_sink ? std::max(1, std::min(tg.sink->writers, regions)) : 1;
     std::vector<uint32_t> order, region_of; order.reserve(nbatch); region_of.reserve(nbatch);
-    {
-        std::vector<uint32_t> next((size_t)regions), end((size_t)regions);
-        for (int k = 0; k < regions; ++k) { next[(size_t)k] = (uint32_t)((uint64_t)nbatch * k / regions); end[(size_t)k] = (uint32_t)((uint64_t)nbatch * (k + 1) / regions); }
-        while (order.size() < nbatch) for (int k = 0; k < regions; ++k) if (next[(size_t)k] < end[(size_t)k]) { order.push_back(next[(size_t)k]++); region_of.push_back((uint32_t)k); }
+    for (int g0 = 0; g0 < regions; g0 += n_writers) {
+        const int g1 = std::min(regions, g0 + n_writers);
+        std::vector<uint32_t> next((size_t)(g1 - g0)), end((size_t)(g1 - g0)); size_t left = 0;
+        for (int r = g0; r < g1; ++r) { next[(size_t)(r - g0)] = (uint32_t)((uint64_t)nbatch * r / regions); end[(size_t)(r - g0)] = (uint32_t)((uint64_t)nbatch * (r + 1) / regions); left += end[(size_t)(r - g0)] - next[(size_t)(r - g0)]; }
+        while (left) for (int r = g0; r < g1; ++r) if (next[(size_t)(r - g0)] < end[(size_t)(r - g0)]) { order.push_back(next[(size_t)(r - g0)]++); region_of.push_back((uint32_t)r); --left; }
     }
     struct PipeGuard { SinkPipe* p; ~PipeGuard() { if (p) (void)p->finish(); } } guard{nullptr};
     if (to_sink) {
         if (!c->pipe) c->pipe = new SinkPipe;
         if (!c->copy_stream) { HIP_OK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking)); for (int k = 0; k < 2; ++k) { HIP_OK(hipEventCreateWithFlags(&c->ev_made[k], hipEventDisableTiming)); HIP_OK(hipEventCreateWithFlags(&c->ev_d2h[k], hipEventDisableTiming)); } }
         c->pipe->start(tg.sink, paired != 0, c->cfg.device); guard.p = c->pipe;
+    }
+    const bool bgzf = to_sink && tg.bgzf;
+    if (bgzf && !c->h_z) {
+        HIP_OK(hipHostMalloc((void**)&c->h_z, 64, hipHostMallocDefault)); memset(c->h_z, 0, 64);
+        for (int k = 0; k < 2; ++k) HIP_OK(hipEventCreateWithFlags(&c->ev_z[k], hipEventDisableTiming));
+        std::vector<uint32_t> tabs(512); bgzf_host_tables(tabs.data(), tabs.data() + 256);
+        upload(c->z_crc, tabs, s); HIP_OK(hipStreamSynchronize(s));
     }
     uint64_t bi = 0;                                                               // batches handed to the sink so far
     // Per batch a PRE-PASS (indel events -> record sizes -> offsets, class lists; k_indels + scans) must finish before the host
@@ -965,6 +981,23 @@ void do_yield(scs_ctx* c, const OutTarget& tg, uint64_t* n1_out, uint64_t* n2_ou
         bpair.assign(v.begin(), v.end()); tg.seg_off1->assign(ALLOC_SLOTS + 1, 0); if (tg.seg_off2) tg.seg_off2->assign(ALLOC_SLOTS + 1, 0);
     }
     bool d2h_rec[2] = {false, false};
+    uint64_t sunk1 = 0, sunk2 = 0;                                                  // bytes handed to the sink (= the text's, or its BGZF blocks')
+    struct Ship { char* p1; char* p2; uint64_t n1, n2; int dsl; uint32_t region; };
+    Ship pending{}; bool have_pending = false;
+    auto ship = [&](Ship sh) {                                                      // D2H on the copy stream into a free pinned slot, then to the region's writer
+        SinkPipe* pp = c->pipe;
+        if (bgzf) { HIP_OK(hipEventSynchronize(c->ev_z[sh.dsl])); sh.n1 = c->h_z[sh.dsl * 2]; sh.n2 = c->h_z[sh.dsl * 2 + 1]; }   // the blocks' totals have arrived
+        const int hs = pp->acquire(sh.n1, sh.n2);                                   // (a pinned slot no writer holds: the host waits here when the sink is the slower side)
+        if (hs < 0) throw ScsError(SCS_EIO, "sink aborted");
+        SinkPipe::Slot& H = pp->slots[(size_t)hs];
+        HIP_OK(hipStreamWaitEvent(c->copy_stream, c->ev_made[sh.dsl], 0));          // ... and crosses PCIe on the copy stream, beside the next batch's kernels
+        if (sh.n1) HIP_OK(hipMemcpyAsync(H.h[0], sh.p1, sh.n1, hipMemcpyDeviceToHost, c->copy_stream));
+        if (sh.n2) HIP_OK(hipMemcpyAsync(H.h[1], sh.p2, sh.n2, hipMemcpyDeviceToHost, c->copy_stream));
+        HIP_OK(hipEventRecord(H.ev, c->copy_stream));
+        HIP_OK(hipEventRecord(c->ev_d2h[sh.dsl], c->copy_stream)); d2h_rec[sh.dsl] = true;
+        pp->submit((int)sh.region, hs, sh.n1, sh.n2);
+        sunk1 += sh.n1; sunk2 += sh.n2;
+    };
     c->cks.clear();
     if (c->want_cks && !tg.device) c->d_cks.reserve(std::max<size_t>((size_t)nbatch * 16, 16), s);
     if (P) prepass((uint64_t)order[0] * batch, bs[0], 0);
@@ -1015,20 +1048,36 @@ void do_yield(scs_ctx* c, const OutTarget& tg, uint64_t* n1_out, uint64_t* n2_ou
         if (ps != s) { HIP_OK(hipEventRecord(c->ev_free[it & 1], s)); free_rec[it & 1] = true; }   // this batch's buffer set is free for the pre-pass after next
         { const hipError_t le = take_launch_error(); if (le != hipSuccess) throw ScsError(SCS_EDEVICE, std::string("k_reads launch failed: ") + hipGetErrorString(le)); }
         if (pp) {
-            HIP_OK(hipEventRecord(c->ev_made[dsl], s));                             // the batch's text is complete ...
-            const int hs = pp->acquire(b1, b2);                                     // (a pinned slot no writer holds: the host waits here when the sink is the slower side)
-            if (hs < 0) throw ScsError(SCS_EIO, "sink aborted");
-            SinkPipe::Slot& H = pp->slots[(size_t)hs];
-            HIP_OK(hipStreamWaitEvent(c->copy_stream, c->ev_made[dsl], 0));         // ... and crosses PCIe on the copy stream, beside the next batch's kernels
-            if (b1) HIP_OK(hipMemcpyAsync(H.h[0], o1, b1, hipMemcpyDeviceToHost, c->copy_stream));
-            if (b2) HIP_OK(hipMemcpyAsync(H.h[1], o2, b2, hipMemcpyDeviceToHost, c->copy_stream));
-            HIP_OK(hipEventRecord(H.ev, c->copy_stream));
-            HIP_OK(hipEventRecord(c->ev_d2h[dsl], c->copy_stream)); d2h_rec[dsl] = true;
-            pp->submit((int)region_of[it], hs, b1, b2);
+            Ship sh{o1, o2, b1, b2, dsl, region_of[it]};
+            if (bgzf) {
+                // the text becomes BGZF blocks where it lies: plan (code lengths, exact block sizes), prefix sum, emit at the final offsets.
+                // The blocks' total is only known on the device: it travels to a pinned word behind ev_z, and the batch is shipped ONE
+                // ITERATION LATER, when the host reads it without waiting while the GPU works on the next batch.
+                for (int m = 0; m < (paired ? 2 : 1); ++m) {
+                    const uint64_t nb = m ? b2 : b1; const uint32_t nblk = bgzf_blocks(nb);
+                    c->z_plan[m].reserve(std::max<size_t>((size_t)nblk * BGZF_PLAN_BYTES, 16), s); c->z_sizes[m].reserve(((size_t)nblk + 2) * 4, s); c->z_offs[m].reserve(((size_t)nblk + 2) * 4, s);
+                    DevBuf& zo = c->z_out[dsl][m];
+                    if (bgzf_bound(nb) > zo.cap && d2h_rec[dsl]) HIP_OK(hipEventSynchronize(c->ev_d2h[dsl]));
+                    zo.reserve(bgzf_bound(nb), s);
+                    if (bgzf_bound(nb) > 0xFFFFFFF0ull) throw ScsError(SCS_EOVERFLOW, "BGZF: a batch's text exceeds 4 GB");
+                    launch_bgzf_plan(s, m ? o2 : o1, nb, c->z_plan[m].as<uint8_t>(), c->z_sizes[m].as<uint32_t>());
+                    exclusive_scan_u32(s, c->z_sizes[m].as<uint32_t>(), c->z_offs[m].as<uint32_t>(), nblk, nullptr, 0);   // (n <= 256 k: the one-workgroup scan, no scratch)
+                    launch_bgzf_emit(s, m ? o2 : o1, nb, c->z_plan[m].as<uint8_t>(), c->z_sizes[m].as<uint32_t>(), c->z_offs[m].as<uint32_t>(),
+                                     c->z_crc.as<uint32_t>(), c->z_crc.as<uint32_t>() + 256, zo.as<char>(), 0);
+                    HIP_OK(hipMemcpyAsync(c->h_z + (dsl * 2 + m), c->z_offs[m].as<uint32_t>() + nblk, 4, hipMemcpyDeviceToHost, s));
+                }
+                if (!paired) c->h_z[dsl * 2 + 1] = 0;
+                HIP_OK(hipEventRecord(c->ev_z[dsl], s));
+                sh.p1 = c->z_out[dsl][0].as<char>(); sh.p2 = paired ? c->z_out[dsl][1].as<char>() : nullptr;
+            }
+            HIP_OK(hipEventRecord(c->ev_made[dsl], s));                             // the batch's text (its blocks) is complete ...
+            if (bgzf) { if (have_pending) ship(pending); pending = sh; have_pending = true; }
+            else ship(sh);
             ++bi;
         }
         tot1 += b1; tot2 += b2;
     }
+    if (have_pending) ship(pending);
     if (tg.seg_off1) {                                                               // record order = batch order: the bytes before each batch
         std::vector<uint64_t> pre1(nbatch + 1, 0), pre2(nbatch + 1, 0);
         for (uint32_t b = 0; b < nbatch; ++b) { pre1[b + 1] = pre1[b] + bb1[b]; pre2[b + 1] = pre2[b] + bb2[b]; }
@@ -1046,6 +1095,7 @@ void do_yield(scs_ctx* c, const OutTarget& tg, uint64_t* n1_out, uint64_t* n2_ou
     c->tm_reads.collect(); c->tm_indels.collect();
     c->st.pairs_written = pairs_written; c->st.reads_written = paired ? 2 * pairs_written : pairs_written;
     c->st.fastq_bytes[0] = tot1; c->st.fastq_bytes[1] = tot2;
+    c->st.sink_bytes[0] = to_sink ? sunk1 : 0; c->st.sink_bytes[1] = to_sink ? sunk2 : 0;
     // 1526 B per created amplicon + per pair (insert size + FASTQ bytes of both records)
     const uint64_t per_pair_tmpl = paired ? (uint64_t)(c->cfg.isize + 1) : (uint64_t)L;
     c->st.algorithmic_bytes = 1526ull * (c->st.semi_amplicons + c->st.full_amplicons) + pairs_written * per_pair_tmpl + tot1 + tot2;
@@ -1116,6 +1166,8 @@ void scs_destroy(scs_ctx* c) {
     if (c->pre_stream) { (void)hipStreamDestroy(c->pre_stream); (void)hipEventDestroy(c->ev_plan); for (int k = 0; k < 2; ++k) { (void)hipEventDestroy(c->ev_pre[k]); (void)hipEventDestroy(c->ev_free[k]); } }
     for (int k = 0; k < 2; ++k) { if (c->ev_made[k]) (void)hipEventDestroy(c->ev_made[k]); if (c->ev_d2h[k]) (void)hipEventDestroy(c->ev_d2h[k]); }
     c->reads_side.release();
+    for (int k = 0; k < 2; ++k) { c->z_plan[k].release(); c->z_sizes[k].release(); c->z_offs[k].release(); c->z_out[k][0].release(); c->z_out[k][1].release(); if (c->ev_z[k]) (void)hipEventDestroy(c->ev_z[k]); }
+    c->z_crc.release(); if (c->h_z) (void)hipHostFree(c->h_z);
     c->semis.release(); c->fulls.release();
     for (KernelTimer* t : {&c->tm_errscan, &c->tm_errscan_f, &c->tm_reads, &c->tm_attach, &c->tm_indels, &c->tm_attach_f}) t->release();
     if (c->h_rb) (void)hipHostFree(c->h_rb);
@@ -1228,22 +1280,24 @@ int scs_yield_reads_device(scs_ctx* c, void* d1, size_t cap1, void* d2, size_t c
 // SeqWriter (lib/seqwriter/SeqWriter.cpp:12-64).  writers <= 1: the reference's files <prefix>_1.fq / _2.fq (.fq) -- a shard of a
 // sharded job: <prefix>.r<rank>_1.fq ... + <prefix>.r<rank>.idx.  writers = K > 1: K part files per mate, each a contiguous
 // range of the job's (shard's) records written by its own thread, + <base>.parts (scs_comm.h: FastqParts).
-int scs_yield_reads_files(scs_ctx* c, const char* prefix, int writers) {
+int scs_yield_reads_files_ex(scs_ctx* c, const char* prefix, int writers, int generations, int bgzf) {
     return guarded(c, [&] {
         if (!prefix || !*prefix) throw ScsError(SCS_EINVAL, "scs_yield_reads_files: no output prefix");
-        if (writers > 64) throw ScsError(SCS_EINVAL, "scs_yield_reads_files: at most 64 writers");
+        if (writers > 64 || generations > 64 || (int64_t)std::max(1, writers) * std::max(1, generations) > 99) throw ScsError(SCS_EINVAL, "scs_yield_reads_files: at most 64 writers and 99 parts");
         const bool pe = c->cfg.paired != 0, shard = c->cfg.shard_count > 1; const std::string pre = prefix;
         const std::string base = shard ? shard_base(pre, c->cfg.shard_rank) : pre;
         FastqParts files; std::string err;
-        if (!files.open(base, pe, writers > 1 ? writers : 1, ".fq", false, err)) throw ScsError(SCS_EIO, err);
+        if (!files.open(base, pe, std::max(1, writers), std::max(1, generations), bgzf ? ".fq.gz" : ".fq", bgzf != 0, err)) throw ScsError(SCS_EIO, err);
         std::vector<uint64_t> so1, so2;
-        double t = now_s(); OutTarget tg{false, nullptr, nullptr, 0, 0, &files}; if (shard) { tg.seg_off1 = &so1; tg.seg_off2 = &so2; }
+        double t = now_s(); OutTarget tg{false, nullptr, nullptr, 0, 0, &files}; tg.bgzf = bgzf != 0;
+        if (shard && !bgzf) { tg.seg_off1 = &so1; tg.seg_off2 = &so2; }              // (byte ranges of compressed shards cannot be spliced: BGZF shards stay shards)
         do_yield(c, tg, nullptr, nullptr, nullptr);
         if (!files.close(err)) throw ScsError(SCS_EIO, err);
-        if (shard && !write_shard_index(shard_index_path(pre, c->cfg.shard_rank), so1, so2, err)) throw ScsError(SCS_EIO, err);
+        if (shard && !bgzf && !write_shard_index(shard_index_path(pre, c->cfg.shard_rank), so1, so2, err)) throw ScsError(SCS_EIO, err);
         c->st.t_stage[5] = now_s() - t;
     });
 }
+int scs_yield_reads_files(scs_ctx* c, const char* prefix, int writers) { return scs_yield_reads_files_ex(c, prefix, writers, 1, 0); }
 int scs_merge_fastq_parts(const char* prefix, int paired, int keep_parts, char* errbuf, size_t errlen) {
     if (!prefix) return SCS_EINVAL;
     std::string err;
@@ -1450,6 +1504,14 @@ int scs_simuvars_probe(const char* ref_fasta, const char* snp_file, const char* 
         if (n_records) *n_records = (int)P.rec_names.size(); if (total_bases) *total_bases = P.total; if (checksum) *checksum = h;
         return SCS_OK;
     } catch (const std::exception& e) { if (errbuf && errlen) { strncpy(errbuf, e.what(), errlen - 1); errbuf[errlen - 1] = 0; } return SCS_EIO; }
+}
+// host-only test seam: the BGZF kernels' arithmetic run on the CPU ("thread" by "thread" over the same functions: scs_bgzf.hip)
+int scs_bgzf_probe(const void* text, uint64_t nbytes, uint32_t lds_out_cap, void* out, uint64_t cap, uint64_t* n_out) {
+    if ((!text && nbytes) || !n_out) return SCS_EINVAL;
+    std::vector<uint8_t> z; bgzf_compress_host((const uint8_t*)text, nbytes, lds_out_cap ? lds_out_cap : BGZF_LDS_OUT, z);
+    *n_out = z.size();
+    if (out) { if (z.size() > cap) return SCS_EOVERFLOW; memcpy(out, z.data(), z.size()); }
+    return SCS_OK;
 }
 int scs_fasta_write_index(const char* path, char* errbuf, size_t errlen) {
     if (!path) return SCS_EINVAL;

@@ -184,3 +184,96 @@ def test_cli_writers_and_unopenable_output(oracle_bin, models, golden_inputs, tm
         assert _cat(files[m]) == open(prefix + s, "rb").read()
     rc, err, _ = _cli(["-i", fa, "-m", prof, "-c", "2", "-o", str(tmp_path / "nodir" / "x"), "--seed", "99"])
     assert rc == 255 and "can not open fastq file" in err
+
+
+def test_bgzf_made_on_the_gpu_inflates_to_the_oracle_text(oracle_bin, models, golden_inputs, tmp_path):
+    """scs_yield_reads_files_ex(..., bgzf): the batches' text becomes BGZF blocks on the GPU (histogram, Huffman lengths, bit packing,
+    CRC-32: scs_bgzf.hip), crosses PCIe compressed and lands in <prefix>_1.fq.gz / part files.  zlib is the checker: every part is
+    a run of well-framed BGZF blocks + the end-of-file block; gunzip of the parts in order is the oracle's text, byte for byte --
+    one writer and several, generations, small batches (blocks cut at batch ends) and one big batch (63 KB blocks), PE and SE."""
+    import gzip
+    fa = str(tmp_path / "simu.fa")
+    subprocess.check_call(["python3", os.path.join(ROOT, "tools", "make_genome.py"), "--lengths", "7000000,5000000", "--seed", "31", "--n-block", "20000", "--simu-out", fa])
+    prof = models["Illumina_HiSeq2500"]
+    prefix = str(tmp_path / "orc")
+    _oracle(oracle_bin, fa, prof, prefix, ["-c", "4"], 41, threads=min(32, os.cpu_count() or 1))
+    want = [open(prefix + s, "rb").read() for s in ("_1.fq", "_2.fq")]
+    eof = bytes([0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0])
+    code = '''
+import sys
+sys.path.insert(0, %r)
+import scssim_amd
+g = scssim_amd.GenReads(profile=%r, input_fasta=%r, coverage=4.0, seed=41)
+g.create_frags(); g.amplify(); g.allocate_reads(0)
+for K, G in %%s:
+    g.yield_reads_files(%r + "_%%%%d_%%%%d" %%%% (K, G), K, G, True)
+    st = g.stats()
+    print("RATIO", K, G, sum(st["fastq_bytes"]) / sum(st["sink_bytes"]))
+''' % (ROOT, prof, fa, str(tmp_path / "z"))
+    for shift, combos in ((None, [(1, 1), (3, 1)]), ("13", [(1, 1), (2, 3), (5, 1)])):
+        env = dict(os.environ) if shift is None else dict(os.environ, SCS_TEST_BATCH_SHIFT=shift)
+        r = subprocess.run([sys.executable, "-c", code % repr(combos)], env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout + r.stderr
+        ratios = [float(l.split()[3]) for l in r.stdout.splitlines() if l.startswith("RATIO")]
+        assert len(ratios) == len(combos) and min(ratios) > 1.8, r.stdout
+        for K, G in combos:
+            base = str(tmp_path / "z") + "_%d_%d" % (K, G)
+            files = scssim_amd.part_paths(base, K * G, True, ".fq.gz")
+            for m in range(2):
+                text = b""
+                for f in files[m]:
+                    z = open(f, "rb").read()
+                    assert z.endswith(eof), f
+                    blocks = scssim_amd.bgzf_blocks(z)
+                    assert all(i <= 64512 for _, i in blocks) and blocks[-1][1] == 0
+                    text += gzip.decompress(z)
+                assert text == want[m], "bgzf K=%d G=%d mate %d (batch shift %s)" % (K, G, m + 1, shift)
+    # single end, through the CLI
+    fa3, prof3 = golden_inputs["g3_hiseq2000_se"], models["Illumina_HiSeq2000"]
+    prefix = str(tmp_path / "orc_se")
+    _oracle(oracle_bin, fa3, prof3, prefix, ["-c", "2", "-l", "SE"], 42)
+    out = str(tmp_path / "cli_se")
+    rc, err, _ = _cli(["-i", fa3, "-m", prof3, "-c", "2", "-l", "SE", "-o", out, "--seed", "42", "--bgzf"])
+    assert rc == 0, err
+    assert gzip.decompress(open(out + ".fq.gz", "rb").read()) == open(prefix + ".fq", "rb").read()
+
+
+def test_generations_finish_their_parts_while_the_job_runs(oracle_bin, models, tmp_path):
+    """writers = 2, generations = 4: eight parts per mate made generation by generation.  A watcher thread sees part p complete (its
+    size final) by the time part p + 2 exists, while the job is still running; the parts concatenate to the oracle's file."""
+    import threading
+    import time
+    fa = str(tmp_path / "simu.fa")
+    subprocess.check_call(["python3", os.path.join(ROOT, "tools", "make_genome.py"), "--lengths", "7000000,5000000", "--seed", "31", "--n-block", "20000", "--simu-out", fa])
+    prof = models["Illumina_HiSeqXTen"]
+    prefix = str(tmp_path / "orc")
+    _oracle(oracle_bin, fa, prof, prefix, ["-c", "4"], 8, threads=min(32, os.cpu_count() or 1))
+    code = '''
+import sys
+sys.path.insert(0, %r)
+import scssim_amd
+g = scssim_amd.GenReads(profile=%r, input_fasta=%r, coverage=4.0, seed=8)
+g.create_frags(); g.amplify(); g.allocate_reads(0)
+g.yield_reads_files(%r, 2, 4)
+''' % (ROOT, prof, fa, str(tmp_path / "gen"))
+    files = scssim_amd.part_paths(str(tmp_path / "gen"), 8, True)
+    seen = {}
+    stop = [False]
+
+    def watch():
+        while not stop[0]:
+            for p in range(6):
+                if p not in seen and os.path.exists(files[0][p + 2]):
+                    seen[p] = os.path.getsize(files[0][p])          # final by the rule
+            time.sleep(0.002)
+    th = threading.Thread(target=watch); th.start()
+    try:
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SCS_TEST_BATCH_SHIFT="10"), capture_output=True, text=True, timeout=600)
+    finally:
+        stop[0] = True; th.join()
+    assert r.returncode == 0, r.stdout + r.stderr
+    for m, s in enumerate(("_1.fq", "_2.fq")):
+        assert _cat(files[m]) == open(prefix + s, "rb").read()
+    assert len(seen) >= 4, "the watcher saw too few parts appear while the job ran"
+    for p, size in seen.items():
+        assert size == os.path.getsize(files[0][p]) and size > 0, "part %d changed after part %d existed" % (p, p + 2)

@@ -258,6 +258,38 @@ def test_cli_sharded_job_fails_fast_when_its_ranks_cannot_start(golden_inputs, m
         assert "no HIP device" in err or "failed" in err
 
 
+def test_bgzf_arithmetic_inflates_with_zlib():
+    """The BGZF kernels' arithmetic run on the CPU (scs_bgzf_probe: the same functions "thread" by "thread" -- Huffman lengths with
+    the 15-bit limit, the run-length coded header under a fixed code-length code, 256 chunks packed at prefix-sum bit offsets, 256
+    chunk CRCs combined by carry-less multiplication) against zlib: every block is a well-framed BGZF block that inflates to its
+    63 KB of the input with the right CRC, for FASTQ-like text, one symbol, random bytes, tiny inputs, Fibonacci frequencies
+    (code lengths beyond 15 without the limit) and the stored fallback."""
+    import gzip
+    import zlib
+    import scssim_amd
+    rng = np.random.default_rng(1)
+    recs = []
+    for i in range(450):
+        recs.append("@%d#1/1\n%s\n+\n%s\n" % (90000 + i, "".join(rng.choice(list("ACGTN"), 150, p=[.3, .2, .2, .29, .01])),
+                                             "".join(chr(33 + int(x)) for x in rng.choice(41, 150, p=np.arange(1, 42) / 861.0))))
+    fq = "".join(recs).encode()
+    fib = [1, 1]
+    while sum(fib) < 60000:
+        fib.append(fib[-1] + fib[-2])
+    cases = {"fastq": fq, "tiny": b"A", "two": b"AB", "one_symbol": b"N" * 70000, "random": os.urandom(150000), "empty": b"",
+             "exact_block": fq[:64512], "block_plus_1": fq[:64513], "fibonacci": b"".join(bytes([65 + i]) * f for i, f in enumerate(fib))}
+    for name, data in cases.items():
+        for cap in (0, 64):                                         # 64: every block takes the stored path
+            z = scssim_amd.bgzf_probe(data, cap)
+            blocks = scssim_amd.bgzf_blocks(z)
+            assert len(blocks) == (len(data) + 64511) // 64512, name
+            assert b"".join(zlib.decompress(b, 31) for b, _ in blocks) == data, (name, cap)      # wbits 31: gzip framing, CRC-32 and ISIZE checked
+            assert [i for _, i in blocks] == [min(64512, len(data) - o) for o in range(0, len(data), 64512)]
+            if data:
+                assert gzip.decompress(z) == data
+    assert len(scssim_amd.bgzf_probe(fq)) < 0.6 * len(fq)             # 2 bits per base + the qualities' entropy (5 bits here)
+
+
 def test_part_files_are_one_logical_file_for_both_merges(tmp_path):
     """A sink with K writers leaves K part files per mate (<base>.p00_1.fq ...) + <base>.parts; their concatenation is the
     single file.  Host only: scs_merge_fastq_parts rebuilds the reference's two files from them, and scs_merge_fastq_shards
