@@ -134,7 +134,7 @@ def cpu_baseline(td, prof, names, seqs, sample_desc, coverage):
             if os.path.exists(fa + suf):
                 os.remove(fa + suf)
         if out:                                                     # -t 1 beside -t cores, on the sample's first quarter (the rate per core)
-            n1 = max(100000, len(seqs[0]) // 4)
+            n1 = max(100000, len(seqs[0]) // 16)
             fa1 = os.path.join(td, "cpu_sample_t1.fa")
             write_simu_fasta(fa1, ["1_1_%d" % n1, "1_2_%d" % n1], [seqs[0][:n1], seqs[0][:n1]])
             t0 = time.perf_counter()
@@ -282,6 +282,29 @@ class Cleaner:
                 self.cv.wait(0.05)
         return time.perf_counter() - t0
 
+    def watch(self, files_by_part, k):
+        """files_by_part[p] = the files of part p, made generation by generation with k writers: part p is final once part p + k
+        exists (scs_yield_reads_files_ex) -- a polling thread hands the finished parts to the unlinkers while the step still runs.
+        Returns a function that stops the watch and queues what is left."""
+        import threading
+        stop = threading.Event()
+        done = set()
+
+        def poll():
+            while not stop.is_set():
+                for p in range(len(files_by_part) - k):
+                    if p not in done and os.path.exists(files_by_part[p + k][0]):
+                        done.add(p)
+                        self.add(files_by_part[p])
+                stop.wait(0.02)
+        th = threading.Thread(target=poll, daemon=True)
+        th.start()
+
+        def finish(extra):
+            stop.set(); th.join()
+            self.add([f for p in range(len(files_by_part)) if p not in done for f in files_by_part[p]] + list(extra))
+        return finish
+
     def close(self):
         self.gate(0)
         for _ in self.th:
@@ -381,6 +404,7 @@ def main():
     ap.add_argument("--genome-mb", type=float, default=0.0, help="scale the 24 hg19-like records to this many Mb (default: the real 3096 Mb)")
     ap.add_argument("--coverage", type=float, default=30.0)
     ap.add_argument("--writers", type=int, default=0, help="part files per mate and writer threads of the FASTQ sink (default: host cores - 4, at most 12)")
+    ap.add_argument("--generations", type=int, default=6, help="the part files are made in this many generations (writers x generations parts per mate): a generation's files are final when the next starts")
     ap.add_argument("--out-dir", default="", help="where the timed steps write their FASTQ part files (default: a fresh directory on /dev/shm)")
     ap.add_argument("--hbm-only", action="store_true", help="time the steps with a NULL sink (text generated into HBM buffers, no files): the generation_hbm leg as the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -474,6 +498,7 @@ def main():
     writers = a.writers or max(1, min(12, cores // max(1, world if world > 1 and not cpu_coll else 1) - 4))
     out_dir = a.out_dir or tempfile.mkdtemp(prefix="scsbench_out_", dir=shm)
     os.makedirs(out_dir, exist_ok=True)
+    generations = a.generations
     cleaner = Cleaner(threads=4)
     GATE_BYTES = 40 << 30                                            # a step's sink starts when at most this much of the older steps' text is still on tmpfs
 
@@ -492,13 +517,17 @@ def main():
         t2 = time.perf_counter(); g.allocate_reads(0)
         t3 = time.perf_counter()
         waited = 0.0
-        if mode == "files":
+        if mode in ("files", "bgzf"):
             waited = cleaner.gate(GATE_BYTES)
             base = os.path.join(out_dir, "step%d" % i)
-            g.yield_reads_files(base, writers)                       # the library's file sink (SeqWriter): D2H + `writers` threads, one part file per mate each
             lbase = base + (".r%d" % rank if world > 1 else "")
-            files = [f for m in scssim_amd.part_paths(lbase, writers, True) for f in m] + [lbase + ".parts", lbase + ".idx"]
-            cleaner.add([f for f in files if os.path.exists(f)])
+            pp = scssim_amd.part_paths(lbase, writers * generations, True, ".fq.gz" if mode == "bgzf" else ".fq")
+            finish = cleaner.watch([[pp[0][p], pp[1][p]] for p in range(writers * generations)], writers)
+            try:
+                # the library's file sink (SeqWriter): D2H + `writers` threads, a part file per mate each, generation by generation
+                g.yield_reads_files(base, writers, generations, mode == "bgzf")
+            finally:
+                finish([f for f in (lbase + ".parts", lbase + ".idx") if os.path.exists(f)])
         elif mode == "null":
             g.yield_reads_sink(None)                                 # generate into HBM batch buffers and count
         else:
@@ -556,10 +585,11 @@ def main():
                        "sharding": ("one job over %d GPUs by fragment lineage; per-pass primer-stock all-reduce + allocation partials over RCCL; a FASTQ shard per rank" % world) if world > 1 else "single GPU",
                        "collectives": coll_path,
                        "output": ("FASTQ text generated batch by batch into HBM buffers (NULL sink): --hbm-only" if a.hbm_only else
-                                  "plain FASTQ files on tmpfs (%s): %d part files per mate%s, each a contiguous range of the records written by its own thread (scs_yield_reads_files, writers = %d; "
-                                  "`cat` of the parts in order is the reference's <prefix>_1.fq / _2.fq); every step writes fresh files, the step before's are unlinked by 4 background threads "
-                                  "while it runs (a step's sink starts when <= 40 GB of them are left: `wait_for_cleanup` in stages_s_per_step, inside the timed region)"
-                                  % (out_dir, writers, " and rank" if world > 1 else "", writers)),
+                                  "plain FASTQ files on tmpfs (%s): %d part files per mate%s, each a contiguous range of the records (scs_yield_reads_files_ex: %d writer threads x %d generations; "
+                                  "`cat` of the parts in order is the reference's <prefix>_1.fq / _2.fq).  Every step writes fresh files; the memory cgroup cannot hold two steps' text, so 4 background "
+                                  "threads unlink every part once it is final (a generation's parts are final when the next generation starts) and a step's sink starts when <= 40 GB of older text "
+                                  "are left (`wait_for_cleanup` in stages_s_per_step): all of it inside the timed region"
+                                  % (out_dir, writers * generations, " and rank" if world > 1 else "", writers, generations)),
                        "sink_GBps": None if a.hbm_only else R["fq_bytes"] / max(1e-9, R["stage"]["reads"] * a.steps) / 1e9,
                        "host_cores": cores},
             "stages_s_per_step": R["stage"],
@@ -608,6 +638,17 @@ def main():
             D = timed(0, 1, count_only, 200)
             out["d2h_only"] = {"value": D["pairs"] / D["elapsed"], "unit": "pairs/s", "seconds": D["elapsed"], "GBps": seen[0] / max(1e-9, D["stage"]["reads"]) / 1e9,
                                "what": "one step with a sink that only counts the bytes it is handed: D2H into pinned slots, nothing written"}
+            # ---- BGZF: the same job with the text compressed on the GPU before it crosses PCIe (<...>.fq.gz parts); an extension (the
+            # reference writes plain text), so a leg of its own
+            try:
+                Z = timed(1, 2, "bgzf", 300)
+                cleaner.gate(0)
+                zs = g.stats()
+                out["bgzf"] = {"value": Z["pairs"] / Z["elapsed"], "unit": "pairs/s", "steps": 2, "ms_per_step": 1e3 * Z["elapsed"] / 2, "stages_s_per_step": Z["stage"],
+                               "compression": sum(zs["fastq_bytes"]) / max(1, sum(zs["sink_bytes"])), "bytes_per_step_in_files": sum(zs["sink_bytes"]),
+                               "what": "the same job with --bgzf: every batch's text made into BGZF blocks by two kernels where it lies in HBM (dynamic-Huffman deflate of literals, CRC-32), D2H and %d x %d .fq.gz part files per mate on tmpfs" % (writers, generations)}
+            except Exception as e:
+                out["bgzf"] = {"error": repr(e)}
             # ---- the sweep north_star asks for (1 Mb -> 3 Gb) in one record: configs[1] and configs[2]'s sizes, same model and options
             try:
                 out["sweep"] = [small_config(torch, scssim_amd, dev, stream, prof, 1.0, a.coverage, "configs[1]: 1 Mb x 2 haplotypes, PE150 %gx" % a.coverage, shm),
