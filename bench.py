@@ -405,6 +405,7 @@ def main():
     ap.add_argument("--coverage", type=float, default=30.0)
     ap.add_argument("--writers", type=int, default=0, help="part files per mate and writer threads of the FASTQ sink (default: host cores - 4, at most 12)")
     ap.add_argument("--generations", type=int, default=6, help="the part files are made in this many generations (writers x generations parts per mate): a generation's files are final when the next starts")
+    ap.add_argument("--cleaners", type=int, default=4, help="background threads that unlink finished part files")
     ap.add_argument("--out-dir", default="", help="where the timed steps write their FASTQ part files (default: a fresh directory on /dev/shm)")
     ap.add_argument("--hbm-only", action="store_true", help="time the steps with a NULL sink (text generated into HBM buffers, no files): the generation_hbm leg as the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -499,7 +500,7 @@ def main():
     out_dir = a.out_dir or tempfile.mkdtemp(prefix="scsbench_out_", dir=shm)
     os.makedirs(out_dir, exist_ok=True)
     generations = a.generations
-    cleaner = Cleaner(threads=4)
+    cleaner = Cleaner(threads=max(1, a.cleaners))
     GATE_BYTES = 40 << 30                                            # a step's sink starts when at most this much of the older steps' text is still on tmpfs
 
     def acc(ktimes, kt, names_):
@@ -586,10 +587,10 @@ def main():
                        "collectives": coll_path,
                        "output": ("FASTQ text generated batch by batch into HBM buffers (NULL sink): --hbm-only" if a.hbm_only else
                                   "plain FASTQ files on tmpfs (%s): %d part files per mate%s, each a contiguous range of the records (scs_yield_reads_files_ex: %d writer threads x %d generations; "
-                                  "`cat` of the parts in order is the reference's <prefix>_1.fq / _2.fq).  Every step writes fresh files; the memory cgroup cannot hold two steps' text, so 4 background "
+                                  "`cat` of the parts in order is the reference's <prefix>_1.fq / _2.fq).  Every step writes fresh files; the memory cgroup cannot hold two steps' text, so %d background "
                                   "threads unlink every part once it is final (a generation's parts are final when the next generation starts) and a step's sink starts when <= 40 GB of older text "
                                   "are left (`wait_for_cleanup` in stages_s_per_step): all of it inside the timed region"
-                                  % (out_dir, writers * generations, " and rank" if world > 1 else "", writers, generations)),
+                                  % (out_dir, writers * generations, " and rank" if world > 1 else "", writers, generations, max(1, a.cleaners))),
                        "sink_GBps": None if a.hbm_only else R["fq_bytes"] / max(1e-9, R["stage"]["reads"] * a.steps) / 1e9,
                        "host_cores": cores},
             "stages_s_per_step": R["stage"],

@@ -1551,6 +1551,33 @@ int scso_predict_counter(void* h, const uint8_t* window, int n, int is_read1, ui
     } catch (const std::exception& e) { g_err = e.what(); return -1; }
 }
 
+// predict() on one window drawing from the REFERENCE's streams (two mt19937 copies of one seed, ThreadPool.cpp:41-47,203-212): a
+// batch of windows in one call, the streams running on from read to read as they do in a worker thread.  For the statistical
+// comparison of the counter-mode remaps with the reference's draws (tests/test_oracle_stats.py); lens[i] = n' of read i,
+// outputs at stride 2 n + 64.
+int scso_predict_ref_batch(void* h, const uint8_t* windows, int n, int count, const uint8_t* is_read1, unsigned seed,
+                           char* out_bases, char* out_quals, int* lens) {
+    try {
+        RefStreams st; st.w_real = std::mt19937(seed); st.w_int = std::mt19937(seed);
+        Rng rng; rng.counter = false; rng.ref = &st;
+        const size_t stride = 2 * (size_t)n + 64;
+        for (int i = 0; i < count; ++i)
+            lens[i] = predict(*(Profile*)h, rng, windows + (size_t)i * n, n, is_read1[i] != 0, 0, 0, out_bases + (size_t)i * stride, out_quals + (size_t)i * stride);
+        return 0;
+    } catch (const std::exception& e) { g_err = e.what(); return -1; }
+}
+// the same batch in counter mode (uid = first_uid + i, attempt 0)
+int scso_predict_counter_batch(void* h, const uint8_t* windows, int n, int count, const uint8_t* is_read1, uint64_t seed, uint64_t first_uid,
+                               char* out_bases, char* out_quals, int* lens) {
+    try {
+        Rng rng; rng.counter = true; rng.key[0] = (uint32_t)seed; rng.key[1] = (uint32_t)(seed >> 32);
+        const size_t stride = 2 * (size_t)n + 64;
+        for (int i = 0; i < count; ++i)
+            lens[i] = predict(*(Profile*)h, rng, windows + (size_t)i * n, n, is_read1[i] != 0, first_uid + (uint64_t)i, 0, out_bases + (size_t)i * stride, out_quals + (size_t)i * stride);
+        return 0;
+    } catch (const std::exception& e) { g_err = e.what(); return -1; }
+}
+
 }  // extern "C"
 
 #ifdef SCS_ORACLE_MAIN

@@ -83,4 +83,10 @@ void  scso_profile_scalars(void* h, double out[8]);  // insertRate, delRate, std
 int scso_predict_counter(void* h, const uint8_t* window, int n, int is_read1,
                          uint64_t seed, uint64_t uid, uint32_t attempt,
                          char* out_bases, char* out_quals);
+// `count` windows in one call, outputs at stride 2 n + 64, lens[i] = n' : from the reference's streams (running on from read
+// to read) / in counter mode (uid = first_uid + i).  For the statistical comparison of the two (tests/test_oracle_stats.py).
+int scso_predict_ref_batch(void* h, const uint8_t* windows, int n, int count, const uint8_t* is_read1, unsigned seed,
+                           char* out_bases, char* out_quals, int* lens);
+int scso_predict_counter_batch(void* h, const uint8_t* windows, int n, int count, const uint8_t* is_read1, uint64_t seed, uint64_t first_uid,
+                               char* out_bases, char* out_quals, int* lens);
 }
