@@ -57,6 +57,8 @@ typedef struct scs_stats {
     uint64_t algorithmic_bytes;  /* 1526 B per created amplicon + per pair (isize + FASTQ bytes) */
     double   t_stage[8];         /* seconds: load, frags, amplify, weights, allocate, yield, -, total */
     uint64_t sink_bytes[2];      /* bytes handed to the sink per mate: fastq_bytes, or their BGZF blocks' (scs_yield_reads_files_ex) */
+    uint64_t staged_bases;       /* bases resident on this GPU: genome_bases, or -- a shard of a sharded job loaded from an indexed FASTA --
+                                    only the stretch its own fragments cover (scs_load_genome_fasta) */
 } scs_stats;
 
 void        scs_default_config(scs_config* cfg);
@@ -75,6 +77,11 @@ int         scs_read_length(const scs_ctx* ctx);
 /* Genome::loadData for genreads = Genome::loadRefSeq (lib/genome/Genome.cpp:18-25,176-195):
  * simuvars-style FASTA (records <chr>_<hap>_<reflen>); ".gz" is inflated with `gzip -cd` as there. */
 int         scs_load_genome_fasta(scs_ctx* ctx, const char* fasta_path);
+/* A shard of a sharded job (shard_count > 1) stages only ITS OWN stretch of the genome when the file has a fastahack index beside
+ * it (<fasta>.fai, not older than the file) that describes it (regular lines): the fragment split needs the record lengths alone
+ * (lib/genome/Genome.cpp:753-782), so the shard reads, uploads, encodes and indexes just the byte ranges its fragments cover
+ * (scs_stats.staged_bases).  The split depends on the seed: after scs_set_seed load the genome again (scs_create_frags says so).
+ * Without a usable index the whole file is staged, which also writes the index. */
 /* Same, from memory: names[i] as they appear after '>' ; seqs[i] = lens[i] ASCII bases. */
 int         scs_upload_genome(scs_ctx* ctx, int n_records, const char* const* names,
                               const char* const* seqs, const uint64_t* lens);

@@ -32,7 +32,7 @@ class _Stats(C.Structure):
     _fields_ = [("records", C.c_uint64), ("genome_bases", C.c_uint64), ("fragments", C.c_uint64),
                 ("semi_amplicons", C.c_uint64), ("full_amplicons", C.c_uint64), ("primers_left", C.c_uint64),
                 ("reads_requested", C.c_uint64), ("pairs_written", C.c_uint64), ("reads_written", C.c_uint64),
-                ("fastq_bytes", C.c_uint64 * 2), ("algorithmic_bytes", C.c_uint64), ("t_stage", C.c_double * 8), ("sink_bytes", C.c_uint64 * 2)]
+                ("fastq_bytes", C.c_uint64 * 2), ("algorithmic_bytes", C.c_uint64), ("t_stage", C.c_double * 8), ("sink_bytes", C.c_uint64 * 2), ("staged_bases", C.c_uint64)]
 
 
 _SINK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t)

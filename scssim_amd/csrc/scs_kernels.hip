@@ -256,6 +256,15 @@ void launch_sv_build(hipStream_t s, const uint8_t* ref, const uint8_t* lit, cons
     if (total && np) hipLaunchKernelGGL(k_sv_build, dim3((unsigned)((total + 16 * 256 - 1) / (16 * 256))), dim3(256), 0, s, ref, lit, pieces, np, out, total);
     if (nsub) hipLaunchKernelGGL(k_sv_subst, dim3((nsub + 255) / 256), dim3(256), 0, s, subs, nsub, out);
 }
+// A piece of a REGULAR FASTA record (every line but the last holds lb bases in lw bytes: what the .fai states) without its line
+// ends: base j of the piece, which starts in column col0 of its line, lies at raw offset j + ((col0 + j) / lb) * (lw - lb).
+__global__ void __launch_bounds__(256) k_fa_gather_regular(const uint8_t* __restrict__ raw, uint8_t* __restrict__ dst, uint64_t n, uint32_t col0, uint32_t lb, uint32_t lw) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) dst[j] = raw[j + ((uint64_t)col0 + j) / lb * (uint64_t)(lw - lb)];
+}
+void launch_fa_gather_regular(hipStream_t s, const uint8_t* raw, uint8_t* dst, uint64_t n, uint32_t col0, uint32_t lb, uint32_t lw) {
+    if (n) hipLaunchKernelGGL(k_fa_gather_regular, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, raw, dst, n, col0, lb, lw);
+}
 void launch_encode_bases(hipStream_t s, uint8_t* g, uint64_t n) {
     if (n) hipLaunchKernelGGL(k_encode_bases, dim3((unsigned)((n + 16 * 256 - 1) / (16 * 256))), dim3(256), 0, s, g, n);
 }

@@ -166,6 +166,7 @@ struct scs_ctx {
     std::vector<FastaRecord> recs; bool have_genome = false; DevBuf genome, genome2; std::vector<uint64_t> rec_off, rec_len; uint64_t genome_bases = 0;   // recs: names only once staged
     std::vector<uint64_t> f_goff; std::vector<uint32_t> f_len; std::vector<int8_t> f_strand; std::vector<uint32_t> f_primers;
     uint64_t f_gidx_base = 0; bool have_frags = false;
+    uint64_t slice_base = 0, slice_len = 0; bool sliced = false;   // sharded job staged from a FASTA: only the bases of this shard's fragments are resident (genome coordinate slice_base ..)
     DevBuf df_blob, df_primers, df_hasn; size_t df_len_off = 0, df_strand_off = 0;           // fragments: offsets | lengths | strands in one block
     uint8_t* h_frag = nullptr; size_t h_frag_cap = 0; bool frag_copy_pending = false;   // its pinned staging copy
     // amplicons
@@ -343,6 +344,7 @@ void do_load_profile(scs_ctx* c, const char* path) {
 // ---------------------------------------------------------------- genome
 // d_ascii: the records' ASCII bases already concatenated in device memory (scs_upload_genome_device), or null: host
 // records in c->recs[i].code.  The host copies are dropped once the genome is resident (6 GB at whole-genome size).
+void index_genome(scs_ctx* c, uint64_t tot);
 void stage_genome(scs_ctx* c, const void* d_ascii = nullptr, const uint64_t* d_lens = nullptr) {
     c->rec_off.clear(); c->rec_len.clear(); uint64_t tot = 0;
     for (size_t i = 0; i < c->recs.size(); ++i) { const uint64_t l = d_ascii ? d_lens[i] : c->recs[i].code.size(); c->rec_off.push_back(tot); c->rec_len.push_back(l); tot += l; }
@@ -352,6 +354,15 @@ void stage_genome(scs_ctx* c, const void* d_ascii = nullptr, const uint64_t* d_l
     else for (size_t i = 0; i < c->recs.size(); ++i)
         if (!c->recs[i].code.empty())
             HIP_OK(hipMemcpyAsync((uint8_t*)c->genome.p + c->rec_off[i], c->recs[i].code.data(), c->recs[i].code.size(), hipMemcpyHostToDevice, c->stream));
+    c->sliced = false; c->slice_base = 0; c->slice_len = tot;
+    index_genome(c, tot);
+    HIP_OK(hipStreamSynchronize(c->stream));
+    for (auto& r : c->recs) std::vector<uint8_t>().swap(r.code);
+    c->have_genome = true; c->have_frags = false; c->amplified = false; c->allocated = false;
+    c->st.records = c->recs.size(); c->st.genome_bases = tot; c->st.staged_bases = tot;
+}
+// the resident bases (tot of them, raw ASCII in c->genome) -> base codes, bit index, two-bit copy
+void index_genome(scs_ctx* c, uint64_t tot) {
     launch_encode_bases(c->stream, c->genome.as<uint8_t>(), tot);                 // raw ASCII -> base codes on the device
     {   // bit index: GC count / any-N of any window in O(1)
         hipStream_t s = c->stream; const uint64_t nw = (tot + 63) / 64;
@@ -361,10 +372,6 @@ void stage_genome(scs_ctx* c, const void* d_ascii = nullptr, const uint64_t* d_l
         launch_genome_bits(s, c->genome.as<uint8_t>(), tot, nw, c->gx_gc_bits.as<unsigned long long>(), c->gx_n_bits.as<unsigned long long>(), c->gx_gc_cnt.as<uint32_t>(),
                            c->gx_n_cnt.as<uint32_t>(), c->gx_gc_pref.as<uint64_t>(), c->gx_n_pref.as<uint64_t>(), c->scan_tmp.p, c->scan_tmp.cap, c->genome2.as<uint32_t>() + 16);
     }
-    HIP_OK(hipStreamSynchronize(c->stream));
-    for (auto& r : c->recs) std::vector<uint8_t>().swap(r.code);
-    c->have_genome = true; c->have_frags = false; c->amplified = false; c->allocated = false;
-    c->st.records = c->recs.size(); c->st.genome_bases = tot;
 }
 
 // Genome::loadRefSeq for whole-genome inputs: the FASTA is mmap'ed and its RAW bytes go to the device in
@@ -433,10 +440,10 @@ void stage_fasta_on_device(scs_ctx* c, const std::string& path_in) {
 }
 
 // ---------------------------------------------------------------- a1: Genome::splitToFrags (Genome.cpp:753-782)
-void do_create_frags(scs_ctx* c) {
-    if (!c->have_genome) throw ScsError(SCS_EINVAL, "scs_create_frags: no genome loaded");
+// the whole job's fragment list (genome coordinates) and this shard's contiguous range [lo, hi) of it, balanced by bases
+void split_frags(scs_ctx* c, std::vector<uint64_t>& goff, std::vector<uint32_t>& len, std::vector<int8_t>& strand, size_t& lo, size_t& hi) {
     const scs_config& cf = c->cfg;
-    std::vector<uint64_t> goff; std::vector<uint32_t> len; std::vector<int8_t> strand;
+    goff.clear(); len.clear(); strand.clear();
     for (size_t r = 0; r < c->recs.size(); ++r) {
         const int64_t chr_len = (int64_t)c->rec_len[r]; int64_t pos = 1; uint32_t k = 0;
         while (pos <= chr_len) {
@@ -450,13 +457,104 @@ void do_create_frags(scs_ctx* c) {
             for (int rep = 0; rep < 2; ++rep) { goff.push_back(c->rec_off[r] + (uint64_t)(pos - 1)); len.push_back((uint32_t)(chr_len - pos + 1)); strand.push_back(1); }
     }
     // fragment-lineage sharding: contiguous fragment ranges balanced by bases
-    size_t lo = 0, hi = len.size();
+    lo = 0; hi = len.size();
     if (cf.shard_count > 1) {
         uint64_t tot = 0; for (auto l : len) tot += l;
         std::vector<size_t> cut(cf.shard_count + 1, len.size()); cut[0] = 0;
         uint64_t acc = 0; int sh = 1;
         for (size_t i = 0; i < len.size() && sh < cf.shard_count; ++i) { acc += len[i]; while (sh < cf.shard_count && acc * cf.shard_count >= tot * (uint64_t)sh) cut[sh++] = i + 1; }
         lo = cut[cf.shard_rank]; hi = cut[cf.shard_rank + 1];
+    }
+}
+
+// Sharded job, regular FASTA with an index beside it ("genome slices needed per GPU = its own fragments only";
+// lib/genome/Genome.cpp:753-782 splits by record length alone): the record lengths come from the .fai, the fragment split from
+// them, and only the byte ranges of THIS shard's fragments are read, uploaded, stripped of their line ends (the .fai's line
+// geometry), encoded and indexed.  Returns false when the file has no usable index (absent, older than the file, or lines
+// that are not what it states: a ragged file) -- the caller then stages the whole file, which also writes the index.
+bool stage_fasta_slice(scs_ctx* c, const std::string& path) {
+    struct stat sf, si;
+    const std::string fai = path + ".fai";
+    if (stat(path.c_str(), &sf) != 0 || stat(fai.c_str(), &si) != 0 || si.st_mtime < sf.st_mtime) return false;
+    struct Ent { std::string name; uint64_t len, off; uint32_t lb, lw; };
+    std::vector<Ent> ents;
+    {   FILE* f = fopen(fai.c_str(), "r"); if (!f) return false;
+        char line[4096];
+        while (fgets(line, sizeof line, f)) {
+            char nm[2048]; unsigned long long l, o; unsigned lb, lw;
+            if (sscanf(line, "%2047s %llu %llu %u %u", nm, &l, &o, &lb, &lw) != 5) { fclose(f); return false; }
+            ents.push_back(Ent{fasta_index_name(nm), l, o, lb, lw});
+        }
+        fclose(f); }
+    if (ents.empty()) return false;
+    const int fd = open(path.c_str(), O_RDONLY);
+    if (fd < 0) return false;
+    struct Close { int fd; ~Close() { close(fd); } } closer{fd};
+    const uint64_t size = (uint64_t)sf.st_size;
+    auto byte_of = [](const Ent& e, uint64_t b) { return e.off + (e.lb ? b / e.lb * e.lw + b % e.lb : 0); };   // file offset of base b of the record
+    // the index must describe THIS file: every record's header and last line end where the geometry puts them
+    for (size_t r = 0; r < ents.size(); ++r) {
+        const Ent& e = ents[r];
+        if (e.len && (e.lb == 0 || e.lw <= e.lb || e.lw - e.lb > 2)) return false;
+        const uint64_t end = e.len ? byte_of(e, e.len - 1) + 1 : e.off;            // one past the record's last base
+        char b[4] = {0, 0, 0, 0};
+        if (e.off == 0 || e.off > size || end > size) return false;
+        if (pread(fd, b, 1, (off_t)(e.off - 1)) != 1 || b[0] != '\n') return false;   // the header line ends right before the first base
+        if (end < size) {                                                           // then a line end, then the next header or the end of the file
+            const ssize_t got = pread(fd, b, 3, (off_t)end);
+            int k = 0; if (got > k && b[k] == '\r') ++k; if (!(got > k && b[k] == '\n')) return false; ++k;
+            const uint64_t next = end + (uint64_t)k;
+            if (r + 1 < ents.size()) { if (next >= size || (got > k ? b[k] : 0) != '>') return false; }
+            else if (next != size) return false;
+        } else if (r + 1 < ents.size()) return false;
+    }
+    c->recs.assign(ents.size(), FastaRecord()); c->rec_off.clear(); c->rec_len.clear(); uint64_t tot = 0;
+    for (size_t r = 0; r < ents.size(); ++r) { c->recs[r].name = ents[r].name; c->rec_off.push_back(tot); c->rec_len.push_back(ents[r].len); tot += ents[r].len; }
+    c->genome_bases = tot;
+    std::vector<uint64_t> goff; std::vector<uint32_t> len; std::vector<int8_t> strand; size_t lo, hi;
+    split_frags(c, goff, len, strand, lo, hi);
+    uint64_t g_lo = 0, g_hi = 0;
+    if (hi > lo) { g_lo = goff[lo]; for (size_t i = lo; i < hi; ++i) g_hi = std::max(g_hi, goff[i] + len[i]); }
+    hipStream_t s = c->stream;
+    const uint64_t n_slice = g_hi - g_lo;
+    if (n_slice == 0) return false;                                                 // (more shards than fragments: nothing of its own to stage)
+    c->genome.reserve(std::max<uint64_t>(n_slice, 16), s);
+    // record by record: the bytes of [a, b) -> pinned -> device, line ends dropped by the gather
+    const size_t CH = 64u << 20; DevBuf d_raw; char* h_raw = nullptr;
+    struct Rel { DevBuf* b; char** h; ~Rel() { b->release(); if (*h) (void)hipHostFree(*h); } } rel{&d_raw, &h_raw};
+    HIP_OK(hipHostMalloc((void**)&h_raw, CH, hipHostMallocDefault)); d_raw.reserve(CH + 16, s);
+    for (size_t r = 0; r < ents.size() && n_slice; ++r) {
+        const uint64_t r0 = c->rec_off[r], r1 = r0 + ents[r].len;
+        uint64_t a = std::max(g_lo, r0), b = std::min(g_hi, r1);
+        const uint64_t per = (uint64_t)(CH / ents[r].lw) * ents[r].lb;              // bases whose lines fit the buffer (two lines of slack: a piece starts and ends inside a line)
+        while (a < b) {
+            const uint64_t take = std::min<uint64_t>(b - a, per > 2ull * ents[r].lb ? per - 2ull * ents[r].lb : 1), ba = a - r0;
+            const uint64_t f0 = byte_of(ents[r], ba), f1 = byte_of(ents[r], ba + take - 1) + 1;
+            HIP_OK(hipStreamSynchronize(s));                                         // the pinned buffer's last upload is done
+            if (pread(fd, h_raw, (size_t)(f1 - f0), (off_t)f0) != (ssize_t)(f1 - f0)) throw ScsError(SCS_EIO, "could not read " + path);
+            HIP_OK(hipMemcpyAsync(d_raw.p, h_raw, (size_t)(f1 - f0), hipMemcpyHostToDevice, s));
+            launch_fa_gather_regular(s, d_raw.as<uint8_t>(), c->genome.as<uint8_t>() + (a - g_lo), take, (uint32_t)(ba % ents[r].lb), ents[r].lb, ents[r].lw);
+            a += take;
+        }
+    }
+    index_genome(c, n_slice);
+    HIP_OK(hipStreamSynchronize(s));
+    { const hipError_t le = take_launch_error(); if (le != hipSuccess) throw ScsError(SCS_EDEVICE, std::string("FASTA slice staging: ") + hipGetErrorString(le)); }
+    c->sliced = true; c->slice_base = g_lo; c->slice_len = n_slice;
+    c->have_genome = true; c->have_frags = false; c->amplified = false; c->allocated = false;
+    c->st.records = c->recs.size(); c->st.genome_bases = tot; c->st.staged_bases = n_slice;
+    return true;
+}
+
+void do_create_frags(scs_ctx* c) {
+    if (!c->have_genome) throw ScsError(SCS_EINVAL, "scs_create_frags: no genome loaded");
+    std::vector<uint64_t> goff; std::vector<uint32_t> len; std::vector<int8_t> strand; size_t lo, hi;
+    split_frags(c, goff, len, strand, lo, hi);
+    if (c->sliced) {   // only this shard's bases are resident: the split (a function of the seed) must still ask for them
+        for (size_t i = lo; i < hi; ++i)
+            if (goff[i] < c->slice_base || goff[i] + len[i] > c->slice_base + c->slice_len)
+                throw ScsError(SCS_EINVAL, "the genome was staged for another seed's fragment split (sharded staging): load it again after scs_set_seed");
+        for (size_t i = lo; i < hi; ++i) goff[i] -= c->slice_base;
     }
     c->nf_all = len.size(); c->frag_len_all = 0; for (auto l : len) c->frag_len_all += l;
     c->f_goff.assign(goff.begin() + lo, goff.begin() + hi); c->f_len.assign(len.begin() + lo, len.begin() + hi);
@@ -1192,6 +1290,9 @@ int scs_load_genome_fasta(scs_ctx* c, const char* path) {
     return guarded(c, [&] {
         if (!path) throw ScsError(SCS_EINVAL, "null path");
         if (getenv("SCS_HOST_FASTA")) { load_fasta(path, c->recs, true); stage_genome(c); }   // the host parser (what scs_fasta_probe checks); debugging aid
+        else if (c->cfg.shard_count > 1 && !getenv("SCS_STAGE_WHOLE") && stage_fasta_slice(c, fasta_plain_path(path))) {
+            if (c->cfg.verbose) fprintf(stderr, "(shard %d of %d: %llu of %llu bases staged)\n", c->cfg.shard_rank, c->cfg.shard_count, (unsigned long long)c->slice_len, (unsigned long long)c->genome_bases);
+        }
         else stage_fasta_on_device(c, path);
         if (c->cfg.verbose) fprintf(stderr, "\nReference sequence was loaded from file %s\n", path);
     });

@@ -24,6 +24,7 @@ def main():
     g.yield_reads_files(prefix, writers)            # this rank's shard + index: <prefix>.r<rank>_1.fq / _2.fq / .idx (or its parts)
     st = g.stats()
     print("rank %d: %d fragments, %d fulls, %d pairs, collectives %s" % (dist.get_rank(), st["fragments"], st["full_amplicons"], st["pairs_written"], coll.calls))
+    print("STAGED %d %d %d" % (dist.get_rank(), st["staged_bases"], st["genome_bases"]))
     dist.barrier()
     dist.destroy_process_group()
 

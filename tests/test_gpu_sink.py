@@ -277,3 +277,58 @@ g.yield_reads_files(%r, 2, 4)
     assert len(seen) >= 4, "the watcher saw too few parts appear while the job ran"
     for p, size in seen.items():
         assert size == os.path.getsize(files[0][p]) and size > 0, "part %d changed after part %d existed" % (p, p + 2)
+
+
+@pytest.mark.parametrize("layout", ["regular", "crlf_and_short_last_record"])
+def test_sharded_ranks_stage_only_their_own_stretch_of_the_genome(layout, oracle_bin, models, tmp_path):
+    """A shard of a sharded job reads, uploads and indexes only the stretch of the genome its own fragments cover when the FASTA
+    has a usable .fai ("genome slices needed per GPU = its own fragments only"): three ranks on a 3-record genome
+    stage about a third each (scs_stats.staged_bases) and the merged output still equals the whole job's; without the index (or
+    with SCS_STAGE_WHOLE) every rank stages everything, same output."""
+    import shutil
+    import socket
+    fa0 = str(tmp_path / "simu0.fa")
+    subprocess.check_call(["python3", os.path.join(ROOT, "tools", "make_genome.py"), "--lengths", "900000,500000,313131", "--seed", "5", "--n-block", "7000", "--lower-frac", "0.03", "--simu-out", fa0])
+    fa = str(tmp_path / "simu.fa")
+    if layout == "regular":
+        shutil.copyfile(fa0, fa)
+    else:                                                               # CRLF line ends, 70 columns, no newline at the end of the file
+        recs = open(fa0).read().split(">")[1:]
+        with open(fa, "wb") as f:
+            for i, r in enumerate(recs):
+                name, seq = r.split("\n", 1)
+                seq = seq.replace("\n", "")
+                body = "\r\n".join(seq[k:k + 70] for k in range(0, len(seq), 70))
+                f.write((">%s\r\n%s" % (name, body)).encode() + (b"" if i == len(recs) - 1 else b"\r\n"))
+    prof = models["Illumina_HiSeq2500"]
+    whole = str(tmp_path / "whole")
+    _oracle(oracle_bin, fa, prof, whole, ["-c", "3"], 91)
+    total = 2 * (900000 + 500000 + 313131)
+
+    def sharded(tag, env_extra):
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = str(s.getsockname()[1]); s.close()
+        procs = []
+        for r in range(3):
+            env = dict(os.environ, RANK=str(r), WORLD_SIZE="3", MASTER_ADDR="127.0.0.1", MASTER_PORT=port, LOCAL_RANK="0", **env_extra)
+            procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_gpu_worker.py"), fa, prof, str(tmp_path / tag), "3", "PE", "91", "device"],
+                                          env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+        outs = [p.communicate(timeout=600)[0] for p in procs]
+        assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+        staged = {}
+        for o in outs:
+            for l in o.splitlines():
+                if l.startswith("STAGED"):
+                    _, r, a, b = l.split(); staged[int(r)] = (int(a), int(b))
+        scssim_amd.merge_fastq_shards(str(tmp_path / tag), 3, paired=True)
+        for suffix in ("_1.fq", "_2.fq"):
+            assert open(str(tmp_path / tag) + suffix, "rb").read() == open(whole + suffix, "rb").read(), (tag, suffix)
+        return staged
+    if os.path.exists(fa + ".fai"):
+        os.remove(fa + ".fai")
+    st = sharded("noidx", {})                                           # no index yet: whole-file staging (which writes it)
+    assert all(v == (total, total) for v in st.values()) and os.path.exists(fa + ".fai")
+    st = sharded("sliced", {})
+    assert all(b == total for _, b in st.values())
+    assert sum(a for a, _ in st.values()) <= total + 3 * 100001 and max(a for a, _ in st.values()) < 0.5 * total, st
+    st = sharded("forced_whole", {"SCS_STAGE_WHOLE": "1"})
+    assert all(v == (total, total) for v in st.values())

@@ -9,7 +9,8 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 1 --warmup 1 --no-extra-legs --no-cpu-baseline $*"
+# --hbm-only: the generation_hbm leg as the timed region (8 M pairs per k_reads launch: where bench.py takes the roofline of the dominant kernel)
+ARGS="--steps 1 --warmup 1 --hbm-only --no-extra-legs --no-cpu-baseline $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python3 $ROOT/bench.py $ARGS > $OUT/bench_trace.log 2>&1
 echo "trace done"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o f -- python3 $ROOT/bench.py $ARGS > $OUT/bench_fetch.log 2>&1
