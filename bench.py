@@ -405,7 +405,7 @@ def main():
     ap.add_argument("--coverage", type=float, default=30.0)
     ap.add_argument("--writers", type=int, default=0, help="part files per mate and writer threads of the FASTQ sink (default: host cores - 4, at most 12)")
     ap.add_argument("--generations", type=int, default=6, help="the part files are made in this many generations (writers x generations parts per mate): a generation's files are final when the next starts")
-    ap.add_argument("--cleaners", type=int, default=4, help="background threads that unlink finished part files")
+    ap.add_argument("--cleaners", type=int, default=6, help="background threads that unlink finished part files")
     ap.add_argument("--out-dir", default="", help="where the timed steps write their FASTQ part files (default: a fresh directory on /dev/shm)")
     ap.add_argument("--hbm-only", action="store_true", help="time the steps with a NULL sink (text generated into HBM buffers, no files): the generation_hbm leg as the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
