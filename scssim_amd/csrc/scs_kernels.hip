@@ -1310,11 +1310,14 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
         // before its wave arrives at the next group's barrier, as the refill's slot reuse assumes.
         uint32_t aT0 = 0, aT1 = 0, aT2 = 0, aE = 0, aX1 = 0, aX2 = 0, aC2 = 0; const LdsU8* aQ = ring8;   // start -> finish_a
         uint32_t bK = 0, bC2 = 0, bX2 = 0, bSym = 0; bool bUgly = false;                                   // finish_a -> finish_b
-        auto start = [&](auto U, int t0) __attribute__((always_inline)) {
+        // (FIRST: t0 == 0, as a compile-time constant -- a run-time test would put branches between the positions, and a branch around
+        // the stores makes the compiler's s_waitcnt before the next ring commit cover them on every path: vmcnt(1) instead of vmcnt(5))
+        auto start = [&](auto U, auto FIRST, int t0) __attribute__((always_inline)) {
             constexpr int u = decltype(U)::value;
+            constexpr bool first = decltype(FIRST)::value;
             uint32_t c2;
             if constexpr (D1) {
-                if (u == 0) { wreg = t0 == 0 ? win32[0] : wnext; wnext = win32[(t0 >> 4) + 1]; if (!mine) { wreg = 0; wnext = 0; } }   // 16 bases + the 16 behind them
+                if (u == 0) { wreg = first ? win32[0] : wnext; wnext = win32[(t0 >> 4) + 1]; if (!mine) { wreg = 0; wnext = 0; } }   // 16 bases + the 16 behind them
                 const bool after = (uint32_t)(t0 + u) >= del_pos;                    // from the deleted base on: the next window base
                 if (u < 15) c2 = __builtin_amdgcn_ubfe(wreg, 2u * u + (after ? 2u : 0u), 2u);
                 else c2 = after ? (wnext & 3u) : (wreg >> 30);
@@ -1325,7 +1328,7 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
             uint32_t x1, x2; xb.next2(x1, x2);                                       // one step of stream B per position
             const LdsU8* bin8 = ring8 + (u & (SLOTS - 1)) * sizeof(Bin);
             const LdsU8* st8 = bin8 + 4 * QROW * 16 + ((c0 << 4) | (c1 << 2) | c2) * 12u;
-            if (u < 2) { const LdsU8* h8 = head8 + (u == 0 ? c2 : 4u + c1 * 4u + c2) * 12u; st8 = t0 == 0 ? h8 : st8; }   // the read's first two bases: 1-mer / 2-mer rows
+            if constexpr (u < 2 && first) st8 = head8 + (u == 0 ? c2 : 4u + c1 * 4u + c2) * 12u;   // the read's first two bases: 1-mer / 2-mer rows
             const LdsU32* st = (const LdsU32*)st8;
             const LdsU32* qrow = (const LdsU32*)(bin8 + c2 * (uint32_t)(QROW * 16));   // the diagonal row (c2, c2) as an alias row
             aT0 = st[0]; aT1 = st[1]; aT2 = st[2]; aE = qrow[x2 >> (32u - Geo::ABITS)];
@@ -1359,21 +1362,22 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
         };
         // MODE 2: all 16 positions exist, t0 >= 48: the previous block (m >= 2) leaves as straight-line stores; 1: all 16 exist, t0 < 48
         // (blocks 0 and 1, stored at t0 = 16 and 32, may hold a stream's first, partial sector: branching stores); 0: the read's last block
-        auto steps = [&](auto MODE, int t0) __attribute__((always_inline)) {
+        auto steps = [&](auto MODE, auto FIRST, int t0) __attribute__((always_inline)) {
             unroll_steps([&](auto U) __attribute__((always_inline)) {
                 constexpr int u = decltype(U)::value;
                 constexpr int mode = decltype(MODE)::value;
+                constexpr bool first = decltype(FIRST)::value;                       // t0 == 0
                 const int t = t0 + u;
                 if (mode == 0 && t >= NP) return;
-                if (u > 0 || t0 > 0) finish_a();
-                if ((u & (GROUP - 1)) == 0 && (u > 0 || t0 > 0)) { commit(t); __syncthreads(); prefetch(t + GROUP); }
-                start(U, t0);
-                if (u > 0 || t0 > 0) finish_b(std::integral_constant<int, (u + 15) & 15>{}, t - 1, false);
+                if constexpr (u > 0 || !first) finish_a();
+                if constexpr ((u & (GROUP - 1)) == 0 && (u > 0 || !first)) { commit(t); __syncthreads(); prefetch(t + GROUP); }
+                start(U, FIRST, t0);
+                if constexpr (u > 0 || !first) finish_b(std::integral_constant<int, (u + 15) & 15>{}, t - 1, false);
                 // The previous 16 characters leave HERE, right behind the ring's loads.  On this hardware loads and stores complete
                 // out of order with each other, so a wait for a load (the next commit) is a wait for EVERY outstanding store too
                 // (s_waitcnt vmcnt(0)); placed here that wait comes a whole group of positions after the stores, when their round
                 // trip to L2 is over.  (The raw words R[] of the stored block are not overwritten before u = 4.)
-                if (u == 0 && t0 > 0) {
+                if constexpr (u == 0 && !first) {
                     if constexpr (mode == 2) {
                         bo_b.block_flat(wg_out, sec1, a1, (uint32_t)(t0 >> 4) - 1u, spare, mine);
                         bo_q.block_flat(wg_out, sec2, a2, (uint32_t)(t0 >> 4) - 1u, spare, mine);
@@ -1385,9 +1389,10 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
             }, std::make_integer_sequence<int, 16>{});
         };
         int t0 = 0;
-        for (; t0 < 48 && t0 + 16 < NP; t0 += 16) steps(std::integral_constant<int, 1>{}, t0);
-        for (; t0 + 16 < NP; t0 += 16) steps(std::integral_constant<int, 2>{}, t0);
-        steps(std::integral_constant<int, 0>{}, t0);
+        if (16 < NP) { steps(std::integral_constant<int, 1>{}, std::true_type{}, 0); t0 = 16; }
+        for (; t0 < 48 && t0 + 16 < NP; t0 += 16) steps(std::integral_constant<int, 1>{}, std::false_type{}, t0);
+        for (; t0 + 16 < NP; t0 += 16) steps(std::integral_constant<int, 2>{}, std::false_type{}, t0);
+        if (t0 == 0) steps(std::integral_constant<int, 0>{}, std::true_type{}, 0); else steps(std::integral_constant<int, 0>{}, std::false_type{}, t0);
         finish_a();                                                                 // drain: the read's last position
         unroll_steps([&](auto U) __attribute__((always_inline)) { if (decltype(U)::value == ((NP - 1) & 15)) finish_b(U, NP - 1, true); }, std::make_integer_sequence<int, 16>{});
         redo = mine && nbad != npend;
