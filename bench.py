@@ -501,7 +501,7 @@ def main():
     os.makedirs(out_dir, exist_ok=True)
     generations = a.generations
     cleaner = Cleaner(threads=max(1, a.cleaners))
-    GATE_BYTES = 40 << 30                                            # a step's sink starts when at most this much of the older steps' text is still on tmpfs
+    GATE_BYTES = (40 << 30) // max(1, world)                                            # a step's sink starts when at most this much of the older steps' text is still on tmpfs
 
     def acc(ktimes, kt, names_):
         for k in names_:
@@ -588,7 +588,7 @@ def main():
                        "output": ("FASTQ text generated batch by batch into HBM buffers (NULL sink): --hbm-only" if a.hbm_only else
                                   "plain FASTQ files on tmpfs (%s): %d part files per mate%s, each a contiguous range of the records (scs_yield_reads_files_ex: %d writer threads x %d generations; "
                                   "`cat` of the parts in order is the reference's <prefix>_1.fq / _2.fq).  Every step writes fresh files; the memory cgroup cannot hold two steps' text, so %d background "
-                                  "threads unlink every part once it is final (a generation's parts are final when the next generation starts) and a step's sink starts when <= 40 GB of older text "
+                                  "threads unlink every part once it is final (a generation's parts are final when the next generation starts) and a step's sink starts when <= 40 GB of older text (over all ranks) "
                                   "are left (`wait_for_cleanup` in stages_s_per_step): all of it inside the timed region"
                                   % (out_dir, writers * generations, " and rank" if world > 1 else "", writers, generations, max(1, a.cleaners))),
                        "sink_GBps": None if a.hbm_only else R["fq_bytes"] / max(1e-9, R["stage"]["reads"] * a.steps) / 1e9,
