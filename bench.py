@@ -12,17 +12,24 @@ PE150 = the shipped HiSeq2500 profile with its bin axis resampled 125 -> 150 (to
 takes the read length from the profile only and ships no 150 bp model); 30x, -p 100000 -r 1e-9 -s 260.
 
 One step = one complete job with a fresh seed: fragment split, 1+5 MALBAC cycles, GC-biased read allocation, fragment
-sampling, indel / substitution / quality injection, FASTQ text -- generated batch by batch into HBM buffers
-(scs_yield_reads with a NULL sink: generate and count).  `value` = pairs / that time (inputs resident in HBM).
+sampling, indel / substitution / quality injection, FASTQ text -- AND THE TEXT IN FILES: every timed step writes its 197 GB of
+plain FASTQ through the library's file sink (scs_yield_reads_files_ex: D2H on a copy stream, `--writers` threads each appending
+to its own part file per mate, `--generations` generations) into fresh files on tmpfs.  `value` = pairs / that time: SURVEY 8(d)'s
+"records in _1.fq / wall".  The memory cgroup cannot hold two steps' text, so background threads unlink every part once it is
+final and a step's sink starts when <= 40 GB of older text are left -- inside the timed region.
 Beside it, at N = 1 and outside the timed region:
-  sink_inclusive : one more step through scs_yield_reads with a real sink -- D2H into pinned buffers + write(2) into two
-                   tmpfs files (rewound every few GB so the page cache stays bounded) -- the window the reference times
-                   (src/scssim.cpp:59-73 includes SeqWriter);
+  generation_hbm : 5 steps with a NULL sink (text generated batch by batch into HBM buffers and counted): what the kernels do
+                   when nothing crosses PCIe; the dominant kernel's roofline is taken here (8 M pairs per launch);
+  d2h_only       : one step through a sink that only counts: what PCIe allows;
+  bgzf           : 2 steps with the text made into BGZF blocks ON THE GPU before it crosses PCIe (.fq.gz parts; an extension);
+  sweep          : configs[1] (1 Mb) and configs[2]'s size (63 Mb) with the same model and options;
   cli_wall       : the `scssim genreads` binary end to end (FASTA parse, profile, job, files) at chr20 size (configs[2]);
   cpu_baseline   : the reference itself (oracle/_ref/scssim_ref, compiled from /root/reference by oracle/Makefile) with
-                   -t <cores> on a bounded sample of the same genome; the oracle port beside it.
+                   -t <cores> and -t 1 on bounded samples of the same genome; the oracle port beside it.
+--hbm-only times the steps with a NULL sink instead (round 2's headline; what tools/profile_bench.sh profiles).
 N > 1 (driver: torch.distributed.run, one rank per GPU): the SAME job sharded N ways by fragment lineage (strong
-scaling); per-pass primer-stock all-reduce and the allocation partials over RCCL; every rank keeps its own FASTQ shard.
+scaling); per-pass primer-stock all-reduce and the allocation partials over RCCL; every rank writes its own FASTQ shard
+(its own part files, its own PCIe link and writer threads).
 """
 import argparse
 import glob

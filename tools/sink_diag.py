@@ -18,14 +18,15 @@ def nop(_u, p1, n1, p2, n2):
     return 0
 t = time.perf_counter(); g.yield_reads_sink(nop); t1 = time.perf_counter() - t
 print("NULL sink %.2f s ; no-op sink (D2H only) %.2f s for %.1f GB -> %.1f GB/s" % (t0, t1, nb[0] / 1e9, nb[0] / 1e9 / t1), flush=True)
-for thr in (1, 4, 8, 16):
-    os.environ["SCS_SINK_RECYCLE_MB"] = "4096"
-    t = time.perf_counter(); g.yield_reads_files("/dev/shm/sinkdiag", thr); t2 = time.perf_counter() - t
-    print("file sink /dev/shm, %d threads: %.2f s -> %.1f GB/s" % (thr, t2, nb[0] / 1e9 / t2), flush=True)
-os.environ["SCS_SINK_RECYCLE_MB"] = "1000000"
-t = time.perf_counter(); g.yield_reads_files("/dev/shm/sinkdiag", 8); t2 = time.perf_counter() - t
-print("file sink /dev/shm, 8 threads, no recycle: %.2f s -> %.1f GB/s" % (t2, nb[0] / 1e9 / t2), flush=True)
-for f in ("/dev/shm/sinkdiag_1.fq", "/dev/shm/sinkdiag_2.fq"):
+import glob
+for thr, gen in ((1, 1), (4, 1), (8, 1), (12, 1), (12, 4), (16, 1)):
+    t = time.perf_counter(); g.yield_reads_files("/dev/shm/sinkdiag", thr, gen); t2 = time.perf_counter() - t
+    print("file sink /dev/shm, %d writers x %d generations: %.2f s -> %.1f GB/s" % (thr, gen, t2, nb[0] / 1e9 / t2), flush=True)
+    for f in glob.glob("/dev/shm/sinkdiag*"):
+        os.remove(f)
+t = time.perf_counter(); g.yield_reads_files("/dev/shm/sinkdiag", 12, 1, True); t2 = time.perf_counter() - t
+print("file sink /dev/shm, BGZF, 12 writers: %.2f s -> %.1f GB/s of text, %.2fx" % (t2, nb[0] / 1e9 / t2, sum(g.stats()["fastq_bytes"]) / sum(g.stats()["sink_bytes"])), flush=True)
+for f in glob.glob("/dev/shm/sinkdiag*"):
     os.remove(f)
 # raw tmpfs write bandwidth
 import numpy as np
