@@ -6,7 +6,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def lib_path():
-    return os.path.join(HERE, "libscssim_hip.so")
+    # SCSSIM_HIP_LIB: another build of the same library (A/B measurements of a kernel change on one box: tools/ab_kernels.sh)
+    return os.environ.get("SCSSIM_HIP_LIB") or os.path.join(HERE, "libscssim_hip.so")
 
 
 def build(verbose=False):
