@@ -977,7 +977,7 @@ struct BlockOut {
 // by k_read_lists from k_indels' result.  The event-free reads need none of the event handling -- no lookahead for the
 // next event, exactly one output position per table bin -- and their waves run with every lane busy at every bin.
 template <bool FROM_PAIRS, int QK, int CLS>
-__global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, DevErrPool spool, DevErrPool fpool, const PairRec* __restrict__ pairs,
+__device__ __forceinline__ void reads_body(const uint32_t bid, const uint8_t* __restrict__ g, DevErrPool spool, DevErrPool fpool, const PairRec* __restrict__ pairs,
                                               uint32_t np, int paired, const uint8_t* __restrict__ windows, const uint64_t* __restrict__ uids,
                                               const uint32_t* __restrict__ atts, const uint8_t* __restrict__ is_read1, uint32_t n_explicit,
                                               const DevTables tb, RngKey key, uint32_t slot, uint32_t n_slots_cap, uint32_t force_replay,
@@ -1011,11 +1011,11 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
     const int tid = threadIdx.x, lane = tid & 63, wib = tid >> 6;
 
     // the workgroup's records are contiguous: stores address them as a uniform base (aligned down to a sector) + a 32-bit offset
-    const bool second_file = FROM_PAIRS && paired && (blockIdx.x & 1u);
+    const bool second_file = FROM_PAIRS && paired && (bid & 1u);
     const uint64_t* __restrict__ offs = second_file ? off2 : off1;
     char* __restrict__ outp = second_file ? out2 : out1;
     const uint32_t* __restrict__ wlist = second_file ? list2 : list1;              // CLS != 0: this mate's list
-    const uint32_t nwork = CLS == 0 ? np : (second_file ? nlist2 : nlist1), wq = (paired ? blockIdx.x >> 1 : blockIdx.x) * RB;
+    const uint32_t nwork = CLS == 0 ? np : (second_file ? nlist2 : nlist1), wq = (paired ? bid >> 1 : bid) * RB;
     if (FROM_PAIRS && wq >= nwork) return;                                          // the grid covers the longer of the two mates' lists
     const uint64_t off0 = FROM_PAIRS ? (offs[CLS == 0 ? wq : wlist[wq]] & OFF_MASK) : 0ull;      // lists ascend: the chunk's first record is its lowest
     const uint32_t adj = (uint32_t)(reinterpret_cast<uintptr_t>(outp) + off0) & 31u;
@@ -1025,8 +1025,8 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
     uint32_t r, pi = 0, rd; bool valid; PairRec pr{}; uint64_t uid = 0; uint32_t att = 0;
     uint32_t rec_rel = 0, rec_h = 0;                                               // pair mode: my record's offset from wg_out, length of its name line
     if (FROM_PAIRS) {
-        const uint32_t q = paired ? blockIdx.x >> 1 : blockIdx.x;
-        rd = paired ? (blockIdx.x & 1u) : 0u;
+        const uint32_t q = paired ? bid >> 1 : bid;
+        rd = paired ? (bid & 1u) : 0u;
         // The workgroup's 256 reads are handed to its lanes ORDERED BY THE SECTOR PHASE of their bases (byte address & 31):
         // a lane stores a sector whenever its stream crosses a 32-byte boundary, and lanes of one wave that do so at the
         // same positions share the store instructions.  (Which lane makes which read does not show in the output.)
@@ -1058,7 +1058,7 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
         if (valid) { record_of(pi, pr, rec_rel, rec_h); uid = pr.uid; att = pr.att; }
         __syncthreads();                                                           // s_perm is read before the staging overwrites it
     } else {
-        r = blockIdx.x * RB + tid; valid = r < n_explicit; rd = 0;
+        r = bid * RB + tid; valid = r < n_explicit; rd = 0;
         if (valid) { uid = uids[r]; att = atts[r]; rd = is_read1[r] ? 0u : 1u; }
     }
     if (!FROM_PAIRS && valid && r >= n_slots_cap) { atomicOr(flags, (uint32_t)FLAG_INTERNAL); valid = false; }   // never write outside the slot buffers
@@ -1146,8 +1146,8 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
             });
         }
     } else {
-        const size_t base_off = (size_t)blockIdx.x * RB * (size_t)n;
-        const uint32_t nblk = min((uint32_t)RB, n_explicit - blockIdx.x * RB);
+        const size_t base_off = (size_t)bid * RB * (size_t)n;
+        const uint32_t nblk = min((uint32_t)RB, n_explicit - bid * RB);
         const uint32_t hb = ((uint32_t)n + 1u) >> 1;
         for (uint32_t idx = tid; idx < nblk * hb; idx += RB) {
             const uint32_t row = idx / hb, b = idx % hb;
@@ -1559,6 +1559,44 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
     if (live && !FROM_PAIRS) {
         lens[r] = (uint32_t)n_out;
     }
+}
+
+// (bid: the workgroup's index within ITS class' grid -- blockIdx.x of a launch of one class, or blockIdx.x less the grids of the
+// classes in front of it in the merged launch below)
+template <bool FROM_PAIRS, int QK, int CLS>
+__global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, DevErrPool spool, DevErrPool fpool, const PairRec* __restrict__ pairs,
+                                              uint32_t np, int paired, const uint8_t* __restrict__ windows, const uint64_t* __restrict__ uids,
+                                              const uint32_t* __restrict__ atts, const uint8_t* __restrict__ is_read1, uint32_t n_explicit,
+                                              const DevTables tb, RngKey key, uint32_t slot, uint32_t n_slots_cap, uint32_t force_replay,
+                                              const uint32_t* __restrict__ ev_hdr, const uint4* __restrict__ ev_dat,
+                                              const uint64_t* __restrict__ off1, const uint64_t* __restrict__ off2, char* __restrict__ out1, char* __restrict__ out2,
+                                              uint32_t amp_index_base, char* __restrict__ slot_b, char* __restrict__ slot_q, uint32_t* __restrict__ lens,
+                                              uint32_t* __restrict__ flags, uint64_t cap1, uint64_t cap2,
+                                              const uint32_t* __restrict__ list1, const uint32_t* __restrict__ list2, uint32_t nlist1, uint32_t nlist2) {
+    reads_body<FROM_PAIRS, QK, CLS>(blockIdx.x, g, spool, fpool, pairs, np, paired, windows, uids, atts, is_read1, n_explicit, tb, key, slot, n_slots_cap, force_replay, ev_hdr, ev_dat,
+                                    off1, off2, out1, out2, amp_index_base, slot_b, slot_q, lens, flags, cap1, cap2, list1, list2, nlist1, nlist2);
+}
+// The base pass of a batch as ONE launch: the workgroups of the general class first (the longest), then the one-deletion class,
+// then the event-free class.  The three grids used to go to three streams; whether they really ran side by side depended on
+// which hardware queues the process' streams had been given (the reads stage moved by +-4 % from process to process).  One
+// grid leaves the mix to the workgroup dispatcher.  lists: {general, one-deletion, event-free} x {mate 1, mate 2}.
+struct ReadLists { const uint32_t* l[3][2]; uint32_t n[3][2]; uint32_t grid[3]; };
+template <int QK>
+__global__ void __launch_bounds__(RB, 4) k_reads_all(const uint8_t* __restrict__ g, const uint8_t* __restrict__ g2, DevErrPool spool, DevErrPool fpool, const PairRec* __restrict__ pairs,
+                                                    uint32_t np, int paired, const DevTables tb, RngKey key, uint32_t slot, uint32_t n_slots_cap, uint32_t force_replay,
+                                                    const uint32_t* __restrict__ ev_hdr, const uint4* __restrict__ ev_dat,
+                                                    const uint64_t* __restrict__ off1, const uint64_t* __restrict__ off2, char* __restrict__ out1, char* __restrict__ out2,
+                                                    uint32_t amp_index_base, uint32_t* __restrict__ flags, uint64_t cap1, uint64_t cap2, ReadLists rl) {
+    const uint32_t b = blockIdx.x;
+    if (b < rl.grid[0])
+        reads_body<true, QK, 2>(b, g, spool, fpool, pairs, np, paired, nullptr, nullptr, nullptr, nullptr, 0u, tb, key, slot, n_slots_cap, force_replay, ev_hdr, ev_dat,
+                                off1, off2, out1, out2, amp_index_base, nullptr, nullptr, nullptr, flags, cap1, cap2, rl.l[0][0], rl.l[0][1], rl.n[0][0], rl.n[0][1]);
+    else if (b < rl.grid[0] + rl.grid[1])
+        reads_body<true, QK, 3>(b - rl.grid[0], g, spool, fpool, pairs, np, paired, g2, nullptr, nullptr, nullptr, 0u, tb, key, slot, n_slots_cap, force_replay, ev_hdr, ev_dat,
+                                off1, off2, out1, out2, amp_index_base, nullptr, nullptr, nullptr, flags, cap1, cap2, rl.l[1][0], rl.l[1][1], rl.n[1][0], rl.n[1][1]);
+    else
+        reads_body<true, QK, 1>(b - rl.grid[0] - rl.grid[1], g, spool, fpool, pairs, np, paired, g2, nullptr, nullptr, nullptr, 0u, tb, key, slot, n_slots_cap, force_replay, ev_hdr, ev_dat,
+                                off1, off2, out1, out2, amp_index_base, nullptr, nullptr, nullptr, flags, cap1, cap2, rl.l[2][0], rl.l[2][1], rl.n[2][0], rl.n[2][1]);
 }
 
 __global__ void k_philox(const uint32_t* __restrict__ ctr, uint32_t n, RngKey key, uint32_t* __restrict__ out) {
@@ -2375,8 +2413,31 @@ void launch_reads(hipStream_t s, const uint8_t* g, const uint32_t* g2, DevErrPoo
     if (tb.L > 1008) { gs = 0; gd = 0; }                                           // reads this long all sit in the general list (launch_indels); what is left in the others are holes: nothing to write
     // The three class kernels write disjoint records: the two small ones go to side streams and run BESIDE the big one (each alone
     // leaves the chip half empty through its first and last wave of workgroups); the caller's stream waits for both.
+    static const bool split_env = getenv("SCS_READS_SPLIT") != nullptr, serial_env = getenv("SCS_READS_SERIAL") != nullptr;
+    if (!split_env && !serial_env) {
+        // ONE launch for the three classes (k_reads_all); its LDS is the larger of the uniform walk's and the general variant's
+        ReadLists rl{};
+        rl.l[0][0] = clist1; rl.l[0][1] = clist2; rl.n[0][0] = nc1; rl.n[0][1] = paired ? nc2 : 0u; rl.grid[0] = paired ? 2 * gc : gc;
+        rl.l[1][0] = dlist1; rl.l[1][1] = dlist2; rl.n[1][0] = nd1; rl.n[1][1] = paired ? nd2 : 0u; rl.grid[1] = paired ? 2 * gd : gd;
+        rl.l[2][0] = slist1; rl.l[2][1] = slist2; rl.n[2][0] = ns1; rl.n[2][1] = ns2; rl.grid[2] = paired ? 2 * gs : gs;
+        const uint32_t grid = rl.grid[0] + rl.grid[1] + rl.grid[2];
+        if (!grid) return;
+        const size_t lds = std::max(reads_lds_bytes(tb, true), reads_lds_bytes(tb, false));
+        static size_t opted_all[64][3] = {};
+        int dev = 0; (void)hipGetDevice(&dev);
+        size_t* opted = opted_all[dev & 63];
+        const uint32_t cap = (uint32_t)(paired ? 2ull * np : np);
+#define SCS_LAUNCH_ALL(QKV, SLOT) do { \
+            if (opted[SLOT] != lds) { note_launch(hipFuncSetAttribute((const void*)k_reads_all<QKV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); opted[SLOT] = lds; } \
+            hipLaunchKernelGGL((k_reads_all<QKV>), dim3(grid), dim3(RB), lds, s, g, reinterpret_cast<const uint8_t*>(g2), spool, fpool, pairs, np, paired, tb, key, slot, cap, reads_force_replay(), \
+                               ev_hdr, ev_dat, off1, off2, out1, out2, amp_index_base, flags, cap1, cap2, rl); } while (0)
+        if (tb.qual_k == 16) SCS_LAUNCH_ALL(16, 0); else if (tb.qual_k == 64) SCS_LAUNCH_ALL(64, 1); else SCS_LAUNCH_ALL(128, 2);
+#undef SCS_LAUNCH_ALL
+        return;
+    }
+    // SCS_READS_SPLIT: the three classes as three launches on three streams (round 2's form); SCS_READS_SERIAL: one after the other
     // (side: the caller's two side streams and fork / join events -- they belong to its ctx, created on first use, destroyed with it)
-    static const bool serial_env = getenv("SCS_READS_SERIAL") != nullptr;
+    static const bool dummy_serial_env = false; (void)dummy_serial_env;
     const bool serial = serial_env || !side;
     ReadsSide none; ReadsSide& sd = side ? *side : none;
     if (!serial && !sd.fork) {
