@@ -181,15 +181,17 @@ def committed_counters(kernel_prefix):
     res = {}
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_pmc_hbm.csv")))
     if files:
-        tot = 0.0
+        tot = totf = 0.0
         for line in open(files[-1]):
             if line.startswith("#") or line.startswith("kernel"):
                 continue
             name, fetch, write, n = line.rstrip("\n").rsplit(",", 3)
             if name.startswith(kernel_prefix):
                 tot += (float(fetch) + float(write)) * 1024.0
+                totf += float(fetch) * 1024.0
         if tot:
             res["traffic"] = tot
+            res["traffic_fetch"] = totf
             res["traffic_source"] = os.path.relpath(files[-1], ROOT)
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_sq.csv")))
     if files:
@@ -348,11 +350,15 @@ def roofline_of(ktimes, fq_bytes, L, dom=None):
     # batches: scaled by pairs per launch (the k_reads / k_indels counters are proportional to the pairs of a launch)
     if dom in ("k_reads", "k_indels") and cc.get("profile_pairs_per_launch") and kd["launches"]:
         scale = (kd["units"] / kd["launches"]) / cc["profile_pairs_per_launch"]
-        for key in ("traffic", "valu_insts_per_launch", "salu_insts_per_launch"):
+        for key in ("traffic", "traffic_fetch", "valu_insts_per_launch", "salu_insts_per_launch"):
             if key in cc:
                 cc[key] *= scale
     roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": cc.get("traffic"), "traffic_source": cc.get("traffic_source"), "algorithmic_bytes": note,
+            # MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reports half the bytes of WIDE coalesced reads (16 B per lane) and is uncalibrated for other
+            # widths; this kernel's reads are a mix (56-B pair records and 16-B ring images: wide; dword gathers of the windows: not), so the
+            # truth lies between `traffic` (raw FETCH_SIZE + WRITE_SIZE) and this figure (every fetched byte doubled)
+            "traffic_if_every_read_is_doubled": (cc["traffic"] + cc["traffic_fetch"]) if "traffic_fetch" in cc else None,
             "algorithmic_bytes_per_launch": alg / max(1, kd["launches"]), "avg_launch_ms": kd["ms"] / max(1, kd["launches"]),
             "timed_launches": kd["launches"], "pairs_per_launch": kd["units"] / max(1, kd["launches"]) if dom in ("k_reads", "k_indels") else None}
     if draws:
