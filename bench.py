@@ -242,10 +242,11 @@ def committed_lane_table():
 
 class Cleaner:
     """Unlinks the files of finished steps on background threads (os.unlink releases the GIL), so that tmpfs holds about one
-    step's FASTQ at a time.  gate(limit): wait until at most `limit` bytes are still queued -- the next step's sink starts behind it,
-    INSIDE the timed region."""
+    step's FASTQ at a time.  `threads` of them work while a step's writers need the cores; gate(limit) -- wait until at most
+    `limit` bytes are still queued: the next step's sink starts behind it, INSIDE the timed region -- lets all `burst` of them
+    work, the writers being idle then."""
 
-    def __init__(self, threads=4):
+    def __init__(self, threads=4, burst=16):
         import queue
         import threading
         self.q = queue.Queue()
@@ -253,7 +254,10 @@ class Cleaner:
         self.cv = threading.Condition(self.lock)
         self.outstanding = 0
         self.freed = 0
-        self.th = [threading.Thread(target=self._run, daemon=True) for _ in range(threads)]
+        self.base, self.burst = threads, max(threads, burst)
+        self.limit = threads                                         # workers allowed to unlink at the same time
+        self.active = 0
+        self.th = [threading.Thread(target=self._run, daemon=True) for _ in range(self.burst)]
         for t in self.th:
             t.start()
 
@@ -262,12 +266,17 @@ class Cleaner:
             p = self.q.get()
             if p is None:
                 return
+            with self.cv:
+                while self.active >= self.limit:
+                    self.cv.wait(0.05)
+                self.active += 1
             try:
                 n = os.path.getsize(p)
                 os.unlink(p)
             except OSError:
                 n = 0
             with self.cv:
+                self.active -= 1
                 self.outstanding -= n if n <= self.outstanding else self.outstanding
                 self.freed += n
                 self.cv.notify_all()
@@ -287,8 +296,11 @@ class Cleaner:
     def gate(self, limit):
         t0 = time.perf_counter()
         with self.cv:
+            self.limit = self.burst
+            self.cv.notify_all()
             while self.outstanding > limit:
-                self.cv.wait(0.05)
+                self.cv.wait(0.02)
+            self.limit = self.base
         return time.perf_counter() - t0
 
     def watch(self, files_by_part, k):
@@ -513,7 +525,7 @@ def main():
     out_dir = a.out_dir or tempfile.mkdtemp(prefix="scsbench_out_", dir=shm)
     os.makedirs(out_dir, exist_ok=True)
     generations = a.generations
-    cleaner = Cleaner(threads=max(1, a.cleaners))
+    cleaner = Cleaner(threads=max(1, a.cleaners), burst=max(cores, a.cleaners))
     GATE_BYTES = (40 << 30) // max(1, world)                                            # a step's sink starts when at most this much of the older steps' text is still on tmpfs
 
     def acc(ktimes, kt, names_):
