@@ -908,7 +908,8 @@ struct SinkPipe {
     void start(BatchSink* f, bool pe, int dev) {
         sink = f; paired = pe; device = dev; done = failed = false;
         const size_t nw = (size_t)std::max(1, f->writers), want = nw + 2;
-        while (slots.size() < want) { Slot sl; HIP_OK(hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming)); slots.push_back(sl); }
+        // (blocking events: a writer that waits for its batch's copy sleeps instead of spinning -- the host's cores are the sink's bottleneck)
+        while (slots.size() < want) { Slot sl; HIP_OK(hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming | hipEventBlockingSync)); slots.push_back(sl); }
         for (auto& sl : slots) sl.busy = false;
         writers = std::vector<Writer>(nw);
         for (size_t w = 0; w < writers.size(); ++w) writers[w].th = std::thread([this, w] {
@@ -1006,7 +1007,7 @@ void do_yield(scs_ctx* c, const OutTarget& tg, uint64_t* n1_out, uint64_t* n2_ou
     const bool bgzf = to_sink && tg.bgzf;
     if (bgzf && !c->h_z) {
         HIP_OK(hipHostMalloc((void**)&c->h_z, 64, hipHostMallocDefault)); memset(c->h_z, 0, 64);
-        for (int k = 0; k < 2; ++k) HIP_OK(hipEventCreateWithFlags(&c->ev_z[k], hipEventDisableTiming));
+        for (int k = 0; k < 2; ++k) HIP_OK(hipEventCreateWithFlags(&c->ev_z[k], hipEventDisableTiming | hipEventBlockingSync));
         std::vector<uint32_t> tabs(512); bgzf_host_tables(tabs.data(), tabs.data() + 256);
         upload(c->z_crc, tabs, s); HIP_OK(hipStreamSynchronize(s));
     }
