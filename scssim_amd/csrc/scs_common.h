@@ -121,9 +121,16 @@ SCS_HD AttachFit attach_fit_count(uint32_t len, uint32_t amin, uint32_t amax) {
 }
 SCS_HD void attach_fit_decode(const AttachFit& f, uint32_t len, uint32_t amin, uint32_t r, uint32_t& spos, uint32_t& alen) {
     const uint32_t full = f.A * f.W;
-    if (r < full) { spos = 27u + r / f.W; alen = amin + r % f.W; return; }
+    if (r < full) {
+        // r / W by a multiplication (W is a run-time value: a 32-bit division costs ~30 instructions with quarter-rate multiplies):
+        // floor(r M / 2^42), M = ceil(2^42 / W), is exact for r < 2^42 / W (r < 2^32 here, W <= 2048)
+        const uint64_t M = ((1ull << 42) + f.W - 1u) / f.W;                        // (uniform: the compiler hoists it out of the try loop)
+        const uint32_t qd = (uint32_t)(((uint64_t)r * M) >> 42);
+        spos = 27u + qd; alen = amin + (r - qd * f.W); return;
+    }
     const uint32_t q = r - full;                                                  // q in [0, D(D+1)/2): row d holds d entries, rows 1, 2, .. D
-    uint32_t d = (uint32_t)((1.0 + sqrt(1.0 + 8.0 * (double)q)) * 0.5);
+    uint32_t d = (uint32_t)((1.0f + sqrtf(1.0f + 8.0f * (float)q)) * 0.5f);        // (a single-precision estimate: the two loops below make it exact)
+    if (d < 1u) d = 1u;
     while (d > 1u && d * (d - 1u) / 2u > q) --d;                                  // exact whatever the rounding of the square root
     while (d * (d + 1u) / 2u <= q) ++d;
     alen = amin + (q - d * (d - 1u) / 2u);
@@ -131,9 +138,18 @@ SCS_HD void attach_fit_decode(const AttachFit& f, uint32_t len, uint32_t amin, u
 }
 // number of non-fitting tries before the next fitting one, capped at 51 (> 50 tries kill the primer): u uniform in (0, 1),
 // qfail = 1 - N / M.  P(gap >= g) = qfail^g, evaluated by repeated multiplication (the same IEEE products everywhere).
+// The largest g <= 51 with u < qfail^g, by the binary digits of g: q^32, q^16 .. q by repeated squaring, then six compare-and-
+// multiply steps -- a fixed 11 products instead of a loop of g of them (mean 11, but a wave runs the LONGEST of its lanes' loops:
+// ~45 with most lanes drawing).  The same IEEE products on the CPU and on the GPU (no contraction), mirrored in the oracle.
 SCS_HD uint32_t attach_gap(double u, double qfail) {
-    double acc = qfail; uint32_t g = 0;
-    while (g < 51u && u < acc) { acc = acc * qfail; ++g; }
+    const double q2 = qfail * qfail, q4 = q2 * q2, q8 = q4 * q4, q16 = q8 * q8, q32 = q16 * q16;
+    double p = 1.0; uint32_t g = 0; double t;
+    t = p * q32;   if (u < t) { p = t; g += 32u; }
+    t = p * q16;   if (u < t && g + 16u <= 51u) { p = t; g += 16u; }
+    t = p * q8;    if (u < t && g + 8u <= 51u) { p = t; g += 8u; }
+    t = p * q4;    if (u < t && g + 4u <= 51u) { p = t; g += 4u; }
+    t = p * q2;    if (u < t && g + 2u <= 51u) { p = t; g += 2u; }
+    t = p * qfail; if (u < t && g + 1u <= 51u) { p = t; g += 1u; }
     return g;
 }
 
