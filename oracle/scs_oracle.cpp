@@ -799,17 +799,9 @@ void attach_fit_decode(const AttachFit& f, uint32_t len, uint32_t amin, uint32_t
     alen = amin + (q - d * (d - 1u) / 2u);
     spos = len - amin + 1u - d;
 }
-// P(gap >= g) = qfail^g, capped at 51: the largest g <= 51 with u < qfail^g, found by the binary digits of g over the powers
-// q^32 .. q made by repeated squaring (eleven IEEE products, the same on the GPU: scs_common.h attach_gap)
-uint32_t attach_gap(double u, double qfail) {
-    const double q2 = qfail * qfail, q4 = q2 * q2, q8 = q4 * q4, q16 = q8 * q8, q32 = q16 * q16;
-    double p = 1.0; uint32_t g = 0; double t;
-    t = p * q32;   if (u < t) { p = t; g += 32u; }
-    t = p * q16;   if (u < t && g + 16u <= 51u) { p = t; g += 16u; }
-    t = p * q8;    if (u < t && g + 8u <= 51u) { p = t; g += 8u; }
-    t = p * q4;    if (u < t && g + 4u <= 51u) { p = t; g += 4u; }
-    t = p * q2;    if (u < t && g + 2u <= 51u) { p = t; g += 2u; }
-    t = p * qfail; if (u < t && g + 1u <= 51u) { p = t; g += 1u; }
+uint32_t attach_gap(double u, double qfail) {                                       // P(gap >= g) = qfail^g, capped at 51
+    double acc = qfail; uint32_t g = 0;
+    while (g < 51u && u < acc) { acc = acc * qfail; ++g; }
     return g;
 }
 

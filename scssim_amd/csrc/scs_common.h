@@ -138,20 +138,13 @@ SCS_HD void attach_fit_decode(const AttachFit& f, uint32_t len, uint32_t amin, u
 }
 // number of non-fitting tries before the next fitting one, capped at 51 (> 50 tries kill the primer): u uniform in (0, 1),
 // qfail = 1 - N / M.  P(gap >= g) = qfail^g, evaluated by repeated multiplication (the same IEEE products everywhere).
-// The largest g <= 51 with u < qfail^g, by the binary digits of g: q^32, q^16 .. q by repeated squaring, then six compare-and-
-// multiply steps -- a fixed 11 products instead of a loop of g of them (mean 11, but a wave runs the LONGEST of its lanes' loops:
-// ~45 with most lanes drawing).  The same IEEE products on the CPU and on the GPU (no contraction), mirrored in the oracle.
 SCS_HD uint32_t attach_gap(double u, double qfail) {
-    const double q2 = qfail * qfail, q4 = q2 * q2, q8 = q4 * q4, q16 = q8 * q8, q32 = q16 * q16;
-    double p = 1.0; uint32_t g = 0; double t;
-    t = p * q32;   if (u < t) { p = t; g += 32u; }
-    t = p * q16;   if (u < t && g + 16u <= 51u) { p = t; g += 16u; }
-    t = p * q8;    if (u < t && g + 8u <= 51u) { p = t; g += 8u; }
-    t = p * q4;    if (u < t && g + 4u <= 51u) { p = t; g += 4u; }
-    t = p * q2;    if (u < t && g + 2u <= 51u) { p = t; g += 2u; }
-    t = p * qfail; if (u < t && g + 1u <= 51u) { p = t; g += 1u; }
+    double acc = qfail; uint32_t g = 0;
+    while (g < 51u && u < acc) { acc = acc * qfail; ++g; }
     return g;
 }
+// (Round 3 tried the gap by the binary digits of g -- q^32 .. q by repeated squaring, six compare-and-multiply steps, no loop:
+// k_attach<semi> 58.9 -> 62.9 ms.  The loop's mean of 11 cheap rounds beats eleven fixed products with six double selects.)
 
 // base codes: 0..3 = ACGT, 4 = N / anything else (MyDefine.cpp:352-367: complement of non-ACGT is 'N')
 SCS_HD uint8_t comp_code(uint8_t c) { return c < 4 ? (uint8_t)(3 - c) : (uint8_t)4; }
