@@ -121,21 +121,17 @@ SCS_HD AttachFit attach_fit_count(uint32_t len, uint32_t amin, uint32_t amax) {
 }
 SCS_HD void attach_fit_decode(const AttachFit& f, uint32_t len, uint32_t amin, uint32_t r, uint32_t& spos, uint32_t& alen) {
     const uint32_t full = f.A * f.W;
-    if (r < full) {
-        // r / W by a multiplication (W is a run-time value: a 32-bit division costs ~30 instructions with quarter-rate multiplies):
-        // floor(r M / 2^42), M = ceil(2^42 / W), is exact for r < 2^42 / W (r < 2^32 here, W <= 2048)
-        const uint64_t M = ((1ull << 42) + f.W - 1u) / f.W;                        // (uniform: the compiler hoists it out of the try loop)
-        const uint32_t qd = (uint32_t)(((uint64_t)r * M) >> 42);
-        spos = 27u + qd; alen = amin + (r - qd * f.W); return;
-    }
+    if (r < full) { spos = 27u + r / f.W; alen = amin + r % f.W; return; }
     const uint32_t q = r - full;                                                  // q in [0, D(D+1)/2): row d holds d entries, rows 1, 2, .. D
-    uint32_t d = (uint32_t)((1.0f + sqrtf(1.0f + 8.0f * (float)q)) * 0.5f);        // (a single-precision estimate: the two loops below make it exact)
-    if (d < 1u) d = 1u;
+    uint32_t d = (uint32_t)((1.0 + sqrt(1.0 + 8.0 * (double)q)) * 0.5);
     while (d > 1u && d * (d - 1u) / 2u > q) --d;                                  // exact whatever the rounding of the square root
     while (d * (d + 1u) / 2u <= q) ++d;
     alen = amin + (q - d * (d - 1u) / 2u);
     spos = len - amin + 1u - d;
 }
+// (Round 3 tried r / W as a multiplication by ceil(2^42 / W) and a single-precision estimate of the triangle row: k_attach<semi>
+// unchanged, k_attach<frag> 21.1 -> 24.0 ms -- the kernel waits for its chain of dependent gathers per candidate (position bitmap,
+// the 8 primer bases, the stock), not for these instructions.)
 // number of non-fitting tries before the next fitting one, capped at 51 (> 50 tries kill the primer): u uniform in (0, 1),
 // qfail = 1 - N / M.  P(gap >= g) = qfail^g, evaluated by repeated multiplication (the same IEEE products everywhere).
 SCS_HD uint32_t attach_gap(double u, double qfail) {
