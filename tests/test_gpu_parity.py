@@ -307,7 +307,9 @@ def test_rccl_inside_the_library_single_rank_and_cli(models, golden_inputs, orac
     prefix = str(tmp_path / "orc")
     _oracle_run(oracle_bin, golden_inputs["g1_hiseq2500_pe"], models["Illumina_HiSeq2500"], prefix, ["-c", "2"], 5)
     g = scssim_amd.GenReads(profile=models["Illumina_HiSeq2500"], input_fasta=golden_inputs["g1_hiseq2500_pe"], coverage=2.0, seed=5)
+    assert g.comm_count() == 0
     g.comm_init(scssim_amd.comm_unique_id(), 0, 1)
+    assert g.comm_count() == 1                                       # what RCCL itself reports (ncclCommCount)
     g.create_frags(); g.amplify(); g.allocate_reads(0)
     g.yield_reads_files(str(tmp_path / "lib"))
     for suffix in ("_1.fq", "_2.fq"):

@@ -332,3 +332,30 @@ def test_sharded_ranks_stage_only_their_own_stretch_of_the_genome(layout, oracle
     assert sum(a for a, _ in st.values()) <= total + 3 * 100001 and max(a for a, _ in st.values()) < 0.5 * total, st
     st = sharded("forced_whole", {"SCS_STAGE_WHOLE": "1"})
     assert all(v == (total, total) for v in st.values())
+
+
+def test_a_job_without_reads_leaves_well_formed_empty_outputs(models, tmp_path):
+    """Zero requested reads (coverage too low for one read) and a genome too short to amplify: the file sink still leaves the files a
+    consumer expects -- empty text files, every part of a parts job with its index, BGZF files that are just the end-of-file block
+    (gunzip gives the empty string) -- and the merges accept them."""
+    import gzip
+    rng = __import__("numpy").random.default_rng(3)
+    fa = str(tmp_path / "tiny.fa")
+    with open(fa, "w") as f:
+        for name in ("1_1_20000", "1_2_20000"):
+            f.write(">%s\n%s\n" % (name, "".join(rng.choice(list("ACGT"), size=20000))))
+    g = scssim_amd.GenReads(profile=models["Illumina_HiSeq2500"], input_fasta=fa, coverage=0.001, seed=7)
+    g.create_frags(); g.amplify(); g.allocate_reads(0)
+    assert g.stats()["reads_requested"] == 0
+    g.yield_reads_files(str(tmp_path / "a"))
+    assert os.path.getsize(str(tmp_path / "a") + "_1.fq") == 0 and os.path.getsize(str(tmp_path / "a") + "_2.fq") == 0
+    g.yield_reads_files(str(tmp_path / "b"), 3, 2)
+    files = scssim_amd.part_paths(str(tmp_path / "b"), 6, True)
+    assert all(os.path.getsize(f) == 0 for m in files for f in m) and os.path.exists(str(tmp_path / "b") + ".parts")
+    scssim_amd.merge_fastq_parts(str(tmp_path / "b"))
+    assert os.path.getsize(str(tmp_path / "b") + "_1.fq") == 0 and not os.path.exists(files[0][0])
+    g.yield_reads_files(str(tmp_path / "c"), 2, 1, True)
+    for f in [x for m in scssim_amd.part_paths(str(tmp_path / "c"), 2, True, ".fq.gz") for x in m]:
+        z = open(f, "rb").read()
+        assert len(z) == 28 and gzip.decompress(z) == b""
+    assert g.stats()["pairs_written"] == 0 and g.stats()["sink_bytes"] == [0, 0]
