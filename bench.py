@@ -597,6 +597,10 @@ def main():
     main_mode = "null" if a.hbm_only else "files"
     R = timed(a.warmup, a.steps, main_mode, 0)
     cleaner.gate(0)                                                  # (outside the timed region: the last step's files)
+    # ---- generation only (every rank takes part: the steps hold the job's collectives): the same job with a NULL sink -- the text is
+    # written into HBM batch buffers (8 M pairs per launch) and counted.  What the kernels do when nothing has to cross PCIe; the
+    # dominant kernel's roofline is taken here.
+    H = timed(1, 5, "null", 100) if not a.no_extra_legs and not a.hbm_only else None
 
     if rank == 0:
         L = g.read_length
@@ -625,11 +629,7 @@ def main():
             "lane_utilisation": committed_lane_table(),
         }
         roof_src, roof_fq, roof_note = R["ktimes"], R["fq_bytes_local"], "HIP events on the ctx stream around every launch of the timed region"
-        H = None
-        if world == 1 and not a.no_extra_legs and not a.hbm_only:
-            # ---- generation only: the same job with a NULL sink -- the text is written into HBM batch buffers (8 M pairs per launch)
-            # and counted.  What the kernels do when nothing has to cross PCIe; the dominant kernel's roofline is taken here.
-            H = timed(1, 5, "null", 100)
+        if H:
             out["generation_hbm"] = {"value": H["pairs"] / H["elapsed"], "unit": "pairs/s", "steps": 5, "ms_per_step": 1e3 * H["elapsed"] / 5, "stages_s_per_step": H["stage"],
                                      "kernels_ms_per_step": {k: v["ms"] / 5 for k, v in H["ktimes"].items()},
                                      "what": "the same job, FASTQ text generated batch by batch into HBM buffers and counted (NULL sink): no PCIe, no files",
