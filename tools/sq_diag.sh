@@ -6,7 +6,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/diag_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 1 --warmup 0 --no-extra-legs --no-cpu-baseline --genome-mb 300 $*"
+ARGS="--steps 1 --warmup 0 --hbm-only --no-extra-legs --no-cpu-baseline --genome-mb 300 $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/p0 -o t -- python3 $ROOT/bench.py $ARGS > $OUT/p0.log 2>&1
 cp $(find $OUT/p0 -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv; rm -rf $OUT/p0
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS --output-format csv -d $OUT/p1 -o a -- python3 $ROOT/bench.py $ARGS > $OUT/p1.log 2>&1
