@@ -75,10 +75,9 @@ struct Xoshiro {
         s[2] ^= t; s[3] = rotl(s[3], 11);
         return result;
     }
-    // [REMAP] one step, two words: the xoshiro128+ output (s0 + s3) and the same scrambler on the other two state words (stream B
-    // of a read: both words are used through order comparisons against 32-bit thresholds: scs_common.h Xoshiro::next2)
+    // [REMAP] one step, two words: the xoshiro128++ output and the same scrambler on the other two state words (stream B of a read)
     inline void next2(uint32_t& a, uint32_t& b) {
-        a = s[0] + s[3]; b = s[1] + s[2];
+        a = rotl(s[0] + s[3], 7) + s[0]; b = rotl(s[1] + s[2], 7) + s[1];
         const uint32_t t = s[1] << 9;
         s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3];
         s[2] ^= t; s[3] = rotl(s[3], 11);

@@ -82,15 +82,13 @@ struct Xoshiro {
         s2 ^= t; s3 = (s3 << 11) | (s3 >> 21);
         return result;
     }
-    // [REMAP] ONE step, TWO words: a = s0 + s3 -- the output of xoshiro128+ (Blackman & Vigna's "plus" scrambler on this very state
-    // transition) --, b = the same scrambler on the other two state words (s1 + s2).  Stream B of a read (substitution / quality
-    // draws) advances one step per output position.  Round 3 took the "+" scrambler instead of "++" here (2 instead of 6 of the
-    // step's 13 instructions, on the hottest loop of the path): its known weakness is the linearity of the LOWEST bits, and both
-    // draws are used through order comparisons against 32-bit thresholds (and the top 6 bits as an alias column), where a low bit
-    // decides only when all the bits above it tie.  tests/test_oracle_stats.py compares 15 M such draws per model with the
-    // reference's mt19937 bin by bin.  Stream A (indel gaps, next()) and the attach streams keep "++".
+    // [REMAP] ONE step, TWO words: a = the xoshiro128++ output (scrambler on s0, s3), b = the same scrambler on the other two
+    // state words (s1, s2).  Stream B of a read (substitution / quality draws) advances one step per output position.
+    // (Round 3 tried the "+" scrambler here -- s0 + s3, s1 + s2: 2 instead of 6 of the step's 13 instructions -- and measured
+    // -1.5 % on k_reads in an alternating A/B: not worth a generator with weak low bits; "++" stays.)
     SCS_HD void next2(uint32_t& a, uint32_t& b) {
-        a = s0 + s3; b = s1 + s2;
+        const uint32_t p = s0 + s3, q = s1 + s2;
+        a = ((p << 7) | (p >> 25)) + s0; b = ((q << 7) | (q >> 25)) + s1;
         const uint32_t t = s1 << 9;
         s2 ^= s0; s3 ^= s1; s1 ^= s2; s0 ^= s3;
         s2 ^= t; s3 = (s3 << 11) | (s3 >> 21);

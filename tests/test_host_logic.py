@@ -352,8 +352,8 @@ def test_part_files_are_one_logical_file_for_both_merges(tmp_path):
 
 
 def test_two_word_stream_step_is_sound():
-    """[REMAP] stream B of a read advances one xoshiro128 step per output position and takes TWO words from it: the xoshiro128+
-    output (the "plus" scrambler on state words s0, s3) for the substitution draw and the same scrambler on the other two words (s1, s2)
+    """[REMAP] stream B of a read advances one xoshiro128 step per output position and takes TWO words from it: the xoshiro128++
+    output (scrambler on state words s0, s3) for the substitution draw and the same scrambler on the other two words (s1, s2)
     for the quality draw (scs_common.h Xoshiro::next2, mirrored in the oracle).  A numpy restatement over 4096 independent
     streams x 512 steps: both words uniform (chi-square over their top byte), uncorrelated with each other within a step and
     across consecutive steps, and the first word is bit for bit the published generator's output."""
@@ -363,10 +363,10 @@ def test_two_word_stream_step_is_sound():
     def rotl(x, k):
         return ((x << np.uint32(k)) | (x >> np.uint32(32 - k))).astype(np.uint32)
 
-    def reference_next(st):                                # xoshiro128+ 1.0 (Blackman & Vigna), one stream, python ints
+    def reference_next(st):                                # xoshiro128++ 1.0 (Blackman & Vigna), one stream, python ints
         s0, s1, s2, s3 = st
         m = 0xFFFFFFFF
-        r = (s0 + s3) & m
+        r = ((((s0 + s3) & m) << 7 | ((s0 + s3) & m) >> 25) + s0) & m
         t = (s1 << 9) & m
         s2 ^= s0; s3 ^= s1; s1 ^= s2; s0 ^= s3; s2 ^= t; s3 = ((s3 << 11) | (s3 >> 21)) & m
         return r, [s0, s1, s2, s3]
@@ -374,8 +374,8 @@ def test_two_word_stream_step_is_sound():
     ref_state = [int(w[0]) for w in s]
     A, Bw = [], []
     for step in range(512):
-        a = (s[0] + s[3]).astype(np.uint32)
-        b = (s[1] + s[2]).astype(np.uint32)
+        a = (rotl(s[0] + s[3], 7) + s[0]).astype(np.uint32)
+        b = (rotl(s[1] + s[2], 7) + s[1]).astype(np.uint32)
         t = (s[1] << np.uint32(9)).astype(np.uint32)
         s[2] = s[2] ^ s[0]; s[3] = s[3] ^ s[1]; s[1] = s[1] ^ s[2]; s[0] = s[0] ^ s[3]
         s[2] = s[2] ^ t; s[3] = rotl(s[3], 11)
