@@ -47,6 +47,7 @@ struct DevTables {
     const uint32_t* subs1; const uint32_t* subs2;   // [84][bins][4] thresholds (uint4 rows)
     const uint32_t* qual;                            // [16][bins][94]
     const uint4* ring1; const uint4* ring2;          // per mate, per bin (padded to a multiple of 8 bins): the bin's image in k_reads' LDS ring (RingBin), ready to copy
+    const uint4* ring1u; const uint4* ring2u;        // the same for the uniform walk (RingBinU): alias rows + the 64 3-mers' KEEP intervals (lo, width) instead of threshold triples
     const uint32_t* qual_alias; int qual_k;          // [16*bins] alias rows of qual_k (16 / 64 / 128) columns: qual_k words + qual_k symbol bytes (scs_tables.h)
     const uint32_t* ins_t; int n_ins;
     const uint32_t* del_t; int n_del;
@@ -181,6 +182,7 @@ void launch_read_lists(hipStream_t s, uint32_t np, int paired, const uint32_t* s
                        const uint32_t* sizes2, const uint64_t* off2, const uint32_t* d1f2, uint32_t* d1p2,
                        uint32_t* slist1, uint32_t* slist2, uint32_t* clist1, uint32_t* clist2, uint32_t* dlist1, uint32_t* dlist2, void* temp, size_t temp_bytes);
 // the indel pass of a batch (n' and events per read, FASTQ record sizes per pair and mate), ahead of launch_reads
+void phase_clock_report();   // -DSCS_PHASE_CLOCK builds: prints and zeroes the uniform walk's phase times (no-op otherwise)
 void launch_indels(hipStream_t s, const PairRec* pairs, uint32_t np, int paired, DevTables tb, RngKey key, uint32_t slot, uint32_t* ev_hdr, uint4* ev_dat,
                    uint32_t* sizes1, uint32_t* sizes2, uint32_t* d1f1, uint32_t* d1f2, uint32_t* flags);
 void launch_predict_windows(hipStream_t s, const uint8_t* windows, uint32_t n_reads, const uint64_t* uids, const uint32_t* atts,

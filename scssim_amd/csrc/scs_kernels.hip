@@ -11,6 +11,15 @@
 #include <rocprim/rocprim.hpp>
 
 namespace scs {
+// Build-time diagnostic (-DSCS_PHASE_CLOCK): where a workgroup of the uniform walk spends its life.  Thread 0 reads the 100 MHz
+// wall clock at the phase boundaries and adds the differences to g_phase[] (g_phase[15] counts the workgroups); the host prints and
+// zeroes them (scs_phase_clock_report, called at the end of a yield when SCS_PHASE_CLOCK is set in the environment).
+#ifdef SCS_PHASE_CLOCK
+__device__ unsigned long long g_phase[16];
+#define SCS_PHASE(i) do { if (UNI && CLS == 1 && tid == 0) { const unsigned long long now_ = wall_clock64(); if ((i) >= 0) atomicAdd(&g_phase[(i) < 0 ? 0 : (i)], now_ - ph_t_); ph_t_ = now_; } } while (0)
+#else
+#define SCS_PHASE(i) do {} while (0)
+#endif
 
 #define WAVE 64
 
@@ -678,6 +687,8 @@ template <> struct RingGeo<16>  { enum { SLOTS = 16, GROUP = 8, QROW = 5,  ABITS
 template <> struct RingGeo<64>  { enum { SLOTS = 8,  GROUP = 4, QROW = 20, ABITS = 6 }; };
 template <> struct RingGeo<128> { enum { SLOTS = 4,  GROUP = 2, QROW = 40, ABITS = 7 }; };
 template <int QK> struct RingBin { uint4 qd[4][RingGeo<QK>::QROW]; uint32_t subs[64][3]; };
+// the uniform walk's bin: the 3-mers' KEEP intervals (lo, width) instead of their threshold triples (scs_pipeline.cpp ring_image_u)
+template <int QK> struct RingBinU { uint4 qd[4][RingGeo<QK>::QROW]; uint32_t keep[64][2]; };
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 // LDS-qualified pointer types: keep the compiler from merging LDS and global accesses into FLAT ones
@@ -708,9 +719,10 @@ __device__ __forceinline__ void win_put2(LdsU8* w, int i, uint32_t v) {         
     LdsU32* d = (LdsU32*)w + (i >> 4); const uint32_t sh = 2u * (uint32_t)(i & 15);
     *d = (*d & ~(3u << sh)) | (v << sh);
 }
-// row of the uniform walk: 16 bytes of pending-quality slots + the window at two bits per base, an odd number of dwords in all
+// row of the uniform walk: 24 bytes of pending-position slots (two entries of three words) + the window at two bits per base, an
+// odd number of dwords in all
 __host__ __device__ static inline uint32_t uni_row_bytes(uint32_t n) {
-    uint32_t d = 4u + ((n + 15u) >> 4);
+    uint32_t d = 6u + ((n + 15u) >> 4);
     if ((d & 1u) == 0) ++d;
     return 4u * d;
 }
@@ -720,6 +732,14 @@ __device__ __forceinline__ void win_put(LdsU8* w, int i, uint32_t v) {
     w[i >> 1] = (uint8_t)((old & ~(15u << sh)) | (v << sh));
 }
 
+// A workgroup barrier that orders LDS accesses ONLY (the HIP __syncthreads() also waits for every outstanding global load and store
+// of the wave -- s_waitcnt vmcnt(0) -- before it lets the wave arrive).  k_reads synchronises nothing but LDS between its waves, and
+// keeps global loads (the next phase's inputs, the ring's prefetch) and the text's stores in flight across its barriers.
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
 // [REMAP] quality symbol by the alias method (scs_tables.h): column = the draw's top bits; its low bits against the column's
 // threshold pick the column's own symbol or its alias; every symbol is hit by exactly as many of the 2^32 draws as in
 // the reference's CDF comparison.  One 4-byte and one 1-byte read, wherever the row lives.
@@ -989,7 +1009,8 @@ __device__ __forceinline__ void reads_body(const uint32_t bid, const uint8_t* __
     constexpr bool SIMPLE = CLS == 1 || CLS == 3;                                 // 3: the uniform walk for reads with ONE deletion of ONE base (below)
     constexpr bool D1 = CLS == 3;
     typedef RingGeo<QK> Geo;
-    typedef RingBin<QK> Bin;
+    constexpr bool UNI = SIMPLE && FROM_PAIRS;
+    typedef typename std::conditional<UNI, RingBinU<QK>, RingBin<QK>>::type Bin;
     constexpr int SLOTS = Geo::SLOTS, GROUP = Geo::GROUP, QROW = Geo::QROW;
     extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
     // the table descriptor is a by-value kernel argument: pointers loaded from the kernarg segment are known to be
@@ -1003,12 +1024,15 @@ __device__ __forceinline__ void reads_body(const uint32_t bid, const uint8_t* __
     // rows: [RB][WS] windows behind the event slots; the uniform walk (UNI) has no events and keeps each lane's 16 bytes
     // IN FRONT of its window instead -- two pending-quality slots, the later ones overlay the consumed start of the window
     // and the window itself with TWO bits per base (its reads see no N): uni_row_bytes
-    constexpr bool UNI = SIMPLE && FROM_PAIRS;
-    constexpr uint32_t WOFF = UNI ? 16u : 0u;
+    constexpr uint32_t WOFF = UNI ? 24u : 0u;
     const uint32_t ROW = UNI ? uni_row_bytes((uint32_t)n) : WS;
     uint8_t* s_win = UNI ? reinterpret_cast<uint8_t*>(s_ev) : reinterpret_cast<uint8_t*>(s_ev + RB * EV_MAX);
     uint32_t* s_head = reinterpret_cast<uint32_t*>(s_dyn + SLOTS * sizeof(Bin) + (size_t)RB * ROW);   // [64] UNI: threshold rows of the 1- and 2-mers
     const int tid = threadIdx.x, lane = tid & 63, wib = tid >> 6;
+#ifdef SCS_PHASE_CLOCK
+    unsigned long long ph_t_ = 0;
+#endif
+    SCS_PHASE(-1);
 
     // the workgroup's records are contiguous: stores address them as a uniform base (aligned down to a sector) + a 32-bit offset
     const bool second_file = FROM_PAIRS && paired && (bid & 1u);
@@ -1041,22 +1065,23 @@ __device__ __forceinline__ void reads_body(const uint32_t bid, const uint8_t* __
         auto pair_of = [&](uint32_t e) -> uint32_t { return e < nwork ? (CLS == 0 ? e : wlist[e]) : 0xFFFFFFFFu; };
         { const uint32_t p = pair_of(q * RB + tid); if (p != 0xFFFFFFFFu) { PairRec o; uint32_t rel, h; record_of(p, o, rel, h); keyp = (rel + h) & 31u; } }
         if (tid < 64) s_cnt[tid] = 0;
-        __syncthreads();
+        lds_barrier();
         const uint32_t rank = atomicAdd(&s_cnt[keyp], 1u);
-        __syncthreads();
+        lds_barrier();
         if (tid < 64) {                                                            // exclusive prefix of the 33 bucket counts
             const uint32_t c = s_cnt[tid]; uint32_t incl = c;
 #pragma unroll
             for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d); if (tid >= d) incl += o; }
             s_cnt[tid] = incl - c;
         }
-        __syncthreads();
+        lds_barrier();
         s_perm[s_cnt[keyp] + rank] = (uint32_t)tid;
-        __syncthreads();
+        lds_barrier();
         pi = pair_of(q * RB + s_perm[tid]); valid = pi != 0xFFFFFFFFu;
         r = paired ? 2 * pi + rd : pi;
         if (valid) { record_of(pi, pr, rec_rel, rec_h); uid = pr.uid; att = pr.att; }
-        __syncthreads();                                                           // s_perm is read before the staging overwrites it
+        lds_barrier();                                                           // s_perm is read before the staging overwrites it
+        SCS_PHASE(0);
     } else {
         r = bid * RB + tid; valid = r < n_explicit; rd = 0;
         if (valid) { uid = uids[r]; att = atts[r]; rd = is_read1[r] ? 0u : 1u; }
@@ -1074,7 +1099,7 @@ __device__ __forceinline__ void reads_body(const uint32_t bid, const uint8_t* __
             else { gb = pr.base + dir * (int64_t)(pr.pos + pr.isz - 1); gf = (comp ^ 1u) | ((dir < 0) ? 0u : 2u) | 4u; }   // read 2 = revcomp of the far end
         }
         s_gbase[tid] = gb; s_gflag[tid] = gf;
-        __syncthreads();
+        lds_barrier();
         // a lane takes 4 consecutive window bases = one dword of the genome (byte-reversed when the view runs backwards),
         // complements them in place and packs them into two LDS bytes: one load instruction covers 256 bases of a read
         if constexpr (UNI) {
@@ -1085,22 +1110,34 @@ __device__ __forceinline__ void reads_body(const uint32_t bid, const uint8_t* __
             const uint32_t* __restrict__ g2 = reinterpret_cast<const uint32_t*>(windows);   // pair mode: the `windows` argument carries the two-bit genome
             const int W2 = (n + 15) >> 4, LPR = W2 + 1, RPI = LPR <= WAVE ? WAVE / LPR : 1;   // (L <= 1008: the host sends longer reads to the general variant)
             const int r5 = lane / LPR, j = lane - r5 * LPR;
-            for (int i0 = 0; i0 < WAVE; i0 += RPI) {
-                const int rq = i0 + r5; const bool on = r5 < RPI && rq < WAVE;
-                const int rr = wib * WAVE + (on ? rq : 0);
-                const uint32_t f = s_gflag[rr]; const int64_t b0 = s_gbase[rr];
-                const bool bwd = (f & 2u) != 0;
-                const int64_t T = b0 >> 4; const uint32_t q = (uint32_t)b0 & 15u;
-                const uint32_t own = g2[bwd ? T - j : T + j];                    // (always inside the padded array)
-                const uint32_t nbr = (uint32_t)__shfl_down((int)own, 1);
-                uint32_t v = bwd ? __builtin_amdgcn_alignbit(own, nbr, 2u * (q + 1u)) : __builtin_amdgcn_alignbit(nbr, own, 2u * q);
-                if (bwd) {
-                    if (q == 15u) v = own;
-                    v = __builtin_bitreverse32(v);                              // reverses the bases AND the two bits of each: swap those back
-                    v = ((v >> 1) & 0x55555555u) | ((v & 0x55555555u) << 1);
+            // (all the loads of a batch leave before the first is used: the gather is latency bound -- 13 rounds one after the other
+            // were 15 of a workgroup's 80 microseconds)
+            constexpr int NB = 16;
+            for (int ib = 0; ib < WAVE; ib += NB * RPI) {
+                uint32_t own[NB];
+#pragma unroll
+                for (int u = 0; u < NB; ++u) {
+                    const int rq = ib + u * RPI + r5; const bool on = r5 < RPI && rq < WAVE;
+                    const int rr = wib * WAVE + (on ? rq : 0);
+                    const bool bwd = (s_gflag[rr] & 2u) != 0; const int64_t T = s_gbase[rr] >> 4;
+                    own[u] = g2[bwd ? T - j : T + j];                          // (always inside the padded array)
                 }
-                if (f & 1u) v = ~v;                                               // complement: 3 - c
-                if (on && (f & 4u) && j < W2) reinterpret_cast<uint32_t*>(s_win + (size_t)rr * ROW + WOFF)[j] = v;
+#pragma unroll
+                for (int u = 0; u < NB; ++u) {
+                    const int rq = ib + u * RPI + r5; const bool on = r5 < RPI && rq < WAVE;
+                    const int rr = wib * WAVE + (on ? rq : 0);
+                    const uint32_t f = s_gflag[rr]; const uint32_t q = (uint32_t)s_gbase[rr] & 15u;
+                    const bool bwd = (f & 2u) != 0;
+                    const uint32_t nbr = (uint32_t)__shfl_down((int)own[u], 1);
+                    uint32_t v = bwd ? __builtin_amdgcn_alignbit(own[u], nbr, 2u * (q + 1u)) : __builtin_amdgcn_alignbit(nbr, own[u], 2u * q);
+                    if (bwd) {
+                        if (q == 15u) v = own[u];
+                        v = __builtin_bitreverse32(v);                          // reverses the bases AND the two bits of each: swap those back
+                        v = ((v >> 1) & 0x55555555u) | ((v & 0x55555555u) << 1);
+                    }
+                    if (f & 1u) v = ~v;                                           // complement: 3 - c
+                    if (on && (f & 4u) && j < W2) reinterpret_cast<uint32_t*>(s_win + (size_t)rr * ROW + WOFF)[j] = v;
+                }
             }
         } else
         for (int kb = 0; kb < n; kb += 4 * WAVE) {                                  // one round for L <= 256
@@ -1132,7 +1169,7 @@ __device__ __forceinline__ void reads_body(const uint32_t bid, const uint8_t* __
                 }
             }
         }
-        __syncthreads();
+        lds_barrier();
         if (live) {
             // U[t] patched at t = k1 - pos(e) with comp(alt) (semi) and at t = pos(e) with alt (full); window index of t:
             // read 1: t - pos ; read 2: pos + isz - 1 - t, complemented
@@ -1157,6 +1194,7 @@ __device__ __forceinline__ void reads_body(const uint32_t bid, const uint8_t* __
         }
     }
 
+    SCS_PHASE(1);
     // ---- phase 1: the indel events of my read: computed by k_indels ahead of this launch (pair mode), or here
     const uint32_t aux = rd | (att << 1);
     LdsU16* my_ev = (LdsU16*)(s_ev + tid * EV_MAX);
@@ -1178,7 +1216,8 @@ __device__ __forceinline__ void reads_body(const uint32_t bid, const uint8_t* __
             my_xa[0] = xa.s0; my_xa[1] = xa.s1; my_xa[2] = xa.s2; my_xa[3] = xa.s3;
         }
     }
-    __syncthreads();                                                               // also: everyone is done with s_gbase/s_gflag (ring alias)
+    lds_barrier();                                                               // also: everyone is done with s_gbase/s_gflag (ring alias)
+    SCS_PHASE(2);
 
     // ---- phase 2: the base pass (Profile.cpp:1632-1694), workgroup-synchronous over the TABLE BINS.  Output position j of a
     // read uses the rows of bin j*binCount/n'; the workgroup walks the bins together and every read emits the positions
@@ -1240,7 +1279,7 @@ __device__ __forceinline__ void reads_body(const uint32_t bid, const uint8_t* __
     // the bins' images come ready-made from global memory (DevTables::ring1/2): a group of GROUP bins is one contiguous run of
     // GROUP * EPB 16-byte entries there and in the ring
     constexpr int GE = GROUP * (int)(sizeof(Bin) / 16), NPRE = (GE + RB - 1) / RB;
-    const uint4* __restrict__ ring_img = (FROM_PAIRS && second && tb.ring2) ? tb.ring2 : tb.ring1;
+    const uint4* __restrict__ ring_img = UNI ? ((second && tb.ring2u) ? tb.ring2u : tb.ring1u) : ((FROM_PAIRS && second && tb.ring2) ? tb.ring2 : tb.ring1);
     u32x4_t* ring16 = reinterpret_cast<u32x4_t*>(s_dyn);
     u32x4_t pre[NPRE];
     auto prefetch = [&](int first) __attribute__((always_inline)) {               // bins [first, first+GROUP) -> registers
@@ -1258,7 +1297,8 @@ __device__ __forceinline__ void reads_body(const uint32_t bid, const uint8_t* __
     for (int idx = tid; idx < GE; idx += RB) ring16[idx] = reinterpret_cast<const u32x4_t*>(ring_img)[idx];
     if (UNI && tid < 64) s_head[tid] = reinterpret_cast<const uint32_t*>(ring_img + (size_t)((B + 7) & ~7) * (sizeof(Bin) / 16))[tid];
     prefetch(GROUP);
-    __syncthreads();
+    lds_barrier();
+    SCS_PHASE(3);
 
     // a substituted base (k != c2) needs an off-diagonal quality row, which only global memory holds.  Its quality does
     // not feed back into the walk, so the lookup is deferred: (position, k, c2, bin, draw) is set aside and resolved after
@@ -1290,8 +1330,6 @@ __device__ __forceinline__ void reads_body(const uint32_t bid, const uint8_t* __
         const LdsU8* ring8 = (const LdsU8*)s_dyn;
         const LdsU32* win32 = (const LdsU32*)my_win;
         const LdsU8* head8 = (const LdsU8*)s_head;
-        LdsU8* row8 = (LdsU8*)my_pend_lds;
-        LdsU8* dummy8 = (LdsU8*)(s_head + 62);
         const bool force_redo = (force_replay & 2u) != 0;
         char* __restrict__ spare = reinterpret_cast<char*>(flags) + 128;               // 32 bytes nobody reads (the flags buffer is 256 bytes)
         uint32_t wreg = 0, wnext = 0, sel = 0, qacc = 0, nbad = 0;
@@ -1308,8 +1346,8 @@ __device__ __forceinline__ void reads_body(const uint32_t bid, const uint8_t* __
         //   finish_b(u-1): the symbol is back -> pending-quality bookkeeping, the output words
         // with the ring's refill (commit, barrier, prefetch) between finish_a and start: every ring read of a group is issued
         // before its wave arrives at the next group's barrier, as the refill's slot reuse assumes.
-        uint32_t aT0 = 0, aT1 = 0, aT2 = 0, aE = 0, aX1 = 0, aX2 = 0, aC2 = 0; const LdsU8* aQ = ring8;   // start -> finish_a
-        uint32_t bK = 0, bC2 = 0, bX2 = 0, bSym = 0; bool bUgly = false;                                   // finish_a -> finish_b
+        uint32_t aLo = 0, aWid = 0, aE = 0, aX1 = 0, aX2 = 0, aC2 = 0, aRow = 0; const LdsU8* aQ = ring8;   // start -> finish_a
+        uint32_t bC2 = 0, bX1 = 0, bX2 = 0, bSym = 0, bRow = 0; bool bKept = true;                          // finish_a -> finish_b
         // (FIRST: t0 == 0, as a compile-time constant -- a run-time test would put branches between the positions, and a branch around
         // the stores makes the compiler's s_waitcnt before the next ring commit cover them on every path: vmcnt(1) instead of vmcnt(5))
         auto start = [&](auto U, auto FIRST, int t0) __attribute__((always_inline)) {
@@ -1327,33 +1365,40 @@ __device__ __forceinline__ void reads_body(const uint32_t bid, const uint8_t* __
             }
             uint32_t x1, x2; xb.next2(x1, x2);                                       // one step of stream B per position
             const LdsU8* bin8 = ring8 + (u & (SLOTS - 1)) * sizeof(Bin);
-            const LdsU8* st8 = bin8 + 4 * QROW * 16 + ((c0 << 4) | (c1 << 2) | c2) * 12u;
-            if constexpr (u < 2 && first) st8 = head8 + (u == 0 ? c2 : 4u + c1 * 4u + c2) * 12u;   // the read's first two bases: 1-mer / 2-mer rows
-            const LdsU32* st = (const LdsU32*)st8;
+            uint32_t rowi = (c0 << 4) | (c1 << 2) | c2;                               // the clean 3-mer: row 20 + rowi of the substitution table
+            const LdsU8* kp8 = bin8 + 4 * QROW * 16 + rowi * 8u;
+            if constexpr (u < 2 && first) { rowi = u == 0 ? c2 : 4u + c1 * 4u + c2; kp8 = head8 + rowi * 8u; }   // the read's first two bases: 1-mer / 2-mer rows (table rows 0..19)
             const LdsU32* qrow = (const LdsU32*)(bin8 + c2 * (uint32_t)(QROW * 16));   // the diagonal row (c2, c2) as an alias row
-            aT0 = st[0]; aT1 = st[1]; aT2 = st[2]; aE = qrow[x2 >> (32u - Geo::ABITS)];
-            aQ = (const LdsU8*)(qrow + QK); aX1 = x1; aX2 = x2; aC2 = c2;
+            const u32x2_t kp = *(const LdsU2*)kp8;                                    // the draws that keep the base: lo <= x1 < lo + width
+            aLo = kp.x; aWid = kp.y; aE = qrow[x2 >> (32u - Geo::ABITS)];
+            aQ = (const LdsU8*)(qrow + QK); aX1 = x1; aX2 = x2; aC2 = c2; aRow = rowi;
             c0 = c1; c1 = c2;
             __builtin_amdgcn_sched_barrier(0);
         };
         auto finish_a = [&]() __attribute__((always_inline)) {
-            bK = (aX1 >= aT0) + (aX1 >= aT1) + (aX1 >= aT2);
+            bKept = aX1 - aLo < aWid;                                                 // k == c2 (never for the draw 0xFFFFFFFF)
             const uint32_t col = aX2 >> (32u - Geo::ABITS);
             const uint32_t pick = ((aX2 << Geo::ABITS) | (uint32_t)(QK - 1)) < aE ? col : (aE & (uint32_t)(QK - 1));   // alias_pick
             bSym = aQ[pick];
-            bC2 = aC2; bX2 = aX2; bUgly = aX1 == 0xFFFFFFFFu;
+            bC2 = aC2; bX1 = aX1; bX2 = aX2; bRow = aRow;
             __builtin_amdgcn_sched_barrier(0);
         };
-        auto finish_b = [&](auto U, int t, bool last) __attribute__((always_inline)) {   // t: the position being finished, u = t & 15
+        auto finish_b = [&](auto U, auto HEAD, int t, bool last) __attribute__((always_inline)) {   // t: the position being finished, u = t & 15
             constexpr int u = decltype(U)::value;
-            // (bitwise, not short-circuit: no divergent region between two positions; lanes without a read count along, ignored later)
-            const bool sub = bK != bC2;
-            const bool wr = sub & !bUgly & (npend <= ((uint32_t)t + 48u) >> 5) & !force_redo;   // entry e fits once 32e - 48 <= t
-            nbad += (sub | bUgly) ? 1u : 0u;                                          // nbad != npend after the pass: the read is made again
-            LdsU8* slot8 = wr ? row8 + 8u * npend : dummy8;
-            *(LdsU2*)slot8 = u32x2_t{((((bC2 << 2) | bK) << 12)) | ((uint32_t)t * 0x10001u), bX2};   // position | k << 12 | c2 << 14 | bin << 16
-            npend += wr ? 1u : 0u;
-            sel |= bK << (8 * (u & 3)); qacc |= bSym << (8 * (u & 3));                // base selectors and raw qualities, four to a word
+            // The walk writes the WINDOW's base and the diagonal row's quality; a position whose draw does not keep the base (a
+            // substitution: a few per thousand; or the draw 0xFFFFFFFF) is set aside -- (position | table row, x1, x2), three words --
+            // and resolved after the pass from the global tables, base and quality patched into the text.  Only a wave in which SOME
+            // lane has one enters the block (a wave-uniform branch: one position in four or five); lanes without a read count along,
+            // ignored later.  Entry e lies in the row's dwords 3e .. 3e + 2: the first two in front of the window, entry e >= 2 over the
+            // window's dwords 3e - 6 .. 3e - 4, which the walk has read once t >= 16 (3e - 4).
+            if (__ballot(!bKept)) {
+                const bool bad = !bKept, ugly = bX1 == 0xFFFFFFFFu;
+                const bool wr = bad & !ugly & (npend <= (((uint32_t)t >> 4) + 4u) / 3u) & !force_redo;
+                nbad += bad ? 1u : 0u;                                                // nbad != npend after the pass: the read is made again
+                if (wr) { LdsU32* e = my_pend_lds + 3u * npend; e[0] = (uint32_t)t | ((bRow + (decltype(HEAD)::value ? 0u : 20u)) << 10); e[1] = bX1; e[2] = bX2; }
+                npend += wr ? 1u : 0u;
+            }
+            sel |= bC2 << (8 * (u & 3)); qacc |= bSym << (8 * (u & 3));               // base selectors and raw qualities, four to a word
             if ((u & 3) == 3 || last) {
                 uint32_t wb = __builtin_amdgcn_perm(0x4Eu, 0x54474341u, sel), wq = qacc + 0x21212121u;   // selector 0..3 -> "ACGT"; + 33
                 if constexpr ((u & 3) != 3) { const uint32_t m = (1u << (8 * ((u & 3) + 1))) - 1u; wb &= m; wq &= m; }   // the read's last, partial word
@@ -1370,9 +1415,9 @@ __device__ __forceinline__ void reads_body(const uint32_t bid, const uint8_t* __
                 const int t = t0 + u;
                 if (mode == 0 && t >= NP) return;
                 if constexpr (u > 0 || !first) finish_a();
-                if constexpr ((u & (GROUP - 1)) == 0 && (u > 0 || !first)) { commit(t); __syncthreads(); prefetch(t + GROUP); }
+                if constexpr ((u & (GROUP - 1)) == 0 && (u > 0 || !first)) { commit(t); lds_barrier(); prefetch(t + GROUP); }
                 start(U, FIRST, t0);
-                if constexpr (u > 0 || !first) finish_b(std::integral_constant<int, (u + 15) & 15>{}, t - 1, false);
+                if constexpr (u > 0 || !first) finish_b(std::integral_constant<int, (u + 15) & 15>{}, std::integral_constant<bool, first && (u == 1 || u == 2)>{}, t - 1, false);
                 // The previous 16 characters leave HERE, right behind the ring's loads.  On this hardware loads and stores complete
                 // out of order with each other, so a wait for a load (the next commit) is a wait for EVERY outstanding store too
                 // (s_waitcnt vmcnt(0)); placed here that wait comes a whole group of positions after the stores, when their round
@@ -1394,14 +1439,15 @@ __device__ __forceinline__ void reads_body(const uint32_t bid, const uint8_t* __
         for (; t0 + 16 < NP; t0 += 16) steps(std::integral_constant<int, 2>{}, std::false_type{}, t0);
         if (t0 == 0) steps(std::integral_constant<int, 0>{}, std::true_type{}, 0); else steps(std::integral_constant<int, 0>{}, std::false_type{}, t0);
         finish_a();                                                                 // drain: the read's last position
-        unroll_steps([&](auto U) __attribute__((always_inline)) { if (decltype(U)::value == ((NP - 1) & 15)) finish_b(U, NP - 1, true); }, std::make_integer_sequence<int, 16>{});
+        unroll_steps([&](auto U) __attribute__((always_inline)) { if (decltype(U)::value == ((NP - 1) & 15)) finish_b(U, std::false_type{}, NP - 1, true); }, std::make_integer_sequence<int, 16>{});
         redo = mine && nbad != npend;
         if (!mine) npend = 0;
+        SCS_PHASE(4);
     } else
     for (int t = 0; t < B; ++t) {
         if ((t & (GROUP - 1)) == 0 && t > 0) {
             commit(t);
-            __syncthreads();
+            lds_barrier();
             prefetch(t + GROUP);
         }
         const Bin* rb = &s_ring[t & (SLOTS - 1)];
@@ -1538,6 +1584,21 @@ __device__ __forceinline__ void reads_body(const uint32_t bid, const uint8_t* __
         bo_b.tail(wg_out, sec1, a1, m, nw, nv, 0x0A2B0Au, (s1 + (uint32_t)n_out + 3u - s2) >> 2, 0u);   // the bases' dwords end where the qualities' first one starts
         bo_q.tail(wg_out, sec2, a2, m, nw, nv, 0x0Au, nq >> 2, nq & 3u);
     }
+    SCS_PHASE(5);
+    if constexpr (UNI) {
+        // the positions the uniform walk set aside: base call and quality from the global tables (bin = position), patched into the
+        // text behind the record's own stores (same lane: program order)
+        for (uint32_t e = 0; e < npend; ++e) {
+            const uint32_t w0 = my_pend_lds[3u * e], x1 = my_pend_lds[3u * e + 1u], x2 = my_pend_lds[3u * e + 2u];
+            const uint32_t pos = w0 & 1023u, ki = w0 >> 10, pc = ki & 3u;
+            const uint4 T = *reinterpret_cast<const uint4*>(subs + ((size_t)ki * (uint32_t)B + pos) * 4u);
+            const uint32_t pk = (x1 >= T.x) + (x1 >= T.y) + (x1 >= T.z);
+            const uint32_t* __restrict__ arow = tb.qual_alias + (size_t)((pc * 4u + pk) * (uint32_t)B + pos) * (QK + QK / 4);
+            const uint32_t qv = alias_pick<QK>(arow, reinterpret_cast<const uint8_t*>(arow + QK), x2);
+            wg_out[sec1 + a1 + pos] = (char)((0x54474341u >> (8u * pk)) & 255u);
+            wg_out[sec2 + a2 + pos] = (char)(33u + qv);
+        }
+    } else
     for (uint32_t e = 0; e < npend; ++e) {                                         // deferred qualities of substituted bases
         uint2 pe;
         if (FROM_PAIRS) { pe.x = my_pend_lds[2u * e]; pe.y = my_pend_lds[2u * e + 1u]; } else pe = my_pend[e];
@@ -1547,6 +1608,7 @@ __device__ __forceinline__ void reads_body(const uint32_t bid, const uint8_t* __
         if (FROM_PAIRS) wg_out[sec2 + a2 + (pe.x & 4095u)] = (char)(33u + qv);    // after the record's own stores (same lane: program order)
         else my_q[pe.x & 4095u] = (char)(33u + qv);
     }
+    SCS_PHASE(6);
     if constexpr (UNI) {
         if (redo) {
             const int64_t dir = (pr.flags & 2u) ? -1 : 1; const uint32_t comp = pr.flags & 1u;
@@ -1559,6 +1621,10 @@ __device__ __forceinline__ void reads_body(const uint32_t bid, const uint8_t* __
     if (live && !FROM_PAIRS) {
         lens[r] = (uint32_t)n_out;
     }
+    SCS_PHASE(7);
+#ifdef SCS_PHASE_CLOCK
+    if (UNI && CLS == 1 && tid == 0) atomicAdd(&g_phase[15], 1ull);
+#endif
 }
 
 // (bid: the workgroup's index within ITS class' grid -- blockIdx.x of a launch of one class, or blockIdx.x less the grids of the
@@ -2368,7 +2434,8 @@ void ReadsSide::release() {
 }
 size_t reads_lds_bytes(const DevTables& tb, bool uni) {
     const size_t ring = tb.qual_k == 16 ? RingGeo<16>::SLOTS * sizeof(RingBin<16>) : tb.qual_k == 64 ? RingGeo<64>::SLOTS * sizeof(RingBin<64>) : RingGeo<128>::SLOTS * sizeof(RingBin<128>);
-    if (uni) return ring + (size_t)RB * uni_row_bytes((uint32_t)tb.L) + 256;       // + the head rows
+    const size_t ring_u = tb.qual_k == 16 ? RingGeo<16>::SLOTS * sizeof(RingBinU<16>) : tb.qual_k == 64 ? RingGeo<64>::SLOTS * sizeof(RingBinU<64>) : RingGeo<128>::SLOTS * sizeof(RingBinU<128>);
+    if (uni) return ring_u + (size_t)RB * uni_row_bytes((uint32_t)tb.L) + 256;     // + the head rows
     return ring + (size_t)RB * EV_MAX * 2 + (size_t)RB * win_stride((uint32_t)tb.L);
 }
 template <bool FROM_PAIRS, int CLS, class... Args>
@@ -2597,4 +2664,16 @@ void exclusive_scan_u32_to_u64(hipStream_t s, const uint32_t* in, uint64_t* out,
     (void)rocprim::exclusive_scan(temp, temp_bytes, rocprim::make_transform_iterator(in, Widen()), out, (uint64_t)0, n + 1, rocprim::plus<uint64_t>(), s);
 }
 
+void phase_clock_report() {
+#ifdef SCS_PHASE_CLOCK
+    unsigned long long h[16] = {}, z[16] = {};
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_phase), sizeof h) != hipSuccess || !h[15]) return;
+    static const char* nm[8] = {"lists, records, sort by sector phase", "window gather + error patch", "event words", "seed, name line, ring fill", "the walk", "tails", "deferred positions", "redo"};
+    fprintf(stderr, "[phase clock] %llu workgroups of the uniform walk; mean time of thread 0 per phase (us):", h[15]);
+    double tot = 0; for (int i = 0; i < 8; ++i) tot += (double)h[i];
+    for (int i = 0; i < 8; ++i) fprintf(stderr, "  %s %.2f", nm[i], (double)h[i] / (double)h[15] / 100.0);
+    fprintf(stderr, "  | total %.2f\n", tot / (double)h[15] / 100.0);
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof z);
+#endif
+}
 }  // namespace scs

@@ -160,7 +160,7 @@ struct scs_ctx {
     RngKey key{0, 0};
     // model
     ProfileTables prof; bool have_profile = false; DevTables dtb{};
-    DevBuf d_tables, t_gap, t_qcompact, t_guide, t_ring1, t_ring2, t_subs1, t_subs2, t_qual, t_ins, t_del, t_isize, d_subs1, d_subs2, d_qual, d_ins, d_del, d_isize, d_gcmeans;
+    DevBuf d_tables, t_gap, t_qcompact, t_guide, t_ring1, t_ring2, t_ring1u, t_ring2u, t_subs1, t_subs2, t_qual, t_ins, t_del, t_isize, d_subs1, d_subs2, d_qual, d_ins, d_del, d_isize, d_gcmeans;
     // genome + fragments
     DevBuf gx_gc_bits, gx_n_bits, gx_gc_cnt, gx_n_cnt, gx_gc_pref, gx_n_pref, d_binom;
     std::vector<FastaRecord> recs; bool have_genome = false; DevBuf genome, genome2; std::vector<uint64_t> rec_off, rec_len; uint64_t genome_bases = 0;   // recs: names only once staged
@@ -317,13 +317,35 @@ void do_load_profile(scs_ctx* c, const char* path) {
         }
         return img;
     };
+    // the uniform walk's image (RingBinU): instead of the three thresholds, the interval of draws that KEEP the window's base c
+    // of the 3-mer -- k = (x >= T0) + (x >= T1) + (x >= T2) equals c  <=>  lo <= x < hi with lo = T[c-1] (0 for c = 0), hi = T[c]
+    // (2^32 for c = 3) -- as (lo, width): kept <=> x - lo < width, one subtraction and one compare.  hi is capped at 2^32 - 1, so the
+    // draw 0xFFFFFFFF (whose base call needs the double tables) is never "kept" and takes the walk's rare path like a substitution.
+    auto keep_pair = [&](const uint32_t* T, uint32_t cbase, uint32_t* out) {
+        const uint32_t lo = cbase ? T[cbase - 1] : 0u, hi = cbase < 3 ? T[cbase] : 0xFFFFFFFFu;
+        out[0] = lo; out[1] = hi > lo ? hi - lo : 0u;
+    };
+    auto ring_image_u = [&](const std::vector<uint32_t>& subs_t) {
+        const size_t B = (size_t)P.bins, qw = (size_t)P.qual_k + (size_t)P.qual_k / 4, bw = 4 * qw + 128, Bpad = (B + 7) & ~(size_t)7;
+        std::vector<uint32_t> img(Bpad * bw + 64, 0u);                              // + the head: the 1-mers at bin 0 and the 2-mers at bin 1
+        for (size_t ki = 0; ki < 20 && B >= 2; ++ki) keep_pair(subs_t.data() + (ki * B + (ki < 4 ? 0 : 1)) * 4, (uint32_t)(ki & 3), img.data() + Bpad * bw + ki * 2);
+        for (size_t b = 0; b < B; ++b) {
+            uint32_t* d = img.data() + b * bw;
+            for (size_t cc = 0; cc < 4; ++cc) memcpy(d + cc * qw, P.qual_alias.data() + ((cc * 5) * B + b) * qw, qw * 4);
+            for (size_t kk = 0; kk < 64; ++kk) keep_pair(subs_t.data() + ((20 + kk) * B + b) * 4, (uint32_t)(kk & 3), d + 4 * qw + kk * 2);
+        }
+        return img;
+    };
     upload(c->t_ring1, ring_image(P.subs1_t), s);
     if (P.have_cdf2) upload(c->t_ring2, ring_image(P.subs2_t), s);
+    upload(c->t_ring1u, ring_image_u(P.subs1_t), s);
+    if (P.have_cdf2) upload(c->t_ring2u, ring_image_u(P.subs2_t), s);
     HIP_OK(hipStreamSynchronize(s));
     DevTables& t = c->dtb;
     t.L = P.read_length; t.bins = P.bins; t.t_insert = P.t_insert; t.t_delete = P.t_delete; t.t_indel = P.t_indel; t.t_ber = threshold_lt(c->cfg.ber); t.gap_t = c->t_gap.as<uint32_t>(); t.t_kind = P.t_kind;
     t.subs1 = c->t_subs1.as<uint32_t>(); t.subs2 = P.have_cdf2 ? c->t_subs2.as<uint32_t>() : nullptr; t.qual = c->t_qual.as<uint32_t>(); t.qual_alias = c->t_qcompact.as<uint32_t>(); t.qual_k = P.qual_k;
     t.ring1 = c->t_ring1.as<uint4>(); t.ring2 = P.have_cdf2 ? c->t_ring2.as<uint4>() : nullptr;
+    t.ring1u = c->t_ring1u.as<uint4>(); t.ring2u = P.have_cdf2 ? c->t_ring2u.as<uint4>() : nullptr;
     t.ins_t = c->t_ins.as<uint32_t>(); t.n_ins = (int)P.ins_t.size(); t.del_t = c->t_del.as<uint32_t>(); t.n_del = (int)P.del_t.size();
     t.isize_t = c->t_isize.as<uint32_t>(); t.n_isize = (int)P.isize_t.size(); t.isize_min = P.isize_min;
     t.subs1_d = c->d_subs1.as<double>(); t.subs2_d = P.have_cdf2 ? c->d_subs2.as<double>() : nullptr; t.qual_d = c->d_qual.as<double>();
@@ -1199,6 +1221,7 @@ void do_yield(scs_ctx* c, const OutTarget& tg, uint64_t* n1_out, uint64_t* n2_ou
     const uint64_t per_pair_tmpl = paired ? (uint64_t)(c->cfg.isize + 1) : (uint64_t)L;
     c->st.algorithmic_bytes = 1526ull * (c->st.semi_amplicons + c->st.full_amplicons) + pairs_written * per_pair_tmpl + tot1 + tot2;
     if (n1_out) *n1_out = tot1; if (n2_out) *n2_out = tot2; if (pairs_out) *pairs_out = pairs_written;
+    if (getenv("SCS_PHASE_CLOCK")) phase_clock_report();                         // (prints only in a -DSCS_PHASE_CLOCK build)
     if (c->cfg.verbose) fprintf(stderr, "\nReads generation done!\n");
 }
 
@@ -1255,7 +1278,7 @@ void scs_destroy(scs_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->cfg.device);
     (void)hipStreamSynchronize(c->stream);
-    for (DevBuf* b : {&c->d_tables, &c->t_gap, &c->t_qcompact, &c->t_guide, &c->t_ring1, &c->t_ring2, &c->t_subs1, &c->t_subs2, &c->t_qual, &c->t_ins, &c->t_del, &c->t_isize, &c->d_subs1, &c->d_subs2, &c->d_qual, &c->d_ins, &c->d_del,
+    for (DevBuf* b : {&c->d_tables, &c->t_gap, &c->t_qcompact, &c->t_guide, &c->t_ring1, &c->t_ring2, &c->t_ring1u, &c->t_ring2u, &c->t_subs1, &c->t_subs2, &c->t_qual, &c->t_ins, &c->t_del, &c->t_isize, &c->d_subs1, &c->d_subs2, &c->d_qual, &c->d_ins, &c->d_del,
                       &c->d_isize, &c->d_gcmeans, &c->genome, &c->genome2, &c->gx_gc_bits, &c->gx_n_bits, &c->gx_gc_cnt, &c->gx_n_cnt, &c->gx_gc_pref, &c->gx_n_pref, &c->d_binom, &c->df_blob, &c->df_primers, &c->df_hasn, &c->primer_cnt, &c->primer_delta,
                       &c->slots, &c->slot_tmpl, &c->slots_fr, &c->slot_tmpl_fr, &c->valid, &c->valid_off, &c->valid_f, &c->valid_off_f, &c->scan_tmp, &c->flags, &c->weights, &c->read_numbers,
                       &c->pair_off, &c->pairs, &c->odd_before, &c->a_part, &c->a_tp, &c->a_probs, &c->a_quota, &c->a_poff, &c->a_plan, &c->a_crn, &c->a_scratch, &c->a_brow, &c->a_bmap, &c->a_send, &c->a_gath, &c->a_odd, &c->d_hostred, &c->d_tot, &c->d_stage, &c->d_mail, &c->budget_f, &c->budget_s, &c->poisson_part, &c->slot_off_f,
