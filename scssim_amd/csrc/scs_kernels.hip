@@ -1034,36 +1034,76 @@ __device__ __forceinline__ void reads_body(const uint32_t bid, const uint8_t* __
 #endif
     SCS_PHASE(-1);
 
-    // the workgroup's records are contiguous: stores address them as a uniform base (aligned down to a sector) + a 32-bit offset
     const bool second_file = FROM_PAIRS && paired && (bid & 1u);
     const uint64_t* __restrict__ offs = second_file ? off2 : off1;
     char* __restrict__ outp = second_file ? out2 : out1;
     const uint32_t* __restrict__ wlist = second_file ? list2 : list1;              // CLS != 0: this mate's list
     const uint32_t nwork = CLS == 0 ? np : (second_file ? nlist2 : nlist1), wq = (paired ? bid >> 1 : bid) * RB;
     if (FROM_PAIRS && wq >= nwork) return;                                          // the grid covers the longer of the two mates' lists
-    const uint64_t off0 = FROM_PAIRS ? (offs[CLS == 0 ? wq : wlist[wq]] & OFF_MASK) : 0ull;      // lists ascend: the chunk's first record is its lowest
-    const uint32_t adj = (uint32_t)(reinterpret_cast<uintptr_t>(outp) + off0) & 31u;
-    char* __restrict__ wg_out = outp + off0 - adj;
+    // ---- the table ring's first two groups of bins and the head rows: their loads leave FIRST and ride through the whole prologue
+    // in registers (nothing they need is computed here; the LDS they go to is used for staging until the windows are in place).
+    // Ring maintenance: the bins of group gq = t/GROUP live in half (gq & 1) of the ring.  Group 0 is loaded up front; the
+    // bins of the next group are prefetched into registers one group ahead and written to LDS at the group boundary,
+    // into the half that group gq-2 used -- every wave left that group before the previous boundary's barrier, so one
+    // barrier per group is enough.
+    // the bins' images come ready-made from global memory (DevTables::ring1/2, ring1u/2u): a group of GROUP bins is one contiguous
+    // run of GROUP * EPB 16-byte entries there and in the ring
+    constexpr int GE = GROUP * (int)(sizeof(Bin) / 16), NPRE = (GE + RB - 1) / RB;
+    const bool second_wg = FROM_PAIRS && paired && (bid & 1u) && tb.subs2 != nullptr;      // (slot mode: the ring holds read 1's rows)
+    const uint4* __restrict__ ring_img = UNI ? ((second_wg && tb.ring2u) ? tb.ring2u : tb.ring1u) : ((second_wg && tb.ring2) ? tb.ring2 : tb.ring1);
+    u32x4_t* ring16 = reinterpret_cast<u32x4_t*>(s_dyn);
+    u32x4_t pre[NPRE], ring0[NPRE];
+    auto prefetch = [&](int first) __attribute__((always_inline)) {               // bins [first, first+GROUP) -> registers
+        // (unconditional loads: past the table's end the last group is fetched again, and an entry index past the group's is clamped)
+        const u32x4_t* __restrict__ src = reinterpret_cast<const u32x4_t*>(ring_img) + (size_t)min(first, ((B + 7) & ~7) - GROUP) * (sizeof(Bin) / 16);
+#pragma unroll
+        for (int u = 0; u < NPRE; ++u) pre[u] = src[min(tid + u * RB, GE - 1)];
+        __builtin_amdgcn_sched_barrier(0);                                         // the loads leave HERE, a group ahead of their use (the scheduler would sink them to the commit and wait there)
+    };
+    auto commit = [&](int first) __attribute__((always_inline)) {                 // registers -> LDS slots of bins [first, first+GROUP)
+        u32x4_t* dst = ring16 + (first & (SLOTS - 1)) * (int)(sizeof(Bin) / 16);
+#pragma unroll
+        for (int u = 0; u < NPRE; ++u) { const int idx = tid + u * RB; if (idx < GE) dst[idx] = pre[u]; }
+    };
+#pragma unroll
+    for (int u = 0; u < NPRE; ++u) ring0[u] = reinterpret_cast<const u32x4_t*>(ring_img)[min(tid + u * RB, GE - 1)];
+    const uint32_t head_w = UNI ? reinterpret_cast<const uint32_t*>(ring_img + (size_t)((B + 7) & ~7) * (sizeof(Bin) / 16))[tid & 63] : 0u;
+    prefetch(GROUP);
 
     // ---- which read is mine
     uint32_t r, pi = 0, rd; bool valid; PairRec pr{}; uint64_t uid = 0; uint32_t att = 0;
     uint32_t rec_rel = 0, rec_h = 0;                                               // pair mode: my record's offset from wg_out, length of its name line
+    uint64_t off0 = 0, my_off = 0;                                                 // pair mode: the byte offsets of the chunk's first record and of mine in the batch's text
+    uint32_t ev_h = 0; uint4 ev_e = make_uint4(0, 0, 0, 0);                        // pair mode: my read's event words (k_indels), loaded as soon as the read is known
     if (FROM_PAIRS) {
         const uint32_t q = paired ? bid >> 1 : bid;
         rd = paired ? (bid & 1u) : 0u;
         // The workgroup's 256 reads are handed to its lanes ORDERED BY THE SECTOR PHASE of their bases (byte address & 31):
         // a lane stores a sector whenever its stream crosses a 32-byte boundary, and lanes of one wave that do so at the
         // same positions share the store instructions.  (Which lane makes which read does not show in the output.)
-        uint32_t* s_cnt = reinterpret_cast<uint32_t*>(s_win); uint32_t* s_perm = s_cnt + 64;   // s_win is free until the staging
-        auto record_of = [&](uint32_t p, PairRec& o, uint32_t& rel, uint32_t& h) {
-            o = pairs[p];
-            const uint32_t amp = amp_index_base + o.amp, cnt = o.att + 1u;
-            h = 1u + dec_digits(amp) + 1u + dec_digits(cnt) + (paired ? 2u : 0u) + 1u;   // "@<amp>#<cnt>[/1|/2]\n"
-            rel = (uint32_t)((offs[p] & OFF_MASK) - off0) + adj;
-        };
+        // Every thread fetches ONE record (list entry -> pair record + text offset: two dependent rounds of loads), parks it in LDS
+        // and picks up the record its sorted place gives it from there: the second trip to global memory this used to be is gone.
+        constexpr uint32_t SR = 19;                                                // parked record: 14 words PairRec, offset (2), pair index, name-line length; odd stride
+        uint32_t* s_park = reinterpret_cast<uint32_t*>(s_dyn);                     // [RB][SR]  (everything in LDS is free until the windows are staged)
+        uint32_t* s_cnt = s_park + RB * SR; uint32_t* s_perm = s_cnt + 64;
+        const uint32_t out_lo = (uint32_t)reinterpret_cast<uintptr_t>(outp);
         uint32_t keyp = 32u;
         auto pair_of = [&](uint32_t e) -> uint32_t { return e < nwork ? (CLS == 0 ? e : wlist[e]) : 0xFFFFFFFFu; };
-        { const uint32_t p = pair_of(q * RB + tid); if (p != 0xFFFFFFFFu) { PairRec o; uint32_t rel, h; record_of(p, o, rel, h); keyp = (rel + h) & 31u; } }
+        {
+            const uint32_t p = pair_of(q * RB + tid);
+            uint32_t* st = s_park + (uint32_t)tid * SR;
+            st[16] = p;
+            if (p != 0xFFFFFFFFu) {
+                const PairRec o = pairs[p]; const uint64_t of = offs[p] & OFF_MASK;
+                const uint32_t amp = amp_index_base + o.amp, cnt = o.att + 1u;
+                const uint32_t h = 1u + dec_digits(amp) + 1u + dec_digits(cnt) + (paired ? 2u : 0u) + 1u;   // "@<amp>#<cnt>[/1|/2]\n"
+                keyp = (out_lo + (uint32_t)of + h) & 31u;                           // sector phase of the record's first base
+                uint32_t w[14]; __builtin_memcpy(w, &o, 56);
+#pragma unroll
+                for (int i = 0; i < 14; ++i) st[i] = w[i];
+                st[14] = (uint32_t)of; st[15] = (uint32_t)(of >> 32); st[17] = h;
+            }
+        }
         if (tid < 64) s_cnt[tid] = 0;
         lds_barrier();
         const uint32_t rank = atomicAdd(&s_cnt[keyp], 1u);
@@ -1077,15 +1117,29 @@ __device__ __forceinline__ void reads_body(const uint32_t bid, const uint8_t* __
         lds_barrier();
         s_perm[s_cnt[keyp] + rank] = (uint32_t)tid;
         lds_barrier();
-        pi = pair_of(q * RB + s_perm[tid]); valid = pi != 0xFFFFFFFFu;
+        const uint32_t* sm = s_park + s_perm[tid] * SR;
+        pi = sm[16]; valid = pi != 0xFFFFFFFFu;
         r = paired ? 2 * pi + rd : pi;
-        if (valid) { record_of(pi, pr, rec_rel, rec_h); uid = pr.uid; att = pr.att; }
-        lds_barrier();                                                           // s_perm is read before the staging overwrites it
+        off0 = ((uint64_t)s_park[15] << 32) | s_park[14];                          // lists ascend: the chunk's first record (always there) is its lowest
+        if (valid) {
+            ev_h = ev_hdr[r]; ev_e = ev_dat[r];
+            uint32_t w[14];
+#pragma unroll
+            for (int i = 0; i < 14; ++i) w[i] = sm[i];
+            __builtin_memcpy(&pr, w, 56);
+            my_off = ((uint64_t)sm[15] << 32) | sm[14]; rec_h = sm[17];
+            uid = pr.uid; att = pr.att;
+        }
+        lds_barrier();                                                           // the parked records are read before the staging overwrites them
         SCS_PHASE(0);
     } else {
         r = bid * RB + tid; valid = r < n_explicit; rd = 0;
         if (valid) { uid = uids[r]; att = atts[r]; rd = is_read1[r] ? 0u : 1u; }
     }
+    // the workgroup's records are contiguous: stores address them as a uniform base (aligned down to a sector) + a 32-bit offset
+    const uint32_t adj = (uint32_t)(reinterpret_cast<uintptr_t>(outp) + off0) & 31u;
+    char* __restrict__ wg_out = outp + off0 - adj;
+    if (FROM_PAIRS && valid) rec_rel = (uint32_t)(my_off - off0) + adj;
     if (!FROM_PAIRS && valid && r >= n_slots_cap) { atomicOr(flags, (uint32_t)FLAG_INTERNAL); valid = false; }   // never write outside the slot buffers
     bool live = valid && (!FROM_PAIRS || pr.isz != 0);
 
@@ -1202,7 +1256,7 @@ __device__ __forceinline__ void reads_body(const uint32_t bid, const uint8_t* __
     int nev = 0, n_out = 0; bool replay = false; uint32_t replay_first = 0, del_pos = 0xFFFFu;
     if (live) {
         if (FROM_PAIRS) {
-            const uint32_t h = ev_hdr[r]; const uint4 e = ev_dat[r];
+            const uint32_t h = ev_h; const uint4 e = ev_e;
             n_out = (int)(h & 0xFFFFu); nev = SIMPLE ? 0 : (int)((h >> 16) & 0xFFu); replay = SIMPLE ? false : (h >> 24) & 1u;
             if (D1) del_pos = ev_pos(e.x & 0xFFFFu);                                 // its one event: the deleted base
             if (!UNI) { my_xa[0] = e.x; my_xa[1] = e.y; my_xa[2] = e.z; my_xa[3] = e.w; }   // 8 x 16-bit events
@@ -1244,7 +1298,7 @@ __device__ __forceinline__ void reads_body(const uint32_t bid, const uint8_t* __
     for (int i = 0; i < 4; ++i) { bo_b.R[i] = bo_q.R[i] = 0; bo_b.H[i] = bo_q.H[i] = 0; if (i < 3) bo_b.P[i] = bo_q.P[i] = 0; }
     // the record must lie inside the batch's text (its offset and size come from k_indels' n'; the walk below emits exactly
     // n' characters per stream): a disagreement would be an internal error, reported, never a store outside the buffer
-    if (FROM_PAIRS && live && n_out > 0 && (offs[pi] & OFF_MASK) + rec_h + 2ull * (uint32_t)n_out + 4ull > (second_file ? cap2 : cap1)) { atomicOr(flags, (uint32_t)FLAG_INTERNAL); live = false; n_out = 0; }
+    if (FROM_PAIRS && live && n_out > 0 && my_off + rec_h + 2ull * (uint32_t)n_out + 4ull > (second_file ? cap2 : cap1)) { atomicOr(flags, (uint32_t)FLAG_INTERNAL); live = false; n_out = 0; }
     if (FROM_PAIRS && live && n_out > 0) {
         const uint32_t amp = amp_index_base + pr.amp, cnt = pr.att + 1u, d2 = dec_digits(cnt), h = rec_h;
         const uint32_t o1 = rec_rel + h, o2 = o1 + (uint32_t)n_out + 3u;          // where the bases / the qualities start
@@ -1272,31 +1326,10 @@ __device__ __forceinline__ void reads_body(const uint32_t bid, const uint8_t* __
             else if (nb4) { wp -= nb4; for (uint32_t i = 0; i < nb4; ++i) wp[i] = (char)(w >> (8u * i)); }
         }
     }
-    // ring maintenance: the bins of group gq = t/GROUP live in half (gq & 1) of the ring.  Group 0 is loaded up front; the
-    // bins of the next group are prefetched into registers one group ahead and written to LDS at the group boundary,
-    // into the half that group gq-2 used -- every wave left that group before the previous boundary's barrier, so one
-    // barrier per group is enough.
-    // the bins' images come ready-made from global memory (DevTables::ring1/2): a group of GROUP bins is one contiguous run of
-    // GROUP * EPB 16-byte entries there and in the ring
-    constexpr int GE = GROUP * (int)(sizeof(Bin) / 16), NPRE = (GE + RB - 1) / RB;
-    const uint4* __restrict__ ring_img = UNI ? ((second && tb.ring2u) ? tb.ring2u : tb.ring1u) : ((FROM_PAIRS && second && tb.ring2) ? tb.ring2 : tb.ring1);
-    u32x4_t* ring16 = reinterpret_cast<u32x4_t*>(s_dyn);
-    u32x4_t pre[NPRE];
-    auto prefetch = [&](int first) __attribute__((always_inline)) {               // bins [first, first+GROUP) -> registers
-        // (unconditional loads: past the table's end the last group is fetched again, and an entry index past the group's is clamped)
-        const u32x4_t* __restrict__ src = reinterpret_cast<const u32x4_t*>(ring_img) + (size_t)min(first, ((B + 7) & ~7) - GROUP) * (sizeof(Bin) / 16);
+    // the ring's first group and the head rows leave their registers (loaded at the kernel's start) for the LDS the staging has freed
 #pragma unroll
-        for (int u = 0; u < NPRE; ++u) pre[u] = src[min(tid + u * RB, GE - 1)];
-        __builtin_amdgcn_sched_barrier(0);                                         // the loads leave HERE, a group ahead of their use (the scheduler would sink them to the commit and wait there)
-    };
-    auto commit = [&](int first) __attribute__((always_inline)) {                 // registers -> LDS slots of bins [first, first+GROUP)
-        u32x4_t* dst = ring16 + (first & (SLOTS - 1)) * (int)(sizeof(Bin) / 16);
-#pragma unroll
-        for (int u = 0; u < NPRE; ++u) { const int idx = tid + u * RB; if (idx < GE) dst[idx] = pre[u]; }
-    };
-    for (int idx = tid; idx < GE; idx += RB) ring16[idx] = reinterpret_cast<const u32x4_t*>(ring_img)[idx];
-    if (UNI && tid < 64) s_head[tid] = reinterpret_cast<const uint32_t*>(ring_img + (size_t)((B + 7) & ~7) * (sizeof(Bin) / 16))[tid];
-    prefetch(GROUP);
+    for (int u = 0; u < NPRE; ++u) { const int idx = tid + u * RB; if (idx < GE) ring16[idx] = ring0[u]; }
+    if (UNI && tid < 64) s_head[tid] = head_w;
     lds_barrier();
     SCS_PHASE(3);
 
@@ -2435,8 +2468,9 @@ void ReadsSide::release() {
 size_t reads_lds_bytes(const DevTables& tb, bool uni) {
     const size_t ring = tb.qual_k == 16 ? RingGeo<16>::SLOTS * sizeof(RingBin<16>) : tb.qual_k == 64 ? RingGeo<64>::SLOTS * sizeof(RingBin<64>) : RingGeo<128>::SLOTS * sizeof(RingBin<128>);
     const size_t ring_u = tb.qual_k == 16 ? RingGeo<16>::SLOTS * sizeof(RingBinU<16>) : tb.qual_k == 64 ? RingGeo<64>::SLOTS * sizeof(RingBinU<64>) : RingGeo<128>::SLOTS * sizeof(RingBinU<128>);
-    if (uni) return ring_u + (size_t)RB * uni_row_bytes((uint32_t)tb.L) + 256;     // + the head rows
-    return ring + (size_t)RB * EV_MAX * 2 + (size_t)RB * win_stride((uint32_t)tb.L);
+    const size_t park = (size_t)RB * 19 * 4 + 320 * 4;                              // the prologue's parked records + sort counters (pair mode)
+    if (uni) return std::max(park, ring_u + (size_t)RB * uni_row_bytes((uint32_t)tb.L) + 256);   // + the head rows
+    return std::max(park, ring + (size_t)RB * EV_MAX * 2 + (size_t)RB * win_stride((uint32_t)tb.L));
 }
 template <bool FROM_PAIRS, int CLS, class... Args>
 static void launch_reads_kernel(hipStream_t s, dim3 grid, const DevTables& tb, Args... args) {
