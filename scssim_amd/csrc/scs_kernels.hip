@@ -719,10 +719,10 @@ __device__ __forceinline__ void win_put2(LdsU8* w, int i, uint32_t v) {         
     LdsU32* d = (LdsU32*)w + (i >> 4); const uint32_t sh = 2u * (uint32_t)(i & 15);
     *d = (*d & ~(3u << sh)) | (v << sh);
 }
-// row of the uniform walk: 24 bytes of pending-position slots (two entries of three words) + the window at two bits per base, an
+// row of the uniform walk: 36 bytes of pending-position slots (three entries of three words) + the window at two bits per base, an
 // odd number of dwords in all
 __host__ __device__ static inline uint32_t uni_row_bytes(uint32_t n) {
-    uint32_t d = 6u + ((n + 15u) >> 4);
+    uint32_t d = 9u + ((n + 15u) >> 4);
     if ((d & 1u) == 0) ++d;
     return 4u * d;
 }
@@ -1024,7 +1024,7 @@ __device__ __forceinline__ void reads_body(const uint32_t bid, const uint8_t* __
     // rows: [RB][WS] windows behind the event slots; the uniform walk (UNI) has no events and keeps each lane's 16 bytes
     // IN FRONT of its window instead -- two pending-quality slots, the later ones overlay the consumed start of the window
     // and the window itself with TWO bits per base (its reads see no N): uni_row_bytes
-    constexpr uint32_t WOFF = UNI ? 24u : 0u;
+    constexpr uint32_t WOFF = UNI ? 36u : 0u;
     const uint32_t ROW = UNI ? uni_row_bytes((uint32_t)n) : WS;
     uint8_t* s_win = UNI ? reinterpret_cast<uint8_t*>(s_ev) : reinterpret_cast<uint8_t*>(s_ev + RB * EV_MAX);
     uint32_t* s_head = reinterpret_cast<uint32_t*>(s_dyn + SLOTS * sizeof(Bin) + (size_t)RB * ROW);   // [64] UNI: threshold rows of the 1- and 2-mers
@@ -1340,7 +1340,7 @@ __device__ __forceinline__ void reads_body(const uint32_t bid, const uint8_t* __
     // entries in the START OF THE READ'S OWN WINDOW ROW in LDS -- entry e over the bases 16e .. 16e+15, dead once the walk
     // has passed them -- and patches the quality character into the FASTQ text after the record is written; slot mode in
     // the free tail of the read's quality slot.  No room (an early position, a fifth substitution) -> resolved in place.
-    constexpr uint32_t PEND_MAX = 4;
+    constexpr uint32_t PEND_MAX = 4, PENDU_MAX = 6;                                // (PENDU_MAX: the uniform walk's entries, three words each)
     const bool can_defer = !FROM_PAIRS && n_out + 15 + (int)(8 * PEND_MAX) <= (int)slot;
     uint32_t npend = 0;
     uint2* my_pend = FROM_PAIRS ? nullptr : reinterpret_cast<uint2*>(my_q + slot - 8 * PEND_MAX);
@@ -1422,11 +1422,13 @@ __device__ __forceinline__ void reads_body(const uint32_t bid, const uint8_t* __
             // substitution: a few per thousand; or the draw 0xFFFFFFFF) is set aside -- (position | table row, x1, x2), three words --
             // and resolved after the pass from the global tables, base and quality patched into the text.  Only a wave in which SOME
             // lane has one enters the block (a wave-uniform branch: one position in four or five); lanes without a read count along,
-            // ignored later.  Entry e lies in the row's dwords 3e .. 3e + 2: the first two in front of the window, entry e >= 2 over the
-            // window's dwords 3e - 6 .. 3e - 4, which the walk has read once t >= 16 (3e - 4).
+            // ignored later.  Entry e lies in the row's dwords 3e .. 3e + 2: the first three in front of the window, entry e >= 3 over the
+            // window's dwords 3e - 9 .. 3e - 7, which the walk has read once t >= 16 (3e - 7); at most PENDU_MAX entries.  (With two
+            // entries in front, one read in a thousand ran out of room and was made again by redo_read: a workgroup in four had one,
+            // 3.5 of its 77 microseconds on average.)
             if (__ballot(!bKept)) {
                 const bool bad = !bKept, ugly = bX1 == 0xFFFFFFFFu;
-                const bool wr = bad & !ugly & (npend <= (((uint32_t)t >> 4) + 4u) / 3u) & !force_redo;
+                const bool wr = bad & !ugly & (npend <= min((((uint32_t)t >> 4) + 7u) / 3u, PENDU_MAX - 1u)) & !force_redo;
                 nbad += bad ? 1u : 0u;                                                // nbad != npend after the pass: the read is made again
                 if (wr) { LdsU32* e = my_pend_lds + 3u * npend; e[0] = (uint32_t)t | ((bRow + (decltype(HEAD)::value ? 0u : 20u)) << 10); e[1] = bX1; e[2] = bX2; }
                 npend += wr ? 1u : 0u;
@@ -1620,16 +1622,38 @@ __device__ __forceinline__ void reads_body(const uint32_t bid, const uint8_t* __
     SCS_PHASE(5);
     if constexpr (UNI) {
         // the positions the uniform walk set aside: base call and quality from the global tables (bin = position), patched into the
-        // text behind the record's own stores (same lane: program order)
-        for (uint32_t e = 0; e < npend; ++e) {
-            const uint32_t w0 = my_pend_lds[3u * e], x1 = my_pend_lds[3u * e + 1u], x2 = my_pend_lds[3u * e + 2u];
-            const uint32_t pos = w0 & 1023u, ki = w0 >> 10, pc = ki & 3u;
-            const uint4 T = *reinterpret_cast<const uint4*>(subs + ((size_t)ki * (uint32_t)B + pos) * 4u);
-            const uint32_t pk = (x1 >= T.x) + (x1 >= T.y) + (x1 >= T.z);
-            const uint32_t* __restrict__ arow = tb.qual_alias + (size_t)((pc * 4u + pk) * (uint32_t)B + pos) * (QK + QK / 4);
-            const uint32_t qv = alias_pick<QK>(arow, reinterpret_cast<const uint8_t*>(arow + QK), x2);
-            wg_out[sec1 + a1 + pos] = (char)((0x54474341u >> (8u * pk)) & 255u);
-            wg_out[sec2 + a2 + pos] = (char)(33u + qv);
+        // text behind the record's own stores (same lane: program order).  Three dependent loads per entry -- threshold row, alias
+        // entry, symbol -- and a lane has up to six entries: the loads of ALL its entries leave together, level by level (three round
+        // trips to memory for the wave instead of three per entry).
+        uint32_t nmax = 0;
+#pragma unroll
+        for (uint32_t e = 0; e < PENDU_MAX; ++e) nmax += __any(npend > e) ? 1u : 0u;   // the wave's largest count (uniform)
+        uint32_t pw0[PENDU_MAX], px2[PENDU_MAX], pk_[PENDU_MAX], ent[PENDU_MAX]; uint4 pT[PENDU_MAX]; uint32_t px1[PENDU_MAX];
+#pragma unroll
+        for (uint32_t e = 0; e < PENDU_MAX; ++e) if (e < nmax) {
+            const bool on = e < npend;                                              // (a lane without entry e works on position 0 of row 0: valid addresses, nothing stored)
+            pw0[e] = on ? my_pend_lds[3u * e] : 0u; px1[e] = on ? my_pend_lds[3u * e + 1u] : 0u; px2[e] = on ? my_pend_lds[3u * e + 2u] : 0u;
+            pT[e] = *reinterpret_cast<const uint4*>(subs + ((size_t)(pw0[e] >> 10) * (uint32_t)B + (pw0[e] & 1023u)) * 4u);
+        }
+        constexpr uint32_t AB = RingGeo<QK>::ABITS;
+#pragma unroll
+        for (uint32_t e = 0; e < PENDU_MAX; ++e) if (e < nmax) {
+            const uint32_t pos = pw0[e] & 1023u, pc = (pw0[e] >> 10) & 3u;
+            pk_[e] = (px1[e] >= pT[e].x) + (px1[e] >= pT[e].y) + (px1[e] >= pT[e].z);
+            ent[e] = tb.qual_alias[(size_t)((pc * 4u + pk_[e]) * (uint32_t)B + pos) * (QK + QK / 4) + (px2[e] >> (32u - AB))];
+        }
+        uint32_t sym[PENDU_MAX];
+#pragma unroll
+        for (uint32_t e = 0; e < PENDU_MAX; ++e) if (e < nmax) {
+            const uint32_t pos = pw0[e] & 1023u, pc = (pw0[e] >> 10) & 3u, col = px2[e] >> (32u - AB);
+            const uint32_t pick = ((px2[e] << AB) | (uint32_t)(QK - 1)) < ent[e] ? col : (ent[e] & (uint32_t)(QK - 1));   // alias_pick
+            sym[e] = reinterpret_cast<const uint8_t*>(tb.qual_alias + (size_t)((pc * 4u + pk_[e]) * (uint32_t)B + pos) * (QK + QK / 4) + QK)[pick];
+        }
+#pragma unroll
+        for (uint32_t e = 0; e < PENDU_MAX; ++e) if (e < nmax && e < npend) {
+            const uint32_t pos = pw0[e] & 1023u;
+            wg_out[sec1 + a1 + pos] = (char)((0x54474341u >> (8u * pk_[e])) & 255u);
+            wg_out[sec2 + a2 + pos] = (char)(33u + sym[e]);
         }
     } else
     for (uint32_t e = 0; e < npend; ++e) {                                         // deferred qualities of substituted bases
