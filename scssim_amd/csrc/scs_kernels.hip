@@ -1393,12 +1393,16 @@ __device__ __forceinline__ void reads_body(const uint32_t bid, const uint8_t* __
                 if (u < 15) c2 = __builtin_amdgcn_ubfe(wreg, 2u * u + (after ? 2u : 0u), 2u);
                 else c2 = after ? (wnext & 3u) : (wreg >> 30);
             } else {
-                if (u == 0) { wreg = win32[t0 >> 4]; if (!mine) wreg = 0; }        // the block's 16 bases
-                c2 = wreg & 3u; wreg >>= 2;
+                if (u == 0) { wnext = wreg; wreg = win32[t0 >> 4]; if (!mine) wreg = 0; }   // the block's 16 bases (wnext: the block before)
+                c2 = __builtin_amdgcn_ubfe(wreg, 2u * u, 2u);
             }
             uint32_t x1, x2; xb.next2(x1, x2);                                       // one step of stream B per position
             const LdsU8* bin8 = ring8 + (u & (SLOTS - 1)) * sizeof(Bin);
-            uint32_t rowi = (c0 << 4) | (c1 << 2) | c2;                               // the clean 3-mer: row 20 + rowi of the substitution table
+            // the clean 3-mer, OLDEST base in the low bits (the ring's keep table is laid out that way): six bits of the window as they lie
+            uint32_t rowi;
+            if constexpr (D1) rowi = c0 | (c1 << 2) | (c2 << 4);
+            else if constexpr (u >= 2) rowi = __builtin_amdgcn_ubfe(wreg, 2u * (u - 2), 6u);
+            else rowi = __builtin_amdgcn_alignbit(wreg, wnext, u == 0 ? 28u : 30u) & 63u;
             const LdsU8* kp8 = bin8 + 4 * QROW * 16 + rowi * 8u;
             if constexpr (u < 2 && first) { rowi = u == 0 ? c2 : 4u + c1 * 4u + c2; kp8 = head8 + rowi * 8u; }   // the read's first two bases: 1-mer / 2-mer rows (table rows 0..19)
             const LdsU32* qrow = (const LdsU32*)(bin8 + c2 * (uint32_t)(QROW * 16));   // the diagonal row (c2, c2) as an alias row
@@ -1430,7 +1434,8 @@ __device__ __forceinline__ void reads_body(const uint32_t bid, const uint8_t* __
                 const bool bad = !bKept, ugly = bX1 == 0xFFFFFFFFu;
                 const bool wr = bad & !ugly & (npend <= min((((uint32_t)t >> 4) + 7u) / 3u, PENDU_MAX - 1u)) & !force_redo;
                 nbad += bad ? 1u : 0u;                                                // nbad != npend after the pass: the read is made again
-                if (wr) { LdsU32* e = my_pend_lds + 3u * npend; e[0] = (uint32_t)t | ((bRow + (decltype(HEAD)::value ? 0u : 20u)) << 10); e[1] = bX1; e[2] = bX2; }
+                const uint32_t ki = decltype(HEAD)::value ? bRow : 20u + (((bRow & 3u) << 4) | (bRow & 12u) | (bRow >> 4));   // table row: newest base in the low bits
+                if (wr) { LdsU32* e = my_pend_lds + 3u * npend; e[0] = (uint32_t)t | (ki << 10); e[1] = bX1; e[2] = bX2; }
                 npend += wr ? 1u : 0u;
             }
             sel |= bC2 << (8 * (u & 3)); qacc |= bSym << (8 * (u & 3));               // base selectors and raw qualities, four to a word
@@ -1611,14 +1616,17 @@ __device__ __forceinline__ void reads_body(const uint32_t bid, const uint8_t* __
             if (SIMPLE) break;
         }
     }
-    if (FROM_PAIRS && live && n_out > 0) {
-        // the streams' ends, once per wave after the pass (reads of different lengths end at different steps): the last
-        // characters + "\n+\n" up to the qualities' first dword / + "\n" to the record's end
-        const uint32_t lastj = (uint32_t)n_out - 1u, m = lastj >> 4, nw = ((lastj & 15u) >> 2) + 1u, nv = (lastj & 3u) + 1u;
-        const uint32_t s1 = a1 & 3u, s2 = a2 & 3u, nq = s2 + (uint32_t)n_out + 1u;
-        bo_b.tail(wg_out, sec1, a1, m, nw, nv, 0x0A2B0Au, (s1 + (uint32_t)n_out + 3u - s2) >> 2, 0u);   // the bases' dwords end where the qualities' first one starts
-        bo_q.tail(wg_out, sec2, a2, m, nw, nv, 0x0Au, nq >> 2, nq & 3u);
-    }
+    auto tails = [&]() __attribute__((always_inline)) {
+        if (FROM_PAIRS && live && n_out > 0) {
+            // the streams' ends, once per wave after the pass (reads of different lengths end at different steps): the last
+            // characters + "\n+\n" up to the qualities' first dword / + "\n" to the record's end
+            const uint32_t lastj = (uint32_t)n_out - 1u, m = lastj >> 4, nw = ((lastj & 15u) >> 2) + 1u, nv = (lastj & 3u) + 1u;
+            const uint32_t s1 = a1 & 3u, s2 = a2 & 3u, nq = s2 + (uint32_t)n_out + 1u;
+            bo_b.tail(wg_out, sec1, a1, m, nw, nv, 0x0A2B0Au, (s1 + (uint32_t)n_out + 3u - s2) >> 2, 0u);   // the bases' dwords end where the qualities' first one starts
+            bo_q.tail(wg_out, sec2, a2, m, nw, nv, 0x0Au, nq >> 2, nq & 3u);
+        }
+    };
+    if constexpr (!UNI) tails();                                                   // (the uniform walk: below, behind the deferred positions' loads)
     SCS_PHASE(5);
     if constexpr (UNI) {
         // the positions the uniform walk set aside: base call and quality from the global tables (bin = position), patched into the
@@ -1649,6 +1657,8 @@ __device__ __forceinline__ void reads_body(const uint32_t bid, const uint8_t* __
             const uint32_t pick = ((px2[e] << AB) | (uint32_t)(QK - 1)) < ent[e] ? col : (ent[e] & (uint32_t)(QK - 1));   // alias_pick
             sym[e] = reinterpret_cast<const uint8_t*>(tb.qual_alias + (size_t)((pc * 4u + pk_[e]) * (uint32_t)B + pos) * (QK + QK / 4) + QK)[pick];
         }
+        // (the streams' ends go out HERE: the loads above do not queue up behind their stores, and the patches below follow them)
+        tails();
 #pragma unroll
         for (uint32_t e = 0; e < PENDU_MAX; ++e) if (e < nmax && e < npend) {
             const uint32_t pos = pw0[e] & 1023u;

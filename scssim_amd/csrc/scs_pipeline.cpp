@@ -332,7 +332,8 @@ void do_load_profile(scs_ctx* c, const char* path) {
         for (size_t b = 0; b < B; ++b) {
             uint32_t* d = img.data() + b * bw;
             for (size_t cc = 0; cc < 4; ++cc) memcpy(d + cc * qw, P.qual_alias.data() + ((cc * 5) * B + b) * qw, qw * 4);
-            for (size_t kk = 0; kk < 64; ++kk) keep_pair(subs_t.data() + ((20 + kk) * B + b) * 4, (uint32_t)(kk & 3), d + 4 * qw + kk * 2);
+            for (size_t kk = 0; kk < 64; ++kk)                                       // 3-mer (c0, c1, c2) = table row 20 + 16 c0 + 4 c1 + c2, kept at c0 | c1 << 2 | c2 << 4: the window's own bit order
+                keep_pair(subs_t.data() + ((20 + kk) * B + b) * 4, (uint32_t)(kk & 3), d + 4 * qw + (((kk >> 4) & 3) | (kk & 12) | ((kk & 3) << 4)) * 2);
         }
         return img;
     };
