@@ -17,8 +17,12 @@ namespace scs {
 #ifdef SCS_PHASE_CLOCK
 __device__ unsigned long long g_phase[16];
 #define SCS_PHASE(i) do { if (UNI && CLS == 1 && tid == 0) { const unsigned long long now_ = wall_clock64(); if ((i) >= 0) atomicAdd(&g_phase[(i) < 0 ? 0 : (i)], now_ - ph_t_); ph_t_ = now_; } } while (0)
+// the same for k_attach<semi>: wave-level sections of its loop (g_phase_att[15] counts the waves)
+__device__ unsigned long long g_phase_att[8 * 256];                                // [section][workgroup & 255]: the waves' sums, spread over 256 slots
+#define SCS_ATT(i) do { if (!FROM_FRAG) { const unsigned long long now_ = wall_clock64(); if (lane == __ffsll((long long)__ballot(1)) - 1) { s_att_acc[i] += now_ - s_att_t; s_att_t = wall_clock64(); } } } while (0)   /* (one wave per workgroup: mark and sums live in LDS, whichever lanes are active) */
 #else
 #define SCS_PHASE(i) do {} while (0)
+#define SCS_ATT(i) do {} while (0)
 #endif
 
 #define WAVE 64
@@ -1917,9 +1921,17 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(G == 4 
     const AttachFit fit = group_done ? AttachFit{0, 1, 0, 1} : attach_fit_count(len, p.amp_min, p.amp_max);
     const double qfail = 1.0 - (double)fit.N / ((double)(len > 27 ? len - 27 : 1) * (double)fit.W);   // P(a try does not fit)
     unsigned long long lsum = 0; Xoshiro xt{};                                     // [REMAP] primer i's try stream, seeded by Philox block i
+#ifdef SCS_PHASE_CLOCK
+    __shared__ unsigned long long s_att_t, s_att_acc[8];
+    if (lane < 8) s_att_acc[lane] = 0;
+    if (lane == 0) s_att_t = wall_clock64();
+    __builtin_amdgcn_wave_barrier();
+#endif
+    SCS_ATT(0);
     while (__ballot(!group_done)) {
         if (!group_done) {
             if (fresh) { i = c0 + gl; unresolved = i < budget; need = unresolved; dead = false; tries = 0; fresh = false; if (unresolved) xt.seed(draw4(p.key, ST_ATTACH, aux, tuid, i)); }
+            SCS_ATT(1);
             if (unresolved && !dead) {
                 if (!need && ((bits[spos >> 5] >> (spos & 31)) & 1u)) need = true;       // a lower primer took this position meanwhile
                 while (need) {
@@ -1937,6 +1949,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(G == 4 
                         cand = true;
                     }
                     if (dead) break;
+                    SCS_ATT(2);
                     // (b) ... and only then its primer 8-mer and the stock, all candidates of the wave in one round of loads.  The 8
                     // bases are contiguous in the genome -> ONE 8-byte load (reversed / complemented in registers), then the semi's
                     // own substitutions are patched in (no load sits under a branch)
@@ -1949,11 +1962,14 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(G == 4 
                     uint32_t idx = 0;
 #pragma unroll
                     for (uint32_t k = 0; k < 8; ++k) idx = (idx << 2) | ((uint32_t)(v8 >> (8u * k)) & 3u);
-                    if (hasN || primer_cnt[idx] <= 0) continue;                          // no stock for N 8-mers; [REMAP] stock as of pass start
+                    const bool nostock = hasN || primer_cnt[idx] <= 0;
+                    SCS_ATT(3);
+                    if (nostock) continue;                          // no stock for N 8-mers; [REMAP] stock as of pass start
                     pidx = idx; need = false;
                 }
             }
         }
+        SCS_ATT(4);
         // blocked = a lower unresolved live lane of my group proposes the same position
         const bool live = !group_done && unresolved && !dead;
         const unsigned long long um = __ballot(live);
@@ -1974,6 +1990,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(G == 4 
         const unsigned long long bm = __ballot(live && blocked) & gmask, dm = __ballot(!group_done && unresolved && dead) & gmask;
         const int first_blocked = bm ? __ffsll((long long)bm) - 1 - gi * G : G, first_dead = dm ? __ffsll((long long)dm) - 1 - gi * G : G;
         const int commit_end = first_blocked < first_dead ? first_blocked : first_dead;
+        SCS_ATT(5);
         if (live && gl < commit_end) {                                                   // commit, in primer order
             atomicOr(&bits[spos >> 5], 1u << (spos & 31));
             atomicAdd(&primer_delta[pidx], 1u);
@@ -1988,7 +2005,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(G == 4 
                 if (c0 >= budget) { group_done = true; v = budget; } else fresh = true;
             }
         } else (void)__ballot(false);
+        SCS_ATT(6);
     }
+#ifdef SCS_PHASE_CLOCK
+    __builtin_amdgcn_wave_barrier();
+    if (!FROM_FRAG && lane < 8) atomicAdd(&g_phase_att[lane * 256 + (blockIdx.x & 255u)], lane == 7 ? 1ull : s_att_acc[lane]);
+#endif
     if (FROM_FRAG) { lsum = wave_sum_u64(lsum); if (lane == 0) len_sum[blockIdx.x] = lsum; }   // per fragment; launch_attach_frags adds them up (no same-address atomics)
     if (gl == 0 && t < nt) valid[t] = v;
 }
@@ -2742,6 +2764,18 @@ void phase_clock_report() {
     for (int i = 0; i < 8; ++i) fprintf(stderr, "  %s %.2f", nm[i], (double)h[i] / (double)h[15] / 100.0);
     fprintf(stderr, "  | total %.2f\n", tot / (double)h[15] / 100.0);
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof z);
+    static unsigned long long ha[8 * 256], za[8 * 256];
+    if (hipMemcpyFromSymbol(ha, HIP_SYMBOL(g_phase_att), sizeof ha) == hipSuccess) {
+        for (int i = 0; i < 8; ++i) { h[i] = 0; for (int k = 0; k < 256; ++k) h[i] += ha[i * 256 + k]; }
+        h[15] = h[7];
+    } else h[15] = 0;
+    if (h[15]) {
+        static const char* an[7] = {"setup", "seeding (Philox)", "gap + decode + bitmap (the candidate)", "8-mer gather, patch, stock", "(loop tail)", "blocked test", "commit + bookkeeping"};
+        fprintf(stderr, "[phase clock] k_attach<semi>: %llu waves; mean wave time per section (us):", h[15]);
+        for (int i = 0; i < 7; ++i) fprintf(stderr, "  %s %.2f", an[i], (double)h[i] / (double)h[15] / 100.0);
+        fprintf(stderr, "\n");
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_phase_att), za, sizeof za);
+    }
 #endif
 }
 }  // namespace scs
