@@ -1303,7 +1303,45 @@ __device__ __forceinline__ void reads_body(const uint32_t bid, const uint8_t* __
     // the record must lie inside the batch's text (its offset and size come from k_indels' n'; the walk below emits exactly
     // n' characters per stream): a disagreement would be an internal error, reported, never a store outside the buffer
     if (FROM_PAIRS && live && n_out > 0 && my_off + rec_h + 2ull * (uint32_t)n_out + 4ull > (second_file ? cap2 : cap1)) { atomicOr(flags, (uint32_t)FLAG_INTERNAL); live = false; n_out = 0; }
-    if (FROM_PAIRS && live && n_out > 0) {
+    LdsU32* my_pend_lds = (LdsU32*)(s_win + (size_t)tid * ROW);                    // rows are dword aligned (win_stride)
+    if (UNI && live && n_out > 0) {
+        // The name line "@<amp>#<cnt>[/1|/2]\n" is WRITTEN INTO LDS FIRST, character by character at its place from the end -- into the
+        // 28 bytes in front of my window that the walk's pending entries use later, the line's last character in byte 27 (h <= 25) --
+        // and read back as seven words: no six-way choice per character, the digit loops are the only data-dependent part.  The words are
+        // shifted to the record's alignment: the last s1 characters ride in the first dword of the bases, the rest ends on the aligned
+        // address ta1 and goes out as whole dwords, then the <= 3 leading bytes.
+        const uint32_t amp = amp_index_base + pr.amp, cnt = pr.att + 1u, d2 = dec_digits(cnt), h = rec_h, dbase = paired ? 3u : 1u, da = h - 2u - dbase - d2;
+        const uint32_t o1 = rec_rel + h, o2 = o1 + (uint32_t)n_out + 3u;          // where the bases / the qualities start
+        a1 = o1 & 31u; sec1 = o1 - a1; a2 = o2 & 31u; sec2 = o2 - a2;
+        const uint32_t s1 = a1 & 3u; char* ta1 = wg_out + (o1 - s1);
+        LdsU8* nb = (LdsU8*)my_pend_lds;
+        nb[27] = (uint8_t)'\n';
+        if (paired) { nb[26] = (uint8_t)(rd ? '2' : '1'); nb[25] = (uint8_t)'/'; }
+        uint32_t at = 27u - dbase, v = cnt;                                        // byte of the next character to the left
+#pragma unroll
+        for (uint32_t j = 0; j < 10; ++j) if (j < d2) { const uint32_t qv = v / 10u; nb[at - j] = (uint8_t)('0' + (v - qv * 10u)); v = qv; }
+        at -= d2; nb[at] = (uint8_t)'#'; at -= 1u; v = amp;
+#pragma unroll
+        for (uint32_t j = 0; j < 10; ++j) if (j < da) { const uint32_t qv = v / 10u; nb[at - j] = (uint8_t)('0' + (v - qv * 10u)); v = qv; }
+        nb[at - da] = (uint8_t)'@';
+        uint32_t nm[7];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) nm[k] = ((const LdsU32*)nb)[k];
+        bo_b.carry = s1 ? nm[6] & (0xFFFFFFFFu << (8u * (4u - s1))) : 0u;
+        uint32_t w[7];                                                             // w[k]: the aligned dword that ends 4 (6 - k) bytes before ta1
+#pragma unroll
+        for (int k = 6; k >= 0; --k) w[k] = s1 ? __builtin_amdgcn_alignbyte(nm[k], k ? nm[k - 1] : 0u, 4u - s1) : nm[k];
+        const uint32_t nd = (h - s1) >> 2, nl = (h - s1) & 3u;                     // whole dwords, leading bytes (h >= 5 > s1)
+        uint32_t lead = 0;
+#pragma unroll
+        for (uint32_t m = 0; m < 7; ++m) {
+            if (m < nd) *reinterpret_cast<uint32_t*>(ta1 - 4u * (m + 1u)) = w[6 - m];
+            lead = m == nd ? w[6 - m] : lead;
+        }
+        char* lp = ta1 - 4u * nd - nl;
+        for (uint32_t i = 0; i < nl; ++i) lp[i] = (char)(lead >> (8u * (4u - nl + i)));
+    }
+    if (!UNI && FROM_PAIRS && live && n_out > 0) {
         const uint32_t amp = amp_index_base + pr.amp, cnt = pr.att + 1u, d2 = dec_digits(cnt), h = rec_h;
         const uint32_t o1 = rec_rel + h, o2 = o1 + (uint32_t)n_out + 3u;          // where the bases / the qualities start
         a1 = o1 & 31u; sec1 = o1 - a1; a2 = o2 & 31u; sec2 = o2 - a2;
@@ -1348,7 +1386,6 @@ __device__ __forceinline__ void reads_body(const uint32_t bid, const uint8_t* __
     const bool can_defer = !FROM_PAIRS && n_out + 15 + (int)(8 * PEND_MAX) <= (int)slot;
     uint32_t npend = 0;
     uint2* my_pend = FROM_PAIRS ? nullptr : reinterpret_cast<uint2*>(my_q + slot - 8 * PEND_MAX);
-    LdsU32* my_pend_lds = (LdsU32*)(s_win + (size_t)tid * ROW);                    // rows are dword aligned (win_stride)
 
     bool redo = false;                                                             // UNI: the read is made again after the pass (redo_read)
     if constexpr (UNI) {
