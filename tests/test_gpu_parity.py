@@ -505,6 +505,27 @@ def test_very_long_reads_take_the_general_variant(oracle_bin, models, tmp_path):
     assert g.stats()["pairs_written"] == want.count(b"\n") // 4
 
 
+@pytest.mark.parametrize("noise", [0.02, 0.12])
+def test_noisy_profile_many_substitutions_bit_exact(noise, oracle_bin, models, tmp_path):
+    """The uniform walk keeps the window's base with one compare and sets a position whose draw does not keep it aside (three
+    entries in front of the read's window in LDS, later ones over the window's consumed start, at most six; resolved after the
+    pass); a read that runs out of room is made again by redo_read.  The shipped models substitute a few bases per thousand:
+    a read has 0-2 entries.  Here every substitution row is mixed with the uniform row -- 1.5 % (2-3 entries per read, the
+    overlaid slots in use) and 9 % (a dozen per read: nearly every read overflows and is made again) -- PE125, byte for byte."""
+    fa = str(tmp_path / "simu.fa")
+    subprocess.check_call(["python3", os.path.join(ROOT, "tools", "make_genome.py"), "--lengths", "1200000", "--seed", "11", "--simu-out", fa])
+    prof = str(tmp_path / "noisy.profile")
+    subprocess.check_call(["python3", os.path.join(ROOT, "tools", "make_profile.py"), models["Illumina_HiSeq2500"], prof, "--read-length", "125", "--noise", "%g" % noise])
+    prefix = str(tmp_path / "orc")
+    _oracle_run(oracle_bin, fa, prof, prefix, ["-c", "3"], 91, threads=min(32, os.cpu_count() or 1))
+    g = scssim_amd.GenReads(profile=prof, input_fasta=fa, coverage=3.0, seed=91)
+    fq1, fq2 = g.run()
+    w1, w2 = open(prefix + "_1.fq", "rb").read(), open(prefix + "_2.fq", "rb").read()
+    assert len(w1) > 1000000
+    assert fq1 == w1, _fastq_diff(fq1, w1)
+    assert fq2 == w2, _fastq_diff(fq2, w2)
+
+
 @pytest.mark.parametrize("case", ["g1", "medium"])
 def test_insert_size_give_up_path_bit_exact(case, oracle_bin, models, golden_inputs, tmp_path):
     """-s 1500: the mean insert is as long as the amplicons (1000-2000 bases), so most insert-size draws are rejected

@@ -16,6 +16,7 @@ def main():
     ap.add_argument("src")
     ap.add_argument("dst")
     ap.add_argument("--read-length", type=int, required=True)
+    ap.add_argument("--noise", type=float, default=0.0, help="tests: mix every substitution row with the uniform row, p' = (1 - F) p + F / 4 (a substitution rate of about 3 F / 4)")
     a = ap.parse_args()
     op = gzip.open if a.src.endswith(".gz") else open
     lines = op(a.src, "rt").read().split("\n")
@@ -35,6 +36,8 @@ def main():
         elif ln.startswith("kmer:") and not ln.startswith("kmer: 3") or (ln.startswith("kmer: ") and len(ln.split(":")[1].strip()) == 3 and not ln.split(":")[1].strip().isdigit()):
             out.append(ln)                                  # "kmer: XXA" block: 2*old rows (read 1, read 2)
             rows = lines[i + 1:i + 1 + 2 * old]
+            if a.noise > 0:
+                rows = ["\t".join("%.9g" % ((1 - a.noise) * float(v) + a.noise / 4) for v in r.split("\t")) for r in rows]
             out += [rows[j] for j in pick] + [rows[old + j] for j in pick]
             i += 2 * old
         elif ln.startswith("basePairIndx:"):
