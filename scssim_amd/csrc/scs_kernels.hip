@@ -666,20 +666,27 @@ __global__ void k_plan_pairs(DevFrags fr, DevAmps semis, DevAmps fulls, uint32_t
 //         whole 32-byte aligned sectors (BlockOut); the workgroup's reads are handed to its lanes ordered by the sector
 //         phase of their records, so that the lanes of a wave cross sector boundaries together.  Explicit-window mode
 //         writes sequence/quality slots.
-//     Three instantiations per batch in pair mode (CLS; lists from k_indels + k_read_lists), launched side by side:
+//     Three instantiations per batch in pair mode (CLS; lists from k_indels + k_read_lists), the workgroups of ONE launch
+//     (k_reads_all):
 //       1  reads without indel events in fragments without a non-ACGT base: the UNIFORM WALK -- position t at bin t, one
 //          step of stream B per position, windows from the two-bit genome, straight-line code unrolled by 16 positions
-//          with a one-position software pipeline, substituted bases' qualities set aside in LDS (redo_read when that
-//          runs out of room);
+//          with a one-position software pipeline; the base call is ONE compare of the draw against the interval that keeps
+//          the window's base (RingBinU), and a position whose draw does not keep it is set aside in LDS and resolved after
+//          the pass, base and quality patched into the text (redo_read when a read runs out of room);
 //       3  the same walk for reads whose only event is the deletion of one base (n' = L - 1: bins j L / (L - 1) = j);
 //       2  everything else: the general loop described above.  (0: explicit-window mode, the general loop.)
-//     LDS per workgroup at L = 150: 16 KB ring + 15 KB rows (uniform walks) / 4 KB events + 19 KB windows (general)
-//     -> 4 workgroups per CU.
+//     The prologue is a chain of dependent loads (list entry -> pair record + offset -> window gather) at four workgroups
+//     per CU: the ring's first groups and the event words are requested early, the records are parked in LDS for the
+//     hand-out by sector phase, the gather issues all its loads before it uses one, and every barrier orders LDS only
+//     (lds_barrier).  -DSCS_PHASE_CLOCK times the phases of a workgroup's life.
+//     LDS per workgroup at L = 150: 14 KB ring + 19 KB rows (uniform walks) / 16 KB ring + 4 KB events + 19 KB windows
+//     (general) -> 4 workgroups per CU.
 // ------------------------------------------------------------------------------------------------
 #define RB 256
 #define EV_MAX 8
 // ring geometry: two groups of bins (one being served, one being filled).  A bin image = the 4 diagonal quality rows as
-// alias rows (QK columns: QK words + QK symbol bytes each, scs_tables.h) + the 64 k-mer substitution rows (3 thresholds).
+// alias rows (QK columns: QK words + QK symbol bytes each, scs_tables.h) + the 64 k-mer substitution rows (3 thresholds; the
+// uniform walk's image, RingBinU: 2 words -- the interval of draws that keep the base -- and 256 bytes less per bin).
 //   QK = 16  (binned-quality models, e.g. HiSeq X):   80 B rows, 1088 B bins, groups of 8
 //   QK = 64  (8-bit-quality models):                 320 B rows, 2048 B bins, groups of 4
 //   QK = 128 (a row with more than 64 symbols):      640 B rows, 3328 B bins, groups of 2
