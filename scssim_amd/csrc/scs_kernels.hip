@@ -1032,9 +1032,9 @@ __device__ __forceinline__ void reads_body(const uint32_t bid, const uint8_t* __
     int64_t* s_gbase = reinterpret_cast<int64_t*>(s_dyn);                  // [RB]  staging only: aliases the ring, which is filled later
     uint32_t* s_gflag = reinterpret_cast<uint32_t*>(s_gbase + RB);         // [RB]  bit0 complement, bit1 direction -1, bit2 valid
     uint16_t* s_ev = reinterpret_cast<uint16_t*>(s_dyn + SLOTS * sizeof(Bin));   // [RB][EV_MAX]; a replayed read keeps its stream-A state here
-    // rows: [RB][WS] windows behind the event slots; the uniform walk (UNI) has no events and keeps each lane's 16 bytes
-    // IN FRONT of its window instead -- two pending-quality slots, the later ones overlay the consumed start of the window
-    // and the window itself with TWO bits per base (its reads see no N): uni_row_bytes
+    // rows: [RB][WS] windows behind the event slots; the uniform walk (UNI) has no events and keeps 36 bytes per lane
+    // IN FRONT of its window instead -- three set-aside entries (the name line is composed there first), later entries overlay
+    // the consumed start of the window -- and the window itself with TWO bits per base (its reads see no N): uni_row_bytes
     constexpr uint32_t WOFF = UNI ? 36u : 0u;
     const uint32_t ROW = UNI ? uni_row_bytes((uint32_t)n) : WS;
     uint8_t* s_win = UNI ? reinterpret_cast<uint8_t*>(s_ev) : reinterpret_cast<uint8_t*>(s_ev + RB * EV_MAX);
@@ -1397,15 +1397,15 @@ __device__ __forceinline__ void reads_body(const uint32_t bid, const uint8_t* __
     bool redo = false;                                                             // UNI: the read is made again after the pass (redo_read)
     if constexpr (UNI) {
         // The event-free, ACGT-only class: every read emits exactly position t at bin t and every position takes exactly two
-        // draws, so the whole walk is WAVE-UNIFORM -- window base t (a dword of 8 bases is fetched every 8th step), output
-        // word t >> 2, a 16-character block at t & 15 == 15 -- and, between two blocks, STRAIGHT-LINE code: ring slot, word
-        // index and table addresses are compile-time or lane arithmetic, nothing branches, and the compiler overlaps the LDS
-        // lookups of neighbouring positions.  A substituted base needs the quality row (c2, k), which only global memory
-        // holds; its quality does not feed back into the walk, so (position, k, c2, draw) is set aside with an unconditional
-        // LDS store (lanes without one store to a dummy word) and resolved after the pass.  Slots: two in front of the
-        // window, the later ones over the window's consumed start -- entry e >= 2 over dwords 2(e-2), 2(e-2)+1 (16 bases
-        // each), both in a register once t >= 32(e-2)+16.  No room, or the draw 0xFFFFFFFF: the read is flagged and made
-        // again by redo_read.
+        // draws, so the whole walk is WAVE-UNIFORM -- window base t (a dword of 16 bases is fetched every 16th step), output
+        // word t >> 2, a 16-character block at t & 15 == 15 -- and, between two blocks, STRAIGHT-LINE code but for one wave-uniform
+        // branch per position: ring slot, word index and table addresses are compile-time or lane arithmetic.  The base call
+        // k = (x1 >= T0) + (x1 >= T1) + (x1 >= T2) keeps the window's base c2 in all but a few draws per thousand, and k = c2 is ONE
+        // compare against the 3-mer's keep interval (lo, width) from the ring (RingBinU): the walk writes c2 and the diagonal quality
+        // row's symbol.  A position whose draw does not keep the base (or draws 0xFFFFFFFF, whose call needs the double tables) is
+        // set aside -- (position | table row, x1, x2), three words in the lane's row -- inside a block that only a wave with such a
+        // lane enters, and resolved after the pass from the global tables (finish_b and the loop behind the walk).  No room, or the
+        // draw 0xFFFFFFFF: the read is flagged and made again by redo_read.
         // Lanes without a read run along on an all-'A' window and store nothing.
         const bool mine = live && n_out > 0;
         const LdsU8* ring8 = (const LdsU8*)s_dyn;
