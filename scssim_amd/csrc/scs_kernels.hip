@@ -1899,15 +1899,16 @@ __global__ void __launch_bounds__(256) k_poisson(DevFrags fr, DevAmps semis, uin
     if (blockIdx.x < fr.n) poisson_frag_block(blockIdx.x, fr, p, budget_f, part);
     else poisson_semis_block(blockIdx.x - fr.n, semis, n_cap, p, budget_s, part);
 }
-// *dst += sum of a u64 array (per-workgroup partials)
+// *dst += sum of a u64 array (per-workgroup partials).  A few dozen workgroups, one atomic each (integer sums: any order): as ONE
+// workgroup this kernel waited 220 memory round trips in a row on the main stream (1.4 ms after every fragment pass)
 __global__ void __launch_bounds__(1024) k_sum_u64_add(const unsigned long long* __restrict__ v, uint32_t n, unsigned long long* __restrict__ dst) {
     __shared__ unsigned long long s_p[16];
     unsigned long long a = 0;
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) a += v[i];
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) a += v[i];
     a = wave_sum_u64(a);
     if ((threadIdx.x & 63) == 0) s_p[threadIdx.x >> 6] = a;
     __syncthreads();
-    if (threadIdx.x == 0) { unsigned long long t = 0; for (int k = 0; k < 16; ++k) t += s_p[k]; *dst += t; }
+    if (threadIdx.x == 0) { unsigned long long t = 0; for (int k = 0; k < 16; ++k) t += s_p[k]; if (t) atomicAdd(dst, t); }
 }
 // sums[0] += budgets of the fragments (workgroups [0, nf)), sums[1] += budgets of the semi amplicons (the rest)
 __global__ void __launch_bounds__(1024) k_poisson_sums(const unsigned long long* __restrict__ part, uint32_t nf, uint32_t nb, unsigned long long* __restrict__ sums) {
@@ -2375,7 +2376,7 @@ void launch_attach_frags(hipStream_t s, const uint8_t* g, DevFrags fr, const uin
     if (fr.n == 0) return;
     DevAmps none{}; DevErrPool np{};
     hipLaunchKernelGGL((k_attach<true, 64>), dim3(fr.n), dim3(64), 0, s, g, fr, none, 0u, np, slot_off, slots, slot_tmpl, valid, primer_cnt, primer_delta, len_part, p);
-    hipLaunchKernelGGL(k_sum_u64_add, dim3(1), dim3(1024), 0, s, len_part, fr.n, len_sum);
+    hipLaunchKernelGGL(k_sum_u64_add, dim3(std::min(cdiv(fr.n, 2048), 128u)), dim3(1024), 0, s, len_part, fr.n, len_sum);
 }
 void launch_poisson(hipStream_t s, DevFrags fr, DevAmps semis, uint32_t n_semis, PoissonParams p, uint32_t* budget_f, uint32_t* budget_s,
                     unsigned long long* sums, unsigned long long* part) {
