@@ -629,7 +629,7 @@ struct Sim {
     std::vector<Record> recs; Profile* prof = nullptr;
     std::vector<Frag> frags; AmpList semis, fulls;
     std::vector<long> primerCount;          // 65536 counters (Malbac.cpp:36-81; flat instead of trie)
-    std::vector<long> primerPending;        // [REMAP] counter mode: decrements applied at pass end
+    int exhausted_passes = 0;               // counter mode: passes in which a primer type ran dry (run again sequentially, amplify_pass)
     std::vector<long> primerUsed;           // attachments per primer type over the whole run (dump / statistics only)
     std::vector<uint64_t> binom;            // [REMAP] counter mode: error-count thresholds
     // sharded mode: this shard owns fragments [frag_gbase, frag_gbase + frags.size()) of the global list
@@ -703,16 +703,17 @@ inline int primer_index(const uint8_t* t) {
     int idx = 0; for (int k = 0; k < 8; ++k) { if (t[k] > 3) return -1; idx = (idx << 2) | t[k]; } return idx;
 }
 struct PrimerPool {
-    Sim& S; std::vector<long>* pending;           // per-thread pending deltas in counter mode
+    Sim& S; std::vector<long>* pending;           // what this worker took during the pass (counter mode)
+    bool live;                                    // decrement the shared stock at once (the reference's way), or look at the pass's start
     bool take(const uint8_t* t) {                 // updatePrimerCount(s, -1)
         int idx = primer_index(t);
         if (idx < 0) return false;                // N-containing 8-mer: node with no stock (A.8 D-item)
-        if (S.prm.counter) {                      // [REMAP] availability = stock at pass start
+        if (!live) {                              // counter mode, first run of a pass: the stock as of the pass's start (amplify_pass below)
             if (S.primerCount[idx] <= 0) return false;
             (*pending)[idx]++; return true;
         }
         if (S.primerCount[idx] - 1 < 0) return false;
-        S.primerCount[idx] -= 1; S.primerUsed[idx] += 1; return true;
+        S.primerCount[idx] -= 1; S.primerUsed[idx] += 1; if (pending) (*pending)[idx]++; return true;
     }
 };
 
@@ -913,54 +914,84 @@ void append_reversed(AmpList& dst, AmpList& add) {
     }
 }
 
-void apply_pending(Sim& S, std::vector<std::vector<long>>& pend) {
-    if (!S.prm.counter) return;
-    std::vector<uint64_t> sum(65536, 0);
-    for (auto& v : pend) for (size_t i = 0; i < v.size(); ++i) sum[i] += (uint64_t)v[i];
-    S.allreduce(sum.data(), sum.size());                                            // sharded: decrements of all shards
-    for (size_t i = 0; i < sum.size(); ++i) { S.primerUsed[i] += (long)sum[i]; S.primerCount[i] -= (long)sum[i]; if (S.primerCount[i] < 0) S.primerCount[i] = 0; }   // [REMAP] clamp at pass end
+// ---- one pass over the templates [0, n) of a list (Malbac::amplifyFrags 318-343, amplifySemiAmplicons 345-368).
+// The reference decrements the stock of a primer type at every attachment (Malbac.cpp:91-103) and walks the templates
+// in list order (one pool task at -t 1): a type is used exactly `stock` times, by the first `stock` attachments that ask
+// for it.  Counter mode keeps exactly that.  To stay free of the thread / shard schedule a pass is first run with every
+// worker looking at the stock as of the pass's START; if no type was then asked for more often than it has stock, its
+// availability never changed during the pass and the run IS the sequential loop's result.  Otherwise the pass is run
+// again the reference's way: one worker, list order, live decrement -- in a sharded job segment by segment in the whole
+// job's list order (`segs`: local template ranges and the order of the shards inside each), the stock handed from shard
+// to shard by an all-reduce to which only the segment's owner contributes.
+struct PassSeg { size_t lo, hi; bool shards_descending; };
+template <class RunRange>
+void amplify_pass(Sim& S, size_t n, size_t min_block, const std::vector<PassSeg>& segs, RunRange run, AmpList& all) {
+    const bool ctr = S.prm.counter; const int th = ctr ? S.prm.threads : 1;
+    auto gather = [&](std::vector<AmpList>& parts) {
+        for (auto& pt : parts) { for (auto a : pt.a) { uint32_t off = (uint32_t)all.errs.size();
+            for (uint32_t e = 0; e < a.err_cnt; ++e) all.errs.push_back(pt.errs[a.err_off + e]); a.err_off = off; all.a.push_back(a); } }
+    };
+    if (!ctr) { std::vector<AmpList> parts(1); PrimerPool pool{S, nullptr, true}; run(0, n, pool, parts[0]); gather(parts); return; }
+    {   std::vector<AmpList> parts; std::vector<std::vector<long>> pend;
+        size_t nbMax = (size_t)std::max(1, th) * 4; parts.resize(nbMax); pend.resize(nbMax);
+        parallel_blocks(n, th, min_block, [&](size_t b, size_t lo, size_t hi) { pend[b].assign(65536, 0); PrimerPool pool{S, &pend[b], false}; run(lo, hi, pool, parts[b]); });
+        std::vector<uint64_t> sum(65536, 0);
+        for (auto& v : pend) for (size_t i = 0; i < v.size(); ++i) sum[i] += (uint64_t)v[i];
+        S.allreduce(sum.data(), sum.size());                                        // sharded: the demand of all shards
+        bool over = false;
+        for (size_t i = 0; i < sum.size(); ++i) over |= (long)sum[i] > S.primerCount[i];
+        if (!over) {
+            for (size_t i = 0; i < sum.size(); ++i) { S.primerUsed[i] += (long)sum[i]; S.primerCount[i] -= (long)sum[i]; }
+            gather(parts); return;
+        }
+    }
+    S.exhausted_passes++;
+    std::vector<AmpList> parts(segs.size());
+    for (size_t sg = 0; sg < segs.size(); ++sg) for (int k = 0; k < S.prm.shard_count; ++k) {
+        const int owner = segs[sg].shards_descending ? S.prm.shard_count - 1 - k : k;
+        std::vector<long> took(65536, 0);
+        if (owner == S.prm.shard_rank) { PrimerPool pool{S, &took, true}; run(segs[sg].lo, segs[sg].hi, pool, parts[sg]); }
+        if (S.prm.shard_count > 1) {
+            std::vector<uint64_t> d(took.begin(), took.end());
+            S.allreduce(d.data(), d.size());
+            if (owner != S.prm.shard_rank) for (size_t i = 0; i < d.size(); ++i) { S.primerUsed[i] += (long)d[i]; S.primerCount[i] -= (long)d[i]; }
+        }
+    }
+    gather(parts);
 }
 
 // Malbac::amplifyFrags (Malbac.cpp:318-343)
 void amplify_frags(Sim& S, uint32_t pass) {
-    int th = S.prm.counter ? S.prm.threads : 1;
-    size_t n = S.frags.size();
-    std::vector<AmpList> parts; std::vector<std::vector<long>> pend;
-    size_t nbMax = (size_t)std::max(1, th) * 4; parts.resize(nbMax); pend.resize(nbMax);
-    parallel_blocks(n, th, 1, [&](size_t b, size_t lo, size_t hi) {
-        pend[b].assign(65536, 0); PrimerPool pool{S, &pend[b]}; std::vector<uint8_t> pa; Rng rng = S.rng;
+    const size_t n = S.frags.size();
+    AmpList all;
+    amplify_pass(S, n, 1, {PassSeg{0, n, false}}, [&](size_t lo, size_t hi, PrimerPool& pool, AmpList& out) {
+        std::vector<uint8_t> pa; Rng rng = S.rng;
         for (size_t i = lo; i < hi; ++i) {
             Frag& f = S.frags[i];
-            amplify_template(S, rng, pool, true, S.frag_gbase + i, (uint32_t)i, f.T.data(), f.len, f.primers, pass, pa, parts[b]);
+            amplify_template(S, rng, pool, true, S.frag_gbase + i, (uint32_t)i, f.T.data(), f.len, f.primers, pass, pa, out);
         }
-    });
-    AmpList all;
-    for (auto& pt : parts) { for (auto a : pt.a) { uint32_t off = (uint32_t)all.errs.size();
-        for (uint32_t e = 0; e < a.err_cnt; ++e) all.errs.push_back(pt.errs[a.err_off + e]); a.err_off = off; all.a.push_back(a); } }
-    apply_pending(S, pend);
+    }, all);
     append_reversed(S.semis, all);
     S.semi_block_end.push_back(S.semis.a.size());
 }
 // Malbac::amplifySemiAmplicons (Malbac.cpp:345-368)
 void amplify_semis(Sim& S, uint32_t cyc) {
-    int th = S.prm.counter ? S.prm.threads : 1;
-    size_t n = S.semis.a.size();
-    std::vector<AmpList> parts; std::vector<std::vector<long>> pend;
-    size_t nbMax = (size_t)std::max(1, th) * 4; parts.resize(nbMax); pend.resize(nbMax);
-    parallel_blocks(n, th, 64, [&](size_t b, size_t lo, size_t hi) {
-        pend[b].assign(65536, 0); PrimerPool pool{S, &pend[b]}; std::vector<uint8_t> pa, seq, tc; Rng rng = S.rng;
+    const size_t n = S.semis.a.size();
+    // the whole job's semi list: block p = the semis of fragment pass p, inside it the fragments DEscending (append_reversed),
+    // hence the shards of a sharded job (contiguous fragment ranges) descending too
+    std::vector<PassSeg> segs;
+    for (size_t pb = 0; pb < S.semi_block_end.size(); ++pb) segs.push_back(PassSeg{pb ? S.semi_block_end[pb - 1] : 0, S.semi_block_end[pb], true});
+    AmpList all;
+    amplify_pass(S, n, 64, segs, [&](size_t lo, size_t hi, PrimerPool& pool, AmpList& out) {
+        std::vector<uint8_t> pa, seq, tc; Rng rng = S.rng;
         for (size_t i = lo; i < hi; ++i) {
             const Amp& a = S.semis.a[i];
             if ((int)a.len < S.prm.ampMin + 27) continue;
             semi_sequence(S, a, seq); tc.resize(seq.size());
             for (size_t t = 0; t < seq.size(); ++t) tc[t] = comp_code(seq[t]);       // Amplicon.cpp:171-172
-            amplify_template(S, rng, pool, false, a.uid, (uint32_t)i, tc.data(), a.len, a.primers, cyc, pa, parts[b]);
+            amplify_template(S, rng, pool, false, a.uid, (uint32_t)i, tc.data(), a.len, a.primers, cyc, pa, out);
         }
-    });
-    AmpList all;
-    for (auto& pt : parts) { for (auto a : pt.a) { uint32_t off = (uint32_t)all.errs.size();
-        for (uint32_t e = 0; e < a.err_cnt; ++e) all.errs.push_back(pt.errs[a.err_off + e]); a.err_off = off; all.a.push_back(a); } }
-    apply_pending(S, pend);
+    }, all);
     {   // segments of this cycle in stored (reversed) order: semis made in fragment pass p, p descending
         std::vector<size_t> cnt(S.semi_block_end.size(), 0);
         for (auto& a : all.a) { size_t pblk = 0; while (a.parent >= S.semi_block_end[pblk]) ++pblk; cnt[pblk]++; }

@@ -34,6 +34,28 @@ def _gunzip_to(src, dst):
     return dst
 
 
+def write_repeat_genome(path, n=1500000, seed=11):
+    """A repeat-rich diploid input: i.i.d. bases with 2 kb runs of (A)n, (AC)n, (AG)n, (T)n, (GT)n over 25 % of it.  At
+    -p 10000 -r 1e-8 (the defaults' growth per cycle) the 8-mers of the runs exhaust their primer stock within 1.5 Mb."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    seq = np.frombuffer(b"ACGT", np.uint8)[rng.choice(4, size=n, p=[0.3, 0.2, 0.2, 0.3])].copy()
+    motifs = [b"A", b"AC", b"AG", b"T", b"GT"]
+    for pos in range(0, n - 8000, 8000):
+        m = motifs[rng.integers(len(motifs))]
+        seq[pos + 6000:pos + 8000] = np.frombuffer((m * 2000)[:2000], np.uint8)
+    with open(path, "wb") as f:
+        for hap in (1, 2):
+            f.write(b">9_%d_%d\n" % (hap, n))
+            f.write(np.concatenate([seq.reshape(-1, 100), np.full((n // 100, 1), 10, np.uint8)], axis=1).tobytes())
+    return path
+
+
+@pytest.fixture(scope="session")
+def repeat_genome(tmp_path_factory):
+    return write_repeat_genome(str(tmp_path_factory.mktemp("repeat") / "rep.fa"))
+
+
 @pytest.fixture(scope="session")
 def models(tmp_path_factory):
     """Unpacked copies of the shipped .profile data files (tests/golden/models/*.gz)."""

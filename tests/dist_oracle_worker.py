@@ -16,6 +16,7 @@ class Params(C.Structure):
 
 def main():
     fasta, profile, prefix, coverage, layout, seed = sys.argv[1:7]
+    primers, gamma = (int(sys.argv[7]), float(sys.argv[8])) if len(sys.argv) > 8 else (None, None)
     import torch.distributed as dist
     from scssim_amd.dist import Collectives
     dist.init_process_group("gloo")
@@ -27,6 +28,8 @@ def main():
     p.input_fasta, p.profile = fasta.encode(), profile.encode()
     p.output_prefix = ("%s.r%d" % (prefix, dist.get_rank())).encode()
     p.coverage, p.paired, p.seed, p.rng_mode, p.threads, p.verbose = float(coverage), int(layout == "PE"), int(seed), 1, 2, 0
+    if primers is not None:
+        p.primers, p.gamma = primers, gamma
     p.shard_rank, p.shard_count = dist.get_rank(), dist.get_world_size()
     p.allreduce = C.cast(coll.allreduce_cb, C.c_void_p)
     p.allgatherv = C.cast(coll.allgatherv_cb, C.c_void_p)
