@@ -59,6 +59,10 @@ typedef struct scs_stats {
     uint64_t sink_bytes[2];      /* bytes handed to the sink per mate: fastq_bytes, or their BGZF blocks' (scs_yield_reads_files_ex) */
     uint64_t staged_bases;       /* bases resident on this GPU: genome_bases, or -- a shard of a sharded job loaded from an indexed FASTA --
                                     only the stretch its own fragments cover (scs_load_genome_fasta) */
+    /* the primer stock of scs_amplify (Malbac::updatePrimerCount, lib/malbac/Malbac.cpp:91-103): passes whose demand was compared
+     * with the stock (a pass that cannot reach the smallest stock is not), passes in which a primer type ran dry, and the
+     * rounds it took to give such a type to exactly its first `stock` attachments in list order */
+    uint64_t stock_checks, stock_exhausted_passes, stock_rounds;
 } scs_stats;
 
 void        scs_default_config(scs_config* cfg);
@@ -225,6 +229,9 @@ int         scs_detlog_batch(scs_ctx* ctx, const double* x, size_t n, double* ou
 int         scs_download_amplicons(scs_ctx* ctx, int kind, uint32_t* parent, uint32_t* spos, uint32_t* len,
                                    uint32_t* gc, uint32_t* primers, uint64_t* uid, uint32_t* errs, uint32_t* nerr);
 int         scs_download_read_numbers(scs_ctx* ctx, uint32_t* read_numbers);
+/* The primer pool after scs_amplify: stock[65536], copies left of every primer type (PrimerIndex.count, lib/malbac/Malbac.h:18-24;
+ * index = the 8-mer at two bits per base, first base in the top bits). */
+int         scs_download_primer_stock(scs_ctx* ctx, int64_t* stock);
 
 /* ---- host-only table access (no GPU needed): the thresholds scs_load_profile uploads -------------
  * which: 0 subs read1 [84][bins][4], 1 subs read2, 2 quality [16][bins][94], 3 insert length,

@@ -33,7 +33,8 @@ class _Stats(C.Structure):
     _fields_ = [("records", C.c_uint64), ("genome_bases", C.c_uint64), ("fragments", C.c_uint64),
                 ("semi_amplicons", C.c_uint64), ("full_amplicons", C.c_uint64), ("primers_left", C.c_uint64),
                 ("reads_requested", C.c_uint64), ("pairs_written", C.c_uint64), ("reads_written", C.c_uint64),
-                ("fastq_bytes", C.c_uint64 * 2), ("algorithmic_bytes", C.c_uint64), ("t_stage", C.c_double * 8), ("sink_bytes", C.c_uint64 * 2), ("staged_bases", C.c_uint64)]
+                ("fastq_bytes", C.c_uint64 * 2), ("algorithmic_bytes", C.c_uint64), ("t_stage", C.c_double * 8), ("sink_bytes", C.c_uint64 * 2), ("staged_bases", C.c_uint64),
+                ("stock_checks", C.c_uint64), ("stock_exhausted_passes", C.c_uint64), ("stock_rounds", C.c_uint64)]
 
 
 _SINK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t)
@@ -81,6 +82,7 @@ def load_library():
     L.scs_detlog_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     L.scs_download_amplicons.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 8
     L.scs_download_read_numbers.argtypes = [C.c_void_p, C.c_void_p]
+    L.scs_download_primer_stock.argtypes = [C.c_void_p, C.c_void_p]
     L.scs_profile_open.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.c_char_p, C.c_size_t]
     L.scs_profile_table.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.POINTER(C.c_double)), C.POINTER(C.c_size_t)]
     L.scs_profile_scalars.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
@@ -488,6 +490,13 @@ class GenReads:
         self._ck(self._L.scs_download_amplicons(self._ctx, kind, ptr(a["parent"]), ptr(a["spos"]), ptr(a["len"]), ptr(a["gc"]),
                                                 ptr(a["primers"]), ptr(a["uid"]), ptr(a["errs"]), ptr(a["nerr"])))
         return a
+
+    def download_primer_stock(self):
+        """Copies of every primer type left after amplify (PrimerIndex.count, lib/malbac/Malbac.h:18-24), index = 2-bit-packed 8-mer."""
+        import numpy as np
+        st = np.zeros(65536, np.int64)
+        self._ck(self._L.scs_download_primer_stock(self._ctx, st.ctypes.data_as(C.c_void_p)))
+        return st
 
     def download_read_numbers(self):
         np = self._np

@@ -79,7 +79,8 @@ __host__ __device__ void write_deflate_header(const uint8_t* len, W& w) {
 }
 
 // Huffman code lengths (at most 15 bits) of the m used symbols order[0..m) (ascending frequency); w / par: 2 m scratch entries
-__host__ __device__ inline void huff_lengths(const uint32_t* freq, const uint16_t* order, uint32_t m, uint32_t* w, uint16_t* par, uint8_t* len) {
+// returns whether the lengths form a complete prefix code (Kraft sum exactly 1; the callers store the block otherwise)
+__host__ __device__ inline bool huff_lengths(const uint32_t* freq, const uint16_t* order, uint32_t m, uint32_t* w, uint16_t* par, uint8_t* len) {
     // the tree by the two-queue method: leaves 0..m-1 in ascending weight, internal nodes m.. in creation (= ascending) order
     for (uint32_t i = 0; i < m; ++i) w[i] = freq[order[i]];
     uint32_t li = 0, ni = m, nn = m;
@@ -92,11 +93,15 @@ __host__ __device__ inline void huff_lengths(const uint32_t* freq, const uint16_
     uint32_t bl[17]; for (int i = 0; i < 17; ++i) bl[i] = 0;
     w[nn - 1] = 0;                                        // the weights are spent: the array now holds depths
     int overflow = 0;
-    for (int i = (int)nn - 2; i >= 0; --i) { uint32_t d = w[par[i]] + 1u; if (d > 15u) { d = 15u; if ((uint32_t)i < m) ++overflow; } w[i] = d; if ((uint32_t)i < m) ++bl[d]; }
+    // (zlib counts EVERY node deeper than the limit, internal ones included: a subtree of L leaves hanging at depth 15 needs L - 1
+    // repair rounds, not L / 2 -- counting the leaves alone left the code oversubscribed for trees deeper than 17)
+    for (int i = (int)nn - 2; i >= 0; --i) { uint32_t d = w[par[i]] + 1u; if (d > 15u) { d = 15u; ++overflow; } w[i] = d; if ((uint32_t)i < m) ++bl[d]; }
     if (m == 1) bl[1] = 1;                                // (a lone symbol would still need one bit; the callers always have two)
     while (overflow > 0) { uint32_t bits = 14; while (bl[bits] == 0) --bits; --bl[bits]; bl[bits + 1] += 2; --bl[15]; overflow -= 2; }
     uint32_t idx = 0;                                     // the longest codes go to the rarest symbols
     for (uint32_t bits = 15; bits >= 1; --bits) for (uint32_t c = bl[bits]; c; --c) len[order[idx++]] = (uint8_t)bits;
+    uint32_t kraft = 0; for (uint32_t bits = 1; bits <= 15; ++bits) kraft += bl[bits] << (15u - bits);
+    return kraft == (1u << 15) || m == 1;
 }
 
 }  // namespace
@@ -138,13 +143,13 @@ __global__ void __launch_bounds__(256) k_bgzf_plan(const uint8_t* __restrict__ t
     __syncthreads();
     if (tid == 0) {
         const uint32_t m = s_used;                        // >= 2: a literal and the end-of-block symbol
-        huff_lengths(s_freq, s_order, m, s_w, s_par, s_len);
+        const bool complete = huff_lengths(s_freq, s_order, m, s_w, s_par, s_len);
         // exact size: BGZF header 18 + deflate (3 header bits ... + data + end-of-block) + CRC32 + ISIZE
         BitCount bc{0}; write_deflate_header(s_len, bc);
         uint64_t bits = bc.bits;
         for (uint32_t i = 0; i < m; ++i) { const uint32_t s = s_order[i]; bits += (uint64_t)s_freq[s] * s_len[s]; }
         uint32_t cbytes = (uint32_t)((bits + 7) >> 3), stored = 0;
-        if (cbytes > BGZF_LDS_OUT || cbytes >= n + 5u) { cbytes = n + 5u; stored = 1; }   // stored deflate block: 1 + LEN + NLEN + the bytes
+        if (!complete || cbytes > BGZF_LDS_OUT || cbytes >= n + 5u) { cbytes = n + 5u; stored = 1; }   // stored deflate block: 1 + LEN + NLEN + the bytes
         s_len[BGZF_PLAN_BYTES - 1] = (uint8_t)stored;
         sizes[blockIdx.x] = 18u + cbytes + 8u;
     }
@@ -282,11 +287,11 @@ void bgzf_compress_host(const uint8_t* text, uint64_t nbytes, uint32_t lds_out_c
         freq[256] = 1;
         for (uint32_t s = 0; s < NSYM; ++s) if (freq[s]) order.push_back((uint16_t)s);
         std::stable_sort(order.begin(), order.end(), [&](uint16_t a, uint16_t b) { return freq[a] < freq[b]; });
-        huff_lengths(freq.data(), order.data(), (uint32_t)order.size(), w.data(), par.data(), len);
+        const bool complete = huff_lengths(freq.data(), order.data(), (uint32_t)order.size(), w.data(), par.data(), len);
         BitCount bc{0}; write_deflate_header(len, bc);
         uint64_t bits = bc.bits; for (uint16_t s : order) bits += (uint64_t)freq[s] * len[s];
         uint32_t cbytes = (uint32_t)((bits + 7) >> 3); bool stored = false;
-        if (cbytes > lds_out_cap || cbytes >= n + 5u) { cbytes = n + 5u; stored = true; }
+        if (!complete || cbytes > lds_out_cap || cbytes >= n + 5u) { cbytes = n + 5u; stored = true; }
         const uint32_t total = 18u + cbytes + 8u;
         // emit
         std::vector<uint8_t> img(total + 8, 0);

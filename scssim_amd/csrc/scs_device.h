@@ -79,7 +79,8 @@ struct PoissonParams {
 // [8] semis, [9] their length, [10] primers left in the pool, [11],[12] {templateNum, totalLen} for setPrimers,
 // [13],[14] fragments and their length over all shards (constants)
 enum { DS_HOLES = 20 };                                // pairs planned but not produced (k_plan_pairs; zeroed by scs_yield_reads)
-enum { DS_SEMI_LEN = 4, DS_SEMIS_N = 5, DS_REPORTED_LEN = 6, DS_G_SEMIS_N = 8, DS_G_SEMI_LEN = 9, DS_G_PRIMERS = 10, DS_G_TOTALS = 11, DS_G_NF = 13, DS_G_FRAG_LEN = 14 };
+enum { DS_SEMI_LEN = 4, DS_SEMIS_N = 5, DS_REPORTED_LEN = 6, DS_G_SEMIS_N = 8, DS_G_SEMI_LEN = 9, DS_G_PRIMERS = 10, DS_G_TOTALS = 11, DS_G_NF = 13, DS_G_FRAG_LEN = 14,
+       DS_MIN_STOCK = 15 };                            // the smallest primer stock > 0 seen at the end of any pass so far (a lower bound of every stock in use)
 enum { SHARD_TAIL_WORDS = 16 };                       // u32 words behind the 65536 primer decrements that ride on the same all-reduce
 struct AllocState { double total; unsigned long long sum_rn, sum_quota; };
 
@@ -116,9 +117,12 @@ struct PairRec {
 };
 
 // ---- launch wrappers (scs_kernels.hip) --------------------------------------------------------------
+// one pass of primer attachment over the templates [t_first, t_end) of the pass's list; primer_cut: the stock as k_attach sees it
+// (scs_kernels.hip, "the primer stock, exactly"); undo: the templates were run before in this pass -- what they took then is taken back first
 void launch_attach_frags(hipStream_t s, const uint8_t* g, DevFrags fr, const uint32_t* slot_off, uint32_t* slots,
-                         uint32_t* slot_tmpl, uint32_t* valid, const int64_t* primer_cnt, uint32_t* primer_delta,
-                         unsigned long long* len_sum, unsigned long long* len_part, AmplifyParams p);   // len_part: one slot per fragment
+                         uint32_t* slot_tmpl, uint32_t* valid, const unsigned long long* primer_cut, uint32_t* primer_delta,
+                         unsigned long long* len_part, AmplifyParams p, uint32_t t_first, uint32_t t_end, int undo, const unsigned long long* t_from);   // len_part: one slot per fragment; t_from (device, or null): skip the templates before it
+void launch_frag_len_sum(hipStream_t s, const unsigned long long* len_part, uint32_t nf, unsigned long long* len_sum);   // *len_sum += the pass's amplicon lengths
 void launch_poisson(hipStream_t s, DevFrags fr, DevAmps semis, uint32_t n_semis, PoissonParams p, uint32_t* budget_f, uint32_t* budget_s,
                     unsigned long long* sums, unsigned long long* part);   // part: one slot per workgroup (fragments + ceil((n_semis + 1) / 256))
 // read allocation, stage by stage (the pipeline puts the shards' exchanges between them)
@@ -136,14 +140,24 @@ void launch_alloc_odd_counts(hipStream_t s, const uint32_t* odd_before, const Al
 void launch_alloc_parity(hipStream_t s, uint32_t* rn, const uint32_t* odd_before, uint32_t ac, const AllocPlan& pl, const unsigned long long* table);
 void launch_attach_semis(hipStream_t s, const uint8_t* g, DevFrags fr, DevAmps semis, uint32_t n_semis, DevErrPool spool,
                          const uint32_t* slot_off, uint32_t* slots, uint32_t* slot_tmpl, uint32_t* valid,
-                         const int64_t* primer_cnt, uint32_t* primer_delta, AmplifyParams p);
+                         const unsigned long long* primer_cut, uint32_t* primer_delta, AmplifyParams p, uint32_t t_first, uint32_t t_end, int undo, const unsigned long long* t_from);
+// exact primer stock: over-/under-demand of the pass so far (info: 8 words), the attachments of the over-demanded types, their sort, the new cuts
+void launch_stock_check(hipStream_t s, const int64_t* cnt, const uint32_t* taken, unsigned long long* cut, bool from_frag, uint32_t* eidx, uint32_t* etype, uint32_t* estart, unsigned long long* info);
+void launch_stock_collect(hipStream_t s, const uint8_t* g, DevFrags fr, DevAmps semis, DevErrPool spool, bool from_frag, const uint32_t* slot_off, const uint32_t* slots,
+                          const uint32_t* valid, const uint32_t* eidx, unsigned long long* list, unsigned long long* info, uint32_t t_first, uint32_t t_end);
+size_t stock_sort_temp_bytes(size_t n);
+void launch_stock_sort(hipStream_t s, const unsigned long long* in, unsigned long long* out, size_t n, void* temp, size_t temp_bytes);
+void launch_stock_pick(hipStream_t s, const int64_t* cnt, const uint32_t* etype, const uint32_t* estart, uint32_t ne, const unsigned long long* sorted, unsigned long long* cut,
+                       bool from_frag, unsigned long long* info);
+void launch_stock_apply(hipStream_t s, int64_t* cnt, uint32_t* gdelta, uint32_t* delta, unsigned long long* cut, uint32_t* flags);
 void launch_errs_frags(hipStream_t s, const uint8_t* g, DevGenomeIdx gx, DevFrags fr, uint32_t n_slots, const uint32_t* slot_off, const uint32_t* slots,
                        const uint32_t* slot_tmpl, const uint32_t* valid_off, DevAmps out, uint32_t out_base, DevErrPool pool, uint32_t* flags,
-                       const unsigned long long* binom, AmplifyParams p, int64_t* primer_cnt, uint32_t* primer_delta, unsigned long long* semis_n);
+                       const unsigned long long* binom, AmplifyParams p, int64_t* primer_cnt, uint32_t* primer_delta, unsigned long long* primer_cut, unsigned long long* sums,
+                       unsigned long long* semis_n);
 void launch_errs_semis(hipStream_t s, const uint8_t* g, DevGenomeIdx gx, DevFrags fr, DevAmps semis, uint32_t n_semis, DevErrPool spool, uint32_t n_slots,
                        const uint32_t* slot_off, const uint32_t* slots, const uint32_t* slot_tmpl, const uint32_t* valid_off,
                        DevAmps out, uint32_t out_base, DevErrPool pool, uint32_t* flags, const unsigned long long* binom, AmplifyParams p,
-                       int64_t* primer_cnt, uint32_t* primer_delta);   // primer_cnt non-null: the pass's stock update rides along (unsharded job)
+                       int64_t* primer_cnt, uint32_t* primer_delta, unsigned long long* primer_cut, unsigned long long* sums);   // primer_cnt non-null: the pass's stock update rides along (unsharded job)
 void launch_encode_bases(hipStream_t s, uint8_t* g, uint64_t n);
 void launch_fa_gather_regular(hipStream_t s, const uint8_t* raw, uint8_t* dst, uint64_t n, uint32_t col0, uint32_t lb, uint32_t lw);   // a piece of a regular FASTA record without its line ends
 void launch_frag_has_n(hipStream_t s, const uint64_t* goff, const uint32_t* len, uint32_t nf, DevGenomeIdx gx, uint8_t* has_n);
@@ -156,9 +170,9 @@ void launch_fasta_chunk(hipStream_t s, const uint8_t* raw, uint32_t n, unsigned 
 void launch_sv_build(hipStream_t s, const uint8_t* ref, const uint8_t* lit, const SvPiece* pieces, uint32_t np, const SvSubst* subs, uint32_t nsub, uint8_t* out, uint64_t total);
 void launch_genome_bits(hipStream_t s, const uint8_t* g, uint64_t n, uint64_t nwords, unsigned long long* gc_bits, unsigned long long* n_bits,
                         uint32_t* gc_cnt, uint32_t* n_cnt, uint64_t* gc_pref, uint64_t* n_pref, void* temp, size_t temp_bytes, uint32_t* g2);   // g2: the genome at two bits per base ((nwords + 1) * 4 words)
-void launch_amplify_init(hipStream_t s, int64_t* primer_cnt, int64_t copies, uint32_t* primer_delta, uint32_t* flags, unsigned long long* sums,
-                         unsigned long long nf_all, unsigned long long frag_len_all, unsigned long long total_primers, uint32_t* pool_head_a, uint32_t* pool_head_b);
-void launch_primer_update(hipStream_t s, int64_t* primer_cnt, uint32_t* primer_delta);
+void launch_amplify_init(hipStream_t s, int64_t* primer_cnt, unsigned long long* primer_cut, int64_t copies, uint32_t* primer_delta, uint32_t* primer_gdelta, uint32_t* flags, unsigned long long* sums,
+                         unsigned long long nf_all, unsigned long long frag_len_all, unsigned long long total_primers, uint32_t* pool_head_a, uint32_t* pool_head_b);   // primer_gdelta: a sharded job's exchange buffer (else null)
+void launch_primer_update(hipStream_t s, int64_t* primer_cnt, uint32_t* primer_delta, unsigned long long* primer_cut, unsigned long long* dsums, uint32_t* flags);
 void launch_weights(hipStream_t s, DevAmps fulls, uint32_t n, DevTables tb, RngKey key, uint32_t frag_size, double* w);
 void launch_plan_pairs(hipStream_t s, DevFrags fr, DevAmps semis, DevAmps fulls, uint32_t first, uint32_t n_fulls, uint32_t pair_lo, uint32_t pair_hi, const uint32_t* read_numbers,
                        const uint32_t* pair_off, SegMap gmap, DevTables tb, RngKey key, int paired, PairRec* pairs, unsigned long long* holes);   // amplicons [first, first + n_fulls); writes (and counts the holes of) the pairs [pair_lo, pair_hi) only
@@ -195,8 +209,8 @@ void launch_detlog(hipStream_t s, const double* x, uint32_t n, double* out);
 // gathers up to 12 device scalars (4 or 8 bytes wide) into mail[dsts[i]] (u64 each)
 #define MAIL_SEQ_SLOT 31                                   // mailbox word the sequence number of a post lands in
 void launch_mail(hipStream_t s, const void* const* srcs, const int* widths, const int* dsts, int n, unsigned clear, unsigned long long* mail, unsigned long long seq);   // n <= 16
-void launch_shard_tail(hipStream_t s, uint32_t* primer_delta, unsigned long long* dsums, const uint32_t* new_semis, int with_budgets);
-void launch_primer_update_sharded(hipStream_t s, int64_t* primer_cnt, uint32_t* primer_delta, unsigned long long* dsums);
+void launch_shard_tail(hipStream_t s, uint32_t* primer_gdelta, const unsigned long long* dsums, const uint32_t* new_semis, int with_budgets);
+void launch_primer_update_sharded(hipStream_t s, int64_t* primer_cnt, uint32_t* primer_gdelta, uint32_t* primer_delta, unsigned long long* primer_cut, unsigned long long* dsums, uint32_t* flags, int with_budgets);
 
 // first error of any kernel launch / attribute call since the last call (hipSuccess if none)
 hipError_t take_launch_error();

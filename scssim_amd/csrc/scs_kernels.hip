@@ -114,49 +114,76 @@ __device__ __forceinline__ uint32_t rand_indx_thr(const uint32_t* __restrict__ T
 }
 
 // start of Malbac::amplify: createPrimers (4^8 primer types x `copies`, Malbac.cpp:204-234) + the run's device scalars
-__global__ void k_amplify_init(int64_t* __restrict__ cnt, int64_t copies, uint32_t* __restrict__ delta, uint32_t* __restrict__ flags,
+__global__ void k_amplify_init(int64_t* __restrict__ cnt, unsigned long long* __restrict__ cut, int64_t copies, uint32_t* __restrict__ delta, uint32_t* __restrict__ gdelta, uint32_t* __restrict__ flags,
                                unsigned long long* __restrict__ sums, unsigned long long nf_all, unsigned long long frag_len_all, unsigned long long total_primers,
                                uint32_t* __restrict__ pool_head_a, uint32_t* __restrict__ pool_head_b) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < 65536) { cnt[i] = copies; delta[i] = 0; }
-    if (i < SHARD_TAIL_WORDS) delta[65536 + i] = 0;
-    if (i < 16) sums[i] = i == DS_G_PRIMERS ? total_primers : i == DS_G_TOTALS || i == DS_G_NF ? nf_all : i == DS_G_TOTALS + 1 || i == DS_G_FRAG_LEN ? frag_len_all : 0ull;
+    if (i < 65536) { cnt[i] = copies; cut[i] = copies > 0 ? ~0ull : 0ull; delta[i] = 0; if (gdelta) gdelta[i] = 0; }
+    if (i < SHARD_TAIL_WORDS && gdelta) gdelta[65536 + i] = 0;
+    if (i < 16) sums[i] = i == DS_G_PRIMERS ? total_primers : i == DS_G_TOTALS || i == DS_G_NF ? nf_all : i == DS_G_TOTALS + 1 || i == DS_G_FRAG_LEN ? frag_len_all : i == DS_MIN_STOCK ? (unsigned long long)copies : 0ull;
     if (i == 0) { flags[0] = 0; if (pool_head_a) *pool_head_a = 0; if (pool_head_b) *pool_head_b = 0; }   // error overflow pools of the two amplicon stores
 }
-// sharded job.  What the shards owe each other besides the primer decrements -- the semi amplicons a fragment pass made
-// (count, total length) and the budgets the last setPrimers handed out -- rides on the SAME all-reduce, as 24-bit limbs in
-// 32-bit words behind the 65536 counters: k_shard_tail writes this shard's share before the collective ...
-__global__ void k_shard_tail(uint32_t* __restrict__ delta, unsigned long long* __restrict__ sums, const uint32_t* __restrict__ new_semis, int with_budgets) {
+// end of a pass (every lane of the wave calls it): the stock loses what the pass took -- never more than there was (k_attach's
+// cuts, exact_stock) --, the next pass's cuts (all of it / none of it), the smallest stock left (the host skips the
+// over-demand check of a pass that cannot reach it)
+__device__ __forceinline__ void stock_update(uint32_t i, int64_t* __restrict__ cnt, const uint32_t* __restrict__ taken, uint32_t* __restrict__ delta, unsigned long long* __restrict__ cut,
+                                             unsigned long long* __restrict__ sums, uint32_t* __restrict__ flags) {
+    unsigned long long left = ~0ull;
+    if (i < 65536u) {
+        int64_t c = cnt[i] - (int64_t)taken[i];
+        if (c < 0) { atomicOr(flags, (uint32_t)FLAG_INTERNAL); c = 0; }
+        cnt[i] = c; cut[i] = c > 0 ? ~0ull : 0ull; delta[i] = 0;
+        if (c > 0) left = (unsigned long long)c;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const unsigned long long o = ((unsigned long long)(uint32_t)__shfl_xor((int)(left >> 32), d) << 32) | (uint32_t)__shfl_xor((int)left, d);
+        left = o < left ? o : left;
+    }
+    if ((threadIdx.x & 63u) == 0 && left != ~0ull) atomicMin(&sums[DS_MIN_STOCK], left);
+}
+// sharded job.  What the shards owe each other besides what they took from the stock -- the semi amplicons a fragment pass
+// made (count, total length) and the budgets the last setPrimers handed out -- rides on the pass's closing all-reduce, as
+// 24-bit limbs in 32-bit words behind the 65536 counters: k_shard_tail writes this shard's share before the collective ...
+__global__ void k_shard_tail(uint32_t* __restrict__ gdelta, const unsigned long long* __restrict__ sums, const uint32_t* __restrict__ new_semis, int with_budgets) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    uint32_t* t = delta + 65536;
-    const unsigned long long len = sums[DS_SEMI_LEN] - sums[DS_REPORTED_LEN]; sums[DS_REPORTED_LEN] = sums[DS_SEMI_LEN];
+    uint32_t* t = gdelta + 65536;
+    const unsigned long long len = sums[DS_SEMI_LEN] - sums[DS_REPORTED_LEN];
     t[0] = new_semis ? *new_semis : 0u;
     t[1] = (uint32_t)(len & 0xFFFFFFull); t[2] = (uint32_t)((len >> 24) & 0xFFFFFFull); t[3] = (uint32_t)(len >> 48);
     for (int k = 0; k < 2; ++k) {
         const unsigned long long b = with_budgets ? sums[k] : 0ull;
         t[4 + 3 * k] = (uint32_t)(b & 0xFFFFFFull); t[5 + 3 * k] = (uint32_t)((b >> 24) & 0xFFFFFFull); t[6 + 3 * k] = (uint32_t)(b >> 48);
-        if (with_budgets) sums[k] = 0;
     }
 }
 // ... and the stock update after it folds the summed tail into the whole-job scalars that setPrimers reads
-__global__ void k_primer_update_sharded(int64_t* __restrict__ cnt, uint32_t* __restrict__ delta, unsigned long long* __restrict__ sums) {
+__global__ void k_primer_update_sharded(int64_t* __restrict__ cnt, uint32_t* __restrict__ gdelta, uint32_t* __restrict__ delta, unsigned long long* __restrict__ cut,
+                                        unsigned long long* __restrict__ sums, uint32_t* __restrict__ flags, int with_budgets) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < 65536) { const int64_t c = cnt[i] - (int64_t)delta[i]; cnt[i] = c < 0 ? 0 : c; delta[i] = 0; }
+    stock_update(i, cnt, gdelta, delta, cut, sums, flags);
+    if (i < 65536u) gdelta[i] = 0;
     if (i == 0) {
-        uint32_t* t = delta + 65536;
+        uint32_t* t = gdelta + 65536;
         auto limbs = [&](int o) { return (unsigned long long)t[o] + ((unsigned long long)t[o + 1] << 24) + ((unsigned long long)t[o + 2] << 48); };
         sums[DS_G_SEMIS_N] += t[0]; sums[DS_G_SEMI_LEN] += limbs(1);
         sums[DS_G_PRIMERS] -= limbs(4) + limbs(7);
         sums[DS_G_TOTALS] = sums[DS_G_NF] + sums[DS_G_SEMIS_N]; sums[DS_G_TOTALS + 1] = sums[DS_G_FRAG_LEN] + sums[DS_G_SEMI_LEN];
+        sums[DS_REPORTED_LEN] = sums[DS_SEMI_LEN];
+        if (with_budgets) { sums[0] = 0; sums[1] = 0; }
         for (int k = 0; k < SHARD_TAIL_WORDS; ++k) t[k] = 0;
     }
 }
-__global__ void k_primer_update(int64_t* __restrict__ cnt, uint32_t* __restrict__ delta) {
+__global__ void k_primer_update(int64_t* __restrict__ cnt, uint32_t* __restrict__ delta, unsigned long long* __restrict__ cut, unsigned long long* __restrict__ sums, uint32_t* __restrict__ flags) {
+    stock_update(blockIdx.x * blockDim.x + threadIdx.x, cnt, delta, delta, cut, sums, flags);
+}
+// sharded job, a pass run again segment by segment (exact_stock): the stock after the segment its owner has just finished
+// (gdelta: what the owner took, summed over the shards: everybody else sent zeros)
+__global__ void k_stock_apply(int64_t* __restrict__ cnt, uint32_t* __restrict__ gdelta, uint32_t* __restrict__ delta, unsigned long long* __restrict__ cut, uint32_t* __restrict__ flags) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= 65536) return;
-    int64_t c = cnt[i] - (int64_t)delta[i];
-    cnt[i] = c < 0 ? 0 : c;                                                      // [REMAP] clamp at pass end
-    delta[i] = 0;
+    if (i >= 65536u) return;
+    int64_t c = cnt[i] - (int64_t)gdelta[i];
+    if (c < 0) { atomicOr(flags, (uint32_t)FLAG_INTERNAL); c = 0; }
+    cnt[i] = c; cut[i] = c > 0 ? ~0ull : 0ull; delta[i] = 0; gdelta[i] = 0;
 }
 
 // ASCII -> base code, in place (0..3 = ACGT either case, 4 = anything else): Genome::getSubSequence's toupper
@@ -337,14 +364,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
                                               const uint32_t* __restrict__ slot_tmpl, const uint32_t* __restrict__ valid_off, uint32_t n_tmpl,
                                               DevAmps out, uint32_t out_base, DevErrPool pool, uint32_t* __restrict__ flags,
                                               const unsigned long long* __restrict__ binom, AmplifyParams p,
-                                              int64_t* __restrict__ primer_cnt, uint32_t* __restrict__ primer_delta, unsigned long long* __restrict__ semis_n) {
+                                              int64_t* __restrict__ primer_cnt, uint32_t* __restrict__ primer_delta, unsigned long long* __restrict__ primer_cut,
+                                              unsigned long long* __restrict__ sums, unsigned long long* __restrict__ semis_n) {
     __shared__ uint16_t s_item[4][256], s_res[4][256];                             // per wave: the errors of its amplicons (owner lane | index << 6), and what came back
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
-    // the pass epilogue rides along (unsharded job; a sharded one all-reduces the decrements first and launches
-    // k_primer_update): primer stock -= this pass's decrements, clamped ([REMAP] snapshot per pass), and the device-side
-    // semi amplicon count that the next setPrimers reads
-    if (primer_cnt) for (uint32_t i = w; i < 65536u; i += gridDim.x * blockDim.x) { const int64_t c = primer_cnt[i] - (int64_t)primer_delta[i]; primer_cnt[i] = c < 0 ? 0 : c; primer_delta[i] = 0; }
+    // the pass epilogue rides along (unsharded job; a sharded one all-reduces what the shards took first and launches
+    // k_primer_update_sharded): primer stock -= what this pass took, and the device-side semi amplicon count that the next
+    // setPrimers reads
+    if (primer_cnt && w < 65536u) stock_update(w, primer_cnt, primer_delta, primer_delta, primer_cut, sums, flags);   // (the grid has at least 256 workgroups then)
     if (FROM_FRAG && w == 0 && semis_n) *semis_n += valid_off[n_tmpl];
     // fragments: a thread per reserved slot (nearly all of them are used).  Semi amplicons: three quarters of the reserved
     // slots stay unused (most primers find no place on a 1-2 kb template), so k_expand_items has listed the template of every
@@ -1922,6 +1950,111 @@ __global__ void __launch_bounds__(1024) k_poisson_sums(const unsigned long long*
 }
 
 // ------------------------------------------------------------------------------------------------
+// a2  the primer stock, exactly (Malbac::updatePrimerCount, lib/malbac/Malbac.cpp:91-103: decrement if positive, under
+//     a mutex; at -t 1 the attachments of a pass ask in list order: template by template, primer by primer).  A type is
+//     used exactly `stock` times -- by the FIRST `stock` attachments in list order that ask for it.
+//     An attachment's place in that order is its key (template index, primer index).  k_attach takes a type when
+//     key <= cut[type].  A pass starts with cut = "all of the pass" for every type in stock (none for the others): if no
+//     type was then taken more often than it has stock -- every pass of a job whose primers do not run out -- the pass IS
+//     the sequential loop's result.  Otherwise (exact_stock in scs_pipeline.cpp) the over-demanded types get the key of
+//     their stock-th attachment as cut (k_stock_collect, a sort, k_stock_pick) and the templates from the earliest such
+//     key on are run again (k_attach with undo); what they now take elsewhere may move other cuts, so this repeats until
+//     no type is over its stock and no cut type under it: at that fixed point every decision equals the sequential
+//     loop's (induction over the keys), and each round extends the prefix of the list on which that holds.
+// ------------------------------------------------------------------------------------------------
+#define STOCK_KEY_BITS 46                                                           // (fragment < 2^26, primer < 2^20) or (semi < 2^32, primer < 2^12), + 1
+template <bool FROM_FRAG> __device__ __forceinline__ unsigned long long attach_key(uint32_t t, uint32_t i) {
+    return (((unsigned long long)t << (FROM_FRAG ? 20 : 12)) | i) + 1ull;         // never 0: cut 0 = nothing to be had
+}
+// one workgroup: which types were taken more often than they have stock (over), which cut types less (under: an earlier
+// round's cut came too early -- it is lifted, and the pass is run again from where it lay); the over types numbered in type
+// order, the start of each one's stretch in the sorted list of their attachments.  info: [0] over types, [1] their
+// attachments, [2] under types, [3] first template to run again on account of the under types; [5] (k_stock_collect's cursor) and
+// [6] (k_stock_pick's first template) are reset here
+__global__ void __launch_bounds__(1024) k_stock_check(const int64_t* __restrict__ cnt, const uint32_t* __restrict__ taken, unsigned long long* __restrict__ cut, int key_shift,
+                                                      uint32_t* __restrict__ eidx, uint32_t* __restrict__ etype, uint32_t* __restrict__ estart, unsigned long long* __restrict__ info) {
+    __shared__ uint32_t s_n[1024], s_m[1024]; __shared__ uint32_t s_under, s_tmin;
+    const uint32_t tid = threadIdx.x;
+    if (tid == 0) { s_under = 0; s_tmin = 0xFFFFFFFFu; }
+    __syncthreads();
+    uint32_t n = 0, m = 0, under = 0, tmin = 0xFFFFFFFFu;
+    for (uint32_t k = 0; k < 64; ++k) {
+        const uint32_t x = tid * 64 + k; const int64_t c = cnt[x]; const uint32_t d = taken[x];
+        if ((int64_t)d > c) { ++n; m += d; }
+        else { const unsigned long long q = cut[x]; if (q != 0ull && q != ~0ull && (int64_t)d < c) { ++under; tmin = min(tmin, (uint32_t)((q - 1ull) >> key_shift)); cut[x] = ~0ull; } }
+    }
+    s_n[tid] = n; s_m[tid] = m;
+    if (under) { atomicAdd(&s_under, under); atomicMin(&s_tmin, tmin); }
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {                                      // inclusive scans of both counts
+        const uint32_t a = tid >= d ? s_n[tid - d] : 0u, b = tid >= d ? s_m[tid - d] : 0u;
+        __syncthreads();
+        s_n[tid] += a; s_m[tid] += b;
+        __syncthreads();
+    }
+    uint32_t e = s_n[tid] - n, off = s_m[tid] - m;
+    for (uint32_t k = 0; k < 64; ++k) {
+        const uint32_t x = tid * 64 + k; const uint32_t d = taken[x];
+        if ((int64_t)d > cnt[x]) { eidx[x] = e; etype[e] = x; estart[e] = off; ++e; off += d; } else eidx[x] = 0xFFFFFFFFu;
+    }
+    if (tid == 1023) { info[0] = s_n[1023]; info[1] = s_m[1023]; info[2] = s_under; info[3] = s_tmin; info[5] = 0; info[6] = s_tmin; }
+}
+// the attachments of the over-demanded types: (type's number, key) of every one the pass has made, in any order
+template <bool FROM_FRAG, int G>
+__global__ void __launch_bounds__(64) k_stock_collect(const uint8_t* __restrict__ g, DevFrags fr, DevAmps semis, DevErrPool spool, const uint32_t* __restrict__ slot_off,
+                                                      const uint32_t* __restrict__ slots, const uint32_t* __restrict__ valid, const uint32_t* __restrict__ eidx,
+                                                      unsigned long long* __restrict__ list, unsigned long long* __restrict__ info, uint32_t t_first, uint32_t t_end) {
+    constexpr int TPB = 64 / G;
+    const int lane = threadIdx.x, gi = lane / G, gl = lane % G;
+    const uint32_t t = t_first + blockIdx.x * TPB + gi;
+    uint32_t len = 0, n = 0, base_slot = 0; uint64_t errs = 0; View tv{0, 1, 0};
+    if (t < t_end) {
+        n = valid[t]; base_slot = slot_off[t];
+        if (FROM_FRAG) { len = fr.len[t]; tv = frag_view(fr.goff[t], len, fr.strand[t]); }
+        else {
+            const uint32_t f = semis.parent[t], sl = semis.sl[t];
+            len = sl_len(sl); errs = semis.errs[t];
+            tv = semi_tmpl_view(frag_view(fr.goff[f], fr.len[f], fr.strand[f]), sl_spos(sl), len);
+        }
+    }
+    uint32_t rounds = (n + G - 1) / G;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) rounds = max(rounds, (uint32_t)__shfl_xor((int)rounds, d));
+    for (uint32_t r = 0; r < rounds; ++r) {
+        const uint32_t w = r * G + gl; uint32_t e = 0xFFFFFFFFu;
+        if (w < n) {
+            const uint32_t sp = sl_spos(slots[base_slot + w]);
+            unsigned long long v8 = view_bases8(g, tv, sp);
+            if (!FROM_FRAG) for_each_err(errs, spool.data, [&](uint32_t er) {
+                const uint32_t k = len - 1u - err_pos(er) - sp;
+                if (k < 8u) v8 = (v8 & ~(0xFFull << (8u * k))) | ((unsigned long long)(3u - err_alt(er)) << (8u * k));
+            });
+            uint32_t idx = 0;
+#pragma unroll
+            for (uint32_t k = 0; k < 8; ++k) idx = (idx << 2) | ((uint32_t)(v8 >> (8u * k)) & 3u);
+            e = eidx[idx];
+        }
+        const unsigned long long hit = __ballot(e != 0xFFFFFFFFu);
+        if (hit) {
+            unsigned long long base = 0;
+            if (lane == __ffsll((long long)hit) - 1) base = atomicAdd(&info[5], (unsigned long long)__popcll(hit));
+            base = ((unsigned long long)__shfl((int)(base >> 32), __ffsll((long long)hit) - 1) << 32) | (uint32_t)__shfl((int)base, __ffsll((long long)hit) - 1);
+            if (e != 0xFFFFFFFFu) list[base + __popcll(hit & ((1ull << lane) - 1ull))] = ((unsigned long long)e << STOCK_KEY_BITS) | attach_key<FROM_FRAG>(t, w);
+        }
+    }
+}
+// an over-demanded type's cut = the key of its stock-th attachment in list order; info[6] = the first template any new cut lies in
+__global__ void __launch_bounds__(256) k_stock_pick(const int64_t* __restrict__ cnt, const uint32_t* __restrict__ etype, const uint32_t* __restrict__ estart, uint32_t ne,
+                                                    const unsigned long long* __restrict__ sorted, unsigned long long* __restrict__ cut, int key_shift, unsigned long long* __restrict__ info) {
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= ne) return;
+    const uint32_t x = etype[e];
+    const unsigned long long k = sorted[(size_t)estart[e] + (size_t)cnt[x] - 1] & ((1ull << STOCK_KEY_BITS) - 1ull);
+    cut[x] = k;
+    atomicMin(&info[6], (k - 1ull) >> key_shift);
+}
+
+// ------------------------------------------------------------------------------------------------
 // K1a  attach: the primer loop of Fragment::amplify (lib/fragment/Fragment.cpp:73-95) and
 //      Amplicon::amplify (lib/amplicon/Amplicon.cpp:176-198).  The reference's loop is sequential
 //      in the primer index (posAttached[] and the >50-tries abort).  Here a group of G lanes owns
@@ -1934,15 +2067,17 @@ __global__ void __launch_bounds__(1024) k_poisson_sums(const unsigned long long*
 template <bool FROM_FRAG, int G>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(G == 4 ? 8 : 1, 8))) k_attach(const uint8_t* __restrict__ g, DevFrags fr, DevAmps semis, uint32_t n_semis, DevErrPool spool,
                                                const uint32_t* __restrict__ slot_off, uint32_t* __restrict__ slots, uint32_t* __restrict__ slot_tmpl,
-                                               uint32_t* __restrict__ valid, const int64_t* __restrict__ primer_cnt, uint32_t* __restrict__ primer_delta,
-                                               unsigned long long* __restrict__ len_sum, AmplifyParams p) {
+                                               uint32_t* __restrict__ valid, const unsigned long long* __restrict__ primer_cut, uint32_t* __restrict__ primer_delta,
+                                               unsigned long long* __restrict__ len_sum, AmplifyParams p, uint32_t t_first, uint32_t t_end, int undo,
+                                               const unsigned long long* __restrict__ t_from) {
     constexpr int TPB = 64 / G;                              // templates per wave
     constexpr int WORDS = FROM_FRAG ? 4096 : 64;             // position bitmap: 131072 / 2048 positions (packed-record limits)
     __shared__ uint32_t s_bits[TPB * WORDS];
     const int lane = threadIdx.x, gi = lane / G, gl = lane % G;
     const unsigned long long gmask = G == 64 ? ~0ull : (((1ull << (G & 63)) - 1ull) << (gi * G));
-    const uint32_t nt = FROM_FRAG ? fr.n : n_semis;
-    const uint32_t t = blockIdx.x * TPB + gi;
+    // templates [t_first, t_end) of the pass's list -- of which a run-again (undo) only touches those from *t_from on
+    const uint32_t t = t_first + blockIdx.x * TPB + gi;
+    const uint32_t nt = t_from && (unsigned long long)t < *t_from ? 0u : t_end;
     uint32_t len = 0, budget = 0; uint64_t tuid = 0, errs = 0; View tv{0, 1, 0};
     if (t < nt) {
         if (FROM_FRAG) { len = fr.len[t]; budget = fr.primers[t]; tuid = fr.gidx_base + t; tv = frag_view(fr.goff[t], len, fr.strand[t]); }
@@ -1954,6 +2089,24 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(G == 4 
     }
     uint32_t* bits = s_bits + gi * WORDS;
     const uint32_t base_slot = t < nt ? slot_off[t] : 0, aux = (FROM_FRAG ? 0u : 1u) | (p.pass << 1);
+    // the primer type under a position of my template: its 8 bases are contiguous in the genome -> ONE 8-byte load (reversed /
+    // complemented in registers), then the semi's own substitutions are patched in (no load sits under a branch)
+    auto primer_type = [&](uint32_t sp, bool& hasN) -> uint32_t {
+        unsigned long long v8 = view_bases8(g, tv, sp);
+        if (!FROM_FRAG) for_each_err(errs, spool.data, [&](uint32_t e) {
+            const uint32_t k = len - 1u - err_pos(e) - sp;                           // template position of the error, relative to sp
+            if (k < 8u) v8 = (v8 & ~(0xFFull << (8u * k))) | ((unsigned long long)(3u - err_alt(e)) << (8u * k));
+        });
+        hasN = (v8 & 0xFCFCFCFCFCFCFCFCull) != 0;
+        uint32_t idx = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < 8; ++k) idx = (idx << 2) | ((uint32_t)(v8 >> (8u * k)) & 3u);
+        return idx;
+    };
+    if (undo && t < nt) {                                                           // a pass run again from here on (exact_stock below): first take back what my template took before
+        const uint32_t old = valid[t];
+        for (uint32_t w = gl; w < old; w += G) { bool hn; const uint32_t idx = primer_type(sl_spos(slots[base_slot + w]), hn); atomicSub(&primer_delta[idx], 1u); }
+    }
     if (FROM_FRAG) {                                                               // (semi amplicons: k_expand_items lists the amplicons made instead)
         for (uint32_t w = gl; w < budget; w += G) slot_tmpl[base_slot + w] = 0xFFFFFFFFu;   // my template's slots start out unused (k_errs skips those)
         __threadfence_block();                                                     // ... before any commit below rewrites one of them
@@ -1995,21 +2148,15 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(G == 4 
                     }
                     if (dead) break;
                     SCS_ATT(2);
-                    // (b) ... and only then its primer 8-mer and the stock, all candidates of the wave in one round of loads.  The 8
-                    // bases are contiguous in the genome -> ONE 8-byte load (reversed / complemented in registers), then the semi's
-                    // own substitutions are patched in (no load sits under a branch)
-                    unsigned long long v8 = view_bases8(g, tv, spos);
-                    if (!FROM_FRAG) for_each_err(errs, spool.data, [&](uint32_t e) {
-                        const uint32_t k = len - 1u - err_pos(e) - spos;                 // template position of the error, relative to spos
-                        if (k < 8u) v8 = (v8 & ~(0xFFull << (8u * k))) | ((unsigned long long)(3u - err_alt(e)) << (8u * k));
-                    });
-                    const bool hasN = (v8 & 0xFCFCFCFCFCFCFCFCull) != 0;
-                    uint32_t idx = 0;
-#pragma unroll
-                    for (uint32_t k = 0; k < 8; ++k) idx = (idx << 2) | ((uint32_t)(v8 >> (8u * k)) & 3u);
-                    const bool nostock = hasN || primer_cnt[idx] <= 0;
+                    // (b) ... and only then its primer 8-mer and the stock, all candidates of the wave in one round of loads.
+                    // updatePrimerCount (Malbac.cpp:91-103) hands a type out while its stock lasts, in the list order of the
+                    // attachments: the type's CUT is the place of this pass's list -- (template, primer) -- up to which it is to
+                    // be had (all of the pass, none of it, or, once the pass's demand is known to exceed the stock, the place of
+                    // the attachment that takes the last copy: exact_stock below)
+                    bool hasN; const uint32_t idx = primer_type(spos, hasN);
+                    const bool nostock = hasN || attach_key<FROM_FRAG>(t, i) > primer_cut[idx];
                     SCS_ATT(3);
-                    if (nostock) continue;                          // no stock for N 8-mers; [REMAP] stock as of pass start
+                    if (nostock) continue;                          // no stock (none for N 8-mers)
                     pidx = idx; need = false;
                 }
             }
@@ -2056,7 +2203,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(G == 4 
     __builtin_amdgcn_wave_barrier();
     if (!FROM_FRAG && lane < 8) atomicAdd(&g_phase_att[lane * 256 + (blockIdx.x & 255u)], lane == 7 ? 1ull : s_att_acc[lane]);
 #endif
-    if (FROM_FRAG) { lsum = wave_sum_u64(lsum); if (lane == 0) len_sum[blockIdx.x] = lsum; }   // per fragment; launch_attach_frags adds them up (no same-address atomics)
+    if (FROM_FRAG) { lsum = wave_sum_u64(lsum); if (lane == 0 && t < nt) len_sum[t] = lsum; }   // per fragment; launch_frag_len_sum adds them up (no same-address atomics)
     if (gl == 0 && t < nt) valid[t] = v;
 }
 
@@ -2372,11 +2519,14 @@ static inline void note_launch(hipError_t e) { if (e != hipSuccess && g_launch_e
 hipError_t take_launch_error() { note_launch(hipGetLastError()); const hipError_t e = g_launch_err; g_launch_err = hipSuccess; return e; }
 
 void launch_attach_frags(hipStream_t s, const uint8_t* g, DevFrags fr, const uint32_t* slot_off, uint32_t* slots, uint32_t* slot_tmpl,
-                         uint32_t* valid, const int64_t* primer_cnt, uint32_t* primer_delta, unsigned long long* len_sum, unsigned long long* len_part, AmplifyParams p) {
-    if (fr.n == 0) return;
+                         uint32_t* valid, const unsigned long long* primer_cut, uint32_t* primer_delta, unsigned long long* len_part, AmplifyParams p,
+                         uint32_t t_first, uint32_t t_end, int undo, const unsigned long long* t_from) {
+    if (t_end <= t_first) return;
     DevAmps none{}; DevErrPool np{};
-    hipLaunchKernelGGL((k_attach<true, 64>), dim3(fr.n), dim3(64), 0, s, g, fr, none, 0u, np, slot_off, slots, slot_tmpl, valid, primer_cnt, primer_delta, len_part, p);
-    hipLaunchKernelGGL(k_sum_u64_add, dim3(std::min(cdiv(fr.n, 2048), 128u)), dim3(1024), 0, s, len_part, fr.n, len_sum);
+    hipLaunchKernelGGL((k_attach<true, 64>), dim3(t_end - t_first), dim3(64), 0, s, g, fr, none, 0u, np, slot_off, slots, slot_tmpl, valid, primer_cut, primer_delta, len_part, p, t_first, t_end, undo, t_from);
+}
+void launch_frag_len_sum(hipStream_t s, const unsigned long long* len_part, uint32_t nf, unsigned long long* len_sum) {
+    if (nf) hipLaunchKernelGGL(k_sum_u64_add, dim3(std::min(cdiv(nf, 2048), 128u)), dim3(1024), 0, s, len_part, nf, len_sum);
 }
 void launch_poisson(hipStream_t s, DevFrags fr, DevAmps semis, uint32_t n_semis, PoissonParams p, uint32_t* budget_f, uint32_t* budget_s,
                     unsigned long long* sums, unsigned long long* part) {
@@ -2446,28 +2596,57 @@ void launch_alloc_odd_counts(hipStream_t s, const uint32_t* odd_before, const Al
 void launch_alloc_parity(hipStream_t s, uint32_t* rn, const uint32_t* odd_before, uint32_t ac, const AllocPlan& pl, const unsigned long long* table) {
     if (ac) hipLaunchKernelGGL(k_alloc_parity, dim3(cdiv(ac, 256)), dim3(256), 0, s, rn, odd_before, ac, pl, table);
 }
+// lanes per semi amplicon (budget ~ Poisson(6)): 4 keeps the lanes busiest when the grid fills the chip, 8 finishes a
+// template in one round when the job is small and the pass is latency bound (measured: 15 vs 18 ms at 13 M semis,
+// 0.35 vs 0.5 ms per step at 44 k)
+static int attach_semi_group(uint32_t n_semis) {
+    static const int forced = getenv("SCS_ATTACH_G") ? atoi(getenv("SCS_ATTACH_G")) : 0;   // tuning experiments
+    return forced == 2 || forced == 4 || forced == 8 || forced == 16 ? forced : (n_semis >= (1u << 18) ? 4 : 8);
+}
 void launch_attach_semis(hipStream_t s, const uint8_t* g, DevFrags fr, DevAmps semis, uint32_t n_semis, DevErrPool spool,
                          const uint32_t* slot_off, uint32_t* slots, uint32_t* slot_tmpl, uint32_t* valid,
-                         const int64_t* primer_cnt, uint32_t* primer_delta, AmplifyParams p) {
-    if (n_semis == 0) return;
-    // lanes per semi amplicon (budget ~ Poisson(6)): 4 keeps the lanes busiest when the grid fills the chip, 8 finishes a
-    // template in one round when the job is small and the pass is latency bound (measured: 15 vs 18 ms at 13 M semis,
-    // 0.35 vs 0.5 ms per step at 44 k)
-    static const int forced = getenv("SCS_ATTACH_G") ? atoi(getenv("SCS_ATTACH_G")) : 0;   // tuning experiments
-    const int G = forced ? forced : (n_semis >= (1u << 18) ? 4 : 8);
-#define SCS_LAUNCH_ATTACH_SEMI(GG) hipLaunchKernelGGL((k_attach<false, GG>), dim3(cdiv(n_semis, 64 / GG)), dim3(64), 0, s, g, fr, semis, n_semis, spool, slot_off, slots, slot_tmpl, valid, \
-                           primer_cnt, primer_delta, (unsigned long long*)nullptr, p)
+                         const unsigned long long* primer_cut, uint32_t* primer_delta, AmplifyParams p, uint32_t t_first, uint32_t t_end, int undo, const unsigned long long* t_from) {
+    if (t_end <= t_first) return;
+    const int G = attach_semi_group(n_semis); const uint32_t nt = t_end - t_first;
+#define SCS_LAUNCH_ATTACH_SEMI(GG) hipLaunchKernelGGL((k_attach<false, GG>), dim3(cdiv(nt, 64 / GG)), dim3(64), 0, s, g, fr, semis, n_semis, spool, slot_off, slots, slot_tmpl, valid, \
+                           primer_cut, primer_delta, (unsigned long long*)nullptr, p, t_first, t_end, undo, t_from)
     if (G == 2) SCS_LAUNCH_ATTACH_SEMI(2); else if (G == 16) SCS_LAUNCH_ATTACH_SEMI(16); else if (G == 8) SCS_LAUNCH_ATTACH_SEMI(8); else SCS_LAUNCH_ATTACH_SEMI(4);
 #undef SCS_LAUNCH_ATTACH_SEMI
 }
+// exact primer stock (k_stock_* above; the loop is exact_stock in scs_pipeline.cpp)
+void launch_stock_check(hipStream_t s, const int64_t* cnt, const uint32_t* taken, unsigned long long* cut, bool from_frag, uint32_t* eidx, uint32_t* etype, uint32_t* estart, unsigned long long* info) {
+    hipLaunchKernelGGL(k_stock_check, dim3(1), dim3(1024), 0, s, cnt, taken, cut, from_frag ? 20 : 12, eidx, etype, estart, info);
+}
+void launch_stock_collect(hipStream_t s, const uint8_t* g, DevFrags fr, DevAmps semis, DevErrPool spool, bool from_frag, const uint32_t* slot_off, const uint32_t* slots,
+                          const uint32_t* valid, const uint32_t* eidx, unsigned long long* list, unsigned long long* info, uint32_t t_first, uint32_t t_end) {
+    if (t_end <= t_first) return;
+    const uint32_t nt = t_end - t_first;
+    if (from_frag) hipLaunchKernelGGL((k_stock_collect<true, 64>), dim3(nt), dim3(64), 0, s, g, fr, semis, spool, slot_off, slots, valid, eidx, list, info, t_first, t_end);
+    else hipLaunchKernelGGL((k_stock_collect<false, 8>), dim3(cdiv(nt, 8)), dim3(64), 0, s, g, fr, semis, spool, slot_off, slots, valid, eidx, list, info, t_first, t_end);
+}
+size_t stock_sort_temp_bytes(size_t n) {
+    size_t b = 0; (void)rocprim::radix_sort_keys(nullptr, b, (const unsigned long long*)nullptr, (unsigned long long*)nullptr, n, 0, STOCK_KEY_BITS + 16);
+    return b + 256;
+}
+void launch_stock_sort(hipStream_t s, const unsigned long long* in, unsigned long long* out, size_t n, void* temp, size_t temp_bytes) {
+    if (n) note_launch(rocprim::radix_sort_keys(temp, temp_bytes, in, out, n, 0, STOCK_KEY_BITS + 16, s));
+}
+void launch_stock_pick(hipStream_t s, const int64_t* cnt, const uint32_t* etype, const uint32_t* estart, uint32_t ne, const unsigned long long* sorted, unsigned long long* cut,
+                       bool from_frag, unsigned long long* info) {
+    if (ne) hipLaunchKernelGGL(k_stock_pick, dim3(cdiv(ne, 256)), dim3(256), 0, s, cnt, etype, estart, ne, sorted, cut, from_frag ? 20 : 12, info);
+}
+void launch_stock_apply(hipStream_t s, int64_t* cnt, uint32_t* gdelta, uint32_t* delta, unsigned long long* cut, uint32_t* flags) {
+    hipLaunchKernelGGL(k_stock_apply, dim3(256), dim3(256), 0, s, cnt, gdelta, delta, cut, flags);
+}
 void launch_errs_frags(hipStream_t s, const uint8_t* g, DevGenomeIdx gx, DevFrags fr, uint32_t n_slots, const uint32_t* slot_off, const uint32_t* slots,
                        const uint32_t* slot_tmpl, const uint32_t* valid_off, DevAmps out, uint32_t out_base, DevErrPool pool, uint32_t* flags,
-                       const unsigned long long* binom, AmplifyParams p, int64_t* primer_cnt, uint32_t* primer_delta, unsigned long long* semis_n) {
+                       const unsigned long long* binom, AmplifyParams p, int64_t* primer_cnt, uint32_t* primer_delta, unsigned long long* primer_cut, unsigned long long* sums,
+                       unsigned long long* semis_n) {
     if (n_slots == 0) return;
     DevAmps none{}; DevErrPool np{};
     // a riding stock update wants every primer type covered with one entry per thread: never fewer than 256 workgroups
     hipLaunchKernelGGL(k_errs<true>, dim3(primer_cnt ? std::max(cdiv(n_slots, 256), 256u) : cdiv(n_slots, 256)), dim3(256), 0, s, g, gx, fr, none, np, n_slots, slot_off, slots, slot_tmpl, valid_off, fr.n, out, out_base, pool, flags, binom, p,
-                       primer_cnt, primer_delta, semis_n);
+                       primer_cnt, primer_delta, primer_cut, sums, semis_n);
 }
 // the template of every amplicon a semi pass made, in creation order (valid_off = exclusive scan of the per-template counts)
 __global__ void k_expand_items(const uint32_t* __restrict__ valid_off, uint32_t n_tmpl, uint32_t* __restrict__ item_tmpl) {
@@ -2479,11 +2658,11 @@ __global__ void k_expand_items(const uint32_t* __restrict__ valid_off, uint32_t 
 void launch_errs_semis(hipStream_t s, const uint8_t* g, DevGenomeIdx gx, DevFrags fr, DevAmps semis, uint32_t n_semis, DevErrPool spool, uint32_t n_slots,
                        const uint32_t* slot_off, const uint32_t* slots, const uint32_t* slot_tmpl, const uint32_t* valid_off,
                        DevAmps out, uint32_t out_base, DevErrPool pool, uint32_t* flags, const unsigned long long* binom, AmplifyParams p,
-                       int64_t* primer_cnt, uint32_t* primer_delta) {
+                       int64_t* primer_cnt, uint32_t* primer_delta, unsigned long long* primer_cut, unsigned long long* sums) {
     if (n_slots == 0) return;
     hipLaunchKernelGGL(k_expand_items, dim3(cdiv(n_semis, 256)), dim3(256), 0, s, valid_off, n_semis, const_cast<uint32_t*>(slot_tmpl));
     hipLaunchKernelGGL(k_errs<false>, dim3(primer_cnt ? std::max(cdiv(n_slots, 256), 256u) : cdiv(n_slots, 256)), dim3(256), 0, s, g, gx, fr, semis, spool, n_slots, slot_off, slots, slot_tmpl, valid_off, n_semis, out, out_base, pool, flags, binom, p,
-                       primer_cnt, primer_delta, (unsigned long long*)nullptr);
+                       primer_cnt, primer_delta, primer_cut, sums, (unsigned long long*)nullptr);
 }
 void launch_genome_bits(hipStream_t s, const uint8_t* g, uint64_t n, uint64_t nwords, unsigned long long* gc_bits, unsigned long long* n_bits,
                         uint32_t* gc_cnt, uint32_t* n_cnt, uint64_t* gc_pref, uint64_t* n_pref, void* temp, size_t temp_bytes, uint32_t* g2) {
@@ -2491,18 +2670,18 @@ void launch_genome_bits(hipStream_t s, const uint8_t* g, uint64_t n, uint64_t nw
     (void)rocprim::exclusive_scan(temp, temp_bytes, rocprim::make_transform_iterator((const uint32_t*)gc_cnt, Widen()), gc_pref, (uint64_t)0, nwords + 1, rocprim::plus<uint64_t>(), s);
     (void)rocprim::exclusive_scan(temp, temp_bytes, rocprim::make_transform_iterator((const uint32_t*)n_cnt, Widen()), n_pref, (uint64_t)0, nwords + 1, rocprim::plus<uint64_t>(), s);
 }
-void launch_amplify_init(hipStream_t s, int64_t* primer_cnt, int64_t copies, uint32_t* primer_delta, uint32_t* flags, unsigned long long* sums,
+void launch_amplify_init(hipStream_t s, int64_t* primer_cnt, unsigned long long* primer_cut, int64_t copies, uint32_t* primer_delta, uint32_t* primer_gdelta, uint32_t* flags, unsigned long long* sums,
                          unsigned long long nf_all, unsigned long long frag_len_all, unsigned long long total_primers, uint32_t* pool_head_a, uint32_t* pool_head_b) {
-    hipLaunchKernelGGL(k_amplify_init, dim3(256), dim3(256), 0, s, primer_cnt, copies, primer_delta, flags, sums, nf_all, frag_len_all, total_primers, pool_head_a, pool_head_b);
+    hipLaunchKernelGGL(k_amplify_init, dim3(256), dim3(256), 0, s, primer_cnt, primer_cut, copies, primer_delta, primer_gdelta, flags, sums, nf_all, frag_len_all, total_primers, pool_head_a, pool_head_b);
 }
-void launch_shard_tail(hipStream_t s, uint32_t* primer_delta, unsigned long long* dsums, const uint32_t* new_semis, int with_budgets) {
-    hipLaunchKernelGGL(k_shard_tail, dim3(1), dim3(64), 0, s, primer_delta, dsums, new_semis, with_budgets);
+void launch_shard_tail(hipStream_t s, uint32_t* primer_gdelta, const unsigned long long* dsums, const uint32_t* new_semis, int with_budgets) {
+    hipLaunchKernelGGL(k_shard_tail, dim3(1), dim3(64), 0, s, primer_gdelta, dsums, new_semis, with_budgets);
 }
-void launch_primer_update_sharded(hipStream_t s, int64_t* primer_cnt, uint32_t* primer_delta, unsigned long long* dsums) {
-    hipLaunchKernelGGL(k_primer_update_sharded, dim3(256), dim3(256), 0, s, primer_cnt, primer_delta, dsums);
+void launch_primer_update_sharded(hipStream_t s, int64_t* primer_cnt, uint32_t* primer_gdelta, uint32_t* primer_delta, unsigned long long* primer_cut, unsigned long long* dsums, uint32_t* flags, int with_budgets) {
+    hipLaunchKernelGGL(k_primer_update_sharded, dim3(256), dim3(256), 0, s, primer_cnt, primer_gdelta, primer_delta, primer_cut, dsums, flags, with_budgets);
 }
-void launch_primer_update(hipStream_t s, int64_t* primer_cnt, uint32_t* primer_delta) {
-    hipLaunchKernelGGL(k_primer_update, dim3(256), dim3(256), 0, s, primer_cnt, primer_delta);
+void launch_primer_update(hipStream_t s, int64_t* primer_cnt, uint32_t* primer_delta, unsigned long long* primer_cut, unsigned long long* dsums, uint32_t* flags) {
+    hipLaunchKernelGGL(k_primer_update, dim3(256), dim3(256), 0, s, primer_cnt, primer_delta, primer_cut, dsums, flags);
 }
 void launch_weights(hipStream_t s, DevAmps fulls, uint32_t n, DevTables tb, RngKey key, uint32_t frag_size, double* w) {
     if (n == 0) return;

@@ -177,7 +177,8 @@ struct scs_ctx {
     bool timing_gate = true; uint32_t timing_every = 1; uint64_t amplify_calls = 0, yield_calls = 0;   // scs_set_kernel_timing: events on every n-th call
     uint64_t frag_total_len = 0, semi_total_len = 0; uint32_t slots_f = 0, slots_s = 0, budget_ns = 0;
     uint64_t nf_all = 0, frag_len_all = 0; bool budgets_pending = false;            // sharded job: fragments of ALL shards; budgets not yet exchanged
-    DevBuf primer_cnt, primer_delta; uint64_t total_primers = 0; bool amplified = false;
+    DevBuf primer_cnt, primer_delta, primer_cut, primer_gdelta; uint64_t total_primers = 0; bool amplified = false;   // stock, what the running pass took (this shard / all shards), the cuts k_attach reads
+    DevBuf st_eidx, st_etype, st_estart, st_info, st_list, st_sorted, st_tmp; uint64_t min_stock_lb = 0;   // exact_stock's work arrays; lower bound of every primer stock in use
     DevBuf slots, slot_tmpl, valid, valid_off, valid_f, valid_off_f, scan_tmp, flags;
     // allocation + reads
     DevBuf weights, read_numbers, pair_off, pairs, odd_before, a_part, a_tp, a_probs, a_quota, a_poff, a_plan, a_crn, a_scratch, a_brow, a_bmap, a_send, a_gath, a_odd; SegMap gmap{}; std::vector<uint32_t> h_read_numbers; uint64_t reads_requested = 0, n_pairs_planned = 0; bool allocated = false;
@@ -640,55 +641,136 @@ void set_primers_finish(scs_ctx* c) {                                           
     c->slots_f = (uint32_t)rb[2]; c->slots_s = (uint32_t)rb[3]; c->budget_ns = c->semis.n;
 }
 
-// sharded job, end of a pass: ONE all-reduce carries the primer decrements and, behind them, what else the shards owe each
-// other (new semi amplicons of a fragment pass, the budgets of the last setPrimers); the update folds it into the device
-// scalars the next setPrimers reads.
-void shard_exchange(scs_ctx* c, const uint32_t* new_semis) {
+// sharded job, end of a pass: what the shards owe each other besides the primer stock (new semi amplicons of a fragment pass,
+// the budgets of the last setPrimers) is summed by a small all-reduce behind the stock counters; the update takes what the
+// pass took from the stock (summed over the shards by attach_pass) and folds the rest into the device scalars the next
+// setPrimers reads.
+void shard_close(scs_ctx* c, const uint32_t* new_semis) {
     hipStream_t s = c->stream;
-    launch_shard_tail(s, c->primer_delta.as<uint32_t>(), c->dsums.as<unsigned long long>(), new_semis, c->budgets_pending ? 1 : 0);
+    const int wb = c->budgets_pending ? 1 : 0;
+    launch_shard_tail(s, c->primer_gdelta.as<uint32_t>(), c->dsums.as<unsigned long long>(), new_semis, wb);
     c->budgets_pending = false;
-    c->reduce_dev(c->primer_delta.p, 65536 + SHARD_TAIL_WORDS, 4);
-    launch_primer_update_sharded(s, c->primer_cnt.as<int64_t>(), c->primer_delta.as<uint32_t>(), c->dsums.as<unsigned long long>());
+    c->reduce_dev(c->primer_gdelta.as<uint32_t>() + 65536, SHARD_TAIL_WORDS, 4);
+    launch_primer_update_sharded(s, c->primer_cnt.as<int64_t>(), c->primer_gdelta.as<uint32_t>(), c->primer_delta.as<uint32_t>(), c->primer_cut.as<unsigned long long>(),
+                                 c->dsums.as<unsigned long long>(), c->flags.as<uint32_t>(), wb);
 }
 
-// ---------------------------------------------------------------- one amplification pass (a4 / a5): launches only, no host sync.
+// ---------------------------------------------------------------- a2: the primer stock, exactly (Malbac::updatePrimerCount, Malbac.cpp:91-103)
+// The kernels and the argument are in scs_kernels.hip ("the primer stock, exactly").  Here: the loop.
+static void attach_range(scs_ctx* c, bool from_frag, const AmplifyParams& p, uint32_t lo, uint32_t hi, int undo, const unsigned long long* t_from) {
+    hipStream_t s = c->stream;
+    const uint32_t* slot_off = (from_frag ? c->slot_off_f : c->slot_off_s).as<uint32_t>();
+    DevBuf& valid = from_frag ? c->valid_f : c->valid; DevBuf& slots = from_frag ? c->slots_fr : c->slots; DevBuf& slot_tmpl = from_frag ? c->slot_tmpl_fr : c->slot_tmpl;
+    DevFrags fr = c->frags_view(); fr.primers = c->budget_f.as<uint32_t>();
+    if (from_frag) launch_attach_frags(s, c->genome.as<uint8_t>(), fr, slot_off, slots.as<uint32_t>(), slot_tmpl.as<uint32_t>(), valid.as<uint32_t>(),
+                                       c->primer_cut.as<unsigned long long>(), c->primer_delta.as<uint32_t>(), c->poisson_part.as<unsigned long long>(), p, lo, hi, undo, t_from);
+    else launch_attach_semis(s, c->genome.as<uint8_t>(), fr, c->semis.view(), c->budget_ns, c->semis.pool_view(), slot_off, slots.as<uint32_t>(), slot_tmpl.as<uint32_t>(),
+                             valid.as<uint32_t>(), c->primer_cut.as<unsigned long long>(), c->primer_delta.as<uint32_t>(), p, lo, hi, undo, t_from);
+}
+// The templates [lo, hi) of a pass have been run against the cuts as they stand, primer_delta = what they took, primer_cnt = the
+// stock they started from.  Until no type is over its stock (and no cut type under it): cut the over-demanded types at their
+// stock-th attachment in list order, run the templates behind the earliest new cut again.  One host wait per round.
+static void exact_stock(scs_ctx* c, bool from_frag, const AmplifyParams& p, uint32_t lo, uint32_t hi, const uint32_t* taken) {
+    hipStream_t s = c->stream;
+    c->st_eidx.reserve(65536 * 4, s); c->st_etype.reserve(65536 * 4, s); c->st_estart.reserve(65536 * 4, s); c->st_info.reserve(64, s);
+    unsigned long long* info = c->st_info.as<unsigned long long>();
+    const uint32_t* slot_off = (from_frag ? c->slot_off_f : c->slot_off_s).as<uint32_t>();
+    DevBuf& valid = from_frag ? c->valid_f : c->valid; DevBuf& slots = from_frag ? c->slots_fr : c->slots;
+    for (int round = 0;; ++round) {
+        launch_stock_check(s, c->primer_cnt.as<int64_t>(), taken, c->primer_cut.as<unsigned long long>(), from_frag, c->st_eidx.as<uint32_t>(), c->st_etype.as<uint32_t>(), c->st_estart.as<uint32_t>(), info);
+        Mail m; m.add(info, 8, 24); m.add(info + 1, 8, 25); m.add(info + 2, 8, 26); mail_post(c, m, true); mail_wait(c);
+        const uint64_t n_over = c->h_rb[24], n_att = c->h_rb[25], n_under = c->h_rb[26];
+        if (round == 0) { c->st.stock_checks++; if (n_over) c->st.stock_exhausted_passes++; }
+        if (!n_over && !n_under) return;
+        if (taken != c->primer_delta.as<uint32_t>()) return;                       // a sharded job's first look at the pass (all shards' demand): attach_pass takes over
+        if (round >= 500) throw ScsError(SCS_EOVERFLOW, "internal: the primer stock of a pass did not settle");
+        if (n_over) {
+            c->st_list.reserve(n_att * 8 + 64, s); c->st_sorted.reserve(n_att * 8 + 64, s); c->st_tmp.reserve(stock_sort_temp_bytes(n_att), s);
+            launch_stock_collect(s, c->genome.as<uint8_t>(), c->frags_view(), c->semis.view(), c->semis.pool_view(), from_frag, slot_off, slots.as<uint32_t>(), valid.as<uint32_t>(),
+                                 c->st_eidx.as<uint32_t>(), c->st_list.as<unsigned long long>(), info, lo, hi);
+            launch_stock_sort(s, c->st_list.as<unsigned long long>(), c->st_sorted.as<unsigned long long>(), n_att, c->st_tmp.p, c->st_tmp.cap);
+            launch_stock_pick(s, c->primer_cnt.as<int64_t>(), c->st_etype.as<uint32_t>(), c->st_estart.as<uint32_t>(), (uint32_t)n_over, c->st_sorted.as<unsigned long long>(),
+                              c->primer_cut.as<unsigned long long>(), from_frag, info);
+        }
+        attach_range(c, from_frag, p, lo, hi, 1, info + 6);                        // info[6]: the first template behind a moved cut (the kernel skips the others)
+        c->st.stock_rounds++;
+    }
+}
+// One pass's attachments over this shard's templates [0, nt), exact.  Unsharded: one run; the over-demand check (a host wait)
+// only when the pass has more primers to place than the smallest stock in use.  Sharded: one run, the shards' demand summed; if
+// a type is over its stock the pass is run again segment by segment in the whole job's list order, every segment by its owner
+// against the stock the segments before it left (handed on by an all-reduce to which only the owner contributes).
+static void attach_pass(scs_ctx* c, bool from_frag, const AmplifyParams& p, uint32_t nt, uint32_t n_slots) {
+    hipStream_t s = c->stream;
+    const bool some = nt != 0 && n_slots != 0;
+    if (some) attach_range(c, from_frag, p, 0, nt, 0, nullptr);
+    if (!c->sharded()) {
+        if (some && (uint64_t)n_slots > c->min_stock_lb) exact_stock(c, from_frag, p, 0, nt, c->primer_delta.as<uint32_t>());
+        c->min_stock_lb = c->min_stock_lb > n_slots ? c->min_stock_lb - n_slots : 0;
+        return;
+    }
+    uint32_t* delta = c->primer_delta.as<uint32_t>(); uint32_t* gdelta = c->primer_gdelta.as<uint32_t>();
+    HIP_OK(hipMemcpyAsync(gdelta, delta, 65536 * 4, hipMemcpyDeviceToDevice, s));
+    c->reduce_dev(gdelta, 65536, 4);
+    const uint64_t before = c->st.stock_exhausted_passes;
+    exact_stock(c, from_frag, p, 0, nt, gdelta);                                   // the check alone: taken != primer_delta
+    if (c->st.stock_exhausted_passes == before) return;                            // gdelta = what the pass took, all shards: applied by shard_close
+    HIP_OK(hipMemsetAsync(delta, 0, 65536 * 4, s)); HIP_OK(hipMemsetAsync(gdelta, 0, 65536 * 4, s));
+    std::vector<std::pair<uint32_t, uint32_t>> segs;                               // local template ranges, in list order
+    if (from_frag) segs.push_back({0u, nt});
+    else for (size_t b = 0; b < c->semi_block_end.size(); ++b) segs.push_back({b ? c->semi_block_end[b - 1] : 0u, std::min(c->semi_block_end[b], nt)});
+    const int R = c->cfg.shard_count;
+    for (auto& sg : segs) for (int k = 0; k < R; ++k) {
+        // fragments ascend with the shard; the semis of a fragment pass lie in the list with their fragments DEscending
+        const int owner = from_frag ? k : R - 1 - k;
+        if (owner == c->cfg.shard_rank && sg.second > sg.first && n_slots) {
+            attach_range(c, from_frag, p, sg.first, sg.second, 0, nullptr);
+            exact_stock(c, from_frag, p, sg.first, sg.second, delta);
+            HIP_OK(hipMemcpyAsync(gdelta, delta, 65536 * 4, hipMemcpyDeviceToDevice, s));
+        }
+        c->reduce_dev(gdelta, 65536, 4);
+        launch_stock_apply(s, c->primer_cnt.as<int64_t>(), gdelta, delta, c->primer_cut.as<unsigned long long>(), c->flags.as<uint32_t>());
+    }
+}
+
+// ---------------------------------------------------------------- one amplification pass (a4 / a5)
 // rb_slot: where the number of amplicons created is read back to (pinned host memory, stream-ordered).
 static void join_errs(scs_ctx* c) { if (c->errs_pending) { HIP_OK(hipStreamWaitEvent(c->stream, c->ev_errs, 0)); c->errs_pending = false; } }
 void launch_pass(scs_ctx* c, bool from_frag, uint32_t pass, int rb_slot) {
     hipStream_t s = c->stream;
     const uint32_t nt = from_frag ? (uint32_t)c->f_len.size() : c->budget_ns;
     const uint32_t n_slots = from_frag ? c->slots_f : c->slots_s;
-    if (nt == 0 || n_slots == 0) {                                                 // nothing local; a shard still joins the pass's collective
-        if (c->sharded()) shard_exchange(c, nullptr);
+    const bool some = nt != 0 && n_slots != 0;                                     // a shard with nothing local still joins the pass's collectives
+    const uint32_t* slot_off = (from_frag ? c->slot_off_f : c->slot_off_s).as<uint32_t>();
+    // the two passes of a group keep their own count arrays: their totals are mailed together at the group's collect
+    DevBuf& valid = from_frag ? c->valid_f : c->valid; DevBuf& valid_off = from_frag ? c->valid_off_f : c->valid_off;
+    DevBuf& slots = from_frag ? c->slots_fr : c->slots; DevBuf& slot_tmpl = from_frag ? c->slot_tmpl_fr : c->slot_tmpl;
+    AmpStore& out = from_frag ? c->semis : c->fulls;
+    AmplifyParams p; p.key = c->key; p.pass = pass; p.amp_min = (uint32_t)c->cfg.amplicon_min_len; p.amp_max = (uint32_t)c->cfg.amplicon_max_len; p.t_ber = c->dtb.t_ber;
+    if (some) {
+        valid.reserve(((size_t)nt + 1) * 4, s); valid_off.reserve(((size_t)nt + 1) * 4, s);
+        slots.reserve((size_t)n_slots * 4, s); slot_tmpl.reserve((size_t)n_slots * 4, s);   // k_attach marks its own slots unused first
+        c->scan_tmp.reserve(scan_temp_bytes(nt), s);
+        out.reserve((uint64_t)out.n + n_slots, s);
+        out.reserve_pool(std::max<uint32_t>(1u << 16, (uint32_t)std::min<uint64_t>(((uint64_t)out.n + n_slots) / 256 + 4096, 0xFFFFFFF0ull)), s);
+    }
+    KernelTimer& tma = from_frag ? c->tm_attach_f : c->tm_attach;
+    if (some) tma.begin(s);
+    attach_pass(c, from_frag, p, nt, n_slots);
+    if (some) { tma.end(s); tma.add_units(nt); }
+    if (!some) {
+        if (c->sharded()) shard_close(c, nullptr);
         c->pend.add(nullptr, 8, rb_slot);
         if (!from_frag) { for (int b = 0; b < 8; ++b) c->pend.add(nullptr, 8, 16 + b); c->pending_seg_cycle = (int)pass; }
         return;
     }
-    const uint32_t* slot_off = (from_frag ? c->slot_off_f : c->slot_off_s).as<uint32_t>();
-    // the two passes of a group keep their own count arrays: their totals are mailed together at the group's collect
-    DevBuf& valid = from_frag ? c->valid_f : c->valid; DevBuf& valid_off = from_frag ? c->valid_off_f : c->valid_off;
-    valid.reserve(((size_t)nt + 1) * 4, s); valid_off.reserve(((size_t)nt + 1) * 4, s);
-    DevBuf& slots = from_frag ? c->slots_fr : c->slots; DevBuf& slot_tmpl = from_frag ? c->slot_tmpl_fr : c->slot_tmpl;
-    slots.reserve((size_t)n_slots * 4, s); slot_tmpl.reserve((size_t)n_slots * 4, s);   // k_attach marks its own slots unused first
-    c->scan_tmp.reserve(scan_temp_bytes(nt), s);
-    AmpStore& out = from_frag ? c->semis : c->fulls;
-    out.reserve((uint64_t)out.n + n_slots, s);
-    out.reserve_pool(std::max<uint32_t>(1u << 16, (uint32_t)std::min<uint64_t>(((uint64_t)out.n + n_slots) / 256 + 4096, 0xFFFFFFF0ull)), s);
-    AmplifyParams p; p.key = c->key; p.pass = pass; p.amp_min = (uint32_t)c->cfg.amplicon_min_len; p.amp_max = (uint32_t)c->cfg.amplicon_max_len; p.t_ber = c->dtb.t_ber;
     DevFrags fr = c->frags_view(); fr.primers = c->budget_f.as<uint32_t>();
     const uint8_t* g = c->genome.as<uint8_t>();
-    KernelTimer& tma = from_frag ? c->tm_attach_f : c->tm_attach;
-    tma.begin(s);
-    if (from_frag) launch_attach_frags(s, g, fr, slot_off, slots.as<uint32_t>(), slot_tmpl.as<uint32_t>(), valid.as<uint32_t>(),
-                                       c->primer_cnt.as<int64_t>(), c->primer_delta.as<uint32_t>(), c->dsums.as<unsigned long long>() + 4, c->poisson_part.as<unsigned long long>(), p);
-    else launch_attach_semis(s, g, fr, c->semis.view(), nt, c->semis.pool_view(), slot_off, slots.as<uint32_t>(), slot_tmpl.as<uint32_t>(),
-                             valid.as<uint32_t>(), c->primer_cnt.as<int64_t>(), c->primer_delta.as<uint32_t>(), p);
-    tma.end(s);
-    tma.add_units(nt);
+    if (from_frag) launch_frag_len_sum(s, c->poisson_part.as<unsigned long long>(), nt, c->dsums.as<unsigned long long>() + DS_SEMI_LEN);
     exclusive_scan_u32(s, valid.as<uint32_t>(), valid_off.as<uint32_t>(), nt, c->scan_tmp.p, c->scan_tmp.cap);
     KernelTimer& tm = from_frag ? c->tm_errscan_f : c->tm_errscan;
     // the stock update rides on k_errs (launched with at least 256 workgroups: one primer type per thread); a sharded job
-    // all-reduces the decrements first
+    // closes the pass with shard_close
     const bool ride = !c->sharded();
     // k_errs<semi->full> writes only the new full amplicons, which nothing reads before the allocation: it runs on its own
     // stream beside the fragment pass that follows (its chain of dependent gathers beside the attach kernel's ALU work); the
@@ -706,16 +788,17 @@ void launch_pass(scs_ctx* c, bool from_frag, uint32_t pass, int rb_slot) {
     const DevGenomeIdx gx{c->gx_gc_bits.as<unsigned long long>(), c->gx_n_bits.as<unsigned long long>(), c->gx_gc_pref.as<uint64_t>(), c->gx_n_pref.as<uint64_t>()};
     if (from_frag) launch_errs_frags(s, g, gx, fr, n_slots, slot_off, slots.as<uint32_t>(), slot_tmpl.as<uint32_t>(), valid_off.as<uint32_t>(),
                                      out.view(), out.n, out.pool_view(), c->flags.as<uint32_t>(), c->d_binom.as<unsigned long long>(), p,
-                                     ride ? c->primer_cnt.as<int64_t>() : nullptr, c->primer_delta.as<uint32_t>(), c->dsums.as<unsigned long long>() + DS_SEMIS_N);
+                                     ride ? c->primer_cnt.as<int64_t>() : nullptr, c->primer_delta.as<uint32_t>(), c->primer_cut.as<unsigned long long>(), c->dsums.as<unsigned long long>(),
+                                     c->dsums.as<unsigned long long>() + DS_SEMIS_N);
     else launch_errs_semis(es, g, gx, fr, c->semis.view(), nt, c->semis.pool_view(), n_slots, slot_off, slots.as<uint32_t>(), slot_tmpl.as<uint32_t>(),
                            valid_off.as<uint32_t>(), out.view(), out.n, out.pool_view(), c->flags.as<uint32_t>(), c->d_binom.as<unsigned long long>(), p,
-                           ride && es == s ? c->primer_cnt.as<int64_t>() : nullptr, c->primer_delta.as<uint32_t>());
+                           ride && es == s ? c->primer_cnt.as<int64_t>() : nullptr, c->primer_delta.as<uint32_t>(), c->primer_cut.as<unsigned long long>(), c->dsums.as<unsigned long long>());
     tm.end(es);
     if (es != s) {
         HIP_OK(hipEventRecord(c->ev_errs, es)); c->errs_pending = true;
-        if (ride) launch_primer_update(s, c->primer_cnt.as<int64_t>(), c->primer_delta.as<uint32_t>());
+        if (ride) launch_primer_update(s, c->primer_cnt.as<int64_t>(), c->primer_delta.as<uint32_t>(), c->primer_cut.as<unsigned long long>(), c->dsums.as<unsigned long long>(), c->flags.as<uint32_t>());
     }
-    if (c->sharded()) shard_exchange(c, from_frag ? valid_off.as<uint32_t>() + nt : nullptr);
+    if (c->sharded()) shard_close(c, from_frag ? valid_off.as<uint32_t>() + nt : nullptr);
     {   // counts of this pass -> mailbox (read by the host at the group's sync): new amplicons, and for a semi pass the
         // fulls made from the semis of each fragment pass (segments)
         c->pend.add(valid_off.as<uint32_t>() + nt, 4, rb_slot);
@@ -729,6 +812,7 @@ void launch_pass(scs_ctx* c, bool from_frag, uint32_t pass, int rb_slot) {
 void collect_post(scs_ctx* c, bool post_now) {
     c->pend.add(c->dsums.as<unsigned long long>() + DS_SEMI_LEN, 8, 8);
     if (c->sharded()) c->pend.add(c->dsums.as<unsigned long long>() + DS_G_PRIMERS, 8, 9);
+    c->pend.add(c->dsums.as<unsigned long long>() + DS_MIN_STOCK, 8, 10);
     if (post_now) { mail_post(c, c->pend, true); c->pend = Mail(); }               // else: rides on the next setPrimers mail
 }
 // ... and are taken over by the host after the next mail_wait: counts of new amplicons, total length of the semis
@@ -747,6 +831,7 @@ void collect_read(scs_ctx* c, int rb_fulls, int rb_semis) {
     if (rb_semis >= 0) { c->semis.n += (uint32_t)c->h_rb[rb_semis]; c->tm_errscan_f.add_units(c->h_rb[rb_semis]); c->semi_block_end.push_back(c->semis.n); }
     c->semi_total_len = c->h_rb[8];
     if (c->sharded()) c->total_primers = c->h_rb[9];                               // whole-job pool size after the budgets exchanged so far
+    c->min_stock_lb = c->h_rb[10];                                                 // the smallest primer stock in use after the passes mailed so far
 }
 
 // ---------------------------------------------------------------- Malbac::amplify (Malbac.cpp:173-201)
@@ -758,8 +843,11 @@ void do_amplify(scs_ctx* c) {
     c->semis.reset_counts(); c->fulls.reset_counts(); c->semi_block_end.clear(); c->full_segs.clear(); c->pending_seg_cycle = -1; c->pend = Mail();
     c->timing_gate = (c->amplify_calls++ % c->timing_every) == 0;
     c->tm_errscan.reset(); c->tm_errscan_f.reset(); c->tm_attach.reset(); c->tm_attach_f.reset();
-    c->primer_cnt.reserve(65536 * 8, s); c->primer_delta.reserve((65536 + SHARD_TAIL_WORDS) * 4, s);   // createPrimers: 4^8 types x `primers` copies
-    launch_amplify_init(s, c->primer_cnt.as<int64_t>(), (int64_t)c->cfg.primers, c->primer_delta.as<uint32_t>(), c->flags.as<uint32_t>(), c->dsums.as<unsigned long long>(),
+    c->primer_cnt.reserve(65536 * 8, s); c->primer_cut.reserve(65536 * 8, s); c->primer_delta.reserve(65536 * 4, s);   // createPrimers: 4^8 types x `primers` copies
+    if (c->sharded()) c->primer_gdelta.reserve((65536 + SHARD_TAIL_WORDS) * 4, s);
+    c->min_stock_lb = c->cfg.primers > 0 ? (uint64_t)c->cfg.primers : 0; c->st.stock_checks = c->st.stock_exhausted_passes = c->st.stock_rounds = 0;
+    launch_amplify_init(s, c->primer_cnt.as<int64_t>(), c->primer_cut.as<unsigned long long>(), (int64_t)c->cfg.primers, c->primer_delta.as<uint32_t>(),
+                        c->sharded() ? c->primer_gdelta.as<uint32_t>() : nullptr, c->flags.as<uint32_t>(), c->dsums.as<unsigned long long>(),
                         c->nf_all, c->frag_len_all, 65536ull * (uint64_t)c->cfg.primers, c->semis.pool_head.as<uint32_t>(), c->fulls.pool_head.as<uint32_t>());
     if (!c->d_binom.p) {   // [REMAP] error-count thresholds for every window length (cfg is fixed for the ctx lifetime)
         std::vector<uint64_t> bt = binom_table(c->cfg.ber, c->cfg.amplicon_min_len - 8, c->cfg.amplicon_max_len - 8);
@@ -1280,7 +1368,7 @@ void scs_destroy(scs_ctx* c) {
     (void)hipSetDevice(c->cfg.device);
     (void)hipStreamSynchronize(c->stream);
     for (DevBuf* b : {&c->d_tables, &c->t_gap, &c->t_qcompact, &c->t_guide, &c->t_ring1, &c->t_ring2, &c->t_ring1u, &c->t_ring2u, &c->t_subs1, &c->t_subs2, &c->t_qual, &c->t_ins, &c->t_del, &c->t_isize, &c->d_subs1, &c->d_subs2, &c->d_qual, &c->d_ins, &c->d_del,
-                      &c->d_isize, &c->d_gcmeans, &c->genome, &c->genome2, &c->gx_gc_bits, &c->gx_n_bits, &c->gx_gc_cnt, &c->gx_n_cnt, &c->gx_gc_pref, &c->gx_n_pref, &c->d_binom, &c->df_blob, &c->df_primers, &c->df_hasn, &c->primer_cnt, &c->primer_delta,
+                      &c->d_isize, &c->d_gcmeans, &c->genome, &c->genome2, &c->gx_gc_bits, &c->gx_n_bits, &c->gx_gc_cnt, &c->gx_n_cnt, &c->gx_gc_pref, &c->gx_n_pref, &c->d_binom, &c->df_blob, &c->df_primers, &c->df_hasn, &c->primer_cnt, &c->primer_delta, &c->primer_cut, &c->primer_gdelta, &c->st_eidx, &c->st_etype, &c->st_estart, &c->st_info, &c->st_list, &c->st_sorted, &c->st_tmp,
                       &c->slots, &c->slot_tmpl, &c->slots_fr, &c->slot_tmpl_fr, &c->valid, &c->valid_off, &c->valid_f, &c->valid_off_f, &c->scan_tmp, &c->flags, &c->weights, &c->read_numbers,
                       &c->pair_off, &c->pairs, &c->odd_before, &c->a_part, &c->a_tp, &c->a_probs, &c->a_quota, &c->a_poff, &c->a_plan, &c->a_crn, &c->a_scratch, &c->a_brow, &c->a_bmap, &c->a_send, &c->a_gath, &c->a_odd, &c->d_hostred, &c->d_tot, &c->d_stage, &c->d_mail, &c->budget_f, &c->budget_s, &c->poisson_part, &c->slot_off_f,
                       &c->slot_off_s, &c->dsums, &c->slot_b, &c->slot_q, &c->lens, &c->ev_hdr, &c->ev_dat, &c->sizes1, &c->sizes2, &c->off1, &c->off2, &c->out1, &c->out2, &c->out1b, &c->out2b, &c->rl_cls, &c->rl_pos, &c->rl_lists, &c->d_bounds, &c->d_cks}) b->release();
@@ -1571,6 +1659,13 @@ int scs_download_amplicons(scs_ctx* c, int kind, uint32_t* parent, uint32_t* spo
             else for (int k = 0; k < 4; ++k) { uint32_t e = (uint32_t)(he[i] >> (16 * k)) & 0xFFFF; if (e) e4[cnt++] = (err_pos(e) << 3) | err_alt(e); }
             if (errs) memcpy(errs + 4 * (size_t)i, e4, 16); if (nerr) nerr[i] = cnt;
         }
+    });
+}
+int scs_download_primer_stock(scs_ctx* c, int64_t* stock) {
+    return guarded(c, [&] {
+        if (!stock) throw ScsError(SCS_EINVAL, "null pointer");
+        if (!c->amplified) throw ScsError(SCS_EINVAL, "scs_download_primer_stock: call scs_amplify first");
+        HIP_OK(hipMemcpyAsync(stock, c->primer_cnt.p, 65536 * 8, hipMemcpyDeviceToHost, c->stream)); HIP_OK(hipStreamSynchronize(c->stream));
     });
 }
 int scs_download_read_numbers(scs_ctx* c, uint32_t* rn) {

@@ -268,6 +268,67 @@ def test_sharded_gpu_job_equals_whole_job(world, case, model, cov, layout, hooks
     assert not os.path.exists(str(tmp_path / "shard") + ".r0_1.fq"), "shards are removed after the merge"
 
 
+# ---- the exhaustion regime (Malbac::updatePrimerCount, Malbac.cpp:91-103): a primer type is used exactly `stock`
+# times, by the first `stock` attachments in list order that ask for it.  The repeat-rich genome of tests/conftest.py at
+# -p 10000 -r 1e-8 drives the 8-mers of its low-complexity runs dry; oracle: sequential live decrement (amplify_pass), HIP: the
+# cut table and its fixed point (scs_kernels.hip "the primer stock, exactly", exact_stock in scs_pipeline.cpp).
+def test_primer_exhaustion_bit_exact(oracle_bin, models, repeat_genome, tmp_path):
+    seed, stock = 31, 10000
+    prefix = str(tmp_path / "orc")
+    _oracle_run(oracle_bin, repeat_genome, models["Illumina_HiSeq2500"], prefix, ["-c", "0.5", "-p", str(stock), "-r", "1e-8"], seed, dump=prefix)
+    prim = np.loadtxt(prefix + ".primers.tsv", dtype=np.int64)                       # primer type, attachments, stock left
+    want_stock = np.full(65536, stock, np.int64); want_stock[prim[:, 0]] = prim[:, 2]
+    assert (want_stock == 0).sum() >= 4 and (prim[:, 1] + prim[:, 2] == stock).all(), "the case must drive primer types dry, exactly"
+    g = scssim_amd.GenReads(profile=models["Illumina_HiSeq2500"], input_fasta=repeat_genome, coverage=0.5, seed=seed, primers=stock, gamma=1e-8)
+    g.create_frags(); g.amplify()
+    st = g.stats()
+    assert st["stock_exhausted_passes"] >= 1 and st["stock_rounds"] >= 1, st
+    got_stock = g.download_primer_stock()
+    bad = np.nonzero(got_stock != want_stock)[0]
+    assert len(bad) == 0, "primer stock differs for %d types, e.g. %s: got %s want %s" % (len(bad), bad[:6], got_stock[bad[:6]], want_stock[bad[:6]])
+    for kind, name in ((0, "semis"), (1, "fulls")):
+        want = _load_dump(prefix + "." + name + ".tsv")
+        a = g.download_amplicons(kind)
+        assert len(a["parent"]) == len(want), name
+        w = np.array([r[:5] for r in want], np.int64)
+        for k, col in enumerate(("parent", "spos", "len", "gc")):
+            d = np.nonzero(a[col].astype(np.int64) != w[:, k])[0]
+            assert len(d) == 0, "%s.%s differs at %d rows, first %d" % (name, col, len(d), d[0])
+    g.allocate_reads(0)
+    fq1, fq2 = g.yield_reads()
+    assert fq1 == open(prefix + "_1.fq", "rb").read(), _fastq_diff(fq1, open(prefix + "_1.fq", "rb").read())
+    assert fq2 == open(prefix + "_2.fq", "rb").read()
+    print("exhaustion: %d types dry, %d passes with a dry type, %d rounds, %d checks" % ((got_stock == 0).sum(), st["stock_exhausted_passes"], st["stock_rounds"], st["stock_checks"]))
+
+
+@pytest.mark.parametrize("world,hooks", [(2, "device"), (3, "host")])
+def test_primer_exhaustion_sharded_equals_whole_job(world, hooks, oracle_bin, models, repeat_genome, tmp_path):
+    """The same regime as 2 and 3 shards: the shards' demand is summed, the pass in which a type runs dry is run again segment by
+    segment in the whole job's list order (attach_pass), and the merged shards equal the unsharded job's -- the oracle's -- files."""
+    import socket
+    import sys
+    seed, stock = "32", "10000"
+    whole = str(tmp_path / "whole")
+    _oracle_run(oracle_bin, repeat_genome, models["Illumina_HiSeq2500"], whole, ["-c", "0.5", "-p", stock, "-r", "1e-8"], seed, dump=whole)
+    prim = np.loadtxt(whole + ".primers.tsv", dtype=np.int64)
+    n_dry = int((prim[:, 2] == 0).sum())
+    assert n_dry >= 4
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = str(s.getsockname()[1]); s.close()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=port, LOCAL_RANK="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_gpu_worker.py"), repeat_genome, models["Illumina_HiSeq2500"],
+                                       str(tmp_path / "shard"), "0.5", "PE", seed, hooks, "0", stock, "1e-8"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=900)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    for o in outs:
+        f = [l for l in o.splitlines() if l.startswith("STOCK ")][0].split()
+        assert int(f[3]) >= 1 and int(f[5]) == n_dry, "every shard must see the dry types of the whole job: " + " ".join(f)
+    scssim_amd.merge_fastq_shards(str(tmp_path / "shard"), world, paired=True)
+    for suffix in ("_1.fq", "_2.fq"):
+        assert open(str(tmp_path / "shard") + suffix, "rb").read() == open(whole + suffix, "rb").read(), "sharded GPU job differs from the whole job (%s)" % suffix
+
+
 def test_device_hooks_over_rccl_single_rank(models, golden_inputs, oracle_bin, tmp_path):
     """The RCCL code path of the device hooks (torch tensors aliasing the library's HBM buffers, collectives on the
     shared stream) with a 1-rank NCCL group: a 1-shard "sharded" job must equal the plain job."""

@@ -278,6 +278,15 @@ def test_bgzf_arithmetic_inflates_with_zlib():
         fib.append(fib[-1] + fib[-2])
     cases = {"fastq": fq, "tiny": b"A", "two": b"AB", "one_symbol": b"N" * 70000, "random": os.urandom(150000), "empty": b"",
              "exact_block": fq[:64512], "block_plus_1": fq[:64513], "fibonacci": b"".join(bytes([65 + i]) * f for i, f in enumerate(fib))}
+    # trees deeper than 17: every count one more than the sum of all but the latest before it (1, 2, 4, 7, 12, 20, 33, ...).  The
+    # 15-bit repair must count the internal nodes below the limit too (zlib's gen_bitlen), or the code is oversubscribed
+    for nsym in range(17, 24):
+        cnt = [1, 2]
+        while len(cnt) < nsym:
+            cnt.append(cnt[-1] + cnt[-2] + 1)
+        if sum(cnt) <= 64000:
+            cases["skewed_%d" % nsym] = b"".join(bytes([97 + i]) * f for i, f in enumerate(cnt))
+    assert sum(1 for k in cases if k.startswith("skewed")) >= 4
     for name, data in cases.items():
         for cap in (0, 64):                                         # 64: every block takes the stored path
             z = scssim_amd.bgzf_probe(data, cap)
