@@ -91,6 +91,21 @@ def synth_genome(torch, dev, lens, seed):
     return names, rl, bases
 
 
+def genome_fingerprint(torch, bases):
+    """Position-weighted 64-bit sum of the genome's bytes in HBM (as int64 words w_i: sum w_i (2 i + 1) mod 2^64): tells whether a box's
+    torch generator made the genome the golden checksums of tests/golden/whole_genome_config3.json belong to."""
+    n = bases.numel() // 8 * 8
+    acc, step = 0, 1 << 27
+    w = bases[:n].view(torch.int64)
+    for o in range(0, w.numel(), step):
+        part = w[o:o + step]
+        idx = torch.arange(o, o + part.numel(), device=bases.device, dtype=torch.int64)
+        acc = (acc + int((part * (2 * idx + 1)).sum().item())) & 0xFFFFFFFFFFFFFFFF
+    for k in range(n, bases.numel()):
+        acc = (acc + int(bases[k].item()) * (k + 12345)) & 0xFFFFFFFFFFFFFFFF
+    return acc
+
+
 def write_simu_fasta(path, names, seqs):
     """simuvars-style FASTA (100 columns) from numpy uint8 arrays."""
     import numpy as np

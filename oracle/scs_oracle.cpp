@@ -743,16 +743,29 @@ void set_primers(Sim& S, bool onlyFrags, uint32_t call) {
     const unsigned long templateNum = tot[0]; const double totalLen = (double)tot[1];
     unsigned long expected = (unsigned long)(S.totalPrimers * S.prm.gamma * templateNum);
     uint64_t count = 0;
-    for (size_t i = 0; i < S.frags.size(); ++i) {
-        double lambda = expected * (1.0 * (unsigned)S.frags[i].len / totalLen);
-        unsigned long k = (unsigned long)poiss_rand(S, lambda, call, 0, S.frag_gbase + i);
-        count += k; S.frags[i].primers = (int)k;
-    }
-    if (!onlyFrags) for (auto& a : S.semis.a) {
-        double lambda = expected * (1.0 * a.len / totalLen);
-        unsigned long k = (unsigned long)poiss_rand(S, lambda, call, 1, a.uid);
-        count += k; a.primers = (uint32_t)(k & 0xFFF);
-    }
+    // (counter mode: the draws are keyed by template, so the templates are handed to the workers in blocks -- same budgets)
+    const int th = S.prm.counter ? S.prm.threads : 1;
+    std::vector<uint64_t> part((size_t)std::max(1, th) * 4, 0);
+    parallel_blocks(S.frags.size(), th, 16, [&](size_t b, size_t lo, size_t hi) {
+        uint64_t c = 0;
+        for (size_t i = lo; i < hi; ++i) {
+            double lambda = expected * (1.0 * (unsigned)S.frags[i].len / totalLen);
+            unsigned long k = (unsigned long)poiss_rand(S, lambda, call, 0, S.frag_gbase + i);
+            c += k; S.frags[i].primers = (int)k;
+        }
+        part[b] += c;
+    });
+    if (!onlyFrags) parallel_blocks(S.semis.a.size(), th, 4096, [&](size_t b, size_t lo, size_t hi) {
+        uint64_t c = 0;
+        for (size_t i = lo; i < hi; ++i) {
+            Amp& a = S.semis.a[i];
+            double lambda = expected * (1.0 * a.len / totalLen);
+            unsigned long k = (unsigned long)poiss_rand(S, lambda, call, 1, a.uid);
+            c += k; a.primers = (uint32_t)(k & 0xFFF);
+        }
+        part[b] += c;
+    });
+    for (uint64_t v : part) count += v;
     S.allreduce(&count, 1);
     S.totalPrimers -= count;
 }
@@ -907,6 +920,7 @@ void full_sequence(const Sim& S, const Amp& a, std::vector<uint8_t>& scratch, st
 // append `add` to `dst`; ref order = reversed creation order per pool task (insertLinkList prepends,
 // Amplicon.cpp:574-585; one task at -t 1, Malbac.cpp:324,351).  Counter mode keeps the same order.
 void append_reversed(AmpList& dst, AmpList& add) {
+    dst.a.reserve(dst.a.size() + add.a.size()); dst.errs.reserve(dst.errs.size() + add.errs.size());
     for (size_t i = add.a.size(); i-- > 0;) {
         Amp a = add.a[i]; uint32_t off = (uint32_t)dst.errs.size();
         for (uint32_t e = 0; e < a.err_cnt; ++e) dst.errs.push_back(add.errs[a.err_off + e]);
@@ -928,8 +942,11 @@ template <class RunRange>
 void amplify_pass(Sim& S, size_t n, size_t min_block, const std::vector<PassSeg>& segs, RunRange run, AmpList& all) {
     const bool ctr = S.prm.counter; const int th = ctr ? S.prm.threads : 1;
     auto gather = [&](std::vector<AmpList>& parts) {
+        size_t na = 0, ne = 0; for (auto& pt : parts) { na += pt.a.size(); ne += pt.errs.size(); }
+        all.a.reserve(all.a.size() + na); all.errs.reserve(all.errs.size() + ne);
         for (auto& pt : parts) { for (auto a : pt.a) { uint32_t off = (uint32_t)all.errs.size();
-            for (uint32_t e = 0; e < a.err_cnt; ++e) all.errs.push_back(pt.errs[a.err_off + e]); a.err_off = off; all.a.push_back(a); } }
+            for (uint32_t e = 0; e < a.err_cnt; ++e) all.errs.push_back(pt.errs[a.err_off + e]); a.err_off = off; all.a.push_back(a); }
+            pt = AmpList(); }                                                       // (a whole-genome pass holds tens of GB here)
     };
     if (!ctr) { std::vector<AmpList> parts(1); PrimerPool pool{S, nullptr, true}; run(0, n, pool, parts[0]); gather(parts); return; }
     {   std::vector<AmpList> parts; std::vector<std::vector<long>> pend;
@@ -1117,56 +1134,76 @@ void allocate_reads(Sim& S, std::vector<double>& w, long reads, std::vector<unsi
     const size_t ac = w.size();
     const unsigned chunk = (unsigned)std::max<size_t>(1, std::min<size_t>(1000, ac / 1));   // loadPerThread at -t 1
     const bool ctr = S.prm.counter;
+    const int th = ctr ? S.prm.threads : 1;                                       // counter mode: every loop below is per element or per chunk
     double total = 0;
     if (ctr) total = tree_sum(w.data(), ac);                                      // [REMAP] fixed-shape sum
     else for (size_t i = 0; i < ac; ++i) total += w[i];
-    for (size_t i = 0; i < ac; ++i) w[i] /= (ZERO_FINAL + total);                 // wls.normalize(0)
     readNumbers.assign(ac, 0);
     unsigned long sum = 0;
-    for (size_t i = 0; i < ac; ++i) { unsigned rc = (unsigned)(w[i] * reads); readNumbers[i] = rc; sum += rc; }
+    {   std::vector<unsigned long> part((size_t)std::max(1, th) * 4, 0);
+        parallel_blocks(ac, th, 1 << 16, [&](size_t b, size_t lo, size_t hi) {
+            unsigned long acc = 0;
+            for (size_t i = lo; i < hi; ++i) { w[i] /= (ZERO_FINAL + total);      // wls.normalize(0)
+                                               unsigned rc = (unsigned)(w[i] * reads); readNumbers[i] = rc; acc += rc; }
+            part[b] += acc;
+        });
+        for (unsigned long v : part) sum += v; }
     reads -= (long)sum;
     // randIndx_hp(wls, reads, readNumbers, true)
     unsigned long n = (unsigned long)reads;
-    struct Chunk { size_t s, e; unsigned quota; std::vector<double> cdf; };
-    std::vector<Chunk> chunks; std::vector<double> totalProbs; unsigned long count = 0;
-    for (size_t s = 0; s < ac; s += chunk) {
-        size_t e = std::min(ac, s + chunk) - 1;
-        Chunk c{s, e, 0, {}};
+    const size_t nch = (ac + chunk - 1) / chunk;
+    // a chunk's probability, and its CDF (the reference keeps every chunk's CDF from here to the sampling; a chunk's CDF is a
+    // function of the chunk alone, so it is made again where it is used: 8 bytes per amplicon less)
+    auto chunk_cdf = [&](size_t c, std::vector<double>& cdf, std::vector<double>& q) -> double {
+        const size_t s0 = c * chunk, e = std::min(ac, s0 + chunk) - 1;
         double tp = 0;
-        c.cdf.resize(e - s + 1);
+        cdf.resize(e - s0 + 1);
         if (ctr) {                                                                // [REMAP] fixed-shape sum and scan
-            tp = tree1000(&w[s], e - s + 1);
-            std::vector<double> q(e - s + 1);
-            for (size_t i = s; i <= e; ++i) q[i - s] = w[i] / tp;
-            scan1000(q.data(), q.size(), c.cdf.data());
+            tp = tree1000(&w[s0], e - s0 + 1);
+            q.resize(e - s0 + 1);
+            for (size_t i = s0; i <= e; ++i) q[i - s0] = w[i] / tp;
+            scan1000(q.data(), q.size(), cdf.data());
         } else {
-            for (size_t i = s; i <= e; ++i) tp += w[i];
+            for (size_t i = s0; i <= e; ++i) tp += w[i];
             double run = 0;
-            for (size_t i = s; i <= e; ++i) { run = run + w[i] / tp; c.cdf[i - s] = run; }
+            for (size_t i = s0; i <= e; ++i) { run = run + w[i] / tp; cdf[i - s0] = run; }
         }
-        c.quota = (unsigned)(tp * n); count += c.quota;
-        totalProbs.push_back(tp); chunks.push_back(std::move(c));
-    }
+        return tp;
+    };
+    std::vector<double> totalProbs(nch); std::vector<unsigned> quota(nch); unsigned long count = 0;
+    parallel_blocks(nch, th, 64, [&](size_t, size_t lo, size_t hi) {
+        for (size_t c = lo; c < hi; ++c) {
+            const size_t s0 = c * chunk, e = std::min(ac, s0 + chunk) - 1;
+            double tp = 0;
+            if (ctr) tp = tree1000(&w[s0], e - s0 + 1); else for (size_t i = s0; i <= e; ++i) tp += w[i];
+            totalProbs[c] = tp; quota[c] = (unsigned)(tp * n);
+        }
+    });
+    for (size_t c = 0; c < nch; ++c) count += quota[c];
     n -= count;
-    if (n > 0 && !chunks.empty()) {
-        std::vector<double> probs(totalProbs.size());
+    if (n > 0 && nch) {
+        std::vector<double> probs(nch);
         if (ctr) scan_all(totalProbs.data(), totalProbs.size(), probs.data());
         else { probs[0] = totalProbs[0]; for (size_t i = 1; i < probs.size(); ++i) probs[i] = probs[i - 1] + totalProbs[i]; }
         uint32_t t = 0;
         while (n-- > 0) {
             const double u = S.rng.main_real(mk(ST_ALLOC_TOP, 0, 0, t++, 0));
             unsigned j = ctr ? first_le(probs.data(), (unsigned)probs.size(), u) : rand_indx(probs.data(), probs.size(), u);
-            chunks[j].quota += 1;
+            quota[j] += 1;
         }
     }
-    for (size_t c = 0; c < chunks.size(); ++c) {                                  // batchSampling, one task per chunk, FIFO
-        Chunk& ch = chunks[c];
-        for (unsigned t = 0; t < ch.quota; ++t) {
-            const double u = S.rng.real(mk(ST_ALLOC_CHUNK, 0, c, t >> 2, (int)(t & 3)));   // [REMAP] draw t = word t & 3 of block t >> 2
-            unsigned j = ctr ? first_le(ch.cdf.data(), (unsigned)ch.cdf.size(), u) : rand_indx(ch.cdf.data(), ch.cdf.size(), u);
-            readNumbers[ch.s + j] += 1;
+    parallel_blocks(nch, th, 64, [&](size_t, size_t lo, size_t hi) {              // batchSampling, one task per chunk, FIFO
+        std::vector<double> cdf, q; Rng rng = S.rng;
+        for (size_t c = lo; c < hi; ++c) {
+            if (!quota[c]) continue;
+            chunk_cdf(c, cdf, q);
+            for (unsigned t = 0; t < quota[c]; ++t) {
+                const double u = rng.real(mk(ST_ALLOC_CHUNK, 0, c, t >> 2, (int)(t & 3)));   // [REMAP] draw t = word t & 3 of block t >> 2
+                unsigned j = ctr ? first_le(cdf.data(), (unsigned)cdf.size(), u) : rand_indx(cdf.data(), cdf.size(), u);
+                readNumbers[c * chunk + j] += 1;
+            }
         }
-    }
+    });
     if (S.prm.paired) { int k = 1; for (size_t i = 0; i < ac; ++i) if (readNumbers[i] % 2 == 1) { readNumbers[i] += k; k *= -1; } }
 }
 
@@ -1203,7 +1240,9 @@ void set_read_counts(Sim& S, long reads) {
 // ---- a11: Amplicon::yieldReads (Amplicon.cpp:402-565) -----------------------------------------
 struct ReadOut { std::string f1, f2; unsigned long pairs = 0; std::string dump; };
 
-void yield_reads_range(Sim& S, Rng& rng, size_t lo, size_t hi, ReadOut& out, bool dump) {
+// poff (checksum mode, below): planned pairs (SE: reads) before every amplicon; only the records whose slot -- poff[i] + their
+// number among the amplicon's produced ones -- lies in [slot_lo, slot_hi) are made
+void yield_reads_range(Sim& S, Rng& rng, size_t lo, size_t hi, ReadOut& out, bool dump, const uint64_t* poff = nullptr, uint64_t slot_lo = 0, uint64_t slot_hi = ~0ull) {
     const Profile& P = *S.prof; const int L = P.L; const bool paired = S.prm.paired;
     std::vector<uint8_t> scratch, seq, win(L);
     std::vector<char> ob(2 * L + 128), oq(2 * L + 128);
@@ -1216,11 +1255,12 @@ void yield_reads_range(Sim& S, Rng& rng, size_t lo, size_t hi, ReadOut& out, boo
         full_sequence(S, a, scratch, seq);
         const int ampLen = (int)a.len;
         if (ampLen < L) continue;
-        int fragCount = 0, failCount = 0;
+        int fragCount = 0, failCount = 0; uint64_t made = 0;
         while (n > 0) {
             fragCount++;
             const uint32_t att = (uint32_t)(fragCount - 1);
             if (!paired) {
+                if (poff) { const uint64_t slot = poff[i] + made++; if (slot < slot_lo || slot >= slot_hi) { n--; continue; } }
                 long pos = (long)(0 + (double)(ampLen - L + 1 - 0) * rng.integer(mk(ST_PAIR, 0, a.uid, att, 1)));
                 int m = predict(P, rng, &seq[pos], L, true, a.uid, att, ob.data(), oq.data());
                 int k = snprintf(name, sizeof name, "@%d#%d\n", (int)gi, fragCount);
@@ -1232,6 +1272,7 @@ void yield_reads_range(Sim& S, Rng& rng, size_t lo, size_t hi, ReadOut& out, boo
                       P.isizeAlphabet[rand_indx(P.isizeCdf.data(), P.isizeCdf.size(), rng.real(mk(ST_PAIR, 0, a.uid, att, 0)))];
             if (isz < 0) fail("Error: unrecognized parameter name \"insertSize\"");      // Profile.cpp:1483-1485 (exit(1))
             if (isz < L || isz > ampLen) { failCount++; if (failCount > 1000) break; continue; }
+            if (poff) { const uint64_t slot = poff[i] + made++; if (slot < slot_lo || slot >= slot_hi) { n -= 2; continue; } }
             long pos = (long)(0 + (double)(ampLen - isz + 1 - 0) * rng.integer(mk(ST_PAIR, 0, a.uid, att, 1)));
             int m1 = predict(P, rng, &seq[pos], L, true, a.uid, att, ob.data(), oq.data());
             int k = snprintf(name, sizeof name, "@%d#%d/1\n", (int)gi, fragCount);
@@ -1300,6 +1341,64 @@ int genreads(const scso_params& q) {
         if (p.paired) { o2 = fopen((pre + "_2.fq").c_str(), "w"); if (!o2) fail("Error: can not open fastq file to save results:\n" + pre); }
     }
     if (p.verbose) fprintf(stderr, "\n*****Producing reads*****\n");
+    if (q.checksum_file) {
+        // checksum mode (tools/whole_genome_golden.py: BASELINE configs[3] at full size, 197 GB of text): the FASTQ is not written
+        // but summed batch by batch the way the library sums its batches (scs_set_batch_checksums, include/scssim_hip.h): batch b
+        // = the records of the planned pairs [b N, (b + 1) N) -- an amplicon plans readNumbers / 2 pairs (SE: readNumbers
+        // reads), the k-th one it produces takes its k-th slot, the slots of pairs it gives up on stay empty -- and its sum =
+        // sum_i fmix64(w_i + (i + 1) phi) over the batch's text as little-endian 64-bit words (the last zero-padded).
+        const uint64_t B = q.batch_pairs ? q.batch_pairs : (1ull << 23);
+        const size_t ac = S.fulls.a.size();
+        std::vector<uint64_t> poff(ac + 1, 0);
+        for (size_t i = 0; i < ac; ++i) poff[i + 1] = poff[i] + (p.paired ? S.readNumbers[i] / 2 : S.readNumbers[i]);
+        const uint64_t P = poff[ac], nb = (P + B - 1) / B;
+        FILE* cf = fopen(q.checksum_file, "w"); if (!cf) fail(std::string("cannot write ") + q.checksum_file);
+        fprintf(cf, "# frags %zu semis %zu fulls %zu planned %llu batch %llu\n", S.frags.size(), S.semis.a.size(), ac, (unsigned long long)P, (unsigned long long)B);
+        auto text_sum = [&](const std::string& t) -> uint64_t {
+            const size_t nw = (t.size() + 7) / 8; std::vector<uint64_t> part((size_t)p.threads * 4, 0);
+            parallel_blocks(nw, p.threads, 1 << 16, [&](size_t b, size_t lo, size_t hi) {
+                uint64_t acc = 0;
+                for (size_t i = lo; i < hi; ++i) {
+                    uint64_t w = 0; const size_t o = i * 8, n = std::min<size_t>(8, t.size() - o); memcpy(&w, t.data() + o, n);
+                    uint64_t x = w + (uint64_t)(i + 1) * 0x9E3779B97F4A7C15ull;
+                    x ^= x >> 33; x *= 0xFF51AFD7ED558CCDull; x ^= x >> 33; x *= 0xC4CEB9FE1A85EC53ull; x ^= x >> 33;
+                    acc += x;
+                }
+                part[b] = acc;
+            });
+            uint64_t sum = 0; for (uint64_t v : part) sum += v;
+            return sum;
+        };
+        unsigned long pairs = 0; size_t i0 = 0; std::string x1, x2;
+        std::vector<uint64_t> only;                                                  // checksum_batches "0,1,35": those batches alone (negative: from the end)
+        if (q.checksum_batches) for (auto& f : split(q.checksum_batches, ',')) { long long v = atoll(f.c_str()); if (v < 0) v += (long long)nb; if (v >= 0 && (uint64_t)v < nb) only.push_back((uint64_t)v); }
+        for (uint64_t b = 0; b < nb; ++b) {
+            if (q.checksum_batches && std::find(only.begin(), only.end(), b) == only.end()) continue;
+            const uint64_t lo = b * B, hi = std::min(P, lo + B);
+            while (poff[i0 + 1] <= lo) ++i0;                                          // first amplicon with a slot in the batch
+            size_t i1 = i0; while (i1 < ac && poff[i1] < hi) ++i1;
+            size_t nbMax = (size_t)p.threads * 4; std::vector<ReadOut> outs(nbMax);
+            parallel_blocks(i1 - i0, p.threads, 256, [&](size_t k, size_t a, size_t e) {
+                Rng rng = S.rng;
+                const size_t room = (size_t)(std::min(hi, poff[i0 + e]) - std::max(lo, poff[i0 + a])) * (size_t)(2 * S.prof->L + 40);
+                outs[k].f1.reserve(room); if (p.paired) outs[k].f2.reserve(room);
+                yield_reads_range(S, rng, i0 + a, i0 + e, outs[k], false, poff.data(), lo, hi);
+            });
+            x1.clear(); x2.clear(); unsigned long bp = 0;
+            { size_t n1 = 0, n2 = 0; for (auto& o : outs) { n1 += o.f1.size(); n2 += o.f2.size(); } x1.reserve(n1); x2.reserve(n2); }
+            for (auto& o : outs) { x1 += o.f1; x2 += o.f2; bp += o.pairs; o = ReadOut(); }
+            pairs += bp;
+            fprintf(cf, "%llu\t%016llx\t%016llx\t%zu\t%zu\t%lu\n", (unsigned long long)b, (unsigned long long)text_sum(x1), (unsigned long long)text_sum(x2), x1.size(), x2.size(), bp);
+            fflush(cf);
+            if (p.verbose) fprintf(stderr, "[oracle] batch %llu / %llu: %lu pairs, %.1f s\n", (unsigned long long)b + 1, (unsigned long long)nb, bp, now_s() - t4);
+        }
+        fclose(cf);
+        double t5 = now_s();
+        if (p.verbose) fprintf(stderr, "[oracle] frags=%zu semis=%zu fulls=%zu primers_left=%lu pairs=%lu | load %.2fs frag %.2fs amplify %.2fs alloc %.2fs readgen %.2fs\n",
+                               S.frags.size(), S.semis.a.size(), S.fulls.a.size(), S.totalPrimers, pairs, t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4);
+        g_timings[0] = t1 - t0; g_timings[1] = t2 - t1; g_timings[2] = t3 - t2; g_timings[3] = t4 - t3; g_timings[4] = t5 - t4; g_timings[5] = (double)pairs;
+        return 0;
+    }
     const bool dump = q.dump_prefix != nullptr;
     FILE* dr = dump ? fopen((std::string(q.dump_prefix) + ".reads.tsv").c_str(), "w") : nullptr;
     unsigned long pairs = 0;
@@ -1614,6 +1713,7 @@ int scso_predict_counter_batch(void* h, const uint8_t* windows, int n, int count
 #ifdef SCS_ORACLE_MAIN
 // scs_oracle genreads: the reference's genreads CLI (src/scssim.cpp:285-404) + oracle extras
 //   --rng ref|counter   --seed N   --fixed-time T   --dump PREFIX   -q (quiet)
+//   --checksums FILE [--batch-pairs N] [--checksum-batches 0,1,-1]   no FASTQ files: the text's checksum per batch of N planned pairs (default 2^23) and mate
 #include <getopt.h>
 int main(int argc, char** argv) {
     if (argc >= 2 && strcmp(argv[1], "simuvars") == 0) {                          // the reference's simuvars CLI (src/scssim.cpp:108-170)
@@ -1627,7 +1727,8 @@ int main(int argc, char** argv) {
     scso_params p; scso_default_params(&p);
     static option lo[] = {{"input", 1, 0, 'i'}, {"primers", 1, 0, 'p'}, {"gamma", 1, 0, 'r'}, {"model", 1, 0, 'm'}, {"layout", 1, 0, 'l'},
                           {"coverage", 1, 0, 'c'}, {"isize", 1, 0, 's'}, {"threads", 1, 0, 't'}, {"output", 1, 0, 'o'},
-                          {"rng", 1, 0, 1000}, {"seed", 1, 0, 1001}, {"fixed-time", 1, 0, 1002}, {"dump", 1, 0, 1003}, {0, 0, 0, 0}};
+                          {"rng", 1, 0, 1000}, {"seed", 1, 0, 1001}, {"fixed-time", 1, 0, 1002}, {"dump", 1, 0, 1003},
+                          {"checksums", 1, 0, 1004}, {"batch-pairs", 1, 0, 1005}, {"checksum-batches", 1, 0, 1006}, {0, 0, 0, 0}};
     int c; argc--; argv++;
     while ((c = getopt_long(argc, argv, "i:p:r:m:l:c:s:t:o:q", lo, nullptr)) != -1) switch (c) {
         case 'i': p.input_fasta = optarg; break; case 'p': p.primers = atol(optarg); break; case 'r': p.gamma = atof(optarg); break;
@@ -1636,9 +1737,10 @@ int main(int argc, char** argv) {
         case 'q': p.verbose = 0; break;
         case 1000: p.rng_mode = strcmp(optarg, "ref") == 0 ? 0 : 1; break; case 1001: p.seed = strtoull(optarg, 0, 10); break;
         case 1002: p.fixed_time = atoll(optarg); break; case 1003: p.dump_prefix = optarg; break;
+        case 1004: p.checksum_file = optarg; break; case 1005: p.batch_pairs = strtoull(optarg, 0, 10); break; case 1006: p.checksum_batches = optarg; break;
         default: return 1;
     }
-    if (!p.input_fasta || !p.profile || !p.output_prefix) { fprintf(stderr, "Error: -i, -m and -o are required\n"); return 1; }
+    if (!p.input_fasta || !p.profile || (!p.output_prefix && !p.checksum_file)) { fprintf(stderr, "Error: -i, -m and -o are required\n"); return 1; }
     int rc = scso_genreads(&p);
     if (rc) fprintf(stderr, "%s\n", scso_last_error());
     return rc;

@@ -55,6 +55,9 @@ struct scso_params {
     scso_allreduce_fn  allreduce;                // required when shard_count > 1
     scso_allgatherv_fn allgatherv;
     void*  coll_user;
+    const char* checksum_file;   // may be NULL.  Not NULL: no FASTQ files; per batch of batch_pairs planned pairs (0: 2^23) and mate the
+    uint64_t batch_pairs;        //   checksum the library computes for its batches (scs_set_batch_checksums), one line per batch
+    const char* checksum_batches;  // may be NULL: every batch.  "0,1,-1": those batches alone (negative = counted from the end)
 };
 void scso_default_params(scso_params* p);
 int  scso_genreads(const scso_params* p);

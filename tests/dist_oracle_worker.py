@@ -11,7 +11,8 @@ class Params(C.Structure):
     _fields_ = [("input_fasta", C.c_char_p), ("profile", C.c_char_p), ("output_prefix", C.c_char_p), ("dump_prefix", C.c_char_p),
                 ("primers", C.c_long), ("gamma", C.c_double), ("coverage", C.c_double), ("isize", C.c_int), ("paired", C.c_int),
                 ("threads", C.c_int), ("rng_mode", C.c_int), ("seed", C.c_uint64), ("fixed_time", C.c_longlong), ("verbose", C.c_int),
-                ("shard_rank", C.c_int), ("shard_count", C.c_int), ("allreduce", C.c_void_p), ("allgatherv", C.c_void_p), ("coll_user", C.c_void_p)]
+                ("shard_rank", C.c_int), ("shard_count", C.c_int), ("allreduce", C.c_void_p), ("allgatherv", C.c_void_p), ("coll_user", C.c_void_p),
+                ("checksum_file", C.c_char_p), ("batch_pairs", C.c_uint64), ("checksum_batches", C.c_char_p)]
 
 
 def main():

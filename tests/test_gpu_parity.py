@@ -610,6 +610,19 @@ def test_insert_size_give_up_path_bit_exact(case, oracle_bin, models, golden_inp
     made = w1.count(b"\n") // 4
     assert st["pairs_written"] == made and st["reads_written"] == 2 * made
     assert 0 < made < 0.9 * (st["reads_requested"] // 2), "the give-up path was not reached"
+    # the per-batch checksums of the text in HBM (scs_set_batch_checksums) against the oracle's checksum mode -- what pins
+    # BASELINE configs[3] at full size (tests/golden/whole_genome_config3.json): a batch = the records of a range of PLANNED pairs,
+    # holes included, so this regime (and the small-batch run's 4096-pair batches) is where the two could disagree
+    shift = int(os.environ.get("SCS_TEST_BATCH_SHIFT", "23"))
+    subprocess.check_call([oracle_bin, "genreads", "-i", fa, "-m", prof, "--rng", "counter", "--seed", str(seed), "-t", "8", "-q", "-c", "%g" % cov, "-s", "1500",
+                           "--checksums", prefix + ".cks", "--batch-pairs", str(1 << shift)])
+    want = [(int(f[1], 16), int(f[2], 16)) for f in (l.split() for l in open(prefix + ".cks") if not l.startswith("#"))]
+    g.set_batch_checksums(True)
+    g.yield_reads_sink(None)
+    got = g.batch_checksums()
+    assert len(want) == (st["reads_requested"] // 2 + (1 << shift) - 1) >> shift and (shift == 23 or case == "g1" or len(want) > 20)
+    assert got == want, "batch checksums differ from the oracle's: first at batch %d of %d" % (next(i for i, (a, b) in enumerate(zip(got, want)) if a != b), len(want))
+    assert sum(int(l.split()[5]) for l in open(prefix + ".cks") if not l.startswith("#")) == made
 
 
 def _md5_file(path):
