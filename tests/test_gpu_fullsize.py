@@ -85,6 +85,7 @@ def test_whole_genome_properties(cfg, models, tmp_path):
         prof = bench.make_profile(td)
         cov, isz, L = 30.0, 260, 150
         names, rl, bases = bench.synth_genome(torch, dev, lens, 3000)
+        genome_fp = bench.genome_fingerprint(torch, bases)
         torch.cuda.synchronize()
         g = scssim_amd.GenReads(profile=prof, coverage=cov, isize=isz, seed=11, stream=stream.cuda_stream)
         g.upload_genome_device(names, rl, bases.data_ptr())
@@ -135,6 +136,14 @@ def test_whole_genome_properties(cfg, models, tmp_path):
         assert total_bases > 2 * G * 1.15                                          # mean copy number 4 over a fifth of the genome
     assert g.read_length == L
     g.set_batch_checksums(True)
+    golden = None
+    if cfg.startswith("config3"):
+        # the oracle's run of this very job (tools/whole_genome_golden.py, 7 minutes of 16 host cores): counts and the checksum of every
+        # 8 M-pair batch's text per mate.  The genome comes from torch's device generator: its fingerprint says whether this box made
+        # the genome the golden belongs to (a different generator is not a parity failure -- but it must be said, not skipped over)
+        import json
+        golden = json.load(open(os.path.join(ROOT, "tests", "golden", "whole_genome_config3.json")))
+        assert golden["genome"]["fingerprint"] == "%016x" % genome_fp, "this box's synthetic genome is not the one tests/golden/whole_genome_config3.json was made from: make it again (tools/whole_genome_golden.py)"
 
     def job(seed, sink=None):
         g.set_seed(seed)
@@ -150,6 +159,15 @@ def test_whole_genome_properties(cfg, models, tmp_path):
     assert 3.5e5 < per_mb < 4.7e5 and 3.5e4 < st["semi_amplicons"] / (total_bases / 2e6) < 5.5e4, per_mb      # ~4.1e5 / ~4.5e4 per haploid Mb
     assert len(cks) == (st["pairs_written"] + (1 << 23) - 1) >> 23 or len(cks) == ((want_reads + 1) // 2 + (1 << 23) - 1) >> 23
     assert all(a and b for a, b in cks)
+    if golden:
+        # BASELINE configs[3] bit for bit against the oracle at full size: 1.1e9 amplicons = 1.1e6 allocation chunks (the third level
+        # of the chunk CDF, MyDefine.cpp:203-253), amplicon indices above 1e9 in the names (Amplicon.cpp:460,498,519), 197 GB of text
+        c = golden["counts"]
+        assert (st["fragments"], st["semi_amplicons"], st["full_amplicons"]) == (c["frags"], c["semis"], c["fulls"]), (st, c)
+        assert st["full_amplicons"] > 1000000000 and len(golden["batches"]) == len(cks) >= 37
+        assert st["pairs_written"] == sum(r[5] for r in golden["batches"]) and st["fastq_bytes"] == [sum(r[3] for r in golden["batches"]), sum(r[4] for r in golden["batches"])]
+        bad = [r[0] for r in golden["batches"] if cks[r[0]] != (int(r[1], 16), int(r[2], 16))]
+        assert not bad, "the text of batches %s differs from the oracle's (of %d)" % (bad[:8], len(cks))
     mean_rec = sum(st["fastq_bytes"]) / (2.0 * st["pairs_written"])
     assert 2 * L + 14 < mean_rec < 2 * L + 30                                         # "@<amp>#<cnt>/1\n" + bases + "\n+\n" + qualities + "\n"
     bytes_null = list(st["fastq_bytes"])
