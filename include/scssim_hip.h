@@ -232,6 +232,10 @@ int         scs_download_read_numbers(scs_ctx* ctx, uint32_t* read_numbers);
 /* The primer pool after scs_amplify: stock[65536], copies left of every primer type (PrimerIndex.count, lib/malbac/Malbac.h:18-24;
  * index = the 8-mer at two bits per base, first base in the top bits). */
 int         scs_download_primer_stock(scs_ctx* ctx, int64_t* stock);
+/* Test seams (csrc/scs_seams.h: small batches, forced kernel variants, injected failures) exist only in libscssim_hip_seams.so, the
+ * build the tests load; there this returns the seam's value.  In libscssim_hip.so it returns NULL for every name: the product reads
+ * no such knob. */
+const char* scs_test_seam(const char* name);
 
 /* ---- host-only table access (no GPU needed): the thresholds scs_load_profile uploads -------------
  * which: 0 subs read1 [84][bins][4], 1 subs read2, 2 quality [16][bins][94], 3 insert length,

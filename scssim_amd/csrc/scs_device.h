@@ -159,7 +159,7 @@ void launch_errs_semis(hipStream_t s, const uint8_t* g, DevGenomeIdx gx, DevFrag
                        DevAmps out, uint32_t out_base, DevErrPool pool, uint32_t* flags, const unsigned long long* binom, AmplifyParams p,
                        int64_t* primer_cnt, uint32_t* primer_delta, unsigned long long* primer_cut, unsigned long long* sums);   // primer_cnt non-null: the pass's stock update rides along (unsharded job)
 void launch_encode_bases(hipStream_t s, uint8_t* g, uint64_t n);
-void launch_fa_gather_regular(hipStream_t s, const uint8_t* raw, uint8_t* dst, uint64_t n, uint32_t col0, uint32_t lb, uint32_t lw);   // a piece of a regular FASTA record without its line ends
+void launch_fa_gather_regular(hipStream_t s, const uint8_t* raw, uint8_t* dst, uint64_t n, uint32_t col0, uint32_t lb, uint32_t lw, uint32_t* ragged);   // a piece of a regular FASTA record without its line ends
 void launch_frag_has_n(hipStream_t s, const uint64_t* goff, const uint32_t* len, uint32_t nf, DevGenomeIdx gx, uint8_t* has_n);
 // one chunk of a FASTA file parsed on the device (k_fa_*): st = {bases so far, headers so far, kind of the open line}; kind n bytes,
 // keep / pos n + 1 words; hdr = pairs {file offset of a header, bases before it}, at most hdr_cap of them
@@ -217,6 +217,7 @@ hipError_t take_launch_error();
 
 // device-wide exclusive scans (n inputs -> n+1 outputs, last = total)
 size_t scan_temp_bytes(size_t n);
+size_t parity_scan_temp_bytes(size_t n);
 void exclusive_scan_u32(hipStream_t s, const uint32_t* in, uint32_t* out, size_t n, void* temp, size_t temp_bytes);
 void exclusive_scan_u32_pair(hipStream_t s, const uint32_t* in0, uint32_t* out0, size_t n0, const uint32_t* in1, uint32_t* out1, size_t n1, void* temp, size_t temp_bytes);
 // record sizes (class flag in bit 31) -> byte offsets in the low OFF_BITS bits, count of flagged reads above (one scan for both)

@@ -3,6 +3,7 @@
 // Reference call sequence reproduced: src/scssim.cpp:46-67 (genreads branch of main()).
 #include "../../include/scssim_hip.h"
 #include "scs_device.h"
+#include "scs_seams.h"
 #include "scs_tables.h"
 #include "scs_comm.h"
 #include "scs_bgzf.h"
@@ -49,10 +50,10 @@ struct DevBuf {
     // equal-sized chunks: on ROCm 7.2 hipMemSetAccess rejects a chunk mapped right behind one of a different size (probed)
     static constexpr size_t kRange = 384ull << 30, kGran = 128ull << 20;
     static size_t virtual_from() {           // SCS_VMM_FROM_MB: tests lower it so that small jobs run on mapped buffers too
-        static const size_t v = getenv("SCS_VMM_FROM_MB") ? (size_t)atol(getenv("SCS_VMM_FROM_MB")) << 20 : 64ull << 20;
+        static const size_t v = seam_env("SCS_VMM_FROM_MB") ? (size_t)atol(seam_env("SCS_VMM_FROM_MB")) << 20 : 64ull << 20;
         return v;
     }
-    static bool& virtual_ok() { static bool ok = getenv("SCS_NO_VMM") == nullptr; return ok; }
+    static bool& virtual_ok() { static bool ok = seam_env("SCS_NO_VMM") == nullptr; return ok; }
     void map_more(size_t ncap) {             // map [cap, ncap) of the reserved range, kGran at a time
         int dev = 0; HIP_OK(hipGetDevice(&dev));
         hipMemAllocationProp prop = {}; prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = dev;
@@ -532,6 +533,9 @@ bool stage_fasta_slice(scs_ctx* c, const std::string& path) {
             else if (next != size) return false;
         } else if (r + 1 < ents.size()) return false;
     }
+    // (the fragment split reads the records from the ctx: what was there comes back if this staging gives up below)
+    struct Keep { scs_ctx* c; std::vector<FastaRecord> recs; std::vector<uint64_t> off, len; uint64_t bases; bool done = false;
+                  ~Keep() { if (!done) { c->recs.swap(recs); c->rec_off.swap(off); c->rec_len.swap(len); c->genome_bases = bases; } } } keep{c, c->recs, c->rec_off, c->rec_len, c->genome_bases};
     c->recs.assign(ents.size(), FastaRecord()); c->rec_off.clear(); c->rec_len.clear(); uint64_t tot = 0;
     for (size_t r = 0; r < ents.size(); ++r) { c->recs[r].name = ents[r].name; c->rec_off.push_back(tot); c->rec_len.push_back(ents[r].len); tot += ents[r].len; }
     c->genome_bases = tot;
@@ -543,11 +547,14 @@ bool stage_fasta_slice(scs_ctx* c, const std::string& path) {
     const uint64_t n_slice = g_hi - g_lo;
     if (n_slice == 0) return false;                                                 // (more shards than fragments: nothing of its own to stage)
     c->genome.reserve(std::max<uint64_t>(n_slice, 16), s);
+    DevBuf d_ragged; struct RelR { DevBuf* b; ~RelR() { b->release(); } } relr{&d_ragged};
+    d_ragged.reserve(16, s); HIP_OK(hipMemsetAsync(d_ragged.p, 0, 4, s));
     // record by record: the bytes of [a, b) -> pinned -> device, line ends dropped by the gather
     const size_t CH = 64u << 20; DevBuf d_raw; char* h_raw = nullptr;
     struct Rel { DevBuf* b; char** h; ~Rel() { b->release(); if (*h) (void)hipHostFree(*h); } } rel{&d_raw, &h_raw};
     HIP_OK(hipHostMalloc((void**)&h_raw, CH, hipHostMallocDefault)); d_raw.reserve(CH + 16, s);
     for (size_t r = 0; r < ents.size() && n_slice; ++r) {
+        if (ents[r].len == 0) continue;                                             // an empty record (index line "name 0 off 0 0"): nothing to read, no line geometry
         const uint64_t r0 = c->rec_off[r], r1 = r0 + ents[r].len;
         uint64_t a = std::max(g_lo, r0), b = std::min(g_hi, r1);
         const uint64_t per = (uint64_t)(CH / ents[r].lw) * ents[r].lb;              // bases whose lines fit the buffer (two lines of slack: a piece starts and ends inside a line)
@@ -557,10 +564,15 @@ bool stage_fasta_slice(scs_ctx* c, const std::string& path) {
             HIP_OK(hipStreamSynchronize(s));                                         // the pinned buffer's last upload is done
             if (pread(fd, h_raw, (size_t)(f1 - f0), (off_t)f0) != (ssize_t)(f1 - f0)) throw ScsError(SCS_EIO, "could not read " + path);
             HIP_OK(hipMemcpyAsync(d_raw.p, h_raw, (size_t)(f1 - f0), hipMemcpyHostToDevice, s));
-            launch_fa_gather_regular(s, d_raw.as<uint8_t>(), c->genome.as<uint8_t>() + (a - g_lo), take, (uint32_t)(ba % ents[r].lb), ents[r].lb, ents[r].lw);
+            launch_fa_gather_regular(s, d_raw.as<uint8_t>(), c->genome.as<uint8_t>() + (a - g_lo), take, (uint32_t)(ba % ents[r].lb), ents[r].lb, ents[r].lw, d_ragged.as<uint32_t>());
             a += take;
         }
     }
+    {   // a line end or a '>' among the bases: the lines are not what the index says (ragged lines that cancel out, a blank line, a
+        // file rewritten within the index's second) -- not this file's index: the whole file is staged by the parser instead
+        uint32_t ragged = 0; HIP_OK(hipMemcpyAsync(&ragged, d_ragged.p, 4, hipMemcpyDeviceToHost, s)); HIP_OK(hipStreamSynchronize(s));
+        if (ragged) return false; }
+    keep.done = true;
     index_genome(c, n_slice);
     HIP_OK(hipStreamSynchronize(s));
     { const hipError_t le = take_launch_error(); if (le != hipSuccess) throw ScsError(SCS_EDEVICE, std::string("FASTA slice staging: ") + hipGetErrorString(le)); }
@@ -776,7 +788,7 @@ void launch_pass(scs_ctx* c, bool from_frag, uint32_t pass, int rb_slot) {
     // stream beside the fragment pass that follows (its chain of dependent gathers beside the attach kernel's ALU work); the
     // stock update it used to carry runs on the main stream.  Joined before the next setPrimers rewrites the slot offsets.
     hipStream_t es = s;
-    if (!from_frag && !getenv("SCS_ERRS_INLINE")) {
+    if (!from_frag && !seam_env("SCS_ERRS_INLINE")) {
         if (!c->errs_stream) {
             HIP_OK(hipStreamCreateWithFlags(&c->errs_stream, hipStreamNonBlocking));
             HIP_OK(hipEventCreateWithFlags(&c->ev_att, hipEventDisableTiming)); HIP_OK(hipEventCreateWithFlags(&c->ev_errs, hipEventDisableTiming));
@@ -1086,7 +1098,7 @@ void do_yield(scs_ctx* c, const OutTarget& tg, uint64_t* n1_out, uint64_t* n2_ou
     // pairs per batch: 8 M with the text staying in HBM (5 GB of text per batch: the base pass' grids are long enough for their tails and
     // the per-batch pre-pass not to matter: 2 M -> 8 M gave -11 % on the stage), 512 k towards a sink (pinned slots; 256 k when many
     // writers each hold one)
-    static const int batch_shift = getenv("SCS_TEST_BATCH_SHIFT") ? atoi(getenv("SCS_TEST_BATCH_SHIFT")) : 0;   // tests: many small batches
+    static const int batch_shift = seam_env("SCS_TEST_BATCH_SHIFT") ? atoi(seam_env("SCS_TEST_BATCH_SHIFT")) : 0;   // tests: many small batches
     const uint64_t batch = std::min<uint64_t>(std::max<uint64_t>(P, 1), batch_shift ? (1ull << batch_shift) : to_sink ? (tg.sink->writers > 4 ? 1ull << 18 : 1ull << 19) : (1ull << 23));
     // The pairs are planned (k_plan_pairs: insert sizes, positions, the amplicon resolved to an index map) batch by batch, at the
     // head of each batch's pre-pass: bounds[b] = the amplicon that holds the batch's first pair.
@@ -1146,7 +1158,7 @@ void do_yield(scs_ctx* c, const OutTarget& tg, uint64_t* n1_out, uint64_t* n2_ou
     // The pre-pass runs on a stream of its own, BESIDE the previous batch's base pass (it is memory-bound and short, the base pass
     // compute-bound).  Its buffer set must be free (the base pass two batches back, which read it, is over: ev_free) and the
     // base pass of its batch starts when the host has seen its mail.  SCS_READS_SERIAL=1: everything on the ctx stream.
-    static const bool serial_pre = getenv("SCS_READS_SERIAL") != nullptr;
+    static const bool serial_pre = seam_env("SCS_READS_SERIAL") != nullptr;
     hipStream_t ps = s; bool free_rec[2] = {false, false};
     if (!serial_pre) {
         if (!c->pre_stream) {
@@ -1310,7 +1322,7 @@ void do_yield(scs_ctx* c, const OutTarget& tg, uint64_t* n1_out, uint64_t* n2_ou
     const uint64_t per_pair_tmpl = paired ? (uint64_t)(c->cfg.isize + 1) : (uint64_t)L;
     c->st.algorithmic_bytes = 1526ull * (c->st.semi_amplicons + c->st.full_amplicons) + pairs_written * per_pair_tmpl + tot1 + tot2;
     if (n1_out) *n1_out = tot1; if (n2_out) *n2_out = tot2; if (pairs_out) *pairs_out = pairs_written;
-    if (getenv("SCS_PHASE_CLOCK")) phase_clock_report();                         // (prints only in a -DSCS_PHASE_CLOCK build)
+    if (seam_env("SCS_PHASE_CLOCK")) phase_clock_report();                         // (prints only in a -DSCS_PHASE_CLOCK build)
     if (c->cfg.verbose) fprintf(stderr, "\nReads generation done!\n");
 }
 
@@ -1402,8 +1414,8 @@ int scs_read_length(const scs_ctx* c) { return c && c->have_profile ? c->prof.re
 int scs_load_genome_fasta(scs_ctx* c, const char* path) {
     return guarded(c, [&] {
         if (!path) throw ScsError(SCS_EINVAL, "null path");
-        if (getenv("SCS_HOST_FASTA")) { load_fasta(path, c->recs, true); stage_genome(c); }   // the host parser (what scs_fasta_probe checks); debugging aid
-        else if (c->cfg.shard_count > 1 && !getenv("SCS_STAGE_WHOLE") && stage_fasta_slice(c, fasta_plain_path(path))) {
+        if (seam_env("SCS_HOST_FASTA")) { load_fasta(path, c->recs, true); stage_genome(c); }   // the host parser (what scs_fasta_probe checks); debugging aid
+        else if (c->cfg.shard_count > 1 && !seam_env("SCS_STAGE_WHOLE") && stage_fasta_slice(c, fasta_plain_path(path))) {
             if (c->cfg.verbose) fprintf(stderr, "(shard %d of %d: %llu of %llu bases staged)\n", c->cfg.shard_rank, c->cfg.shard_count, (unsigned long long)c->slice_len, (unsigned long long)c->genome_bases);
         }
         else stage_fasta_on_device(c, path);
@@ -1661,6 +1673,7 @@ int scs_download_amplicons(scs_ctx* c, int kind, uint32_t* parent, uint32_t* spo
         }
     });
 }
+const char* scs_test_seam(const char* name) { return name ? seam_env(name) : nullptr; }
 int scs_download_primer_stock(scs_ctx* c, int64_t* stock) {
     return guarded(c, [&] {
         if (!stock) throw ScsError(SCS_EINVAL, "null pointer");

@@ -4,6 +4,7 @@
 // lib/mydefine/MyDefine.cpp:54-57 (normpdf), 274-282 (randIndx), 337-349 (getNextLine);
 // lib/fastahack/Fasta.cpp:45-215 + lib/genome/Genome.cpp:176-195,272-278 (FASTA).
 #include "scs_tables.h"
+#include "scs_seams.h"
 #include "scs_common.h"
 
 #include <algorithm>
@@ -219,7 +220,7 @@ void load_profile(const std::string& path, bool paired, int isize, ProfileTables
         std::vector<uint8_t> sym((size_t)16 * B * 94); std::vector<uint64_t> w((size_t)16 * B * 94); std::vector<int> ns((size_t)16 * B); int max_syms = 1;
         for (size_t row = 0; row < (size_t)16 * B; ++row) { ns[row] = quality_row_weights(&T.qual[row * 94], &sym[row * 94], &w[row * 94]); max_syms = std::max(max_syms, ns[row]); }
         T.qual_k = max_syms <= 16 ? 16 : max_syms <= 64 ? 64 : 128;
-        if (const char* f = getenv("SCS_TEST_QK")) T.qual_k = std::max(T.qual_k, atoi(f) >= 128 ? 128 : atoi(f) >= 64 ? 64 : 16);   // tests: more columns than needed (no shipped model needs the 128-column kernels; the oracle reads the same variable)
+        if (const char* f = seam_env("SCS_TEST_QK")) T.qual_k = std::max(T.qual_k, atoi(f) >= 128 ? 128 : atoi(f) >= 64 ? 64 : 16);   // tests: more columns than needed (no shipped model needs the 128-column kernels; the oracle reads the same variable)
         const size_t RW = (size_t)T.qual_k + T.qual_k / 4;
         T.qual_alias.assign((size_t)16 * B * RW, 0u);
         for (size_t row = 0; row < (size_t)16 * B; ++row) quality_alias_row(&sym[row * 94], &w[row * 94], ns[row], T.qual_k, &T.qual_alias[row * RW]);
@@ -300,12 +301,20 @@ void encode_record(const char* name, const char* seq, uint64_t len, FastaRecord&
 #include <unistd.h>
 namespace scs {
 std::string fasta_index_name(const std::string& header_text) { return index_name(header_text); }
+// a path as ONE word of a /bin/sh command line: single-quoted, embedded single quotes closed, escaped and reopened
+static std::string sh_quote(const std::string& p) {
+    std::string q = "'";
+    for (char ch : p) { if (ch == '\'') q += "'\\''"; else q += ch; }
+    return q + "'";
+}
+// "<name>.gz" is inflated beside itself with `gzip -cd`, as the reference does (Genome.cpp:183-187: the same command through
+// system(), there with the path unquoted -- a name with a blank or a shell character is a word of its own here)
 std::string fasta_plain_path(const std::string& path_in) {
     std::string path = path_in;
     if (path.empty()) throw std::runtime_error("reference sequence file not specified!");
-    if (path.size() > 3 && path.compare(path.size() - 3, 3, ".gz") == 0) {      // Genome.cpp:183-187
+    if (path.size() > 3 && path.compare(path.size() - 3, 3, ".gz") == 0) {
         const std::string plain = path.substr(0, path.size() - 3);
-        const std::string cmd = "gzip -cd " + path + " > " + plain;
+        const std::string cmd = "gzip -cd " + sh_quote(path) + " > " + sh_quote(plain);
         if (system(cmd.c_str()) != 0) throw std::runtime_error("could not inflate " + path);
         path = plain;
     }
@@ -335,14 +344,7 @@ void fasta_write_fai(const std::string& path, const char* base, size_t size, con
     fclose(fai);
 }
 void load_fasta(const std::string& path_in, std::vector<FastaRecord>& out, bool make_index) {
-    std::string path = path_in;
-    if (path.empty()) throw std::runtime_error("reference sequence file not specified!");
-    if (path.size() > 3 && path.compare(path.size() - 3, 3, ".gz") == 0) {      // Genome.cpp:183-187
-        const std::string plain = path.substr(0, path.size() - 3);
-        const std::string cmd = "gzip -cd " + path + " > " + plain;
-        if (system(cmd.c_str()) != 0) throw std::runtime_error("could not inflate " + path);
-        path = plain;
-    }
+    const std::string path = fasta_plain_path(path_in);                          // ".gz": inflated first (Genome.cpp:183-187)
     const int fd = open(path.c_str(), O_RDONLY);
     if (fd < 0) throw std::runtime_error("could not open " + path);
     struct stat st;

@@ -10,6 +10,16 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 sys.path.insert(0, ROOT)
 
 
+SEAMS_LIB = os.path.join(ROOT, "scssim_amd", "libscssim_hip_seams.so")
+SEAMS_CLI = os.path.join(ROOT, "scssim_amd", "bin", "scssim_seams")
+
+
+def seams_env(base=None, **knobs):
+    """Environment of a child process that needs a test seam (scssim_amd/csrc/scs_seams.h: small batches, forced kernel variants,
+    injected failures): the knobs + SCSSIM_HIP_LIB = the seams build of the library.  The product library reads none of them."""
+    return dict(base if base is not None else os.environ, SCSSIM_HIP_LIB=SEAMS_LIB, **knobs)
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

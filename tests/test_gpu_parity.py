@@ -7,7 +7,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from conftest import ROOT
+from conftest import ROOT, seams_env
 
 import scssim_amd
 
@@ -327,6 +327,27 @@ def test_primer_exhaustion_sharded_equals_whole_job(world, hooks, oracle_bin, mo
     scssim_amd.merge_fastq_shards(str(tmp_path / "shard"), world, paired=True)
     for suffix in ("_1.fq", "_2.fq"):
         assert open(str(tmp_path / "shard") + suffix, "rb").read() == open(whole + suffix, "rb").read(), "sharded GPU job differs from the whole job (%s)" % suffix
+
+
+def test_gz_input_matches_oracle(oracle_bin, models, golden_inputs, tmp_path):
+    """`-i simu.fa.gz` (Genome::loadRefSeq, lib/genome/Genome.cpp:183-187: inflated with gzip -cd beside itself), from a directory
+    whose name needs quoting, through the library and through the CLI."""
+    import gzip
+    d = tmp_path / "in put's"
+    d.mkdir()
+    gz = str(d / "simu.fa.gz")
+    with open(golden_inputs["g1_hiseq2500_pe"], "rb") as f, gzip.open(gz, "wb") as g:
+        g.write(f.read())
+    prefix = str(tmp_path / "orc")
+    _oracle_run(oracle_bin, golden_inputs["g1_hiseq2500_pe"], models["Illumina_HiSeq2500"], prefix, ["-c", "2"], 19)
+    w1, w2 = open(prefix + "_1.fq", "rb").read(), open(prefix + "_2.fq", "rb").read()
+    g = scssim_amd.GenReads(profile=models["Illumina_HiSeq2500"], input_fasta=gz, coverage=2.0, seed=19)
+    assert g.run() == (w1, w2)
+    os.remove(gz[:-3]); os.remove(gz[:-3] + ".fai")
+    out = str(tmp_path / "cli")
+    r = subprocess.run([os.path.join(ROOT, "scssim_amd", "bin", "scssim"), "genreads", "-i", gz, "-m", models["Illumina_HiSeq2500"], "-c", "2", "-o", out, "--seed", "19"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert open(out + "_1.fq", "rb").read() == w1 and open(out + "_2.fq", "rb").read() == w2
 
 
 def test_device_hooks_over_rccl_single_rank(models, golden_inputs, oracle_bin, tmp_path):
@@ -741,7 +762,7 @@ def test_replayed_indel_reads_match_oracle(models, tmp_path):
     """A read whose indel events do not fit the 16-bit LDS slots is 'replayed' (phase 2 re-draws stream A).  The fallback is
     rare in production, so the same parity checks run once more in a child process with SCS_EV_REPLAY=1, which sends every
     read with an indel through it."""
-    env = dict(os.environ, SCS_EV_REPLAY="1")
+    env = seams_env(SCS_EV_REPLAY="1")
     sel = ["tests/test_gpu_parity.py::test_predict_batch_matches_oracle", "tests/test_gpu_parity.py::test_full_pipeline_fastq_bit_exact"]
     if os.environ.get("SCS_EV_REPLAY"):
         pytest.skip("already inside the replay run")
@@ -757,7 +778,7 @@ def test_wider_alias_rows_match_oracle(qk, models, tmp_path):
     columns, so the wider instantiations run the same parity checks (child processes: the tables are built once per process)."""
     if os.environ.get("SCS_TEST_QK"):
         pytest.skip("already inside the wide-row run")
-    env = dict(os.environ, SCS_TEST_QK=qk)
+    env = seams_env(SCS_TEST_QK=qk)
     sel = ["tests/test_gpu_parity.py::test_full_pipeline_fastq_bit_exact", "tests/test_gpu_parity.py::test_predict_batch_matches_oracle"]
     r = subprocess.run(["python", "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider"] + sel, cwd=ROOT, env=env,
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
@@ -827,7 +848,7 @@ def test_many_small_batches_match_oracle(models, tmp_path):
     more in a child process with 4096-pair batches (SCS_TEST_BATCH_SHIFT=12): dozens of batches, ragged last one."""
     if os.environ.get("SCS_TEST_BATCH_SHIFT"):
         pytest.skip("already inside the small-batch run")
-    env = dict(os.environ, SCS_TEST_BATCH_SHIFT="12")
+    env = seams_env(SCS_TEST_BATCH_SHIFT="12")
     sel = ["tests/test_gpu_parity.py::test_full_pipeline_fastq_bit_exact", "tests/test_gpu_parity.py::test_medium_genome_bit_exact",
            "tests/test_gpu_parity.py::test_very_long_reads_take_the_general_variant", "tests/test_gpu_parity.py::test_device_resident_output_matches_oracle",
            "tests/test_gpu_parity.py::test_insert_size_give_up_path_bit_exact"]
@@ -848,7 +869,7 @@ def test_read_class_fallbacks_match_oracle(knob, models, tmp_path):
     processes (the knobs are read once per process)."""
     if os.environ.get(knob):
         pytest.skip("already inside the %s run" % knob)
-    env = dict(os.environ, **{knob: "1"})
+    env = seams_env(**{knob: "1"})
     sel = ["tests/test_gpu_parity.py::test_full_pipeline_fastq_bit_exact", "tests/test_gpu_parity.py::test_medium_genome_bit_exact"]
     r = subprocess.run(["python", "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider"] + sel, cwd=ROOT, env=env,
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
@@ -874,7 +895,7 @@ def test_mapped_buffers_parity(models, tmp_path):
     0 MB: every growable buffer is a mapped one."""
     if os.environ.get("SCS_VMM_FROM_MB"):
         pytest.skip("already inside the mapped-buffer run")
-    env = dict(os.environ, SCS_VMM_FROM_MB="0")
+    env = seams_env(SCS_VMM_FROM_MB="0")
     sel = ["tests/test_gpu_parity.py::test_full_pipeline_fastq_bit_exact", "tests/test_gpu_parity.py::test_medium_genome_bit_exact",
            "tests/test_gpu_parity.py::test_degenerate_inputs_match_oracle"]
     r = subprocess.run(["python", "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider"] + sel, cwd=ROOT, env=env,
@@ -986,7 +1007,7 @@ except scssim_amd.ScsError as e:
     assert e.code == 4 and "internal" in str(e), str(e)
     print("GUARDED")
 ''' % (ROOT, models["Illumina_HiSeq2500"], golden_inputs["g1_hiseq2500_pe"])
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SCS_TEST_SHRINK_OUT="1"), capture_output=True, text=True, timeout=300)
+    r = subprocess.run([sys.executable, "-c", code], env=seams_env(SCS_TEST_SHRINK_OUT="1"), capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "GUARDED" in r.stdout, r.stdout + r.stderr
 
 

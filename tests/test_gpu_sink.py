@@ -6,7 +6,7 @@ import sys
 
 import pytest
 
-from conftest import ROOT
+from conftest import ROOT, SEAMS_CLI, seams_env
 
 import scssim_amd
 
@@ -51,7 +51,7 @@ def test_part_files_concatenate_to_the_oracle_files(case, layout, shift, ks, ora
     _oracle(oracle_bin, fa, prof, prefix, ["-c", "%g" % cov, "-l", layout], seed, threads=min(32, os.cpu_count() or 1))
     out = str(tmp_path / "gpu")
     code = _CHILD % dict(root=ROOT, prof=prof, fa=fa, cov=cov, layout=layout, seed=seed, ks=tuple(ks), out=out)
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SCS_TEST_BATCH_SHIFT=shift), capture_output=True, text=True, timeout=900)
+    r = subprocess.run([sys.executable, "-c", code], env=seams_env(SCS_TEST_BATCH_SHIFT=shift), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout + r.stderr
     paired = layout == "PE"
     want = [open(prefix + s, "rb").read() for s in (("_1.fq", "_2.fq") if paired else (".fq",))]
@@ -83,7 +83,7 @@ def test_sharded_job_written_in_parts_merges_to_the_whole_job(oracle_bin, models
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = str(s.getsockname()[1]); s.close()
     procs = []
     for r in range(world):
-        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=port, LOCAL_RANK="0", SCS_TEST_BATCH_SHIFT="9")
+        env = seams_env(RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=port, LOCAL_RANK="0", SCS_TEST_BATCH_SHIFT="9")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_gpu_worker.py"), golden_inputs[case], models[model],
                                        str(tmp_path / "shard"), cov, "PE", seed, "device", "3"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = [p.communicate(timeout=600)[0] for p in procs]
@@ -117,7 +117,7 @@ def test_failing_sink_aborts_the_job_and_the_ctx_stays_usable(models, golden_inp
 
 def _cli(args, env=None, timeout=300):
     import signal
-    exe = os.path.join(ROOT, "scssim_amd", "bin", "scssim")
+    exe = SEAMS_CLI if env else os.path.join(ROOT, "scssim_amd", "bin", "scssim")   # a test seam in the environment: the seams build of the CLI (scs_seams.h)
     p = subprocess.Popen([exe, "genreads"] + args, env=dict(os.environ, **(env or {})), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
     try:
         _, err = p.communicate(timeout=timeout)
@@ -211,7 +211,7 @@ for K, G in %%s:
     print("RATIO", K, G, sum(st["fastq_bytes"]) / sum(st["sink_bytes"]))
 ''' % (ROOT, prof, fa, str(tmp_path / "z"))
     for shift, combos in ((None, [(1, 1), (3, 1)]), ("13", [(1, 1), (2, 3), (5, 1)])):
-        env = dict(os.environ) if shift is None else dict(os.environ, SCS_TEST_BATCH_SHIFT=shift)
+        env = dict(os.environ) if shift is None else seams_env(SCS_TEST_BATCH_SHIFT=shift)
         r = subprocess.run([sys.executable, "-c", code % repr(combos)], env=env, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stdout + r.stderr
         ratios = [float(l.split()[3]) for l in r.stdout.splitlines() if l.startswith("RATIO")]
@@ -268,7 +268,7 @@ g.yield_reads_files(%r, 2, 4)
             time.sleep(0.002)
     th = threading.Thread(target=watch); th.start()
     try:
-        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SCS_TEST_BATCH_SHIFT="10"), capture_output=True, text=True, timeout=600)
+        r = subprocess.run([sys.executable, "-c", code], env=seams_env(SCS_TEST_BATCH_SHIFT="10"), capture_output=True, text=True, timeout=600)
     finally:
         stop[0] = True; th.join()
     assert r.returncode == 0, r.stdout + r.stderr
@@ -309,7 +309,7 @@ def test_sharded_ranks_stage_only_their_own_stretch_of_the_genome(layout, oracle
         s = socket.socket(); s.bind(("127.0.0.1", 0)); port = str(s.getsockname()[1]); s.close()
         procs = []
         for r in range(3):
-            env = dict(os.environ, RANK=str(r), WORLD_SIZE="3", MASTER_ADDR="127.0.0.1", MASTER_PORT=port, LOCAL_RANK="0", **env_extra)
+            env = (seams_env if env_extra else dict)(os.environ, RANK=str(r), WORLD_SIZE="3", MASTER_ADDR="127.0.0.1", MASTER_PORT=port, LOCAL_RANK="0", **env_extra)
             procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_gpu_worker.py"), fa, prof, str(tmp_path / tag), "3", "PE", "91", "device"],
                                           env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
         outs = [p.communicate(timeout=600)[0] for p in procs]

@@ -6,7 +6,7 @@ import re
 import numpy as np
 import pytest
 
-from conftest import ROOT
+from conftest import ROOT, SEAMS_CLI, SEAMS_LIB
 
 import scssim_amd
 
@@ -243,7 +243,7 @@ def test_cli_sharded_job_fails_fast_when_its_ranks_cannot_start(golden_inputs, m
     exe = os.path.join(ROOT, "scssim_amd", "bin", "scssim")
     for extra, env in (([], {}), (["--host-collectives", "--one-device"], {"SCS_TEST_FAIL_AT": "start", "SCS_TEST_FAIL_RANK": "2"})):
         t0 = time.time()
-        p = subprocess.Popen([exe, "genreads", "-i", golden_inputs["g1_hiseq2500_pe"], "-m", models["Illumina_HiSeq2500"], "-o", str(tmp_path / "o"), "--gpus", "3", "--seed", "1"] + extra,
+        p = subprocess.Popen([SEAMS_CLI if env else exe, "genreads", "-i", golden_inputs["g1_hiseq2500_pe"], "-m", models["Illumina_HiSeq2500"], "-o", str(tmp_path / "o"), "--gpus", "3", "--seed", "1"] + extra,
                              env=dict(os.environ, **env), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
         try:
             _, err = p.communicate(timeout=120)
@@ -405,3 +405,54 @@ def test_two_word_stream_step_is_sound():
     lim = 5.0 / np.sqrt(n)
     assert abs(corr(A, Bn)) < lim
     assert abs(corr(Bn[:-1], A[1:])) < lim and abs(corr(A[:-1], Bn[1:])) < lim and abs(corr(Bn[:-1], Bn[1:])) < lim
+
+
+def test_the_product_library_reads_no_test_seam():
+    """The knobs the tests turn (scssim_amd/csrc/scs_seams.h) exist in libscssim_hip_seams.so only: with every one of them set in the
+    environment the product library still answers "unset" -- its seam_env is a function that returns NULL, no getenv behind it --
+    while the seams build hands the values through.  Both builds export the same C ABI."""
+    import subprocess
+    import sys
+    knobs = re.findall(r"SCS_[A-Z0-9_]+", open(os.path.join(ROOT, "scssim_amd", "csrc", "scs_seams.h")).read().split("#pragma once")[0])
+    knobs = sorted(set(k for k in knobs if k not in ("SCS_HD",)))
+    assert "SCS_TEST_BATCH_SHIFT" in knobs and "SCS_TEST_QK" in knobs and len(knobs) >= 12
+    code = """
+import ctypes, sys
+L = ctypes.CDLL(sys.argv[1]); L.scs_test_seam.restype = ctypes.c_char_p; L.scs_test_seam.argtypes = [ctypes.c_char_p]
+print(",".join("%s=%s" % (k, (L.scs_test_seam(k.encode()) or b"<unset>").decode()) for k in sys.argv[2:]))
+"""
+    env = dict(os.environ, **{k: "7" for k in knobs})
+    out = {}
+    for name, lib in (("product", scssim_amd.lib_path() if not os.environ.get("SCSSIM_HIP_LIB") else os.path.join(ROOT, "scssim_amd", "libscssim_hip.so")), ("seams", SEAMS_LIB)):
+        r = subprocess.run([sys.executable, "-c", code, lib] + knobs, env=env, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        out[name] = dict(kv.split("=") for kv in r.stdout.strip().split(","))
+    assert all(v == "<unset>" for v in out["product"].values()), out["product"]
+    assert all(v == "7" for v in out["seams"].values()), out["seams"]
+    nm = lambda lib: set(l.split()[-1] for l in subprocess.run(["nm", "-D", "--defined-only", lib], capture_output=True, text=True).stdout.splitlines() if " T " in l and "scs_" in l)
+    assert nm(SEAMS_LIB) == nm(os.path.join(ROOT, "scssim_amd", "libscssim_hip.so")) and "scs_test_seam" in nm(SEAMS_LIB)
+    # and no getenv of a seam is left in the library's sources outside scs_seams_on.cpp
+    for fn in os.listdir(os.path.join(ROOT, "scssim_amd", "csrc")):
+        if fn.endswith((".cpp", ".hip", ".h")) and fn != "scs_seams_on.cpp":
+            src = open(os.path.join(ROOT, "scssim_amd", "csrc", fn)).read()
+            assert not re.search(r'(?<![_a-z])getenv\("SCS_(TEST|READS|ERRS|ATTACH|VMM|NO_VMM|HOST_FASTA|STAGE|EV_)', src), fn
+
+
+def test_gz_input_is_inflated_beside_itself_whatever_its_name(golden_inputs, tmp_path):
+    """Genome::loadRefSeq inflates "<name>.gz" with `gzip -cd <name>.gz > <name>` through system() (lib/genome/Genome.cpp:183-187).
+    Same behaviour here, with the path as ONE shell word: a directory with a blank and a quote in its name works (and runs nothing)."""
+    import gzip
+    import shutil
+    d = tmp_path / "my dir; it's $(touch pwned)"
+    d.mkdir()
+    plain = str(d / "simu.fa")
+    shutil.copy(golden_inputs["g2_xten_pe_nblock"], plain)
+    want = scssim_amd.fasta_probe(plain)
+    os.remove(plain); os.remove(plain + ".fai") if os.path.exists(plain + ".fai") else None
+    with open(golden_inputs["g2_xten_pe_nblock"], "rb") as f, gzip.open(plain + ".gz", "wb") as g:
+        g.write(f.read())
+    got = scssim_amd.fasta_probe(plain + ".gz")
+    assert got == want and os.path.exists(plain), "the plain file is left beside the .gz, as the reference leaves it"
+    assert not os.path.exists("pwned") and not (tmp_path / "pwned").exists()
+    with pytest.raises(Exception):
+        scssim_amd.fasta_probe(str(d / "absent.fa.gz"))
