@@ -8,11 +8,16 @@
 //             libstdc++ normal_distribution over minstd_rand0) -> byte-identical
 //             FASTQ to the compiled reference at -t 1 under oracle/seedshim.cpp.
 //   counter : Philox4x32-10 keyed by logical ids (DESIGN.md "RNG remapping").
-// Apart from where a draw comes from, the two modes differ only in the three
-// places marked [REMAP] below (primer-pool snapshot per pass, chunked weight
-// sum, GC-factor normal sampler, software log in the Poisson sampler, binomial
-// count + positions for the amplification errors) -- each is order-free /
-// libm-free so that any thread / GPU schedule gives the same bytes.
+// Apart from where a draw comes from, the two modes differ only in the places marked [REMAP] below -- eight, DESIGN.md
+// section 4 numbers them: (2) amplification errors as a binomial count + distinct positions, (3) the Poisson sampler's
+// software logarithm / product form, (4) the GC factor's normal sampler, (5) fixed-SHAPE sums and scans of the read
+// allocation, (6) attach tries by geometric skip + a uniform draw over the feasible pairs, (7) a read's two xoshiro
+// streams with one two-word step per output position, (8) indel events by geometric gaps, (9) quality symbols by the
+// alias method.  Each is order-free / libm-free, so that any thread, shard or GPU schedule gives the same bytes, and is
+// pinned statistically against the reference streams by tests/test_oracle_stats.py.  The primer stock is NOT among
+// them: counter mode hands a primer type out exactly as the reference's live decrement does at -t 1 (amplify_pass).
+// --rng ref is never touched by such changes: it reproduces the compiled reference's FASTQ byte for byte
+// (tests/test_oracle_golden.py).
 #include "scs_oracle.h"
 
 #include <algorithm>
