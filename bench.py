@@ -155,6 +155,22 @@ def cpu_baseline(td, prof, names, seqs, sample_desc, coverage):
         for suf in (".ref_1.fq", ".ref_2.fq"):
             if os.path.exists(fa + suf):
                 os.remove(fa + suf)
+        noaff = os.path.join(ROOT, "oracle", "_ref", "libnoaffinity.so")
+        if out and os.path.exists(noaff):                            # the same run with the workers NOT pinned to CPUs 0..t-1 (oracle/noaffinity.cpp)
+            t0 = time.perf_counter()
+            r = subprocess.run([ref, "genreads", "-i", fa, "-m", prof, "-c", "%g" % coverage, "-t", str(cores), "-o", fa + ".ref"], capture_output=True, text=True,
+                               env=dict(os.environ, LD_PRELOAD=noaff))
+            secs = time.perf_counter() - t0
+            if r.returncode == 0 and os.path.exists(fa + ".ref_1.fq"):
+                pairs = sum(1 for _ in open(fa + ".ref_1.fq", "rb")) // 4
+                out["unpinned"] = dict(value=pairs / secs, unit="pairs/s", cores=cores,
+                                       sample="the same run with pthread_setaffinity_np made a no-op (LD_PRELOAD oracle/_ref/libnoaffinity.so): %d pairs in %.1f s" % (pairs, secs))
+            for suf in (".ref_1.fq", ".ref_2.fq"):
+                if os.path.exists(fa + suf):
+                    os.remove(fa + suf)
+        if out:
+            # what the same binary did in the survey container (Xeon 2.1 GHz, 8 vCPU, 1 Mb, HiSeq2500 125 bp, 30x)
+            out["baseline_md_container"] = {"t1_pairs_per_s": 5200, "t8_pairs_per_s": 27900, "what": "BASELINE.md section 2: 1 Mb diploid, HiSeq2500 (125 bp) PE 30x, -t 1 / -t 8 on 8 vCPU"}
         if out:                                                     # -t 1 beside -t cores, on the sample's first quarter (the rate per core)
             n1 = max(100000, len(seqs[0]) // 16)
             fa1 = os.path.join(td, "cpu_sample_t1.fa")
@@ -261,9 +277,10 @@ class Cleaner:
     `limit` bytes are still queued: the next step's sink starts behind it, INSIDE the timed region -- lets all `burst` of them
     work, the writers being idle then."""
 
-    def __init__(self, threads=4, burst=16):
+    def __init__(self, threads=4, burst=16, cpus=None):
         import queue
         import threading
+        self.cpus = set(cpus) if cpus else None                      # the GPU's NUMA node: freeing a page from the node it lies on
         self.q = queue.Queue()
         self.lock = threading.Lock()
         self.cv = threading.Condition(self.lock)
@@ -277,6 +294,11 @@ class Cleaner:
             t.start()
 
     def _run(self):
+        if self.cpus:
+            try:
+                os.sched_setaffinity(0, self.cpus)                   # (the calling thread)
+            except OSError:
+                pass
         while True:
             p = self.q.get()
             if p is None:
@@ -537,11 +559,22 @@ def main():
                 coll_path = "torch.distributed RCCL group on the library's HBM buffers (device hooks), %d ranks" % dist.get_world_size()
 
     cores = host_cores()
-    writers = a.writers or max(1, min(12, cores // max(1, world if world > 1 and not cpu_coll else 1) - 4))
+    # N ranks on one node share its cores: every rank's sink gets cores / N of them (12 writers + 6 cleaners on the 16 cores a one-GPU box
+    # has is the measured best, profiles/r03_sink_tune_writers_cleaners.log), on the CPUs of its own GPU's NUMA node (the library binds
+    # its writer threads and pinned slots there itself; the cleaners here, and this rank's main thread when the node has several GPUs)
+    share = cores // max(1, world if world > 1 and not cpu_coll else 1)
+    writers = a.writers or max(1, min(12, share - 4))
+    n_clean = max(1, a.cleaners if world == 1 else min(a.cleaners, max(2, share // 4)))
+    local_cpus = scssim_amd.gpu_local_cpus(local)
+    if world > 1 and local_cpus and not cpu_coll:
+        try:
+            os.sched_setaffinity(0, set(local_cpus))
+        except OSError:
+            pass
     out_dir = a.out_dir or tempfile.mkdtemp(prefix="scsbench_out_", dir=shm)
     os.makedirs(out_dir, exist_ok=True)
     generations = a.generations
-    cleaner = Cleaner(threads=max(1, a.cleaners), burst=max(cores, a.cleaners))
+    cleaner = Cleaner(threads=n_clean, burst=max(share, n_clean), cpus=local_cpus)
     GATE_BYTES = (40 << 30) // max(1, world)                                            # a step's sink starts when at most this much of the older steps' text is still on tmpfs
 
     def acc(ktimes, kt, names_):
@@ -598,16 +631,24 @@ def main():
         if world > 1:
             dist.barrier()
         elapsed = time.perf_counter() - t0
+        per_rank = None
         if world > 1:
             t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t[0])
             pt = torch.tensor([pairs, fqb, amps], dtype=torch.int64, device=cdev)
             dist.all_reduce(pt)
+            # every rank's own stage times and bytes: the curve over N separates what the GPUs do (amplify, allocate, reads into HBM) from
+            # what the host does (the sink: bytes / reads-stage seconds per rank)
+            mine = torch.tensor([stage.get(k, 0.0) / n_steps for k in ("amplify", "allocate", "reads", "wait_for_cleanup")] + [fqb / n_steps, pairs / n_steps], dtype=torch.float64, device=cdev)
+            allr = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(allr, mine)
+            per_rank = [dict(rank=r, amplify_s=float(v[0]), allocate_s=float(v[1]), reads_s=float(v[2]), wait_for_cleanup_s=float(v[3]), fastq_GB=float(v[4]) / 1e9,
+                             pairs=int(v[5]), sink_GBps=(float(v[4]) / 1e9 / max(1e-9, float(v[2]))) if mode != "null" else None) for r, v in enumerate(allr)]
             pairs, fqb_all, amps = int(pt[0]), int(pt[1]), int(pt[2])
         else:
             fqb_all = fqb
-        return dict(elapsed=elapsed, pairs=pairs, fq_bytes_local=fqb, fq_bytes=fqb_all, amps=amps, ktimes=kt, stage={k: v / n_steps for k, v in stage.items()})
+        return dict(elapsed=elapsed, pairs=pairs, fq_bytes_local=fqb, fq_bytes=fqb_all, amps=amps, ktimes=kt, stage={k: v / n_steps for k, v in stage.items()}, per_rank=per_rank)
 
     main_mode = "null" if a.hbm_only else "files"
     R = timed(a.warmup, a.steps, main_mode, 0)
@@ -637,8 +678,9 @@ def main():
                                   "are left (`wait_for_cleanup` in stages_s_per_step): all of it inside the timed region"
                                   % (out_dir, writers * generations, " and rank" if world > 1 else "", writers, generations, max(1, a.cleaners))),
                        "sink_GBps": None if a.hbm_only else R["fq_bytes"] / max(1e-9, R["stage"]["reads"] * a.steps) / 1e9,
-                       "host_cores": cores},
+                       "host_cores": cores, "sink_threads_per_rank": {"writers": writers, "cleaners": n_clean, "bound_to_gpu_numa_node_cpus": len(local_cpus) or None}},
             "stages_s_per_step": R["stage"],
+            "per_rank": R["per_rank"],
             "kernels_ms_per_step": {k: v["ms"] / a.steps for k, v in R["ktimes"].items()},
             "setup_s": {"genome_generated_in_hbm": t_gen, "genome_staged_(encode+bit_index)": t_up},
             "lane_utilisation": committed_lane_table(),
@@ -648,6 +690,7 @@ def main():
             out["generation_hbm"] = {"value": H["pairs"] / H["elapsed"], "unit": "pairs/s", "steps": 5, "ms_per_step": 1e3 * H["elapsed"] / 5, "stages_s_per_step": H["stage"],
                                      "kernels_ms_per_step": {k: v["ms"] / 5 for k, v in H["ktimes"].items()},
                                      "what": "the same job, FASTQ text generated batch by batch into HBM buffers and counted (NULL sink): no PCIe, no files",
+                                     "per_rank": H["per_rank"],
                                      # whole job against HBM: the implementation's compulsory bytes (68 B per amplicon, 56 B pair record written + read,
                                      # 40 B events, 261 B template + FASTQ per pair); SURVEY 8(d)'s model (1526 B per amplicon) beside it
                                      "whole_job_GBps": {"compulsory": (68.0 * H["amps"] + (261.0 + 152.0) * H["pairs"] + H["fq_bytes"]) / H["elapsed"] / 1e9,

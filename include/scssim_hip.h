@@ -232,6 +232,10 @@ int         scs_download_read_numbers(scs_ctx* ctx, uint32_t* read_numbers);
 /* The primer pool after scs_amplify: stock[65536], copies left of every primer type (PrimerIndex.count, lib/malbac/Malbac.h:18-24;
  * index = the 8-mer at two bits per base, first base in the top bits). */
 int         scs_download_primer_stock(scs_ctx* ctx, int64_t* stock);
+/* The CPUs of the NUMA node `device` hangs on that this process may run on (cpus[0..cap), returns their number; 0: unknown, or the
+ * whole affinity mask is local).  The library's sink threads and pinned buffers bind themselves to them; a caller with host threads of
+ * its own around the sink (bench.py's cleaners) can do the same. */
+int         scs_gpu_local_cpus(int device, int* cpus, int cap);
 /* Test seams (csrc/scs_seams.h: small batches, forced kernel variants, injected failures) exist only in libscssim_hip_seams.so, the
  * build the tests load; there this returns the seam's value.  In libscssim_hip.so it returns NULL for every name: the product reads
  * no such knob. */

@@ -124,6 +124,14 @@ def part_paths(base, parts, paired=True, suffix=".fq"):
     return [[base + ".p%02d" % k + m + suffix for k in range(parts)] for m in mates]
 
 
+def gpu_local_cpus(device=0):
+    """CPUs of the NUMA node the GPU hangs on, within this process's affinity mask ([]: unknown or no choice)."""
+    L = load_library()
+    buf = (C.c_int * 4096)()
+    n = L.scs_gpu_local_cpus(int(device), buf, 4096)
+    return [buf[i] for i in range(min(n, 4096))]
+
+
 def text_checksum(data):
     """The library's batch checksum (scs_set_batch_checksums) of a bytes-like object, in numpy: the text as little-endian 64-bit
     words w_i (the last zero-padded), sum_i fmix64(w_i + (i + 1) * 0x9E3779B97F4A7C15) mod 2^64."""

@@ -2,6 +2,8 @@
 // One scs_ctx = one HIP device + one stream; all amplicon state lives in HBM as flat SoA arrays.
 // Reference call sequence reproduced: src/scssim.cpp:46-67 (genreads branch of main()).
 #include "../../include/scssim_hip.h"
+#include <sched.h>
+#include <pthread.h>
 #include "scs_device.h"
 #include "scs_seams.h"
 #include "scs_tables.h"
@@ -1021,7 +1023,40 @@ void do_allocate(scs_ctx* c, uint64_t reads) {
 // waits for the copy's event, writes, and frees the slot -- while the GPU already produces the next batches.  writers + 2
 // slots: every writer can hold one while one is being filled and one crosses PCIe.  (regions = writers x generations: writer w
 // serves the regions r = w mod writers, one after the other.)
+// ---- where the sink's host work runs.  A GPU hangs on one NUMA node of the host; a copy into pinned memory of the OTHER node runs at
+// half the rate (profiles/r03_numa_probe.log: 29 against 57 GB/s), and on a node with several GPUs every rank's writers should stay
+// on their own GPU's node.  gpu_local_cpus: the CPUs of the ctx device's node that this process may run on (empty: unknown, or no
+// choice to make); NumaScope binds the calling thread to them for its lifetime (pinned allocations: first touch).
+static std::vector<int> gpu_local_cpus(int device) {
+    std::vector<int> out; char bdf[64] = {0};
+    if (hipDeviceGetPCIBusId(bdf, (int)sizeof bdf, device) != hipSuccess) return out;
+    for (char* q = bdf; *q; ++q) *q = (char)tolower(*q);
+    int node = -1;
+    { FILE* f = fopen((std::string("/sys/bus/pci/devices/") + bdf + "/numa_node").c_str(), "r"); if (!f) return out; if (fscanf(f, "%d", &node) != 1) node = -1; fclose(f); }
+    if (node < 0) return out;
+    char list[4096] = {0};
+    { FILE* f = fopen(("/sys/devices/system/node/node" + std::to_string(node) + "/cpulist").c_str(), "r"); if (!f) return out; if (!fgets(list, sizeof list, f)) list[0] = 0; fclose(f); }
+    cpu_set_t allowed; CPU_ZERO(&allowed);
+    if (sched_getaffinity(0, sizeof allowed, &allowed) != 0) return out;
+    for (char* tok = strtok(list, ",\n"); tok; tok = strtok(nullptr, ",\n")) {
+        int a = 0, b = 0; const int k = sscanf(tok, "%d-%d", &a, &b); if (k < 1) continue; if (k == 1) b = a;
+        for (int c = a; c <= b && c < CPU_SETSIZE; ++c) if (CPU_ISSET(c, &allowed)) out.push_back(c);
+    }
+    if ((int)out.size() == CPU_COUNT(&allowed)) out.clear();                       // the whole mask is local already
+    return out;
+}
+struct NumaScope {
+    cpu_set_t old; bool on = false;
+    explicit NumaScope(const std::vector<int>& cpus) {
+        if (cpus.empty() || pthread_getaffinity_np(pthread_self(), sizeof old, &old) != 0) return;
+        cpu_set_t s; CPU_ZERO(&s); for (int c : cpus) CPU_SET(c, &s);
+        on = pthread_setaffinity_np(pthread_self(), sizeof s, &s) == 0;
+    }
+    ~NumaScope() { if (on) (void)pthread_setaffinity_np(pthread_self(), sizeof old, &old); }
+};
+
 struct SinkPipe {
+    std::vector<int> local_cpus;                                                   // of the device's NUMA node (gpu_local_cpus)
     struct Slot { char* h[2] = {nullptr, nullptr}; size_t cap[2] = {0, 0}; hipEvent_t ev = nullptr; bool busy = false; };
     struct Job { int slot, region; size_t n1, n2; };
     struct Writer { std::thread th; std::vector<Job> q; };
@@ -1030,6 +1065,7 @@ struct SinkPipe {
     BatchSink* sink = nullptr; bool paired = true; int device = 0;
     void start(BatchSink* f, bool pe, int dev) {
         sink = f; paired = pe; device = dev; done = failed = false;
+        local_cpus = gpu_local_cpus(dev);
         const size_t nw = (size_t)std::max(1, f->writers), want = nw + 2;
         // (blocking events: a writer that waits for its batch's copy sleeps instead of spinning -- the host's cores are the sink's bottleneck)
         while (slots.size() < want) { Slot sl; HIP_OK(hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming | hipEventBlockingSync)); slots.push_back(sl); }
@@ -1037,6 +1073,7 @@ struct SinkPipe {
         writers = std::vector<Writer>(nw);
         for (size_t w = 0; w < writers.size(); ++w) writers[w].th = std::thread([this, w] {
             (void)hipSetDevice(device);
+            if (!local_cpus.empty()) { cpu_set_t cs; CPU_ZERO(&cs); for (int c : local_cpus) CPU_SET(c, &cs); (void)pthread_setaffinity_np(pthread_self(), sizeof cs, &cs); }   // a writer stays on its GPU's node
             Writer& W = writers[w];
             for (;;) {
                 Job j;
@@ -1063,6 +1100,7 @@ struct SinkPipe {
                 if (sl.h[f]) HIP_OK(hipHostFree(sl.h[f]));
                 sl.h[f] = nullptr; sl.cap[f] = 0;
                 const size_t nc = std::max<size_t>(need + need / 8, 1 << 20);
+                NumaScope here(local_cpus);                                        // the slot's pages on the GPU's node
                 HIP_OK(hipHostMalloc((void**)&sl.h[f], nc, hipHostMallocDefault)); sl.cap[f] = nc;
             }
         }
@@ -1672,6 +1710,9 @@ int scs_download_amplicons(scs_ctx* c, int kind, uint32_t* parent, uint32_t* spo
             if (errs) memcpy(errs + 4 * (size_t)i, e4, 16); if (nerr) nerr[i] = cnt;
         }
     });
+}
+int scs_gpu_local_cpus(int device, int* cpus, int cap) {
+    try { const std::vector<int> v = gpu_local_cpus(device); for (int i = 0; i < (int)v.size() && i < cap && cpus; ++i) cpus[i] = v[(size_t)i]; return (int)v.size(); } catch (...) { return 0; }
 }
 const char* scs_test_seam(const char* name) { return name ? seam_env(name) : nullptr; }
 int scs_download_primer_stock(scs_ctx* c, int64_t* stock) {

@@ -422,23 +422,27 @@ g.yield_reads_files(%r)
         assert open(str(tmp_path / "cli") + suffix, "rb").read() == open(prefix + suffix, "rb").read()
 
 
-def test_bench_two_rank_control_flow(tmp_path):
-    """bench.py's N > 1 path (ONE job sharded 2 ways by fragment lineage -- strong scaling --, a FASTQ shard per rank,
-    max-over-ranks timing) rehearsed as 2 ranks on this box's one GPU on a scaled-down genome: gloo collectives staged
-    through the CPU instead of RCCL.  Checks the control flow and the JSON contract, not a rate."""
+@pytest.mark.parametrize("ranks", [2, 5])
+def test_bench_two_rank_control_flow(ranks, tmp_path):
+    """bench.py's N > 1 path (ONE job sharded N ways by fragment lineage -- strong scaling --, a FASTQ shard per rank,
+    max-over-ranks timing) rehearsed as 2 and as 5 ranks on this box's one GPU on a scaled-down genome (5 + this process: the
+    most the pool lets share a card): gloo collectives staged through the CPU instead of RCCL.  Checks the control flow and the
+    JSON contract -- the per-rank stage times and sink rates the scaling curve is read with --, not a rate."""
     import json
     import sys
     env = dict(os.environ, SCS_BENCH_BACKEND="gloo", SCS_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29791", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--genome-mb", "4"],
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
+                        "--master-port", str(29791 + ranks), os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "2", "--warmup", "1", "--genome-mb", "4"],
                        env=env, capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, "rank 0 prints exactly one JSON line"
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "strong" and d["vs_baseline"] is None
+    assert d["n_gpus"] == ranks and d["steps"] == 2 and d["scaling"] == "strong" and d["vs_baseline"] is None
+    assert [p["rank"] for p in d["per_rank"]] == list(range(ranks)) and all(p["sink_GBps"] > 0 and p["amplify_s"] > 0 for p in d["per_rank"])
+    assert sum(p["pairs"] for p in d["per_rank"]) == d["config"]["pairs_per_step"] and len(d["generation_hbm"]["per_rank"]) == ranks
     assert d["value"] > 0 and abs(d["value"] - d["config"]["pairs_per_step"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 0.05
     assert 350000 < d["config"]["pairs_per_step"] < 450000                         # the whole 4 Mb job at 30x, PE150: ~400 k pairs
     assert 0 < d["roofline"]["frac"] <= 1 and "cpu_baseline" not in d

@@ -154,6 +154,19 @@ def test_cli_forks_two_ranks_on_one_gpu_and_merges_their_shards(oracle_bin, mode
     assert [open(out + s, "rb").read() for s in ("_1.fq", "_2.fq")] == want
 
 
+def test_cli_five_ranks_on_one_gpu(oracle_bin, models, golden_inputs, tmp_path):
+    """`scssim genreads --gpus 5` through the same seam (five ranks + this process: the most the pool lets share one card): more ranks
+    than some list segments have amplicons, shards with empty segments, the merge over five indexes -- and the oracle's bytes."""
+    fa, prof = golden_inputs["g2_xten_pe_nblock"], models["Illumina_HiSeqXTen"]
+    prefix = str(tmp_path / "orc")
+    _oracle(oracle_bin, fa, prof, prefix, ["-c", "3"], 37)
+    out = str(tmp_path / "cli5")
+    rc, err, left = _cli(["-i", fa, "-m", prof, "-c", "3", "-o", out, "--seed", "37", "--gpus", "5", "--one-device", "--host-collectives"])
+    assert rc == 0 and not left, err
+    for s in ("_1.fq", "_2.fq"):
+        assert open(out + s, "rb").read() == open(prefix + s, "rb").read(), s
+
+
 @pytest.mark.parametrize("where,who", [("amplify", 1), ("reads", 1), ("comm", 2), ("amplify", 0)])
 def test_cli_rank_failure_ends_the_job(where, who, models, golden_inputs, tmp_path):
     """A rank that dies mid-job (injected: SCS_TEST_FAIL_AT / SCS_TEST_FAIL_RANK) leaves its siblings inside an exchange that
