@@ -1134,10 +1134,18 @@ void do_yield(scs_ctx* c, const OutTarget& tg, uint64_t* n1_out, uint64_t* n2_ou
     const bool to_sink = !tg.device && tg.sink;
     const int regions = to_sink ? std::max(1, tg.sink->regions) : 1;
     // pairs per batch: 8 M with the text staying in HBM (5 GB of text per batch: the base pass' grids are long enough for their tails and
-    // the per-batch pre-pass not to matter: 2 M -> 8 M gave -11 % on the stage), 512 k towards a sink (pinned slots; 256 k when many
-    // writers each hold one)
+    // the per-batch pre-pass not to matter: 2 M -> 8 M gave -11 % on the stage).  Towards a sink a batch fills a pinned slot and every
+    // writer holds one: as large as leaves each part file of each generation a couple of batches -- 2 M pairs (1.3 GB of text) on a
+    // whole-genome job, where the base pass then runs at the rate it has in HBM (256 k-pair launches ran at 0.09 of the HBM roofline
+    // with the chip half empty through their tails, 2 M-pair ones at 0.15: profiles/r04_sink_batch_sizes.log; the job, bound by the
+    // host's copies, is the same to within its run-to-run spread) --, never fewer than 256 k (512 k with few writers)
     static const int batch_shift = seam_env("SCS_TEST_BATCH_SHIFT") ? atoi(seam_env("SCS_TEST_BATCH_SHIFT")) : 0;   // tests: many small batches
-    const uint64_t batch = std::min<uint64_t>(std::max<uint64_t>(P, 1), batch_shift ? (1ull << batch_shift) : to_sink ? (tg.sink->writers > 4 ? 1ull << 18 : 1ull << 19) : (1ull << 23));
+    uint64_t sink_batch = 1ull << 19;
+    if (to_sink && tg.sink->writers > 4) {
+        const uint64_t per_part = P / (2ull * (uint64_t)std::max(1, regions));     // two batches per part file
+        sink_batch = 1ull << 18; while (sink_batch < (1ull << 21) && sink_batch * 2 <= per_part) sink_batch <<= 1;
+    }
+    const uint64_t batch = std::min<uint64_t>(std::max<uint64_t>(P, 1), batch_shift ? (1ull << batch_shift) : to_sink ? sink_batch : (1ull << 23));
     // The pairs are planned (k_plan_pairs: insert sizes, positions, the amplicon resolved to an index map) batch by batch, at the
     // head of each batch's pre-pass: bounds[b] = the amplicon that holds the batch's first pair.
     const uint32_t nbatch = (uint32_t)((P + batch - 1) / batch);
