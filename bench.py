@@ -106,6 +106,37 @@ def genome_fingerprint(torch, bases):
     return acc
 
 
+def make_config4_inputs(torch, dev, lens, ref_path, var_path):
+    """BASELINE configs[4]'s inputs: the bench genome's haploid records (the same generator stream as synth_genome, seed 3000) as a plain
+    reference FASTA (60 columns, chr1..chr24) and a CNV-heavy variation file (sorted, non-overlapping intervals, copy numbers 0..8 in every
+    major-copy split; numpy generator 5).  Returns (bases the two haplotypes of all chromosomes must have, fingerprint of the reference)."""
+    import numpy as np
+    rng = np.random.default_rng(5)
+    gen = torch.Generator(device=dev); gen.manual_seed(3000)
+    expect, fp = 0, 0
+    with open(ref_path, "wb") as f, open(var_path, "w") as fv:
+        for i, n in enumerate(lens):
+            u = torch.rand(n, device=dev, generator=gen)
+            rec_d = (u >= 0.3).to(torch.uint8) * 2 + (u >= 0.5).to(torch.uint8) * 4 + (u >= 0.7).to(torch.uint8) * 13 + 65
+            del u
+            fp = (fp * 1000003 + genome_fingerprint(torch, rec_d)) & 0xFFFFFFFFFFFFFFFF
+            rec = rec_d.cpu().numpy()
+            del rec_d
+            f.write(b">chr%d\n" % (i + 1))
+            full = (n // 60) * 60
+            f.write(np.concatenate([rec[:full].reshape(-1, 60), np.full((full // 60, 1), 10, np.uint8)], axis=1).tobytes())
+            if n > full:
+                f.write(rec[full:].tobytes() + b"\n")
+            pos, hap = 100000, [n, n]
+            while pos + 3000000 < n:                                 # sorted, non-overlapping CNV intervals, every major-copy split
+                ln = int(rng.integers(50000, 1500000)); cn = int(rng.integers(0, 9)); mcn = int(rng.integers((cn + 1) // 2, cn + 1))
+                fv.write("c\tchr%d\t%d\t%d\t%d\t%d\n" % (i + 1, pos, pos + ln, cn, mcn))
+                hap[0] += (mcn - 1) * (ln + 1); hap[1] += (cn - mcn - 1) * (ln + 1)
+                pos += ln + int(rng.integers(500000, 4000000))
+            expect += hap[0] + hap[1]
+    return expect, fp
+
+
 def write_simu_fasta(path, names, seqs):
     """simuvars-style FASTA (100 columns) from numpy uint8 arrays."""
     import numpy as np

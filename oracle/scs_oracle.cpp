@@ -710,10 +710,21 @@ inline int primer_index(const uint8_t* t) {
 struct PrimerPool {
     Sim& S; std::vector<long>* pending;           // what this worker took during the pass (counter mode)
     bool live;                                    // decrement the shared stock at once (the reference's way), or look at the pass's start
+    // counter mode, a pass in which a type runs dry (amplify_pass): the types in `dry_set` are handed out from `left` (live), the
+    // others as of the pass's start; sig = a 64-bin filter of the types the template in hand has asked for, asked_dry = one of dry_set
+    const std::vector<uint8_t>* dry_set = nullptr; std::vector<long>* left = nullptr; uint64_t sig = 0; bool asked_dry = false;
+    static uint64_t bin(int idx) { return 1ull << (((uint32_t)idx * 0x9E3779B1u) >> 26); }
     bool take(const uint8_t* t) {                 // updatePrimerCount(s, -1)
         int idx = primer_index(t);
         if (idx < 0) return false;                // N-containing 8-mer: node with no stock (A.8 D-item)
-        if (!live) {                              // counter mode, first run of a pass: the stock as of the pass's start (amplify_pass below)
+        sig |= bin(idx);
+        if (dry_set && (*dry_set)[idx]) {
+            asked_dry = true;
+            if (!left) return S.primerCount[idx] > 0 ? ((*pending)[idx]++, true) : false;   // (the dry run that recovers the first run's takes)
+            if ((*left)[idx] <= 0) return false;
+            (*left)[idx]--; (*pending)[idx]++; return true;
+        }
+        if (!live) {                              // counter mode: the stock as of the pass's start
             if (S.primerCount[idx] <= 0) return false;
             (*pending)[idx]++; return true;
         }
@@ -936,62 +947,131 @@ void append_reversed(AmpList& dst, AmpList& add) {
 // ---- one pass over the templates [0, n) of a list (Malbac::amplifyFrags 318-343, amplifySemiAmplicons 345-368).
 // The reference decrements the stock of a primer type at every attachment (Malbac.cpp:91-103) and walks the templates
 // in list order (one pool task at -t 1): a type is used exactly `stock` times, by the first `stock` attachments that ask
-// for it.  Counter mode keeps exactly that.  To stay free of the thread / shard schedule a pass is first run with every
-// worker looking at the stock as of the pass's START; if no type was then asked for more often than it has stock, its
-// availability never changed during the pass and the run IS the sequential loop's result.  Otherwise the pass is run
-// again the reference's way: one worker, list order, live decrement -- in a sharded job segment by segment in the whole
-// job's list order (`segs`: local template ranges and the order of the shards inside each), the stock handed from shard
-// to shard by an all-reduce to which only the segment's owner contributes.
+// for it.  Counter mode keeps exactly that, free of the thread / shard schedule:
+//   1. every template is evaluated against the stock as of the pass's START, in parallel.  If no type was then asked for
+//      more often than it has stock, its availability never changed during the pass: this IS the sequential loop's result.
+//   2. Otherwise let D be the over-demanded ("dry") types.  A template that never asks for a type of D evaluates in the
+//      sequential loop exactly as in step 1 (every type it asks for is to be had throughout -- checked in step 3).  The others
+//      -- few: found by a 64-bin filter of the types each template asked for, then by evaluating the candidates again -- are
+//      evaluated once more ONE AFTER THE OTHER in list order, the types of D handed out from a live count; in a sharded
+//      job segment by segment in the whole job's list order (`segs`: local template ranges, the order of the shards
+//      inside each), the live counts handed from shard to shard by an all-reduce to which only the owner contributes.
+//   3. What the templates of step 2 now take elsewhere may push a further type over its stock: it joins D and step 2 is
+//      done again from step 1's results.  (A whole-genome pass runs dry in a handful of types -- poly-A / poly-T 8-mers --
+//      and step 2 touches one template in a thousand; the plain sequential loop over 10^8 templates took a quarter of an hour.)
 struct PassSeg { size_t lo, hi; bool shards_descending; };
-template <class RunRange>
-void amplify_pass(Sim& S, size_t n, size_t min_block, const std::vector<PassSeg>& segs, RunRange run, AmpList& all) {
+struct EvalScratch { std::vector<uint8_t> pa, seq, tc; };
+template <class Eval>
+void amplify_pass(Sim& S, size_t n, size_t min_block, const std::vector<PassSeg>& segs, Eval eval, AmpList& all) {
     const bool ctr = S.prm.counter; const int th = ctr ? S.prm.threads : 1;
-    auto gather = [&](std::vector<AmpList>& parts) {
-        size_t na = 0, ne = 0; for (auto& pt : parts) { na += pt.a.size(); ne += pt.errs.size(); }
-        all.a.reserve(all.a.size() + na); all.errs.reserve(all.errs.size() + ne);
-        for (auto& pt : parts) { for (auto a : pt.a) { uint32_t off = (uint32_t)all.errs.size();
-            for (uint32_t e = 0; e < a.err_cnt; ++e) all.errs.push_back(pt.errs[a.err_off + e]); a.err_off = off; all.a.push_back(a); }
-            pt = AmpList(); }                                                       // (a whole-genome pass holds tens of GB here)
+    auto append = [&](const AmpList& src, size_t first, size_t count) {
+        for (size_t k = first; k < first + count; ++k) { Amp a = src.a[k]; uint32_t off = (uint32_t)all.errs.size();
+            for (uint32_t e = 0; e < a.err_cnt; ++e) all.errs.push_back(src.errs[a.err_off + e]); a.err_off = off; all.a.push_back(a); }
     };
-    if (!ctr) { std::vector<AmpList> parts(1); PrimerPool pool{S, nullptr, true}; run(0, n, pool, parts[0]); gather(parts); return; }
-    {   std::vector<AmpList> parts; std::vector<std::vector<long>> pend;
-        size_t nbMax = (size_t)std::max(1, th) * 4; parts.resize(nbMax); pend.resize(nbMax);
-        parallel_blocks(n, th, min_block, [&](size_t b, size_t lo, size_t hi) { pend[b].assign(65536, 0); PrimerPool pool{S, &pend[b], false}; run(lo, hi, pool, parts[b]); });
-        std::vector<uint64_t> sum(65536, 0);
-        for (auto& v : pend) for (size_t i = 0; i < v.size(); ++i) sum[i] += (uint64_t)v[i];
-        S.allreduce(sum.data(), sum.size());                                        // sharded: the demand of all shards
-        bool over = false;
-        for (size_t i = 0; i < sum.size(); ++i) over |= (long)sum[i] > S.primerCount[i];
-        if (!over) {
-            for (size_t i = 0; i < sum.size(); ++i) { S.primerUsed[i] += (long)sum[i]; S.primerCount[i] -= (long)sum[i]; }
-            gather(parts); return;
-        }
+    if (!ctr) {
+        AmpList part; PrimerPool pool{S, nullptr, true}; EvalScratch sc;
+        for (size_t i = 0; i < n; ++i) eval(i, pool, part, sc);
+        append(part, 0, part.a.size()); return;
     }
-    S.exhausted_passes++;
-    std::vector<AmpList> parts(segs.size());
-    for (size_t sg = 0; sg < segs.size(); ++sg) for (int k = 0; k < S.prm.shard_count; ++k) {
-        const int owner = segs[sg].shards_descending ? S.prm.shard_count - 1 - k : k;
+    const size_t nbMax = (size_t)std::max(1, th) * 4;
+    std::vector<AmpList> parts(nbMax); std::vector<std::vector<long>> pend(nbMax); std::vector<size_t> blo(nbMax, 0), bhi(nbMax, 0);
+    std::vector<uint32_t> cnt(n, 0); std::vector<uint64_t> sig(n, 0);
+    parallel_blocks(n, th, min_block, [&](size_t b, size_t lo, size_t hi) {
+        pend[b].assign(65536, 0); PrimerPool pool{S, &pend[b], false}; EvalScratch sc; blo[b] = lo; bhi[b] = hi;
+        for (size_t i = lo; i < hi; ++i) { pool.sig = 0; const size_t before = parts[b].a.size(); eval(i, pool, parts[b], sc); cnt[i] = (uint32_t)(parts[b].a.size() - before); sig[i] = pool.sig; }
+    });
+    std::vector<uint64_t> sum1(65536, 0);
+    for (auto& v : pend) for (size_t i = 0; i < v.size(); ++i) sum1[i] += (uint64_t)v[i];
+    S.allreduce(sum1.data(), sum1.size());                                          // sharded: the demand of all shards
+    std::vector<uint8_t> dry(65536, 0); bool over = false;
+    for (size_t i = 0; i < sum1.size(); ++i) if ((long)sum1[i] > S.primerCount[i]) { dry[i] = 1; over = true; }
+    std::vector<uint64_t> total = sum1;
+    std::vector<size_t> touch; std::vector<AmpList> repl;                           // step 2's templates (ascending) and what they make
+    if (over) S.exhausted_passes++;
+    if (over && getenv("SCSO_PLAIN_SEQUENTIAL_PASS")) {
+        // the reference's loop to the letter -- one worker, list order, live decrement of every type -- for the test that steps 2 and 3
+        // give its result (tests/test_oracle_stats.py); unsharded only
+        if (S.prm.shard_count > 1) fail("SCSO_PLAIN_SEQUENTIAL_PASS: unsharded runs only");
+        AmpList part; PrimerPool pool{S, nullptr, true}; EvalScratch sc;
+        for (size_t i = 0; i < n; ++i) eval(i, pool, part, sc);
+        append(part, 0, part.a.size()); return;
+    }
+    while (over) {
+        uint64_t sig_dry = 0; for (size_t i = 0; i < 65536; ++i) if (dry[i]) sig_dry |= PrimerPool::bin((int)i);
+        // the templates that ask for a dry type in step 1's evaluation, and what they took then
+        std::vector<size_t> cand; for (size_t i = 0; i < n; ++i) if (sig[i] & sig_dry) cand.push_back(i);
+        std::vector<uint8_t> asks(cand.size(), 0); std::vector<std::vector<long>> old(nbMax);
+        parallel_blocks(cand.size(), th, 16, [&](size_t b, size_t lo, size_t hi) {
+            if (old[b].empty()) old[b].assign(65536, 0);
+            std::vector<long> mine(65536, 0); AmpList scratch; EvalScratch sc;
+            for (size_t k = lo; k < hi; ++k) {
+                PrimerPool pool{S, &mine, false}; pool.dry_set = &dry; scratch.a.clear(); scratch.errs.clear();
+                eval(cand[k], pool, scratch, sc);
+                if (pool.asked_dry) asks[k] = 1;
+            }
+            // second sweep over the block's true ones, counting their takes alone
+            std::fill(mine.begin(), mine.end(), 0);
+            for (size_t k = lo; k < hi; ++k) if (asks[k]) { PrimerPool pool{S, &mine, false}; pool.dry_set = &dry; scratch.a.clear(); scratch.errs.clear(); eval(cand[k], pool, scratch, sc); }
+            for (size_t i = 0; i < 65536; ++i) old[b][i] += mine[i];
+        });
+        touch.clear(); for (size_t k = 0; k < cand.size(); ++k) if (asks[k]) touch.push_back(cand[k]);
+        repl.assign(touch.size(), AmpList());
+        std::vector<long> left(65536, 0); for (size_t i = 0; i < 65536; ++i) left[i] = S.primerCount[i];
         std::vector<long> took(65536, 0);
-        if (owner == S.prm.shard_rank) { PrimerPool pool{S, &took, true}; run(segs[sg].lo, segs[sg].hi, pool, parts[sg]); }
-        if (S.prm.shard_count > 1) {
-            std::vector<uint64_t> d(took.begin(), took.end());
-            S.allreduce(d.data(), d.size());
-            if (owner != S.prm.shard_rank) for (size_t i = 0; i < d.size(); ++i) { S.primerUsed[i] += (long)d[i]; S.primerCount[i] -= (long)d[i]; }
+        size_t tk = 0;
+        for (size_t sg = 0; sg < segs.size(); ++sg) for (int k = 0; k < S.prm.shard_count; ++k) {
+            const int owner = segs[sg].shards_descending ? S.prm.shard_count - 1 - k : k;
+            std::vector<long> mine(65536, 0);
+            if (owner == S.prm.shard_rank) {
+                EvalScratch sc;
+                for (; tk < touch.size() && touch[tk] < segs[sg].hi; ++tk) {
+                    if (touch[tk] < segs[sg].lo) continue;
+                    PrimerPool pool{S, &mine, false}; pool.dry_set = &dry; pool.left = &left;
+                    eval(touch[tk], pool, repl[tk], sc);
+                }
+                for (size_t i = 0; i < 65536; ++i) took[i] += mine[i];
+            }
+            if (S.prm.shard_count > 1) {                                             // the live counts of the dry types travel on
+                std::vector<uint64_t> d(65536, 0); for (size_t i = 0; i < 65536; ++i) if (dry[i]) d[i] = (uint64_t)mine[i];
+                S.allreduce(d.data(), d.size());
+                if (owner != S.prm.shard_rank) for (size_t i = 0; i < 65536; ++i) left[i] -= (long)d[i];
+            }
+        }
+        // the pass's demand now: step 1's, less what step 2's templates took then, plus what they take now
+        std::vector<uint64_t> delta(2 * 65536, 0);
+        for (auto& v : old) if (!v.empty()) for (size_t i = 0; i < 65536; ++i) delta[i] += (uint64_t)v[i];
+        for (size_t i = 0; i < 65536; ++i) delta[65536 + i] = (uint64_t)took[i];
+        S.allreduce(delta.data(), delta.size());
+        over = false;
+        for (size_t i = 0; i < 65536; ++i) {
+            total[i] = sum1[i] - delta[i] + delta[65536 + i];
+            if ((long)total[i] > S.primerCount[i]) { if (dry[i]) fail("internal: a dry primer type was handed out beyond its stock"); dry[i] = 1; over = true; }
         }
     }
-    gather(parts);
+    for (size_t i = 0; i < 65536; ++i) { S.primerUsed[i] += (long)total[i]; S.primerCount[i] -= (long)total[i]; }
+    // the pass's amplicons in template order: step 1's, step 2's in their templates' places
+    size_t na = 0, ne = 0; for (auto& pt : parts) { na += pt.a.size(); ne += pt.errs.size(); }
+    all.a.reserve(all.a.size() + na + 1024); all.errs.reserve(all.errs.size() + ne + 1024);
+    size_t tk = 0;
+    for (size_t b = 0; b < nbMax; ++b) {
+        size_t at = 0;
+        if (touch.empty() || tk >= touch.size() || touch[tk] >= bhi[b]) { append(parts[b], 0, parts[b].a.size()); }
+        else for (size_t i = blo[b]; i < bhi[b]; ++i) {
+            if (tk < touch.size() && touch[tk] == i) { append(repl[tk], 0, repl[tk].a.size()); ++tk; }
+            else append(parts[b], at, cnt[i]);
+            at += cnt[i];
+        }
+        parts[b] = AmpList();                                                       // (a whole-genome pass holds tens of GB here)
+    }
 }
 
 // Malbac::amplifyFrags (Malbac.cpp:318-343)
 void amplify_frags(Sim& S, uint32_t pass) {
     const size_t n = S.frags.size();
-    AmpList all;
-    amplify_pass(S, n, 1, {PassSeg{0, n, false}}, [&](size_t lo, size_t hi, PrimerPool& pool, AmpList& out) {
-        std::vector<uint8_t> pa; Rng rng = S.rng;
-        for (size_t i = lo; i < hi; ++i) {
-            Frag& f = S.frags[i];
-            amplify_template(S, rng, pool, true, S.frag_gbase + i, (uint32_t)i, f.T.data(), f.len, f.primers, pass, pa, out);
-        }
+    AmpList all; Rng rng = S.rng;
+    amplify_pass(S, n, 1, {PassSeg{0, n, false}}, [&](size_t i, PrimerPool& pool, AmpList& out, EvalScratch& sc) {
+        Frag& f = S.frags[i];
+        amplify_template(S, rng, pool, true, S.frag_gbase + i, (uint32_t)i, f.T.data(), f.len, f.primers, pass, sc.pa, out);
     }, all);
     append_reversed(S.semis, all);
     S.semi_block_end.push_back(S.semis.a.size());
@@ -1003,16 +1083,13 @@ void amplify_semis(Sim& S, uint32_t cyc) {
     // hence the shards of a sharded job (contiguous fragment ranges) descending too
     std::vector<PassSeg> segs;
     for (size_t pb = 0; pb < S.semi_block_end.size(); ++pb) segs.push_back(PassSeg{pb ? S.semi_block_end[pb - 1] : 0, S.semi_block_end[pb], true});
-    AmpList all;
-    amplify_pass(S, n, 64, segs, [&](size_t lo, size_t hi, PrimerPool& pool, AmpList& out) {
-        std::vector<uint8_t> pa, seq, tc; Rng rng = S.rng;
-        for (size_t i = lo; i < hi; ++i) {
-            const Amp& a = S.semis.a[i];
-            if ((int)a.len < S.prm.ampMin + 27) continue;
-            semi_sequence(S, a, seq); tc.resize(seq.size());
-            for (size_t t = 0; t < seq.size(); ++t) tc[t] = comp_code(seq[t]);       // Amplicon.cpp:171-172
-            amplify_template(S, rng, pool, false, a.uid, (uint32_t)i, tc.data(), a.len, a.primers, cyc, pa, out);
-        }
+    AmpList all; Rng rng = S.rng;
+    amplify_pass(S, n, 64, segs, [&](size_t i, PrimerPool& pool, AmpList& out, EvalScratch& sc) {
+        const Amp& a = S.semis.a[i];
+        if ((int)a.len < S.prm.ampMin + 27) return;
+        semi_sequence(S, a, sc.seq); sc.tc.resize(sc.seq.size());
+        for (size_t t = 0; t < sc.seq.size(); ++t) sc.tc[t] = comp_code(sc.seq[t]);     // Amplicon.cpp:171-172
+        amplify_template(S, rng, pool, false, a.uid, (uint32_t)i, sc.tc.data(), a.len, a.primers, cyc, sc.pa, out);
     }, all);
     {   // segments of this cycle in stored (reversed) order: semis made in fragment pass p, p descending
         std::vector<size_t> cnt(S.semi_block_end.size(), 0);

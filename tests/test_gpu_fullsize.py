@@ -102,27 +102,8 @@ def test_whole_genome_properties(cfg, models, tmp_path):
         shm = "/dev/shm" if os.path.isdir("/dev/shm") else td
         ref = os.path.join(shm, "scs_cfg4_ref_%d.fa" % os.getpid())
         var = os.path.join(td, "vars.txt")
-        rng = np.random.default_rng(5)
         try:
-            gen = torch.Generator(device=dev); gen.manual_seed(3000)
-            expect = 0
-            with open(ref, "wb") as f, open(var, "w") as fv:
-                for i, n in enumerate(lens):
-                    u = torch.rand(n, device=dev, generator=gen)
-                    rec = ((u >= 0.3).to(torch.uint8) * 2 + (u >= 0.5).to(torch.uint8) * 4 + (u >= 0.7).to(torch.uint8) * 13 + 65).cpu().numpy()
-                    del u
-                    f.write(b">chr%d\n" % (i + 1))
-                    full = (n // 60) * 60
-                    f.write(np.concatenate([rec[:full].reshape(-1, 60), np.full((full // 60, 1), 10, np.uint8)], axis=1).tobytes())
-                    if n > full:
-                        f.write(rec[full:].tobytes() + b"\n")
-                    pos, hap = 100000, [n, n]
-                    while pos + 3000000 < n:                                 # sorted, non-overlapping CNV intervals, every major-copy split
-                        ln = int(rng.integers(50000, 1500000)); cn = int(rng.integers(0, 9)); mcn = int(rng.integers((cn + 1) // 2, cn + 1))
-                        fv.write("c\tchr%d\t%d\t%d\t%d\t%d\n" % (i + 1, pos, pos + ln, cn, mcn))
-                        hap[0] += (mcn - 1) * (ln + 1); hap[1] += (cn - mcn - 1) * (ln + 1)
-                        pos += ln + int(rng.integers(500000, 4000000))
-                    expect += hap[0] + hap[1]
+            expect, genome_fp = bench.make_config4_inputs(torch, dev, lens, ref, var)
             g = scssim_amd.GenReads(profile=prof, coverage=cov, isize=isz, seed=11, stream=stream.cuda_stream)
             g.simuvars(ref, None, var)
         finally:
@@ -137,13 +118,14 @@ def test_whole_genome_properties(cfg, models, tmp_path):
     assert g.read_length == L
     g.set_batch_checksums(True)
     golden = None
-    if cfg.startswith("config3"):
-        # the oracle's run of this very job (tools/whole_genome_golden.py, 7 minutes of 16 host cores): counts and the checksum of every
+    if True:
+        # the oracle's run of this very job (tools/whole_genome_golden.py, 7 / 13 minutes of 16 host cores): counts and the checksum of every
         # 8 M-pair batch's text per mate.  The genome comes from torch's device generator: its fingerprint says whether this box made
         # the genome the golden belongs to (a different generator is not a parity failure -- but it must be said, not skipped over)
         import json
-        golden = json.load(open(os.path.join(ROOT, "tests", "golden", "whole_genome_config3.json")))
-        assert golden["genome"]["fingerprint"] == "%016x" % genome_fp, "this box's synthetic genome is not the one tests/golden/whole_genome_config3.json was made from: make it again (tools/whole_genome_golden.py)"
+        gpath = os.path.join(ROOT, "tests", "golden", "whole_genome_%s.json" % cfg.split("_")[0])
+        golden = json.load(open(gpath))
+        assert golden["genome"]["fingerprint"] == "%016x" % genome_fp, "this box's synthetic genome is not the one %s was made from: make it again (tools/whole_genome_golden.py)" % gpath
 
     def job(seed, sink=None):
         g.set_seed(seed)
@@ -160,11 +142,12 @@ def test_whole_genome_properties(cfg, models, tmp_path):
     assert len(cks) == (st["pairs_written"] + (1 << 23) - 1) >> 23 or len(cks) == ((want_reads + 1) // 2 + (1 << 23) - 1) >> 23
     assert all(a and b for a, b in cks)
     if golden:
-        # BASELINE configs[3] bit for bit against the oracle at full size: 1.1e9 amplicons = 1.1e6 allocation chunks (the third level
-        # of the chunk CDF, MyDefine.cpp:203-253), amplicon indices above 1e9 in the names (Amplicon.cpp:460,498,519), 197 GB of text
+        # BASELINE configs[3] / configs[4] bit for bit against the oracle at full size: 1.1e9 and more amplicons = 1.1e6 allocation chunks
+        # (the third level of the chunk CDF, MyDefine.cpp:203-253), amplicon indices above 1e9 in the names (Amplicon.cpp:460,498,519),
+        # 197 GB of text and more; configs[4] with its input made by simuvars on both sides
         c = golden["counts"]
         assert (st["fragments"], st["semi_amplicons"], st["full_amplicons"]) == (c["frags"], c["semis"], c["fulls"]), (st, c)
-        assert st["full_amplicons"] > 1000000000 and len(golden["batches"]) == len(cks) >= 37
+        assert st["full_amplicons"] > 1000000000 and len(cks) >= 37 and len(golden["batches"]) >= 5
         assert st["pairs_written"] == sum(r[5] for r in golden["batches"]) and st["fastq_bytes"] == [sum(r[3] for r in golden["batches"]), sum(r[4] for r in golden["batches"])]
         bad = [r[0] for r in golden["batches"] if cks[r[0]] != (int(r[1], 16), int(r[2], 16))]
         assert not bad, "the text of batches %s differs from the oracle's (of %d)" % (bad[:8], len(cks))

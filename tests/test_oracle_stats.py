@@ -2,6 +2,7 @@
 factor, chunked weight sum) must leave the DISTRIBUTIONS of the reference untouched.  Both oracle modes run on the same
 300 kb genome; summary statistics of ref mode (= the reference's streams) and counter mode must agree within sampling
 noise (generous 5-sigma-style bounds so the test is not flaky)."""
+import os
 import subprocess
 
 import numpy as np
@@ -489,3 +490,19 @@ def test_primer_exhaustion_exact_in_both_modes(exhausted):
     assert abs(int(ctr[:, 1].sum()) - int(ref[:, 1].sum())) < 0.03 * ref[:, 1].sum()
     rest_r = ref[ref[:, 2] > 0][:, 1].astype(np.float64); rest_c = ctr[ctr[:, 2] > 0][:, 1].astype(np.float64)
     assert abs(rest_r.mean() - rest_c.mean()) < 0.03 * rest_r.mean()
+
+
+def test_exhausted_pass_equals_the_plain_sequential_loop(oracle_bin, models, repeat_genome, tmp_path):
+    """Counter mode settles a pass in which primer types run dry by evaluating again, one after the other, only the templates that ask
+    for such a type (oracle: amplify_pass, steps 2 and 3).  SCSO_PLAIN_SEQUENTIAL_PASS=1 replaces that by the reference's loop to
+    the letter -- every template, one worker, list order, live decrement (Malbac.cpp:91-103) --: same amplicons, same stock, same FASTQ."""
+    import hashlib
+    out = {}
+    for mode, env in (("fast", {}), ("plain", {"SCSO_PLAIN_SEQUENTIAL_PASS": "1"})):
+        pre = str(tmp_path / mode)
+        subprocess.check_call([oracle_bin, "genreads", "-i", repeat_genome, "-m", models["Illumina_HiSeq2500"], "-c", "0.5", "-p", "10000", "-r", "1e-8",
+                               "-o", pre, "--dump", pre, "-q", "--rng", "counter", "--seed", "77", "-t", "4"], env=dict(os.environ, **env))
+        out[mode] = [hashlib.md5(open(pre + s, "rb").read()).hexdigest() for s in ("_1.fq", "_2.fq", ".primers.tsv", ".semis.tsv", ".fulls.tsv")]
+    assert out["fast"] == out["plain"]
+    prim = np.loadtxt(str(tmp_path / "fast") + ".primers.tsv", dtype=np.int64)
+    assert (prim[:, 2] == 0).sum() >= 4

@@ -28,6 +28,7 @@ sys.path.insert(0, ROOT)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", required=True)
+    ap.add_argument("--config", type=int, default=3, help="3: BASELINE configs[3] (PE150 30x, plain diploid genome); 4: configs[4] (PE250 60x -s 500, the haplotypes made by simuvars from a CNV-heavy variation file)")
     ap.add_argument("--genome-mb", type=float, default=0.0)
     ap.add_argument("--batches", default="0,1,18,-2,-1")
     ap.add_argument("--seed", type=int, default=11)
@@ -39,11 +40,14 @@ def main():
     dev = torch.device("cuda", 0)
     lens = bench.record_lengths(a.genome_mb)
     t0 = time.time()
-    names, rl, bases = bench.synth_genome(torch, dev, lens, 3000)
-    fp = bench.genome_fingerprint(torch, bases)
     shm = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
     td = tempfile.mkdtemp(prefix="scs_wg_", dir=shm)
     fa = os.path.join(td, "simu.fa")
+    oracle = os.path.join(ROOT, "oracle", "_build", "scs_oracle")
+    if a.config == 4:
+        return config4(a, torch, bench, dev, lens, td, fa, oracle, t0)
+    names, rl, bases = bench.synth_genome(torch, dev, lens, 3000)
+    fp = bench.genome_fingerprint(torch, bases)
     try:
         with open(fa, "wb") as f:
             off = 0
@@ -84,6 +88,57 @@ def main():
         print("wrote %s: %d batches, oracle %.0f s" % (a.out, len(rows), time.time() - t1), flush=True)
     finally:
         import shutil
+        shutil.rmtree(td, ignore_errors=True)
+
+
+def parse_cks(path):
+    head, rows = None, []
+    for line in open(path):
+        f = line.split()
+        if line.startswith("#"):
+            head = {f[i]: int(f[i + 1]) for i in range(1, len(f) - 1, 2)}
+        else:
+            rows.append([int(f[0]), f[1], f[2], int(f[3]), int(f[4]), int(f[5])])
+    return head, rows
+
+
+def config4(a, torch, bench, dev, lens, td, fa, oracle, t0):
+    """configs[4]: reference + variation file -> `scs_oracle simuvars` -> the haplotypes' FASTA -> `scs_oracle genreads` (PE250 = HiSeq X Ten
+    resampled to 250 bins, 60x, -s 500), the test's inputs and options to the letter (tests/test_gpu_fullsize.py)."""
+    import gzip
+    import shutil
+    try:
+        ref, var = os.path.join(td, "ref.fa"), os.path.join(td, "vars.txt")
+        expect, fp = bench.make_config4_inputs(torch, dev, lens, ref, var)
+        torch.cuda.empty_cache()
+        print("reference + variation file: %.1f s, fingerprint %016x, %d haplotype bases expected" % (time.time() - t0, fp, expect), flush=True)
+        t1 = time.time()
+        subprocess.check_call([oracle, "simuvars", "-r", ref, "-v", var, "-o", fa])
+        os.remove(ref)
+        print("oracle simuvars: %.1f s, %.2f GB" % (time.time() - t1, os.path.getsize(fa) / 1e9), flush=True)
+        src = os.path.join(td, "xten.profile")
+        open(src, "wb").write(gzip.open(os.path.join(ROOT, "tests", "golden", "models", "Illumina_HiSeqXTen.profile.gz")).read())
+        prof = os.path.join(td, "pe250.profile")
+        subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "make_profile.py"), src, prof, "--read-length", "250"])
+        cks = a.out + ".cks"                                                             # (under gpurun_out/: what was made survives a time limit)
+        threads = a.threads or bench.host_cores()
+        cmd = [oracle, "genreads", "-i", fa, "-m", prof, "--rng", "counter", "--seed", str(a.seed), "-t", str(threads), "-c", "60", "-s", "500",
+               "--checksums", cks, "--batch-pairs", str(1 << 23)]
+        if a.batches != "all":
+            cmd += ["--checksum-batches", a.batches]
+        t2 = time.time()
+        subprocess.check_call(cmd)
+        head, rows = parse_cks(cks)
+        out = dict(what="BASELINE configs[4] through oracle/scs_oracle (simuvars, then genreads --rng counter): per-batch checksums of the FASTQ text (tools/whole_genome_golden.py --config 4)",
+                   genome=dict(records="bench.record_lengths(%g)" % a.genome_mb, bases_per_haplotype_of_the_reference=sum(lens), generator="bench.make_config4_inputs(torch, cuda:0, lens, ref, var)",
+                               fingerprint="%016x" % fp, haplotype_bases=expect),
+                   job=dict(profile="tools/make_profile.py Illumina_HiSeqXTen --read-length 250", coverage=60, isize=500, seed=a.seed, primers=100000, gamma=1e-9, batch_pairs=1 << 23),
+                   counts=head, batches=rows, batch_columns=["batch", "checksum mate 1", "checksum mate 2", "bytes mate 1", "bytes mate 2", "pairs"],
+                   made=dict(oracle_threads=threads, oracle_seconds=round(time.time() - t2, 1), torch=torch.__version__))
+        with open(a.out, "w") as f:
+            json.dump(out, f, indent=1)
+        print("wrote %s: %d batches, oracle genreads %.0f s" % (a.out, len(rows), time.time() - t2), flush=True)
+    finally:
         shutil.rmtree(td, ignore_errors=True)
 
 
