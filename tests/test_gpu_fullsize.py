@@ -148,7 +148,10 @@ def test_whole_genome_properties(cfg, models, tmp_path):
         c = golden["counts"]
         assert (st["fragments"], st["semi_amplicons"], st["full_amplicons"]) == (c["frags"], c["semis"], c["fulls"]), (st, c)
         assert st["full_amplicons"] > 1000000000 and len(cks) >= 37 and len(golden["batches"]) >= 5
-        assert st["pairs_written"] == sum(r[5] for r in golden["batches"]) and st["fastq_bytes"] == [sum(r[3] for r in golden["batches"]), sum(r[4] for r in golden["batches"])]
+        if len(golden["batches"]) == len(cks):                                        # (configs[4]'s golden holds a sample of the 45 batches)
+            assert st["pairs_written"] == sum(r[5] for r in golden["batches"]) and st["fastq_bytes"] == [sum(r[3] for r in golden["batches"]), sum(r[4] for r in golden["batches"])]
+        assert c["planned"] == (want_reads + 1) // 2 or c["planned"] == want_reads // 2
+        print("%s: %d batches of %d compared with the oracle's; primer stock: %d checks, %d passes with a dry type, %d rounds" % (cfg, len(golden["batches"]), len(cks), st["stock_checks"], st["stock_exhausted_passes"], st["stock_rounds"]))
         bad = [r[0] for r in golden["batches"] if cks[r[0]] != (int(r[1], 16), int(r[2], 16))]
         assert not bad, "the text of batches %s differs from the oracle's (of %d)" % (bad[:8], len(cks))
     mean_rec = sum(st["fastq_bytes"]) / (2.0 * st["pairs_written"])
