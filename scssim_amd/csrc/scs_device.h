@@ -141,8 +141,15 @@ void launch_alloc_parity(hipStream_t s, uint32_t* rn, const uint32_t* odd_before
 void launch_attach_semis(hipStream_t s, const uint8_t* g, DevFrags fr, DevAmps semis, uint32_t n_semis, DevErrPool spool,
                          const uint32_t* slot_off, uint32_t* slots, uint32_t* slot_tmpl, uint32_t* valid,
                          const unsigned long long* primer_cut, uint32_t* primer_delta, AmplifyParams p, uint32_t t_first, uint32_t t_end, int undo, const unsigned long long* t_from);
+// the dense form of the semi pass (one lane = one primer): a plan per pass, then the pass over every wave's templates (scs_k_amplify.hip)
+uint32_t attach_dense_waves(uint32_t n_slots);
+void launch_attach_plan(hipStream_t s, const uint32_t* slot_off, uint32_t nt, uint32_t n_slots, uint32_t* item_tmpl, uint32_t* wave_first, uint32_t* valid);
+void launch_attach_dense(hipStream_t s, const uint8_t* g, DevFrags fr, DevAmps semis, DevErrPool spool, const uint32_t* slot_off, uint32_t* slots, const uint32_t* item_tmpl,
+                         const uint32_t* wave_first, uint32_t n_slots, uint32_t* valid, const unsigned long long* primer_cut, uint32_t* primer_delta, AmplifyParams p, int undo,
+                         const unsigned long long* t_from);
 // exact primer stock: over-/under-demand of the pass so far (info: 8 words), the attachments of the over-demanded types, their sort, the new cuts
-void launch_stock_check(hipStream_t s, const int64_t* cnt, const uint32_t* taken, unsigned long long* cut, bool from_frag, uint32_t* eidx, uint32_t* etype, uint32_t* estart, unsigned long long* info);
+void launch_stock_check(hipStream_t s, const int64_t* cnt, const uint32_t* taken, unsigned long long* cut, bool from_frag, unsigned long long* info);
+void launch_stock_list(hipStream_t s, const int64_t* cnt, const uint32_t* taken, uint32_t* eidx, uint32_t* etype, uint32_t* estart, unsigned long long* info);   // only when the check found something
 void launch_stock_collect(hipStream_t s, const uint8_t* g, DevFrags fr, DevAmps semis, DevErrPool spool, bool from_frag, const uint32_t* slot_off, const uint32_t* slots,
                           const uint32_t* valid, const uint32_t* eidx, unsigned long long* list, unsigned long long* info, uint32_t t_first, uint32_t t_end);
 size_t stock_sort_temp_bytes(size_t n);

@@ -377,25 +377,28 @@ __global__ void __launch_bounds__(1024) k_poisson_sums(const unsigned long long*
 template <bool FROM_FRAG> __device__ __forceinline__ unsigned long long attach_key(uint32_t t, uint32_t i) {
     return (((unsigned long long)t << (FROM_FRAG ? 20 : 12)) | i) + 1ull;         // never 0: cut 0 = nothing to be had
 }
-// one workgroup: which types were taken more often than they have stock (over), which cut types less (under: an earlier
-// round's cut came too early -- it is lifted, and the pass is run again from where it lay); the over types numbered in type
-// order, the start of each one's stretch in the sorted list of their attachments.  info: [0] over types, [1] their
-// attachments, [2] under types, [3] first template to run again on account of the under types; [5] (k_stock_collect's cursor) and
-// [6] (k_stock_pick's first template) are reset here
-__global__ void __launch_bounds__(1024) k_stock_check(const int64_t* __restrict__ cnt, const uint32_t* __restrict__ taken, unsigned long long* __restrict__ cut, int key_shift,
-                                                      uint32_t* __restrict__ eidx, uint32_t* __restrict__ etype, uint32_t* __restrict__ estart, unsigned long long* __restrict__ info) {
-    __shared__ uint32_t s_n[1024], s_m[1024]; __shared__ uint32_t s_under, s_tmin;
+// which types were taken more often than they have stock (over), which cut types less (under: an earlier round's cut came too
+// early -- it is lifted, and the pass is run again from where it lay).  info (zeroed by the launcher): [0] over types, [1] their
+// attachments, [2] under types, [3] 2^32 - 1 - the first template to run again on account of the under types.  Nearly every call
+// finds nothing: one thread per type, a handful of atomics.
+__global__ void __launch_bounds__(256) k_stock_check(const int64_t* __restrict__ cnt, const uint32_t* __restrict__ taken, unsigned long long* __restrict__ cut, int key_shift,
+                                                     unsigned long long* __restrict__ info) {
+    const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= 65536u) return;
+    const int64_t c = cnt[x]; const uint32_t d = taken[x];
+    if ((int64_t)d > c) { atomicAdd(&info[0], 1ull); atomicAdd(&info[1], (unsigned long long)d); }
+    else { const unsigned long long q = cut[x]; if (q != 0ull && q != ~0ull && (int64_t)d < c) { atomicAdd(&info[2], 1ull); atomicMax(&info[3], 0xFFFFFFFFull - ((q - 1ull) >> key_shift)); cut[x] = ~0ull; } }
+}
+// one workgroup, only when the check found something: the over types numbered in type order, the start of each one's stretch in the
+// sorted list of their attachments; [5] (k_stock_collect's cursor) and [6] (the first template to run again: the under types', then
+// k_stock_pick's) are set here
+__global__ void __launch_bounds__(1024) k_stock_list(const int64_t* __restrict__ cnt, const uint32_t* __restrict__ taken,
+                                                     uint32_t* __restrict__ eidx, uint32_t* __restrict__ etype, uint32_t* __restrict__ estart, unsigned long long* __restrict__ info) {
+    __shared__ uint32_t s_n[1024], s_m[1024];
     const uint32_t tid = threadIdx.x;
-    if (tid == 0) { s_under = 0; s_tmin = 0xFFFFFFFFu; }
-    __syncthreads();
-    uint32_t n = 0, m = 0, under = 0, tmin = 0xFFFFFFFFu;
-    for (uint32_t k = 0; k < 64; ++k) {
-        const uint32_t x = tid * 64 + k; const int64_t c = cnt[x]; const uint32_t d = taken[x];
-        if ((int64_t)d > c) { ++n; m += d; }
-        else { const unsigned long long q = cut[x]; if (q != 0ull && q != ~0ull && (int64_t)d < c) { ++under; tmin = min(tmin, (uint32_t)((q - 1ull) >> key_shift)); cut[x] = ~0ull; } }
-    }
+    uint32_t n = 0, m = 0;
+    for (uint32_t k = 0; k < 64; ++k) { const uint32_t x = tid * 64 + k; const uint32_t d = taken[x]; if ((int64_t)d > cnt[x]) { ++n; m += d; } }
     s_n[tid] = n; s_m[tid] = m;
-    if (under) { atomicAdd(&s_under, under); atomicMin(&s_tmin, tmin); }
     __syncthreads();
     for (uint32_t d = 1; d < 1024; d <<= 1) {                                      // inclusive scans of both counts
         const uint32_t a = tid >= d ? s_n[tid - d] : 0u, b = tid >= d ? s_m[tid - d] : 0u;
@@ -408,7 +411,7 @@ __global__ void __launch_bounds__(1024) k_stock_check(const int64_t* __restrict_
         const uint32_t x = tid * 64 + k; const uint32_t d = taken[x];
         if ((int64_t)d > cnt[x]) { eidx[x] = e; etype[e] = x; estart[e] = off; ++e; off += d; } else eidx[x] = 0xFFFFFFFFu;
     }
-    if (tid == 1023) { info[0] = s_n[1023]; info[1] = s_m[1023]; info[2] = s_under; info[3] = s_tmin; info[5] = 0; info[6] = s_tmin; }
+    if (tid == 0) { info[5] = 0; info[6] = 0xFFFFFFFFull - info[3]; }
 }
 // the attachments of the over-demanded types: (type's number, key) of every one the pass has made, in any order
 template <bool FROM_FRAG, int G>
@@ -618,6 +621,159 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(G == 4 
     if (gl == 0 && t < nt) valid[t] = v;
 }
 
+// ------------------------------------------------------------------------------------------------
+// K1a' attach, semi amplicons, DENSE: one lane = one primer.  k_attach<false, 4> gives every semi amplicon four lanes and
+//      walks its budget (Poisson, mean 6.5) four primers at a time: 27 of 64 lanes worked (profiles/r03n_bench_sq.csv).  Here the
+//      pass's primers are numbered through -- item s = slot_off[t] + i, which is also where the attachment is recorded -- and a
+//      wave takes the templates whose first item lies in [56 w, 56 w + 56) with ALL their primers, lane by lane (eight lanes of
+//      slack for the last template's overhang; what does not fit, or more than the bitmap rows hold, goes to a further chunk of
+//      the same wave).  The templates of a chunk are segments of the wave, delimited by head flags; the speculative evaluation
+//      and the in-order commit are k_attach's, with the group masks read from the segment bounds.  k_attach_plan maps the
+//      items to their templates (slot_tmpl, free until k_expand_items rewrites it) and the waves to their first template.
+// ------------------------------------------------------------------------------------------------
+#define ATTACH_DENSE_STRIDE 56u
+__global__ void __launch_bounds__(256) k_attach_plan(const uint32_t* __restrict__ slot_off, uint32_t nt, uint32_t n_slots, uint32_t n_waves, uint32_t* __restrict__ item_tmpl,
+                                                     uint32_t* __restrict__ wave_first, uint32_t* __restrict__ valid) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t > nt) return;
+    const uint32_t h = slot_off[t];                                                // (slot_off[nt] = n_slots)
+    const uint32_t lo = t == 0 ? 0u : slot_off[t - 1] / ATTACH_DENSE_STRIDE + 1u;  // the waves w with slot_off[t - 1] < 56 w <= slot_off[t]: t is their first template
+    const uint32_t hi = t == nt ? n_waves : min(h / ATTACH_DENSE_STRIDE, n_waves);
+    for (uint32_t w = lo; w <= hi; ++w) wave_first[w] = t;
+    if (t == nt) return;
+    const uint32_t e = slot_off[t + 1];
+    for (uint32_t k = h; k < e; ++k) item_tmpl[k] = t;
+    if (e == h) valid[t] = 0;                                                      // no primer: nothing attached (no lane of the pass will say so)
+}
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 8))) k_attach_dense(const uint8_t* __restrict__ g, DevFrags fr, DevAmps semis, DevErrPool spool,
+                                               const uint32_t* __restrict__ slot_off, uint32_t* __restrict__ slots, const uint32_t* __restrict__ item_tmpl, const uint32_t* __restrict__ wave_first,
+                                               uint32_t* __restrict__ valid, const unsigned long long* __restrict__ primer_cut, uint32_t* __restrict__ primer_delta,
+                                               AmplifyParams p, uint32_t w_first, uint32_t n_waves, uint32_t row_words, int undo, const unsigned long long* __restrict__ t_from) {
+    __shared__ uint32_t s_bits[1024];                                              // position bitmaps: 1024 / row_words rows, one per template of the chunk
+    const uint32_t lane = threadIdx.x, w = w_first + blockIdx.x;
+    if (w >= n_waves) return;
+    const uint32_t t0 = wave_first[w], t1 = wave_first[w + 1];
+    if (t1 <= t0) return;
+    const uint32_t tf = t_from ? (uint32_t)min(*t_from, 0xFFFFFFFFull) : 0u;
+    if (t1 <= tf) return;                                                          // a run-again touches the templates from *t_from on
+    const uint32_t end = slot_off[t1], max_rows = 1024u / row_words, aux = 1u | (p.pass << 1);
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    uint32_t item0 = slot_off[t0];
+    bool carry_open = false, carry_abort = false; uint32_t carry_v = 0;            // the template cut by the previous chunk's end: still open? aborted? its count so far
+    while (item0 < end) {                                                          // (wave-uniform)
+        const uint32_t item = item0 + lane; const bool has = item < end;
+        uint32_t t = 0, i = 0, len = 0, budget = 0; uint64_t tuid = 0, errs = 0; View tv{0, 1, 0};
+        if (has) {
+            t = item_tmpl[item]; i = item - slot_off[t];
+            const uint32_t f = semis.parent[t], sl = semis.sl[t];
+            len = sl_len(sl); budget = semis.primers[t]; tuid = semis.uid[t]; errs = semis.errs[t];
+            tv = semi_tmpl_view(frag_view(fr.goff[f], fr.len[f], fr.strand[f]), sl_spos(sl), len);
+        }
+        // segments: a lane is a head when its primer is its template's first -- or the chunk's first lane (a template cut by the
+        // previous chunk).  Row = the segment's number in the chunk; the chunk ends before the first segment without a row.
+        const unsigned long long hm0 = __ballot(has && (i == 0u || lane == 0u));
+        const uint32_t row = (uint32_t)__popcll(hm0 & (lt_mask | (1ull << lane))) - 1u;
+        const bool in = has && row < max_rows;
+        const unsigned long long inm = __ballot(in), hm = hm0 & inm;
+        const uint32_t n_in = (uint32_t)__popcll(inm);                               // the chunk's lanes are 0 .. n_in - 1
+        const uint32_t seg_lo = 63u - (uint32_t)__builtin_clzll((hm & (lt_mask | (1ull << lane))) | 1ull);
+        const unsigned long long above = hm & ~(lt_mask | (1ull << lane));
+        const uint32_t seg_hi = above ? (uint32_t)__ffsll((long long)above) - 1u : n_in;   // one past my segment's last lane
+        const unsigned long long gmask = in ? ((seg_hi >= 64u ? ~0ull : (1ull << seg_hi) - 1ull) & ~((1ull << seg_lo) - 1ull)) : 0ull;
+        const bool cont = in && seg_lo == 0u && carry_open && __shfl((int)i, 0) != 0;   // my segment continues the template the last chunk cut
+        const bool skip = in && t < tf;
+        uint32_t* bits = s_bits + row * row_words;
+        // the type under a position of my template (k_attach's primer_type)
+        auto primer_type = [&](uint32_t sp, bool& hasN) -> uint32_t {
+            unsigned long long v8 = view_bases8(g, tv, sp);
+            for_each_err(errs, spool.data, [&](uint32_t e) {
+                const uint32_t k = len - 1u - err_pos(e) - sp;
+                if (k < 8u) v8 = (v8 & ~(0xFFull << (8u * k))) | ((unsigned long long)(3u - err_alt(e)) << (8u * k));
+            });
+            hasN = (v8 & 0xFCFCFCFCFCFCFCFCull) != 0;
+            uint32_t idx = 0;
+#pragma unroll
+            for (uint32_t k = 0; k < 8; ++k) idx = (idx << 2) | ((uint32_t)(v8 >> (8u * k)) & 3u);
+            return idx;
+        };
+        if (undo && in && !skip && i < valid[t]) { bool hn; const uint32_t idx = primer_type(sl_spos(slots[item]), hn); atomicSub(&primer_delta[idx], 1u); }
+        // bitmap rows: row 0 keeps the cut template's positions (moved there at the last chunk's end), the others start empty
+        __builtin_amdgcn_wave_barrier();
+        {   const uint32_t rows = (uint32_t)__popcll(hm), total = rows * row_words;
+            const uint32_t keep = (carry_open && __shfl((int)i, 0) != 0) ? row_words : 0u;
+            for (uint32_t k = lane; k < total; k += 64u) if (k >= keep) s_bits[k] = 0u;
+        }
+        __builtin_amdgcn_wave_barrier();
+        bool unresolved = in && !skip && len >= p.amp_min + 27u && !(cont && carry_abort);
+        bool need = unresolved, dead = false; uint32_t tries = 0, spos = 0, alen = 0, pidx = 0;
+        const AttachFit fit = unresolved ? attach_fit_count(len, p.amp_min, p.amp_max) : AttachFit{0, 1, 0, 1};
+        const double qfail = 1.0 - (double)fit.N / ((double)(len > 27 ? len - 27 : 1) * (double)fit.W);
+        Xoshiro xt{}; if (unresolved) xt.seed(draw4(p.key, ST_ATTACH, aux, tuid, i));
+        bool aborted = cont && carry_abort; uint32_t v_abort = cont ? carry_v : 0u; // my segment: abandoned at primer v_abort
+        while (__ballot(unresolved)) {
+            if (unresolved && !dead) {
+                const uint32_t bp = spos - 27u;
+                if (!need && ((bits[bp >> 5] >> (bp & 31u)) & 1u)) need = true;       // a lower primer took this position meanwhile
+                while (need) {
+                    bool cand = false;
+                    while (!cand) {
+                        tries += attach_gap(((double)xt.next() + 0.5) / 4294967296.0, qfail) + 1u;
+                        if (tries > 50) { dead = true; break; }
+                        const unsigned long long x64 = ((unsigned long long)xt.next() << 32) | xt.next();
+                        attach_fit_decode(fit, len, p.amp_min, (uint32_t)__umul64hi(x64, (unsigned long long)fit.N), spos, alen);
+                        const uint32_t b2 = spos - 27u;
+                        if ((bits[b2 >> 5] >> (b2 & 31u)) & 1u) continue;              // posAttached[spos]
+                        cand = true;
+                    }
+                    if (dead) break;
+                    bool hasN; const uint32_t idx = primer_type(spos, hasN);
+                    if (hasN || attach_key<false>(t, i) > primer_cut[idx]) continue;  // no stock (none for N 8-mers): the try counts, the next one follows
+                    pidx = idx; need = false;
+                }
+            }
+            // blocked = a lower unresolved live lane of my segment proposes the same position
+            const bool live = unresolved && !dead;
+            const unsigned long long um = __ballot(live);
+            bool blocked = false;
+            for (uint32_t d = 1; __ballot(in && lane >= seg_lo + d); ++d) {
+                const uint32_t src = lane >= d ? lane - d : 0u;
+                const uint32_t sj = (uint32_t)__shfl((int)spos, (int)src);
+                if (live && lane >= seg_lo + d && ((um >> src) & 1ull) && sj == spos) blocked = true;
+            }
+            const unsigned long long bm = __ballot(live && blocked) & gmask, dm = __ballot(unresolved && dead) & gmask;
+            const uint32_t first_blocked = bm ? (uint32_t)__ffsll((long long)bm) - 1u : 64u, first_dead = dm ? (uint32_t)__ffsll((long long)dm) - 1u : 64u;
+            if (live && lane < first_blocked && lane < first_dead) {                  // commit, in primer order
+                const uint32_t bp = spos - 27u;
+                atomicOr(&bits[bp >> 5], 1u << (bp & 31u));
+                atomicAdd(&primer_delta[pidx], 1u);
+                slots[item] = pack_sl(spos, alen);
+                unresolved = false;
+            }
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t vi = (uint32_t)__shfl((int)i, (int)(first_dead < 64u ? first_dead : lane));
+            if (first_dead < 64u && first_dead <= first_blocked) {                     // the template abandons its remaining primers (> 50 tries)
+                if (in && !aborted) { aborted = true; v_abort = vi; }
+                if (lane >= first_dead) unresolved = false;
+            }
+        }
+        // what my template attached: its budget, or the primer it was abandoned at.  A template cut by the chunk's end waits.
+        const uint32_t last = n_in - 1u;                                              // the chunk's last lane
+        const uint32_t l_t = (uint32_t)__shfl((int)t, (int)last), l_i = (uint32_t)__shfl((int)i, (int)last), l_b = (uint32_t)__shfl((int)budget, (int)last);
+        const bool open_next = l_i + 1u < l_b;                                         // the last segment's template has primers beyond the chunk
+        const bool mine_open = in && open_next && t == l_t && seg_hi == n_in;
+        const bool ok_len = len >= p.amp_min + 27u;
+        if (in && !skip && lane == seg_lo && !mine_open) valid[t] = aborted ? v_abort : (ok_len ? budget : 0u);
+        // carry the cut template over: abort state, and its bitmap row to row 0
+        const uint32_t l_row = (uint32_t)__shfl((int)row, (int)last);
+        const bool l_ab = __shfl((int)(aborted ? 1 : 0), (int)last) != 0; const uint32_t l_v = (uint32_t)__shfl((int)v_abort, (int)last);
+        __builtin_amdgcn_wave_barrier();
+        if (open_next && l_row != 0u) { for (uint32_t k = lane; k < row_words; k += 64u) s_bits[k] = s_bits[l_row * row_words + k]; }
+        __builtin_amdgcn_wave_barrier();
+        carry_open = open_next; carry_abort = l_ab; carry_v = l_v;
+        item0 += n_in;
+    }
+}
+
 void launch_attach_frags(hipStream_t s, const uint8_t* g, DevFrags fr, const uint32_t* slot_off, uint32_t* slots, uint32_t* slot_tmpl,
                          uint32_t* valid, const unsigned long long* primer_cut, uint32_t* primer_delta, unsigned long long* len_part, AmplifyParams p,
                          uint32_t t_first, uint32_t t_end, int undo, const unsigned long long* t_from) {
@@ -643,6 +799,19 @@ static int attach_semi_group(uint32_t n_semis) {
     static const int forced = seam_env("SCS_ATTACH_G") ? atoi(seam_env("SCS_ATTACH_G")) : 0;   // tuning experiments
     return forced == 2 || forced == 4 || forced == 8 || forced == 16 ? forced : (n_semis >= (1u << 18) ? 4 : 8);
 }
+uint32_t attach_dense_waves(uint32_t n_slots) { return n_slots / ATTACH_DENSE_STRIDE + 1u; }
+// once per pass: items -> templates (item_tmpl: n_slots words), waves -> their first template (wave_first: attach_dense_waves + 1 words)
+void launch_attach_plan(hipStream_t s, const uint32_t* slot_off, uint32_t nt, uint32_t n_slots, uint32_t* item_tmpl, uint32_t* wave_first, uint32_t* valid) {
+    hipLaunchKernelGGL(k_attach_plan, dim3(cdiv((uint64_t)nt + 1, 256)), dim3(256), 0, s, slot_off, nt, n_slots, attach_dense_waves(n_slots), item_tmpl, wave_first, valid);
+}
+void launch_attach_dense(hipStream_t s, const uint8_t* g, DevFrags fr, DevAmps semis, DevErrPool spool, const uint32_t* slot_off, uint32_t* slots, const uint32_t* item_tmpl,
+                         const uint32_t* wave_first, uint32_t n_slots, uint32_t* valid, const unsigned long long* primer_cut, uint32_t* primer_delta, AmplifyParams p, int undo,
+                         const unsigned long long* t_from) {
+    // a bitmap row holds the positions 27 .. len - amp_min of a template (len <= amp_max)
+    const uint32_t row_words = (p.amp_max > p.amp_min ? (p.amp_max - p.amp_min) / 32u : 0u) + 2u;
+    hipLaunchKernelGGL(k_attach_dense, dim3(attach_dense_waves(n_slots)), dim3(64), 0, s, g, fr, semis, spool, slot_off, slots, item_tmpl, wave_first, valid, primer_cut, primer_delta, p, 0u,
+                       attach_dense_waves(n_slots), std::min(row_words, 1024u), undo, t_from);
+}
 void launch_attach_semis(hipStream_t s, const uint8_t* g, DevFrags fr, DevAmps semis, uint32_t n_semis, DevErrPool spool,
                          const uint32_t* slot_off, uint32_t* slots, uint32_t* slot_tmpl, uint32_t* valid,
                          const unsigned long long* primer_cut, uint32_t* primer_delta, AmplifyParams p, uint32_t t_first, uint32_t t_end, int undo, const unsigned long long* t_from) {
@@ -654,8 +823,12 @@ void launch_attach_semis(hipStream_t s, const uint8_t* g, DevFrags fr, DevAmps s
 #undef SCS_LAUNCH_ATTACH_SEMI
 }
 // exact primer stock (k_stock_* above; the loop is exact_stock in scs_pipeline.cpp)
-void launch_stock_check(hipStream_t s, const int64_t* cnt, const uint32_t* taken, unsigned long long* cut, bool from_frag, uint32_t* eidx, uint32_t* etype, uint32_t* estart, unsigned long long* info) {
-    hipLaunchKernelGGL(k_stock_check, dim3(1), dim3(1024), 0, s, cnt, taken, cut, from_frag ? 20 : 12, eidx, etype, estart, info);
+void launch_stock_check(hipStream_t s, const int64_t* cnt, const uint32_t* taken, unsigned long long* cut, bool from_frag, unsigned long long* info) {
+    (void)hipMemsetAsync(info, 0, 64, s);
+    hipLaunchKernelGGL(k_stock_check, dim3(256), dim3(256), 0, s, cnt, taken, cut, from_frag ? 20 : 12, info);
+}
+void launch_stock_list(hipStream_t s, const int64_t* cnt, const uint32_t* taken, uint32_t* eidx, uint32_t* etype, uint32_t* estart, unsigned long long* info) {
+    hipLaunchKernelGGL(k_stock_list, dim3(1), dim3(1024), 0, s, cnt, taken, eidx, etype, estart, info);
 }
 void launch_stock_collect(hipStream_t s, const uint8_t* g, DevFrags fr, DevAmps semis, DevErrPool spool, bool from_frag, const uint32_t* slot_off, const uint32_t* slots,
                           const uint32_t* valid, const uint32_t* eidx, unsigned long long* list, unsigned long long* info, uint32_t t_first, uint32_t t_end) {

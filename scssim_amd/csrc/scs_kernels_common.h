@@ -176,6 +176,10 @@ __device__ __forceinline__ void block_add_u64(unsigned long long v, unsigned lon
 }
 
 
+// (Round 4 tried an XCD-aware order of the workgroups for k_attach<semi> and k_errs -- every XCD a contiguous eighth of the amplicon
+// list, so that its L2 holds the fragments of an eighth of the workgroups in flight: k_attach unchanged, k_errs<semi->full> 1.47 ->
+// 1.92 ms per pass at 600 Mb.  With the hardware's round-robin the eight XCDs work on ONE stretch of the genome at a time and share its
+// lines in the Infinity Cache; eight distant stretches at once cost more than the L2 hits bring.  profiles/r04_attach_ab_xcd.log)
 static inline uint32_t cdiv(uint64_t a, uint32_t b) { return (uint32_t)((a + b - 1) / b); }
 // launch errors are latched (scs_k_misc.hip) and surfaced by the pipeline at its next check (take_launch_error)
 void note_launch(hipError_t e);
