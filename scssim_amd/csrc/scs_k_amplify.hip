@@ -630,6 +630,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(G == 4 
 //      the same wave).  The templates of a chunk are segments of the wave, delimited by head flags; the speculative evaluation
 //      and the in-order commit are k_attach's, with the group masks read from the segment bounds.  k_attach_plan maps the
 //      items to their templates (slot_tmpl, free until k_expand_items rewrites it) and the waves to their first template.
+//      Measured (profiles/r04_attach_ab_dense_vs_groups.log, 600 Mb): 42 lanes per VALU instruction instead of 27 -- and the same
+//      2.5 ms per pass: a wave's round costs what it costs whatever the number of lanes in it (1.09e9 against 1.13e9
+//      wave-instructions per pass), and a round of 56 primers replaces 1.6 rounds of the sixteen groups' 104.  The per-template
+//      table of attach_gap's thresholds (the gap by bisection instead of the loop the wave's slowest lane sets the length of)
+//      took 38 % of the scalar and 5 % of the vector instructions out and gave 2.66 ms (its 3.5 KB of LDS cost a wave per
+//      SIMD): the pass is priced by its fp64 / 32-bit-multiply instructions (Philox seeding, the 64-bit scaling of the draw,
+//      the decode's division and square root), not by loop control.  Not kept.
 // ------------------------------------------------------------------------------------------------
 #define ATTACH_DENSE_STRIDE 56u
 __global__ void __launch_bounds__(256) k_attach_plan(const uint32_t* __restrict__ slot_off, uint32_t nt, uint32_t n_slots, uint32_t n_waves, uint32_t* __restrict__ item_tmpl,
