@@ -43,7 +43,8 @@ __device__ __forceinline__ void stock_update(uint32_t i, int64_t* __restrict__ c
         const unsigned long long o = ((unsigned long long)(uint32_t)__shfl_xor((int)(left >> 32), d) << 32) | (uint32_t)__shfl_xor((int)left, d);
         left = o < left ? o : left;
     }
-    if ((threadIdx.x & 63u) == 0 && left != ~0ull) atomicMin(&sums[DS_MIN_STOCK], left);
+    // (a thousand waves' atomics on one word cost the pass 13 us on a small job: only a wave that undercuts the word's last value speaks)
+    if ((threadIdx.x & 63u) == 0 && left < __hip_atomic_load(&sums[DS_MIN_STOCK], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&sums[DS_MIN_STOCK], left);
 }
 // sharded job.  What the shards owe each other besides what they took from the stock -- the semi amplicons a fragment pass
 // made (count, total length) and the budgets the last setPrimers handed out -- rides on the pass's closing all-reduce, as
