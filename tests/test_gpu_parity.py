@@ -468,7 +468,7 @@ def test_bench_single_gpu_contract(tmp_path):
     assert "part files per mate" in d["config"]["output"] and "/" in d["config"]["output"] and d["config"]["sink_GBps"] > 0
     assert d["generation_hbm"]["value"] > d["value"] and d["d2h_only"]["value"] > 0
     assert rf["kernel"] == "k_reads" and rf["timed_launches"] > 0 and rf["generation_hbm_leg"]["timed_launches"] > 0 and d["roofline_amplification"]["frac"] > 0
-        assert "timed region" in rf["timing"] and d["cpu_baseline"].get("unpinned", {}).get("value", 1) > 0
+    assert "timed region" in rf["timing"] and d["cpu_baseline"].get("unpinned", {}).get("value", 1) > 0
     assert isinstance(d["sweep"], list) and len(d["sweep"]) == 2 and all(x["generation_hbm_pairs_per_s"] > 0 for x in d["sweep"])
     assert d["cli_wall"].get("value", 0) > 0, d["cli_wall"]
     assert abs(d["value"] - d["config"]["pairs_per_step"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 0.05
