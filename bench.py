@@ -423,7 +423,7 @@ def roofline_of(ktimes, fq_bytes, L, dom=None):
         draws = None; draws_note = None
         survey_alg = 1526.0 * made
     achieved = alg / (kd["ms"] * 1e-3) / 1e9 if kd["ms"] > 0 else 0.0
-    prefix = {"k_reads": "scs::k_reads", "k_indels": "scs::k_indels", "k_attach<semi>": "scs::k_attach<false", "k_attach<frag>": "scs::k_attach<true",
+    prefix = {"k_reads": "scs::k_reads", "k_indels": "scs::k_indels", "k_attach<semi>": "scs::k_attach_dense", "k_attach<frag>": "scs::k_attach<true",
               "k_errs<semi->full>": "scs::k_errs<false>", "k_errs<frag->semi>": "scs::k_errs<true>"}[dom]
     cc = committed_counters(prefix)
     # the committed counters are per launch of the profiled command (one GPU, 8 M-pair batches); a sharded run launches smaller
