@@ -301,6 +301,43 @@ def test_primer_exhaustion_bit_exact(oracle_bin, models, repeat_genome, tmp_path
     print("exhaustion: %d types dry, %d passes with a dry type, %d rounds, %d checks" % ((got_stock == 0).sum(), st["stock_exhausted_passes"], st["stock_rounds"], st["stock_checks"]))
 
 
+def test_primer_exhaustion_of_every_usable_type_bit_exact(oracle_bin, models, tmp_path):
+    """A genome of A and T alone: 256 primer types carry every attachment, and at -p 10000 -r 1e-8 all of them run dry in the course of
+    an 8 Mb job, dozens in the same pass -- the cuts of one round move each other's (exact_stock iterates), later passes start with
+    most types at 0.  Amplicon tables, stock and FASTQ against the oracle."""
+    rng = np.random.default_rng(23)
+    n = 8000000
+    seq = np.frombuffer(b"AT", np.uint8)[rng.integers(0, 2, size=n)]
+    fa = str(tmp_path / "at.fa")
+    with open(fa, "wb") as f:
+        for hap in (1, 2):
+            f.write(b">7_%d_%d\n" % (hap, n))
+            f.write(np.concatenate([seq.reshape(-1, 100), np.full((n // 100, 1), 10, np.uint8)], axis=1).tobytes())
+    seed, stock, gamma = 41, 10000, 1e-8
+    prefix = str(tmp_path / "orc")
+    _oracle_run(oracle_bin, fa, models["Illumina_HiSeqXTen"], prefix, ["-c", "0.2", "-p", str(stock), "-r", repr(gamma)], seed, dump=prefix)
+    prim = np.loadtxt(prefix + ".primers.tsv", dtype=np.int64)
+    want_stock = np.full(65536, stock, np.int64); want_stock[prim[:, 0]] = prim[:, 2]
+    assert (want_stock == 0).sum() >= 200 and (prim[:, 1] + prim[:, 2] == stock).all()
+    g = scssim_amd.GenReads(profile=models["Illumina_HiSeqXTen"], input_fasta=fa, coverage=0.2, seed=seed, primers=stock, gamma=gamma)
+    g.create_frags(); g.amplify()
+    st = g.stats()
+    got_stock = g.download_primer_stock()
+    bad = np.nonzero(got_stock != want_stock)[0]
+    assert len(bad) == 0, "primer stock differs for %d types, e.g. %s: got %s want %s" % (len(bad), bad[:6], got_stock[bad[:6]], want_stock[bad[:6]])
+    for kind, name in ((0, "semis"), (1, "fulls")):
+        a = g.download_amplicons(kind)
+        w = np.loadtxt(prefix + "." + name + ".tsv", dtype=np.int64, usecols=(1, 2, 3, 4), delimiter="\t")
+        assert len(a["parent"]) == len(w), name
+        for k, col in enumerate(("parent", "spos", "len", "gc")):
+            assert np.array_equal(a[col].astype(np.int64), w[:, k]), "%s.%s" % (name, col)
+    g.allocate_reads(0)
+    fq1, fq2 = g.yield_reads()
+    assert fq1 == open(prefix + "_1.fq", "rb").read() and fq2 == open(prefix + "_2.fq", "rb").read()
+    print("AT genome: %d types dry, %d passes with a dry type, %d rounds" % ((got_stock == 0).sum(), st["stock_exhausted_passes"], st["stock_rounds"]))
+    assert st["stock_exhausted_passes"] >= 1 and st["stock_rounds"] >= 2, "hundreds of cuts in one pass move each other: more than one round"
+
+
 @pytest.mark.parametrize("world,hooks", [(2, "device"), (3, "host")])
 def test_primer_exhaustion_sharded_equals_whole_job(world, hooks, oracle_bin, models, repeat_genome, tmp_path):
     """The same regime as 2 and 3 shards: the shards' demand is summed, the pass in which a type runs dry is run again segment by
