@@ -84,7 +84,7 @@ enum { DS_SEMI_LEN = 4, DS_SEMIS_N = 5, DS_REPORTED_LEN = 6, DS_G_SEMIS_N = 8, D
 enum { SHARD_TAIL_WORDS = 16 };                       // u32 words behind the 65536 primer decrements that ride on the same all-reduce
 struct AllocState { double total; unsigned long long sum_rn, sum_quota; };
 
-// ---- read allocation over the whole job's amplicon list, computed by the shards (scs_kernels.hip, K3) ---------------
+// ---- read allocation over the whole job's amplicon list, computed by the shards (scs_k_allocate.hip, K3) ---------------
 // The list is cut into chunks of 1000 (randIndx_hp's chunks, MyDefine.cpp:203-253).  A shard's local list is the
 // concatenation of its segments (cycle ascending, fragment pass descending: slot = cycle * 8 + (7 - pass)); the whole
 // job's list interleaves the shards' segments slot by slot (order = slot * shards + rank).
@@ -116,9 +116,9 @@ struct PairRec {
     uint64_t e1, e2, uid;             // error words of the semi / the full amplicon; lineage uid
 };
 
-// ---- launch wrappers (scs_kernels.hip) --------------------------------------------------------------
+// ---- launch wrappers (scs_k_*.hip) --------------------------------------------------------------
 // one pass of primer attachment over the templates [t_first, t_end) of the pass's list; primer_cut: the stock as k_attach sees it
-// (scs_kernels.hip, "the primer stock, exactly"); undo: the templates were run before in this pass -- what they took then is taken back first
+// (scs_k_amplify.hip, "the primer stock, exactly"); undo: the templates were run before in this pass -- what they took then is taken back first
 void launch_attach_frags(hipStream_t s, const uint8_t* g, DevFrags fr, const uint32_t* slot_off, uint32_t* slots,
                          uint32_t* slot_tmpl, uint32_t* valid, const unsigned long long* primer_cut, uint32_t* primer_delta,
                          unsigned long long* len_part, AmplifyParams p, uint32_t t_first, uint32_t t_end, int undo, const unsigned long long* t_from);   // len_part: one slot per fragment; t_from (device, or null): skip the templates before it

@@ -368,7 +368,7 @@ __global__ void __launch_bounds__(1024) k_poisson_sums(const unsigned long long*
 //     An attachment's place in that order is its key (template index, primer index).  k_attach takes a type when
 //     key <= cut[type].  A pass starts with cut = "all of the pass" for every type in stock (none for the others): if no
 //     type was then taken more often than it has stock -- every pass of a job whose primers do not run out -- the pass IS
-//     the sequential loop's result.  Otherwise (exact_stock in scs_pipeline.cpp) the over-demanded types get the key of
+//     the sequential loop's result.  Otherwise (exact_stock in scs_amplify.cpp) the over-demanded types get the key of
 //     their stock-th attachment as cut (k_stock_collect, a sort, k_stock_pick) and the templates from the earliest such
 //     key on are run again (k_attach with undo); what they now take elsewhere may move other cuts, so this repeats until
 //     no type is over its stock and no cut type under it: at that fixed point every decision equals the sequential
@@ -830,7 +830,7 @@ void launch_attach_semis(hipStream_t s, const uint8_t* g, DevFrags fr, DevAmps s
     if (G == 2) SCS_LAUNCH_ATTACH_SEMI(2); else if (G == 16) SCS_LAUNCH_ATTACH_SEMI(16); else if (G == 8) SCS_LAUNCH_ATTACH_SEMI(8); else SCS_LAUNCH_ATTACH_SEMI(4);
 #undef SCS_LAUNCH_ATTACH_SEMI
 }
-// exact primer stock (k_stock_* above; the loop is exact_stock in scs_pipeline.cpp)
+// exact primer stock (k_stock_* above; the loop is exact_stock in scs_amplify.cpp)
 void launch_stock_check(hipStream_t s, const int64_t* cnt, const uint32_t* taken, unsigned long long* cut, bool from_frag, unsigned long long* info) {
     (void)hipMemsetAsync(info, 0, 64, s);
     hipLaunchKernelGGL(k_stock_check, dim3(256), dim3(256), 0, s, cnt, taken, cut, from_frag ? 20 : 12, info);

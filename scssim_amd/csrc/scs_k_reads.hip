@@ -123,7 +123,7 @@ template <> struct RingGeo<16>  { enum { SLOTS = 16, GROUP = 8, QROW = 5,  ABITS
 template <> struct RingGeo<64>  { enum { SLOTS = 8,  GROUP = 4, QROW = 20, ABITS = 6 }; };
 template <> struct RingGeo<128> { enum { SLOTS = 4,  GROUP = 2, QROW = 40, ABITS = 7 }; };
 template <int QK> struct RingBin { uint4 qd[4][RingGeo<QK>::QROW]; uint32_t subs[64][3]; };
-// the uniform walk's bin: the 3-mers' KEEP intervals (lo, width) instead of their threshold triples (scs_pipeline.cpp ring_image_u)
+// the uniform walk's bin: the 3-mers' KEEP intervals (lo, width) instead of their threshold triples (scs_stage.cpp ring_image_u)
 template <int QK> struct RingBinU { uint4 qd[4][RingGeo<QK>::QROW]; uint32_t keep[64][2]; };
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));

@@ -71,7 +71,7 @@ struct FastaRecord { std::string name; std::vector<uint8_t> code; };
 // make_index: also leave <path>.fai beside the file when there is none, as the reference does (fastahack, Fasta.cpp:241-249)
 void load_fasta(const std::string& path, std::vector<FastaRecord>& out, bool make_index = false);
 void encode_record(const char* name, const char* seq, uint64_t len, FastaRecord& out);
-// pieces of load_fasta for the GPU-side parser (scs_pipeline.cpp stage_fasta_on_device): the plain path of a possibly
+// pieces of load_fasta for the GPU-side parser (scs_stage.cpp stage_fasta_on_device): the plain path of a possibly
 // gzip'ed input (inflated beside itself with `gzip -cd`, Genome.cpp:183-187), the index name of a header line, and the
 // .fai beside the file (written only when absent) from the header offsets and record lengths the device found
 std::string fasta_plain_path(const std::string& path);

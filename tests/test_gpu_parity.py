@@ -271,7 +271,7 @@ def test_sharded_gpu_job_equals_whole_job(world, case, model, cov, layout, hooks
 # ---- the exhaustion regime (Malbac::updatePrimerCount, Malbac.cpp:91-103): a primer type is used exactly `stock`
 # times, by the first `stock` attachments in list order that ask for it.  The repeat-rich genome of tests/conftest.py at
 # -p 10000 -r 1e-8 drives the 8-mers of its low-complexity runs dry; oracle: sequential live decrement (amplify_pass), HIP: the
-# cut table and its fixed point (scs_kernels.hip "the primer stock, exactly", exact_stock in scs_pipeline.cpp).
+# cut table and its fixed point (scs_k_amplify.hip "the primer stock, exactly", exact_stock in scs_amplify.cpp).
 def test_primer_exhaustion_bit_exact(oracle_bin, models, repeat_genome, tmp_path):
     seed, stock = 31, 10000
     prefix = str(tmp_path / "orc")
