@@ -53,7 +53,7 @@ void shard_close(scs_ctx* c, const uint32_t* new_semis) {
 }
 
 // ---------------------------------------------------------------- a2: the primer stock, exactly (Malbac::updatePrimerCount, Malbac.cpp:91-103)
-// The kernels and the argument are in scs_kernels.hip ("the primer stock, exactly").  Here: the loop.
+// The kernels and the argument are in scs_k_amplify.hip ("the primer stock, exactly").  Here: the loop.
 static void attach_range(scs_ctx* c, bool from_frag, const AmplifyParams& p, uint32_t lo, uint32_t hi, int undo, const unsigned long long* t_from) {
     hipStream_t s = c->stream;
     const uint32_t* slot_off = (from_frag ? c->slot_off_f : c->slot_off_s).as<uint32_t>();

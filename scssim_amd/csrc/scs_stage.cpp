@@ -11,7 +11,7 @@ void do_load_profile(scs_ctx* c, const char* path) {
     upload(c->d_subs1, P.subs1, s); upload(c->d_subs2, P.subs2, s); upload(c->d_qual, P.qual, s);
     upload(c->d_ins, P.ins_cdf, s); upload(c->d_del, P.del_cdf, s); upload(c->d_isize, P.isize_cdf, s);
     std::vector<double> gm(P.gc_means, P.gc_means + 101); upload(c->d_gcmeans, gm, s);
-    // the bins as k_reads keeps them in its LDS ring (scs_kernels.hip RingBin): the four diagonal alias rows (c, c), then the
+    // the bins as k_reads keeps them in its LDS ring (scs_k_reads.hip RingBin): the four diagonal alias rows (c, c), then the
     // threshold triples of the 64 clean 3-mers; a workgroup refills its ring with straight 16-byte copies of this image
     auto ring_image = [&](const std::vector<uint32_t>& subs_t) {
         const size_t B = (size_t)P.bins, qw = (size_t)P.qual_k + (size_t)P.qual_k / 4, bw = 4 * qw + 192, Bpad = (B + 7) & ~(size_t)7;
