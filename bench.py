@@ -654,9 +654,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        pairs = fqb = amps = 0
+        pairs = fqb = amps = 0; per_step = []
         for i in range(n_steps):
+            ts = time.perf_counter()
             last = step(first + n_warm + i, kt, stage, mode)
+            per_step.append(time.perf_counter() - ts)                   # (this rank's view; the timed region is the barrier-to-barrier total)
             pairs += last["pairs_written"]; fqb += sum(last["fastq_bytes"]); amps += last["semi_amplicons"] + last["full_amplicons"]
         torch.cuda.synchronize()
         if world > 1:
@@ -679,7 +681,7 @@ def main():
             pairs, fqb_all, amps = int(pt[0]), int(pt[1]), int(pt[2])
         else:
             fqb_all = fqb
-        return dict(elapsed=elapsed, pairs=pairs, fq_bytes_local=fqb, fq_bytes=fqb_all, amps=amps, ktimes=kt, stage={k: v / n_steps for k, v in stage.items()}, per_rank=per_rank)
+        return dict(elapsed=elapsed, pairs=pairs, fq_bytes_local=fqb, fq_bytes=fqb_all, amps=amps, ktimes=kt, stage={k: v / n_steps for k, v in stage.items()}, per_rank=per_rank, per_step=per_step)
 
     main_mode = "null" if a.hbm_only else "files"
     R = timed(a.warmup, a.steps, main_mode, 0)
@@ -711,6 +713,9 @@ def main():
                        "sink_GBps": None if a.hbm_only else R["fq_bytes"] / max(1e-9, R["stage"]["reads"] * a.steps) / 1e9,
                        "host_cores": cores, "sink_threads_per_rank": {"writers": writers, "cleaners": n_clean, "bound_to_gpu_numa_node_cpus": len(local_cpus) or None}},
             "stages_s_per_step": R["stage"],
+            # the steps one by one (rank 0's clock): the job with files is bound by the host, and its spread from step to step and box to box
+            # (46-60 M pairs/s over rounds 3 and 4) is the host's
+            "ms_per_step_each": [1e3 * t for t in R["per_step"]],
             "per_rank": R["per_rank"],
             "kernels_ms_per_step": {k: v["ms"] / a.steps for k, v in R["ktimes"].items()},
             "setup_s": {"genome_generated_in_hbm": t_gen, "genome_staged_(encode+bit_index)": t_up},
