@@ -623,12 +623,16 @@ def main():
         t2 = time.perf_counter(); g.allocate_reads(0)
         t3 = time.perf_counter()
         waited = 0.0
-        if mode in ("files", "bgzf"):
-            waited = cleaner.gate(GATE_BYTES)
+        if mode in ("files", "bgzf", "files_alone"):
+            waited = cleaner.gate(0 if mode == "files_alone" else GATE_BYTES)
             base = os.path.join(out_dir, "step%d" % i)
             lbase = base + (".r%d" % rank if world > 1 else "")
             pp = scssim_amd.part_paths(lbase, writers * generations, True, ".fq.gz" if mode == "bgzf" else ".fq")
-            finish = cleaner.watch([[pp[0][p], pp[1][p]] for p in range(writers * generations)], writers)
+            if mode == "files_alone":                                # one job on an EMPTY tmpfs, nothing unlinked while it runs: what a single run sees
+                def finish(extra):
+                    cleaner.add([f for p in range(writers * generations) for f in (pp[0][p], pp[1][p])] + list(extra))
+            else:
+                finish = cleaner.watch([[pp[0][p], pp[1][p]] for p in range(writers * generations)], writers)
             try:
                 # the library's file sink (SeqWriter): D2H + `writers` threads, a part file per mate each, generation by generation
                 g.yield_reads_files(base, writers, generations, mode == "bgzf")
@@ -640,7 +644,7 @@ def main():
             g.yield_reads_sink(mode)
         t4 = time.perf_counter()
         acc(ktimes, g.kernel_times(), ("k_reads", "k_indels"))
-        for k, v in (("frags", t1 - t0), ("amplify", t2 - t1), ("allocate", t3 - t2), ("reads", t4 - t3 - waited), ("wait_for_cleanup", waited)):
+        for k, v in (("frags", t1 - t0), ("amplify", t2 - t1), ("allocate", t3 - t2), ("reads", t4 - t3 - waited), ("wait_for_cleanup", waited if mode != "files_alone" else 0.0)):
             stage[k] = stage.get(k, 0.0) + v
         return g.stats()
 
@@ -759,6 +763,18 @@ def main():
             D = timed(0, 1, count_only, 200)
             out["d2h_only"] = {"value": D["pairs"] / D["elapsed"], "unit": "pairs/s", "seconds": D["elapsed"], "GBps": seen[0] / max(1e-9, D["stage"]["reads"]) / 1e9,
                                "what": "one step with a sink that only counts the bytes it is handed: D2H into pinned slots, nothing written"}
+            # ---- ONE job alone: the tmpfs empty when it starts, nothing unlinked while it runs.  The timed steps above pay, inside the
+            # timed region, for getting rid of the step before (the memory cgroup cannot hold two steps' text): 6 unlinking threads beside
+            # the 12 writers on 16 cores.  A user's single job has no step before it.
+            try:
+                cleaner.gate(0)
+                A1 = timed(0, 1, "files_alone", 250)
+                out["single_job_on_empty_tmpfs"] = {"value": A1["pairs"] / A1["elapsed"], "unit": "pairs/s", "seconds": A1["elapsed"], "stages_s": A1["stage"],
+                                                    "what": "one whole job, its 144 part files written to an empty tmpfs and kept until it is over (no older text to unlink beside it): what ONE run of the job sees; "
+                                                            "`value` above is the steady state of steps back to back, each unlinking the one before inside the timed region"}
+                cleaner.gate(0)
+            except Exception as e:
+                out["single_job_on_empty_tmpfs"] = {"error": repr(e)}
             # ---- BGZF: the same job with the text compressed on the GPU before it crosses PCIe (<...>.fq.gz parts); an extension (the
             # reference writes plain text), so a leg of its own
             try:
