@@ -165,7 +165,7 @@ struct scs_ctx {
     ProfileTables prof; bool have_profile = false; DevTables dtb{};
     DevBuf d_tables, t_gap, t_qcompact, t_guide, t_ring1, t_ring2, t_ring1u, t_ring2u, t_subs1, t_subs2, t_qual, t_ins, t_del, t_isize, d_subs1, d_subs2, d_qual, d_ins, d_del, d_isize, d_gcmeans;
     // genome + fragments
-    DevBuf gx_gc_bits, gx_n_bits, gx_gc_cnt, gx_n_cnt, gx_gc_pref, gx_n_pref, d_binom;
+    DevBuf gx_gc_bits, gx_n_bits, gx_gc_cnt, gx_n_cnt, gx_gc_pref, gx_n_pref, gx_gc_pair, d_binom;
     std::vector<FastaRecord> recs; bool have_genome = false; DevBuf genome, genome2; std::vector<uint64_t> rec_off, rec_len; uint64_t genome_bases = 0;   // recs: names only once staged
     std::vector<uint64_t> f_goff; std::vector<uint32_t> f_len; std::vector<int8_t> f_strand; std::vector<uint32_t> f_primers;
     uint64_t f_gidx_base = 0; bool have_frags = false;

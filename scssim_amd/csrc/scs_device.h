@@ -33,7 +33,8 @@ struct DevAmps {
 };
 
 // genome bit index (k_genome_bits): per 64-base word, G/C and N masks + counts before the word
-struct DevGenomeIdx { const unsigned long long* gc_bits; const unsigned long long* n_bits; const uint64_t* gc_pref; const uint64_t* n_pref; };
+struct DevGenomeIdx { const unsigned long long* gc_bits; const unsigned long long* n_bits; const uint64_t* gc_pref; const uint64_t* n_pref;
+                      const ulonglong2* gc_pair; };   // gc_pair[w] = {gc_bits[w], gc_pref[w]}: ONE 16-byte load per end of a window (k_errs reads two random places of the index per amplicon: two lines instead of four)
 
 struct DevErrPool { uint32_t* data; uint32_t* head; uint32_t cap; };
 
@@ -176,7 +177,7 @@ void launch_fasta_chunk(hipStream_t s, const uint8_t* raw, uint32_t n, unsigned 
 // simuvars: out[piece.dst ..] = upper(ref | literal pool), then the SNP / SNV alleles
 void launch_sv_build(hipStream_t s, const uint8_t* ref, const uint8_t* lit, const SvPiece* pieces, uint32_t np, const SvSubst* subs, uint32_t nsub, uint8_t* out, uint64_t total);
 void launch_genome_bits(hipStream_t s, const uint8_t* g, uint64_t n, uint64_t nwords, unsigned long long* gc_bits, unsigned long long* n_bits,
-                        uint32_t* gc_cnt, uint32_t* n_cnt, uint64_t* gc_pref, uint64_t* n_pref, void* temp, size_t temp_bytes, uint32_t* g2);   // g2: the genome at two bits per base ((nwords + 1) * 4 words)
+                        uint32_t* gc_cnt, uint32_t* n_cnt, uint64_t* gc_pref, uint64_t* n_pref, void* temp, size_t temp_bytes, uint32_t* g2, ulonglong2* gc_pair);   // g2: the genome at two bits per base ((nwords + 1) * 4 words)
 void launch_amplify_init(hipStream_t s, int64_t* primer_cnt, unsigned long long* primer_cut, int64_t copies, uint32_t* primer_delta, uint32_t* primer_gdelta, uint32_t* flags, unsigned long long* sums,
                          unsigned long long nf_all, unsigned long long frag_len_all, unsigned long long total_primers, uint32_t* pool_head_a, uint32_t* pool_head_b);   // primer_gdelta: a sharded job's exchange buffer (else null)
 void launch_primer_update(hipStream_t s, int64_t* primer_cnt, uint32_t* primer_delta, unsigned long long* primer_cut, unsigned long long* dsums, uint32_t* flags);

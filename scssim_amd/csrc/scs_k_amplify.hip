@@ -144,7 +144,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
         // ---- GC / N of the template window [spos, spos+alen)
         const int64_t first = tv.base + (int64_t)tv.dir * (int64_t)spos;
         const uint64_t ga = (uint64_t)(tv.dir > 0 ? first : first - (int64_t)(alen - 1)), gb = ga + alen;
-        int gc = (int)(bit_rank(gx.gc_bits, gx.gc_pref, gb) - bit_rank(gx.gc_bits, gx.gc_pref, ga));
+        int gc = (int)(bit_rank_pair(gx.gc_pair, gb) - bit_rank_pair(gx.gc_pair, ga));
         // the N count costs four more scattered loads: skipped for the templates of a fragment without any N (nearly all)
         int nn = fr.has_n[FROM_FRAG ? t : semis.parent[t]] ? (int)(bit_rank(gx.n_bits, gx.n_pref, gb) - bit_rank(gx.n_bits, gx.n_pref, ga)) : 0;
         if (!FROM_FRAG) for_each_err(perrs, spool.data, [&](uint32_t e) {

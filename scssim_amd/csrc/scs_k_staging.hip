@@ -177,10 +177,15 @@ void launch_frag_has_n(hipStream_t s, const uint64_t* goff, const uint32_t* len,
 }
 
 struct Widen { __host__ __device__ uint64_t operator()(uint32_t v) const { return (uint64_t)v; } };
+__global__ void __launch_bounds__(256) k_genome_pair(const unsigned long long* __restrict__ bits, const uint64_t* __restrict__ pref, uint64_t nwords, ulonglong2* __restrict__ pair) {
+    const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w <= nwords) pair[w] = make_ulonglong2(bits[w], pref[w]);
+}
 void launch_genome_bits(hipStream_t s, const uint8_t* g, uint64_t n, uint64_t nwords, unsigned long long* gc_bits, unsigned long long* n_bits,
-                        uint32_t* gc_cnt, uint32_t* n_cnt, uint64_t* gc_pref, uint64_t* n_pref, void* temp, size_t temp_bytes, uint32_t* g2) {
+                        uint32_t* gc_cnt, uint32_t* n_cnt, uint64_t* gc_pref, uint64_t* n_pref, void* temp, size_t temp_bytes, uint32_t* g2, ulonglong2* gc_pair) {
     hipLaunchKernelGGL(k_genome_bits, dim3(cdiv(nwords + 1, 256)), dim3(256), 0, s, g, n, nwords, gc_bits, n_bits, gc_cnt, n_cnt, g2);
     (void)rocprim::exclusive_scan(temp, temp_bytes, rocprim::make_transform_iterator((const uint32_t*)gc_cnt, Widen()), gc_pref, (uint64_t)0, nwords + 1, rocprim::plus<uint64_t>(), s);
     (void)rocprim::exclusive_scan(temp, temp_bytes, rocprim::make_transform_iterator((const uint32_t*)n_cnt, Widen()), n_pref, (uint64_t)0, nwords + 1, rocprim::plus<uint64_t>(), s);
+    hipLaunchKernelGGL(k_genome_pair, dim3(cdiv(nwords + 1, 256)), dim3(256), 0, s, gc_bits, gc_pref, nwords, gc_pair);
 }
 }  // namespace scs

@@ -109,6 +109,10 @@ __device__ __forceinline__ uint64_t bit_rank(const unsigned long long* __restric
     const uint64_t w = x >> 6; const uint32_t r = (uint32_t)(x & 63);
     return pref[w] + (uint64_t)__popcll(bits[w] & ((1ull << r) - 1ull));
 }
+__device__ __forceinline__ uint64_t bit_rank_pair(const ulonglong2* __restrict__ pair, uint64_t x) {   // the same from the interleaved index: one 16-byte load
+    const ulonglong2 v = pair[x >> 6]; const uint32_t r = (uint32_t)(x & 63);
+    return v.y + (uint64_t)__popcll(v.x & ((1ull << r) - 1ull));
+}
 
 __device__ __forceinline__ uint32_t u4_word(const U4& d, uint32_t k) { return k == 0 ? d.w[0] : k == 1 ? d.w[1] : k == 2 ? d.w[2] : d.w[3]; }
 // ------------------------------------------------------------------------------------------------

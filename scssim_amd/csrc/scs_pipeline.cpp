@@ -96,7 +96,7 @@ void scs_destroy(scs_ctx* c) {
     (void)hipSetDevice(c->cfg.device);
     (void)hipStreamSynchronize(c->stream);
     for (DevBuf* b : {&c->d_tables, &c->t_gap, &c->t_qcompact, &c->t_guide, &c->t_ring1, &c->t_ring2, &c->t_ring1u, &c->t_ring2u, &c->t_subs1, &c->t_subs2, &c->t_qual, &c->t_ins, &c->t_del, &c->t_isize, &c->d_subs1, &c->d_subs2, &c->d_qual, &c->d_ins, &c->d_del,
-                      &c->d_isize, &c->d_gcmeans, &c->genome, &c->genome2, &c->gx_gc_bits, &c->gx_n_bits, &c->gx_gc_cnt, &c->gx_n_cnt, &c->gx_gc_pref, &c->gx_n_pref, &c->d_binom, &c->df_blob, &c->df_primers, &c->df_hasn, &c->primer_cnt, &c->primer_delta, &c->primer_cut, &c->primer_gdelta, &c->st_eidx, &c->st_etype, &c->st_estart, &c->st_info, &c->st_list, &c->st_sorted, &c->st_tmp, &c->att_wave_first,
+                      &c->d_isize, &c->d_gcmeans, &c->genome, &c->genome2, &c->gx_gc_bits, &c->gx_n_bits, &c->gx_gc_cnt, &c->gx_n_cnt, &c->gx_gc_pref, &c->gx_n_pref, &c->gx_gc_pair, &c->d_binom, &c->df_blob, &c->df_primers, &c->df_hasn, &c->primer_cnt, &c->primer_delta, &c->primer_cut, &c->primer_gdelta, &c->st_eidx, &c->st_etype, &c->st_estart, &c->st_info, &c->st_list, &c->st_sorted, &c->st_tmp, &c->att_wave_first,
                       &c->slots, &c->slot_tmpl, &c->slots_fr, &c->slot_tmpl_fr, &c->valid, &c->valid_off, &c->valid_f, &c->valid_off_f, &c->scan_tmp, &c->flags, &c->weights, &c->read_numbers,
                       &c->pair_off, &c->pairs, &c->odd_before, &c->a_part, &c->a_tp, &c->a_probs, &c->a_quota, &c->a_poff, &c->a_plan, &c->a_crn, &c->a_scratch, &c->a_brow, &c->a_bmap, &c->a_send, &c->a_gath, &c->a_odd, &c->d_hostred, &c->d_tot, &c->d_stage, &c->d_mail, &c->budget_f, &c->budget_s, &c->poisson_part, &c->slot_off_f,
                       &c->slot_off_s, &c->dsums, &c->slot_b, &c->slot_q, &c->lens, &c->ev_hdr, &c->ev_dat, &c->sizes1, &c->sizes2, &c->off1, &c->off2, &c->out1, &c->out2, &c->out1b, &c->out2b, &c->rl_cls, &c->rl_pos, &c->rl_lists, &c->d_bounds, &c->d_cks}) b->release();

@@ -96,10 +96,10 @@ void index_genome(scs_ctx* c, uint64_t tot) {
     {   // bit index: GC count / any-N of any window in O(1)
         hipStream_t s = c->stream; const uint64_t nw = (tot + 63) / 64;
         c->gx_gc_bits.reserve((nw + 1) * 8, s); c->gx_n_bits.reserve((nw + 1) * 8, s); c->gx_gc_cnt.reserve((nw + 2) * 4, s); c->gx_n_cnt.reserve((nw + 2) * 4, s);
-        c->gx_gc_pref.reserve((nw + 2) * 8, s); c->gx_n_pref.reserve((nw + 2) * 8, s); c->scan_tmp.reserve(scan_temp_bytes(nw + 1), s);
+        c->gx_gc_pref.reserve((nw + 2) * 8, s); c->gx_n_pref.reserve((nw + 2) * 8, s); c->gx_gc_pair.reserve((nw + 2) * 16, s); c->scan_tmp.reserve(scan_temp_bytes(nw + 1), s);
         c->genome2.reserve((nw + 1) * 16 + 256, s);                               // two bits per base, 64 bytes of slack in front and 192 behind (the window gather over-reads by up to a dozen words)
         launch_genome_bits(s, c->genome.as<uint8_t>(), tot, nw, c->gx_gc_bits.as<unsigned long long>(), c->gx_n_bits.as<unsigned long long>(), c->gx_gc_cnt.as<uint32_t>(),
-                           c->gx_n_cnt.as<uint32_t>(), c->gx_gc_pref.as<uint64_t>(), c->gx_n_pref.as<uint64_t>(), c->scan_tmp.p, c->scan_tmp.cap, c->genome2.as<uint32_t>() + 16);
+                           c->gx_n_cnt.as<uint32_t>(), c->gx_gc_pref.as<uint64_t>(), c->gx_n_pref.as<uint64_t>(), c->scan_tmp.p, c->scan_tmp.cap, c->genome2.as<uint32_t>() + 16, c->gx_gc_pair.as<ulonglong2>());
     }
 }
 
@@ -315,7 +315,7 @@ void do_create_frags(scs_ctx* c) {
     }
     c->df_primers.reserve(std::max<size_t>(c->f_len.size() * 4, 16), c->stream);
     c->df_hasn.reserve(std::max<size_t>(c->f_len.size(), 16), c->stream);
-    {   const DevGenomeIdx gx{c->gx_gc_bits.as<unsigned long long>(), c->gx_n_bits.as<unsigned long long>(), c->gx_gc_pref.as<uint64_t>(), c->gx_n_pref.as<uint64_t>()};
+    {   const DevGenomeIdx gx{c->gx_gc_bits.as<unsigned long long>(), c->gx_n_bits.as<unsigned long long>(), c->gx_gc_pref.as<uint64_t>(), c->gx_n_pref.as<uint64_t>(), c->gx_gc_pair.as<ulonglong2>()};
         const DevFrags fv = c->frags_view();
         launch_frag_has_n(c->stream, fv.goff, fv.len, fv.n, gx, c->df_hasn.as<uint8_t>()); }
     c->have_frags = true; c->amplified = false; c->allocated = false;
