@@ -387,6 +387,29 @@ def test_gz_input_matches_oracle(oracle_bin, models, golden_inputs, tmp_path):
     assert open(out + "_1.fq", "rb").read() == w1 and open(out + "_2.fq", "rb").read() == w2
 
 
+def test_sharded_medium_job_equals_oracle(oracle_bin, models, tmp_path):
+    """The sharded path at a size where its bookkeeping has something to do: 12 Mb in two records, 3 shards (device hooks) -- 4.5 M
+    amplicons = 4 500 allocation chunks, most list segments' ends inside a chunk (the boundary rows), tens of thousands of pairs per
+    shard and segment; every shard writes two part files per mate; the merged files against the oracle's."""
+    import socket
+    import sys
+    fa = str(tmp_path / "simu.fa")
+    subprocess.check_call(["python3", os.path.join(ROOT, "tools", "make_genome.py"), "--lengths", "7000000,5000000", "--seed", "33", "--n-block", "20000", "--simu-out", fa])
+    whole = str(tmp_path / "whole")
+    _oracle_run(oracle_bin, fa, models["Illumina_HiSeq2500"], whole, ["-c", "4"], 88, threads=min(32, os.cpu_count() or 1))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = str(s.getsockname()[1]); s.close()
+    procs = []
+    for r in range(3):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="3", MASTER_ADDR="127.0.0.1", MASTER_PORT=port, LOCAL_RANK="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_gpu_worker.py"), fa, models["Illumina_HiSeq2500"],
+                                       str(tmp_path / "shard"), "4", "PE", "88", "device", "2"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=900)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    scssim_amd.merge_fastq_shards(str(tmp_path / "shard"), 3, paired=True)
+    for suffix in ("_1.fq", "_2.fq"):
+        assert _md5_file(str(tmp_path / "shard") + suffix) == _md5_file(whole + suffix), "sharded GPU job differs from the whole job (%s)" % suffix
+
+
 def test_device_hooks_over_rccl_single_rank(models, golden_inputs, oracle_bin, tmp_path):
     """The RCCL code path of the device hooks (torch tensors aliasing the library's HBM buffers, collectives on the
     shared stream) with a 1-rank NCCL group: a 1-shard "sharded" job must equal the plain job."""
