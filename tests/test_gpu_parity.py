@@ -301,6 +301,24 @@ def test_primer_exhaustion_bit_exact(oracle_bin, models, repeat_genome, tmp_path
     print("exhaustion: %d types dry, %d passes with a dry type, %d rounds, %d checks" % ((got_stock == 0).sum(), st["stock_exhausted_passes"], st["stock_rounds"], st["stock_checks"]))
 
 
+@pytest.mark.parametrize("gseed,seed,stock,gamma,n", [(1, 5, 10000, 1e-8, 1500000), (2, 6, 10000, 1e-8, 1800000), (3, 7, 12000, 1e-8, 2400000)])
+def test_primer_exhaustion_seed_sweep(gseed, seed, stock, gamma, n, oracle_bin, models, tmp_path):
+    """More genomes, seeds and stocks in the regime where primer types run dry (pool x gamma as the defaults': the growth per cycle that
+    lets a stock of 10^4 run out within 2 Mb): the primer stock after the job and the FASTQ against the oracle."""
+    from conftest import write_repeat_genome
+    fa = write_repeat_genome(str(tmp_path / "rep.fa"), n=n, seed=gseed)
+    prefix = str(tmp_path / "orc")
+    _oracle_run(oracle_bin, fa, models["Illumina_HiSeq2000"], prefix, ["-c", "0.5", "-p", str(stock), "-r", repr(gamma)], seed, dump=prefix)
+    prim = np.loadtxt(prefix + ".primers.tsv", dtype=np.int64)
+    want_stock = np.full(65536, stock, np.int64); want_stock[prim[:, 0]] = prim[:, 2]
+    assert (want_stock == 0).sum() >= 2 and (prim[:, 1] + prim[:, 2] == stock).all()
+    g = scssim_amd.GenReads(profile=models["Illumina_HiSeq2000"], input_fasta=fa, coverage=0.5, seed=seed, primers=stock, gamma=gamma)
+    fq1, fq2 = g.run()
+    assert np.array_equal(g.download_primer_stock(), want_stock)
+    assert fq1 == open(prefix + "_1.fq", "rb").read() and fq2 == open(prefix + "_2.fq", "rb").read()
+    assert g.stats()["stock_exhausted_passes"] >= 1
+
+
 def test_primer_exhaustion_of_every_usable_type_bit_exact(oracle_bin, models, tmp_path):
     """A genome of A and T alone: 256 primer types carry every attachment, and at -p 10000 -r 1e-8 all of them run dry in the course of
     an 8 Mb job, dozens in the same pass -- the cuts of one round move each other's (exact_stock iterates), later passes start with
