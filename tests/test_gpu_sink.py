@@ -167,6 +167,19 @@ def test_cli_five_ranks_on_one_gpu(oracle_bin, models, golden_inputs, tmp_path):
         assert open(out + s, "rb").read() == open(prefix + s, "rb").read(), s
 
 
+def test_cli_sharded_job_with_primer_types_running_dry(oracle_bin, models, repeat_genome, tmp_path):
+    """`scssim genreads --gpus 3 -p 10000 -r 1e-8` on the repeat-rich genome: the pass in which primer types run dry is run again segment
+    by segment across the forked ranks (the exchanges through the CLI's host-memory seam), and the merged files are the oracle's."""
+    prof = models["Illumina_HiSeq2500"]
+    prefix = str(tmp_path / "orc")
+    _oracle(oracle_bin, repeat_genome, prof, prefix, ["-c", "0.5", "-p", "10000", "-r", "1e-8"], 53)
+    out = str(tmp_path / "cli")
+    rc, err, left = _cli(["-i", repeat_genome, "-m", prof, "-c", "0.5", "-p", "10000", "-r", "1e-8", "-o", out, "--seed", "53", "--gpus", "3", "--one-device", "--host-collectives"])
+    assert rc == 0 and not left, err
+    for s in ("_1.fq", "_2.fq"):
+        assert open(out + s, "rb").read() == open(prefix + s, "rb").read(), s
+
+
 @pytest.mark.parametrize("where,who", [("amplify", 1), ("reads", 1), ("comm", 2), ("amplify", 0)])
 def test_cli_rank_failure_ends_the_job(where, who, models, golden_inputs, tmp_path):
     """A rank that dies mid-job (injected: SCS_TEST_FAIL_AT / SCS_TEST_FAIL_RANK) leaves its siblings inside an exchange that
