@@ -638,6 +638,8 @@ def main():
                 g.yield_reads_files(base, writers, generations, mode == "bgzf")
             finally:
                 finish([f for f in (lbase + ".parts", lbase + ".idx") if os.path.exists(f)])
+        elif mode == "files_in_place":                               # every step writes over the files of the step before (SCS_SINK_IN_PLACE): nothing to unlink
+            g.yield_reads_files(os.path.join(out_dir, "inplace"), writers, generations, False, True)
         elif mode == "null":
             g.yield_reads_sink(None)                                 # generate into HBM batch buffers and count
         else:
@@ -775,6 +777,22 @@ def main():
                 cleaner.gate(0)
             except Exception as e:
                 out["single_job_on_empty_tmpfs"] = {"error": repr(e)}
+            # ---- steps that REPLACE the files of the step before (the same prefix, SCS_SINK_IN_PLACE: the files are overwritten where they
+            # lie and cut to their new length): what a loop of jobs costs when it does not have to give 197 GB of pages back and take
+            # them again.  Two untimed steps: the first makes the files, the second is the first to write over them -- and takes twice as
+            # long as every later one (the kernel moves every page it is written to a second time to the active list); steady state from the third.
+            try:
+                P = timed(2, 3, "files_in_place", 260)
+                out["files_overwritten_in_place"] = {"value": P["pairs"] / P["elapsed"], "unit": "pairs/s", "steps": 3, "ms_per_step": 1e3 * P["elapsed"] / 3, "stages_s_per_step": P["stage"],
+                                                     "per_step_s": P["per_step"],
+                                                     "what": "the same job, every step (fresh seed) writing over the part files of the step before: scs_yield_reads_files_ex(..., SCS_SINK_IN_PLACE) / "
+                                                             "`scssim genreads --in-place`.  Same bytes generated, copied and left in the files as in `value`'s steps; no unlink, no page allocation (two untimed steps first: "
+                                                             "making the files, and the first pass over them, which costs 8 s -- profiles/r04_bench_inplace.json.log)"}
+                base = os.path.join(out_dir, "inplace")
+                cleaner.add([f for m in scssim_amd.part_paths(base, writers * generations, True, ".fq") for f in m] + [base + ".parts"])
+                cleaner.gate(0)
+            except Exception as e:
+                out["files_overwritten_in_place"] = {"error": repr(e)}
             # ---- BGZF: the same job with the text compressed on the GPU before it crosses PCIe (<...>.fq.gz parts); an extension (the
             # reference writes plain text), so a leg of its own
             try:

@@ -201,8 +201,14 @@ int         scs_yield_reads_files(scs_ctx* ctx, const char* prefix, int writers)
  *   The blocks are made ON THE GPU from the text where it lies in HBM (scs_bgzf.hip: one dynamic-Huffman deflate block of
  *   literals per 63 KB of text, CRC-32 included), so 3-4x fewer bytes cross PCIe and reach the file system -- the two walls of a
  *   job.  `zcat` of a part is the text of that part; every part ends with the BGZF end-of-file block.  An extension: the
- *   reference writes plain text only.  The shards of a sharded job stay shards (compressed byte ranges cannot be spliced). */
-int         scs_yield_reads_files_ex(scs_ctx* ctx, const char* prefix, int writers, int generations, int bgzf);
+ *   reference writes plain text only.  The shards of a sharded job stay shards (compressed byte ranges cannot be spliced).
+ * flags: SCS_SINK_BGZF (1; `bgzf` was this argument's name when it was the only choice) | SCS_SINK_IN_PLACE (2): output files that
+ *   exist already are not truncated when they are opened (what `ofstream` does, SeqWriter.cpp:17-30) but overwritten where they lie
+ *   and cut to their new length when they are finished -- the same files in the end, and a job that replaces the files of an earlier
+ *   one does not pay for giving their pages back and taking them again.  Until a file is finished its tail is the old file's. */
+#define SCS_SINK_BGZF     1
+#define SCS_SINK_IN_PLACE 2
+int         scs_yield_reads_files_ex(scs_ctx* ctx, const char* prefix, int writers, int generations, int flags);
 int         scs_merge_fastq_shards(const char* prefix, int nranks, int paired, int keep_shards, char* errbuf, size_t errlen);
 /* host only: <prefix>.p*_1.fq ... -> <prefix>_1.fq ... (byte-range copies; parts removed unless keep_parts) */
 int         scs_merge_fastq_parts(const char* prefix, int paired, int keep_parts, char* errbuf, size_t errlen);

@@ -392,13 +392,14 @@ class GenReads:
         cb = _SINK(sink) if sink is not None else _SINK()
         self._ck(self._L.scs_yield_reads(self._ctx, cb, None))
 
-    def yield_reads_files(self, prefix, writers=0, generations=1, bgzf=False):
+    def yield_reads_files(self, prefix, writers=0, generations=1, bgzf=False, in_place=False):
         """Malbac::yieldReads + SeqWriter: <prefix>_1.fq/_2.fq (.fq), or this shard's <prefix>.r<rank>_*.fq + .idx.
         writers = K > 1: K part files per mate (<base>.p00_1.fq ...: contiguous record ranges, one writer thread each; their
         concatenation is the single file) + <base>.parts.  generations = G > 1: K x G parts made generation by generation (part p
-        is final once part p + K exists).  bgzf: <...>.fq.gz, BGZF blocks made on the GPU."""
+        is final once part p + K exists).  bgzf: <...>.fq.gz, BGZF blocks made on the GPU.  in_place: files that exist are overwritten
+        where they lie and cut to length at the end, not truncated first (SCS_SINK_IN_PLACE)."""
         self._L.scs_yield_reads_files_ex.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_int]
-        self._ck(self._L.scs_yield_reads_files_ex(self._ctx, os.fsencode(prefix), int(writers), int(generations), int(bool(bgzf))))
+        self._ck(self._L.scs_yield_reads_files_ex(self._ctx, os.fsencode(prefix), int(writers), int(generations), (1 if bgzf else 0) | (2 if in_place else 0)))
 
     def comm_init(self, comm_id, rank, nranks):
         """RCCL inside the library: every rank of a sharded job calls this with rank 0's comm_unique_id()."""

@@ -114,7 +114,9 @@ bool FastqParts::open_part(int k, std::string& err) {
     if (P.opened) return true;
     for (int m = 0; m < (paired_ ? 2 : 1); ++m) {
         const std::string p = part_path(base_, k, regions, m, paired_, suffix_);
-        P.fd[m] = ::open(p.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+        // in place: a file that is there already keeps its pages and is overwritten where it lies; its length is set when the part is
+        // finished.  (Freeing a file system's pages and taking them again costs more than the copy into them: tools/overwrite_probe.py)
+        P.fd[m] = ::open(p.c_str(), O_WRONLY | O_CREAT | (in_place_ ? 0 : O_TRUNC), 0644);
         if (P.fd[m] < 0) { err = "Error: can not open fastq file to save results:\n" + p; P.failed = true; return false; }
     }
     P.opened = true;
@@ -125,13 +127,14 @@ void FastqParts::finish_part(int k) {                                           
     if (!P.opened || P.done) return;
     for (int m = 0; m < 2; ++m) if (P.fd[m] >= 0) {
         if (eof_ && !P.failed) { if (pwrite_all(P.fd[m], (const char*)kBgzfEof, sizeof kBgzfEof, P.pos[m])) P.pos[m] += sizeof kBgzfEof; else P.failed = true; }
+        if (in_place_ && ftruncate(P.fd[m], (off_t)P.pos[m]) != 0) P.failed = true;
         if (::close(P.fd[m]) != 0) P.failed = true;
         P.fd[m] = -1;
     }
     P.done = true;
 }
-bool FastqParts::open(const std::string& base, bool paired, int nwriters, int generations, const std::string& suffix, bool bgzf_eof, std::string& err) {
-    base_ = base; paired_ = paired; eof_ = bgzf_eof; suffix_ = suffix;
+bool FastqParts::open(const std::string& base, bool paired, int nwriters, int generations, const std::string& suffix, bool bgzf_eof, std::string& err, bool in_place) {
+    base_ = base; paired_ = paired; eof_ = bgzf_eof; suffix_ = suffix; in_place_ = in_place;
     writers = std::max(1, nwriters); regions = writers * std::max(1, generations);
     part_.assign((size_t)regions, Part()); cur_.assign((size_t)writers, -1);
     first_ = part_path(base, 0, regions, 0, paired, suffix);

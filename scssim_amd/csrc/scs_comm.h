@@ -41,7 +41,9 @@ struct BatchSink {
 class FastqParts : public BatchSink {
 public:
     ~FastqParts() override;
-    bool open(const std::string& base, bool paired, int writers, int generations, const std::string& suffix, bool bgzf_eof, std::string& err);
+    // in_place: files that exist are not truncated when they are opened but overwritten where they lie (their pages stay) and cut
+    // to their new length when the part is finished -- the same files in the end
+    bool open(const std::string& base, bool paired, int writers, int generations, const std::string& suffix, bool bgzf_eof, std::string& err, bool in_place = false);
     int put(int region, const char* a, size_t na, const char* b, size_t nb) override;
     bool close(std::string& err);                          // sizes final, index written (parts > 1)
     uint64_t bytes(int mate) const { uint64_t t = 0; for (auto& p : part_) t += p.pos[mate]; return t; }
@@ -49,7 +51,7 @@ public:
 private:
     struct Part { int fd[2] = {-1, -1}; uint64_t pos[2] = {0, 0}; bool failed = false, opened = false, done = false; };
     bool open_part(int k, std::string& err); void finish_part(int k);
-    std::vector<Part> part_; std::vector<int> cur_; std::string base_, first_, suffix_; bool paired_ = true, eof_ = false;
+    std::vector<Part> part_; std::vector<int> cur_; std::string base_, first_, suffix_; bool paired_ = true, eof_ = false, in_place_ = false;
 };
 std::string part_path(const std::string& base, int part, int parts, int mate, bool paired, const std::string& suffix);
 std::string parts_index_path(const std::string& base);                                 // <base>.parts

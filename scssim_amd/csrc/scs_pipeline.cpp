@@ -222,14 +222,16 @@ int scs_yield_reads_device(scs_ctx* c, void* d1, size_t cap1, void* d2, size_t c
 // SeqWriter (lib/seqwriter/SeqWriter.cpp:12-64).  writers <= 1: the reference's files <prefix>_1.fq / _2.fq (.fq) -- a shard of a
 // sharded job: <prefix>.r<rank>_1.fq ... + <prefix>.r<rank>.idx.  writers = K > 1: K part files per mate, each a contiguous
 // range of the job's (shard's) records written by its own thread, + <base>.parts (scs_comm.h: FastqParts).
-int scs_yield_reads_files_ex(scs_ctx* c, const char* prefix, int writers, int generations, int bgzf) {
+int scs_yield_reads_files_ex(scs_ctx* c, const char* prefix, int writers, int generations, int flags) {
+    const int bgzf = flags & SCS_SINK_BGZF; const bool in_place = (flags & SCS_SINK_IN_PLACE) != 0;
     return guarded(c, [&] {
+        if (flags & ~(SCS_SINK_BGZF | SCS_SINK_IN_PLACE)) throw ScsError(SCS_EINVAL, "scs_yield_reads_files: unknown sink flag");
         if (!prefix || !*prefix) throw ScsError(SCS_EINVAL, "scs_yield_reads_files: no output prefix");
         if (writers > 64 || generations > 64 || (int64_t)std::max(1, writers) * std::max(1, generations) > 99) throw ScsError(SCS_EINVAL, "scs_yield_reads_files: at most 64 writers and 99 parts");
         const bool pe = c->cfg.paired != 0, shard = c->cfg.shard_count > 1; const std::string pre = prefix;
         const std::string base = shard ? shard_base(pre, c->cfg.shard_rank) : pre;
         FastqParts files; std::string err;
-        if (!files.open(base, pe, std::max(1, writers), std::max(1, generations), bgzf ? ".fq.gz" : ".fq", bgzf != 0, err)) throw ScsError(SCS_EIO, err);
+        if (!files.open(base, pe, std::max(1, writers), std::max(1, generations), bgzf ? ".fq.gz" : ".fq", bgzf != 0, err, in_place)) throw ScsError(SCS_EIO, err);
         std::vector<uint64_t> so1, so2;
         double t = now_s(); OutTarget tg{false, nullptr, nullptr, 0, 0, &files}; tg.bgzf = bgzf != 0;
         if (shard && !bgzf) { tg.seg_off1 = &so1; tg.seg_off2 = &so2; }              // (byte ranges of compressed shards cannot be spliced: BGZF shards stay shards)

@@ -73,6 +73,41 @@ def test_part_files_concatenate_to_the_oracle_files(case, layout, shift, ks, ora
         assert open(f[0], "rb").read() == want[m]
 
 
+def test_in_place_sink_leaves_the_same_files_as_truncating(oracle_bin, models, golden_inputs, tmp_path):
+    """SCS_SINK_IN_PLACE: output files that exist are overwritten where they lie and cut to their new length when they are finished.
+    A big job, then a smaller one, then the big one again into the SAME prefix (part files of 3 writers x 2 generations, BGZF and the
+    reference's two files): after every job the files are exactly what a job into fresh files leaves -- no tail of the older, longer
+    file, the parts index of the new job; the CLI's --in-place the same."""
+    import gzip
+    fa, prof = golden_inputs["g1_hiseq2500_pe"], models["Illumina_HiSeq2500"]
+    want = {}
+    for cov, seed in ((3.0, 21), (1.0, 22)):
+        prefix = str(tmp_path / ("orc%d" % seed))
+        _oracle(oracle_bin, fa, prof, prefix, ["-c", "%g" % cov], seed)
+        want[seed] = [open(prefix + s, "rb").read() for s in ("_1.fq", "_2.fq")]
+    assert len(want[21][0]) > 2 * len(want[22][0]) > 100000
+    out, single, gz = str(tmp_path / "parts"), str(tmp_path / "two"), str(tmp_path / "gz")
+    for cov, seed in ((3.0, 21), (1.0, 22), (3.0, 21)):
+        g = scssim_amd.GenReads(profile=prof, input_fasta=fa, coverage=cov, seed=seed)
+        g.create_frags(); g.amplify(); g.allocate_reads(0)
+        g.yield_reads_files(out, 3, 2, in_place=True)
+        g.yield_reads_files(single, 1, in_place=True)
+        g.yield_reads_files(gz, 2, 1, bgzf=True, in_place=True)
+        files = scssim_amd.part_paths(out, 6, True)
+        for m in range(2):
+            assert _cat(files[m]) == want[seed][m], (seed, m)
+            assert open(single + ("_1.fq", "_2.fq")[m], "rb").read() == want[seed][m], (seed, m)
+            assert b"".join(gzip.decompress(open(f, "rb").read()) for f in scssim_amd.part_paths(gz, 2, True, ".fq.gz")[m]) == want[seed][m], (seed, m)
+        sizes = [l.split("\t") for l in open(out + ".parts").read().splitlines() if not l.startswith("#")]
+        assert [int(x[1]) for x in sizes] == [os.path.getsize(f) for f in files[0]]
+        g.close()
+    # the command line: a short job over the long job's files
+    rc, err, left = _cli(["-i", fa, "-m", prof, "-c", "1", "-o", single, "--seed", "22", "--in-place"])
+    assert rc == 0 and not left, err
+    for m in range(2):
+        assert open(single + ("_1.fq", "_2.fq")[m], "rb").read() == want[22][m]
+
+
 def test_sharded_job_written_in_parts_merges_to_the_whole_job(oracle_bin, models, golden_inputs, tmp_path):
     """Two shards (two processes on this box's GPU, gloo hooks), each writing its shard as 3 part files per mate with small
     batches: the native range merge reads the parts as one logical file per shard and rebuilds the unsharded job's files."""
