@@ -326,7 +326,10 @@ void fasta_write_fai(const std::string& path, const char* base, size_t size, con
     const std::string fname = path + ".fai"; struct stat fst;
     if (stat(fname.c_str(), &fst) == 0) return;
     fprintf(stderr, "index file %s not found, generating...\n", fname.c_str());
-    FILE* fai = fopen(fname.c_str(), "w");
+    // (written under a name of its own and renamed: the ranks of a sharded job stage side by side, and one that looks for the index
+    // while another writes it must find a whole index or none)
+    const std::string tmp = fname + ".tmp." + std::to_string((long)getpid());
+    FILE* fai = fopen(tmp.c_str(), "w");
     if (!fai) { fprintf(stderr, "could not open index file %s for writing! (continuing without it)\n", fname.c_str()); return; }
     for (size_t r = 0; r < hdr_off.size(); ++r) {
         const size_t hdr = (size_t)hdr_off[r], end = r + 1 < hdr_off.size() ? (size_t)hdr_off[r + 1] : size;
@@ -341,7 +344,7 @@ void fasta_write_fai(const std::string& path, const char* base, size_t size, con
         const std::string first = full.substr(0, full.find(' '));
         fprintf(fai, "%s\t%llu\t%zu\t%zu\t%zu\n", first.c_str(), (unsigned long long)lens[r], fl, line_blen, line_len);
     }
-    fclose(fai);
+    if (fclose(fai) != 0 || rename(tmp.c_str(), fname.c_str()) != 0) { (void)unlink(tmp.c_str()); fprintf(stderr, "could not write index file %s! (continuing without it)\n", fname.c_str()); }
 }
 void load_fasta(const std::string& path_in, std::vector<FastaRecord>& out, bool make_index) {
     const std::string path = fasta_plain_path(path_in);                          // ".gz": inflated first (Genome.cpp:183-187)
@@ -374,12 +377,12 @@ void load_fasta(const std::string& path_in, std::vector<FastaRecord>& out, bool 
     out.resize(spans.size());
     // the reference indexes the FASTA through fastahack and leaves <file>.fai beside it when there is none
     // (lib/fastahack/Fasta.cpp:241-249; entry = first word of the name, length, offset, bases per line, bytes per line)
-    FILE* fai = nullptr;
+    FILE* fai = nullptr; const std::string fai_name = path + ".fai", fai_tmp = fai_name + ".tmp." + std::to_string((long)getpid());   // (renamed when whole: fasta_write_fai)
     if (make_index) {
-        const std::string fname = path + ".fai"; struct stat fst;
-        if (stat(fname.c_str(), &fst) != 0) {
-            fprintf(stderr, "index file %s not found, generating...\n", fname.c_str());
-            if (!(fai = fopen(fname.c_str(), "w"))) fprintf(stderr, "could not open index file %s for writing! (continuing without it)\n", fname.c_str());
+        struct stat fst;
+        if (stat(fai_name.c_str(), &fst) != 0) {
+            fprintf(stderr, "index file %s not found, generating...\n", fai_name.c_str());
+            if (!(fai = fopen(fai_tmp.c_str(), "w"))) fprintf(stderr, "could not open index file %s for writing! (continuing without it)\n", fai_name.c_str());
         }
     }
     for (size_t r = 0; r < spans.size(); ++r) {
@@ -409,7 +412,7 @@ void load_fasta(const std::string& path_in, std::vector<FastaRecord>& out, bool 
             fprintf(fai, "%s\t%zu\t%zu\t%zu\t%zu\n", first.c_str(), w, fl, line_blen, line_len);
         }
     }
-    if (fai) fclose(fai);
+    if (fai && (fclose(fai) != 0 || rename(fai_tmp.c_str(), fai_name.c_str()) != 0)) { (void)unlink(fai_tmp.c_str()); fprintf(stderr, "could not write index file %s! (continuing without it)\n", fai_name.c_str()); }
     munmap((void*)base, size); close(fd);
     if (out.empty()) throw std::runtime_error("ERROR: reference sequence cannot be empty!");
 }
