@@ -108,6 +108,41 @@ def test_in_place_sink_leaves_the_same_files_as_truncating(oracle_bin, models, g
         assert open(single + ("_1.fq", "_2.fq")[m], "rb").read() == want[22][m]
 
 
+def test_two_jobs_on_two_host_threads_at_once(oracle_bin, models, golden_inputs, tmp_path):
+    """One ctx per host thread, no state shared between them ("no global state, thread-compatible"): two different jobs --
+    another model, layout, seed, sink -- run at the same time from two threads of one process, three times over, and each leaves
+    the oracle's files."""
+    import threading
+    jobs = [dict(fa=golden_inputs["g1_hiseq2500_pe"], prof=models["Illumina_HiSeq2500"], cov=3.0, layout="PE", seed=61, writers=3),
+            dict(fa=golden_inputs["g3_hiseq2000_se"], prof=models["Illumina_HiSeq2000"], cov=2.0, layout="SE", seed=62, writers=1)]
+    for k, j in enumerate(jobs):
+        j["want_prefix"] = str(tmp_path / ("orc%d" % k))
+        _oracle(oracle_bin, j["fa"], j["prof"], j["want_prefix"], ["-c", "%g" % j["cov"], "-l", j["layout"]], j["seed"])
+    errors = []
+
+    def run(k, j):
+        try:
+            for rep in range(3):
+                g = scssim_amd.GenReads(profile=j["prof"], input_fasta=j["fa"], coverage=j["cov"], layout=j["layout"], seed=j["seed"])
+                g.create_frags(); g.amplify(); g.allocate_reads(0)
+                out = str(tmp_path / ("t%d_%d" % (k, rep)))
+                g.yield_reads_files(out, j["writers"])
+                g.close()
+                paired = j["layout"] == "PE"
+                files = scssim_amd.part_paths(out, j["writers"], paired)
+                for m, suf in enumerate(("_1.fq", "_2.fq") if paired else (".fq",)):
+                    if _cat(files[m]) != open(j["want_prefix"] + suf, "rb").read():
+                        errors.append("job %d, repetition %d, file %s differs from the oracle's" % (k, rep, suf))
+        except Exception as e:                                           # (an exception in a thread would otherwise pass silently)
+            errors.append("job %d: %r" % (k, e))
+    th = [threading.Thread(target=run, args=(k, j)) for k, j in enumerate(jobs)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
+
+
 def test_sharded_job_written_in_parts_merges_to_the_whole_job(oracle_bin, models, golden_inputs, tmp_path):
     """Two shards (two processes on this box's GPU, gloo hooks), each writing its shard as 3 part files per mate with small
     batches: the native range merge reads the parts as one logical file per shard and rebuilds the unsharded job's files."""
