@@ -741,6 +741,12 @@ def main():
         # chip's memory system) beside it
         roof = roofline_of(R["ktimes"], R["fq_bytes_local"], L, "k_reads")
         roof["timing"] = "HIP events on the ctx stream around every launch of the timed region"
+        if main_mode == "files":
+            # (measured: profiles/r04_sdma_vs_blit.log, r04_bench_files_kernel_stats.csv)
+            roof["under_a_profiler"] = ("rocprofv3 --kernel-trace makes the runtime copy D2H with shader kernels (__amd_rocclr_copyBuffer) instead of the SDMA engines; they share the CUs "
+                                        "with k_reads, whose launches then take 22 ms instead of 1.6 (HIP events and the trace agree on that inside such a run; HSA_ENABLE_SDMA=0 without a "
+                                        "profiler gives the same 21 ms). `value` does not move (the host binds it). The undisturbed cross-check of the kernel's duration is the generation_hbm "
+                                        "leg against profiles/r04_bench_kernel_stats.csv (no copies in flight)")
         if H:
             hb = roofline_of(H["ktimes"], H["fq_bytes_local"], L, roof["kernel"])
             roof["generation_hbm_leg"] = {k: hb[k] for k in ("achieved", "frac", "avg_launch_ms", "timed_launches", "pairs_per_launch", "algorithmic_bytes_per_launch")}
