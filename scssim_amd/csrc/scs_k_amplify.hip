@@ -134,6 +134,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
         n_fwd = valid_off[t] + i;
         const uint32_t sl = slots[slot_off[t] + i];
         spos = sl_spos(sl); alen = sl_len(sl);
+        // the first four thresholds of the error count's row leave HERE, beside the template's loads (the row only needs the window's
+        // length): read where they are used, behind the Philox block, they were one or two more round trips at the end of the chain
+        const unsigned long long* __restrict__ Tn = binom + (size_t)(alen - 8 - (p.amp_min - 8)) * BINOM_KMAX;
+        const ulonglong2 tn01 = reinterpret_cast<const ulonglong2*>(Tn)[0], tn23 = reinterpret_cast<const ulonglong2*>(Tn)[1];
         if (FROM_FRAG) { tv = frag_view(fr.goff[t], fr.len[t], fr.strand[t]); nuid = semi_uid(fr.gidx_base + t, p.pass, i); }
         else {
             const uint32_t f = semis.parent[t], psl = semis.sl[t];
@@ -160,8 +164,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
         ntr = alen - 8;
         d0 = draw4(p.key, ST_ERR, kind, nuid, 0);
         const unsigned long long x64 = ((unsigned long long)d0.w[0] << 32) | d0.w[1];
-        const unsigned long long* __restrict__ Tn = binom + (size_t)(ntr - (p.amp_min - 8)) * BINOM_KMAX;
-        while (K < (uint32_t)BINOM_KMAX && x64 >= Tn[K]) ++K;
+        K = (x64 >= tn01.x ? 1u : 0u) + (x64 >= tn01.y ? 1u : 0u) + (x64 >= tn23.x ? 1u : 0u) + (x64 >= tn23.y ? 1u : 0u);   // (the thresholds ascend: the count IS the first k with x64 < T[k])
+        if (K == 4u) while (K < (uint32_t)BINOM_KMAX && x64 >= Tn[K]) ++K;
         // the K positions, sorted: 16 bits each of one register for K <= 4; the 2 amplicons in 10 000 with more keep them (and
         // then their entries) in their slice of the overflow pool (two 16-entry register arrays cost the kernel a wave per SIMD)
         if (K && K <= 4) {
