@@ -47,7 +47,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-VALU_PEAK_MEASURED = 7.72e11   # wave-instructions/s: the best integer issue rate tools/valu_peak.hip reached (3.18 cycles, profiles/r02_valu_peak.log)
+VALU_PEAK_MEASURED = 7.72e11   # wave-instructions/s: the best integer issue rate tools/probes/valu_peak.hip reached (3.18 cycles, profiles/r02_valu_peak.log)
 VALU_PEAK_SPEC = 256 * 4 * 2.4e9 / 2   # the guide's 2-cycle wave64 issue per SIMD (v_fma_f32): 1.23e12/s
 HG19 = [249250621, 243199373, 198022430, 191154276, 180915260, 171115067, 159138663, 146364022, 141213431, 135534747,
         135006516, 133851895, 115169878, 107349540, 102531392, 90354753, 81195210, 78077248, 59128983, 63025520,
@@ -235,6 +235,15 @@ def cpu_baseline(td, prof, names, seqs, sample_desc, coverage):
     return out or None
 
 
+def summary_rows(path):
+    """rows (kernel, a, b, c) of a profiles/ summary written by tools/pmc_summary.py / sq_summary.py: csv with quoted kernel names (rounds
+    1-4 wrote them unquoted: the name is then what precedes the last three fields)"""
+    import csv
+    for f in csv.reader(l for l in open(path) if not l.startswith("#")):
+        if len(f) >= 4 and f[0] != "kernel":
+            yield [",".join(f[:-3])] + f[-3:]
+
+
 def committed_counters(kernel_prefix):
     """Counters bench.py cannot collect itself, read from the newest committed rocprofv3 summaries of this same command
     (tools/profile_bench.sh -> profiles/r*_bench_pmc_hbm.csv: FETCH_SIZE / WRITE_SIZE in separate --pmc passes, KB -> bytes, per
@@ -244,10 +253,7 @@ def committed_counters(kernel_prefix):
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_pmc_hbm.csv")))
     if files:
         tot = totf = 0.0
-        for line in open(files[-1]):
-            if line.startswith("#") or line.startswith("kernel"):
-                continue
-            name, fetch, write, n = line.rstrip("\n").rsplit(",", 3)
+        for name, fetch, write, n in summary_rows(files[-1]):
             if name.startswith(kernel_prefix):
                 tot += (float(fetch) + float(write)) * 1024.0
                 totf += float(fetch) * 1024.0
@@ -258,11 +264,8 @@ def committed_counters(kernel_prefix):
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_sq.csv")))
     if files:
         valu = salu = lanes_w = 0.0
-        for line in open(files[-1]):
-            if line.startswith("#") or line.startswith("kernel"):
-                continue
-            f = line.rstrip("\n").rsplit(",", 3)                      # kernel names contain commas
-            if len(f) == 4 and f[0].startswith(kernel_prefix):
+        for f in summary_rows(files[-1]):
+            if f[0].startswith(kernel_prefix):
                 try:
                     v = float(f[1]); valu += v; lanes_w += v * float(f[2]); salu += float(f[3])
                 except ValueError:
@@ -288,11 +291,8 @@ def committed_lane_table():
     if not files:
         return None
     rows = {}
-    for line in open(files[-1]):
-        if line.startswith("#") or line.startswith("kernel"):
-            continue
-        f = line.rstrip("\n").rsplit(",", 3)
-        if len(f) != 4 or not f[0].startswith("scs::"):
+    for f in summary_rows(files[-1]):
+        if not f[0].startswith("scs::"):
             continue
         try:
             rows[f[0][5:]] = {"lanes_per_valu_inst": float(f[2]), "valu_insts_per_launch": float(f[1]), "salu_per_valu": float(f[3]) / max(1.0, float(f[1]))}
@@ -436,7 +436,7 @@ def roofline_of(ktimes, fq_bytes, L, dom=None):
     roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": cc.get("traffic"), "traffic_source": cc.get("traffic_source"), "algorithmic_bytes": note,
             # MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reports half the bytes of WIDE coalesced reads (16 B per lane) and is uncalibrated for other
-            # widths.  tools/fetch_calib.hip (profiles/r03_fetch_size_calibration.txt): the counter is 64 B per memory-side request -- 1/2 for wide
+            # widths.  tools/probes/fetch_calib.hip (profiles/r03_fetch_size_calibration.txt): the counter is 64 B per memory-side request -- 1/2 for wide
             # streaming reads, 64 B per random dword gather and per 44-byte window gather.  This kernel's reads are mostly such gathers, so the raw
             # `traffic` is close to the bytes moved; this figure (every fetched byte doubled) is the bound if all of them were wide
             "traffic_if_every_read_is_doubled": (cc["traffic"] + cc["traffic_fetch"]) if "traffic_fetch" in cc else None,
@@ -446,7 +446,7 @@ def roofline_of(ktimes, fq_bytes, L, dom=None):
         roof["draws_per_s"] = draws / (kd["ms"] * 1e-3)
         roof["draws"] = draws_note
     if "valu_insts_per_launch" in cc:
-        # VALU issue: 256 CUs x 4 SIMDs at 2.4 GHz.  Priced against the BEST rate tools/valu_peak.hip reached with independent integer
+        # VALU issue: 256 CUs x 4 SIMDs at 2.4 GHz.  Priced against the BEST rate tools/probes/valu_peak.hip reached with independent integer
         # chains (3.18 cycles per wave-instruction: 7.72e11/s, profiles/r02_valu_peak.log); the microarchitecture guide's 2-cycle
         # issue (1.23e12/s, quoted for v_fma_f32) beside it
         per_s = cc["valu_insts_per_launch"] / (kd["ms"] * 1e-3 / max(1, kd["launches"]))
@@ -490,6 +490,34 @@ def small_config(torch, scssim_amd, dev, stream, prof, mb, cov, label, shm, step
             "with_two_fastq_files_on_tmpfs_pairs_per_s": pf / tf, "ms_per_step_files": 1e3 * tf}
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher on the command line: start the N ranks as fresh children -- the same
+    `python -m torch.distributed.run` command the driver uses -- BEFORE this process has made any GPU call (it never makes one: torch
+    is not even imported here), pass rank 0's one JSON line through (the children inherit stdout / stderr), and return the launcher's
+    exit status: non-zero when any rank died (torch.distributed.run ends the other ranks then).  Replaces the reference's pool fan-out,
+    lib/malbac/Malbac.cpp:318-368,438-454, at process granularity."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")                # dmabuf IPC: what RCCL needs on these hosts
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    p = subprocess.Popen(cmd, env=env)
+    try:
+        return p.wait()
+    except KeyboardInterrupt:
+        p.terminate()
+        try:
+            return p.wait(10) or 130
+        except subprocess.TimeoutExpired:
+            p.kill()
+            return 130
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -507,6 +535,9 @@ def main():
     ap.add_argument("--cpu-sample-mb", type=float, default=4.0)
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(a.gpus))                               # (this process never touches the GPU)
+
     import torch
     import torch.distributed as dist
     import scssim_amd
@@ -514,8 +545,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus and world == 1 and a.gpus > 1:
-        sys.exit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d bench.py --gpus %d ..." % (a.gpus, a.gpus))
+    if world != a.gpus:
+        sys.exit("bench.py --gpus %d was started with WORLD_SIZE=%d: one rank per GPU" % (a.gpus, world))
     # rehearsal of the N > 1 control flow on a box with ONE GPU: SCS_BENCH_BACKEND=gloo SCS_BENCH_ONE_DEVICE=1 (all ranks on
     # cuda:0, collectives staged through the CPU).  Never a measurement.
     backend = os.environ.get("SCS_BENCH_BACKEND", "nccl")
@@ -757,7 +788,6 @@ def main():
             # amplification has its own entry: this design's compulsory 68 B per created amplicon over the four kernels' time
             out["roofline_amplification"] = {"bound": "hbm (latency / issue bound in practice)", "achieved": 68.0 * made / max(1e-9, amp_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                              "frac": 68.0 * made / max(1e-9, amp_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "compulsory_bytes_per_amplicon": 68, "amplicons": made, "kernels_ms": {k: v["ms"] for k, v in amp.items()},
-                                             "survey_8d_model_frac": 1526.0 * made / max(1e-9, amp_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                              "lanes_per_valu_inst": {k: v["lanes_per_valu_inst"] for k, v in lanes.items() if k.startswith("k_attach") or k.startswith("k_errs")},
                                              "salu_per_valu": {k: v["salu_per_valu"] for k, v in lanes.items() if k.startswith("k_attach") or k.startswith("k_errs")}}
         out["roofline"] = roof

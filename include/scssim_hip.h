@@ -205,7 +205,10 @@ int         scs_yield_reads_files(scs_ctx* ctx, const char* prefix, int writers)
  * flags: SCS_SINK_BGZF (1; `bgzf` was this argument's name when it was the only choice) | SCS_SINK_IN_PLACE (2): output files that
  *   exist already are not truncated when they are opened (what `ofstream` does, SeqWriter.cpp:17-30) but overwritten where they lie
  *   and cut to their new length when they are finished -- the same files in the end, and a job that replaces the files of an earlier
- *   one does not pay for giving their pages back and taking them again.  Until a file is finished its tail is the old file's. */
+ *   one does not pay for giving their pages back and taking them again.  Until a file is finished its tail is the old file's.
+ *   With generations > 1 the "part p + writers exists => part p is final" signal is kept: the call first renames the earlier job's
+ *   files of the LATER generations to <name>.prev, and each comes back under its name (its pages kept) when its part's first batch
+ *   arrives; no .prev file is left when the call returns. */
 #define SCS_SINK_BGZF     1
 #define SCS_SINK_IN_PLACE 2
 int         scs_yield_reads_files_ex(scs_ctx* ctx, const char* prefix, int writers, int generations, int flags);

@@ -234,6 +234,15 @@ std::vector<Record> load_fasta(const std::string& path) {
 // Profile (lib/profile/Profile.cpp:69-123 kmers, 171-214 init, 930-1234 load,
 // 832-863/897-927 normParas(true), 1363-1430 initCDFs; Matrix.h:328-336,483-522)
 // ---------------------------------------------------------------------------
+// TEST-ONLY: SCSO_TEST_BIAS=<branch>[:<factor>] makes ONE counter-mode remap wrong by 2 % (or by the factor given): errors | attach | indel | alias | gc, so that
+// tests/test_oracle_stats.py can show that its statistics would catch such a remap (test_a_biased_remap_is_caught).  Read at every
+// use, never set by anything but that test.
+static double test_bias(const char* branch) {                                       // SCSO_TEST_BIAS=<branch>[:<factor>], factor 1.02 by default
+    const char* e = getenv("SCSO_TEST_BIAS"); const size_t n = strlen(branch);
+    if (!e || strncmp(e, branch, n) != 0 || (e[n] != 0 && e[n] != ':')) return 1.0;
+    return e[n] == ':' ? atof(e + n + 1) : 1.02;
+}
+
 struct Profile {
     int L = 0, bins = 0, kmer = 3, N = 4, kmerCount = 84, nq = 94;
     double insertRate = 0, delRate = 0, stdISize = 0, gcStd = 0;
@@ -255,6 +264,7 @@ struct Profile {
     // 2^32 / K draws of which the lowest t_j go to the row's j-th drawable symbol and the others to column alias_j's --
     // hits it with exactly w_k draws as well (integer Vose construction).  Row = K words (t_j << log2 K | alias_j) + K bytes.
     int qualK = 16; std::vector<uint32_t> qualAlias;
+    double biasAlias = 1.0;               // test_bias("alias") when the model was loaded (1.0 outside the bias test: the top 2 % of a column's draws go to the next column's symbol)
     std::vector<int> isizeAlphabet;
     std::vector<double> isizeCdf;
     double gcMeans[101];
@@ -439,7 +449,7 @@ Profile* load_profile(const std::string& path, bool paired, int isize) {
         if (const char* f = getenv("SCS_TEST_QK")) K = std::max(K, atoi(f) >= 128 ? 128 : atoi(f) >= 64 ? 64 : 16);   // tests: more columns than needed (the 128-column kernels; the product reads the same variable)
         const int abits = K == 16 ? 4 : K == 64 ? 6 : 7;
         const uint64_t C = (1ull << 32) / (uint64_t)K; const size_t RW = (size_t)K + K / 4;
-        P->qualK = K; P->qualAlias.assign((size_t)16 * Bq * RW, 0u);
+        P->qualK = K; P->qualAlias.assign((size_t)16 * Bq * RW, 0u); P->biasAlias = test_bias("alias");
         for (size_t row = 0; row < (size_t)16 * Bq; ++row) {
             std::vector<uint64_t> m((size_t)K, 0); std::vector<uint32_t> t((size_t)K, 0), al((size_t)K, 0); std::vector<int> small, large;
             for (size_t j = 0; j < w[row].size(); ++j) m[j] = w[row][j];
@@ -464,7 +474,7 @@ Profile* load_profile(const std::string& path, bool paired, int isize) {
         const uint32_t tDel = count_true([dr](uint32_t x) { return (x / 4294967296.0) < dr; });
         P->tIns = tIns; P->tIndel = tIns + (uint32_t)((((1ull << 32) - tIns) * (uint64_t)tDel) >> 32);
         P->tGap.assign((size_t)P->L + 1, 0xFFFFFFFFu);
-        { const double q = 1.0 - (double)P->tIndel / 4294967296.0; double pw = 1.0;
+        { const double q = 1.0 - (double)P->tIndel / 4294967296.0 * test_bias("indel"); double pw = 1.0;
           for (int g = 1; g <= P->L; ++g) { pw = pw * q; const double v = std::floor(pw * 4294967296.0); P->tGap[(size_t)g] = v >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)v; } }
         if (P->tIndel) { const double v = std::floor(4294967296.0 * ((double)P->tIns / (double)P->tIndel)); P->tKind = v >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)v; }
     }
@@ -594,7 +604,8 @@ int predict(const Profile& P, Rng& rng, const uint8_t* win, int n, bool isRead1,
                 const int K = P.qualK, abits = K == 16 ? 4 : K == 64 ? 6 : 7;
                 const uint32_t* row = &P.qualAlias[((size_t)bp * B + bin) * ((size_t)K + K / 4)];
                 const uint32_t x = xq, col = x >> (32 - abits), e = row[col];
-                const uint32_t pick = (x & ((1u << (32 - abits)) - 1u)) < (e >> abits) ? col : (e & (uint32_t)(K - 1));
+                uint32_t pick = (x & ((1u << (32 - abits)) - 1u)) < (e >> abits) ? col : (e & (uint32_t)(K - 1));
+                if (P.biasAlias != 1.0 && (double)(x & ((1u << (32 - abits)) - 1u)) >= (double)(1u << (32 - abits)) / P.biasAlias) pick = (col + 1u) & (uint32_t)(K - 1);   // (bias test only)
                 out_q[j] = (char)(33 + reinterpret_cast<const uint8_t*>(row + K)[pick]);
             } else out_q[j] = (char)(33 + rand_indx(&P.qual[((size_t)bp * B + bin) * 94], 94, drawB()));
         }
@@ -637,6 +648,7 @@ struct Sim {
     int exhausted_passes = 0;               // counter mode: passes in which a primer type ran dry (run again sequentially, amplify_pass)
     std::vector<long> primerUsed;           // attachments per primer type over the whole run (dump / statistics only)
     std::vector<uint64_t> binom;            // [REMAP] counter mode: error-count thresholds
+    double bias_attach = 1.0, bias_gc = 1.0; // test_bias() of the two per-unit branches (1.0 outside the bias test)
     // sharded mode: this shard owns fragments [frag_gbase, frag_gbase + frags.size()) of the global list
     uint64_t frag_gbase = 0;
     std::vector<size_t> semi_block_end;     // local semi count after each fragment pass (block p = semis made in pass p)
@@ -855,7 +867,7 @@ void amplify_template(Sim& S, Rng& rng, PrimerPool& pool, bool fromFrag, uint64_
             // fitting try is uniform over the feasible (position, length) pairs (a 64-bit draw); tries that fit but land on
             // an attached position or a primer type without stock fail as in the reference and count as tries
             const AttachFit fit = attach_fit_count(length, (uint32_t)p.ampMin, (uint32_t)p.ampMax);
-            const double qfail = 1.0 - (double)fit.N / ((double)(length - 27) * (double)fit.W);
+            const double qfail = 1.0 - (double)fit.N / ((double)(length - 27) * (double)fit.W) / S.bias_attach;
             do {
                 tryTimes += (int)attach_gap(((double)xt.next() + 0.5) / 4294967296.0, qfail) + 1;
                 if (tryTimes > 50) break;
@@ -1103,7 +1115,8 @@ void amplify_semis(Sim& S, uint32_t cyc) {
 void amplify(Sim& S) {
     if (S.prm.verbose) fprintf(stderr, "\nMALBAC amplification...\n");
     S.primerCount.assign(65536, S.prm.primers); S.primerUsed.assign(65536, 0);
-    if (S.prm.counter) S.binom = binom_table(S.prm.ber, S.prm.ampMin - 8, S.prm.ampMax - 8);
+    if (S.prm.counter) S.binom = binom_table(S.prm.ber * test_bias("errors"), S.prm.ampMin - 8, S.prm.ampMax - 8);
+    S.bias_attach = test_bias("attach"); S.bias_gc = test_bias("gc");
     S.totalPrimers = 65536UL * (unsigned long)S.prm.primers;
     set_primers(S, true, 0);
     amplify_frags(S, 0);
@@ -1134,7 +1147,7 @@ double gc_factor(Sim& S, int gc, uint64_t uid) {
         double r2 = x * x + y * y;
         if (r2 > 1.0 || r2 == 0.0) continue;
         double mult = sqrt(-2.0 * det_log(r2) / r2);
-        double v = S.prof->gcMeans[gc] + S.prof->gcStd * (y * mult);
+        double v = S.prof->gcMeans[gc] + S.prof->gcStd * S.bias_gc * (y * mult);
         if (v < 0) continue;
         return v;
     }
@@ -1786,6 +1799,55 @@ int scso_predict_counter_batch(void* h, const uint8_t* windows, int n, int count
         const size_t stride = 2 * (size_t)n + 64;
         for (int i = 0; i < count; ++i)
             lens[i] = predict(*(Profile*)h, rng, windows + (size_t)i * n, n, is_read1[i] != 0, first_uid + (uint64_t)i, 0, out_bases + (size_t)i * stride, out_quals + (size_t)i * stride);
+        return 0;
+    } catch (const std::exception& e) { g_err = e.what(); return -1; }
+}
+
+// ---- probes of two more [REMAP] branches, for tests/test_oracle_stats.py: the same unit through the reference's draws and through counter mode
+// The attach tries of ONE primer on an EMPTY template of `length` bases (nothing attached, every primer type in stock: only the "does not
+// fit" failures of Fragment.cpp:76-82 / Amplicon.cpp:179-185 are left), `count` times: tries[i] = tries used (51 = gave up), spos / alen
+// of the try that fit.  counter = 0: try by try from two mt19937 streams (int stream: position, real stream: length); counter = 1: the
+// geometric gap + the closed-form fitting try of amplify_template, primer i = Philox block i of ST_ATTACH.
+int scso_attach_tries_batch(unsigned length, int amin, int amax, int count, int counter, uint64_t seed, uint32_t* tries, uint32_t* spos_out, uint32_t* alen_out) {
+    try {
+        if ((int)length < amin + 27) fail("scso_attach_tries_batch: template too short");
+        // (a worker's two generators start from one seed, ThreadPool.cpp:41-47, and run apart as soon as the per-base error draws consume the
+        // real stream alone; in lockstep position and length of a try would be one draw -- the probe starts them a million draws apart)
+        RefStreams st; st.w_real = std::mt19937((unsigned)seed); st.w_int = std::mt19937((unsigned)seed); st.w_real.discard(1000003);
+        Rng rng; rng.counter = counter != 0; rng.ref = &st; rng.key[0] = (uint32_t)seed; rng.key[1] = (uint32_t)(seed >> 32);
+        const AttachFit fit = attach_fit_count(length, (uint32_t)amin, (uint32_t)amax);
+        const double qfail = 1.0 - (double)fit.N / ((double)(length - 27) * (double)fit.W) / test_bias("attach");
+        for (int i = 0; i < count; ++i) {
+            int tryTimes = 0; unsigned spos = 0, alen = 0;
+            if (counter) {
+                Xoshiro xt; { uint32_t c[4] = {(uint32_t)i, 77u, 0u, ST_ATTACH}, o[4]; philox(c, rng.key, o); xt.seed(o); }
+                tryTimes += (int)attach_gap(((double)xt.next() + 0.5) / 4294967296.0, qfail) + 1;
+                if (tryTimes <= 50) {
+                    const uint64_t hi = xt.next(), lo = xt.next(), x64 = (hi << 32) | lo;
+                    attach_fit_decode(fit, length, (uint32_t)amin, (uint32_t)(((unsigned __int128)x64 * fit.N) >> 64), spos, alen);
+                }
+            } else do {
+                const double u1 = rng.integer(Key{}), u2 = rng.real(Key{});
+                spos = (unsigned)(long)(27 + ((long)length - 27) * u1);
+                alen = (unsigned)(amin + (double)(amax + 1 - amin) * u2);
+                tryTimes++;
+                if (tryTimes > 50) break;
+            } while (spos + alen > length);
+            const bool gave_up = tryTimes > 50;
+            tries[i] = gave_up ? 51u : (uint32_t)tryTimes; spos_out[i] = gave_up ? 0u : spos; alen_out[i] = gave_up ? 0u : alen;
+        }
+        return 0;
+    } catch (const std::exception& e) { g_err = e.what(); return -1; }
+}
+// Profile::getGCFactor (Profile.cpp:1503-1513) for one GC percentage, `count` times: counter = 0 from the reference's engine of that
+// percentage (minstd_rand0 + libstdc++ normal_distribution, Profile.cpp:1405-1411), counter = 1 the keyed polar method (uid = i).
+int scso_gc_factor_batch(void* h, int gc, int count, int counter, uint64_t seed, double* out) {
+    try {
+        Sim S; S.prof = (Profile*)h; S.prm.counter = counter != 0; S.rng.counter = counter != 0;
+        S.rng.key[0] = (uint32_t)seed; S.rng.key[1] = (uint32_t)(seed >> 32); S.bias_gc = test_bias("gc");
+        struct Lend { Sim& s; ~Lend() { s.prof = nullptr; } } lend{S};               // (the profile stays the caller's)
+        for (int l = 0; l < 101; ++l) { S.gcGen.emplace_back((unsigned)seed); S.gcDist.emplace_back(S.prof->gcMeans[l], S.prof->gcStd); }
+        for (int i = 0; i < count; ++i) out[i] = gc_factor(S, gc, (uint64_t)i);
         return 0;
     } catch (const std::exception& e) { g_err = e.what(); return -1; }
 }

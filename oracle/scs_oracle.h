@@ -92,4 +92,8 @@ int scso_predict_ref_batch(void* h, const uint8_t* windows, int n, int count, co
                            char* out_bases, char* out_quals, int* lens);
 int scso_predict_counter_batch(void* h, const uint8_t* windows, int n, int count, const uint8_t* is_read1, uint64_t seed, uint64_t first_uid,
                                char* out_bases, char* out_quals, int* lens);
+// two more remapped units, the reference's draws (counter = 0) against counter mode (counter = 1): the attach tries of one primer on an
+// empty template (tries used, 51 = gave up; position and length of the try that fit) and the GC factor of one GC percentage
+int scso_attach_tries_batch(unsigned length, int amin, int amax, int count, int counter, uint64_t seed, uint32_t* tries, uint32_t* spos, uint32_t* alen);
+int scso_gc_factor_batch(void* h, int gc, int count, int counter, uint64_t seed, double* out);
 }

@@ -7,4 +7,5 @@ createFrags, amplify, yieldReads).  There is no CPU fallback: importing works an
 `GenReads` needs the built library and a GPU, and fails loudly otherwise.
 """
 from .api import (GenReads, ScsError, Profile, fasta_probe, fasta_write_index, lib_path, load_library, build,  # noqa: F401
-                  merge_fastq_shards, merge_fastq_parts, part_paths, text_checksum, gpu_local_cpus, bgzf_probe, bgzf_blocks, comm_unique_id, simuvars_probe, devbuf_probe)
+                  merge_fastq_shards, merge_fastq_parts, part_paths, text_checksum, gpu_local_cpus, bgzf_probe, bgzf_blocks, comm_unique_id, simuvars_probe, devbuf_probe,
+                  SCS_OK, SCS_EINVAL, SCS_EIO, SCS_EDEVICE, SCS_EOVERFLOW)

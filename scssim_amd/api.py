@@ -15,6 +15,9 @@ def build(verbose=False):
     subprocess.check_call(["make", "-C", os.path.join(HERE, "csrc"), "-j4"] + ([] if verbose else ["-s"]))
 
 
+SCS_OK, SCS_EINVAL, SCS_EIO, SCS_EDEVICE, SCS_EOVERFLOW = 0, 1, 2, 3, 4       # include/scssim_hip.h
+
+
 class ScsError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__("scssim_hip error %d: %s" % (code, msg))

@@ -11,6 +11,7 @@ namespace {
 void set_primers_launch(scs_ctx* c, bool only_frags, uint32_t call, uint32_t ns_cap) {
     hipStream_t s = c->stream;
     const uint32_t nf = (uint32_t)c->f_len.size(), ns = only_frags ? 0u : ns_cap;
+    if (nf >= (1u << 26)) throw ScsError(SCS_EOVERFLOW, "more than 2^26 fragments on one GPU: shard the job (the stock keys hold 26 bits of fragment index)");
     PoissonParams p; p.key = c->key; p.call = call; p.gamma = c->cfg.gamma; p.total_primers = c->total_primers;
     p.nf = nf; p.frag_len = c->frag_total_len; p.dev = c->dsums.as<unsigned long long>(); p.totals = nullptr; p.total_primers_dev = nullptr;
     if (c->sharded()) {
@@ -23,7 +24,7 @@ void set_primers_launch(scs_ctx* c, bool only_frags, uint32_t call, uint32_t ns_
     c->scan_tmp.reserve(scan_temp_bytes(std::max(nf, ns)), s);
     // sums[0..1] are zero here: the previous call's mail cleared them after reading (k_amplify_init zeroes them first)
     c->poisson_part.reserve(((size_t)nf + (size_t)ns / 256 + 4) * 8, s);
-    launch_poisson(s, c->frags_view(), c->semis.view(), ns, p, c->budget_f.as<uint32_t>(), c->budget_s.as<uint32_t>(), c->dsums.as<unsigned long long>(), c->poisson_part.as<unsigned long long>());
+    launch_poisson(s, c->frags_view(), c->semis.view(), ns, p, c->budget_f.as<uint32_t>(), c->budget_s.as<uint32_t>(), c->dsums.as<unsigned long long>(), c->poisson_part.as<unsigned long long>(), c->flags.as<uint32_t>());
     exclusive_scan_u32_pair(s, c->budget_f.as<uint32_t>(), c->slot_off_f.as<uint32_t>(), nf, ns ? c->budget_s.as<uint32_t>() : nullptr, c->slot_off_s.as<uint32_t>(), ns, c->scan_tmp.p, c->scan_tmp.cap);
     const bool sh = c->sharded();                                                  // sharded: the budget sums ride on the next pass's all-reduce (and are cleared there)
     c->budgets_pending = sh;

@@ -109,13 +109,19 @@ std::string part_path(const std::string& base, int part, int parts, int mate, bo
 std::string parts_index_path(const std::string& base) { return base + ".parts"; }
 
 FastqParts::~FastqParts() { std::string e; (void)close(e); }
+// (close() opens every part, so no set-aside file of an in-place job outlives it; a part that failed to open leaves its ".prev" behind, unlinked here)
+void FastqParts::drop_set_aside() {
+    if (!in_place_) return;
+    for (int k = writers; k < regions; ++k) for (int m = 0; m < (paired_ ? 2 : 1); ++m) (void)::unlink((part_path(base_, k, regions, m, paired_, suffix_) + ".prev").c_str());
+}
 bool FastqParts::open_part(int k, std::string& err) {
     Part& P = part_[(size_t)k];
     if (P.opened) return true;
     for (int m = 0; m < (paired_ ? 2 : 1); ++m) {
         const std::string p = part_path(base_, k, regions, m, paired_, suffix_);
         // in place: a file that is there already keeps its pages and is overwritten where it lies; its length is set when the part is
-        // finished.  (Freeing a file system's pages and taking them again costs more than the copy into them: tools/overwrite_probe.py)
+        // finished.  (Freeing a file system's pages and taking them again costs more than the copy into them: tools/probes/overwrite_probe.py)
+        if (in_place_ && k >= writers) (void)::rename((p + ".prev").c_str(), p.c_str());   // a later generation's old file, set aside by open(): back under its name now
         P.fd[m] = ::open(p.c_str(), O_WRONLY | O_CREAT | (in_place_ ? 0 : O_TRUNC), 0644);
         if (P.fd[m] < 0) { err = "Error: can not open fastq file to save results:\n" + p; P.failed = true; return false; }
     }
@@ -141,6 +147,12 @@ bool FastqParts::open(const std::string& base, bool paired, int nwriters, int ge
     (void)::unlink(parts_index_path(base).c_str());                                  // a stale index must not describe the new files
     // the first generation's files are opened here, so that an output that cannot be written is reported before the job runs;
     // the later ones when their first batch arrives (a part's existence tells a consumer that the part `writers` before it is final)
+    // In place, the files of an earlier job are still there under the later generations' names, and a consumer would take them for the
+    // signal that the generation before is final: they are set aside (renamed, pages kept) until their part's first batch arrives.
+    if (in_place_) for (int k = writers; k < regions; ++k) for (int m = 0; m < (paired_ ? 2 : 1); ++m) {
+        const std::string p = part_path(base_, k, regions, m, paired_, suffix_);
+        if (::rename(p.c_str(), (p + ".prev").c_str()) != 0 && errno != ENOENT) { err = "Error: can not open fastq file to save results:\n" + p; return false; }
+    }
     for (int k = 0; k < writers; ++k) if (!open_part(k, err)) return false;
     return true;
 }
@@ -174,6 +186,7 @@ bool FastqParts::close(std::string& err) {
         finish_part((int)k);
         if (part_[k].failed) { good = false; if (err.empty()) err = e.empty() ? "writing " + part_path(base_, (int)k, regions, 0, paired_, suffix_) + " failed" : e; }
     }
+    if (any) drop_set_aside();
     if (!good) return false;
     if (any && regions > 1) {
         FILE* f = fopen(parts_index_path(base_).c_str(), "w");

@@ -42,7 +42,9 @@ class FastqParts : public BatchSink {
 public:
     ~FastqParts() override;
     // in_place: files that exist are not truncated when they are opened but overwritten where they lie (their pages stay) and cut
-    // to their new length when the part is finished -- the same files in the end
+    // to their new length when the part is finished -- the same files in the end.  With generations the "part p + writers exists => part p is
+    // final" protocol still holds: the earlier job's files of the later generations are renamed to <name>.prev by open() and come back under
+    // their names (pages kept) when their first batch arrives
     bool open(const std::string& base, bool paired, int writers, int generations, const std::string& suffix, bool bgzf_eof, std::string& err, bool in_place = false);
     int put(int region, const char* a, size_t na, const char* b, size_t nb) override;
     bool close(std::string& err);                          // sizes final, index written (parts > 1)
@@ -50,7 +52,7 @@ public:
     const std::string& first_path() const { return first_; }
 private:
     struct Part { int fd[2] = {-1, -1}; uint64_t pos[2] = {0, 0}; bool failed = false, opened = false, done = false; };
-    bool open_part(int k, std::string& err); void finish_part(int k);
+    bool open_part(int k, std::string& err); void finish_part(int k); void drop_set_aside();
     std::vector<Part> part_; std::vector<int> cur_; std::string base_, first_, suffix_; bool paired_ = true, eof_ = false, in_place_ = false;
 };
 std::string part_path(const std::string& base, int part, int parts, int mate, bool paired, const std::string& suffix);

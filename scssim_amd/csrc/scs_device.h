@@ -105,7 +105,7 @@ struct AllocPlan {
 struct SegMap { uint32_t n; uint32_t lo[ALLOC_SLOTS], cnt[ALLOC_SLOTS]; unsigned long long go[ALLOC_SLOTS]; };
 
 // error flags raised by kernels (never silent): bit 0 error-list cap, 1 error pool, 2 read slot, 3 other
-enum DevFlag : uint32_t { FLAG_ERRCAP = 1, FLAG_ERRPOOL = 2, FLAG_READSLOT = 4, FLAG_INTERNAL = 8 };
+enum DevFlag : uint32_t { FLAG_ERRCAP = 1, FLAG_ERRPOOL = 2, FLAG_READSLOT = 4, FLAG_INTERNAL = 8, FLAG_KEYSPACE = 16 };
 
 // one planned read pair (or SE read) with its amplicon already resolved to an index map into the genome:
 // U[t] = maybe_comp(G[base + dir*t]) patched by the semi's errors (at t = k1 - pos(e), value comp(alt))
@@ -125,7 +125,7 @@ void launch_attach_frags(hipStream_t s, const uint8_t* g, DevFrags fr, const uin
                          unsigned long long* len_part, AmplifyParams p, uint32_t t_first, uint32_t t_end, int undo, const unsigned long long* t_from);   // len_part: one slot per fragment; t_from (device, or null): skip the templates before it
 void launch_frag_len_sum(hipStream_t s, const unsigned long long* len_part, uint32_t nf, unsigned long long* len_sum);   // *len_sum += the pass's amplicon lengths
 void launch_poisson(hipStream_t s, DevFrags fr, DevAmps semis, uint32_t n_semis, PoissonParams p, uint32_t* budget_f, uint32_t* budget_s,
-                    unsigned long long* sums, unsigned long long* part);   // part: one slot per workgroup (fragments + ceil((n_semis + 1) / 256))
+                    unsigned long long* sums, unsigned long long* part, uint32_t* flags);   // part: one slot per workgroup (fragments + ceil((n_semis + 1) / 256))
 // read allocation, stage by stage (the pipeline puts the shards' exchanges between them)
 void launch_alloc_bpack(hipStream_t s, const double* w, const AllocPlan& pl, double* send);
 void launch_alloc_bgather(hipStream_t s, const double* w, const AllocPlan& pl, const double* gathered, double* brow, int* bmap);

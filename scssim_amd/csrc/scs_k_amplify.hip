@@ -305,7 +305,7 @@ __device__ __forceinline__ void poisson_semis_block(uint32_t block, DevAmps semi
 // fragments: lambda in the hundreds to thousands -> one 256-thread workgroup per fragment.  A round = 1024 draws: every
 // thread turns one Philox block into four logs (LDS, draw order); then the first wave adds them to log1 IN DRAW ORDER
 // (the rounding of the serial loop), eight at a time with one exit test per eight.
-__device__ __forceinline__ void poisson_frag_block(uint32_t t, DevFrags fr, const PoissonParams& p, uint32_t* __restrict__ budget_f, unsigned long long* __restrict__ part) {
+__device__ __forceinline__ void poisson_frag_block(uint32_t t, DevFrags fr, const PoissonParams& p, uint32_t* __restrict__ budget_f, unsigned long long* __restrict__ part, uint32_t* __restrict__ flags) {
     __shared__ double s_lg[1024];
     __shared__ int s_more;
     const int tid = threadIdx.x;
@@ -334,13 +334,16 @@ __device__ __forceinline__ void poisson_frag_block(uint32_t t, DevFrags fr, cons
         __syncthreads();
         if (!s_more) break;
     }
-    if (tid == 0) { budget_f[t] = (uint32_t)(int)x; part[blockIdx.x] = (unsigned long long)x; }
+    if (tid == 0) {
+        budget_f[t] = (uint32_t)(int)x; part[blockIdx.x] = (unsigned long long)x;
+        if ((unsigned long long)x >= (1ull << 20)) atomicOr(flags, (uint32_t)FLAG_KEYSPACE);   // attach_key packs a fragment's primer index into 20 bits
+    }
 }
 
 // one launch for both template kinds: workgroups [0, nf) take a fragment each, the rest 256 semi amplicons each
 __global__ void __launch_bounds__(256) k_poisson(DevFrags fr, DevAmps semis, uint32_t n_cap, PoissonParams p, uint32_t* __restrict__ budget_f,
-                                                 uint32_t* __restrict__ budget_s, unsigned long long* __restrict__ part) {
-    if (blockIdx.x < fr.n) poisson_frag_block(blockIdx.x, fr, p, budget_f, part);
+                                                 uint32_t* __restrict__ budget_s, unsigned long long* __restrict__ part, uint32_t* __restrict__ flags) {
+    if (blockIdx.x < fr.n) poisson_frag_block(blockIdx.x, fr, p, budget_f, part, flags);
     else poisson_semis_block(blockIdx.x - fr.n, semis, n_cap, p, budget_s, part);
 }
 // *dst += sum of a u64 array (per-workgroup partials).  A few dozen workgroups, one atomic each (integer sums: any order): as ONE
@@ -378,6 +381,7 @@ __global__ void __launch_bounds__(1024) k_poisson_sums(const unsigned long long*
 //     no type is over its stock and no cut type under it: at that fixed point every decision equals the sequential
 //     loop's (induction over the keys), and each round extends the prefix of the list on which that holds.
 // ------------------------------------------------------------------------------------------------
+// (enforced: set_primers_launch refuses 2^26 local fragments, k_poisson flags a fragment budget of 2^20 -- FLAG_KEYSPACE --; a semi's budget is masked to 12 bits)
 #define STOCK_KEY_BITS 46                                                           // (fragment < 2^26, primer < 2^20) or (semi < 2^32, primer < 2^12), + 1
 template <bool FROM_FRAG> __device__ __forceinline__ unsigned long long attach_key(uint32_t t, uint32_t i) {
     return (((unsigned long long)t << (FROM_FRAG ? 20 : 12)) | i) + 1ull;         // never 0: cut 0 = nothing to be had
@@ -797,10 +801,10 @@ void launch_frag_len_sum(hipStream_t s, const unsigned long long* len_part, uint
     if (nf) hipLaunchKernelGGL(k_sum_u64_add, dim3(std::min(cdiv(nf, 2048), 128u)), dim3(1024), 0, s, len_part, nf, len_sum);
 }
 void launch_poisson(hipStream_t s, DevFrags fr, DevAmps semis, uint32_t n_semis, PoissonParams p, uint32_t* budget_f, uint32_t* budget_s,
-                    unsigned long long* sums, unsigned long long* part) {
+                    unsigned long long* sums, unsigned long long* part, uint32_t* flags) {
     const uint32_t semi_blocks = n_semis ? cdiv((uint64_t)n_semis + 1, 256) : 0u;
     if (fr.n + semi_blocks) {
-        hipLaunchKernelGGL(k_poisson, dim3(fr.n + semi_blocks), dim3(256), 0, s, fr, semis, n_semis, p, budget_f, budget_s, part);
+        hipLaunchKernelGGL(k_poisson, dim3(fr.n + semi_blocks), dim3(256), 0, s, fr, semis, n_semis, p, budget_f, budget_s, part, flags);
         hipLaunchKernelGGL(k_poisson_sums, dim3(1), dim3(1024), 0, s, part, fr.n, fr.n + semi_blocks, sums);
     }
 }

@@ -99,6 +99,7 @@ __device__ __noinline__ uint32_t rand_indx_slow(const double* __restrict__ cdf, 
 }
 // first k with x < T[k], else ac-1 (T non-decreasing)
 __device__ __forceinline__ uint32_t rand_indx_thr(const uint32_t* __restrict__ T, const double* __restrict__ cdf, uint32_t ac, uint32_t x) {
+    if (ac == 0u) return 0u;                  // an empty table has no last entry (the hosts refuse such a lookup before any launch: do_yield)
     if (x == 0xFFFFFFFFu) return rand_indx_slow(cdf, ac, x);
     uint32_t lo = 0, hi = ac;                 // lower bound of "x < T[k]"
     while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (x < T[mid]) hi = mid; else lo = mid + 1; }

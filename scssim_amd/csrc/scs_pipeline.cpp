@@ -42,6 +42,7 @@ void flags_eval(scs_ctx* c) {
         if (f & FLAG_ERRPOOL) m += " error overflow pool";
         if (f & FLAG_READSLOT) m += " read slot (indel-extended read longer than the slot)";
         if (f & FLAG_INTERNAL) m += " internal";
+        if (f & FLAG_KEYSPACE) m += " primer budget of a fragment beyond 2^20 (-p / -r far outside the reference's ranges)";
         throw ScsError(SCS_EOVERFLOW, m);
     }
 }

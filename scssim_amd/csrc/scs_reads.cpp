@@ -142,7 +142,8 @@ std::vector<int> gpu_local_cpus(int device) {
     { FILE* f = fopen(("/sys/devices/system/node/node" + std::to_string(node) + "/cpulist").c_str(), "r"); if (!f) return out; if (!fgets(list, sizeof list, f)) list[0] = 0; fclose(f); }
     cpu_set_t allowed; CPU_ZERO(&allowed);
     if (sched_getaffinity(0, sizeof allowed, &allowed) != 0) return out;
-    for (char* tok = strtok(list, ",\n"); tok; tok = strtok(nullptr, ",\n")) {
+    char* save = nullptr;                                                          // (strtok_r: two ctxs on two host threads come through here at once)
+    for (char* tok = strtok_r(list, ",\n", &save); tok; tok = strtok_r(nullptr, ",\n", &save)) {
         int a = 0, b = 0; const int k = sscanf(tok, "%d-%d", &a, &b); if (k < 1) continue; if (k == 1) b = a;
         for (int c = a; c <= b && c < CPU_SETSIZE; ++c) if (CPU_ISSET(c, &allowed)) out.push_back(c);
     }
@@ -221,6 +222,10 @@ void do_yield(scs_ctx* c, const OutTarget& tg, uint64_t* n1_out, uint64_t* n2_ou
     c->timing_gate = (c->yield_calls++ % c->timing_every) == 0;
     c->tm_reads.reset(); c->tm_indels.reset();
     const uint64_t P = c->n_pairs_planned;
+    // A paired-end job on a model whose [Insert Size Standard Deviation] is 0 has no insert-size alphabet (Profile.cpp:908: built only when
+    // stdISize > 0); the reference's first yieldInsertSize then asks its Config for a parameter that does not exist and exit(1)s
+    // (Profile.cpp:1482-1485 -> Config.cpp:85-93) -- after the amplification, with the output files opened and empty.  Same here, as an error code.
+    if (paired && P > 0 && c->prof.isize_t.empty()) throw ScsError(SCS_EIO, "Error: unrecognized parameter name \"insertSize\"");
     const uint32_t L = (uint32_t)c->prof.read_length, slot = ((L + 64 + 63) / 64) * 64;
     c->pairs.reserve(std::max<size_t>(P * sizeof(PairRec), 16), s);
     HIP_OK(hipMemsetAsync(c->dsums.as<unsigned long long>() + DS_HOLES, 0, 8, s));
@@ -237,6 +242,10 @@ void do_yield(scs_ctx* c, const OutTarget& tg, uint64_t* n1_out, uint64_t* n2_ou
     if (to_sink && tg.sink->writers > 4) {
         const uint64_t per_part = P / (2ull * (uint64_t)std::max(1, regions));     // two batches per part file
         sink_batch = 1ull << 18; while (sink_batch < (1ull << 21) && sink_batch * 2 <= per_part) sink_batch <<= 1;
+        // writers + 2 pinned slots of two mates each stay allocated until the ctx goes: at most 24 GB of them per ctx (12 writers x 2 M pairs of
+        // PE150 = 19.5 GB; 64 writers would pin 92 GB per rank)
+        const uint64_t per_pair = 4ull * L + 64ull;
+        while (sink_batch > (1ull << 18) && ((uint64_t)tg.sink->writers + 2ull) * sink_batch * per_pair > (24ull << 30)) sink_batch >>= 1;
     }
     const uint64_t batch = std::min<uint64_t>(std::max<uint64_t>(P, 1), batch_shift ? (1ull << batch_shift) : to_sink ? sink_batch : (1ull << 23));
     // The pairs are planned (k_plan_pairs: insert sizes, positions, the amplicon resolved to an index map) batch by batch, at the

@@ -511,8 +511,11 @@ def test_bench_two_rank_control_flow(ranks, tmp_path):
     env = dict(os.environ, SCS_BENCH_BACKEND="gloo", SCS_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
-                        "--master-port", str(29791 + ranks), os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "2", "--warmup", "1", "--genome-mb", "4"],
+    # 2 ranks: the plain command, no launcher on the command line -- bench.py starts its own ranks before its first GPU call
+    # (launch_ranks); 4 ranks: the driver's own command
+    launcher = [] if ranks == 2 else ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
+                                      "--master-port", str(29791 + ranks)]
+    r = subprocess.run([sys.executable] + launcher + [os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "2", "--warmup", "1", "--genome-mb", "4"],
                        env=env, capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -624,6 +627,68 @@ def test_bench_profile_pe150_bit_exact(oracle_bin, models, tmp_path):
     assert g.stats()["pairs_written"] == 10000
     assert fq1 == open(prefix + "_1.fq", "rb").read()
     assert fq2 == open(prefix + "_2.fq", "rb").read()
+
+
+def test_config1_full_size_bit_exact(oracle_bin, models, tmp_path):
+    """BASELINE configs[1] AT ITS STATED SIZE, bit for bit: 1 Mb synthetic reference (x 2 haplotypes), PE150 (the HiSeq2500 model
+    resampled to 150 bins), 30x, -s 260 -- 100 000 pairs; the FASTQ of the HIP path == the oracle's, through the API and through the
+    CLI's two files."""
+    fa = str(tmp_path / "simu.fa")
+    subprocess.check_call(["python3", os.path.join(ROOT, "tools", "make_genome.py"), "--lengths", "1000000", "--seed", "1", "--simu-out", fa])
+    prof = str(tmp_path / "pe150.profile")
+    subprocess.check_call(["python3", os.path.join(ROOT, "tools", "make_profile.py"), models["Illumina_HiSeq2500"], prof, "--read-length", "150"])
+    prefix = str(tmp_path / "orc")
+    _oracle_run(oracle_bin, fa, prof, prefix, ["-c", "30", "-s", "260"], 11, threads=min(32, os.cpu_count() or 1))
+    want = [open(prefix + s, "rb").read() for s in ("_1.fq", "_2.fq")]
+    g = scssim_amd.GenReads(profile=prof, input_fasta=fa, coverage=30.0, isize=260, seed=11)
+    fq1, fq2 = g.run()
+    st = g.stats()
+    assert st["reads_requested"] == 200000 and st["pairs_written"] == 100000 == want[0].count(b"\n") // 4
+    assert fq1 == want[0] and fq2 == want[1]
+    g.close()
+    exe = os.path.join(ROOT, "scssim_amd", "bin", "scssim")
+    out = str(tmp_path / "cli")
+    r = subprocess.run([exe, "genreads", "-i", fa, "-m", prof, "-c", "30", "-s", "260", "-o", out, "--seed", "11"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert open(out + "_1.fq", "rb").read() == want[0] and open(out + "_2.fq", "rb").read() == want[1]
+
+
+def test_paired_end_job_on_a_model_without_insert_size_spread_fails_like_the_reference(oracle_bin, models, golden_inputs, tmp_path):
+    """[Insert Size Standard Deviation] 0 + PE: the reference has no insert-size alphabet (Profile.cpp:908), its first yieldInsertSize
+    asks Config for a parameter that does not exist and exit(1)s with `Error: unrecognized parameter name "insertSize"`
+    (Profile.cpp:1482-1485, Config.cpp:85-93) after the amplification, its two files opened and empty.  The oracle fails the same way;
+    the library returns SCS_EIO with that message (the ctx stays usable), the CLI prints it and leaves with status 1 -- and the same model
+    runs a single-end job, equal to the oracle's."""
+    import re
+    fa = golden_inputs["g1_hiseq2500_pe"]
+    prof = str(tmp_path / "sigma0.profile")
+    text = open(models["Illumina_HiSeq2500"]).read()
+    text2 = re.sub(r"(\[Insert Size Standard Deviation\]\s*\n)\S+", r"\g<1>0", text)
+    assert text2 != text
+    open(prof, "w").write(text2)
+    msg = 'Error: unrecognized parameter name "insertSize"'
+    r = subprocess.run([oracle_bin, "genreads", "-i", fa, "-m", prof, "-c", "2", "-o", str(tmp_path / "orc_pe"), "--rng", "counter", "--seed", "4", "-t", "4", "-q"],
+                       capture_output=True, text=True)
+    assert r.returncode != 0 and msg in r.stderr
+    g = scssim_amd.GenReads(profile=prof, input_fasta=fa, coverage=2.0, seed=4)
+    g.create_frags(); g.amplify(); g.allocate_reads(0)
+    with pytest.raises(scssim_amd.ScsError) as e:
+        g.yield_reads_files(str(tmp_path / "lib_pe"))
+    assert msg in str(e.value) and e.value.code == scssim_amd.SCS_EIO
+    assert os.path.getsize(str(tmp_path / "lib_pe") + "_1.fq") == 0 and os.path.getsize(str(tmp_path / "lib_pe") + "_2.fq") == 0   # SeqWriter opened them (Malbac.cpp:426-435)
+    with pytest.raises(scssim_amd.ScsError) as e:
+        g.yield_reads_sink(None)
+    assert msg in str(e.value)
+    g.close()
+    exe = os.path.join(ROOT, "scssim_amd", "bin", "scssim")
+    r = subprocess.run([exe, "genreads", "-i", fa, "-m", prof, "-c", "2", "-o", str(tmp_path / "cli_pe"), "--seed", "4"], capture_output=True, text=True)
+    assert r.returncode == 1 and msg in r.stderr and "MALBAC amplification..." in r.stderr, r.stderr
+    # single end: no insert size is drawn, the model is fine
+    _oracle_run(oracle_bin, fa, prof, str(tmp_path / "orc_se"), ["-c", "2", "-l", "SE"], 4)
+    g = scssim_amd.GenReads(profile=prof, input_fasta=fa, coverage=2.0, layout="SE", seed=4)
+    fq, _ = g.run()
+    assert fq == open(str(tmp_path / "orc_se") + ".fq", "rb").read() and len(fq) > 100000
+    g.close()
 
 
 @pytest.mark.parametrize("rl,layout", [(17, "SE"), (36, "PE"), (51, "PE"), (75, "SE"), (257, "PE")])

@@ -79,6 +79,7 @@ def test_in_place_sink_leaves_the_same_files_as_truncating(oracle_bin, models, g
     reference's two files): after every job the files are exactly what a job into fresh files leaves -- no tail of the older, longer
     file, the parts index of the new job; the CLI's --in-place the same."""
     import gzip
+    import threading
     fa, prof = golden_inputs["g1_hiseq2500_pe"], models["Illumina_HiSeq2500"]
     want = {}
     for cov, seed in ((3.0, 21), (1.0, 22)):
@@ -90,7 +91,25 @@ def test_in_place_sink_leaves_the_same_files_as_truncating(oracle_bin, models, g
     for cov, seed in ((3.0, 21), (1.0, 22), (3.0, 21)):
         g = scssim_amd.GenReads(profile=prof, input_fasta=fa, coverage=cov, seed=seed)
         g.create_frags(); g.amplify(); g.allocate_reads(0)
-        g.yield_reads_files(out, 3, 2, in_place=True)
+        # a consumer that follows the protocol beside the job: whenever it sees part p + writers it reads part p and requires the FINAL
+        # bytes (the files of the job before, still lying under the later generation's names, must not give that signal: they are set aside)
+        files_now = scssim_amd.part_paths(out, 6, True)
+        stop, seen_bad = threading.Event(), []
+
+        def follow():
+            while not stop.is_set():
+                for p_ in range(3):
+                    if os.path.exists(files_now[0][p_ + 3]):
+                        got = open(files_now[0][p_], "rb").read()
+                        if got not in want[seed][0]:
+                            seen_bad.append((seed, p_, len(got)))
+        th = threading.Thread(target=follow); th.start()
+        try:
+            g.yield_reads_files(out, 3, 2, in_place=True)
+        finally:
+            stop.set(); th.join()
+        assert not seen_bad, seen_bad
+        assert not [f for f in os.listdir(str(tmp_path)) if f.endswith(".prev")]
         g.yield_reads_files(single, 1, in_place=True)
         g.yield_reads_files(gz, 2, 1, bgzf=True, in_place=True)
         files = scssim_amd.part_paths(out, 6, True)

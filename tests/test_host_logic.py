@@ -258,6 +258,26 @@ def test_cli_sharded_job_fails_fast_when_its_ranks_cannot_start(golden_inputs, m
         assert "no HIP device" in err or "failed" in err
 
 
+def test_bench_starts_its_own_ranks_and_relays_their_failure(tmp_path):
+    """`python bench.py --gpus 2` with no launcher on the command line: the parent (which never touches a GPU) starts the two ranks as
+    children and returns non-zero when they die -- here, on the GPU-less build box, both do at once; no JSON line, no usage line."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: tests/test_gpu_parity.py::test_bench_two_rank_control_flow runs the real thing")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--genome-mb", "4"],
+                       env=env, capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
+    assert r.returncode != 0
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")] and "launch with" not in r.stderr
+    assert "local_rank: 1" in r.stderr or "rank      : 1" in r.stderr or "exitcode" in r.stderr      # torch.distributed.run's report of the dead ranks
+    # a rank count that disagrees with the launcher's is refused by every rank
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3"], env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"),
+                       capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
+
+
 def test_bgzf_arithmetic_inflates_with_zlib():
     """The BGZF kernels' arithmetic run on the CPU (scs_bgzf_probe: the same functions "thread" by "thread" -- Huffman lengths with
     the 15-bit limit, the run-length coded header under a fixed code-length code, 256 chunks packed at prefix-sum bit offsets, 256

@@ -31,9 +31,10 @@ def main():
     rows = sorted(((short(k), f[k][0], w.get(k, (0.0, 0))[0], f[k][1]) for k in f), key=lambda r: -(r[1] + r[2]) * r[3])
     with open(out, "w") as o:
         o.write("# rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes), %s; values in KB per launch, raw (no gfx950 x2 read correction applied)\n" % cmd)
-        o.write("kernel,FETCH_SIZE_KB_per_launch,WRITE_SIZE_KB_per_launch,launches\n")
+        wr = csv.writer(o, lineterminator="\n")                       # (kernel names hold commas: scs::k_attach<true, 64> -- quoted)
+        wr.writerow(["kernel", "FETCH_SIZE_KB_per_launch", "WRITE_SIZE_KB_per_launch", "launches"])
         for k, a, b, n in rows:
-            o.write("%s,%.1f,%.1f,%d\n" % (k, a, b, n))
+            wr.writerow([k, "%.1f" % a, "%.1f" % b, "%d" % n])
 
 
 if __name__ == "__main__":

@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of one environment knob on the same box: tools/ab_env.sh KNOB [bench.py arguments]; alternates default / KNOB=1 twice
+# A/B of one environment knob on the same box: tools/probes/ab_env.sh KNOB [bench.py arguments]; alternates default / KNOB=1 twice
 K=$1; shift
 for r in 1 2; do
   for v in "" 1; do

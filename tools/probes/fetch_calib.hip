@@ -8,7 +8,7 @@
 //   k_dword  : one dword per lane at a random place (k_attach's primer gathers are 8 bytes: the same sector economics)
 //   k_store32: every lane stores one whole 32-byte sector (two dwordx4) at a random sector (k_reads' sector stores)
 // Run under rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes); the program prints the true bytes per kernel.
-//   hipcc --offload-arch=gfx950 -O3 tools/fetch_calib.hip -o /tmp/fetch_calib
+//   hipcc --offload-arch=gfx950 -O3 tools/probes/fetch_calib.hip -o /tmp/fetch_calib
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>

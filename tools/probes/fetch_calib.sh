@@ -1,9 +1,9 @@
 #!/bin/bash
-# builds and runs tools/fetch_calib.hip under rocprofv3 (FETCH_SIZE and WRITE_SIZE in separate passes): gpurun -- 'bash tools/fetch_calib.sh'
+# builds and runs tools/probes/fetch_calib.hip under rocprofv3 (FETCH_SIZE and WRITE_SIZE in separate passes): gpurun -- 'bash tools/probes/fetch_calib.sh'
 set -e
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/fetch_calib; rm -rf $OUT; mkdir -p $OUT
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 $ROOT/tools/fetch_calib.hip -o $OUT/fetch_calib
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 $ROOT/tools/probes/fetch_calib.hip -o $OUT/fetch_calib
 cd /tmp && export TMPDIR=/tmp
 $OUT/fetch_calib > $OUT/truth.txt
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/f -o f -- $OUT/fetch_calib > /dev/null 2>&1

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Buffered-write, overwrite and unlink rates of a file system from T threads on T files (what bounds a FASTQ sink on the GPU
-box): python tools/fs_probe.py DIR [threads] [GB per file].  os.pwrite / os.unlink release the GIL."""
+box): python tools/probes/fs_probe.py DIR [threads] [GB per file].  os.pwrite / os.unlink release the GIL."""
 import os, sys, threading, time
 
 d = sys.argv[1] if len(sys.argv) > 1 else "/dev/shm"

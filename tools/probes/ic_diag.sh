@@ -1,5 +1,5 @@
 #!/bin/bash
-# Instruction-cache counters of the reads kernels on a reduced genome: tools/ic_diag.sh <tag>
+# Instruction-cache counters of the reads kernels on a reduced genome: tools/probes/ic_diag.sh <tag>
 set -e
 TAG=$1; shift
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}

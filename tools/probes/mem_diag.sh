@@ -1,5 +1,5 @@
 #!/bin/bash
-# Diagnostic L2 / L1 write counters of the reads kernels on a reduced genome: tools/mem_diag.sh <tag>
+# Diagnostic L2 / L1 write counters of the reads kernels on a reduced genome: tools/probes/mem_diag.sh <tag>
 set -e
 TAG=$1; shift
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}

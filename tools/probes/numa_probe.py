@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Where the GPU sits (NUMA node of its PCIe function), which CPUs are local to it, and what tmpfs writes cost from local and
-from remote CPUs: python tools/numa_probe.py"""
+from remote CPUs: python tools/probes/numa_probe.py"""
 import glob, os, subprocess, sys, time, threading
 import torch
 p = torch.cuda.get_device_properties(0)

@@ -1,5 +1,5 @@
 // ONE output file written by T threads: pwrite() (serialised by the inode lock) against stores through a shared mapping (page faults
-// take pages one by one, no inode lock).   g++ -O2 -pthread tools/onefile_probe.cpp -o /tmp/onefile_probe && /tmp/onefile_probe [threads] [GiB] [chunk MiB]
+// take pages one by one, no inode lock).   g++ -O2 -pthread tools/probes/onefile_probe.cpp -o /tmp/onefile_probe && /tmp/onefile_probe [threads] [GiB] [chunk MiB]
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <unistd.h>

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """What a part file's pages cost: T threads pwrite() G GiB each into tmpfs files that are (a) new, (b) there already (no O_TRUNC:
 the pages are overwritten where they lie), (c) new while T/3 other threads unlink the previous round's files (the bench loop).
-    python tools/overwrite_probe.py [threads=12] [GiB per thread=6]"""
+    python tools/probes/overwrite_probe.py [threads=12] [GiB per thread=6]"""
 import os, sys, threading, time
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 G = float(sys.argv[2]) if len(sys.argv) > 2 else 6.0

@@ -2,7 +2,7 @@
 // tmpfs file; the previous round's files go away (a) by U unlinking threads beside them (what bench.py's Cleaner does), (b) by the
 // writers themselves, a stretch of the old file punched out (fallocate PUNCH_HOLE) before every stretch of the new one is written:
 // the pages a CPU frees are the pages it takes next (per-CPU page lists), (c) not at all (the files are kept: the floor).
-//   g++ -O2 -pthread tools/recycle_probe.cpp -o /tmp/recycle_probe && /tmp/recycle_probe [writers=12] [GiB each=6] [stretch MiB=1] [unlinkers=4]
+//   g++ -O2 -pthread tools/probes/recycle_probe.cpp -o /tmp/recycle_probe && /tmp/recycle_probe [writers=12] [GiB each=6] [stretch MiB=1] [unlinkers=4]
 #include <fcntl.h>
 #include <sys/stat.h>
 #include <unistd.h>

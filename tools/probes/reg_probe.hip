@@ -1,6 +1,6 @@
 // Probe: can a batch's text cross PCIe STRAIGHT INTO the page cache of a tmpfs file (the file mapped shared, the mapping registered
 // with the HIP runtime, the D2H copy's destination) more cheaply than through a pinned slot + pwrite()?  Prints GB/s of each step,
-// for T threads each working on its own file.   hipcc -O2 tools/reg_probe.hip -o /tmp/reg_probe -lpthread ; /tmp/reg_probe [dir] [MB] [threads]
+// for T threads each working on its own file.   hipcc -O2 tools/probes/reg_probe.hip -o /tmp/reg_probe -lpthread ; /tmp/reg_probe [dir] [MB] [threads]
 #include <hip/hip_runtime.h>
 #include <sys/mman.h>
 #include <sys/stat.h>

@@ -1,6 +1,6 @@
 // How fast are the two Random123 block functions on gfx950?  Philox4x32-10 is built on 32 x 32 -> 64-bit multiplies (v_mul_hi_u32 +
 // v_mul_lo_u32: quarter rate on CDNA), Threefry4x32 on add / rotate / xor (full rate).  Blocks per second, every lane busy.
-//   hipcc -O3 --offload-arch=gfx950 tools/rng_rate.hip -o /tmp/rng_rate && /tmp/rng_rate
+//   hipcc -O3 --offload-arch=gfx950 tools/probes/rng_rate.hip -o /tmp/rng_rate && /tmp/rng_rate
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>

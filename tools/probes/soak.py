@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Soak: N whole jobs on a 600 Mb genome in one process (text left in HBM, then through a counting sink), fresh seed each: free
-device memory and the host's resident set before and after (a leak shows as a trend), every job's counts sane.  python tools/soak.py [--jobs 60]"""
+device memory and the host's resident set before and after (a leak shows as a trend), every job's counts sane.  python tools/probes/soak.py [--jobs 60]"""
 import argparse, os, sys, tempfile, time, resource
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

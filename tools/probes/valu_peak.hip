@@ -2,7 +2,7 @@
 // against (bench.py roofline.valu.issue_frac).  Every lane runs K independent chains of the
 // full-rate 32-bit ops the hot kernels are made of (v_add_u32, v_xor_b32, v_alignbit/v_lshl_or); the grid puts 1, 2, 4
 // or 8 waves on every SIMD.  Prints wave-instructions per cycle per SIMD at the nominal 2.4 GHz and the measured time.
-//   hipcc --offload-arch=gfx950 -O3 tools/valu_peak.hip -o /tmp/valu_peak && /tmp/valu_peak
+//   hipcc --offload-arch=gfx950 -O3 tools/probes/valu_peak.hip -o /tmp/valu_peak && /tmp/valu_peak
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>

@@ -24,12 +24,13 @@ def main():
     rows = sorted(((k, v, len(disp[k])) for k, v in tot.items()), key=lambda r: -r[1].get("SQ_INSTS_VALU", 0))
     with open(out, "w") as o:
         o.write("# rocprofv3 --pmc SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU, %s; per launch\n" % cmd)
-        o.write("kernel,valu_insts_per_launch,lanes_per_valu_inst,salu_insts_per_launch\n")
+        wr = csv.writer(o, lineterminator="\n")                       # (kernel names hold commas: quoted)
+        wr.writerow(["kernel", "valu_insts_per_launch", "lanes_per_valu_inst", "salu_insts_per_launch"])
         for k, v, n in rows:
             if not k.startswith("scs::"):
                 continue
             act = v.get("SQ_ACTIVE_INST_VALU", 0.0)
-            o.write("%s,%.0f,%.1f,%.0f\n" % (k, v.get("SQ_INSTS_VALU", 0.0) / n, v.get("SQ_THREAD_CYCLES_VALU", 0.0) / act if act else 0.0, v.get("SQ_INSTS_SALU", 0.0) / n))
+            wr.writerow([k, "%.0f" % (v.get("SQ_INSTS_VALU", 0.0) / n), "%.1f" % (v.get("SQ_THREAD_CYCLES_VALU", 0.0) / act if act else 0.0), "%.0f" % (v.get("SQ_INSTS_SALU", 0.0) / n)])
 
 
 if __name__ == "__main__":
