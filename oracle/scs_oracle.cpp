@@ -1436,6 +1436,10 @@ int genreads(const scso_params& q) {
         if (p.paired) { o2 = fopen((pre + "_2.fq").c_str(), "w"); if (!o2) fail("Error: can not open fastq file to save results:\n" + pre); }
     }
     if (p.verbose) fprintf(stderr, "\n*****Producing reads*****\n");
+    // Profile.cpp:1483-1485: the first yieldInsertSize of a paired-end job on a model without insert-size alphabet exit(1)s; said here, on the
+    // main thread (the same failure inside a worker of the range loop below would end in std::terminate)
+    if (p.paired && S.prof->isizeAlphabet.empty())
+        for (size_t i = 0; i < S.fulls.a.size(); ++i) if (S.readNumbers[i] > 0 && S.fulls.a[i].len >= (unsigned)S.prof->L) fail("Error: unrecognized parameter name \"insertSize\"");
     if (q.checksum_file) {
         // checksum mode (tools/whole_genome_golden.py: BASELINE configs[3] at full size, 197 GB of text): the FASTQ is not written
         // but summed batch by batch the way the library sums its batches (scs_set_batch_checksums, include/scssim_hip.h): batch b
