@@ -301,6 +301,41 @@ def test_cli_writers_and_unopenable_output(oracle_bin, models, golden_inputs, tm
     assert rc == 255 and "can not open fastq file" in err
 
 
+def test_cli_option_errors_exit_like_the_reference(models, golden_inputs, tmp_path):
+    """src/scssim.cpp:349-393: every option check prints the reference's line and leaves with status 1 (before any GPU call)."""
+    fa, prof, out = golden_inputs["g1_hiseq2500_pe"], models["Illumina_HiSeq2500"], str(tmp_path / "o")
+    for args, msg in ((["-m", prof, "-o", out], "reference file (.fasta) not specified"), (["-i", fa, "-o", out], "sequencing profile must be specified"),
+                      (["-i", fa, "-m", prof], "prefix of output file not specified"), (["-i", fa, "-m", prof, "-o", out, "-p", "999"], "should be at least 1000"),
+                      (["-i", fa, "-m", prof, "-o", out, "-r", "1e-7"], "should be in 0~1e-8"), (["-i", fa, "-m", prof, "-o", out, "-l", "XX"], "sequence layout incorrectly specified"),
+                      (["-i", fa, "-m", prof, "-o", out, "-c", "0"], "coverage not properly specified"), (["-i", fa, "-m", prof, "-o", out, "-t", "0"], "threads should be a positive integer")):
+        rc, err, _ = _cli(args)
+        assert rc == 1 and msg in err, (args, rc, err)
+    assert not os.path.exists(out + "_1.fq")
+
+
+def test_cli_input_errors_exit_like_the_reference(models, golden_inputs, tmp_path):
+    """The reference's exit sites behind the option checks ("Error behaviour"): an input FASTA that cannot be opened or holds
+    no sequence -> status 1 (Fasta.cpp:236-237, Genome.cpp:190-193); a model that cannot be opened -> 255 (Profile.cpp:933-936: exit(-1));
+    a model with a section missing or a malformed line -> 1 (Profile.cpp:950-1231)."""
+    fa, prof, out = golden_inputs["g1_hiseq2500_pe"], models["Illumina_HiSeq2500"], str(tmp_path / "o")
+    rc, err, _ = _cli(["-i", str(tmp_path / "missing.fa"), "-m", prof, "-o", out])
+    assert rc == 1 and "could not open" in err, err
+    empty = tmp_path / "empty.fa"; empty.write_text("")
+    rc, err, _ = _cli(["-i", str(empty), "-m", prof, "-o", out])
+    assert rc == 1 and "reference sequence cannot be empty" in err, err
+    rc, err, _ = _cli(["-i", fa, "-m", str(tmp_path / "missing.profile"), "-o", out])
+    assert rc == 255 and "can not open file" in err, err
+    text = open(prof).read()
+    cut = tmp_path / "cut.profile"; cut.write_text(text[:text.index("[Base Quality Distribution]")])
+    rc, err, _ = _cli(["-i", fa, "-m", str(cut), "-o", out])
+    assert rc == 1 and "corrupted model file" in err, err
+    bad = tmp_path / "bad.profile"; bad.write_text(text.replace("kmer: XXA", "kmer: XXZ", 1))          # a k-mer that is not one
+    assert bad.read_text() != text
+    rc, err, _ = _cli(["-i", fa, "-m", str(bad), "-o", out])
+    assert rc == 1 and "model file" in err, err
+    assert not os.path.exists(out + "_1.fq")
+
+
 def test_bgzf_made_on_the_gpu_inflates_to_the_oracle_text(oracle_bin, models, golden_inputs, tmp_path):
     """scs_yield_reads_files_ex(..., bgzf): the batches' text becomes BGZF blocks on the GPU (histogram, Huffman lengths, bit packing,
     CRC-32: scs_bgzf.hip), crosses PCIe compressed and lands in <prefix>_1.fq.gz / part files.  zlib is the checker: every part is
