@@ -459,14 +459,16 @@ def roofline_of(ktimes, fq_bytes, L, dom=None):
     return roof
 
 
-def small_config(torch, scssim_amd, dev, stream, prof, mb, cov, label, shm, steps=5):
+def small_config(torch, scssim_amd, dev, stream, prof, mb, cov, label, shm, steps=5, concurrent=0):
     """One of the smaller BASELINE configurations as an extra line of the same record: the whole job with the text left in HBM
     (`steps` steps) and once with its two FASTQ files on tmpfs."""
     lens = [int(mb * 1e6)]
     names, rl, bases = synth_genome(torch, dev, lens, 7000 + int(mb))
     g = scssim_amd.GenReads(profile=prof, coverage=cov, isize=260, layout="PE", seed=1, device=dev.index, stream=stream.cuda_stream)
     g.upload_genome_device(names, rl, bases.data_ptr())
+    bases_keep = bases if concurrent > 1 else None
     del bases
+    last_stats = {}
 
     def one(i, files=None):
         g.set_seed(500 + i)
@@ -475,6 +477,7 @@ def small_config(torch, scssim_amd, dev, stream, prof, mb, cov, label, shm, step
             g.yield_reads_files(files)
         else:
             g.yield_reads_sink(None)
+        last_stats.update(g.stats())
         return g.stats()["pairs_written"]
     one(0)
     torch.cuda.synchronize()
@@ -486,8 +489,46 @@ def small_config(torch, scssim_amd, dev, stream, prof, mb, cov, label, shm, step
     finally:
         shutil.rmtree(sd, ignore_errors=True)
     g.close()
-    return {"workload": label, "pairs_per_step": pairs // steps, "generation_hbm_pairs_per_s": pairs / dt, "ms_per_step_hbm": 1e3 * dt / steps,
-            "with_two_fastq_files_on_tmpfs_pairs_per_s": pf / tf, "ms_per_step_files": 1e3 * tf}
+    out = {"workload": label, "pairs_per_step": pairs // steps, "generation_hbm_pairs_per_s": pairs / dt, "ms_per_step_hbm": 1e3 * dt / steps,
+           "with_two_fastq_files_on_tmpfs_pairs_per_s": pf / tf, "ms_per_step_files": 1e3 * tf,
+           # fresh pages of ONE tmpfs file come at 5.3-5.7 GB/s whatever the number of threads (the inode lock: profiles/r04_onefile_probe.log), so the
+           # reference's two-file layout cannot take this job's text faster than bytes / 2 / 5.5 GB/s, whatever the GPU does
+           "two_file_estimate_ms_at_5p5_GBps_per_file": 1e3 * (g_fastq_bytes / 2) / 5.5e9 if (g_fastq_bytes := sum(last_stats["fastq_bytes"])) else None}
+    if concurrent > 1:
+        # many small jobs at once (a many-cell run): `concurrent` ctxs on as many streams and host threads, each with its own copy of the genome,
+        # the text left in HBM -- the aggregate rate is what such a run sees of the GPU (one job alone leaves the chip mostly empty: 780 workgroups
+        # in its largest launch)
+        import threading
+        gs = []
+        for k in range(concurrent):
+            st_k = torch.cuda.Stream()
+            gk = scssim_amd.GenReads(profile=prof, coverage=cov, isize=260, layout="PE", seed=1, device=dev.index, stream=st_k.cuda_stream)
+            gk.upload_genome_device(names, rl, bases_keep.data_ptr())
+            gs.append((gk, st_k))
+        done = [0] * concurrent
+
+        def work(k, n):
+            gk = gs[k][0]
+            for i in range(n):
+                gk.set_seed(9000 + 97 * k + i)
+                gk.create_frags(); gk.amplify(); gk.allocate_reads(0); gk.yield_reads_sink(None)
+                done[k] += gk.stats()["pairs_written"]
+        for n, timed_run in ((2, False), (4 * steps, True)):
+            for k in range(concurrent):
+                done[k] = 0
+            th = [threading.Thread(target=work, args=(k, n)) for k in range(concurrent)]
+            torch.cuda.synchronize(); t2 = time.perf_counter()
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+            torch.cuda.synchronize(); dt2 = time.perf_counter() - t2
+            if timed_run:
+                out["concurrent_jobs"] = {"ctxs": concurrent, "jobs": concurrent * n, "aggregate_pairs_per_s": sum(done) / dt2, "ms_per_job_amortised": 1e3 * dt2 / (concurrent * n),
+                                          "what": "%d ctxs on %d streams and host threads, each running %d jobs of this size back to back, text left in HBM" % (concurrent, concurrent, n)}
+        for gk, _ in gs:
+            gk.close()
+    return out
 
 
 def launch_ranks(n):
@@ -842,8 +883,16 @@ def main():
                 out["bgzf"] = {"error": repr(e)}
             # ---- the sweep north_star asks for (1 Mb -> 3 Gb) in one record: configs[1] and configs[2]'s sizes, same model and options
             try:
-                out["sweep"] = [small_config(torch, scssim_amd, dev, stream, prof, 1.0, a.coverage, "configs[1]: 1 Mb x 2 haplotypes, PE150 %gx" % a.coverage, shm),
+                out["sweep"] = [small_config(torch, scssim_amd, dev, stream, prof, 1.0, a.coverage, "configs[1]: 1 Mb x 2 haplotypes, PE150 %gx" % a.coverage, shm, concurrent=8),
                                 small_config(torch, scssim_amd, dev, stream, prof, 63.02552, a.coverage, "configs[2] size: 63 Mb (chr20) x 2 haplotypes, PE150 %gx" % a.coverage, shm)]
+                # what the DROP-IN default (the reference's two files, `scssim genreads` without --writers) does: bound by the inode lock of a
+                # tmpfs file (5.3-5.7 GB/s of fresh pages per file, whatever the size of the job), measured here at chr20 size
+                big = out["sweep"][1]
+                out["two_file_layout"] = {"value": big["with_two_fastq_files_on_tmpfs_pairs_per_s"], "unit": "pairs/s", "measured_on": big["workload"],
+                                          "what": "the same library writing the reference's <prefix>_1.fq / _2.fq (writers = 1: the CLI's default).  `value` above uses an EXTENSION -- "
+                                                  "%d part files per mate written by %d threads in %d generations -- because fresh pages of one tmpfs file come at 5.5 GB/s whatever the "
+                                                  "thread count; the two-file rate does not depend on the job's size, so the 3 Gb job with two files takes about %d s"
+                                                  % (writers * generations, writers, generations, round(R["fq_bytes"] / a.steps / 2 / 5.5e9))}
             except Exception as e:                                   # an extra leg must not cost the record
                 out["sweep"] = {"error": repr(e)}
             # ---- CLI wall at chr20 size
