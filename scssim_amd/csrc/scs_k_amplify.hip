@@ -668,6 +668,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 8)))
     __shared__ uint32_t s_bits[1024];                                              // position bitmaps: 1024 / row_words rows, one per template of the chunk
     const uint32_t lane = threadIdx.x, w = w_first + blockIdx.x;
     if (w >= n_waves) return;
+#ifdef SCS_PHASE_CLOCK
+    constexpr bool FROM_FRAG = false;                                              // (SCS_ATT's switch)
+    __shared__ unsigned long long s_att_t, s_att_acc[8];
+    if (lane < 8) s_att_acc[lane] = 0;
+    if (lane == 0) s_att_t = wall_clock64();
+    __builtin_amdgcn_wave_barrier();
+#endif
     const uint32_t t0 = wave_first[w], t1 = wave_first[w + 1];
     if (t1 <= t0) return;
     const uint32_t tf = t_from ? (uint32_t)min(*t_from, 0xFFFFFFFFull) : 0u;
@@ -724,9 +731,14 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 8)))
         bool need = unresolved, dead = false; uint32_t tries = 0, spos = 0, alen = 0, pidx = 0;
         const AttachFit fit = unresolved ? attach_fit_count(len, p.amp_min, p.amp_max) : AttachFit{0, 1, 0, 1};
         const double qfail = 1.0 - (double)fit.N / ((double)(len > 27 ? len - 27 : 1) * (double)fit.W);
+        SCS_ATT(0);
         Xoshiro xt{}; if (unresolved) xt.seed(draw4(p.key, ST_ATTACH, aux, tuid, i));
         bool aborted = cont && carry_abort; uint32_t v_abort = cont ? carry_v : 0u; // my segment: abandoned at primer v_abort
+        SCS_ATT(1);
         while (__ballot(unresolved)) {
+#ifdef SCS_PHASE_CLOCK
+            if (lane == 0) s_att_acc[4] += 100ull;                                  // (rounds, in the clock's unit: printed as a count)
+#endif
             if (unresolved && !dead) {
                 const uint32_t bp = spos - 27u;
                 if (!need && ((bits[bp >> 5] >> (bp & 31u)) & 1u)) need = true;       // a lower primer took this position meanwhile
@@ -742,12 +754,16 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 8)))
                         cand = true;
                     }
                     if (dead) break;
+                    SCS_ATT(2);
                     bool hasN; const uint32_t idx = primer_type(spos, hasN);
-                    if (hasN || attach_key<false>(t, i) > primer_cut[idx]) continue;  // no stock (none for N 8-mers): the try counts, the next one follows
+                    const bool nostock_ = hasN || attach_key<false>(t, i) > primer_cut[idx];
+                    SCS_ATT(3);
+                    if (nostock_) continue;                                          // no stock (none for N 8-mers): the try counts, the next one follows
                     pidx = idx; need = false;
                 }
             }
             // blocked = a lower unresolved live lane of my segment proposes the same position
+            SCS_ATT(2);
             const bool live = unresolved && !dead;
             const unsigned long long um = __ballot(live);
             bool blocked = false;
@@ -758,6 +774,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 8)))
             }
             const unsigned long long bm = __ballot(live && blocked) & gmask, dm = __ballot(unresolved && dead) & gmask;
             const uint32_t first_blocked = bm ? (uint32_t)__ffsll((long long)bm) - 1u : 64u, first_dead = dm ? (uint32_t)__ffsll((long long)dm) - 1u : 64u;
+            SCS_ATT(5);
             if (live && lane < first_blocked && lane < first_dead) {                  // commit, in primer order
                 const uint32_t bp = spos - 27u;
                 atomicOr(&bits[bp >> 5], 1u << (bp & 31u));
@@ -771,6 +788,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 8)))
                 if (in && !aborted) { aborted = true; v_abort = vi; }
                 if (lane >= first_dead) unresolved = false;
             }
+            SCS_ATT(6);
         }
         // what my template attached: its budget, or the primer it was abandoned at.  A template cut by the chunk's end waits.
         const uint32_t last = n_in - 1u;                                              // the chunk's last lane
@@ -787,7 +805,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 8)))
         __builtin_amdgcn_wave_barrier();
         carry_open = open_next; carry_abort = l_ab; carry_v = l_v;
         item0 += n_in;
+        SCS_ATT(0);
     }
+#ifdef SCS_PHASE_CLOCK
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 8) atomicAdd(&g_phase_att[lane * 256 + (blockIdx.x & 255u)], lane == 7 ? 1ull : s_att_acc[lane]);
+#endif
 }
 
 void launch_attach_frags(hipStream_t s, const uint8_t* g, DevFrags fr, const uint32_t* slot_off, uint32_t* slots, uint32_t* slot_tmpl,
@@ -915,7 +938,7 @@ void phase_clock_report_attach() {
         h[15] = h[7];
     } else h[15] = 0;
     if (h[15]) {
-        static const char* an[7] = {"setup", "seeding (Philox)", "gap + decode + bitmap (the candidate)", "8-mer gather, patch, stock", "(loop tail)", "blocked test", "commit + bookkeeping"};
+        static const char* an[7] = {"setup + chunk end", "seeding (Philox)", "gap + decode + bitmap (the candidate)", "8-mer gather, patch, stock", "ROUNDS (a count)", "blocked test", "commit + bookkeeping"};
         fprintf(stderr, "[phase clock] k_attach<semi>: %llu waves; mean wave time per section (us):", h[15]);
         for (int i = 0; i < 7; ++i) fprintf(stderr, "  %s %.2f", an[i], (double)h[i] / (double)h[15] / 100.0);
         fprintf(stderr, "\n");

@@ -467,6 +467,7 @@ __device__ __forceinline__ void reads_body(const uint32_t bid, const uint8_t* __
     const int tid = threadIdx.x, lane = tid & 63, wib = tid >> 6;
 #ifdef SCS_PHASE_CLOCK
     unsigned long long ph_t_ = 0;
+    const unsigned long long ph_c0_ = __builtin_amdgcn_s_memtime(), ph_r0_ = wall_clock64();   // shader clock beside the 100 MHz one: the clock the chip holds
 #endif
     SCS_PHASE(-1);
 
@@ -1163,7 +1164,7 @@ __device__ __forceinline__ void reads_body(const uint32_t bid, const uint8_t* __
     }
     SCS_PHASE(7);
 #ifdef SCS_PHASE_CLOCK
-    if (UNI && CLS == 1 && tid == 0) atomicAdd(&g_phase[15], 1ull);
+    if (UNI && CLS == 1 && tid == 0) { atomicAdd(&g_phase[15], 1ull); atomicAdd(&g_phase[12], __builtin_amdgcn_s_memtime() - ph_c0_); atomicAdd(&g_phase[13], wall_clock64() - ph_r0_); }
 #endif
 }
 
@@ -1395,7 +1396,7 @@ void phase_clock_report() {
     fprintf(stderr, "[phase clock] %llu workgroups of the uniform walk; mean time of thread 0 per phase (us):", h[15]);
     double tot = 0; for (int i = 0; i < 8; ++i) tot += (double)h[i];
     for (int i = 0; i < 8; ++i) fprintf(stderr, "  %s %.2f", nm[i], (double)h[i] / (double)h[15] / 100.0);
-    fprintf(stderr, "  | total %.2f\n", tot / (double)h[15] / 100.0);
+    fprintf(stderr, "  | total %.2f | shader clock over the workgroups' lives %.3f GHz\n", tot / (double)h[15] / 100.0, h[13] ? (double)h[12] / (double)h[13] * 0.1 : 0.0);
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof z);
     phase_clock_report_attach();
 #endif
