@@ -29,17 +29,34 @@ __global__ void k_plan_pairs(DevFrags fr, DevAmps semis, DevAmps fulls, uint32_t
     // the insert-size thresholds (a few hundred) go to LDS: the lookup is a nine-step bisection per attempt, and from global
     // memory those dependent loads are what the kernel waits for
     __shared__ uint32_t s_isz[1024];
+    __shared__ uint32_t s_act[256], s_wcnt[4];
     const uint32_t n_isz = (uint32_t)tb.n_isize;
     const bool isz_lds = n_isz <= 1024u;
     if (isz_lds) for (uint32_t k = threadIdx.x; k < n_isz; k += blockDim.x) s_isz[k] = tb.isize_t[k];
-    __syncthreads();
-    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n_fulls) return;
+    // Three amplicons in four get no read at 30x: the block's amplicons WITH pairs in this batch are handed to its first threads,
+    // densely (a thread per amplicon left 14 of 64 lanes working through the attempt loop's Philox blocks: profiles/r05_bench_sq.csv)
+    {
+        const uint32_t j0 = blockIdx.x * blockDim.x + threadIdx.x;
+        bool act = false;
+        if (j0 < n_fulls && read_numbers[first + j0] != 0u) {
+            const uint32_t po0 = pair_off[first + j0], want0 = pair_off[first + j0 + 1] - po0;
+            act = !(po0 >= pair_hi || po0 + want0 <= pair_lo);                       // some of its pairs lie in this batch
+        }
+        const unsigned long long m = __ballot(act);
+        const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+        if (lane == 0) s_wcnt[w] = (uint32_t)__popcll(m);
+        __syncthreads();
+        uint32_t base = 0;
+        for (uint32_t k = 0; k < w; ++k) base += s_wcnt[k];
+        if (act) s_act[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = j0;
+        __syncthreads();
+    }
+    const uint32_t n_act = s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
+    if (threadIdx.x >= n_act) return;
+    const uint32_t j = s_act[threadIdx.x];
     const uint32_t i = first + j;
     int n = (int)read_numbers[i];
-    if (n == 0) return;
     const uint32_t po = pair_off[i], want = pair_off[i + 1] - po;
-    if (po >= pair_hi || po + want <= pair_lo) return;                               // none of its pairs lies in this batch
     PairRec* dst = pairs + po;
     const uint32_t q_lo = pair_lo > po ? pair_lo - po : 0u, q_hi = pair_hi - po < want ? pair_hi - po : want;   // its pairs [q_lo, q_hi) are this batch's
     const uint32_t fsl = fulls.sl[i], amp_len = sl_len(fsl), s2 = sl_spos(fsl);
@@ -299,26 +316,59 @@ __global__ void __launch_bounds__(256) k_indels(const PairRec* __restrict__ pair
                                                 uint32_t force_replay, uint32_t* __restrict__ ev_hdr, uint4* __restrict__ ev_dat,
                                                 uint32_t* __restrict__ sizes1, uint32_t* __restrict__ sizes2, uint32_t* __restrict__ d1f1, uint32_t* __restrict__ d1f2,
                                                 uint32_t* __restrict__ flags) {
-    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    // 86 % of the reads have no indel event and are done after ONE draw of stream A; the others walk an event loop with a Philox block per
+    // event.  A thread per read left 22 of 64 lanes working there (profiles/r05_bench_sq.csv): every thread seeds stream A and looks at its
+    // read's first gap; the reads WITH an event are then handed to the block's first threads, densely, and run the whole pass there.
+    __shared__ uint32_t s_act[256], s_wcnt[4];
+    const uint32_t r0 = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t nreads = paired ? 2 * np : np;
-    if (r >= nreads) return;
+    // what a read leaves behind: header, event words, record size (+ class bit), one-deletion flag
+    auto emit = [&](uint32_t r, const IndelPass& ip, unsigned long long e_lo, unsigned long long e_hi, uint32_t att, uint32_t amp, uint32_t has_n) {
+        const uint32_t pi = paired ? r >> 1 : r, rd = paired ? (r & 1u) : 0u;
+        uint32_t* sz = rd ? sizes2 : sizes1;
+        uint32_t* d1f = rd ? d1f2 : d1f1;                                          // 1: the read's only event is the deletion of one base (k_reads' one-deletion walk)
+        ev_hdr[r] = (uint32_t)ip.n_out | ((uint32_t)ip.nev << 16) | (ip.replay ? 1u << 24 : 0u) | (1u << 25);
+        if (ip.nev > 0) ev_dat[r] = make_uint4((uint32_t)e_lo, (uint32_t)(e_lo >> 32), (uint32_t)e_hi, (uint32_t)(e_hi >> 32));   // (86 % of the reads have no event: nothing reads their slots)
+        const uint32_t e0 = (uint32_t)e_lo & 0xFFFFu;
+        const bool d1 = ip.nev == 1 && !ip.replay && !has_n && !(force_replay & 12u) && ev_del(e0) && ev_len(e0) == 1u && ip.n_out == tb.L - 1 && tb.bins == tb.L;
+        d1f[pi] = d1 ? 1u : 0u;
+        const uint32_t cls = ((ip.nev > 0 || ip.replay || has_n || (force_replay & 4u)) && !d1) ? 1u : 0u;   // the uniform walk takes ACGT-only windows without events
+        // "@<ampIdx>#<fragCount>[/1|/2]\n" + seq + "\n+\n" + qual + "\n"   (Amplicon.cpp:459-466,497-504)
+        sz[pi] = (ip.n_out == 0 ? 0u : 1u + dec_digits(amp) + 1u + dec_digits(att + 1) + (paired ? 2u : 0u) + 1u + 2u * (uint32_t)ip.n_out + 4u) | (cls << 31);   // bit 31: the class rides along into the offsets' scan
+    };
+    bool with_event = false;
+    if (r0 < nreads) {
+        const uint32_t pi = paired ? r0 >> 1 : r0, rd = paired ? (r0 & 1u) : 0u;
+        const uint64_t uid = pairs[pi].uid; const uint32_t att = pairs[pi].att, isz = pairs[pi].isz, amp = pairs[pi].amp, has_n = pairs[pi].flags & 4u;
+        if (isz == 0) { ev_hdr[r0] = 0; (rd ? sizes2 : sizes1)[pi] = 0; (rd ? d1f2 : d1f1)[pi] = 0; }   // hole: the insert-size loop gave up (Amplicon.cpp:484-489)
+        else {
+            if (tb.t_indel) { Xoshiro xa; xa.seed(draw4(key, ST_READ, rd | (att << 1), uid, 0)); with_event = xa.next() >= tb.gap_t[tb.L]; }   // indel_pass' first gap: an event among the L bases?
+            if (!with_event) {
+                IndelPass ip{tb.L, 0, false};
+                if (ip.n_out > (int)slot) { atomicOr(flags, (uint32_t)FLAG_READSLOT); ip.n_out = 0; }
+                emit(r0, ip, 0ull, 0ull, att, amp, has_n);
+            }
+        }
+    }
+    {
+        const unsigned long long m = __ballot(with_event);
+        const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+        if (lane == 0) s_wcnt[w] = (uint32_t)__popcll(m);
+        __syncthreads();
+        uint32_t base = 0;
+        for (uint32_t k = 0; k < w; ++k) base += s_wcnt[k];
+        if (with_event) s_act[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = r0;
+        __syncthreads();
+    }
+    if (threadIdx.x >= s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3]) return;
+    const uint32_t r = s_act[threadIdx.x];
     const uint32_t pi = paired ? r >> 1 : r, rd = paired ? (r & 1u) : 0u;
-    const uint64_t uid = pairs[pi].uid; const uint32_t att = pairs[pi].att, isz = pairs[pi].isz, amp = pairs[pi].amp, has_n = pairs[pi].flags & 4u;
-    uint32_t* sz = rd ? sizes2 : sizes1;
-    uint32_t* d1f = rd ? d1f2 : d1f1;                                              // 1: the read's only event is the deletion of one base (k_reads' one-deletion walk)
-    if (isz == 0) { ev_hdr[r] = 0; sz[pi] = 0; d1f[pi] = 0; return; }               // hole: the insert-size loop gave up (Amplicon.cpp:484-489)
+    const uint64_t uid = pairs[pi].uid; const uint32_t att = pairs[pi].att, amp = pairs[pi].amp, has_n = pairs[pi].flags & 4u;
     unsigned long long e_lo = 0, e_hi = 0;
     const IndelPass ip = indel_pass(tb, key, rd | (att << 1), uid, force_replay, slot, flags, [&](int i, uint32_t v) {
         if (i < 4) e_lo |= (unsigned long long)v << (16 * i); else e_hi |= (unsigned long long)v << (16 * (i - 4));
     });
-    ev_hdr[r] = (uint32_t)ip.n_out | ((uint32_t)ip.nev << 16) | (ip.replay ? 1u << 24 : 0u) | (1u << 25);
-    if (ip.nev > 0) ev_dat[r] = make_uint4((uint32_t)e_lo, (uint32_t)(e_lo >> 32), (uint32_t)e_hi, (uint32_t)(e_hi >> 32));   // (86 % of the reads have no event: nothing reads their slots)
-    const uint32_t e0 = (uint32_t)e_lo & 0xFFFFu;
-    const bool d1 = ip.nev == 1 && !ip.replay && !has_n && !(force_replay & 12u) && ev_del(e0) && ev_len(e0) == 1u && ip.n_out == tb.L - 1 && tb.bins == tb.L;
-    d1f[pi] = d1 ? 1u : 0u;
-    const uint32_t cls = ((ip.nev > 0 || ip.replay || has_n || (force_replay & 4u)) && !d1) ? 1u : 0u;   // the uniform walk takes ACGT-only windows without events
-    // "@<ampIdx>#<fragCount>[/1|/2]\n" + seq + "\n+\n" + qual + "\n"   (Amplicon.cpp:459-466,497-504)
-    sz[pi] = (ip.n_out == 0 ? 0u : 1u + dec_digits(amp) + 1u + dec_digits(att + 1) + (paired ? 2u : 0u) + 1u + 2u * (uint32_t)ip.n_out + 4u) | (cls << 31);   // bit 31: the class rides along into the offsets' scan
+    emit(r, ip, e_lo, e_hi, att, amp, has_n);
 }
 
 // ---- FASTQ text straight from the base pass (pair mode).  A record is two byte streams per read: the name line + bases +
