@@ -232,28 +232,35 @@ template <int QK>
 __device__ __noinline__ void redo_read(const uint8_t* __restrict__ g, int64_t gb, uint32_t gf, const uint32_t* __restrict__ spool, const uint32_t* __restrict__ fpool,
                                        uint64_t e1, uint64_t e2, int k1, uint32_t pos, uint32_t isz, uint32_t rd, int n, uint32_t B,
                                        const uint32_t* __restrict__ subs, const double* __restrict__ subs_d, const uint32_t* __restrict__ qalias,
-                                       U4 seed, char* __restrict__ out_b, char* __restrict__ out_q, uint32_t del_pos) {
-    // (del_pos: the one deleted base of a read of the one-deletion class, 0xFFFF for none: n - 1 positions, bins j * n / (n - 1) = j)
+                                       U4 seed, char* __restrict__ out_b, char* __restrict__ out_q, uint32_t del_pos, uint32_t ins_pos) {
+    // (del_pos: the one deleted base of a read of the one-event class, 0xFFFF for none: n - 1 positions, bins j * n / (n - 1) = j;
+    //  ins_pos: the base behind which its one inserted base follows: n + 1 positions, bins j * n / (n + 1) = 0, 0, 1, 2, ...)
     Xoshiro xb; xb.seed(seed);
     uint32_t c0 = 5u, c1 = 5u;
-    const int np = del_pos == 0xFFFFu ? n : n - 1;
+    const bool ins = ins_pos != 0xFFFFu;
+    const int np = ins ? n + 1 : del_pos == 0xFFFFu ? n : n - 1;
     for (int tp = 0; tp < np; ++tp) {
-        const int t = tp + ((uint32_t)tp >= del_pos ? 1 : 0);                      // window base of output position tp
-        uint32_t c2 = g[(gf & 2u) ? gb - t : gb + t];
-        if ((gf & 1u) && c2 < 4u) c2 = 3u - c2;
-        for_each_err(e1, spool, [&](uint32_t e) {
-            const int tt = k1 - (int)err_pos(e); const int k = rd ? (int)(pos + isz - 1) - tt : tt - (int)pos;
-            if (k == t) c2 = rd ? err_alt(e) : 3u - err_alt(e);
-        });
-        for_each_err(e2, fpool, [&](uint32_t e) {
-            const int tt = (int)err_pos(e); const int k = rd ? (int)(pos + isz - 1) - tt : tt - (int)pos;
-            if (k == t) c2 = rd ? 3u - err_alt(e) : err_alt(e);
-        });
+        const int t = ins ? tp - ((uint32_t)tp > ins_pos ? 1 : 0) : tp + ((uint32_t)tp >= del_pos ? 1 : 0);   // window base of output position tp
+        uint32_t c2;
+        if (ins && (uint32_t)tp == ins_pos + 1u) { uint32_t xi, xu; xb.next2(xi, xu); c2 = scale_draw(xi, 0, 3); }   // the inserted base: a step of its own
+        else {
+            c2 = g[(gf & 2u) ? gb - t : gb + t];
+            if ((gf & 1u) && c2 < 4u) c2 = 3u - c2;
+            for_each_err(e1, spool, [&](uint32_t e) {
+                const int tt = k1 - (int)err_pos(e); const int k = rd ? (int)(pos + isz - 1) - tt : tt - (int)pos;
+                if (k == t) c2 = rd ? err_alt(e) : 3u - err_alt(e);
+            });
+            for_each_err(e2, fpool, [&](uint32_t e) {
+                const int tt = (int)err_pos(e); const int k = rd ? (int)(pos + isz - 1) - tt : tt - (int)pos;
+                if (k == t) c2 = rd ? 3u - err_alt(e) : err_alt(e);
+            });
+        }
         const int ki = kmer_index(c0, c1, c2);
         uint32_t xs, xq; xb.next2(xs, xq);
         uint32_t bc, qc;
+        const uint32_t bin = ins ? (tp ? (uint32_t)tp - 1u : 0u) : (uint32_t)tp;
         if (ki < 0 && c2 > 3u) { bc = 'N'; qc = 33u + scale_draw(xq, 0, 20); }
-        else { const uint32_t kq = call_global_body<QK>(subs, subs_d, qalias, B, ki, c2, c2, (uint32_t)tp, xs, xq); bc = (0x54474341u >> (8u * (kq & 255u))) & 255u; qc = 33u + (kq >> 8); }
+        else { const uint32_t kq = call_global_body<QK>(subs, subs_d, qalias, B, ki, c2, c2, bin, xs, xq); bc = (0x54474341u >> (8u * (kq & 255u))) & 255u; qc = 33u + (kq >> 8); }
         out_b[tp] = (char)bc; out_q[tp] = (char)qc;
         c0 = c1; c1 = c2;
     }
@@ -326,11 +333,14 @@ __global__ void __launch_bounds__(256) k_indels(const PairRec* __restrict__ pair
     auto emit = [&](uint32_t r, const IndelPass& ip, unsigned long long e_lo, unsigned long long e_hi, uint32_t att, uint32_t amp, uint32_t has_n) {
         const uint32_t pi = paired ? r >> 1 : r, rd = paired ? (r & 1u) : 0u;
         uint32_t* sz = rd ? sizes2 : sizes1;
-        uint32_t* d1f = rd ? d1f2 : d1f1;                                          // 1: the read's only event is the deletion of one base (k_reads' one-deletion walk)
+        uint32_t* d1f = rd ? d1f2 : d1f1;                                          // 1: the read's only event is the deletion or the insertion of one base (k_reads' one-event walk)
         ev_hdr[r] = (uint32_t)ip.n_out | ((uint32_t)ip.nev << 16) | (ip.replay ? 1u << 24 : 0u) | (1u << 25);
         if (ip.nev > 0) ev_dat[r] = make_uint4((uint32_t)e_lo, (uint32_t)(e_lo >> 32), (uint32_t)e_hi, (uint32_t)(e_hi >> 32));   // (86 % of the reads have no event: nothing reads their slots)
         const uint32_t e0 = (uint32_t)e_lo & 0xFFFFu;
-        const bool d1 = ip.nev == 1 && !ip.replay && !has_n && !(force_replay & 12u) && ev_del(e0) && ev_len(e0) == 1u && ip.n_out == tb.L - 1 && tb.bins == tb.L;
+        // the one-event class of k_reads: the deletion of one base (n' = L - 1) -- or the insertion of one (n' = L + 1; not when L - 1 is a
+        // multiple of 16: reads_body, NP)
+        const bool one = ip.nev == 1 && !ip.replay && !has_n && !(force_replay & 12u) && ev_len(e0) == 1u && tb.bins == tb.L;
+        const bool d1 = one && (ev_del(e0) ? ip.n_out == tb.L - 1 : (ip.n_out == tb.L + 1 && !(force_replay & 16u) && ((tb.L - 1) & 15) != 0));
         d1f[pi] = d1 ? 1u : 0u;
         const uint32_t cls = ((ip.nev > 0 || ip.replay || has_n || (force_replay & 4u)) && !d1) ? 1u : 0u;   // the uniform walk takes ACGT-only windows without events
         // "@<ampIdx>#<fragCount>[/1|/2]\n" + seq + "\n+\n" + qual + "\n"   (Amplicon.cpp:459-466,497-504)
@@ -513,7 +523,7 @@ __device__ __forceinline__ void reads_body(const uint32_t bid, const uint8_t* __
     constexpr uint32_t WOFF = UNI ? 36u : 0u;
     const uint32_t ROW = UNI ? uni_row_bytes((uint32_t)n) : WS;
     uint8_t* s_win = UNI ? reinterpret_cast<uint8_t*>(s_ev) : reinterpret_cast<uint8_t*>(s_ev + RB * EV_MAX);
-    uint32_t* s_head = reinterpret_cast<uint32_t*>(s_dyn + SLOTS * sizeof(Bin) + (size_t)RB * ROW);   // [64] UNI: threshold rows of the 1- and 2-mers
+    uint32_t* s_head = reinterpret_cast<uint32_t*>(s_dyn + SLOTS * sizeof(Bin) + (size_t)RB * ROW);   // [128] UNI: keep intervals of the 1- and 2-mers (head rows: scs_stage.cpp ring_image_u)
     const int tid = threadIdx.x, lane = tid & 63, wib = tid >> 6;
 #ifdef SCS_PHASE_CLOCK
     unsigned long long ph_t_ = 0;
@@ -554,7 +564,7 @@ __device__ __forceinline__ void reads_body(const uint32_t bid, const uint8_t* __
     };
 #pragma unroll
     for (int u = 0; u < NPRE; ++u) ring0[u] = reinterpret_cast<const u32x4_t*>(ring_img)[min(tid + u * RB, GE - 1)];
-    const uint32_t head_w = UNI ? reinterpret_cast<const uint32_t*>(ring_img + (size_t)((B + 7) & ~7) * (sizeof(Bin) / 16))[tid & 63] : 0u;
+    const uint32_t head_w = UNI ? reinterpret_cast<const uint32_t*>(ring_img + (size_t)((B + 7) & ~7) * (sizeof(Bin) / 16))[tid & 127] : 0u;
     prefetch(GROUP);
 
     // ---- which read is mine
@@ -740,12 +750,12 @@ __device__ __forceinline__ void reads_body(const uint32_t bid, const uint8_t* __
     const uint32_t aux = rd | (att << 1);
     LdsU16* my_ev = (LdsU16*)(s_ev + tid * EV_MAX);
     LdsU32* my_xa = (LdsU32*)(s_ev + tid * EV_MAX);                                // the same 16 bytes, as a stream-A state (replayed reads)
-    int nev = 0, n_out = 0; bool replay = false; uint32_t replay_first = 0, del_pos = 0xFFFFu;
+    int nev = 0, n_out = 0; bool replay = false; uint32_t replay_first = 0, del_pos = 0xFFFFu; bool is_i1 = false;   // D1 class: its one event -- the deleted base, or (is_i1) the base behind which one base is inserted
     if (live) {
         if (FROM_PAIRS) {
             const uint32_t h = ev_h; const uint4 e = ev_e;
             n_out = (int)(h & 0xFFFFu); nev = SIMPLE ? 0 : (int)((h >> 16) & 0xFFu); replay = SIMPLE ? false : (h >> 24) & 1u;
-            if (D1) del_pos = ev_pos(e.x & 0xFFFFu);                                 // its one event: the deleted base
+            if (D1) { del_pos = ev_pos(e.x & 0xFFFFu); is_i1 = !ev_del(e.x & 0xFFFFu); }
             if (!UNI) { my_xa[0] = e.x; my_xa[1] = e.y; my_xa[2] = e.z; my_xa[3] = e.w; }   // 8 x 16-bit events
         } else {
             const IndelPass ip = indel_pass(tb, key, aux, uid, force_replay, slot, flags, [&](int i, uint32_t v) { my_ev[i] = (uint16_t)v; });
@@ -787,20 +797,47 @@ __device__ __forceinline__ void reads_body(const uint32_t bid, const uint8_t* __
     // n' characters per stream): a disagreement would be an internal error, reported, never a store outside the buffer
     if (FROM_PAIRS && live && n_out > 0 && my_off + rec_h + 2ull * (uint32_t)n_out + 4ull > (second_file ? cap2 : cap1)) { atomicOr(flags, (uint32_t)FLAG_INTERNAL); live = false; n_out = 0; }
     LdsU32* my_pend_lds = (LdsU32*)(s_win + (size_t)tid * ROW);                    // rows are dword aligned (win_stride)
+    // One-event class, a read with ONE INSERTED base (is_i1): n' = L + 1 positions in the bins j L / (L + 1) = 0, 0, 1, 2, ... -- position 0
+    // is made HERE, ahead of the walk (bin 0: the ring's first group and the head rows go to LDS first), and rides in front of the two
+    // streams: its base as the last character of the name line, its quality behind "\n+\n".  The walk's step t then makes position
+    // t + 1 at bin t, as the other walks' step t makes position t.
+    uint32_t b0ch = 0, q0ch = 0, c1_pre = 0;
+    const uint32_t sh1 = (D1 && is_i1 && live && n_out > 0) ? 1u : 0u;
+    if constexpr (D1) {
+#pragma unroll
+        for (int u = 0; u < NPRE; ++u) { const int idx = tid + u * RB; if (idx < GE) ring16[idx] = ring0[u]; }
+        if (tid < 128) s_head[tid] = head_w;
+        lds_barrier();
+        if (__any(sh1 != 0u)) {
+            if (sh1) {
+                const uint32_t cb = ((const LdsU32*)(s_win + (size_t)tid * ROW + WOFF))[0] & 3u;   // window base 0
+                uint32_t x1, x2; xb.next2(x1, x2);
+                const u32x2_t kp = *(const LdsU2*)((const LdsU8*)s_head + cb * 8u);  // the 1-mer's keep interval at bin 0
+                uint32_t k = cb, qv;
+                if (x1 - kp.x < kp.y) {
+                    const LdsU32* qrow = (const LdsU32*)((const LdsU8*)s_dyn + cb * (uint32_t)(QROW * 16));   // bin 0 (ring slot 0): the diagonal row (cb, cb)
+                    qv = alias_pick<QK>(qrow, (const LdsU8*)(qrow + QK), x2);
+                } else { const uint32_t kq = call_global<QK>(subs, subs_d, tb.qual_alias, (uint32_t)B, (int)cb, cb, cb, 0u, x1, x2); k = kq & 255u; qv = kq >> 8; }
+                b0ch = (0x54474341u >> (8u * k)) & 255u; q0ch = 33u + qv; c1_pre = cb;
+            }
+        }
+    }
     if (UNI && live && n_out > 0) {
         // The name line "@<amp>#<cnt>[/1|/2]\n" is WRITTEN INTO LDS FIRST, character by character at its place from the end -- into the
         // 28 bytes in front of my window that the walk's pending entries use later, the line's last character in byte 27 (h <= 25) --
         // and read back as seven words: no six-way choice per character, the digit loops are the only data-dependent part.  The words are
         // shifted to the record's alignment: the last s1 characters ride in the first dword of the bases, the rest ends on the aligned
         // address ta1 and goes out as whole dwords, then the <= 3 leading bytes.
-        const uint32_t amp = amp_index_base + pr.amp, cnt = pr.att + 1u, d2 = dec_digits(cnt), h = rec_h, dbase = paired ? 3u : 1u, da = h - 2u - dbase - d2;
+        // (sh1: the line carries the base of position 0 behind its "\n"; the streams start one character later)
+        const uint32_t amp = amp_index_base + pr.amp, cnt = pr.att + 1u, d2 = dec_digits(cnt), h = rec_h + sh1, dbase = paired ? 3u : 1u, da = rec_h - 2u - dbase - d2;
         const uint32_t o1 = rec_rel + h, o2 = o1 + (uint32_t)n_out + 3u;          // where the bases / the qualities start
         a1 = o1 & 31u; sec1 = o1 - a1; a2 = o2 & 31u; sec2 = o2 - a2;
         const uint32_t s1 = a1 & 3u; char* ta1 = wg_out + (o1 - s1);
         LdsU8* nb = (LdsU8*)my_pend_lds;
-        nb[27] = (uint8_t)'\n';
-        if (paired) { nb[26] = (uint8_t)(rd ? '2' : '1'); nb[25] = (uint8_t)'/'; }
-        uint32_t at = 27u - dbase, v = cnt;                                        // byte of the next character to the left
+        if (sh1) { nb[27] = (uint8_t)b0ch; bo_q.carry = (q0ch << 24) | 0x000A2B0Au; }
+        nb[27u - sh1] = (uint8_t)'\n';
+        if (paired) { nb[26u - sh1] = (uint8_t)(rd ? '2' : '1'); nb[25u - sh1] = (uint8_t)'/'; }
+        uint32_t at = 27u - sh1 - dbase, v = cnt;                                  // byte of the next character to the left
 #pragma unroll
         for (uint32_t j = 0; j < 10; ++j) if (j < d2) { const uint32_t qv = v / 10u; nb[at - j] = (uint8_t)('0' + (v - qv * 10u)); v = qv; }
         at -= d2; nb[at] = (uint8_t)'#'; at -= 1u; v = amp;
@@ -852,10 +889,12 @@ __device__ __forceinline__ void reads_body(const uint32_t bid, const uint8_t* __
         }
     }
     // the ring's first group and the head rows leave their registers (loaded at the kernel's start) for the LDS the staging has freed
+    if constexpr (!D1) {                                                           // (the one-event class: done above, ahead of its first position)
 #pragma unroll
-    for (int u = 0; u < NPRE; ++u) { const int idx = tid + u * RB; if (idx < GE) ring16[idx] = ring0[u]; }
-    if (UNI && tid < 64) s_head[tid] = head_w;
-    lds_barrier();
+        for (int u = 0; u < NPRE; ++u) { const int idx = tid + u * RB; if (idx < GE) ring16[idx] = ring0[u]; }
+        if (UNI && tid < 128) s_head[tid] = head_w;
+        lds_barrier();
+    }
     SCS_PHASE(3);
 
     // a substituted base (k != c2) needs an off-diagonal quality row, which only global memory holds.  Its quality does
@@ -890,12 +929,17 @@ __device__ __forceinline__ void reads_body(const uint32_t bid, const uint8_t* __
         const bool force_redo = (force_replay & 2u) != 0;
         char* __restrict__ spare = reinterpret_cast<char*>(flags) + 128;               // 32 bytes nobody reads (the flags buffer is 256 bytes)
         uint32_t wreg = 0, wnext = 0, sel = 0, qacc = 0, nbad = 0;
-        c0 = 0; c1 = 0;
+        c0 = 0; c1 = c1_pre;
         // D1 (CLS 3): the reads with exactly ONE indel event, the deletion of ONE base, run the same walk.  Their n' = L - 1 positions
         // fall into bins j * L / (L - 1) = j, one step of stream B each; only the source base differs: position j reads window
         // base j before the deleted base and j + 1 from it on (a shift by one two-bit field, the next dword kept beside the
         // current one).  NP: the positions of a read of this class.
-        const int NP = D1 ? B - 1 : B;
+        // ... and the reads whose one event is the INSERTION of one base (is_i1; ahead of the walk: position 0, above): step t makes position
+        // t + 1 at bin t from window base t + 1 before the event's base e, the inserted base (a draw of its own) at t = e, window base t behind
+        // it; B steps.  A one-deletion read in the same wave idles through the last step (its draw kept, its character cleared).  When B - 1 is
+        // a multiple of 16 that step would open a block of its own: k_indels sends no insertion reads here then and the walk has B - 1 steps.
+        const bool i1_ok = D1 && ((B - 1) & 15) != 0;
+        const int NP = (D1 && !i1_ok) ? B - 1 : B;
         // SOFTWARE PIPELINE, one position deep.  The compiler's scheduler waits for an LDS read right where it issues it; here
         // every read gets a stage's worth of independent work before its use.  Step u runs, in this order,
         //   finish_a(u-1): thresholds and alias entry of the previous position are back -> its base k, its alias column -> issue the symbol read
@@ -903,7 +947,7 @@ __device__ __forceinline__ void reads_body(const uint32_t bid, const uint8_t* __
         //   finish_b(u-1): the symbol is back -> pending-quality bookkeeping, the output words
         // with the ring's refill (commit, barrier, prefetch) between finish_a and start: every ring read of a group is issued
         // before its wave arrives at the next group's barrier, as the refill's slot reuse assumes.
-        uint32_t aLo = 0, aWid = 0, aE = 0, aX1 = 0, aX2 = 0, aC2 = 0, aRow = 0; const LdsU8* aQ = ring8;   // start -> finish_a
+        uint32_t aLo = 0, aWid = 0, aE = 0, aX1 = 0, aX2 = 0, aC2 = 0, aRow = 0; const LdsU8* aQ = ring8; bool aIdle = false;   // start -> finish_a
         uint32_t bC2 = 0, bX1 = 0, bX2 = 0, bSym = 0, bRow = 0; bool bKept = true;                          // finish_a -> finish_b
         // (FIRST: t0 == 0, as a compile-time constant -- a run-time test would put branches between the positions, and a branch around
         // the stores makes the compiler's s_waitcnt before the next ring commit cover them on every path: vmcnt(1) instead of vmcnt(5))
@@ -913,9 +957,12 @@ __device__ __forceinline__ void reads_body(const uint32_t bid, const uint8_t* __
             uint32_t c2;
             if constexpr (D1) {
                 if (u == 0) { wreg = first ? win32[0] : wnext; wnext = win32[(t0 >> 4) + 1]; if (!mine) { wreg = 0; wnext = 0; } }   // 16 bases + the 16 behind them
-                const bool after = (uint32_t)(t0 + u) >= del_pos;                    // from the deleted base on: the next window base
+                const bool after = ((uint32_t)(t0 + u) >= del_pos) != is_i1;         // from the deleted base on -- or up to the base the insertion follows: the next window base
                 if (u < 15) c2 = __builtin_amdgcn_ubfe(wreg, 2u * u + (after ? 2u : 0u), 2u);
                 else c2 = after ? (wnext & 3u) : (wreg >> 30);
+                if (__ballot(is_i1 && (uint32_t)(t0 + u) == del_pos)) {                // the inserted base: randomInteger(0, 3), a step of stream B of its own (Profile.cpp:1640-1646)
+                    if (is_i1 && (uint32_t)(t0 + u) == del_pos) { uint32_t xi, xu; xb.next2(xi, xu); c2 = scale_draw(xi, 0, 3); }
+                }
             } else {
                 if (u == 0) { wnext = wreg; wreg = win32[t0 >> 4]; if (!mine) wreg = 0; }   // the block's 16 bases (wnext: the block before)
                 c2 = __builtin_amdgcn_ubfe(wreg, 2u * u, 2u);
@@ -928,16 +975,25 @@ __device__ __forceinline__ void reads_body(const uint32_t bid, const uint8_t* __
             else if constexpr (u >= 2) rowi = __builtin_amdgcn_ubfe(wreg, 2u * (u - 2), 6u);
             else rowi = __builtin_amdgcn_alignbit(wreg, wnext, u == 0 ? 28u : 30u) & 63u;
             const LdsU8* kp8 = bin8 + 4 * QROW * 16 + rowi * 8u;
-            if constexpr (u < 2 && first) { rowi = u == 0 ? c2 : 4u + c1 * 4u + c2; kp8 = head8 + rowi * 8u; }   // the read's first two bases: 1-mer / 2-mer rows (table rows 0..19)
+            if constexpr (u < 2 && first) {                                          // the read's first two bases: 1-mer / 2-mer rows (table rows 0..19)
+                const uint32_t row3 = rowi;
+                rowi = u == 0 ? c2 : 4u + c1 * 4u + c2; kp8 = head8 + rowi * 8u;
+                if constexpr (D1) if (is_i1) {                                       // these steps make positions 1 and 2: the 2-mer at bin 0 (head rows 20..35), the 3-mer at bin 1
+                    if (u == 0) { rowi = 4u + c1 * 4u + c2; kp8 = head8 + (16u + rowi) * 8u; }
+                    else { rowi = 20u + (((row3 & 3u) << 4) | (row3 & 12u) | (row3 >> 4)); kp8 = bin8 + 4 * QROW * 16 + row3 * 8u; }   // (rowi: the TABLE row, as finish_b's HEAD form takes it)
+                }
+            }
             const LdsU32* qrow = (const LdsU32*)(bin8 + c2 * (uint32_t)(QROW * 16));   // the diagonal row (c2, c2) as an alias row
             const u32x2_t kp = *(const LdsU2*)kp8;                                    // the draws that keep the base: lo <= x1 < lo + width
             aLo = kp.x; aWid = kp.y; aE = qrow[x2 >> (32u - Geo::ABITS)];
             aQ = (const LdsU8*)(qrow + QK); aX1 = x1; aX2 = x2; aC2 = c2; aRow = rowi;
+            if constexpr (D1) aIdle = i1_ok && !is_i1 && t0 + u == B - 1;
             c0 = c1; c1 = c2;
             __builtin_amdgcn_sched_barrier(0);
         };
         auto finish_a = [&]() __attribute__((always_inline)) {
             bKept = aX1 - aLo < aWid;                                                 // k == c2 (never for the draw 0xFFFFFFFF)
+            if constexpr (D1) if (aIdle) bKept = true;                                // (a one-deletion read's idle last step)
             const uint32_t col = aX2 >> (32u - Geo::ABITS);
             const uint32_t pick = ((aX2 << Geo::ABITS) | (uint32_t)(QK - 1)) < aE ? col : (aE & (uint32_t)(QK - 1));   // alias_pick
             bSym = aQ[pick];
@@ -966,6 +1022,7 @@ __device__ __forceinline__ void reads_body(const uint32_t bid, const uint8_t* __
             if ((u & 3) == 3 || last) {
                 uint32_t wb = __builtin_amdgcn_perm(0x4Eu, 0x54474341u, sel), wq = qacc + 0x21212121u;   // selector 0..3 -> "ACGT"; + 33
                 if constexpr ((u & 3) != 3) { const uint32_t m = (1u << (8 * ((u & 3) + 1))) - 1u; wb &= m; wq &= m; }   // the read's last, partial word
+                if constexpr (D1) if (last && i1_ok && !is_i1) { const uint32_t m = (1u << (8 * (u & 3))) - 1u; wb &= m; wq &= m; }   // (one deletion: the idle step's character is not the read's)
                 bo_b.R[u >> 2] = wb; bo_q.R[u >> 2] = wq; sel = 0; qacc = 0;
             }
         };
@@ -1144,9 +1201,11 @@ __device__ __forceinline__ void reads_body(const uint32_t bid, const uint8_t* __
         if (FROM_PAIRS && live && n_out > 0) {
             // the streams' ends, once per wave after the pass (reads of different lengths end at different steps): the last
             // characters + "\n+\n" up to the qualities' first dword / + "\n" to the record's end
-            const uint32_t lastj = (uint32_t)n_out - 1u, m = lastj >> 4, nw = ((lastj & 15u) >> 2) + 1u, nv = (lastj & 3u) + 1u;
-            const uint32_t s1 = a1 & 3u, s2 = a2 & 3u, nq = s2 + (uint32_t)n_out + 1u;
-            bo_b.tail(wg_out, sec1, a1, m, nw, nv, 0x0A2B0Au, (s1 + (uint32_t)n_out + 3u - s2) >> 2, 0u);   // the bases' dwords end where the qualities' first one starts
+            // (a read with one inserted base: the streams hold its positions 1 .. n' - 1, and position 0's quality rides behind "\n+\n")
+            const uint32_t ns = (uint32_t)n_out - sh1;
+            const uint32_t lastj = ns - 1u, m = lastj >> 4, nw = ((lastj & 15u) >> 2) + 1u, nv = (lastj & 3u) + 1u;
+            const uint32_t s1 = a1 & 3u, s2 = a2 & 3u, nq = s2 + ns + 1u;
+            bo_b.tail(wg_out, sec1, a1, m, nw, nv, 0x0A2B0Au | (sh1 ? q0ch << 24 : 0u), (s1 + ns + 3u + sh1 - s2) >> 2, 0u);   // the bases' dwords end where the qualities' first one starts
             bo_q.tail(wg_out, sec2, a2, m, nw, nv, 0x0Au, nq >> 2, nq & 3u);
         }
     };
@@ -1206,7 +1265,7 @@ __device__ __forceinline__ void reads_body(const uint32_t bid, const uint8_t* __
             const int64_t gb = rd == 0 ? pr.base + dir * (int64_t)pr.pos : pr.base + dir * (int64_t)(pr.pos + pr.isz - 1);
             const uint32_t gf = rd == 0 ? (comp | ((dir < 0) ? 2u : 0u)) : ((comp ^ 1u) | ((dir < 0) ? 0u : 2u));
             redo_read<QK>(g, gb, gf, spool.data, fpool.data, pr.e1, pr.e2, pr.k1, pr.pos, pr.isz, rd, n, (uint32_t)B, subs, subs_d, tb.qual_alias,
-                          draw4(key, ST_READ, aux, uid, 1), wg_out + sec1 + a1, wg_out + sec2 + a2, D1 ? del_pos : 0xFFFFu);
+                          draw4(key, ST_READ, aux, uid, 1), wg_out + sec1 + a1 - sh1, wg_out + sec2 + a2 - sh1, D1 && !is_i1 ? del_pos : 0xFFFFu, D1 && is_i1 ? del_pos : 0xFFFFu);
         }
     }
     if (live && !FROM_PAIRS) {
@@ -1283,7 +1342,7 @@ size_t reads_lds_bytes(const DevTables& tb, bool uni) {
     const size_t ring = tb.qual_k == 16 ? RingGeo<16>::SLOTS * sizeof(RingBin<16>) : tb.qual_k == 64 ? RingGeo<64>::SLOTS * sizeof(RingBin<64>) : RingGeo<128>::SLOTS * sizeof(RingBin<128>);
     const size_t ring_u = tb.qual_k == 16 ? RingGeo<16>::SLOTS * sizeof(RingBinU<16>) : tb.qual_k == 64 ? RingGeo<64>::SLOTS * sizeof(RingBinU<64>) : RingGeo<128>::SLOTS * sizeof(RingBinU<128>);
     const size_t park = (size_t)RB * 19 * 4 + 320 * 4;                              // the prologue's parked records + sort counters (pair mode)
-    if (uni) return std::max(park, ring_u + (size_t)RB * uni_row_bytes((uint32_t)tb.L) + 256);   // + the head rows
+    if (uni) return std::max(park, ring_u + (size_t)RB * uni_row_bytes((uint32_t)tb.L) + 512);   // + the head rows
     return std::max(park, ring + (size_t)RB * EV_MAX * 2 + (size_t)RB * win_stride((uint32_t)tb.L));
 }
 template <bool FROM_PAIRS, int CLS, class... Args>
@@ -1301,7 +1360,7 @@ static void launch_reads_kernel(hipStream_t s, dim3 grid, const DevTables& tb, A
 #undef SCS_LAUNCH_READS
 }
 static uint32_t reads_force_replay() {                                             // tests: bit 0: every read with an indel takes the replay path;
-    static const uint32_t v = (seam_env("SCS_EV_REPLAY") ? 1u : 0u) | (seam_env("SCS_TEST_REDO") ? 2u : 0u) | (seam_env("SCS_TEST_GENERAL") ? 4u : 0u) | (seam_env("SCS_TEST_NO_D1") ? 8u : 0u);   // bit 1: every event-free read with a substitution is redone (redo_read)
+    static const uint32_t v = (seam_env("SCS_EV_REPLAY") ? 1u : 0u) | (seam_env("SCS_TEST_REDO") ? 2u : 0u) | (seam_env("SCS_TEST_GENERAL") ? 4u : 0u) | (seam_env("SCS_TEST_NO_D1") ? 8u : 0u) | (seam_env("SCS_TEST_NO_I1") ? 16u : 0u);   // bit 1: every event-free read with a substitution is redone (redo_read)
     return v;
 }
 void launch_indels(hipStream_t s, const PairRec* pairs, uint32_t np, int paired, DevTables tb, RngKey key, uint32_t slot, uint32_t* ev_hdr, uint4* ev_dat,

@@ -378,6 +378,7 @@ void do_yield(scs_ctx* c, const OutTarget& tg, uint64_t* n1_out, uint64_t* n2_ou
         const BatchSet& B = bs[it & 1];
         mail_wait(c);                                                              // this batch's byte and class counts
         const uint64_t b1 = c->h_rb[0] & OFF_MASK, b2 = c->h_rb[1] & OFF_MASK; const uint32_t nc1 = (uint32_t)(c->h_rb[0] >> OFF_BITS), nc2 = (uint32_t)(c->h_rb[1] >> OFF_BITS), nd1 = (uint32_t)c->h_rb[2], nd2 = (uint32_t)c->h_rb[3];
+        if (seam_env("SCS_DEBUG_CLASSES")) fprintf(stderr, "[classes] batch of %u pairs: general %u / %u, one-event %u / %u\n", np, nc1, nc2, nd1, nd2);
         if (ps != s) HIP_OK(hipStreamWaitEvent(s, c->ev_pre[it & 1], 0));          // (the host has seen the pre-pass' mail already: ordering for the device's sake)
         if (it + 1 < nbatch) prepass((uint64_t)order[it + 1] * batch, bs[(it + 1) & 1], (int)((it + 1) & 1));   // the next batch's pre-pass starts now, beside this batch's base pass
         bb1[bidx] = b1; bb2[bidx] = b2;

@@ -34,8 +34,9 @@ void do_load_profile(scs_ctx* c, const char* path) {
     };
     auto ring_image_u = [&](const std::vector<uint32_t>& subs_t) {
         const size_t B = (size_t)P.bins, qw = (size_t)P.qual_k + (size_t)P.qual_k / 4, bw = 4 * qw + 128, Bpad = (B + 7) & ~(size_t)7;
-        std::vector<uint32_t> img(Bpad * bw + 64, 0u);                              // + the head: the 1-mers at bin 0 and the 2-mers at bin 1
+        std::vector<uint32_t> img(Bpad * bw + 128, 0u);                             // + the head: the 1-mers at bin 0 and the 2-mers at bin 1 (rows 0..19), the 2-mers at bin 0 (rows 20..35: a read with one inserted base has its second position there)
         for (size_t ki = 0; ki < 20 && B >= 2; ++ki) keep_pair(subs_t.data() + (ki * B + (ki < 4 ? 0 : 1)) * 4, (uint32_t)(ki & 3), img.data() + Bpad * bw + ki * 2);
+        for (size_t ki = 4; ki < 20 && B >= 2; ++ki) keep_pair(subs_t.data() + (ki * B + 0) * 4, (uint32_t)(ki & 3), img.data() + Bpad * bw + (16 + ki) * 2);
         for (size_t b = 0; b < B; ++b) {
             uint32_t* d = img.data() + b * bw;
             for (size_t cc = 0; cc < 4; ++cc) memcpy(d + cc * qw, P.qual_alias.data() + ((cc * 5) * B + b) * qw, qw * 4);

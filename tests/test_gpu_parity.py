@@ -1005,12 +1005,13 @@ def test_many_small_batches_match_oracle(models, tmp_path):
     assert r.returncode == 0, r.stdout[-3000:]
 
 
-@pytest.mark.parametrize("knob", ["SCS_TEST_REDO", "SCS_TEST_GENERAL", "SCS_TEST_NO_D1", "SCS_READS_SERIAL", "SCS_READS_SPLIT", "SCS_ERRS_INLINE"])
+@pytest.mark.parametrize("knob", ["SCS_TEST_REDO", "SCS_TEST_GENERAL", "SCS_TEST_NO_D1", "SCS_TEST_NO_I1", "SCS_READS_SERIAL", "SCS_READS_SPLIT", "SCS_ERRS_INLINE"])
 def test_read_class_fallbacks_match_oracle(knob, models, tmp_path):
     """The base pass has a straight-line variant for event-free, ACGT-only reads and one for reads whose only event is the
-    deletion of one base.  A read of them that runs out of room for a substituted base's quality (or draws 0xFFFFFFFF) is made
+    deletion or the insertion of one base.  A read of them that runs out of room for a substituted base's quality (or draws 0xFFFFFFFF) is made
     again by a scalar fallback (redo_read): SCS_TEST_REDO=1 sends every such read with a substitution through it.
-    SCS_TEST_GENERAL=1 sends every read through the general variant instead, SCS_TEST_NO_D1=1 the one-deletion reads;
+    SCS_TEST_GENERAL=1 sends every read through the general variant instead, SCS_TEST_NO_D1=1 the one-event reads,
+    SCS_TEST_NO_I1=1 only those with an inserted base;
     SCS_READS_SERIAL=1 launches the class kernels one after the other and SCS_READS_SPLIT=1 on three streams instead of as one merged
     launch; SCS_ERRS_INLINE=1 keeps the
     amplification's k_errs<semi->full> on the main stream (it has its own by default).  Same parity checks, in child
