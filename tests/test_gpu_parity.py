@@ -691,10 +691,12 @@ def test_paired_end_job_on_a_model_without_insert_size_spread_fails_like_the_ref
     g.close()
 
 
-@pytest.mark.parametrize("rl,layout", [(17, "SE"), (36, "PE"), (51, "PE"), (75, "SE"), (257, "PE")])
+@pytest.mark.parametrize("rl,layout", [(17, "SE"), (36, "PE"), (51, "PE"), (75, "SE"), (257, "PE"), (130, "PE"), (145, "SE"), (148, "PE"), (149, "SE"), (160, "PE")])
 def test_odd_read_lengths_bit_exact(rl, layout, oracle_bin, models, tmp_path):
     """Read lengths around the walk's block sizes (16-position blocks, 16-base window dwords, the 50-base floor under which indels
-    are dropped): a model resampled to the length, 1 Mb genome, byte for byte against the oracle."""
+    are dropped): a model resampled to the length, 1 Mb genome, byte for byte against the oracle.  130 .. 160: where the one-event walk's
+    last step falls in its block -- a one-deletion read idles through it beside the one-insertion reads (its character cleared: byte 1, 3,
+    0 of the word, the block's last position), and at L = 16 k + 1 (145, 257) the insertion reads stay with the general variant."""
     fa = str(tmp_path / "simu.fa")
     subprocess.check_call(["python3", os.path.join(ROOT, "tools", "make_genome.py"), "--lengths", "1000000", "--seed", "9", "--simu-out", fa])
     prof = str(tmp_path / "m.profile")
