@@ -115,7 +115,8 @@ __global__ void k_plan_pairs(DevFrags fr, DevAmps semis, DevAmps fulls, uint32_t
 //          with a one-position software pipeline; the base call is ONE compare of the draw against the interval that keeps
 //          the window's base (RingBinU), and a position whose draw does not keep it is set aside in LDS and resolved after
 //          the pass, base and quality patched into the text (redo_read when a read runs out of room);
-//       3  the same walk for reads whose only event is the deletion of one base (n' = L - 1: bins j L / (L - 1) = j);
+//       3  the same walk for reads whose only event is the deletion of one base (n' = L - 1: bins j L / (L - 1) = j) or the insertion
+//          of one (n' = L + 1: bins j L / (L + 1) = 0, 0, 1, 2, ...: position 0 is made ahead of the walk, step t makes position t + 1);
 //       2  everything else: the general loop described above.  (0: explicit-window mode, the general loop.)
 //     The prologue is a chain of dependent loads (list entry -> pair record + offset -> window gather) at four workgroups
 //     per CU: the ring's first groups and the event words are requested early, the records are parked in LDS for the
@@ -329,7 +330,7 @@ __global__ void __launch_bounds__(256) k_indels(const PairRec* __restrict__ pair
     __shared__ uint32_t s_act[256], s_wcnt[4];
     const uint32_t r0 = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t nreads = paired ? 2 * np : np;
-    // what a read leaves behind: header, event words, record size (+ class bit), one-deletion flag
+    // what a read leaves behind: header, event words, record size (+ class bit), one-event flag
     auto emit = [&](uint32_t r, const IndelPass& ip, unsigned long long e_lo, unsigned long long e_hi, uint32_t att, uint32_t amp, uint32_t has_n) {
         const uint32_t pi = paired ? r >> 1 : r, rd = paired ? (r & 1u) : 0u;
         uint32_t* sz = rd ? sizes2 : sizes1;
@@ -1292,10 +1293,10 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
     reads_body<FROM_PAIRS, QK, CLS>(blockIdx.x, g, spool, fpool, pairs, np, paired, windows, uids, atts, is_read1, n_explicit, tb, key, slot, n_slots_cap, force_replay, ev_hdr, ev_dat,
                                     off1, off2, out1, out2, amp_index_base, slot_b, slot_q, lens, flags, cap1, cap2, list1, list2, nlist1, nlist2);
 }
-// The base pass of a batch as ONE launch: the workgroups of the general class first (the longest), then the one-deletion class,
+// The base pass of a batch as ONE launch: the workgroups of the general class first (the longest), then the one-event class,
 // then the event-free class.  The three grids used to go to three streams; whether they really ran side by side depended on
 // which hardware queues the process' streams had been given (the reads stage moved by +-4 % from process to process).  One
-// grid leaves the mix to the workgroup dispatcher.  lists: {general, one-deletion, event-free} x {mate 1, mate 2}.
+// grid leaves the mix to the workgroup dispatcher.  lists: {general, one-event, event-free} x {mate 1, mate 2}.
 struct ReadLists { const uint32_t* l[3][2]; uint32_t n[3][2]; uint32_t grid[3]; };
 template <int QK>
 __global__ void __launch_bounds__(RB, 4) k_reads_all(const uint8_t* __restrict__ g, const uint8_t* __restrict__ g2, DevErrPool spool, DevErrPool fpool, const PairRec* __restrict__ pairs,
@@ -1440,7 +1441,7 @@ void launch_reads(hipStream_t s, const uint8_t* g, const uint32_t* g2, DevErrPoo
 }
 // the batch's reads split by class (k_indels' flags cls, their exclusive scans cpos): ascending lists of pair indices
 // (general class = bit 31 of the record size as k_indels left it, its list position = the scanned offset's bits above OFF_BITS; the
-// one-deletion class = its flag array and that array's scan; the event-free class takes what is left)
+// one-event class = its flag array and that array's scan; the event-free class takes what is left)
 __global__ void k_read_lists(uint32_t np, int paired, const uint32_t* __restrict__ sizes1, const uint64_t* __restrict__ off1, const uint32_t* __restrict__ d1f1,
                              const uint32_t* __restrict__ d1p1, const uint32_t* __restrict__ sizes2, const uint64_t* __restrict__ off2, const uint32_t* __restrict__ d1f2,
                              const uint32_t* __restrict__ d1p2, uint32_t* __restrict__ slist1, uint32_t* __restrict__ slist2, uint32_t* __restrict__ clist1,
