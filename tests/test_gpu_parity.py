@@ -653,6 +653,33 @@ def test_config1_full_size_bit_exact(oracle_bin, models, tmp_path):
     assert open(out + "_1.fq", "rb").read() == want[0] and open(out + "_2.fq", "rb").read() == want[1]
 
 
+def test_read_classes_take_the_share_of_the_reads_they_are_built_for(models, tmp_path):
+    """The straight-line walks only pay while the reads they are built for reach them: with the PE150 model 86 % of the reads have no indel
+    event, 7 % one deleted base, 2 % one inserted base (the one-event walk takes both) and what is left goes through the general variant.
+    The seams build prints the class lists' sizes per batch (SCS_DEBUG_CLASSES): general below 5.5 % and one-event above 8 % of the reads;
+    with SCS_TEST_NO_I1 the inserted-base reads are back in the general class (above 6 %)."""
+    import re
+    fa = str(tmp_path / "simu.fa")
+    subprocess.check_call(["python3", os.path.join(ROOT, "tools", "make_genome.py"), "--lengths", "2000000", "--seed", "3", "--simu-out", fa])
+    prof = str(tmp_path / "pe150.profile")
+    subprocess.check_call(["python3", os.path.join(ROOT, "tools", "make_profile.py"), models["Illumina_HiSeq2500"], prof, "--read-length", "150"])
+    exe = os.path.join(ROOT, "scssim_amd", "bin", "scssim_seams")                    # the seams build of the CLI (scs_seams.h)
+
+    def shares(**knobs):
+        r = subprocess.run([exe, "genreads", "-i", fa, "-m", prof, "-c", "30", "-s", "260", "-o", str(tmp_path / "o"), "--seed", "5"],
+                           capture_output=True, text=True, env=dict(os.environ, SCS_DEBUG_CLASSES="1", **knobs))
+        assert r.returncode == 0, r.stderr
+        m = re.findall(r"\[classes\] batch of (\d+) pairs: general (\d+) / (\d+), one-event (\d+) / (\d+)", r.stderr)
+        assert m, r.stderr[-2000:]
+        pairs = sum(int(x[0]) for x in m)
+        return sum(int(x[1]) + int(x[2]) for x in m) / (2.0 * pairs), sum(int(x[3]) + int(x[4]) for x in m) / (2.0 * pairs)
+
+    gen, one = shares()
+    assert 0.03 < gen < 0.055 and 0.08 < one < 0.11, (gen, one)
+    gen0, one0 = shares(SCS_TEST_NO_I1="1")
+    assert 0.06 < gen0 < 0.08 and 0.06 < one0 < 0.08, (gen0, one0)
+
+
 def test_paired_end_job_on_a_model_without_insert_size_spread_fails_like_the_reference(oracle_bin, models, golden_inputs, tmp_path):
     """[Insert Size Standard Deviation] 0 + PE: the reference has no insert-size alphabet (Profile.cpp:908), its first yieldInsertSize
     asks Config for a parameter that does not exist and exit(1)s with `Error: unrecognized parameter name "insertSize"`
