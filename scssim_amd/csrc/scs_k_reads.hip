@@ -125,7 +125,10 @@ __global__ void k_plan_pairs(DevFrags fr, DevAmps semis, DevAmps fulls, uint32_t
 //     LDS per workgroup at L = 150: 14 KB ring + 19 KB rows (uniform walks) / 16 KB ring + 4 KB events + 19 KB windows
 //     (general) -> 4 workgroups per CU.
 // ------------------------------------------------------------------------------------------------
-#define RB 256
+#ifndef SCS_RB
+#define SCS_RB 256
+#endif
+#define RB SCS_RB
 #define EV_MAX 8
 // ring geometry: two groups of bins (one being served, one being filled).  A bin image = the 4 diagonal quality rows as
 // alias rows (QK columns: QK words + QK symbol bytes each, scs_tables.h) + the 64 k-mer substitution rows (3 thresholds; the
@@ -1281,7 +1284,7 @@ __device__ __forceinline__ void reads_body(const uint32_t bid, const uint8_t* __
 // (bid: the workgroup's index within ITS class' grid -- blockIdx.x of a launch of one class, or blockIdx.x less the grids of the
 // classes in front of it in the merged launch below)
 template <bool FROM_PAIRS, int QK, int CLS>
-__global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, DevErrPool spool, DevErrPool fpool, const PairRec* __restrict__ pairs,
+__global__ void __launch_bounds__(RB, 1024 / RB) k_reads(const uint8_t* __restrict__ g, DevErrPool spool, DevErrPool fpool, const PairRec* __restrict__ pairs,
                                               uint32_t np, int paired, const uint8_t* __restrict__ windows, const uint64_t* __restrict__ uids,
                                               const uint32_t* __restrict__ atts, const uint8_t* __restrict__ is_read1, uint32_t n_explicit,
                                               const DevTables tb, RngKey key, uint32_t slot, uint32_t n_slots_cap, uint32_t force_replay,
@@ -1299,7 +1302,7 @@ __global__ void __launch_bounds__(RB, 4) k_reads(const uint8_t* __restrict__ g, 
 // grid leaves the mix to the workgroup dispatcher.  lists: {general, one-event, event-free} x {mate 1, mate 2}.
 struct ReadLists { const uint32_t* l[3][2]; uint32_t n[3][2]; uint32_t grid[3]; };
 template <int QK>
-__global__ void __launch_bounds__(RB, 4) k_reads_all(const uint8_t* __restrict__ g, const uint8_t* __restrict__ g2, DevErrPool spool, DevErrPool fpool, const PairRec* __restrict__ pairs,
+__global__ void __launch_bounds__(RB, 1024 / RB) k_reads_all(const uint8_t* __restrict__ g, const uint8_t* __restrict__ g2, DevErrPool spool, DevErrPool fpool, const PairRec* __restrict__ pairs,
                                                     uint32_t np, int paired, const DevTables tb, RngKey key, uint32_t slot, uint32_t n_slots_cap, uint32_t force_replay,
                                                     const uint32_t* __restrict__ ev_hdr, const uint4* __restrict__ ev_dat,
                                                     const uint64_t* __restrict__ off1, const uint64_t* __restrict__ off2, char* __restrict__ out1, char* __restrict__ out2,
@@ -1342,7 +1345,7 @@ void ReadsSide::release() {
 size_t reads_lds_bytes(const DevTables& tb, bool uni) {
     const size_t ring = tb.qual_k == 16 ? RingGeo<16>::SLOTS * sizeof(RingBin<16>) : tb.qual_k == 64 ? RingGeo<64>::SLOTS * sizeof(RingBin<64>) : RingGeo<128>::SLOTS * sizeof(RingBin<128>);
     const size_t ring_u = tb.qual_k == 16 ? RingGeo<16>::SLOTS * sizeof(RingBinU<16>) : tb.qual_k == 64 ? RingGeo<64>::SLOTS * sizeof(RingBinU<64>) : RingGeo<128>::SLOTS * sizeof(RingBinU<128>);
-    const size_t park = (size_t)RB * 19 * 4 + 320 * 4;                              // the prologue's parked records + sort counters (pair mode)
+    const size_t park = (size_t)RB * 19 * 4 + (64 + RB) * 4;                              // the prologue's parked records + sort counters (pair mode)
     if (uni) return std::max(park, ring_u + (size_t)RB * uni_row_bytes((uint32_t)tb.L) + 512);   // + the head rows
     return std::max(park, ring + (size_t)RB * EV_MAX * 2 + (size_t)RB * win_stride((uint32_t)tb.L));
 }
